@@ -1,0 +1,141 @@
+"""Each restated cv2 stage of the oracle against an independent definition: brute-force NumPy
+written from SURVEY.md App. A, and scipy.ndimage for the morphology."""
+import numpy as np
+import pytest
+from scipy import ndimage as ndi
+
+
+def test_ellipse_structuring_elements(oracle):
+    assert oracle.ellipse_kernel(5).tolist() == [[0, 0, 1, 0, 0], [1] * 5, [1] * 5, [1] * 5, [0, 0, 1, 0, 0]]
+    dx29, taps29 = oracle.ellipse_halfwidths(29)
+    dx55, taps55 = oracle.ellipse_halfwidths(55)
+    assert taps29 == 641 and taps55 == 2337          # lane_tracker.py:203-204 footprints
+    assert dx29[:15] == [0, 5, 7, 9, 10, 11, 11, 12, 13, 13, 13, 14, 14, 14, 14]
+    assert dx55[:28] == [0, 7, 10, 12, 14, 16, 17, 18, 19, 20, 21, 22, 22, 23, 24, 24, 25, 25, 25, 26,
+                         26, 26, 27, 27, 27, 27, 27, 27]
+    assert dx29 == dx29[::-1] and dx55 == dx55[::-1]
+
+
+@pytest.mark.parametrize("k", [5, 29, 55])
+@pytest.mark.parametrize("shape", [(70, 90), (23, 140), (1, 1), (60, 17)])
+def test_morphology_fast_equals_definition_and_scipy(oracle, k, shape):
+    rng = np.random.default_rng(k * 1000 + shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    el = oracle.ellipse_kernel(k).astype(bool)
+    er, di = oracle.erode(img, k), oracle.dilate(img, k)
+    assert np.array_equal(er, oracle.erode(img, k, brute=True))
+    assert np.array_equal(di, oracle.dilate(img, k, brute=True))
+    assert np.array_equal(er, ndi.grey_erosion(img, footprint=el, mode="constant", cval=255))
+    assert np.array_equal(di, ndi.grey_dilation(img, footprint=el, mode="constant", cval=0))
+    th = oracle.tophat(img, k)
+    op = oracle.dilate(er, k)
+    assert np.array_equal(th, (img.astype(int) - op).clip(0).astype(np.uint8))
+    assert np.array_equal(oracle.morph_open(img, k), op)
+
+
+def _bilateral_numpy(img, k, C, mode="floor"):
+    """lane_tracker.py:61-81 as four correlations with zero border."""
+    h, w = img.shape
+    p = np.zeros((h + 2 * k, w + 2 * k), np.int64)
+    p[k:k + h, k:k + w] = img
+    c = p[k:k + h, k:k + w]
+    sl = sum(p[k:k + h, k - i:k - i + w] for i in range(1, k + 1))
+    sr = sum(p[k:k + h, k + i:k + i + w] for i in range(1, k + 1))
+    su = sum(p[k - i:k - i + h, k:k + w] for i in range(1, k + 1))
+    sd = sum(p[k + i:k + i + h, k:k + w] for i in range(1, k + 1))
+    delta = C * k if mode == "floor" else -C * k
+    l, r, u, d = (s - k * c + delta for s in (sl, sr, su, sd))
+    if mode == "floor":
+        return ((l < 0) & (r < 0)) | ((u < 0) & (d < 0))
+    return ((l > 0) & (r > 0)) | ((u > 0) & (d > 0))
+
+
+@pytest.mark.parametrize("k,C", [(15, 8), (35, 5), (65, 10), (3, 0)])
+def test_bilateral_threshold_definition(oracle, k, C):
+    rng = np.random.default_rng(k)
+    img = rng.integers(0, 256, (80, 120), dtype=np.uint8)
+    img[20:60, 50:56] = np.minimum(255, img[20:60, 50:56].astype(int) + 120).astype(np.uint8)
+    for mode in ("floor", "ceil"):
+        got = oracle.bilateral_adaptive_threshold(img, k, C, mode, 200, 7)
+        want = np.where(_bilateral_numpy(img, k, C, mode), 200, 7).astype(np.uint8)
+        assert np.array_equal(got, want)
+    with pytest.raises(ValueError):
+        oracle.bilateral_adaptive_threshold(img, k, C, "round")
+
+
+@pytest.mark.parametrize("bs,C", [(15, 5), (35, 5), (3, 0)])
+def test_adaptive_mean_threshold_definition(oracle, bs, C):
+    rng = np.random.default_rng(bs)
+    img = rng.integers(0, 256, (64, 96), dtype=np.uint8)
+    r = bs // 2
+    pad = np.pad(img.astype(np.int64), r, mode="edge")
+    s = sum(pad[i:i + 64, j:j + 96] for i in range(bs) for j in range(bs))
+    mean = np.rint(s / float(bs * bs)).astype(np.int64)      # never an exact tie: bs*bs is odd
+    want = np.where(img.astype(np.int64) - mean > C, 255, 0).astype(np.uint8)
+    assert np.array_equal(oracle.adaptive_mean_threshold(img, bs, C), want)
+    assert np.array_equal(mean, ndi.uniform_filter(img.astype(np.float64), bs, mode="nearest").round().astype(np.int64))
+
+
+def test_remap_weights_and_border(oracle, ref_calib):
+    """App. A.0: exact 15-bit weights, constant-0 border, taps (sx,sy)..(sx+1,sy+1)."""
+    rng = np.random.default_rng(0)
+    frame = rng.integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    xy, al = oracle.warp_map(ref_calib)
+    bev = oracle.warp(ref_calib, frame)
+    ys = rng.integers(0, 1100, 4000)
+    xs = rng.integers(0, 1080, 4000)
+    f = frame.astype(np.int64)
+    for y, x in zip(ys, xs):
+        sx, sy = int(xy[y, x, 0]), int(xy[y, x, 1])
+        fx, fy = int(al[y, x]) & 31, int(al[y, x]) >> 5
+        acc = np.zeros(3, np.int64)
+        for (dy, dx, wgt) in ((0, 0, (32 - fx) * (32 - fy)), (0, 1, fx * (32 - fy)), (1, 0, (32 - fx) * fy), (1, 1, fx * fy)):
+            yy, xx = sy + dy, sx + dx
+            if 0 <= yy < 720 and 0 <= xx < 1280:
+                acc += f[yy, xx] * wgt * 32
+        assert np.array_equal(bev[y, x], (acc + 16384) >> 15)
+
+
+def test_front_end_row_window_equals_full_undistort(oracle, ref_calib):
+    frame = np.random.default_rng(1).integers(0, 256, (720, 1280, 3), dtype=np.uint8)
+    r0, r1 = oracle.warp_source_rows(ref_calib)
+    assert (r0, r1) == (457, 695)
+    assert np.array_equal(oracle.front_end(ref_calib, frame), oracle.warp(ref_calib, oracle.undistort(ref_calib, frame)))
+
+
+def test_undistort_map_is_near_identity_at_principal_point(oracle, ref_calib):
+    xy, al = oracle.undistort_map(ref_calib, 384, 388)
+    # at the principal point (669.68, 385.86) distortion vanishes: map ~ identity
+    assert abs(int(xy[2, 670, 0]) - 670) <= 1 and abs(int(xy[2, 670, 1]) - 386) <= 1
+
+
+def test_lab_b_tables_and_neutral_axis(oracle):
+    g, c, k = oracle.lab_tables()
+    assert g[0] == 0 and g[255] == 2040 and c[0] == round(32768 * 0.13793103448275862)
+    assert k.tolist()[3:6] == [871, 2929, 296]        # round(4096 * Y row)
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[:, None], 3, 1)[None]
+    b = oracle.lab_b(grey)
+    assert np.all(np.abs(b.astype(int) - 128) <= 1)   # greys have b* = 0 -> 128
+    assert oracle.lab_b(np.array([[[255, 255, 0]]], np.uint8))[0, 0] > 200   # yellow: strongly positive b*
+    assert oracle.lab_b(np.array([[[0, 0, 255]]], np.uint8))[0, 0] < 60      # blue: strongly negative b*
+
+
+def test_filter_lane_points_composition(oracle):
+    rng = np.random.default_rng(3)
+    bev = rng.integers(0, 256, (120, 150, 3), dtype=np.uint8)
+    fp = oracle.filter_params()
+    mask, planes = oracle.filter_lane_points(bev, fp, want_planes=True)
+    R, B = bev[:, :, 0], oracle.lab_b(bev)
+    assert np.array_equal(planes[0], R) and np.array_equal(planes[1], B)
+    thr, thb = oracle.tophat(R, 29), oracle.tophat(B, 55)
+    assert np.array_equal(planes[2], thr) and np.array_equal(planes[3], thb)
+    merged = (oracle.bilateral_adaptive_threshold(thr, 15, 8) | oracle.bilateral_adaptive_threshold(thb, 35, 5))
+    assert np.array_equal(mask, oracle.morph_open(merged, 5))
+    fp2 = oracle.filter_params(filter_type="neighborhood", C_r=5)
+    merged2 = oracle.adaptive_mean_threshold(R, 15, 5) | oracle.adaptive_mean_threshold(B, 35, 5)
+    assert np.array_equal(oracle.filter_lane_points(bev, fp2), oracle.morph_open(merged2, 5))
+    fp3 = oracle.filter_params(mask_noise=True)
+    noise = (~(B >= 140)) | (oracle.bilateral_adaptive_threshold(B, 65, 10) > 0)
+    assert np.array_equal(oracle.filter_lane_points(bev, fp3), oracle.morph_open(np.where((merged > 0) & noise, 255, 0).astype(np.uint8), 5))
+    with pytest.raises(ValueError):
+        oracle.filter_lane_points(bev, oracle.filter_params(filter_type="median"))
