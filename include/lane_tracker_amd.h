@@ -1,0 +1,177 @@
+/*
+ * lane_tracker_amd.h -- C ABI of the MI355X-native lane-tracker hot path.
+ *
+ * The upstream reference (pierluigiferrari/lane_tracker) is pure Python and has no FFI of its own;
+ * its boundary for this path is the Python API used by process_video.py.  This header is what a
+ * maintainer binds with ctypes to replace the cv2/NumPy call sites on that path (INTEGRATION.md
+ * shows the binding).  Each entry point cites the reference lines it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative lt_status on failure;
+ * lt_last_error() returns a thread-local description.  No exceptions cross the ABI, no torch or
+ * HIP types appear in signatures.  A context owns one HIP stream and all of its device buffers;
+ * contexts are not thread-safe (one per tracker / per rank).  Host buffers are caller-owned.
+ * The library is HIP-only: there is no CPU fallback behind any entry point.
+ *
+ * Frame "slots": a context holds `capacity` (lt_reserve) independent frame slots in HBM.  Slot i
+ * keeps the camera frame, every intermediate plane, the mask, the lane-pixel lists and the 64-byte
+ * lane record of frame i.  The *_run functions enqueue kernels on the context's stream and return
+ * immediately; downloads synchronise.
+ */
+#ifndef LANE_TRACKER_AMD_H
+#define LANE_TRACKER_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LT_ABI_VERSION 1
+
+typedef enum lt_status {
+    LT_OK = 0,
+    LT_ERR_INVALID = -1,     /* bad argument (also the reference's ValueError cases) */
+    LT_ERR_HIP = -2,         /* a HIP runtime call failed */
+    LT_ERR_NOMEM = -3,
+    LT_ERR_CAPACITY = -4,    /* slot range outside lt_reserve()'d capacity */
+    LT_ERR_STATE = -5        /* e.g. search requested before a mask exists */
+} lt_status;
+
+typedef struct lt_ctx lt_ctx;
+
+/* LaneTracker.__init__ arguments that shape the kernels (lane_tracker.py:101-137). */
+typedef struct lt_calib {
+    int32_t img_w, img_h;        /* img_size     (width, height) */
+    int32_t warp_w, warp_h;      /* warped_size  (width, height) */
+    double  cam_matrix[9];       /* row major */
+    double  dist_coeffs[5];      /* k1 k2 p1 p2 k3 */
+    double  M[9];                /* warp_matrices[0]: camera -> bird's eye */
+} lt_calib;
+
+/* filter_lane_points() keyword arguments (lane_tracker.py:183-193). */
+typedef struct lt_filter_params {
+    int32_t filter_type;         /* 0 'bilateral', 1 'neighborhood'; anything else -> LT_ERR_INVALID (:220) */
+    int32_t ksize_r, C_r, ksize_b, C_b;
+    int32_t mask_noise, noise_thresh, ksize_noise, C_noise;
+} lt_filter_params;
+
+/* sliding_window_search() / band_search() arguments (lane_tracker.py:242-253, 449). */
+typedef struct lt_search_params {
+    int32_t window_width, window_height, search_range, no_success_limit;
+    int32_t ignore_sides, ignore_bottom, bandwidth, _pad;
+    double  mu, start_slice, partial;
+} lt_search_params;
+
+/* One fitted frame, 64 bytes; this is the unit the multi-GPU gather moves. */
+typedef struct lt_lane_record {
+    double  left_coeffs[3];      /* np.polyfit order: x = a*y^2 + b*y + c (lane_tracker.py:506) */
+    double  right_coeffs[3];     /* (:507) */
+    int32_t n_left, n_right;     /* lane-pixel counts */
+    uint8_t detected;            /* self.detected_pixels (:438, :496) */
+    uint8_t fit_flags;           /* bit0: left fit rank-deficient (<3 distinct y), bit1: right */
+    uint8_t mode;                /* 0 sliding-window, 1 band */
+    uint8_t _pad;
+    int32_t frame;               /* caller-defined global frame index */
+} lt_lane_record;
+
+typedef struct lt_info {
+    int32_t abi_version, device, capacity, cu_count;
+    int32_t src_row0, src_row1;  /* camera rows [row0,row1) that influence the bird's-eye view */
+    int32_t max_pixels_per_side; /* capacity of each lane-pixel list */
+    int32_t max_levels;          /* capacity of each centroid list */
+    int64_t alg_bytes_mask;      /* algorithmic bytes / frame of the warp+threshold stage */
+    int64_t alg_bytes_search;    /* algorithmic bytes / frame of search+fit, excluding emitted pixels */
+    char    device_name[64];
+} lt_info;
+
+enum lt_plane {                  /* lt_download_plane selectors (bird's-eye planes, h*w bytes each) */
+    LT_PLANE_R = 0,              /* rgb_r_channel        (:207) */
+    LT_PLANE_LAB_B = 1,          /* lab_b_channel        (:208) */
+    LT_PLANE_TOPHAT_R = 2,       /* rgb_r_tophat         (:210) */
+    LT_PLANE_TOPHAT_B = 3,       /* lab_b_tophat         (:211) */
+    LT_PLANE_MERGED = 4,         /* merged               (:229-235) */
+    LT_PLANE_MASK = 5            /* opened = return value (:238) */
+};
+
+#define LT_NUM_STAGES 12         /* lt_stage_ms slots, see lt_stage_name() */
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+const char* lt_last_error(void);
+int  lt_abi_version(void);
+int  lt_device_count(int* count);
+/* Builds the calibration-constant tables (remap tables, Lab LUTs, structuring elements) on the
+ * host in f64 and uploads them.  Replaces the per-call table work inside cv2.undistort /
+ * cv2.warpPerspective / cv2.cvtColor / cv2.getStructuringElement (:203-205, :208, :832, :834). */
+int  lt_create(const lt_calib* calib, int device, lt_ctx** out);
+void lt_destroy(lt_ctx* ctx);
+int  lt_reserve(lt_ctx* ctx, int capacity);
+int  lt_get_info(lt_ctx* ctx, lt_info* out);
+int  lt_sync(lt_ctx* ctx);
+
+/* ---- frames in, results out ------------------------------------------------------------------ */
+/* frames: n * img_h * img_w * 3 bytes, RGB interleaved, as LaneTracker.process() receives them (:876) */
+int  lt_upload_frames(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
+/* masks: n * warp_h * warp_w bytes; lets the search stages run on caller-supplied binary images */
+int  lt_upload_masks(lt_ctx* ctx, const uint8_t* masks, int first_slot, int n);
+int  lt_download_masks(lt_ctx* ctx, int first_slot, int n, uint8_t* masks);
+int  lt_download_plane(lt_ctx* ctx, int plane, int first_slot, int n, uint8_t* out);
+/* the undistorted camera rows [src_row0, src_row1) as RGB interleaved: n * rows * img_w * 3 */
+int  lt_download_undistorted(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+int  lt_download_records(lt_ctx* ctx, int first_slot, int n, lt_lane_record* out);
+/* side 0 = left, 1 = right.  Writes at most cap (y,x) pairs in reference order; returns the count
+ * through *count (self.left_y/left_x/right_y/right_x, :434-437, :492-495). */
+int  lt_download_pixels(lt_ctx* ctx, int slot, int side, int32_t* ys, int32_t* xs, int cap, int* count);
+/* self.left_window_centroids / right_window_centroids (:439-440) */
+int  lt_download_centroids(lt_ctx* ctx, int slot, int side, int32_t* out, int cap, int* count);
+/* device-to-device copy of n records into caller-owned device memory (e.g. a collective's send buffer) */
+int  lt_copy_records_to_device(lt_ctx* ctx, int first_slot, int n, void* dst_device);
+
+/* ---- the hot path, device resident ----------------------------------------------------------- */
+/* find_lane_points() part 1 (:832-846): undistort -> warpPerspective -> filter_lane_points. */
+int  lt_mask_run(lt_ctx* ctx, int first_slot, int n, const lt_filter_params* p);
+/* filter_lane_points() only, on bird's-eye RGB images already uploaded with lt_upload_bev (:183-240) */
+int  lt_upload_bev(lt_ctx* ctx, const uint8_t* bev_rgb, int first_slot, int n);
+int  lt_filter_run(lt_ctx* ctx, int first_slot, int n, const lt_filter_params* p);
+/* sliding_window_search() + fit_poly() (:242-447, :502-509) on the slots' masks */
+int  lt_sws_fit_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p);
+/* band_search() + fit_poly() (:449-509); prev_coeffs: n * 6 doubles (last_left_coeffs, last_right_coeffs) */
+int  lt_band_fit_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p, const double* prev_coeffs);
+/* tag records with global frame indices first_frame, first_frame+1, ... */
+int  lt_set_frame_base(lt_ctx* ctx, int first_slot, int n, int first_frame);
+
+/* ---- host-buffer convenience wrappers (upload + run + download) -------------------------------- */
+int  lt_mask_batch(lt_ctx* ctx, const uint8_t* frames_rgb, int n, const lt_filter_params* p, uint8_t* masks);
+/* masks == NULL: use the device-resident masks of slots [0,n) */
+int  lt_sws_fit_batch(lt_ctx* ctx, const uint8_t* masks, int n, const lt_search_params* p, lt_lane_record* out);
+int  lt_band_fit_batch(lt_ctx* ctx, const uint8_t* masks, int n, const lt_search_params* p,
+                       const double* prev_coeffs, lt_lane_record* out);
+
+/* ---- single-image operators with the reference's module-level signatures ----------------------- */
+/* bilateral_adaptive_threshold(img, ksize, C, mode, true_value, false_value) (:14-83).
+ * mode 0 'floor', 1 'ceil', anything else -> LT_ERR_INVALID (the reference's ValueError, :71). */
+int  lt_bilateral_adaptive_threshold(lt_ctx* ctx, const uint8_t* img, int h, int w, int ksize, int C,
+                                     int mode, int true_value, int false_value, uint8_t* out);
+/* LaneTracker.filter_lane_points(img, ...) on one bird's-eye RGB image of any size (:183-240) */
+int  lt_filter_lane_points(lt_ctx* ctx, const uint8_t* bev_rgb, int h, int w, const lt_filter_params* p,
+                           uint8_t* mask);
+
+/* LaneTracker.fit_poly() on explicit pixel lists (np.polyfit(ys, xs, 2), :506-507): n (y,x) pairs with
+ * coordinates in [0, 65535].  *rank_deficient is set when fewer than 3 distinct y exist (coef = 0). */
+int  lt_fit_poly2(lt_ctx* ctx, const int32_t* ys, const int32_t* xs, int n, int h, int w, double coef[3],
+                  int* rank_deficient);
+
+/* ---- measurement ------------------------------------------------------------------------------ */
+/* hipEvent pair on the context's stream */
+int  lt_timer_start(lt_ctx* ctx);
+int  lt_timer_stop(lt_ctx* ctx, float* ms);
+/* when enabled, every *_run records a hipEvent after each kernel; lt_stage_ms returns the
+ * accumulated milliseconds and launch counts per stage since the last lt_stage_reset */
+int  lt_set_stage_timing(lt_ctx* ctx, int enabled);
+int  lt_stage_reset(lt_ctx* ctx);
+int  lt_stage_ms(lt_ctx* ctx, float* ms, int32_t* launches, int n);
+const char* lt_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

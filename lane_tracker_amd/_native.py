@@ -1,0 +1,342 @@
+"""ctypes binding of liblane_tracker_amd.so (include/lane_tracker_amd.h).
+
+The library is HIP-only.  There is deliberately no fallback: if the shared object is missing or no
+GPU is visible, constructing a `Context` raises -- nothing in this package computes on the CPU.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblane_tracker_amd.so")
+NUM_STAGES = 12
+
+PLANE_R, PLANE_LAB_B, PLANE_TOPHAT_R, PLANE_TOPHAT_B, PLANE_MERGED, PLANE_MASK = range(6)
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Calib(C.Structure):
+    _fields_ = [("img_w", C.c_int32), ("img_h", C.c_int32), ("warp_w", C.c_int32), ("warp_h", C.c_int32),
+                ("cam_matrix", C.c_double * 9), ("dist_coeffs", C.c_double * 5), ("M", C.c_double * 9)]
+
+
+class FilterParams(C.Structure):
+    _fields_ = [("filter_type", C.c_int32), ("ksize_r", C.c_int32), ("C_r", C.c_int32), ("ksize_b", C.c_int32),
+                ("C_b", C.c_int32), ("mask_noise", C.c_int32), ("noise_thresh", C.c_int32),
+                ("ksize_noise", C.c_int32), ("C_noise", C.c_int32)]
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("window_width", C.c_int32), ("window_height", C.c_int32), ("search_range", C.c_int32),
+                ("no_success_limit", C.c_int32), ("ignore_sides", C.c_int32), ("ignore_bottom", C.c_int32),
+                ("bandwidth", C.c_int32), ("_pad", C.c_int32), ("mu", C.c_double), ("start_slice", C.c_double),
+                ("partial", C.c_double)]
+
+
+class LaneRecord(C.Structure):
+    _fields_ = [("left_coeffs", C.c_double * 3), ("right_coeffs", C.c_double * 3), ("n_left", C.c_int32),
+                ("n_right", C.c_int32), ("detected", C.c_uint8), ("fit_flags", C.c_uint8), ("mode", C.c_uint8),
+                ("_pad", C.c_uint8), ("frame", C.c_int32)]
+
+
+RECORD_DTYPE = np.dtype([("left_coeffs", "<f8", 3), ("right_coeffs", "<f8", 3), ("n_left", "<i4"),
+                         ("n_right", "<i4"), ("detected", "u1"), ("fit_flags", "u1"), ("mode", "u1"),
+                         ("_pad", "u1"), ("frame", "<i4")])
+assert RECORD_DTYPE.itemsize == 64 and C.sizeof(LaneRecord) == 64
+
+
+class Info(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("capacity", C.c_int32),
+                ("cu_count", C.c_int32), ("src_row0", C.c_int32), ("src_row1", C.c_int32),
+                ("max_pixels_per_side", C.c_int32), ("max_levels", C.c_int32), ("alg_bytes_mask", C.c_int64),
+                ("alg_bytes_search", C.c_int64), ("device_name", C.c_char * 64)]
+
+
+# name -> (restype, argtypes); every symbol include/lane_tracker_amd.h declares
+_P = C.c_void_p
+_SIGNATURES = {
+    "lt_last_error": (C.c_char_p, []),
+    "lt_abi_version": (C.c_int, []),
+    "lt_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "lt_create": (C.c_int, [C.POINTER(Calib), C.c_int, C.POINTER(_P)]),
+    "lt_destroy": (None, [_P]),
+    "lt_reserve": (C.c_int, [_P, C.c_int]),
+    "lt_get_info": (C.c_int, [_P, C.POINTER(Info)]),
+    "lt_sync": (C.c_int, [_P]),
+    "lt_upload_frames": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_upload_masks": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_download_masks": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_download_plane": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    "lt_download_undistorted": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_download_records": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_download_pixels": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
+    "lt_download_centroids": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "lt_copy_records_to_device": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
+    "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
+    "lt_sws_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams)]),
+    "lt_band_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
+    "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "lt_mask_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(FilterParams), _P]),
+    "lt_sws_fit_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(SearchParams), _P]),
+    "lt_band_fit_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(SearchParams), _P, _P]),
+    "lt_bilateral_adaptive_threshold": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.c_int, _P]),
+    "lt_filter_lane_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FilterParams), _P]),
+    "lt_fit_poly2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "lt_timer_start": (C.c_int, [_P]),
+    "lt_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "lt_set_stage_timing": (C.c_int, [_P, C.c_int]),
+    "lt_stage_reset": (C.c_int, [_P]),
+    "lt_stage_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]),
+    "lt_stage_name": (C.c_char_p, [C.c_int]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the shared library in-tree with hipcc for gfx950 (csrc/Makefile)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-s", "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and bind every declared symbol.  Raises NativeError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950).  lane_tracker_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this table ever diverge
+        fn.restype = res
+        fn.argtypes = args
+    if lib.lt_abi_version() != 1:
+        raise NativeError("ABI version mismatch between _native.py and liblane_tracker_amd.so")
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().lt_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise NativeError(f"lane_tracker_amd error {rc}: {msg}")
+
+
+def _u8(a, shape_tail=None):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return a
+
+
+def filter_params(filter_type="bilateral", ksize_r=15, C_r=8, ksize_b=35, C_b=5, mask_noise=False,
+                  noise_thresh=140, ksize_noise=65, C_noise=10):
+    ft = {"bilateral": 0, "neighborhood": 1}.get(filter_type, 2)   # 2 -> ValueError from the library (:220)
+    return FilterParams(ft, int(ksize_r), int(C_r), int(ksize_b), int(C_b), int(bool(mask_noise)),
+                        int(noise_thresh), int(ksize_noise), int(C_noise))
+
+
+def search_params(window_width=30, window_height=40, search_range=20, mu=0.1, no_success_limit=8,
+                  start_slice=0.25, ignore_sides=360, ignore_bottom=30, bandwidth=25, partial=1.0):
+    return SearchParams(int(window_width), int(window_height), int(search_range), int(no_success_limit),
+                        int(ignore_sides), int(ignore_bottom), int(bandwidth), 0, float(mu), float(start_slice),
+                        float(partial))
+
+
+class Context:
+    """One device context = one HIP stream + calibration tables + `capacity` frame slots in HBM."""
+
+    def __init__(self, img_size, warped_size, cam_matrix, dist_coeffs, M, device=0, capacity=1):
+        self._h = None
+        lib = load()
+        cal = Calib()
+        cal.img_w, cal.img_h = int(img_size[0]), int(img_size[1])
+        cal.warp_w, cal.warp_h = int(warped_size[0]), int(warped_size[1])
+        cal.cam_matrix[:] = [float(v) for v in np.asarray(cam_matrix, np.float64).reshape(9)]
+        d = np.asarray(dist_coeffs, np.float64).reshape(-1)
+        cal.dist_coeffs[:] = [float(v) for v in (list(d[:5]) + [0.0] * 5)[:5]]
+        cal.M[:] = [float(v) for v in np.asarray(M, np.float64).reshape(9)]
+        h = _P()
+        _check(lib.lt_create(C.byref(cal), int(device), C.byref(h)))
+        self._h = h
+        self.lib = lib
+        self.img_w, self.img_h, self.warp_w, self.warp_h = cal.img_w, cal.img_h, cal.warp_w, cal.warp_h
+        self.reserve(capacity)
+
+    def close(self):
+        if self._h is not None:
+            self.lib.lt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- bookkeeping
+    def reserve(self, capacity):
+        _check(self.lib.lt_reserve(self._h, int(capacity)))
+        self.capacity = max(getattr(self, "capacity", 0), int(capacity))
+
+    def info(self):
+        i = Info()
+        _check(self.lib.lt_get_info(self._h, C.byref(i)))
+        return i
+
+    def sync(self):
+        _check(self.lib.lt_sync(self._h))
+
+    # -- data movement
+    def upload_frames(self, frames, first=0):
+        f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
+        _check(self.lib.lt_upload_frames(self._h, f.ctypes.data, first, f.shape[0]))
+        return f.shape[0]
+
+    def upload_masks(self, masks, first=0):
+        m = _u8(masks).reshape(-1, self.warp_h, self.warp_w)
+        _check(self.lib.lt_upload_masks(self._h, m.ctypes.data, first, m.shape[0]))
+        return m.shape[0]
+
+    def upload_bev(self, bev, first=0):
+        b = _u8(bev).reshape(-1, self.warp_h, self.warp_w, 3)
+        _check(self.lib.lt_upload_bev(self._h, b.ctypes.data, first, b.shape[0]))
+        return b.shape[0]
+
+    def download_masks(self, n, first=0):
+        out = np.empty((n, self.warp_h, self.warp_w), np.uint8)
+        _check(self.lib.lt_download_masks(self._h, first, n, out.ctypes.data))
+        return out
+
+    def download_plane(self, plane, n, first=0):
+        out = np.empty((n, self.warp_h, self.warp_w), np.uint8)
+        _check(self.lib.lt_download_plane(self._h, plane, first, n, out.ctypes.data))
+        return out
+
+    def download_undistorted(self, n, first=0):
+        i = self.info()
+        out = np.empty((n, i.src_row1 - i.src_row0, self.img_w, 3), np.uint8)
+        _check(self.lib.lt_download_undistorted(self._h, first, n, out.ctypes.data))
+        return out
+
+    def download_records(self, n, first=0):
+        out = np.zeros(n, RECORD_DTYPE)
+        _check(self.lib.lt_download_records(self._h, first, n, out.ctypes.data))
+        return out
+
+    def download_pixels(self, slot, side):
+        cnt = C.c_int(0)
+        _check(self.lib.lt_download_pixels(self._h, slot, side, None, None, 0, C.byref(cnt)))
+        n = cnt.value
+        ys, xs = np.empty(n, np.int32), np.empty(n, np.int32)
+        if n:
+            _check(self.lib.lt_download_pixels(self._h, slot, side, ys.ctypes.data, xs.ctypes.data, n, C.byref(cnt)))
+        return ys.astype(np.int64), xs.astype(np.int64)
+
+    def download_centroids(self, slot, side):
+        cap = self.info().max_levels + 2
+        out = np.zeros(cap, np.int32)
+        cnt = C.c_int(0)
+        _check(self.lib.lt_download_centroids(self._h, slot, side, out.ctypes.data, cap, C.byref(cnt)))
+        return [int(v) for v in out[:cnt.value]]
+
+    def copy_records_to_device(self, n, dst_ptr, first=0):
+        _check(self.lib.lt_copy_records_to_device(self._h, first, n, C.c_void_p(int(dst_ptr))))
+
+    def set_frame_base(self, n, first_frame, first=0):
+        _check(self.lib.lt_set_frame_base(self._h, first, n, int(first_frame)))
+
+    # -- compute (asynchronous on the context's stream)
+    def mask_run(self, n, fp=None, first=0):
+        fp = fp or filter_params()
+        _check(self.lib.lt_mask_run(self._h, first, n, C.byref(fp)))
+
+    def filter_run(self, n, fp=None, first=0):
+        fp = fp or filter_params()
+        _check(self.lib.lt_filter_run(self._h, first, n, C.byref(fp)))
+
+    def sws_fit_run(self, n, sp=None, first=0):
+        sp = sp or search_params()
+        _check(self.lib.lt_sws_fit_run(self._h, first, n, C.byref(sp)))
+
+    def band_fit_run(self, n, prev_coeffs, sp=None, first=0):
+        sp = sp or search_params()
+        prev = np.ascontiguousarray(prev_coeffs, np.float64).reshape(n, 6)
+        _check(self.lib.lt_band_fit_run(self._h, first, n, C.byref(sp), prev.ctypes.data))
+
+    # -- single-image operators
+    def bilateral_adaptive_threshold(self, img, ksize, C_, mode, true_value, false_value):
+        a = _u8(img)
+        if a.ndim != 2:
+            raise ValueError("bilateral_adaptive_threshold expects a single-channel image")
+        out = np.empty_like(a)
+        _check(self.lib.lt_bilateral_adaptive_threshold(self._h, a.ctypes.data, a.shape[0], a.shape[1], int(ksize),
+                                                        int(C_), int(mode), int(true_value), int(false_value),
+                                                        out.ctypes.data))
+        return out
+
+    def filter_lane_points(self, bev, fp=None):
+        fp = fp or filter_params()
+        a = _u8(bev)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("filter_lane_points expects an RGB image (H, W, 3)")
+        out = np.empty(a.shape[:2], np.uint8)
+        _check(self.lib.lt_filter_lane_points(self._h, a.ctypes.data, a.shape[0], a.shape[1], C.byref(fp),
+                                              out.ctypes.data))
+        return out
+
+    def fit_poly2(self, ys, xs):
+        """np.polyfit(ys, xs, 2) on the device; rank-deficient inputs get NumPy's minimum-norm answer."""
+        ys = np.ascontiguousarray(ys, np.int32)
+        xs = np.ascontiguousarray(xs, np.int32)
+        coef = (C.c_double * 3)()
+        bad = C.c_int(0)
+        _check(self.lib.lt_fit_poly2(self._h, ys.ctypes.data, xs.ctypes.data, int(ys.size), self.warp_h, self.warp_w,
+                                     coef, C.byref(bad)))
+        if bad.value:
+            from .lane_tracker import _minimum_norm_parabola
+            return _minimum_norm_parabola(ys, xs)
+        return np.array(coef[:], np.float64)
+
+    # -- measurement
+    def timer_start(self):
+        _check(self.lib.lt_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        _check(self.lib.lt_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+    def set_stage_timing(self, enabled):
+        _check(self.lib.lt_set_stage_timing(self._h, int(bool(enabled))))
+
+    def stage_reset(self):
+        _check(self.lib.lt_stage_reset(self._h))
+
+    def stage_ms(self):
+        ms = (C.c_float * NUM_STAGES)()
+        ln = (C.c_int32 * NUM_STAGES)()
+        _check(self.lib.lt_stage_ms(self._h, ms, ln, NUM_STAGES))
+        return {self.lib.lt_stage_name(i).decode(): (ms[i], ln[i]) for i in range(NUM_STAGES)}
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(load().lt_device_count(C.byref(n)))
+    return n.value

@@ -1,0 +1,203 @@
+// filter_lane_points() kernels (lane_tracker.py:183-240), gfx950.  All planes are u8, h x w,
+// one plane per frame at `plane_stride` bytes apart; blockIdx.z is the frame.
+//
+//   k_morph_ellipse   morphologyEx TOPHAT / OPEN building block   lane_tracker.py:210-211, 238
+//   k_bilateral       bilateral_adaptive_threshold                lane_tracker.py:14-83, 214-215, 224
+//   k_adaptive_mean   cv2.adaptiveThreshold(MEAN_C)               lane_tracker.py:217-218
+//   k_merge           OR / noise-mask merge                       lane_tracker.py:221-235
+#include "lt_internal.h"
+
+namespace lt {
+namespace {
+
+// ---- generic elliptical erode / dilate: direct evaluation of the footprint (any k <= 63) ---------
+// Used for the 5x5 OPEN and for arbitrary image sizes; the 29x29 / 55x55 top-hats of the batched
+// path use the decomposed kernels in k_tophat.hip.
+template <bool DILATE>
+__global__ __launch_bounds__(256) void k_morph_ellipse(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      const uint8_t* __restrict__ minuend, int h, int w,
+                                                      EllipseSE se, size_t plane_stride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t fo = (size_t)blockIdx.z * plane_stride;
+    const uint8_t* s = src + fo;
+    const int r = se.k / 2;
+    int acc = DILATE ? 0 : 255;
+    for (int i = 0; i < se.k; ++i) {
+        const int yy = y + i - r;
+        if (yy < 0 || yy >= h) continue;  // out-of-image taps are neutral
+        const int d = se.dx[i];
+        const int xa = max(x - d, 0), xb = min(x + d, w - 1);
+        const uint8_t* row = s + (size_t)yy * w;
+        for (int xx = xa; xx <= xb; ++xx) {
+            const int v = row[xx];
+            acc = DILATE ? max(acc, v) : min(acc, v);
+        }
+    }
+    const size_t o = fo + (size_t)y * w + x;
+    if (minuend) {
+        const int m = minuend[o];
+        acc = m > acc ? m - acc : 0;  // TOPHAT: src - open(src), saturating
+    }
+    dst[o] = (uint8_t)acc;
+}
+
+// ---- bilateral adaptive threshold ------------------------------------------------------------------
+// left = sum_{i=1..k} p(x-i,y) - k*p + C*k  (zero outside the image), likewise right/up/down;
+// 'floor': pass iff (left<0 && right<0) || (up<0 && down<0); 'ceil': same with >0 and delta=-C*k.
+// A 64x16 tile plus its cross-shaped halo is staged in LDS as running prefix sums along rows and
+// along columns, so each side sum is a difference of two prefix values.
+constexpr int BT_W = 64, BT_H = 16;
+
+__global__ __launch_bounds__(256) void k_bilateral(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int h,
+                                                  int w, int ksize, int C, int mode, int tv, int fv,
+                                                  size_t plane_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // rowp: BT_H rows x (BT_W + 2k + 1) prefix sums;  colp: BT_W columns x (BT_H + 2k + 1)
+    const int rw = BT_W + 2 * ksize + 1, ch = BT_H + 2 * ksize + 1;
+    int32_t* rowp = reinterpret_cast<int32_t*>(smem);
+    int32_t* colp = rowp + BT_H * rw;
+    const size_t fo = (size_t)blockIdx.z * plane_stride;
+    const uint8_t* s = src + fo;
+    const int x0 = blockIdx.x * BT_W, y0 = blockIdx.y * BT_H;
+    const int tid = threadIdx.x;
+    // raw values first (zero outside the image = BORDER_CONSTANT 0)
+    for (int i = tid; i < BT_H * (rw - 1); i += 256) {
+        const int ry = i / (rw - 1), rx = i % (rw - 1);
+        const int gy = y0 + ry, gx = x0 - ksize + rx;
+        rowp[ry * rw + rx + 1] = (gy < h && gx >= 0 && gx < w) ? s[(size_t)gy * w + gx] : 0;
+    }
+    for (int i = tid; i < BT_W * (ch - 1); i += 256) {
+        const int cy = i / BT_W, cx = i % BT_W;  // consecutive threads -> consecutive x
+        const int gy = y0 - ksize + cy, gx = x0 + cx;
+        colp[cx * ch + cy + 1] = (gx < w && gy >= 0 && gy < h) ? s[(size_t)gy * w + gx] : 0;
+    }
+    __syncthreads();
+    // in-place inclusive prefix, one thread per row / per column
+    if (tid < BT_H) {
+        int32_t* p = rowp + tid * rw;
+        int acc = 0;
+        p[0] = 0;
+        for (int i = 1; i < rw; ++i) { acc += p[i]; p[i] = acc; }
+    } else if (tid >= 64 && tid < 64 + BT_W) {
+        int32_t* p = colp + (tid - 64) * ch;
+        int acc = 0;
+        p[0] = 0;
+        for (int i = 1; i < ch; ++i) { acc += p[i]; p[i] = acc; }
+    }
+    __syncthreads();
+    const int delta = mode == 0 ? C * ksize : -C * ksize;
+    for (int i = tid; i < BT_W * BT_H; i += 256) {
+        const int ty = i / BT_W, tx = i % BT_W;
+        const int gx = x0 + tx, gy = y0 + ty;
+        if (gx >= w || gy >= h) continue;
+        const int32_t* rp = rowp + ty * rw;
+        const int32_t* cp = colp + tx * ch;
+        const int cx = tx + ksize, cy = ty + ksize;  // index of the centre in raw coordinates
+        const int p = rp[cx + 1] - rp[cx];
+        const int sl = rp[cx] - rp[cx - ksize], sr = rp[cx + 1 + ksize] - rp[cx + 1];
+        const int su = cp[cy] - cp[cy - ksize], sd = cp[cy + 1 + ksize] - cp[cy + 1];
+        const int kp = ksize * p;
+        const int l = sl - kp + delta, r = sr - kp + delta, u = su - kp + delta, d = sd - kp + delta;
+        const bool pass = mode == 0 ? ((l < 0 && r < 0) || (u < 0 && d < 0)) : ((l > 0 && r > 0) || (u > 0 && d > 0));
+        dst[fo + (size_t)gy * w + gx] = (uint8_t)(pass ? tv : fv);
+    }
+}
+
+// ---- adaptiveThreshold(MEAN_C, THRESH_BINARY, bs, -C): 255 iff src - round(boxmean) > C ------------
+// replicated border; bs*bs is odd so the rounded mean is (2*sum + bs^2) / (2*bs^2) exactly.
+constexpr int AT_W = 64, AT_H = 16;
+
+__global__ __launch_bounds__(256) void k_adaptive_mean(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      int h, int w, int bs, int C, size_t plane_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int r = bs / 2;
+    const int tw = AT_W + 2 * r, th = AT_H + 2 * r;
+    uint8_t* tile = smem;                                             // th x tw raw (replicated)
+    int32_t* hs = reinterpret_cast<int32_t*>(smem + ((th * tw + 15) & ~15));  // th x AT_W horizontal sums
+    const size_t fo = (size_t)blockIdx.z * plane_stride;
+    const uint8_t* s = src + fo;
+    const int x0 = blockIdx.x * AT_W, y0 = blockIdx.y * AT_H, tid = threadIdx.x;
+    for (int i = tid; i < th * tw; i += 256) {
+        const int ty = i / tw, tx = i % tw;
+        const int gy = min(max(y0 - r + ty, 0), h - 1), gx = min(max(x0 - r + tx, 0), w - 1);
+        tile[i] = s[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    for (int i = tid; i < th * AT_W; i += 256) {
+        const int ty = i / AT_W, tx = i % AT_W;
+        const uint8_t* p = tile + ty * tw + tx;
+        int acc = 0;
+        for (int j = 0; j < bs; ++j) acc += p[j];
+        hs[i] = acc;
+    }
+    __syncthreads();
+    const int area = bs * bs;
+    for (int i = tid; i < AT_H * AT_W; i += 256) {
+        const int ty = i / AT_W, tx = i % AT_W;
+        const int gx = x0 + tx, gy = y0 + ty;
+        if (gx >= w || gy >= h) continue;
+        int acc = 0;
+        for (int j = 0; j < bs; ++j) acc += hs[(ty + j) * AT_W + tx];
+        const int mean = (2 * acc + area) / (2 * area);
+        const int v = tile[(ty + r) * tw + tx + r];
+        dst[fo + (size_t)gy * w + gx] = (uint8_t)(v - mean > C ? 255 : 0);
+    }
+}
+
+// ---- merge ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_merge(const uint8_t* __restrict__ tr, const uint8_t* __restrict__ tb,
+                                              const uint8_t* __restrict__ labb, const uint8_t* __restrict__ noise_bil,
+                                              int noise_thresh, int use_noise, uint8_t* __restrict__ merged,
+                                              size_t npix, size_t plane_stride) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const size_t o = (size_t)blockIdx.z * plane_stride + i;
+    bool v = tr[o] || tb[o];
+    if (use_noise) {
+        const bool part1 = labb[o] >= noise_thresh;  // inRange(b, thresh, 255)
+        v = v && (!part1 || noise_bil[o]);
+    }
+    merged[o] = v ? 255 : 0;
+}
+
+}  // namespace
+
+void launch_morph_ellipse(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w,
+                          const EllipseSE& se, bool dilate, size_t plane_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return;
+    dim3 grid((w + 63) / 64, (h + 3) / 4, n);
+    if (dilate)
+        hipLaunchKernelGGL(k_morph_ellipse<true>, grid, dim3(256), 0, s, src, dst, minuend, h, w, se, plane_stride);
+    else
+        hipLaunchKernelGGL(k_morph_ellipse<false>, grid, dim3(256), 0, s, src, dst, minuend, h, w, se, plane_stride);
+}
+
+void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int ksize, int C, int mode,
+                      int tv, int fv, size_t plane_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return;
+    const int rw = BT_W + 2 * ksize + 1, ch = BT_H + 2 * ksize + 1;
+    const size_t lds = (size_t)(BT_H * rw + BT_W * ch) * sizeof(int32_t);
+    dim3 grid((w + BT_W - 1) / BT_W, (h + BT_H - 1) / BT_H, n);
+    hipLaunchKernelGGL(k_bilateral, grid, dim3(256), lds, s, src, dst, h, w, ksize, C, mode, tv, fv, plane_stride);
+}
+
+void launch_adaptive_mean(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int bs, int C,
+                          size_t plane_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return;
+    const int r = bs / 2, tw = AT_W + 2 * r, th = AT_H + 2 * r;
+    const size_t lds = (size_t)((th * tw + 15) & ~15) + (size_t)th * AT_W * sizeof(int32_t);
+    dim3 grid((w + AT_W - 1) / AT_W, (h + AT_H - 1) / AT_H, n);
+    hipLaunchKernelGGL(k_adaptive_mean, grid, dim3(256), lds, s, src, dst, h, w, bs, C, plane_stride);
+}
+
+void launch_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uint8_t* labb, const uint8_t* noise_bil,
+                  int noise_thresh, int use_noise, uint8_t* merged, size_t npix, size_t plane_stride, int n) {
+    if (n <= 0 || npix == 0) return;
+    dim3 grid((unsigned)((npix + 255) / 256), 1, n);
+    hipLaunchKernelGGL(k_merge, grid, dim3(256), 0, s, tr, tb, labb, noise_bil, noise_thresh, use_noise, merged, npix,
+                       plane_stride);
+}
+
+}  // namespace lt

@@ -1,0 +1,181 @@
+// Geometric front end + colour split, gfx950.
+//
+//   k_undistort_rows   cv2.undistort            lane_tracker.py:832   (only the rows the warp reads)
+//   k_warp_split       cv2.warpPerspective      lane_tracker.py:834
+//                      + img[:,:,0]             lane_tracker.py:207
+//                      + cvtColor(RGB2LAB)[:,:,2] lane_tracker.py:208
+//
+// Both resamplings are OpenCV's 8-bit bilinear remap: integer tap (sx,sy) + 5-bit fractions,
+// exact 15-bit weights, constant-0 border, (sum + 2^14) >> 15.  They cannot be composed into one
+// resampling because the intermediate is rounded to u8, so the undistorted rows are materialised
+// once (planar, 3 x rows x W bytes per frame: it stays in L2 for the warp that follows).
+// The bird's-eye RGB image itself is never written: the warp emits the R plane and the Lab-b
+// plane directly.
+#include "lt_internal.h"
+
+namespace lt {
+namespace {
+
+__device__ __forceinline__ int bilerp(int v00, int v01, int v10, int v11, int fx, int fy) {
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
+    const int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    return (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
+}
+
+// one thread per undistorted pixel; frames are RGB interleaved, output is planar
+__global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restrict__ frames, size_t frame_stride,
+                                                       const int16_t* __restrict__ uxy,
+                                                       const uint16_t* __restrict__ ufrac, FrontEndGeom g,
+                                                       uint8_t* __restrict__ und, size_t und_stride) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;  // relative to g.r0
+    if (x >= g.img_w) return;
+    const uint8_t* src = frames + (size_t)blockIdx.z * frame_stride;
+    uint8_t* dst = und + (size_t)blockIdx.z * und_stride;
+    const size_t o = (size_t)row * g.img_w + x;
+    const int sx = uxy[o * 2], sy = uxy[o * 2 + 1];
+    const int f = ufrac[o], fx = f & 31, fy = f >> 5;
+    const bool y0 = sy >= 0 && sy < g.img_h, y1 = sy + 1 >= 0 && sy + 1 < g.img_h;
+    const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
+    const size_t plane = (size_t)g.nrows * g.img_w;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int v00 = (y0 && x0) ? src[((size_t)sy * g.img_w + sx) * 3 + ch] : 0;
+        const int v01 = (y0 && x1) ? src[((size_t)sy * g.img_w + sx + 1) * 3 + ch] : 0;
+        const int v10 = (y1 && x0) ? src[((size_t)(sy + 1) * g.img_w + sx) * 3 + ch] : 0;
+        const int v11 = (y1 && x1) ? src[((size_t)(sy + 1) * g.img_w + sx + 1) * 3 + ch] : 0;
+        dst[ch * plane + o] = (uint8_t)bilerp(v00, v01, v10, v11, fx, fy);
+    }
+}
+
+struct LabLut {
+    const uint16_t* gamma_tab;
+    const uint16_t* cbrt_tab;
+};
+
+__device__ __forceinline__ int lab_b_of(int r, int g, int b, const uint16_t* gt, const uint16_t* ct,
+                                        const int32_t* C) {
+    const int R = gt[r], G = gt[g], B = gt[b];
+    int iy = (R * C[3] + G * C[4] + B * C[5] + (1 << 11)) >> 12;
+    int iz = (R * C[6] + G * C[7] + B * C[8] + (1 << 11)) >> 12;
+    iy = iy > 3071 ? 3071 : iy;
+    iz = iz > 3071 ? 3071 : iz;
+    const int fY = ct[iy], fZ = ct[iz];
+    const int v = (200 * (fY - fZ) + 128 * (1 << 15) + (1 << 14)) >> 15;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__device__ __forceinline__ void stage_lab_tables(uint16_t* s_gamma, uint16_t* s_cbrt, int32_t* s_coef,
+                                                 const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
+                                                 const int32_t* coeffs) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) s_gamma[i] = gamma_tab[i];
+    for (int i = threadIdx.x; i < 3072; i += blockDim.x) s_cbrt[i] = cbrt_tab[i];
+    if (threadIdx.x < 9) s_coef[threadIdx.x] = coeffs[threadIdx.x];
+    __syncthreads();
+}
+
+// one thread per bird's-eye pixel: three bilinear samples of the planar undistorted rows, then
+// R plane and Lab-b plane
+__global__ __launch_bounds__(256) void k_warp_split(const uint8_t* __restrict__ und, size_t und_stride,
+                                                   const int16_t* __restrict__ wxy,
+                                                   const uint16_t* __restrict__ wfrac, FrontEndGeom g,
+                                                   const uint16_t* __restrict__ gamma_tab,
+                                                   const uint16_t* __restrict__ cbrt_tab,
+                                                   const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
+                                                   uint8_t* __restrict__ planeB, size_t plane_stride) {
+    __shared__ uint16_t s_gamma[256];
+    __shared__ uint16_t s_cbrt[3072];
+    __shared__ int32_t s_coef[9];
+    stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
+    const size_t npix = (size_t)g.warp_h * g.warp_w;
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= npix) return;
+    const uint8_t* src = und + (size_t)blockIdx.z * und_stride;
+    const int sx = wxy[o * 2], sy = wxy[o * 2 + 1];
+    const int f = wfrac[o], fx = f & 31, fy = f >> 5;
+    // taps outside the camera frame are 0; in-frame taps always fall inside rows [r0, r0+nrows)
+    const int ry0 = sy - g.r0, ry1 = sy + 1 - g.r0;
+    const bool y0 = sy >= 0 && sy < g.img_h && ry0 >= 0 && ry0 < g.nrows;
+    const bool y1 = sy + 1 >= 0 && sy + 1 < g.img_h && ry1 >= 0 && ry1 < g.nrows;
+    const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
+    const size_t plane = (size_t)g.nrows * g.img_w;
+    int rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const uint8_t* p = src + ch * plane;
+        const int v00 = (y0 && x0) ? p[(size_t)ry0 * g.img_w + sx] : 0;
+        const int v01 = (y0 && x1) ? p[(size_t)ry0 * g.img_w + sx + 1] : 0;
+        const int v10 = (y1 && x0) ? p[(size_t)ry1 * g.img_w + sx] : 0;
+        const int v11 = (y1 && x1) ? p[(size_t)ry1 * g.img_w + sx + 1] : 0;
+        rgb[ch] = bilerp(v00, v01, v10, v11, fx, fy);
+    }
+    planeR[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)rgb[0];
+    planeB[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, s_coef);
+}
+
+// filter_lane_points() entry on an already-warped RGB image (lane_tracker.py:207-208)
+__global__ __launch_bounds__(256) void k_split_bev(const uint8_t* __restrict__ bev, size_t bev_stride, int npix,
+                                                  const uint16_t* __restrict__ gamma_tab,
+                                                  const uint16_t* __restrict__ cbrt_tab,
+                                                  const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
+                                                  uint8_t* __restrict__ planeB, size_t plane_stride) {
+    __shared__ uint16_t s_gamma[256];
+    __shared__ uint16_t s_cbrt[3072];
+    __shared__ int32_t s_coef[9];
+    stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= (size_t)npix) return;
+    const uint8_t* p = bev + (size_t)blockIdx.z * bev_stride + o * 3;
+    const int r = p[0], gg = p[1], b = p[2];
+    planeR[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)r;
+    planeB[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)lab_b_of(r, gg, b, s_gamma, s_cbrt, s_coef);
+}
+
+__global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint8_t* __restrict__ und, size_t und_stride,
+                                                           int nrows, int w, uint8_t* __restrict__ out) {
+    const size_t plane = (size_t)nrows * w;
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= plane) return;
+    const uint8_t* src = und + (size_t)blockIdx.z * und_stride;
+    uint8_t* dst = out + (size_t)blockIdx.z * plane * 3 + o * 3;
+    dst[0] = src[o];
+    dst[1] = src[plane + o];
+    dst[2] = src[2 * plane + o];
+}
+
+}  // namespace
+
+void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
+                           const uint16_t* ufrac, FrontEndGeom g, uint8_t* und, size_t und_stride, int n) {
+    if (n <= 0 || g.nrows <= 0) return;
+    dim3 grid((g.img_w + 255) / 256, g.nrows, n);
+    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride);
+}
+
+void launch_warp_split(hipStream_t s, const uint8_t* und, size_t und_stride, const int16_t* wxy,
+                       const uint16_t* wfrac, FrontEndGeom g, const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
+                       const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB, size_t plane_stride, int n) {
+    if (n <= 0) return;
+    const size_t npix = (size_t)g.warp_h * g.warp_w;
+    dim3 grid((unsigned)((npix + 255) / 256), 1, n);
+    hipLaunchKernelGGL(k_warp_split, grid, dim3(256), 0, s, und, und_stride, wxy, wfrac, g, gamma_tab, cbrt_tab,
+                       coeffs, planeR, planeB, plane_stride);
+}
+
+void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int npix, const uint16_t* gamma_tab,
+                      const uint16_t* cbrt_tab, const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB,
+                      size_t plane_stride, int n) {
+    if (n <= 0) return;
+    dim3 grid((unsigned)((npix + 255) / 256), 1, n);
+    hipLaunchKernelGGL(k_split_bev, grid, dim3(256), 0, s, bev, bev_stride, npix, gamma_tab, cbrt_tab, coeffs, planeR,
+                       planeB, plane_stride);
+}
+
+void launch_undistorted_to_rgb(hipStream_t s, const uint8_t* und, size_t und_stride, int nrows, int w, uint8_t* out,
+                               int n) {
+    if (n <= 0 || nrows <= 0) return;
+    dim3 grid((unsigned)(((size_t)nrows * w + 255) / 256), 1, n);
+    hipLaunchKernelGGL(k_undistorted_to_rgb, grid, dim3(256), 0, s, und, und_stride, nrows, w, out);
+}
+
+}  // namespace lt

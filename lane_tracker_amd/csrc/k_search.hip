@@ -1,0 +1,529 @@
+// Lane-pixel search + polynomial fit, gfx950.  One 256-thread workgroup per frame.
+//
+//   k_sws_fit    LaneTracker.sliding_window_search + fit_poly   lane_tracker.py:242-447, 502-509
+//   k_band_fit   LaneTracker.band_search + fit_poly             lane_tracker.py:449-509
+//
+// Column histograms are LDS atomics, the first/last-argmax of the box-filtered histogram and the
+// per-row stream compaction are wavefront ballots/shuffles (64 lanes), and the 2nd-degree fit is a
+// per-lane 3x3 normal-equations solve on exact int64 moments taken about the image centre.
+// Lane pixels are emitted in the reference's order (level-major, then row-major inside a window;
+// row-major for the band search) as packed (y << 16) | x.
+#include "lt_internal.h"
+
+namespace lt {
+namespace {
+
+constexpr int NT = 256, NW = NT / 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Moments of the lane pixels about (y0, x0), exact in int64:
+//   m[0..4] = sum (y-y0)^k, k = 0..4 ;  m[5..7] = sum (x-x0) (y-y0)^k, k = 0..2
+struct Moments {
+    long long m[8];
+    __device__ void clear() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = 0;
+    }
+    __device__ void add(int y, int x, int y0, int x0) {
+        const long long dy = y - y0, dx = x - x0, dy2 = dy * dy;
+        m[0] += 1; m[1] += dy; m[2] += dy2; m[3] += dy2 * dy; m[4] += dy2 * dy2;
+        m[5] += dx; m[6] += dx * dy; m[7] += dx * dy2;
+    }
+};
+
+// Least-squares parabola x = a y^2 + b y + c from the centred moments (np.polyfit(y, x, 2)).
+// The normal equations are solved in f64 on variables scaled to O(1); returns false when the
+// system is rank deficient (fewer than 3 distinct y), which the host then handles like NumPy.
+__device__ bool solve_poly2(const long long* m, int distinct_rows, double y0, double x0, double sy, double* out) {
+    out[0] = out[1] = out[2] = 0.0;
+    if (m[0] <= 0) return false;
+    if (distinct_rows < 3) return false;
+    const double is = 1.0 / sy, is2 = is * is, is3 = is2 * is, is4 = is2 * is2;
+    // u = (y - y0)/sy ; x' = x - x0 ;  [S4 S3 S2; S3 S2 S1; S2 S1 S0] [A B C]' = [T2 T1 T0]'
+    const double S0 = (double)m[0], S1 = (double)m[1] * is, S2 = (double)m[2] * is2, S3 = (double)m[3] * is3,
+                 S4 = (double)m[4] * is4;
+    const double T0 = (double)m[5], T1 = (double)m[6] * is, T2 = (double)m[7] * is2;
+    // symmetric positive definite: Cholesky  G = L L'
+    const double l00 = sqrt(S4);
+    if (!(l00 > 0.0)) return false;
+    const double l10 = S3 / l00, l20 = S2 / l00;
+    const double d1 = S2 - l10 * l10;
+    if (!(d1 > 0.0)) return false;
+    const double l11 = sqrt(d1);
+    const double l21 = (S1 - l20 * l10) / l11;
+    const double d2 = S0 - l20 * l20 - l21 * l21;
+    if (!(d2 > 0.0)) return false;
+    const double l22 = sqrt(d2);
+    const double z0 = T2 / l00, z1 = (T1 - l10 * z0) / l11, z2 = (T0 - l20 * z0 - l21 * z1) / l22;
+    const double C = z2 / l22, B = (z1 - l21 * C) / l11, A = (z0 - l10 * B - l20 * C) / l00;
+    // x - x0 = A u^2 + B u + C with u = (y - y0)/sy
+    const double a = A * is2, b = B * is;
+    out[0] = a;
+    out[1] = b - 2.0 * a * y0;
+    out[2] = a * y0 * y0 - b * y0 + C + x0;
+    return true;
+}
+
+// exclusive prefix of an LDS int array of n entries into out[0..n] (out[n] = total), by wave 0
+__device__ void wave0_exclusive_scan(const unsigned* in, unsigned* out, int n) {
+    if (wave_id() != 0) return;
+    const int lane = lane_id(), chunk = (n + 63) / 64;
+    const int a = min(lane * chunk, n), b = min(a + chunk, n);
+    unsigned s = 0;
+    for (int i = a; i < b; ++i) s += in[i];
+    unsigned incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    unsigned run = incl - s;
+    for (int i = a; i < b; ++i) {
+        const unsigned v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (lane == 63) out[n] = incl;
+}
+
+// np.sum(img[r0:r1, c0:c1], axis=0) into sums[0..c1-c0) (LDS atomics; the masks are sparse)
+__device__ void column_sums(const uint8_t* mask, int w, int r0, int r1, int c0, int c1, unsigned* sums) {
+    const int n = c1 - c0;
+    for (int i = threadIdx.x; i < n; i += NT) sums[i] = 0;
+    __syncthreads();
+    if (n > 0 && r1 > r0) {
+        const int items = (r1 - r0) * n;
+        for (int i = threadIdx.x; i < items; i += NT) {
+            const int ry = i / n, cx = i - ry * n;
+            const unsigned v = mask[(size_t)(r0 + ry) * w + c0 + cx];
+            if (v) atomicAdd(&sums[cx], v);
+        }
+    }
+    __syncthreads();
+}
+
+// first/last argmax of conv[a:b), conv = np.convolve(ones(ww), sums[0:ncnt)) ('full'), from the
+// exclusive prefix array; every wave computes the same answer redundantly.  false <=> np.any false.
+__device__ bool box_argmax(const unsigned* prefix, int ncnt, int ww, int a, int b, int& first, int& last) {
+    const int lane = lane_id();
+    unsigned best = 0;
+    for (int k = a + lane; k < b; k += 64) {
+        const int lo = max(k - ww + 1, 0), hi = min(k + 1, ncnt);
+        const unsigned v = hi > lo ? prefix[hi] - prefix[lo] : 0u;
+        best = max(best, v);
+    }
+    best = wave_max_u32(best);
+    if (best == 0) return false;
+    int f = 0x7fffffff, l = -1;
+    for (int k = a + lane; k < b; k += 64) {
+        const int lo = max(k - ww + 1, 0), hi = min(k + 1, ncnt);
+        const unsigned v = hi > lo ? prefix[hi] - prefix[lo] : 0u;
+        if (v == best) { f = min(f, k); l = max(l, k); }
+    }
+    first = wave_min_i32(f) - a;
+    last = wave_max_i32(l) - a;
+    return true;
+}
+
+struct Roi {
+    int active, a, b;  // columns [a, b), already clipped; active = 0: no window on this level
+};
+
+// roi.nonzero() for the (up to) two windows of one level, rows [r0, r1): count pass, row offsets,
+// then an ordered write.  n_out[side] is advanced; moments and distinct-row counts accumulate.
+__device__ void extract_windows(const uint8_t* mask, int w, int r0, int r1, const Roi* roi, unsigned* rowcnt,
+                                unsigned* rowoff, int wh_cap, uint32_t* pix, int maxpix, int* n_out, Moments* mom,
+                                int* distinct, int y0c, int x0c) {
+    const int lane = lane_id(), wv = wave_id(), nrows = r1 - r0;
+    // pass 1: per-row non-zero counts
+    for (int s = 0; s < 2; ++s) {
+        if (!roi[s].active) continue;
+        for (int ry = wv; ry < nrows; ry += NW) {
+            unsigned c = 0;
+            for (int x = roi[s].a + lane; x - lane < roi[s].b; x += 64) {
+                const bool nz = x < roi[s].b && mask[(size_t)(r0 + ry) * w + x] != 0;
+                c += __popcll(__ballot(nz));
+            }
+            if (lane == 0) rowcnt[s * wh_cap + ry] = c;
+        }
+    }
+    __syncthreads();
+    // row offsets: exclusive scan over at most wh_cap rows, one thread per row (rows are few)
+    for (int s = 0; s < 2; ++s) {
+        if (!roi[s].active) continue;
+        for (int ry = threadIdx.x; ry <= nrows; ry += NT) {
+            unsigned acc = 0;
+            for (int q = 0; q < ry; ++q) acc += rowcnt[s * wh_cap + q];
+            rowoff[s * (wh_cap + 1) + ry] = acc;
+        }
+    }
+    __syncthreads();
+    // pass 2: ordered write
+    for (int s = 0; s < 2; ++s) {
+        if (!roi[s].active) continue;
+        const int base = n_out[s];
+        for (int ry = wv; ry < nrows; ry += NW) {
+            unsigned run = rowoff[s * (wh_cap + 1) + ry];
+            const int y = r0 + ry;
+            for (int x = roi[s].a + lane; x - lane < roi[s].b; x += 64) {
+                const bool nz = x < roi[s].b && mask[(size_t)y * w + x] != 0;
+                const unsigned long long bal = __ballot(nz);
+                if (nz) {
+                    const unsigned rank = __popcll(bal & ((1ull << lane) - 1ull));
+                    const int idx = base + (int)(run + rank);
+                    if (idx < maxpix) pix[(size_t)s * maxpix + idx] = ((uint32_t)y << 16) | (uint32_t)x;
+                    mom[s].add(y, x, y0c, x0c);
+                }
+                run += __popcll(bal);
+            }
+        }
+        // uniform bookkeeping (every thread keeps the same copy)
+        int d = 0;
+        for (int ry = 0; ry < nrows; ++ry) d += rowcnt[s * wh_cap + ry] != 0;
+        distinct[s] += d;
+        n_out[s] = base + (int)rowoff[s * (wh_cap + 1) + nrows];
+    }
+    __syncthreads();
+}
+
+__device__ void reduce_and_fit(Moments* mom, const int* distinct, long long* s_mom, int h, int w, int n_left,
+                               int n_right, bool detected, int mode, lt_lane_record* rec) {
+    // block-reduce the per-thread moments: wave shuffle, then LDS atomics
+    for (int i = threadIdx.x; i < 16; i += NT) s_mom[i] = 0;
+    __syncthreads();
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long long v = wave_sum_i64(mom[s].m[k]);
+            if (lane_id() == 0 && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&s_mom[s * 8 + k]), (unsigned long long)v);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lt_lane_record r;
+        const double y0 = (double)(h / 2), x0 = (double)(w / 2), sy = (double)(h > 1 ? h : 2) * 0.5;
+        unsigned flags = 0;
+        for (int k = 0; k < 3; ++k) r.left_coeffs[k] = r.right_coeffs[k] = 0.0;
+        if (detected) {
+            if (!solve_poly2(s_mom, distinct[0], y0, x0, sy, r.left_coeffs)) flags |= 1u;
+            if (!solve_poly2(s_mom + 8, distinct[1], y0, x0, sy, r.right_coeffs)) flags |= 2u;
+        }
+        r.n_left = n_left;
+        r.n_right = n_right;
+        r.detected = detected ? 1 : 0;
+        r.fit_flags = (uint8_t)flags;
+        r.mode = (uint8_t)mode;
+        r._pad = 0;
+        r.frame = rec->frame;  // keep the caller's tag
+        *rec = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+                                               uint32_t* __restrict__ pix_all, int32_t* __restrict__ cent_all,
+                                               lt_lane_record* __restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* sums = reinterpret_cast<unsigned*>(smem);          // w
+    unsigned* prefix = sums + g.w;                               // w + 1
+    unsigned* rowcnt = prefix + g.w + 1;                         // 2 * wh
+    unsigned* rowoff = rowcnt + 2 * g.wh;                        // 2 * (wh + 1)
+    long long* s_mom = reinterpret_cast<long long*>(smem + (((size_t)(2 * g.w + 1 + 4 * g.wh + 2) * 4 + 15) & ~(size_t)15));
+
+    const int frame = blockIdx.x;
+    const uint8_t* mask = masks + (size_t)frame * mask_stride;
+    uint32_t* pix = pix_all + (size_t)frame * 2 * g.maxpix;
+    int32_t* cent = cent_all + (size_t)frame * 2 * (g.maxlev + 2);   // [side][0] = count, then entries
+    const int W = g.w, ww = g.ww, wh = g.wh, hw = g.hw, H1 = g.img_height;
+    const int y0c = g.h / 2, x0c = g.w / 2;
+
+    Moments mom[2];
+    mom[0].clear();
+    mom[1].clear();
+    int n_out[2] = {0, 0}, distinct[2] = {0, 0};
+    // per-side search state, identical in every thread  (lane_tracker.py:335-343)
+    int c[2], ns[2] = {0, 0}, lo[2], hi[2], ndiff[2] = {0, 0}, last_diff[2] = {0, 0}, ncent[2] = {0, 0},
+        nroi[2] = {0, 0};
+    Roi roi[2];
+
+    // ---- level 0 (:290-332)
+    for (int s = 0; s < 2; ++s) {
+        const int c0 = s == 0 ? g.ignore_sides : g.img_center;
+        const int c1 = s == 0 ? g.img_center : W - g.ignore_sides;
+        const int off = c0;
+        bool found = false;
+        int first = 0, last = 0;
+        if (c1 > c0 && H1 > g.y_start) {
+            column_sums(mask, W, max(g.y_start, 0), H1, c0, c1, sums);
+            wave0_exclusive_scan(sums, prefix, c1 - c0);
+            __syncthreads();
+            found = box_argmax(prefix, c1 - c0, ww, 0, (c1 - c0) + ww - 1, first, last);
+            __syncthreads();
+        }
+        roi[s].active = 0;
+        if (found) {
+            c[s] = ((first + last) >> 1) - hw + off;                 // :296-297 / :316-317
+            const int a = c[s] - hw, b = min(c[s] + hw, W);
+            roi[s].active = 1;
+            roi[s].a = a < 0 ? b : a;                                // negative start: NumPy slice is empty
+            roi[s].b = b;
+            nroi[s]++;
+        } else {
+            c[s] = s == 0 ? g.def_left : g.def_right;                // :308 / :328
+        }
+        if (threadIdx.x == 0) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = c[s];
+        ncent[s]++;
+        lo[s] = -g.search_range;
+        hi[s] = g.search_range;
+    }
+    if (H1 - wh >= 0)
+        extract_windows(mask, W, H1 - wh, H1, roi, rowcnt, rowoff, wh, pix, g.maxpix, n_out, mom, distinct, y0c, x0c);
+
+    // ---- levels 1 .. nlevels-1 (:346-430)
+    for (int level = 1; level < g.nlevels; ++level) {
+        const int r0 = H1 - (1 + level) * wh, r1 = H1 - level * wh;
+        column_sums(mask, W, r0, r1, 0, W, sums);                    // :350
+        wave0_exclusive_scan(sums, prefix, W);
+        __syncthreads();
+        const int conv_len = W + ww - 1;                             // :351
+        for (int s = 0; s < 2; ++s) {                                // left first, then right (:354, :395)
+            roi[s].active = 0;
+            if (ns[s] >= g.limit) continue;
+            const int lo_i = max(c[s] + lo[s] + hw, 0);              // :356
+            const int hi_i = min(c[s] + hi[s] + hw, W);              // :357
+            const int a = min(lo_i, conv_len);                       // conv[lo_i:hi_i], Python slice rules
+            const int b = hi_i < 0 ? max(conv_len + hi_i, 0) : min(hi_i, conv_len);
+            int first = 0, last = 0;
+            const bool found = b > a && box_argmax(prefix, W, ww, a, b, first, last);   // :360
+            if (found) {
+                const int newc = ((first + last + 1) >> 1) + lo_i - hw;   // ceil, :363-364
+                if (threadIdx.x == 0 && ncent[s] < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = newc;
+                ncent[s]++;
+                last_diff[s] = newc - c[s];                          // :366
+                ndiff[s]++;
+                c[s] = newc;
+                ns[s] = 0;                                           // :368
+                const int ra = c[s] - hw, rb = min(c[s] + hw, W);
+                roi[s].active = 1;
+                roi[s].a = ra < 0 ? rb : ra;
+                roi[s].b = rb;
+                nroi[s]++;
+                const int t = (int)(g.mu * (double)last_diff[s]);    // :380-381, truncation toward zero
+                lo[s] += t;
+                hi[s] += t;
+            } else {
+                const int o = 1 - s;
+                if (ndiff[o] > 0 && ns[o] == 0) c[s] += last_diff[o]; // :385-387 / :423-425
+                if (threadIdx.x == 0 && ncent[s] < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = c[s];
+                ncent[s]++;
+                ns[s]++;                                             // :390
+                if (ns[s] >= g.limit) ncent[s] -= min(g.limit > 0 ? g.limit : ncent[s], ncent[s]);   // :391-392
+            }
+        }
+        __syncthreads();
+        if (roi[0].active || roi[1].active)
+            extract_windows(mask, W, r0, r1, roi, rowcnt, rowoff, wh, pix, g.maxpix, n_out, mom, distinct, y0c, x0c);
+    }
+    if (threadIdx.x == 0) {
+        cent[0] = ncent[0];
+        cent[g.maxlev + 2] = ncent[1];
+    }
+    const bool detected = nroi[0] > 0 && nroi[1] > 0 && n_out[0] > 0 && n_out[1] > 0;   // :432-447
+    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, n_out[0], n_out[1], detected, 0, recs + frame);
+}
+
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+                                                const double* __restrict__ prev, uint32_t* __restrict__ pix_all,
+                                                lt_lane_record* __restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* rowcnt = reinterpret_cast<unsigned*>(smem);        // 2 * h
+    unsigned* rowoff = rowcnt + 2 * g.h;                         // 2 * (h + 1)
+    long long* s_mom = reinterpret_cast<long long*>(smem + (((size_t)(4 * g.h + 2 + 4) * 4 + 15) & ~(size_t)15));
+    const int frame = blockIdx.x, lane = lane_id(), wv = wave_id();
+    const uint8_t* mask = masks + (size_t)frame * mask_stride;
+    uint32_t* pix = pix_all + (size_t)frame * 2 * g.maxpix;
+    const double* pc = prev + (size_t)frame * 6;
+    const int W = g.w, top = g.band_top, bottom = g.band_bottom, nrows = max(bottom - top, 0);
+    const int y0c = g.h / 2, x0c = g.w / 2;
+    const double bw = g.bandwidth;
+
+    // pass 1: per-row counts for both lanes.  The predicate is the reference's f64 expression
+    // ((a*y^2 + b*y) + c) -/+ bw with strict comparisons (:474-489); no FMA contraction.
+    for (int ry = wv; ry < nrows; ry += NW) {
+        const int y = top + ry;
+        const double y2 = (double)((long long)y * y), yd = (double)y;
+        for (int s = 0; s < 2; ++s) {
+            const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];
+            const double lo = t - bw, hi = t + bw;
+            // integer columns that can satisfy lo < x < hi, clipped to the image (NaN-safe)
+            int xa = 0, xb = -1;
+            if (lo < hi && hi > 0.0 && lo < (double)(W - 1)) {
+                xa = lo < 0.0 ? 0 : (int)floor(lo);
+                xb = hi > (double)(W - 1) ? W - 1 : (int)ceil(hi);
+            }
+            unsigned c = 0;
+            for (int x = xa + lane; x - lane <= xb; x += 64) {
+                const bool in = x <= xb && (double)x > lo && (double)x < hi && mask[(size_t)y * W + x] != 0;
+                c += __popcll(__ballot(in));
+            }
+            if (lane == 0) rowcnt[s * g.h + ry] = c;
+        }
+    }
+    __syncthreads();
+    if (wv < 2) {
+        // exclusive scan over rows: wave 0 -> left, wave 1 -> right
+        const int s = wv, chunk = (nrows + 63) / 64;
+        const int a = min(lane * chunk, nrows), b = min(a + chunk, nrows);
+        unsigned sum = 0;
+        for (int i = a; i < b; ++i) sum += rowcnt[s * g.h + i];
+        unsigned incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = (unsigned)__shfl_up((int)incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        unsigned run = incl - sum;
+        for (int i = a; i < b; ++i) {
+            const unsigned v = rowcnt[s * g.h + i];
+            rowoff[s * (g.h + 1) + i] = run;
+            run += v;
+        }
+        if (lane == 63) rowoff[s * (g.h + 1) + nrows] = incl;
+    }
+    __syncthreads();
+    Moments mom[2];
+    mom[0].clear();
+    mom[1].clear();
+    // pass 2: ordered write (row-major, like nonzero())
+    for (int ry = wv; ry < nrows; ry += NW) {
+        const int y = top + ry;
+        const double y2 = (double)((long long)y * y), yd = (double)y;
+        for (int s = 0; s < 2; ++s) {
+            const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];
+            const double lo = t - bw, hi = t + bw;
+            int xa = 0, xb = -1;
+            if (lo < hi && hi > 0.0 && lo < (double)(W - 1)) {
+                xa = lo < 0.0 ? 0 : (int)floor(lo);
+                xb = hi > (double)(W - 1) ? W - 1 : (int)ceil(hi);
+            }
+            unsigned run = rowoff[s * (g.h + 1) + ry];
+            for (int x = xa + lane; x - lane <= xb; x += 64) {
+                const bool in = x <= xb && (double)x > lo && (double)x < hi && mask[(size_t)y * W + x] != 0;
+                const unsigned long long bal = __ballot(in);
+                if (in) {
+                    const unsigned idx = run + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (idx < (unsigned)g.maxpix) pix[(size_t)s * g.maxpix + idx] = ((uint32_t)y << 16) | (uint32_t)x;
+                    mom[s].add(y, x, y0c, x0c);
+                }
+                run += __popcll(bal);
+            }
+        }
+    }
+    int distinct[2] = {0, 0};
+    for (int s = 0; s < 2; ++s) {
+        int d = 0;
+        for (int i = threadIdx.x; i < nrows; i += NT) d += rowcnt[s * g.h + i] != 0;
+        // cheap block reduction through the (now free) moments scratch is overkill: use ballots
+        int tot = (int)wave_sum_i64(d);
+        // combine the 4 waves through LDS
+        __syncthreads();
+        if (lane == 0) rowoff[2 * (g.h + 1) + wv] = (unsigned)tot;   // 4 spare words reserved by the launcher
+        __syncthreads();
+        distinct[s] = (int)(rowoff[2 * (g.h + 1)] + rowoff[2 * (g.h + 1) + 1] + rowoff[2 * (g.h + 1) + 2] + rowoff[2 * (g.h + 1) + 3]);
+    }
+    const int nl = (int)rowoff[nrows], nr = (int)rowoff[(g.h + 1) + nrows];
+    const bool detected = nl != 0 && nr != 0;                        // :491
+    __syncthreads();
+    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, nl, nr, detected, 1, recs + frame);
+}
+
+// fit_poly() on an explicit pixel list: moments by all threads, one Cholesky solve
+__global__ __launch_bounds__(NT) void k_fit_list(const uint32_t* __restrict__ pix, int n, int h, int w,
+                                                double* __restrict__ out4) {
+    __shared__ long long s_mom[8];
+    __shared__ int s_ymin, s_ymax, s_mid;
+    if (threadIdx.x < 8) s_mom[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_ymin = 0x7fffffff; s_ymax = -1; s_mid = 0; }
+    __syncthreads();
+    Moments m;
+    m.clear();
+    int ymin = 0x7fffffff, ymax = -1;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const uint32_t p = pix[i];
+        const int y = (int)(p >> 16), x = (int)(p & 0xffffu);
+        m.add(y, x, h / 2, w / 2);
+        ymin = min(ymin, y);
+        ymax = max(ymax, y);
+    }
+    ymin = wave_min_i32(ymin);
+    ymax = wave_max_i32(ymax);
+    if (lane_id() == 0) { atomicMin(&s_ymin, ymin); atomicMax(&s_ymax, ymax); }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const long long v = wave_sum_i64(m.m[k]);
+        if (lane_id() == 0 && v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&s_mom[k]), (unsigned long long)v);
+    }
+    __syncthreads();
+    // a third distinct y exists iff some y is strictly between the extremes
+    int mid = 0;
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const int y = (int)(pix[i] >> 16);
+        mid |= (y != s_ymin && y != s_ymax);
+    }
+    if (mid) atomicOr(&s_mid, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int distinct = n <= 0 ? 0 : (s_ymin == s_ymax ? 1 : (s_mid ? 3 : 2));
+        double c[3];
+        const bool ok = solve_poly2(s_mom, distinct, (double)(h / 2), (double)(w / 2), (double)(h > 1 ? h : 2) * 0.5, c);
+        out4[0] = c[0]; out4[1] = c[1]; out4[2] = c[2];
+        out4[3] = ok ? 0.0 : 1.0;
+    }
+}
+
+}  // namespace
+
+void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, double* out4) {
+    hipLaunchKernelGGL(k_fit_list, dim3(1), dim3(NT), 0, s, pix, n, h, w, out4);
+}
+
+void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* pix,
+                    int32_t* cent, lt_lane_record* rec, int n) {
+    if (n <= 0) return;
+    const size_t words = (size_t)(2 * g.w + 1 + 4 * g.wh + 2);
+    const size_t lds = ((words * 4 + 15) & ~(size_t)15) + 16 * sizeof(long long);
+    hipLaunchKernelGGL(k_sws_fit, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, pix, cent, rec);
+}
+
+void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
+                     uint32_t* pix, lt_lane_record* rec, int n) {
+    if (n <= 0) return;
+    const size_t words = (size_t)(4 * g.h + 2) + 4;  // + 4 words for the distinct-row reduction
+    const size_t lds = ((words * 4 + 15) & ~(size_t)15) + 16 * sizeof(long long);
+    hipLaunchKernelGGL(k_band_fit, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);
+}
+
+}  // namespace lt

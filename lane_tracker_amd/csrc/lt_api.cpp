@@ -1,0 +1,811 @@
+// C-ABI layer of liblane_tracker_amd.so (see include/lane_tracker_amd.h).
+// Owns the context: HIP stream, calibration tables, frame slots; sequences the kernel chain of
+// LaneTracker.find_lane_points() (lane_tracker.py:795-874) for a batch of independent frames.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lt_internal.h"
+
+using namespace lt;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(LT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+enum Stage {
+    ST_UNDISTORT = 0, ST_WARP_SPLIT, ST_ERODE_R, ST_TOPHAT_R, ST_ERODE_B, ST_TOPHAT_B, ST_THRESHOLD, ST_MERGE,
+    ST_OPEN, ST_SWS_FIT, ST_BAND_FIT, ST_SPLIT_BEV
+};
+const char* kStageNames[LT_NUM_STAGES] = {"undistort_rows", "warp_split", "erode_r29", "tophat_r29", "erode_b55",
+                                          "tophat_b55", "threshold", "merge", "open5", "sws_fit", "band_fit",
+                                          "split_bev"};
+
+enum Plane { P_R = 0, P_B, P_THR, P_THB, P_MERGED, P_MASK, P_T0, P_T1, P_T2, P_T3, P_COUNT };
+
+}  // namespace
+
+struct lt_ctx {
+    lt_calib calib{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    FrontEndGeom fe{};
+    EllipseSE se5{}, se29{}, se55{};
+    // device tables
+    int16_t *d_uxy = nullptr, *d_wxy = nullptr;
+    uint16_t *d_ufrac = nullptr, *d_wfrac = nullptr, *d_gamma = nullptr, *d_cbrt = nullptr;
+    int32_t* d_coef = nullptr;
+    // slots
+    int capacity = 0;
+    size_t frame_bytes = 0, und_bytes = 0, plane_bytes = 0, bev_bytes = 0;
+    uint8_t *d_frames = nullptr, *d_und = nullptr, *d_bev = nullptr;
+    uint8_t* d_plane[P_COUNT] = {};
+    lt_lane_record* d_rec = nullptr;
+    double* d_prev = nullptr;
+    uint32_t* d_pix = nullptr;
+    int32_t* d_cent = nullptr;
+    int maxpix = 0, maxlev = 0;
+    bool have_mask = false;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool stage_timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    struct Pending { int stage; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    size_t ev_used = 0;
+    float stage_ms[LT_NUM_STAGES] = {};
+    int32_t stage_launches[LT_NUM_STAGES] = {};
+};
+
+namespace {
+
+template <class T>
+int dev_alloc(T** p, size_t count) {
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+    if (e != hipSuccess) return fail(LT_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    return LT_OK;
+}
+template <class T>
+void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+int flush_stage_events(lt_ctx* c) {
+    if (c->pending.empty()) return LT_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
+        c->stage_ms[p.stage] += ms;
+        c->stage_launches[p.stage] += 1;
+    }
+    c->pending.clear();
+    c->ev_used = 0;
+    return LT_OK;
+}
+
+// RAII-free helper pair: bracket one kernel launch with events when stage timing is on
+struct StageScope {
+    lt_ctx* c;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(lt_ctx* c_, int stage_) : c(c_), stage(stage_) {
+        if (!c->stage_timing) return;
+        if (c->ev_used + 2 > c->ev_pool.size()) {
+            if (flush_stage_events(c) != LT_OK) return;
+            while (c->ev_pool.size() < 256) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) break;
+                c->ev_pool.push_back(e);
+            }
+        }
+        if (c->ev_used + 2 > c->ev_pool.size()) return;
+        a = c->ev_pool[c->ev_used++];
+        b = c->ev_pool[c->ev_used++];
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~StageScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({stage, a, b});
+    }
+};
+
+int check_slots(lt_ctx* c, int first, int n) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (first < 0 || n < 0 || first + n > c->capacity)
+        return fail(LT_ERR_CAPACITY, "slots [%d, %d) outside reserved capacity %d", first, first + n, c->capacity);
+    return LT_OK;
+}
+
+int set_device(lt_ctx* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return LT_OK;
+}
+
+void free_slots(lt_ctx* c) {
+    dev_free(c->d_frames);
+    dev_free(c->d_und);
+    dev_free(c->d_bev);
+    for (auto& p : c->d_plane) dev_free(p);
+    dev_free(c->d_rec);
+    dev_free(c->d_prev);
+    dev_free(c->d_pix);
+    dev_free(c->d_cent);
+    c->capacity = 0;
+    c->maxpix = 0;
+    c->maxlev = 0;
+    c->have_mask = false;
+}
+
+int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev) {
+    if (maxpix > c->maxpix) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dev_free(c->d_pix);
+        int rc = dev_alloc(&c->d_pix, (size_t)c->capacity * 2 * maxpix);
+        if (rc) return rc;
+        c->maxpix = maxpix;
+    }
+    if (maxlev > c->maxlev) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dev_free(c->d_cent);
+        int rc = dev_alloc(&c->d_cent, (size_t)c->capacity * 2 * (maxlev + 2));
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_cent, 0, (size_t)c->capacity * 2 * (maxlev + 2) * sizeof(int32_t), c->stream));
+        c->maxlev = maxlev;
+    }
+    return LT_OK;
+}
+
+int ensure_bev(lt_ctx* c) {
+    if (c->d_bev) return LT_OK;
+    return dev_alloc(&c->d_bev, (size_t)c->capacity * c->bev_bytes);
+}
+
+int validate_filter(const lt_filter_params* p) {
+    if (!p) return fail(LT_ERR_INVALID, "null filter params");
+    if (p->filter_type != 0 && p->filter_type != 1)
+        return fail(LT_ERR_INVALID, "Unexpected filter mode. Expected modes are 'bilateral' or 'neighborhood'.");
+    if (p->ksize_r < 1 || p->ksize_b < 1 || (p->mask_noise && p->ksize_noise < 1))
+        return fail(LT_ERR_INVALID, "filter sizes must be >= 1");
+    if (p->filter_type == 1 && ((p->ksize_r & 1) == 0 || (p->ksize_b & 1) == 0))
+        return fail(LT_ERR_INVALID, "'neighborhood' block sizes must be odd (cv2.adaptiveThreshold requirement)");
+    if (p->ksize_r > 400 || p->ksize_b > 400 || p->ksize_noise > 400)
+        return fail(LT_ERR_INVALID, "filter size too large (max 400)");
+    return LT_OK;
+}
+
+// filter_lane_points() on planes P_R / P_B of the given slots (lane_tracker.py:210-238)
+int run_filter_chain(lt_ctx* c, int first, int n, const lt_filter_params* p, int h, int w) {
+    const size_t ps = c->plane_bytes, off = (size_t)first * ps;
+    uint8_t* R = c->d_plane[P_R] + off;
+    uint8_t* B = c->d_plane[P_B] + off;
+    uint8_t* thR = c->d_plane[P_THR] + off;
+    uint8_t* thB = c->d_plane[P_THB] + off;
+    uint8_t* t0 = c->d_plane[P_T0] + off;
+    uint8_t* t1 = c->d_plane[P_T1] + off;
+    uint8_t* t2 = c->d_plane[P_T2] + off;
+    uint8_t* t3 = c->d_plane[P_T3] + off;
+    uint8_t* merged = c->d_plane[P_MERGED] + off;
+    uint8_t* mask = c->d_plane[P_MASK] + off;
+    hipStream_t s = c->stream;
+    if (p->filter_type == 0) {
+        { StageScope t(c, ST_ERODE_R);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
+        { StageScope t(c, ST_TOPHAT_R); launch_morph_ellipse(s, t0, thR, R, h, w, c->se29, true, ps, n); }
+        { StageScope t(c, ST_ERODE_B);  launch_morph_ellipse(s, B, t0, nullptr, h, w, c->se55, false, ps, n); }
+        { StageScope t(c, ST_TOPHAT_B); launch_morph_ellipse(s, t0, thB, B, h, w, c->se55, true, ps, n); }
+        { StageScope t(c, ST_THRESHOLD);
+          launch_bilateral(s, thR, t1, h, w, p->ksize_r, p->C_r, 0, 255, 0, ps, n);
+          launch_bilateral(s, thB, t2, h, w, p->ksize_b, p->C_b, 0, 255, 0, ps, n); }
+    } else {
+        StageScope t(c, ST_THRESHOLD);
+        launch_adaptive_mean(s, R, t1, h, w, p->ksize_r, p->C_r, ps, n);
+        launch_adaptive_mean(s, B, t2, h, w, p->ksize_b, p->C_b, ps, n);
+    }
+    if (p->mask_noise) {
+        StageScope t(c, ST_THRESHOLD);
+        launch_bilateral(s, B, t3, h, w, p->ksize_noise, p->C_noise, 0, 255, 0, ps, n);
+    }
+    { StageScope t(c, ST_MERGE);
+      launch_merge(s, t1, t2, B, t3, p->noise_thresh, p->mask_noise ? 1 : 0, merged, (size_t)h * w, ps, n); }
+    { StageScope t(c, ST_OPEN);
+      launch_morph_ellipse(s, merged, t0, nullptr, h, w, c->se5, false, ps, n);
+      launch_morph_ellipse(s, t0, mask, nullptr, h, w, c->se5, true, ps, n); }
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+int make_search_geom(lt_ctx* c, const lt_search_params* p, bool band, SearchGeom& g) {
+    if (!p) return fail(LT_ERR_INVALID, "null search params");
+    const int h = c->calib.warp_h, w = c->calib.warp_w;
+    std::memset(&g, 0, sizeof g);
+    g.h = h;
+    g.w = w;
+    if (p->ignore_bottom < 0 || p->ignore_bottom > h) return fail(LT_ERR_INVALID, "ignore_bottom out of range");
+    if (!(p->partial >= 0.0 && p->partial <= 1.0)) return fail(LT_ERR_INVALID, "partial must be in [0,1]");
+    g.img_height = h - p->ignore_bottom;                                      // lane_tracker.py:277
+    if (band) {
+        if (p->bandwidth < 0) return fail(LT_ERR_INVALID, "bandwidth must be >= 0");
+        g.bandwidth = (double)p->bandwidth;
+        g.band_bottom = h - p->ignore_bottom;                                 // :465
+        g.band_top = (int)((double)h * (1.0 - p->partial));                   // :466 (2017 NumPy: int())
+        if (g.band_top < 0) g.band_top = 0;
+        const long long per_row = std::min<long long>(w, 2LL * p->bandwidth + 2);
+        long long need = (long long)std::max(g.band_bottom - g.band_top, 0) * per_row;
+        g.maxpix = (int)std::min<long long>(std::max<long long>(need, 64), (long long)h * w);
+        g.maxlev = 1;
+        return LT_OK;
+    }
+    if (p->window_width < 1 || p->window_height < 1) return fail(LT_ERR_INVALID, "window size must be >= 1");
+    if (p->window_height > h) return fail(LT_ERR_INVALID, "window_height exceeds the image height");
+    if (p->ignore_sides < 0 || p->search_range < 0) return fail(LT_ERR_INVALID, "negative margin/range");
+    g.ww = p->window_width;
+    g.wh = p->window_height;
+    g.hw = (int)(p->window_width / 2.0);                                      // int(window_width/2)
+    g.img_center = (int)(w / 2.0);                                            // :278
+    g.y_start = (int)((1.0 - p->start_slice) * g.img_height);                 // :279
+    g.nlevels = (int)((p->partial * g.img_height) / p->window_height);        // :282
+    if (g.nlevels < 0) g.nlevels = 0;
+    g.limit = p->no_success_limit;
+    g.ignore_sides = p->ignore_sides;
+    g.search_range = p->search_range;
+    g.def_left = (int)(w * 0.4);                                              // :308
+    g.def_right = (int)(w * 0.6);                                             // :328
+    g.mu = p->mu;
+    const long long need = (long long)std::max(g.nlevels, 1) * g.wh * std::min(2 * g.hw, w);
+    g.maxpix = (int)std::max<long long>(need, 64);
+    g.maxlev = std::max(g.nlevels, 1) + 1;
+    return LT_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* lt_last_error(void) { return g_err.c_str(); }
+int lt_abi_version(void) { return LT_ABI_VERSION; }
+
+int lt_device_count(int* count) {
+    if (!count) return fail(LT_ERR_INVALID, "null count");
+    HIP_TRY(hipGetDeviceCount(count));
+    return LT_OK;
+}
+
+const char* lt_stage_name(int stage) { return stage >= 0 && stage < LT_NUM_STAGES ? kStageNames[stage] : ""; }
+
+int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
+    if (!calib || !out) return fail(LT_ERR_INVALID, "null argument");
+    if (calib->img_w < 2 || calib->img_h < 2 || calib->warp_w < 2 || calib->warp_h < 2 || calib->img_w > 16384 ||
+        calib->img_h > 16384 || calib->warp_w > 16384 || calib->warp_h > 16384)
+        return fail(LT_ERR_INVALID, "image sizes must be in [2, 16384]");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(LT_ERR_HIP, "no HIP device visible: the lane-tracker kernels need a GPU (gfx950)");
+    if (device < 0 || device >= ndev) return fail(LT_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    lt_ctx* c = new lt_ctx();
+    c->calib = *calib;
+    c->device = device;
+    auto bail = [&](int rc) {
+        lt_destroy(c);
+        return rc;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipSetDevice(%d) failed", device));
+    if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipGetDeviceProperties failed"));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipStreamCreate failed"));
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipEventCreate failed"));
+
+    // host tables
+    RemapTable warp, und;
+    build_warp_table(*calib, warp);
+    int r0 = 0, r1 = 0;
+    warp_source_rows(*calib, warp, r0, r1);
+    build_undistort_table(*calib, r0, r1, und);
+    c->fe = FrontEndGeom{calib->img_h, calib->img_w, calib->warp_h, calib->warp_w, r0, r1 - r0};
+    uint16_t gamma_tab[256], cbrt_tab[3072];
+    int32_t coef[9];
+    build_lab_tables(gamma_tab, cbrt_tab, coef);
+    auto make_se = [](int k, EllipseSE& se) {
+        int dx[64];
+        ellipse_halfwidths(k, dx);
+        se.k = k;
+        for (int i = 0; i < 64; ++i) se.dx[i] = (int8_t)(i < k ? dx[i] : 0);
+    };
+    make_se(5, c->se5);
+    make_se(29, c->se29);
+    make_se(55, c->se55);
+
+    int rc;
+    if ((rc = dev_alloc(&c->d_wxy, warp.xy.size()))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_wfrac, warp.frac.size()))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_uxy, und.xy.size()))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_ufrac, und.frac.size()))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_gamma, 256))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_cbrt, 3072))) return bail(rc);
+    if ((rc = dev_alloc(&c->d_coef, 9))) return bail(rc);
+    hipError_t e = hipSuccess;
+    auto up = [&](void* dst, const void* src, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    up(c->d_wxy, warp.xy.data(), warp.xy.size() * 2);
+    up(c->d_wfrac, warp.frac.data(), warp.frac.size() * 2);
+    up(c->d_uxy, und.xy.data(), und.xy.size() * 2);
+    up(c->d_ufrac, und.frac.data(), und.frac.size() * 2);
+    up(c->d_gamma, gamma_tab, sizeof gamma_tab);
+    up(c->d_cbrt, cbrt_tab, sizeof cbrt_tab);
+    up(c->d_coef, coef, sizeof coef);
+    if (e != hipSuccess) return bail(fail(LT_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
+
+    c->frame_bytes = (size_t)calib->img_h * calib->img_w * 3;
+    c->und_bytes = (size_t)c->fe.nrows * calib->img_w * 3;
+    c->plane_bytes = (size_t)calib->warp_h * calib->warp_w;
+    c->bev_bytes = c->plane_bytes * 3;
+    *out = c;
+    return LT_OK;
+}
+
+void lt_destroy(lt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_slots(c);
+    dev_free(c->d_uxy);
+    dev_free(c->d_wxy);
+    dev_free(c->d_ufrac);
+    dev_free(c->d_wfrac);
+    dev_free(c->d_gamma);
+    dev_free(c->d_cbrt);
+    dev_free(c->d_coef);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int lt_reserve(lt_ctx* c, int capacity) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (capacity < 1) return fail(LT_ERR_INVALID, "capacity must be >= 1");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (capacity <= c->capacity) return LT_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_slots(c);
+    c->capacity = capacity;
+    const size_t n = (size_t)capacity;
+    if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_und, n * c->und_bytes))) { free_slots(c); return rc; }
+    for (int i = 0; i < P_COUNT; ++i)
+        if ((rc = dev_alloc(&c->d_plane[i], n * c->plane_bytes))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_prev, n * 6))) { free_slots(c); return rc; }
+    c->capacity = capacity;
+    HIP_TRY(hipMemsetAsync(c->d_rec, 0, n * sizeof(lt_lane_record), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_plane[P_MASK], 0, n * c->plane_bytes, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_get_info(lt_ctx* c, lt_info* out) {
+    if (!c || !out) return fail(LT_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->abi_version = LT_ABI_VERSION;
+    out->device = c->device;
+    out->capacity = c->capacity;
+    out->cu_count = c->prop.multiProcessorCount;
+    out->src_row0 = c->fe.r0;
+    out->src_row1 = c->fe.r0 + c->fe.nrows;
+    out->max_pixels_per_side = c->maxpix;
+    out->max_levels = c->maxlev;
+    // compulsory input rows (full width, 3 B/px) + the mask written once
+    out->alg_bytes_mask = (int64_t)c->fe.nrows * c->calib.img_w * 3 + (int64_t)c->plane_bytes;
+    out->alg_bytes_search = (int64_t)c->plane_bytes + (int64_t)sizeof(lt_lane_record);
+    std::snprintf(out->device_name, sizeof out->device_name, "%s", c->prop.name);
+    return LT_OK;
+}
+
+int lt_sync(lt_ctx* c) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+// ---- data movement -------------------------------------------------------------------------------
+int lt_upload_frames(lt_ctx* c, const uint8_t* frames, int first, int n) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!frames) return fail(LT_ERR_INVALID, "null frames");
+    if ((rc = set_device(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_frames + (size_t)first * c->frame_bytes, frames, (size_t)n * c->frame_bytes,
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_upload_masks(lt_ctx* c, const uint8_t* masks, int first, int n) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!masks) return fail(LT_ERR_INVALID, "null masks");
+    if ((rc = set_device(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, masks, (size_t)n * c->plane_bytes,
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->have_mask = true;
+    return LT_OK;
+}
+
+int lt_upload_bev(lt_ctx* c, const uint8_t* bev, int first, int n) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!bev) return fail(LT_ERR_INVALID, "null image");
+    if ((rc = set_device(c))) return rc;
+    if ((rc = ensure_bev(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_bev + (size_t)first * c->bev_bytes, bev, (size_t)n * c->bev_bytes,
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+static int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
+    if (!dst) return fail(LT_ERR_INVALID, "null output buffer");
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_download_masks(lt_ctx* c, int first, int n, uint8_t* masks) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    return download(c, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, masks, (size_t)n * c->plane_bytes);
+}
+
+int lt_download_plane(lt_ctx* c, int plane, int first, int n, uint8_t* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    static const int map[6] = {P_R, P_B, P_THR, P_THB, P_MERGED, P_MASK};
+    if (plane < 0 || plane > 5) return fail(LT_ERR_INVALID, "unknown plane %d", plane);
+    return download(c, c->d_plane[map[plane]] + (size_t)first * c->plane_bytes, out, (size_t)n * c->plane_bytes);
+}
+
+int lt_download_undistorted(lt_ctx* c, int first, int n, uint8_t* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (n == 0 || c->und_bytes == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    uint8_t* tmp = nullptr;
+    if ((rc = dev_alloc(&tmp, (size_t)n * c->und_bytes))) return rc;
+    launch_undistorted_to_rgb(c->stream, c->d_und + (size_t)first * c->und_bytes, c->und_bytes, c->fe.nrows,
+                              c->fe.img_w, tmp, n);
+    rc = download(c, tmp, out, (size_t)n * c->und_bytes);
+    dev_free(tmp);
+    return rc;
+}
+
+int lt_download_records(lt_ctx* c, int first, int n, lt_lane_record* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    return download(c, c->d_rec + first, out, (size_t)n * sizeof(lt_lane_record));
+}
+
+int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, int cap, int* count) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (side < 0 || side > 1 || !count || cap < 0) return fail(LT_ERR_INVALID, "bad side/count/cap");
+    if (!c->d_pix) return fail(LT_ERR_STATE, "no search has run yet");
+    lt_lane_record r;
+    if ((rc = download(c, c->d_rec + slot, &r, sizeof r))) return rc;
+    int n = side == 0 ? r.n_left : r.n_right;
+    if (n > c->maxpix) n = c->maxpix;
+    *count = n;
+    if (n > cap) n = cap;
+    if (n <= 0) return LT_OK;
+    if (!ys || !xs) return fail(LT_ERR_INVALID, "null pixel buffers");
+    std::vector<uint32_t> tmp((size_t)n);
+    if ((rc = download(c, c->d_pix + ((size_t)slot * 2 + side) * c->maxpix, tmp.data(), (size_t)n * 4))) return rc;
+    for (int i = 0; i < n; ++i) {
+        ys[i] = (int32_t)(tmp[i] >> 16);
+        xs[i] = (int32_t)(tmp[i] & 0xffffu);
+    }
+    return LT_OK;
+}
+
+int lt_download_centroids(lt_ctx* c, int slot, int side, int32_t* out, int cap, int* count) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (side < 0 || side > 1 || !count || cap < 0) return fail(LT_ERR_INVALID, "bad side/count/cap");
+    if (!c->d_cent) return fail(LT_ERR_STATE, "no sliding-window search has run yet");
+    std::vector<int32_t> tmp((size_t)c->maxlev + 2);
+    if ((rc = download(c, c->d_cent + ((size_t)slot * 2 + side) * (c->maxlev + 2), tmp.data(), tmp.size() * 4))) return rc;
+    int n = tmp[0];
+    if (n < 0) n = 0;
+    if (n > c->maxlev + 1) n = c->maxlev + 1;
+    *count = n;
+    for (int i = 0; i < n && i < cap; ++i) out[i] = tmp[1 + i];
+    return LT_OK;
+}
+
+int lt_copy_records_to_device(lt_ctx* c, int first, int n, void* dst) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!dst) return fail(LT_ERR_INVALID, "null destination");
+    if ((rc = set_device(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, c->d_rec + first, (size_t)n * sizeof(lt_lane_record), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_set_frame_base(lt_ctx* c, int first, int n, int first_frame) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    std::vector<lt_lane_record> tmp((size_t)n);
+    if (n == 0) return LT_OK;
+    if ((rc = download(c, c->d_rec + first, tmp.data(), tmp.size() * sizeof(lt_lane_record)))) return rc;
+    for (int i = 0; i < n; ++i) tmp[i].frame = first_frame + i;
+    HIP_TRY(hipMemcpyAsync(c->d_rec + first, tmp.data(), tmp.size() * sizeof(lt_lane_record), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+// ---- compute ------------------------------------------------------------------------------------------
+int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if ((rc = validate_filter(p))) return rc;
+    if ((rc = set_device(c))) return rc;
+    if (n == 0) return LT_OK;
+    const size_t ps = c->plane_bytes;
+    { StageScope t(c, ST_UNDISTORT);
+      launch_undistort_rows(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->frame_bytes, c->d_uxy,
+                            c->d_ufrac, c->fe, c->d_und + (size_t)first * c->und_bytes, c->und_bytes, n); }
+    { StageScope t(c, ST_WARP_SPLIT);
+      launch_warp_split(c->stream, c->d_und + (size_t)first * c->und_bytes, c->und_bytes, c->d_wxy, c->d_wfrac, c->fe,
+                        c->d_gamma, c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)first * ps,
+                        c->d_plane[P_B] + (size_t)first * ps, ps, n); }
+    if ((rc = run_filter_chain(c, first, n, p, c->calib.warp_h, c->calib.warp_w))) return rc;
+    c->have_mask = true;
+    return LT_OK;
+}
+
+int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if ((rc = validate_filter(p))) return rc;
+    if ((rc = set_device(c))) return rc;
+    if (!c->d_bev) return fail(LT_ERR_STATE, "lt_upload_bev has not been called");
+    if (n == 0) return LT_OK;
+    const size_t ps = c->plane_bytes;
+    { StageScope t(c, ST_SPLIT_BEV);
+      launch_split_bev(c->stream, c->d_bev + (size_t)first * c->bev_bytes, c->bev_bytes, (int)ps, c->d_gamma, c->d_cbrt,
+                       c->d_coef, c->d_plane[P_R] + (size_t)first * ps, c->d_plane[P_B] + (size_t)first * ps, ps, n); }
+    if ((rc = run_filter_chain(c, first, n, p, c->calib.warp_h, c->calib.warp_w))) return rc;
+    c->have_mask = true;
+    return LT_OK;
+}
+
+int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    if (!c->have_mask) return fail(LT_ERR_STATE, "no mask in the slots: run lt_mask_run or lt_upload_masks first");
+    SearchGeom g;
+    if ((rc = make_search_geom(c, p, false, g))) return rc;
+    if ((rc = ensure_search_buffers(c, g.maxpix, g.maxlev))) return rc;
+    g.maxpix = c->maxpix;
+    g.maxlev = c->maxlev;
+    if (n == 0) return LT_OK;
+    { StageScope t(c, ST_SWS_FIT);
+      launch_sws_fit(c->stream, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, g,
+                     c->d_pix + (size_t)first * 2 * c->maxpix, c->d_cent + (size_t)first * 2 * (c->maxlev + 2),
+                     c->d_rec + first, n); }
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, const double* prev) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!prev) return fail(LT_ERR_INVALID, "band search needs the previous coefficients (last_left_coeffs/last_right_coeffs)");
+    if ((rc = set_device(c))) return rc;
+    if (!c->have_mask) return fail(LT_ERR_STATE, "no mask in the slots: run lt_mask_run or lt_upload_masks first");
+    SearchGeom g;
+    if ((rc = make_search_geom(c, p, true, g))) return rc;
+    if ((rc = ensure_search_buffers(c, g.maxpix, 1))) return rc;
+    g.maxpix = c->maxpix;
+    if (n == 0) return LT_OK;
+    HIP_TRY(hipMemcpyAsync(c->d_prev + (size_t)first * 6, prev, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // prev is caller memory: do not keep reading it after return
+    { StageScope t(c, ST_BAND_FIT);
+      launch_band_fit(c->stream, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, g,
+                      c->d_prev + (size_t)first * 6, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n); }
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+// ---- host-buffer wrappers --------------------------------------------------------------------------------
+int lt_mask_batch(lt_ctx* c, const uint8_t* frames, int n, const lt_filter_params* p, uint8_t* masks) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc;
+    if (n > c->capacity && (rc = lt_reserve(c, n))) return rc;
+    if ((rc = lt_upload_frames(c, frames, 0, n))) return rc;
+    if ((rc = lt_mask_run(c, 0, n, p))) return rc;
+    return lt_download_masks(c, 0, n, masks);
+}
+
+int lt_sws_fit_batch(lt_ctx* c, const uint8_t* masks, int n, const lt_search_params* p, lt_lane_record* out) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc;
+    if (n > c->capacity && (rc = lt_reserve(c, n))) return rc;
+    if (masks && (rc = lt_upload_masks(c, masks, 0, n))) return rc;
+    if ((rc = lt_sws_fit_run(c, 0, n, p))) return rc;
+    return lt_download_records(c, 0, n, out);
+}
+
+int lt_band_fit_batch(lt_ctx* c, const uint8_t* masks, int n, const lt_search_params* p, const double* prev,
+                      lt_lane_record* out) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc;
+    if (n > c->capacity && (rc = lt_reserve(c, n))) return rc;
+    if (masks && (rc = lt_upload_masks(c, masks, 0, n))) return rc;
+    if ((rc = lt_band_fit_run(c, 0, n, p, prev))) return rc;
+    return lt_download_records(c, 0, n, out);
+}
+
+// ---- single-image operators ------------------------------------------------------------------------------
+int lt_bilateral_adaptive_threshold(lt_ctx* c, const uint8_t* img, int h, int w, int ksize, int C, int mode, int tv,
+                                    int fv, uint8_t* out) {
+    if (!c || !img || !out) return fail(LT_ERR_INVALID, "null argument");
+    if (mode != 0 && mode != 1) return fail(LT_ERR_INVALID, "Unexpected mode value. Expected value is 'floor' or 'ceil'.");
+    if (h < 1 || w < 1 || ksize < 1 || ksize > 400) return fail(LT_ERR_INVALID, "bad image size or ksize");
+    if (tv < 0 || tv > 255 || fv < 0 || fv > 255) return fail(LT_ERR_INVALID, "true/false values must be in [0,255]");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t n = (size_t)h * w;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    if ((rc = dev_alloc(&d_in, n))) return rc;
+    if ((rc = dev_alloc(&d_out, n))) { dev_free(d_in); return rc; }
+    hipError_t e = hipMemcpyAsync(d_in, img, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_bilateral(c->stream, d_in, d_out, h, w, ksize, C, mode, tv, fv, n, 1);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_in);
+    dev_free(d_out);
+    if (e != hipSuccess) return fail(LT_ERR_HIP, "bilateral threshold failed: %s", hipGetErrorString(e));
+    return LT_OK;
+}
+
+int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_filter_params* p, uint8_t* mask) {
+    if (!c || !bev || !mask) return fail(LT_ERR_INVALID, "null argument");
+    int rc = validate_filter(p);
+    if (rc) return rc;
+    if (h < 1 || w < 1 || h > 16384 || w > 16384) return fail(LT_ERR_INVALID, "bad image size");
+    if ((rc = set_device(c))) return rc;
+    // a private one-slot arena of the requested size (the image may differ from the calibration's BEV size)
+    lt_ctx tmp;
+    tmp.device = c->device;
+    tmp.stream = c->stream;
+    tmp.se5 = c->se5; tmp.se29 = c->se29; tmp.se55 = c->se55;
+    tmp.plane_bytes = (size_t)h * w;
+    tmp.capacity = 1;
+    uint8_t* d_bev = nullptr;
+    auto cleanup = [&]() {
+        for (auto& q : tmp.d_plane) dev_free(q);
+        dev_free(d_bev);
+        tmp.stream = nullptr;
+    };
+    for (int i = 0; i < P_COUNT; ++i)
+        if ((rc = dev_alloc(&tmp.d_plane[i], tmp.plane_bytes))) { cleanup(); return rc; }
+    if ((rc = dev_alloc(&d_bev, tmp.plane_bytes * 3))) { cleanup(); return rc; }
+    hipError_t e = hipMemcpyAsync(d_bev, bev, tmp.plane_bytes * 3, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launch_split_bev(c->stream, d_bev, tmp.plane_bytes * 3, (int)tmp.plane_bytes, c->d_gamma, c->d_cbrt, c->d_coef,
+                         tmp.d_plane[P_R], tmp.d_plane[P_B], tmp.plane_bytes, 1);
+        rc = run_filter_chain(&tmp, 0, 1, p, h, w);
+        if (rc == LT_OK) e = hipMemcpyAsync(mask, tmp.d_plane[P_MASK], tmp.plane_bytes, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(LT_ERR_HIP, "filter_lane_points failed: %s", hipGetErrorString(e));
+    return LT_OK;
+}
+
+int lt_fit_poly2(lt_ctx* c, const int32_t* ys, const int32_t* xs, int n, int h, int w, double coef[3], int* rank_deficient) {
+    if (!c || !coef || !rank_deficient || n < 0 || (n > 0 && (!ys || !xs))) return fail(LT_ERR_INVALID, "bad argument");
+    if (h < 1 || w < 1) return fail(LT_ERR_INVALID, "bad image size");
+    int rc = set_device(c);
+    if (rc) return rc;
+    std::vector<uint32_t> packed((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (ys[i] < 0 || ys[i] > 65535 || xs[i] < 0 || xs[i] > 65535) return fail(LT_ERR_INVALID, "pixel coordinate outside [0, 65535]");
+        packed[i] = ((uint32_t)ys[i] << 16) | (uint32_t)xs[i];
+    }
+    uint32_t* d_pix = nullptr;
+    double* d_out = nullptr;
+    if ((rc = dev_alloc(&d_pix, (size_t)n))) return rc;
+    if ((rc = dev_alloc(&d_out, 4))) { dev_free(d_pix); return rc; }
+    double out[4] = {0, 0, 0, 1};
+    hipError_t e = n ? hipMemcpyAsync(d_pix, packed.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream) : hipSuccess;
+    if (e == hipSuccess) {
+        launch_fit_list(c->stream, d_pix, n, h, w, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof out, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_pix);
+    dev_free(d_out);
+    if (e != hipSuccess) return fail(LT_ERR_HIP, "fit_poly2 failed: %s", hipGetErrorString(e));
+    coef[0] = out[0]; coef[1] = out[1]; coef[2] = out[2];
+    *rank_deficient = out[3] != 0.0;
+    return LT_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------------
+int lt_timer_start(lt_ctx* c) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return LT_OK;
+}
+
+int lt_timer_stop(lt_ctx* c, float* ms) {
+    if (!c || !ms) return fail(LT_ERR_INVALID, "null argument");
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return LT_OK;
+}
+
+int lt_set_stage_timing(lt_ctx* c, int enabled) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc = flush_stage_events(c);
+    c->stage_timing = enabled != 0;
+    return rc;
+}
+
+int lt_stage_reset(lt_ctx* c) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc = flush_stage_events(c);
+    std::memset(c->stage_ms, 0, sizeof c->stage_ms);
+    std::memset(c->stage_launches, 0, sizeof c->stage_launches);
+    return rc;
+}
+
+int lt_stage_ms(lt_ctx* c, float* ms, int32_t* launches, int n) {
+    if (!c || !ms) return fail(LT_ERR_INVALID, "null argument");
+    int rc = flush_stage_events(c);
+    for (int i = 0; i < n && i < LT_NUM_STAGES; ++i) {
+        ms[i] = c->stage_ms[i];
+        if (launches) launches[i] = c->stage_launches[i];
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Internal declarations shared by the C-ABI layer (lt_api.cpp), the host table builders
+// (lt_tables.cpp) and the kernel launchers (*.hip).  Not installed; the public ABI is
+// include/lane_tracker_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/lane_tracker_amd.h"
+
+namespace lt {
+
+// ---- host tables (lt_tables.cpp) ----------------------------------------------------------------
+struct RemapTable {              // cv::remap fixed-point maps: integer tap + 5+5-bit fraction
+    std::vector<int16_t> xy;     // (sx, sy) interleaved
+    std::vector<uint16_t> frac;  // fy*32 + fx
+    int rows = 0, cols = 0;
+};
+void build_warp_table(const lt_calib& c, RemapTable& t);
+void warp_source_rows(const lt_calib& c, const RemapTable& warp, int& r0, int& r1);
+void build_undistort_table(const lt_calib& c, int r0, int r1, RemapTable& t);
+void build_lab_tables(uint16_t gamma_tab[256], uint16_t cbrt_tab[3072], int32_t coeffs[9]);
+int  ellipse_halfwidths(int k, int* dx);  // returns tap count
+
+struct EllipseSE {               // one horizontal run per row
+    int k;
+    int8_t dx[64];
+};
+
+// ---- kernel launchers ----------------------------------------------------------------------------
+struct FrontEndGeom {
+    int img_h, img_w, warp_h, warp_w, r0, nrows;
+};
+void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
+                           const uint16_t* ufrac, FrontEndGeom g, uint8_t* und, size_t und_stride, int n);
+void launch_warp_split(hipStream_t s, const uint8_t* und, size_t und_stride, const int16_t* wxy,
+                       const uint16_t* wfrac, FrontEndGeom g, const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
+                       const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB, size_t plane_stride, int n);
+void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int npix, const uint16_t* gamma_tab,
+                      const uint16_t* cbrt_tab, const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB,
+                      size_t plane_stride, int n);
+void launch_undistorted_to_rgb(hipStream_t s, const uint8_t* und, size_t und_stride, int nrows, int w, uint8_t* out,
+                               int n);
+
+// dst = erode/dilate(src) with the ellipse; if minuend != nullptr: dst = sat(minuend - result)
+void launch_morph_ellipse(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w,
+                          const EllipseSE& se, bool dilate, size_t plane_stride, int n);
+void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int ksize, int C, int mode,
+                      int tv, int fv, size_t plane_stride, int n);
+void launch_adaptive_mean(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int bs, int C,
+                          size_t plane_stride, int n);
+// merged = ((tr | tb) & (use_noise ? (!(labb >= thresh) | noise_bil) : 1)) ? 255 : 0
+void launch_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uint8_t* labb, const uint8_t* noise_bil,
+                  int noise_thresh, int use_noise, uint8_t* merged, size_t npix, size_t plane_stride, int n);
+
+struct SearchGeom {
+    int h, w;                    // mask size
+    int ww, wh, hw;              // window
+    int img_height;              // h - ignore_bottom
+    int img_center, y_start, nlevels, limit;
+    int ignore_sides, search_range, def_left, def_right;
+    int band_top, band_bottom;   // band search rows [top, bottom)
+    double mu, bandwidth;
+    int maxpix, maxlev;
+};
+void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* pix,
+                    int32_t* cent, lt_lane_record* rec, int n);
+void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
+                     uint32_t* pix, lt_lane_record* rec, int n);
+
+// fit of one explicit pixel list (packed (y<<16)|x); out: 3 doubles + 1 flag double (1.0 = rank deficient)
+void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, double* out4);
+
+}  // namespace lt

@@ -1,0 +1,420 @@
+"""Host side of the MI355X lane tracker: the reference's `LaneTracker` API and per-stream state
+machine (reference lane_tracker.py:85-181, 795-1209) on top of the HIP kernel chain.
+
+What runs where
+  GPU (liblane_tracker_amd.so): undistort, perspective warp, filter_lane_points, the sliding-window
+      and band searches and the polynomial fit -- the hot path.
+  Host (this file): the ~20 scalars of cross-frame state, the two-try policy, check_validity and
+      get_poly_points (a few f64 operations per frame; BASELINE north_star keeps them on the host),
+      curve radius / eccentricity, and the lane overlay.
+
+There is no CPU implementation of the hot path in this package: without the shared library and a
+GPU, constructing a LaneTracker raises.
+"""
+import numpy as np
+
+from . import _native
+from . import overlay as _overlay
+
+__all__ = ["LaneTracker", "bilateral_adaptive_threshold"]
+
+_default_ctx = None
+
+
+def _context_for_module_functions():
+    """Context used by the module-level `bilateral_adaptive_threshold` (it needs only a stream)."""
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = _native.Context((2, 2), (2, 2), np.eye(3), np.zeros(5), np.eye(3), device=0, capacity=1)
+    return _default_ctx
+
+
+def bilateral_adaptive_threshold(img, ksize=30, C=0, mode='floor', true_value=255, false_value=0):
+    """Cross-shaped adaptive threshold of a single-channel u8 image (reference lane_tracker.py:14-83).
+
+    A pixel passes in 'floor' mode iff it is brighter by more than C than the mean of its `ksize`
+    left AND right neighbours, or of its `ksize` upper AND lower neighbours (zeros beyond the
+    border); 'ceil' mode tests darker instead.  Returns a u8 mask of `true_value` / `false_value`.
+    """
+    if mode not in ('floor', 'ceil'):
+        raise ValueError("Unexpected mode value. Expected value is 'floor' or 'ceil'.")
+    return _context_for_module_functions().bilateral_adaptive_threshold(
+        img, ksize, C, 0 if mode == 'floor' else 1, true_value, false_value)
+
+
+def _as_index(v):
+    """The 2017 NumPy the reference ran on truncated float slice bounds / counts with int()."""
+    return int(v)
+
+
+class LaneTracker:
+    """Tracks the left and right lines of the ego lane across the frames of one video stream.
+
+    Drop-in for the reference class: same constructor, same `process()` signature and defaults,
+    same public attributes.  One instance per stream; not thread-safe (reference :85-99).
+    Extra keyword `device` selects the GPU.
+    """
+
+    def __init__(self, img_size, warped_size, cam_matrix, dist_coeffs, warp_matrices, mpp_conversion,
+                 n_fail=8, n_reset=4, n_average=2, print_frame_count=False, device=0):
+        self.img_size = img_size
+        self.warped_size = warped_size
+        self.cam_matrix = cam_matrix
+        self.dist_coeffs = dist_coeffs
+        self.M = warp_matrices[0]
+        self.Minv = warp_matrices[1]
+        self.mppv = mpp_conversion[0]
+        self.mpph = mpp_conversion[1]
+        self.n_reset = n_reset
+        self.n_fail = n_fail
+        self.n_average = n_average
+        self.print_frame_count = print_frame_count
+
+        # cross-frame state (reference :139-176)
+        self.last_detection = n_reset + 1
+        self.detected_pixels = False
+        self.valid_lane_lines = False
+        self.left_fit_coeffs = []
+        self.right_fit_coeffs = []
+        self.last_left_coeffs = None
+        self.last_right_coeffs = None
+        self.left_avg_coeffs = None
+        self.right_avg_coeffs = None
+        self.left_avg_y = np.array([])
+        self.left_avg_x = np.array([])
+        self.right_avg_y = np.array([])
+        self.right_avg_x = np.array([])
+        self.left_y = None
+        self.left_x = None
+        self.right_y = None
+        self.right_x = None
+        self.left_window_centroids = None
+        self.right_window_centroids = None
+        self.left_curve_radius = None
+        self.right_curve_radius = None
+        self.average_curve_radius = None
+        self.average_curve_radii = []
+        self.eccentricity = None
+        self.counter = 0
+        self.success = 0
+
+        # device side
+        self.device = device
+        self._ctx = _native.Context(img_size, warped_size, cam_matrix, dist_coeffs, self.M, device=device, capacity=1)
+        self._aux_ctx = {}          # contexts for images that are not the calibration's BEV size
+        self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search
+        self._overlay = None
+
+    # ------------------------------------------------------------------------------------------
+    def get_success_ratio(self):
+        return self.success / self.counter, self.success, self.counter
+
+    def close(self):
+        self._ctx.close()
+        for c in self._aux_ctx.values():
+            c.close()
+        self._aux_ctx = {}
+
+    # ---- device plumbing ----------------------------------------------------------------------
+    def _ctx_for_plane(self, h, w):
+        if (w, h) == (self._ctx.warp_w, self._ctx.warp_h):
+            return self._ctx
+        key = (h, w)
+        if key not in self._aux_ctx:
+            self._aux_ctx[key] = _native.Context((2, 2), (w, h), np.eye(3), np.zeros(5), np.eye(3),
+                                                 device=self.device, capacity=1)
+        return self._aux_ctx[key]
+
+    def _collect_search(self, ctx, want_centroids):
+        """Pull the lane record (and, if lanes were found, the pixel lists) of slot 0."""
+        rec = ctx.download_records(1)[0]
+        self.detected_pixels = bool(rec["detected"])
+        if not self.detected_pixels:
+            self._fit = None
+            return
+        self.left_y, self.left_x = ctx.download_pixels(0, 0)
+        self.right_y, self.right_x = ctx.download_pixels(0, 1)
+        if want_centroids:
+            self.left_window_centroids = ctx.download_centroids(0, 0)
+            self.right_window_centroids = ctx.download_centroids(0, 1)
+        lf = np.array(rec["left_coeffs"], np.float64)
+        rf = np.array(rec["right_coeffs"], np.float64)
+        flags = int(rec["fit_flags"])
+        if flags & 1:
+            lf = _minimum_norm_parabola(self.left_y, self.left_x)
+        if flags & 2:
+            rf = _minimum_norm_parabola(self.right_y, self.right_x)
+        self._fit = (self.left_y, self.right_y, lf, rf)
+
+    # ---- filter_lane_points (reference :183-240) ------------------------------------------------
+    def filter_lane_points(self, img, filter_type='bilateral', ksize_r=25, C_r=8, ksize_b=35, C_b=5,
+                           mask_noise=False, ksize_noise=65, C_noise=10, noise_thresh=135):
+        """RGB bird's-eye image -> binary lane mask {0,255}: R and Lab-b planes, 29x29 / 55x55
+        elliptical top-hats, bilateral (or box-mean 'neighborhood') thresholds, OR-merge with the
+        optional greenery mask, 5x5 elliptical open."""
+        fp = _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
+                                   ksize_noise, C_noise)
+        return self._ctx.filter_lane_points(img, fp)
+
+    # ---- searches (reference :242-500) --------------------------------------------------------------
+    def sliding_window_search(self, img, window_width, window_height, search_range, mu, no_success_limit,
+                              start_slice=0.25, ignore_sides=360, ignore_bottom=30, partial=1, diagnostics=False):
+        """Bottom-up two-lane window search on a binary bird's-eye image; stores left/right pixel
+        index arrays, window centroids and `detected_pixels`."""
+        if diagnostics:
+            print("Using sliding window search.")
+        img = np.ascontiguousarray(img, np.uint8)
+        ctx = self._ctx_for_plane(*img.shape[:2])
+        ctx.upload_masks(img)
+        self._search_uploaded(ctx, 'sws', dict(window_width=window_width, window_height=window_height,
+                                               search_range=search_range, mu=mu, no_success_limit=no_success_limit,
+                                               start_slice=start_slice, ignore_sides=ignore_sides,
+                                               ignore_bottom=ignore_bottom, partial=partial), diagnostics)
+
+    def band_search(self, img, bandwidth, ignore_bottom=30, partial=1, diagnostics=False):
+        """Collects the non-zero pixels within `bandwidth` px of the last valid left/right fits."""
+        if diagnostics:
+            print("Using band search.")
+        img = np.ascontiguousarray(img, np.uint8)
+        ctx = self._ctx_for_plane(*img.shape[:2])
+        ctx.upload_masks(img)
+        self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
+                              diagnostics)
+
+    def _search_uploaded(self, ctx, mode, kw, diagnostics):
+        if mode == 'sws':
+            ctx.sws_fit_run(1, _native.search_params(**kw))
+        else:
+            prev = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
+                                   np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
+            ctx.band_fit_run(1, prev, _native.search_params(**kw))
+        self._collect_search(ctx, want_centroids=(mode == 'sws'))
+        if diagnostics:
+            print("Lane pixels found." if self.detected_pixels else "No lane pixels found.")
+
+    # ---- fit (reference :502-509) ---------------------------------------------------------------------
+    def fit_poly(self):
+        """Second-degree least-squares fits x(y) of the current left/right lane pixels.  The fit is
+        produced by the search kernel (exact int64 moments, 3x3 normal equations in f64)."""
+        if self._fit is not None and self._fit[0] is self.left_y and self._fit[1] is self.right_y:
+            return self._fit[2].copy(), self._fit[3].copy()
+        # pixel arrays were replaced by the caller: fit them on the device from the lists
+        lf = self._ctx.fit_poly2(self.left_y, self.left_x)
+        rf = self._ctx.fit_poly2(self.right_y, self.right_x)
+        return lf, rf
+
+    # ---- host geometry (reference :511-528, 561-627) ---------------------------------------------------
+    def get_poly_points(self, left_fit_coeffs, right_fit_coeffs, partial=1):
+        img_height, img_width = self.warped_size[1], self.warped_size[0]
+        ploty = np.linspace(img_height * (1 - partial), img_height - 1, _as_index(img_height * partial))
+        left_fitx = left_fit_coeffs[0] * ploty ** 2 + left_fit_coeffs[1] * ploty + left_fit_coeffs[2]
+        right_fitx = right_fit_coeffs[0] * ploty ** 2 + right_fit_coeffs[1] * ploty + right_fit_coeffs[2]
+        left_fit_x = left_fitx[(left_fitx <= img_width - 1) & (left_fitx >= 0)]
+        right_fit_x = right_fitx[(right_fitx <= img_width - 1) & (right_fitx >= 0)]
+        left_fit_y = np.linspace(img_height - len(left_fit_x), img_height - 1, len(left_fit_x))
+        right_fit_y = np.linspace(img_height - len(right_fit_x), img_height - 1, len(right_fit_x))
+        return (left_fit_y.astype(np.int64), left_fit_x.astype(np.int64),
+                right_fit_y.astype(np.int64), right_fit_x.astype(np.int64))
+
+    # separation limits at y1, y2, y3 and the tangent threshold: the values hard-coded upstream
+    # (:588-593, :617; the "Demo 2" set of tracker_settings.md).  Overridable per instance.
+    validity_limits = dict(min_dist_y1=150, max_dist_y1=230, min_dist_y2=110, max_dist_y2=230,
+                           min_dist_y3=80, max_dist_y3=200, thresh=0.25)
+
+    def check_validity(self, left_fit_coeffs, right_fit_coeffs, diagnostics=False):
+        lim = self.validity_limits
+        left_fit_y, _, right_fit_y, _ = self.get_poly_points(left_fit_coeffs, right_fit_coeffs)
+        n = min(len(left_fit_y), len(right_fit_y))
+        # NB: the reference takes the image WIDTH as the bottom y (:571-573); reproduced as is
+        y1 = self.warped_size[0] - 1
+        y2 = self.warped_size[0] - int(n * 0.35)
+        y3 = self.warped_size[0] - int(n * 0.75)
+        lf, rf = left_fit_coeffs, right_fit_coeffs
+        at = lambda c, y: c[0] * (y ** 2) + c[1] * y + c[2]
+        x1_diff, x2_diff, x3_diff = abs(at(lf, y1) - at(rf, y1)), abs(at(lf, y2) - at(rf, y2)), abs(at(lf, y3) - at(rf, y3))
+        if ((x1_diff < lim['min_dist_y1']) | (x1_diff > lim['max_dist_y1']) | (x2_diff < lim['min_dist_y2'])
+                | (x2_diff > lim['max_dist_y2']) | (x3_diff < lim['min_dist_y3']) | (x3_diff > lim['max_dist_y3'])):
+            self.valid_lane_lines = False
+            if diagnostics:
+                print("No valid lane lines found, violated distance criterion: "
+                      "x1_diff == {:.2f}, x2_diff == {:.2f}, x3_diff == {:.2f}".format(x1_diff, x2_diff, x3_diff))
+            return
+        slope = lambda c, y: 2 * c[0] * y + c[1]
+        norm1 = abs(slope(lf, y1) - slope(rf, y1))
+        norm2 = abs(slope(lf, y3) - slope(rf, y3))
+        if (norm1 >= lim['thresh']) | (norm2 >= lim['thresh']):
+            self.valid_lane_lines = False
+            if diagnostics:
+                print("No valid lane lines found, violated tangent criterion: norm1 == {:.3f}, norm2 == {:.3f}".format(norm1, norm2))
+        else:
+            self.valid_lane_lines = True
+            if diagnostics:
+                print("Valid lane lines found. Tangents: norm1 == {:.3f}, norm2 == {:.3f}. Distance: x1_diff == {:.2f}, "
+                      "x2_diff == {:.2f}, x3_diff == {:.2f}".format(norm1, norm2, x1_diff, x2_diff, x3_diff))
+
+    # ---- metrics (reference :530-559) -------------------------------------------------------------------
+    def get_curve_radius(self):
+        """Curve radius in metres.  The reference refits the pixels in metric units with two more
+        np.polyfit calls; a least-squares parabola is equivariant under axis scaling, so the metric
+        coefficients follow from the pixel fit exactly: a_m = a*mpph/mppv^2, b_m = b*mpph/mppv."""
+        lf, rf = self.fit_poly()
+        y_eval = self.warped_size[1]
+        radii = []
+        for c in (lf, rf):
+            a_m, b_m = c[0] * self.mpph / (self.mppv ** 2), c[1] * self.mpph / self.mppv
+            radii.append(int(((1 + (2 * a_m * y_eval * self.mppv + b_m) ** 2) ** 1.5) / np.absolute(2 * a_m)))
+        self.left_curve_radius, self.right_curve_radius = radii
+        average_curve_radius = int(0.5 * (self.left_curve_radius + self.right_curve_radius))
+        self.average_curve_radii.append(average_curve_radius)
+        if len(self.average_curve_radii) > self.n_average:
+            self.average_curve_radii.pop(0)
+        real_curve_radii = [radius for radius in self.average_curve_radii if radius > 0]
+        self.average_curve_radius = int(np.average(real_curve_radii))
+
+    def get_eccentricity(self):
+        left, right = self.left_avg_x[-1], self.right_avg_x[-1]
+        mid = int(self.warped_size[0] / 2)
+        self.eccentricity = (((mid - left) - (right - mid)) / 2) * self.mpph
+
+    # ---- presentation (reference :629-673) -----------------------------------------
+    def draw_lane(self, img):
+        if self._overlay is None:
+            self._overlay = _overlay.LaneOverlay(self.img_size, self.warped_size, self.M)
+        out = self._overlay.draw(img, self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x)
+        lines = ["Curve Radius: {} m".format(self.average_curve_radius),
+                 "Eccentricity: {:.2f} m".format(self.eccentricity)]
+        if self.print_frame_count:
+            lines.append("Frame: {}".format(self.counter - 1))
+        return _overlay.put_lines(out, lines)
+
+    def print_failure(self, img):
+        lines = ["Lane Line Detection Failed"]
+        if self.print_frame_count:
+            lines.append("Frame: {}".format(self.counter - 1))
+        return _overlay.put_lines(np.array(img, copy=True), lines)
+
+    # ---- find_lane_points (reference :795-874) ---------------------------------------------------------------
+    def find_lane_points(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=True,
+                         noise_thresh=140, ksize_noise=65, C_noise=10, window_width=30, window_height=40,
+                         search_range=20, mu=0.1, no_success_limit=8, start_slice=0.25, ignore_sides=360,
+                         ignore_bottom=30, bandwidth=30, partial=0.5, diagnostics=False):
+        """frame -> (binary bird's-eye mask, 'sws' | 'bs'); lane pixels are stored on the tracker."""
+        mode = self._find_lane_points_device(img, ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh,
+                                             ksize_noise, C_noise, window_width, window_height, search_range, mu,
+                                             no_success_limit, start_slice, ignore_sides, ignore_bottom, bandwidth,
+                                             partial, diagnostics)
+        return self._ctx.download_masks(1)[0], mode
+
+    def _find_lane_points_device(self, img, ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh,
+                                 ksize_noise, C_noise, window_width, window_height, search_range, mu,
+                                 no_success_limit, start_slice, ignore_sides, ignore_bottom, bandwidth, partial,
+                                 diagnostics, reuse_frame=False):
+        ctx = self._ctx
+        if not reuse_frame:
+            ctx.upload_frames(img)
+        ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
+                                              ksize_noise, C_noise))
+        if self.last_detection > self.n_reset:                       # :851
+            if diagnostics:
+                print("Using sliding window search.")
+            self._search_uploaded(ctx, 'sws', dict(window_width=window_width, window_height=window_height,
+                                                   search_range=search_range, mu=mu,
+                                                   no_success_limit=no_success_limit, start_slice=start_slice,
+                                                   ignore_sides=ignore_sides, ignore_bottom=ignore_bottom,
+                                                   partial=partial), diagnostics)
+            return 'sws'
+        if diagnostics:
+            print("Using band search.")
+        self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
+                              diagnostics)
+        return 'bs'
+
+    # ---- process (reference :876-1209) -----------------------------------------------------------------------
+    def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,
+                noise_thresh=140, ksize_noise=65, C_noise=10, window_width=30, window_height=40, search_range=20,
+                mu=0.1, no_success_limit=8, start_slice=0.25, ignore_sides=360, ignore_bottom=30, bandwidth=25,
+                partial=1.0, n_tries=2, visualize_search=False, split_view=False, diagnostics=False):
+        """One video frame (RGB u8, the constructor's img_size) in, the annotated frame out.
+
+        Up to two detection attempts per frame: the caller's parameters first, then the
+        'neighborhood' parameter set (reference :1081-1099).  A valid detection updates the
+        running average over `n_average` fits and resets `last_detection`; a failure re-draws the
+        last averaged lane for up to `n_fail` frames and falls back from band search to
+        sliding-window search after `n_reset` misses.
+        """
+        if visualize_search or split_view:
+            raise NotImplementedError("search visualisation / split view are presentation features outside the "
+                                      "accelerated path (SURVEY.md section 8(f), row N1)")
+        self.counter += 1
+        self.detected_pixels = False
+        self.valid_lane_lines = False
+        left_fit_coeffs = right_fit_coeffs = None
+
+        first_try = (ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh, ksize_noise, C_noise,
+                     window_width, window_height, search_range, mu, no_success_limit, start_slice, ignore_sides,
+                     ignore_bottom, bandwidth, partial)
+        self._find_lane_points_device(img, *first_try, diagnostics)
+        if self.detected_pixels:
+            left_fit_coeffs, right_fit_coeffs = self.fit_poly()
+            self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
+            if diagnostics and self.valid_lane_lines:
+                print("Success at first attempt!")
+
+        if ((not self.detected_pixels) or (not self.valid_lane_lines)) and ((n_tries >= 2) or (n_tries == -1)):
+            if diagnostics:
+                print("No success at first attempt, now trying second.")
+            partial = 1.0                                               # the second parameter set (:1081-1099)
+            second_try = (15, 5, 35, 5, 'neighborhood', False, 140, 65, 10, 30, 40, 20, 0.1, 50, 0.25, 360, 30, 30,
+                          partial)
+            self._find_lane_points_device(img, *second_try, diagnostics, reuse_frame=True)
+            if self.detected_pixels:
+                left_fit_coeffs, right_fit_coeffs = self.fit_poly()
+                self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
+                if diagnostics and self.valid_lane_lines:
+                    print("Success at second attempt!")
+
+        if not self.valid_lane_lines:                                   # :1142-1173
+            if diagnostics:
+                print("No success after all attempts.")
+            self.left_fit_coeffs.append(np.array([]))
+            self.right_fit_coeffs.append(np.array([]))
+            self.average_curve_radii.append(-1)
+            if len(self.left_fit_coeffs) > self.n_average:
+                self.left_fit_coeffs.pop(0)
+                self.right_fit_coeffs.pop(0)
+            if len(self.average_curve_radii) > self.n_average:
+                self.average_curve_radii.pop(0)
+            self.last_detection += 1
+            if (self.left_avg_y.size != 0) and (self.last_detection <= self.n_fail):
+                return self.draw_lane(img)
+            return self.print_failure(img)
+
+        # success (:1178-1209)
+        self.left_fit_coeffs.append(left_fit_coeffs)
+        self.right_fit_coeffs.append(right_fit_coeffs)
+        self.last_left_coeffs = left_fit_coeffs
+        self.last_right_coeffs = right_fit_coeffs
+        if len(self.left_fit_coeffs) > self.n_average:
+            self.left_fit_coeffs.pop(0)
+            self.right_fit_coeffs.pop(0)
+        self.last_detection = 0
+        self.success += 1
+        self.left_avg_coeffs = np.average([c for c in self.left_fit_coeffs if c.size != 0], axis=0)
+        self.right_avg_coeffs = np.average([c for c in self.right_fit_coeffs if c.size != 0], axis=0)
+        self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x = self.get_poly_points(
+            self.left_avg_coeffs, self.right_avg_coeffs, partial)
+        self.get_curve_radius()
+        self.get_eccentricity()
+        return self.draw_lane(img)
+
+
+def _minimum_norm_parabola(y, x):
+    """np.polyfit's answer for rank-deficient input (fewer than 3 distinct y): column-scaled
+    Vandermonde, minimum-norm least squares with rcond = len(y)*eps.  Only reached for degenerate
+    pixel sets; the regular fit is done on the GPU."""
+    y = np.asarray(y, np.float64)
+    lhs = np.vander(y, 3)
+    scale = np.sqrt((lhs * lhs).sum(axis=0))
+    scale[scale == 0] = 1.0
+    c = np.linalg.lstsq(lhs / scale, np.asarray(x, np.float64), rcond=len(y) * np.finfo(np.float64).eps)[0]
+    return c / scale

@@ -1,0 +1,62 @@
+"""Presentation of the result on the camera frame (reference draw_lane / print_failure,
+lane_tracker.py:629-673).  SURVEY.md section 8(f) row N1: outside the accelerated path and not
+bit-matched -- OpenCV's fillPoly rasteriser, its inverse warp of the polygon and its anti-aliased
+Hershey text cannot be reproduced without OpenCV.  This is plain NumPy (+ Pillow for text when it
+is installed) so that `LaneTracker.process()` returns an annotated frame like the reference."""
+import numpy as np
+
+
+class LaneOverlay:
+    def __init__(self, img_size, warped_size, M):
+        self.w, self.h = int(img_size[0]), int(img_size[1])
+        self.bw, self.bh = int(warped_size[0]), int(warped_size[1])
+        M = np.asarray(M, np.float64)
+        u, v = np.meshgrid(np.arange(self.w, dtype=np.float64), np.arange(self.h, dtype=np.float64))
+        den = M[2, 0] * u + M[2, 1] * v + M[2, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            bx = np.rint((M[0, 0] * u + M[0, 1] * v + M[0, 2]) / den)
+            by = np.rint((M[1, 0] * u + M[1, 1] * v + M[1, 2]) / den)
+        ok = np.isfinite(bx) & np.isfinite(by) & (np.abs(den) > 1e-12)
+        ok &= (bx >= 0) & (bx < self.bw) & (by >= 0) & (by < self.bh)
+        self.cam_idx = np.flatnonzero(ok.ravel())
+        self.bev_idx = (by[ok].astype(np.int64) * self.bw + bx[ok].astype(np.int64))
+
+    def draw(self, img, left_y, left_x, right_y, right_x, alpha=0.3):
+        """Green lane polygon between the two averaged curves, blended like addWeighted(img,1,lane,0.3,0)."""
+        out = np.array(img, dtype=np.uint8, copy=True)
+        lane = np.zeros(self.bh * self.bw, bool)
+        ly, lx = np.asarray(left_y, np.int64), np.asarray(left_x, np.int64)
+        ry, rx = np.asarray(right_y, np.int64), np.asarray(right_x, np.int64)
+        if ly.size and ry.size:
+            lrow = np.full(self.bh, -1, np.int64)
+            rrow = np.full(self.bh, -1, np.int64)
+            lrow[np.clip(ly, 0, self.bh - 1)] = lx
+            rrow[np.clip(ry, 0, self.bh - 1)] = rx
+            rows = np.flatnonzero((lrow >= 0) & (rrow >= 0))
+            lane2d = lane.reshape(self.bh, self.bw)
+            cols = np.arange(self.bw)[None, :]
+            a = np.minimum(lrow[rows], rrow[rows])[:, None]
+            b = np.maximum(lrow[rows], rrow[rows])[:, None]
+            lane2d[rows] = (cols >= a) & (cols <= b)
+        hit = lane[self.bev_idx]
+        g = out.reshape(-1, 3)[:, 1]
+        sel = self.cam_idx[hit]
+        g[sel] = np.minimum(255, g[sel].astype(np.int64) + int(np.rint(255 * alpha))).astype(np.uint8)
+        return out
+
+
+def put_lines(img, lines, origin=(20, 8), step=35):
+    """White text lines at the reference's positions ((20,35), (20,70), ... baselines)."""
+    try:
+        from PIL import Image, ImageDraw, ImageFont
+    except Exception:
+        return img
+    try:
+        font = ImageFont.load_default(size=28)
+    except Exception:
+        font = ImageFont.load_default()
+    pil = Image.fromarray(np.ascontiguousarray(img))
+    d = ImageDraw.Draw(pil)
+    for i, text in enumerate(lines):
+        d.text((origin[0], origin[1] + i * step), text, fill=(255, 255, 255), font=font)
+    return np.asarray(pil).copy()

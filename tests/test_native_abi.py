@@ -1,0 +1,108 @@
+"""CPU-side checks of the boundary: the shared library loads, exports every symbol that
+include/lane_tracker_amd.h declares, the record layout is 64 bytes, and -- with no GPU -- the
+product fails loudly instead of computing anything on the CPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lane_tracker_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from lane_tracker_amd import _native
+    lib = _native.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert sorted(_native.exported_symbols()) == declared
+    assert lib.lt_abi_version() == 1
+
+
+def test_struct_layouts():
+    import ctypes as C
+    from lane_tracker_amd import _native
+    assert C.sizeof(_native.LaneRecord) == 64 and _native.RECORD_DTYPE.itemsize == 64
+    assert C.sizeof(_native.Calib) == 16 + 8 * 23
+    assert C.sizeof(_native.SearchParams) == 8 * 4 + 3 * 8
+    assert C.sizeof(_native.FilterParams) == 9 * 4
+    names = [_native.load().lt_stage_name(i).decode() for i in range(_native.NUM_STAGES)]
+    assert names[0] == "undistort_rows" and names[9] == "sws_fit" and all(names)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_gpu_fails_loudly():
+    from lane_tracker_amd import _native, calib
+    from lane_tracker_amd.lane_tracker import LaneTracker, bilateral_adaptive_threshold
+    with pytest.raises(_native.NativeError):
+        LaneTracker(**calib.reference_calibration())
+    with pytest.raises(_native.NativeError):
+        bilateral_adaptive_threshold(np.zeros((8, 8), np.uint8))
+
+
+def test_argument_validation_needs_no_gpu():
+    from lane_tracker_amd.lane_tracker import bilateral_adaptive_threshold
+    with pytest.raises(ValueError):
+        bilateral_adaptive_threshold(np.zeros((8, 8), np.uint8), mode="round")   # reference :71
+
+
+def test_dropin_modules_expose_reference_names():
+    import importlib.util
+    for mod, names in (("lane_tracker", ["LaneTracker", "bilateral_adaptive_threshold"]),
+                       ("utils", ["load_camera_calib", "load_warp_params", "create_split_view"])):
+        spec = importlib.util.spec_from_file_location("dropin_" + mod, os.path.join(ROOT, "dropin", mod + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        for n in names:
+            assert hasattr(m, n)
+
+
+def test_process_signature_matches_reference_defaults():
+    """process() keyword names and defaults, lane_tracker.py:876-900."""
+    import inspect
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    sig = inspect.signature(LaneTracker.process)
+    want = dict(ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False, noise_thresh=140,
+                ksize_noise=65, C_noise=10, window_width=30, window_height=40, search_range=20, mu=0.1,
+                no_success_limit=8, start_slice=0.25, ignore_sides=360, ignore_bottom=30, bandwidth=25, partial=1.0,
+                n_tries=2, visualize_search=False, split_view=False, diagnostics=False)
+    got = {k: v.default for k, v in sig.parameters.items() if k not in ("self", "img")}
+    assert got == want and list(got) == list(want)
+    ctor = inspect.signature(LaneTracker.__init__)
+    assert list(ctor.parameters)[1:11] == ["img_size", "warped_size", "cam_matrix", "dist_coeffs", "warp_matrices",
+                                           "mpp_conversion", "n_fail", "n_reset", "n_average", "print_frame_count"]
+
+
+def test_utils_loaders_round_trip(tmp_path):
+    from lane_tracker_amd import calib, utils
+    cam, warp = str(tmp_path / "cam.npz"), str(tmp_path / "warp.npz")
+    utils.save_calibration_npz(cam, warp, calib.CAM_MATRIX, calib.DIST_COEFFS, calib.M, calib.MINV,
+                               calib.IMAGE_WIDTH_HEIGHT, calib.WARPED_WIDTH_HEIGHT, calib.MPPV, calib.MPPH)
+    K, D = utils.load_camera_calib(cam)
+    M, Minv, isz, wsz, mppv, mpph = utils.load_warp_params(warp)
+    assert np.array_equal(K, calib.CAM_MATRIX) and np.array_equal(D, calib.DIST_COEFFS)
+    assert isz == (1280, 720) and wsz == (1080, 1100) and (mppv, mpph) == (calib.MPPV, calib.MPPH)
+    assert np.array_equal(M, calib.M) and np.array_equal(Minv, calib.MINV)
+
+
+def test_calibration_literals_match_reference_pickles():
+    ref = "/root/reference/cam_calib.p"
+    if not os.path.exists(ref):
+        pytest.skip("reference not present")
+    import io
+    import contextlib
+    from lane_tracker_amd import calib, utils
+    with contextlib.redirect_stdout(io.StringIO()):
+        K, D = utils.load_camera_calib(ref)
+        M, Minv, isz, wsz, mppv, mpph = utils.load_warp_params("/root/reference/warp_params.p")
+    assert np.array_equal(K, calib.CAM_MATRIX) and np.array_equal(D, calib.DIST_COEFFS)
+    assert np.array_equal(M, calib.M) and np.array_equal(Minv, calib.MINV)
+    assert (isz, wsz, mppv, mpph) == (calib.IMAGE_WIDTH_HEIGHT, calib.WARPED_WIDTH_HEIGHT, calib.MPPV, calib.MPPH)
