@@ -155,6 +155,11 @@ int  lt_bilateral_adaptive_threshold(lt_ctx* ctx, const uint8_t* img, int h, int
 int  lt_filter_lane_points(lt_ctx* ctx, const uint8_t* bev_rgb, int h, int w, const lt_filter_params* p,
                            uint8_t* mask);
 
+/* One elliptical morphology operator on a single-channel image of any size: the building block of
+ * morphologyEx (:210-211, :238).  k in {5, 29, 55}; op 0 erode, 1 dilate, 2 top-hat, 3 open.
+ * direct != 0 evaluates the footprint tap by tap instead of using the run decomposition (k = 5 always does). */
+int  lt_morph_ellipse(lt_ctx* ctx, const uint8_t* img, int h, int w, int k, int op, int direct, uint8_t* out);
+
 /* LaneTracker.fit_poly() on explicit pixel lists (np.polyfit(ys, xs, 2), :506-507): n (y,x) pairs with
  * coordinates in [0, 65535].  *rank_deficient is set when fewer than 3 distinct y exist (coef = 0). */
 int  lt_fit_poly2(lt_ctx* ctx, const int32_t* ys, const int32_t* xs, int n, int h, int w, double coef[3],

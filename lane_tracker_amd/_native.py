@@ -89,6 +89,7 @@ _SIGNATURES = {
     "lt_bilateral_adaptive_threshold": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                  C.c_int, _P]),
     "lt_filter_lane_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FilterParams), _P]),
+    "lt_morph_ellipse": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "lt_fit_poly2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "lt_timer_start": (C.c_int, [_P]),
     "lt_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
@@ -299,6 +300,17 @@ class Context:
         out = np.empty(a.shape[:2], np.uint8)
         _check(self.lib.lt_filter_lane_points(self._h, a.ctypes.data, a.shape[0], a.shape[1], C.byref(fp),
                                               out.ctypes.data))
+        return out
+
+    def morph_ellipse(self, img, k, op, direct=False):
+        """op: 'erode' | 'dilate' | 'tophat' | 'open' with the k x k ellipse (k in 5, 29, 55)."""
+        a = _u8(img)
+        if a.ndim != 2:
+            raise ValueError("morph_ellipse expects a single-channel image")
+        out = np.empty_like(a)
+        code = {"erode": 0, "dilate": 1, "tophat": 2, "open": 3}[op]
+        _check(self.lib.lt_morph_ellipse(self._h, a.ctypes.data, a.shape[0], a.shape[1], int(k), code,
+                                         int(bool(direct)), out.ctypes.data))
         return out
 
     def fit_poly2(self, ys, xs):

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +67,7 @@ struct lt_ctx {
     int32_t* d_cent = nullptr;
     int maxpix = 0, maxlev = 0;
     bool have_mask = false;
+    bool brute_tophat = false;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stage_timing = false;
@@ -212,10 +214,17 @@ int run_filter_chain(lt_ctx* c, int first, int n, const lt_filter_params* p, int
     uint8_t* mask = c->d_plane[P_MASK] + off;
     hipStream_t s = c->stream;
     if (p->filter_type == 0) {
-        { StageScope t(c, ST_ERODE_R);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
-        { StageScope t(c, ST_TOPHAT_R); launch_morph_ellipse(s, t0, thR, R, h, w, c->se29, true, ps, n); }
-        { StageScope t(c, ST_ERODE_B);  launch_morph_ellipse(s, B, t0, nullptr, h, w, c->se55, false, ps, n); }
-        { StageScope t(c, ST_TOPHAT_B); launch_morph_ellipse(s, t0, thB, B, h, w, c->se55, true, ps, n); }
+        if (c->brute_tophat) {   // debugging aid (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
+            { StageScope t(c, ST_ERODE_R);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_R); launch_morph_ellipse(s, t0, thR, R, h, w, c->se29, true, ps, n); }
+            { StageScope t(c, ST_ERODE_B);  launch_morph_ellipse(s, B, t0, nullptr, h, w, c->se55, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_B); launch_morph_ellipse(s, t0, thB, B, h, w, c->se55, true, ps, n); }
+        } else {
+            { StageScope t(c, ST_ERODE_R);  launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_R); launch_morph_runs(s, t0, thR, R, h, w, 29, true, ps, n); }
+            { StageScope t(c, ST_ERODE_B);  launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_B); launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n); }
+        }
         { StageScope t(c, ST_THRESHOLD);
           launch_bilateral(s, thR, t1, h, w, p->ksize_r, p->C_r, 0, 255, 0, ps, n);
           launch_bilateral(s, thB, t2, h, w, p->ksize_b, p->C_b, 0, 255, 0, ps, n); }
@@ -336,6 +345,12 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     make_se(5, c->se5);
     make_se(29, c->se29);
     make_se(55, c->se55);
+    if (!tophat_tables_match(c->se29, c->se55))
+        return bail(fail(LT_ERR_STATE, "compiled-in ellipse run tables disagree with getStructuringElement's formula"));
+    {
+        const char* e = std::getenv("LT_TOPHAT_BRUTE");
+        c->brute_tophat = e && e[0] == '1';
+    }
 
     int rc;
     if ((rc = dev_alloc(&c->d_wxy, warp.xy.size()))) return bail(rc);
@@ -422,7 +437,7 @@ int lt_get_info(lt_ctx* c, lt_info* out) {
     // compulsory input rows (full width, 3 B/px) + the mask written once
     out->alg_bytes_mask = (int64_t)c->fe.nrows * c->calib.img_w * 3 + (int64_t)c->plane_bytes;
     out->alg_bytes_search = (int64_t)c->plane_bytes + (int64_t)sizeof(lt_lane_record);
-    std::snprintf(out->device_name, sizeof out->device_name, "%s", c->prop.name);
+    std::snprintf(out->device_name, sizeof out->device_name, "%s", c->prop.name[0] ? c->prop.name : c->prop.gcnArchName);
     return LT_OK;
 }
 
@@ -713,6 +728,7 @@ int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_
     tmp.device = c->device;
     tmp.stream = c->stream;
     tmp.se5 = c->se5; tmp.se29 = c->se29; tmp.se55 = c->se55;
+    tmp.brute_tophat = c->brute_tophat;
     tmp.plane_bytes = (size_t)h * w;
     tmp.capacity = 1;
     uint8_t* d_bev = nullptr;
@@ -735,6 +751,38 @@ int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_
     cleanup();
     if (rc) return rc;
     if (e != hipSuccess) return fail(LT_ERR_HIP, "filter_lane_points failed: %s", hipGetErrorString(e));
+    return LT_OK;
+}
+
+int lt_morph_ellipse(lt_ctx* c, const uint8_t* img, int h, int w, int k, int op, int direct, uint8_t* out) {
+    if (!c || !img || !out) return fail(LT_ERR_INVALID, "null argument");
+    if (h < 1 || w < 1 || h > 16384 || w > 16384) return fail(LT_ERR_INVALID, "bad image size");
+    if (k != 5 && k != 29 && k != 55) return fail(LT_ERR_INVALID, "structuring element size must be 5, 29 or 55");
+    if (op < 0 || op > 3) return fail(LT_ERR_INVALID, "op must be 0 erode, 1 dilate, 2 tophat, 3 open");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t n = (size_t)h * w;
+    uint8_t *d_in = nullptr, *d_t = nullptr, *d_out = nullptr;
+    if ((rc = dev_alloc(&d_in, n)) || (rc = dev_alloc(&d_t, n)) || (rc = dev_alloc(&d_out, n))) {
+        dev_free(d_in); dev_free(d_t); dev_free(d_out);
+        return rc;
+    }
+    const EllipseSE& se = k == 5 ? c->se5 : (k == 29 ? c->se29 : c->se55);
+    auto pass = [&](const uint8_t* src, uint8_t* dst, const uint8_t* minuend, bool dilate) {
+        if (k == 5 || direct) launch_morph_ellipse(c->stream, src, dst, minuend, h, w, se, dilate, n, 1);
+        else launch_morph_runs(c->stream, src, dst, minuend, h, w, k, dilate, n, 1);
+    };
+    hipError_t e = hipMemcpyAsync(d_in, img, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        if (op == 0) pass(d_in, d_out, nullptr, false);
+        else if (op == 1) pass(d_in, d_out, nullptr, true);
+        else { pass(d_in, d_t, nullptr, false); pass(d_t, d_out, op == 2 ? d_in : nullptr, true); }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_in); dev_free(d_t); dev_free(d_out);
+    if (e != hipSuccess) return fail(LT_ERR_HIP, "morph_ellipse failed: %s", hipGetErrorString(e));
     return LT_OK;
 }
 

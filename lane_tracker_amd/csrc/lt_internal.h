@@ -46,6 +46,10 @@ void launch_undistorted_to_rgb(hipStream_t s, const uint8_t* und, size_t und_str
 // dst = erode/dilate(src) with the ellipse; if minuend != nullptr: dst = sat(minuend - result)
 void launch_morph_ellipse(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w,
                           const EllipseSE& se, bool dilate, size_t plane_stride, int n);
+// decomposed 29x29 / 55x55 ellipses (k_tophat.hip); same contract as launch_morph_ellipse
+void launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
+                       bool dilate, size_t plane_stride, int n);
+bool tophat_tables_match(const EllipseSE& se29, const EllipseSE& se55);
 void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int ksize, int C, int mode,
                       int tv, int fv, size_t plane_stride, int n);
 void launch_adaptive_mean(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int bs, int C,

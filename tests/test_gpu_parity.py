@@ -302,3 +302,28 @@ def test_full_batch_256_properties(nat, cal, oracle, ref_calib):
         assert rec["detected"].all()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("k", [5, 29, 55])
+@pytest.mark.parametrize("shape", [(200, 300), (57, 129), (1, 1), (130, 64), (64, 1081)])
+def test_morph_ellipse_operators(ctx, oracle, k, shape):
+    """Single-pass erode/dilate/top-hat/open, run-decomposed kernel vs the oracle (and vs direct taps)."""
+    rng = np.random.default_rng(k * 31 + shape[1])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    img[rng.random(shape) < 0.02] = 0
+    img[rng.random(shape) < 0.02] = 255
+    assert_same(ctx.morph_ellipse(img, k, "erode"), oracle.erode(img, k), f"erode {k} {shape}")
+    assert_same(ctx.morph_ellipse(img, k, "dilate"), oracle.dilate(img, k), f"dilate {k} {shape}")
+    assert_same(ctx.morph_ellipse(img, k, "tophat"), oracle.tophat(img, k), f"tophat {k} {shape}")
+    assert_same(ctx.morph_ellipse(img, k, "open"), oracle.morph_open(img, k), f"open {k} {shape}")
+    assert_same(ctx.morph_ellipse(img, k, "erode", direct=True), oracle.erode(img, k), f"direct erode {k} {shape}")
+
+
+def test_morph_ellipse_footprint_probe(ctx, oracle):
+    """Delta images expose every tap of the footprint, including across the 64-column lane seams."""
+    for k in (29, 55):
+        for x in (0, 63, 64, 127, 128, 200, 299):
+            img = np.full((140, 300), 255, np.uint8)
+            img[70, x] = 0
+            assert_same(ctx.morph_ellipse(img, k, "erode"), oracle.erode(img, k), f"erode probe {k} x={x}")
+            assert_same(ctx.morph_ellipse(255 - img, k, "dilate"), oracle.dilate(255 - img, k), f"dilate probe {k} x={x}")
