@@ -179,6 +179,8 @@ void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, in
     if (n <= 0 || h <= 0 || w <= 0) return;
     const int rw = BT_W + 2 * ksize + 1, ch = BT_H + 2 * ksize + 1;
     const size_t lds = (size_t)(BT_H * rw + BT_W * ch) * sizeof(int32_t);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((w + BT_W - 1) / BT_W, (h + BT_H - 1) / BT_H, n);
     hipLaunchKernelGGL(k_bilateral, grid, dim3(256), lds, s, src, dst, h, w, ksize, C, mode, tv, fv, plane_stride);
 }

@@ -8,7 +8,7 @@
 // Both resamplings are OpenCV's 8-bit bilinear remap: integer tap (sx,sy) + 5-bit fractions,
 // exact 15-bit weights, constant-0 border, (sum + 2^14) >> 15.  They cannot be composed into one
 // resampling because the intermediate is rounded to u8, so the undistorted rows are materialised
-// once (planar, 3 x rows x W bytes per frame: it stays in L2 for the warp that follows).
+// once (one RGBX dword per pixel, rows x W x 4 bytes per frame: it stays in L2 for the warp).
 // The bird's-eye RGB image itself is never written: the warp emits the R plane and the Lab-b
 // plane directly.
 #include "lt_internal.h"
@@ -22,30 +22,40 @@ __device__ __forceinline__ int bilerp(int v00, int v01, int v10, int v11, int fx
     return (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + (1 << 14)) >> 15;
 }
 
-// one thread per undistorted pixel; frames are RGB interleaved, output is planar
+// One thread per undistorted pixel.  Frames are RGB interleaved (3 B/px); the output is one RGBX
+// dword per pixel, so that the warp fetches a whole tap with a single aligned load.  All loads are
+// unconditional on clamped addresses and masked afterwards (a guarded load serialises on its own
+// s_waitcnt).
 __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restrict__ frames, size_t frame_stride,
                                                        const int16_t* __restrict__ uxy,
                                                        const uint16_t* __restrict__ ufrac, FrontEndGeom g,
-                                                       uint8_t* __restrict__ und, size_t und_stride) {
+                                                       uint32_t* __restrict__ und, size_t und_stride_px) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;  // relative to g.r0
     if (x >= g.img_w) return;
     const uint8_t* src = frames + (size_t)blockIdx.z * frame_stride;
-    uint8_t* dst = und + (size_t)blockIdx.z * und_stride;
     const size_t o = (size_t)row * g.img_w + x;
     const int sx = uxy[o * 2], sy = uxy[o * 2 + 1];
     const int f = ufrac[o], fx = f & 31, fy = f >> 5;
     const bool y0 = sy >= 0 && sy < g.img_h, y1 = sy + 1 >= 0 && sy + 1 < g.img_h;
     const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
-    const size_t plane = (size_t)g.nrows * g.img_w;
+    const int cy0 = min(max(sy, 0), g.img_h - 1), cy1 = min(max(sy + 1, 0), g.img_h - 1);
+    const int cx0 = min(max(sx, 0), g.img_w - 1), cx1 = min(max(sx + 1, 0), g.img_w - 1);
+    const uint8_t* p00 = src + ((size_t)cy0 * g.img_w + cx0) * 3;
+    const uint8_t* p01 = src + ((size_t)cy0 * g.img_w + cx1) * 3;
+    const uint8_t* p10 = src + ((size_t)cy1 * g.img_w + cx0) * 3;
+    const uint8_t* p11 = src + ((size_t)cy1 * g.img_w + cx1) * 3;
+    int t[12];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) { t[ch] = p00[ch]; t[3 + ch] = p01[ch]; t[6 + ch] = p10[ch]; t[9 + ch] = p11[ch]; }
+    uint32_t out = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const int v00 = (y0 && x0) ? src[((size_t)sy * g.img_w + sx) * 3 + ch] : 0;
-        const int v01 = (y0 && x1) ? src[((size_t)sy * g.img_w + sx + 1) * 3 + ch] : 0;
-        const int v10 = (y1 && x0) ? src[((size_t)(sy + 1) * g.img_w + sx) * 3 + ch] : 0;
-        const int v11 = (y1 && x1) ? src[((size_t)(sy + 1) * g.img_w + sx + 1) * 3 + ch] : 0;
-        dst[ch * plane + o] = (uint8_t)bilerp(v00, v01, v10, v11, fx, fy);
+        const int v00 = (y0 && x0) ? t[ch] : 0, v01 = (y0 && x1) ? t[3 + ch] : 0;
+        const int v10 = (y1 && x0) ? t[6 + ch] : 0, v11 = (y1 && x1) ? t[9 + ch] : 0;
+        out |= (uint32_t)bilerp(v00, v01, v10, v11, fx, fy) << (8 * ch);
     }
+    und[(size_t)blockIdx.z * und_stride_px + o] = out;
 }
 
 struct LabLut {
@@ -74,15 +84,78 @@ __device__ __forceinline__ void stage_lab_tables(uint16_t* s_gamma, uint16_t* s_
     __syncthreads();
 }
 
-// one thread per bird's-eye pixel: three bilinear samples of the planar undistorted rows, then
-// R plane and Lab-b plane
-__global__ __launch_bounds__(256) void k_warp_split(const uint8_t* __restrict__ und, size_t und_stride,
-                                                   const int16_t* __restrict__ wxy,
-                                                   const uint16_t* __restrict__ wfrac, FrontEndGeom g,
-                                                   const uint16_t* __restrict__ gamma_tab,
-                                                   const uint16_t* __restrict__ cbrt_tab,
-                                                   const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
-                                                   uint8_t* __restrict__ planeB, size_t plane_stride) {
+__device__ __forceinline__ void warp_pixel(const uint32_t* __restrict__ src, const FrontEndGeom& g, int sx, int sy,
+                                           int f, const uint16_t* gt, const uint16_t* ct, const int32_t* C, int& r_out,
+                                           int& b_out) {
+    const int fx = f & 31, fy = f >> 5;
+    // taps outside the camera frame are 0; in-frame taps always fall inside rows [r0, r0+nrows)
+    const int ry0 = sy - g.r0, ry1 = sy + 1 - g.r0;
+    const bool y0 = sy >= 0 && sy < g.img_h && ry0 >= 0 && ry0 < g.nrows;
+    const bool y1 = sy + 1 >= 0 && sy + 1 < g.img_h && ry1 >= 0 && ry1 < g.nrows;
+    const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
+    const int cy0 = min(max(ry0, 0), g.nrows - 1), cy1 = min(max(ry1, 0), g.nrows - 1);
+    const int cx0 = min(max(sx, 0), g.img_w - 1), cx1 = min(max(sx + 1, 0), g.img_w - 1);
+    uint32_t t00 = src[(size_t)cy0 * g.img_w + cx0], t01 = src[(size_t)cy0 * g.img_w + cx1];
+    uint32_t t10 = src[(size_t)cy1 * g.img_w + cx0], t11 = src[(size_t)cy1 * g.img_w + cx1];
+    t00 = (y0 && x0) ? t00 : 0u;
+    t01 = (y0 && x1) ? t01 : 0u;
+    t10 = (y1 && x0) ? t10 : 0u;
+    t11 = (y1 && x1) ? t11 : 0u;
+    int rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+        rgb[ch] = bilerp((t00 >> (8 * ch)) & 255, (t01 >> (8 * ch)) & 255, (t10 >> (8 * ch)) & 255,
+                         (t11 >> (8 * ch)) & 255, fx, fy);
+    r_out = rgb[0];
+    b_out = lab_b_of(rgb[0], rgb[1], rgb[2], gt, ct, C);
+}
+
+// Four adjacent bird's-eye pixels per thread: bilinear samples of the RGBX undistorted rows, then
+// one dword store to the R plane and one to the Lab-b plane.  `quads` = pixels / 4 (w % 4 == 0).
+__global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict__ und, size_t und_stride_px,
+                                                    const int16_t* __restrict__ wxy,
+                                                    const uint16_t* __restrict__ wfrac, FrontEndGeom g,
+                                                    const uint16_t* __restrict__ gamma_tab,
+                                                    const uint16_t* __restrict__ cbrt_tab,
+                                                    const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
+                                                    uint8_t* __restrict__ planeB, size_t plane_stride) {
+    __shared__ uint16_t s_gamma[256];
+    __shared__ uint16_t s_cbrt[3072];
+    __shared__ int32_t s_coef[9];
+    stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
+    const size_t quads = ((size_t)g.warp_h * g.warp_w) >> 2;
+    const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= quads) return;
+    const uint32_t* src = und + (size_t)blockIdx.z * und_stride_px;
+    const uint4 xy = reinterpret_cast<const uint4*>(wxy)[qi];        // 4 x (sx, sy) int16 pairs
+    const uint2 fr = reinterpret_cast<const uint2*>(wfrac)[qi];      // 4 x u16
+    const uint32_t xyv[4] = {xy.x, xy.y, xy.z, xy.w};
+    const uint32_t frv[4] = {fr.x & 0xffffu, fr.x >> 16, fr.y & 0xffffu, fr.y >> 16};
+    uint32_t outR = 0, outB = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
+        int r, b;
+        warp_pixel(src, g, sx, sy, (int)frv[i], s_gamma, s_cbrt, s_coef, r, b);
+        // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
+        // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the
+        // third pixel (caught by the parity test); the barrier costs nothing at run time.
+        asm volatile("" : "+v"(r), "+v"(b));
+        outR |= ((uint32_t)r & 255u) << (8 * i);
+        outB |= ((uint32_t)b & 255u) << (8 * i);
+    }
+    reinterpret_cast<uint32_t*>(planeR + (size_t)blockIdx.z * plane_stride)[qi] = outR;
+    reinterpret_cast<uint32_t*>(planeB + (size_t)blockIdx.z * plane_stride)[qi] = outB;
+}
+
+// any width: one pixel per thread
+__global__ __launch_bounds__(256) void k_warp_split1(const uint32_t* __restrict__ und, size_t und_stride_px,
+                                                    const int16_t* __restrict__ wxy,
+                                                    const uint16_t* __restrict__ wfrac, FrontEndGeom g,
+                                                    const uint16_t* __restrict__ gamma_tab,
+                                                    const uint16_t* __restrict__ cbrt_tab,
+                                                    const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
+                                                    uint8_t* __restrict__ planeB, size_t plane_stride) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_cbrt[3072];
     __shared__ int32_t s_coef[9];
@@ -90,27 +163,11 @@ __global__ __launch_bounds__(256) void k_warp_split(const uint8_t* __restrict__ 
     const size_t npix = (size_t)g.warp_h * g.warp_w;
     const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= npix) return;
-    const uint8_t* src = und + (size_t)blockIdx.z * und_stride;
-    const int sx = wxy[o * 2], sy = wxy[o * 2 + 1];
-    const int f = wfrac[o], fx = f & 31, fy = f >> 5;
-    // taps outside the camera frame are 0; in-frame taps always fall inside rows [r0, r0+nrows)
-    const int ry0 = sy - g.r0, ry1 = sy + 1 - g.r0;
-    const bool y0 = sy >= 0 && sy < g.img_h && ry0 >= 0 && ry0 < g.nrows;
-    const bool y1 = sy + 1 >= 0 && sy + 1 < g.img_h && ry1 >= 0 && ry1 < g.nrows;
-    const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
-    const size_t plane = (size_t)g.nrows * g.img_w;
-    int rgb[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const uint8_t* p = src + ch * plane;
-        const int v00 = (y0 && x0) ? p[(size_t)ry0 * g.img_w + sx] : 0;
-        const int v01 = (y0 && x1) ? p[(size_t)ry0 * g.img_w + sx + 1] : 0;
-        const int v10 = (y1 && x0) ? p[(size_t)ry1 * g.img_w + sx] : 0;
-        const int v11 = (y1 && x1) ? p[(size_t)ry1 * g.img_w + sx + 1] : 0;
-        rgb[ch] = bilerp(v00, v01, v10, v11, fx, fy);
-    }
-    planeR[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)rgb[0];
-    planeB[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, s_coef);
+    int r, b;
+    warp_pixel(und + (size_t)blockIdx.z * und_stride_px, g, wxy[o * 2], wxy[o * 2 + 1], wfrac[o], s_gamma, s_cbrt,
+               s_coef, r, b);
+    planeR[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)r;
+    planeB[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)b;
 }
 
 // filter_lane_points() entry on an already-warped RGB image (lane_tracker.py:207-208)
@@ -131,35 +188,41 @@ __global__ __launch_bounds__(256) void k_split_bev(const uint8_t* __restrict__ b
     planeB[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)lab_b_of(r, gg, b, s_gamma, s_cbrt, s_coef);
 }
 
-__global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint8_t* __restrict__ und, size_t und_stride,
+__global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint32_t* __restrict__ und, size_t und_stride_px,
                                                            int nrows, int w, uint8_t* __restrict__ out) {
     const size_t plane = (size_t)nrows * w;
     const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= plane) return;
-    const uint8_t* src = und + (size_t)blockIdx.z * und_stride;
+    const uint32_t v = und[(size_t)blockIdx.z * und_stride_px + o];
     uint8_t* dst = out + (size_t)blockIdx.z * plane * 3 + o * 3;
-    dst[0] = src[o];
-    dst[1] = src[plane + o];
-    dst[2] = src[2 * plane + o];
+    dst[0] = (uint8_t)v;
+    dst[1] = (uint8_t)(v >> 8);
+    dst[2] = (uint8_t)(v >> 16);
 }
 
 }  // namespace
 
 void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
-                           const uint16_t* ufrac, FrontEndGeom g, uint8_t* und, size_t und_stride, int n) {
+                           const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_stride_px, int n) {
     if (n <= 0 || g.nrows <= 0) return;
     dim3 grid((g.img_w + 255) / 256, g.nrows, n);
-    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride);
+    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px);
 }
 
-void launch_warp_split(hipStream_t s, const uint8_t* und, size_t und_stride, const int16_t* wxy,
+void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy,
                        const uint16_t* wfrac, FrontEndGeom g, const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
                        const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB, size_t plane_stride, int n) {
-    if (n <= 0) return;
+    if (n <= 0 || g.nrows <= 0) return;
     const size_t npix = (size_t)g.warp_h * g.warp_w;
-    dim3 grid((unsigned)((npix + 255) / 256), 1, n);
-    hipLaunchKernelGGL(k_warp_split, grid, dim3(256), 0, s, und, und_stride, wxy, wfrac, g, gamma_tab, cbrt_tab,
-                       coeffs, planeR, planeB, plane_stride);
+    if ((g.warp_w & 3) == 0 && (plane_stride & 3) == 0) {
+        dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, n);
+        hipLaunchKernelGGL(k_warp_split4, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
+                           coeffs, planeR, planeB, plane_stride);
+    } else {
+        dim3 grid((unsigned)((npix + 255) / 256), 1, n);
+        hipLaunchKernelGGL(k_warp_split1, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
+                           coeffs, planeR, planeB, plane_stride);
+    }
 }
 
 void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int npix, const uint16_t* gamma_tab,
@@ -171,11 +234,11 @@ void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int 
                        planeB, plane_stride);
 }
 
-void launch_undistorted_to_rgb(hipStream_t s, const uint8_t* und, size_t und_stride, int nrows, int w, uint8_t* out,
+void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, int nrows, int w, uint8_t* out,
                                int n) {
     if (n <= 0 || nrows <= 0) return;
     dim3 grid((unsigned)(((size_t)nrows * w + 255) / 256), 1, n);
-    hipLaunchKernelGGL(k_undistorted_to_rgb, grid, dim3(256), 0, s, und, und_stride, nrows, w, out);
+    hipLaunchKernelGGL(k_undistorted_to_rgb, grid, dim3(256), 0, s, und, und_stride_px, nrows, w, out);
 }
 
 }  // namespace lt

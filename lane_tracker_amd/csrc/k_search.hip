@@ -109,18 +109,54 @@ __device__ void wave0_exclusive_scan(const unsigned* in, unsigned* out, int n) {
     if (lane == 63) out[n] = incl;
 }
 
-// np.sum(img[r0:r1, c0:c1], axis=0) into sums[0..c1-c0) (LDS atomics; the masks are sparse)
-__device__ void column_sums(const uint8_t* mask, int w, int r0, int r1, int c0, int c1, unsigned* sums) {
-    const int n = c1 - c0;
-    for (int i = threadIdx.x; i < n; i += NT) sums[i] = 0;
-    __syncthreads();
-    if (n > 0 && r1 > r0) {
-        const int items = (r1 - r0) * n;
-        for (int i = threadIdx.x; i < items; i += NT) {
-            const int ry = i / n, cx = i - ry * n;
-            const unsigned v = mask[(size_t)(r0 + ry) * w + c0 + cx];
-            if (v) atomicAdd(&sums[cx], v);
+// ---- column sums of every search band, all frames at once -------------------------------------------
+// np.sum(img[r0:r1, :], axis=0) (lane_tracker.py:290, 310, 350) for band 0 = the start slice
+// [y_start, img_height) and bands 1..nlevels-1 = the level rows.  One thread per 4 columns
+// (dword loads, unconditional and batched), sums[frame][band][w] as u32.
+template <bool VEC4>
+__global__ __launch_bounds__(64) void k_band_sums(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+                                                 uint32_t* __restrict__ sums) {
+    const int band = blockIdx.y, frame = blockIdx.z;
+    const int r0 = band == 0 ? max(g.y_start, 0) : g.img_height - (1 + band) * g.wh;
+    const int r1 = band == 0 ? g.img_height : g.img_height - band * g.wh;
+    const uint8_t* m = masks + (size_t)frame * mask_stride;
+    uint32_t* out = sums + ((size_t)frame * g.nbands + band) * g.w;
+    if (VEC4) {
+        const int q = blockIdx.x * 64 + threadIdx.x, nq = g.w >> 2;
+        if (q >= nq) return;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        const uint32_t* col = reinterpret_cast<const uint32_t*>(m) + q;
+        int y = max(r0, 0);
+        for (; y + 8 <= r1; y += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(y + u) * nq];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0 += v[u] & 255u; a1 += (v[u] >> 8) & 255u; a2 += (v[u] >> 16) & 255u; a3 += v[u] >> 24; }
         }
+        for (; y < r1; ++y) {
+            const uint32_t v = col[(size_t)y * nq];
+            a0 += v & 255u; a1 += (v >> 8) & 255u; a2 += (v >> 16) & 255u; a3 += v >> 24;
+        }
+        reinterpret_cast<uint4*>(out)[q] = make_uint4(a0, a1, a2, a3);
+    } else {
+        const int x = blockIdx.x * 64 + threadIdx.x;
+        if (x >= g.w) return;
+        uint32_t acc = 0;
+        for (int y = max(r0, 0); y < r1; ++y) acc += m[(size_t)y * g.w + x];
+        out[x] = acc;
+    }
+}
+
+// copy n band sums (global) into LDS, coalesced and batched
+__device__ void load_sums(const uint32_t* __restrict__ src, int n, unsigned* dst) {
+    for (int base = threadIdx.x; base < n; base += NT * 4) {
+        unsigned v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[min(base + u * NT, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (base + u * NT < n) dst[base + u * NT] = v[u];
     }
     __syncthreads();
 }
@@ -152,59 +188,83 @@ struct Roi {
     int active, a, b;  // columns [a, b), already clipped; active = 0: no window on this level
 };
 
-// roi.nonzero() for the (up to) two windows of one level, rows [r0, r1): count pass, row offsets,
-// then an ordered write.  n_out[side] is advanced; moments and distinct-row counts accumulate.
+// Non-zero pixels of columns [a, b) of one row, in ascending x, through aligned dword loads.
+// EMIT = false: returns the count.  EMIT = true: writes packed (y<<16)|x from pix[idx], adds moments.
+template <bool EMIT, bool VEC4>
+__device__ __forceinline__ int roi_row(const uint8_t* __restrict__ row, int a, int b, int y, uint32_t* pix, int idx,
+                                       int maxpix, Moments& mom, int y0c, int x0c) {
+    int cnt = 0;
+    if (VEC4) {
+        const int xa = a & ~3, nd = (b - xa + 3) >> 2;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(row + xa);
+        for (int d0 = 0; d0 < nd; d0 += 4) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = p[min(d0 + u, nd - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (d0 + u >= nd) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = xa + (d0 + u) * 4 + j;
+                    if (((v[u] >> (8 * j)) & 255u) != 0 && x >= a && x < b) {
+                        if (EMIT) {
+                            if (idx + cnt < maxpix) pix[idx + cnt] = ((uint32_t)y << 16) | (uint32_t)x;
+                            mom.add(y, x, y0c, x0c);
+                        }
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    } else {
+        for (int x = a; x < b; ++x)
+            if (row[x] != 0) {
+                if (EMIT) {
+                    if (idx + cnt < maxpix) pix[idx + cnt] = ((uint32_t)y << 16) | (uint32_t)x;
+                    mom.add(y, x, y0c, x0c);
+                }
+                ++cnt;
+            }
+    }
+    return cnt;
+}
+
+// roi.nonzero() for the (up to) two windows of one level, rows [r0, r1): one thread per
+// (side, row) counts its row, offsets are a short serial sum, then the same thread emits its
+// pixels in order.  n_out[side] is advanced; moments and distinct-row counts accumulate.
+template <bool VEC4>
 __device__ void extract_windows(const uint8_t* mask, int w, int r0, int r1, const Roi* roi, unsigned* rowcnt,
                                 unsigned* rowoff, int wh_cap, uint32_t* pix, int maxpix, int* n_out, Moments* mom,
                                 int* distinct, int y0c, int x0c) {
-    const int lane = lane_id(), wv = wave_id(), nrows = r1 - r0;
-    // pass 1: per-row non-zero counts
-    for (int s = 0; s < 2; ++s) {
-        if (!roi[s].active) continue;
-        for (int ry = wv; ry < nrows; ry += NW) {
-            unsigned c = 0;
-            for (int x = roi[s].a + lane; x - lane < roi[s].b; x += 64) {
-                const bool nz = x < roi[s].b && mask[(size_t)(r0 + ry) * w + x] != 0;
-                c += __popcll(__ballot(nz));
-            }
-            if (lane == 0) rowcnt[s * wh_cap + ry] = c;
-        }
+    const int nrows = r1 - r0, pairs = 2 * nrows;
+    for (int pi = threadIdx.x; pi < pairs; pi += NT) {
+        const int s = pi >= nrows ? 1 : 0, ry = pi - s * nrows;
+        unsigned c = 0;
+        if (roi[s].active && roi[s].b > roi[s].a)
+            c = roi_row<false, VEC4>(mask + (size_t)(r0 + ry) * w, roi[s].a, roi[s].b, r0 + ry, nullptr, 0, 0, mom[s], y0c, x0c);
+        rowcnt[s * wh_cap + ry] = c;
     }
     __syncthreads();
-    // row offsets: exclusive scan over at most wh_cap rows, one thread per row (rows are few)
-    for (int s = 0; s < 2; ++s) {
-        if (!roi[s].active) continue;
-        for (int ry = threadIdx.x; ry <= nrows; ry += NT) {
-            unsigned acc = 0;
-            for (int q = 0; q < ry; ++q) acc += rowcnt[s * wh_cap + q];
-            rowoff[s * (wh_cap + 1) + ry] = acc;
-        }
+    for (int pi = threadIdx.x; pi < pairs + 2; pi += NT) {   // exclusive offsets; entry nrows = total
+        const int s = pi >= nrows + 1 ? 1 : 0, ry = pi - s * (nrows + 1);
+        unsigned acc = 0;
+        for (int q = 0; q < ry; ++q) acc += rowcnt[s * wh_cap + q];
+        rowoff[s * (wh_cap + 1) + ry] = acc;
     }
     __syncthreads();
-    // pass 2: ordered write
-    for (int s = 0; s < 2; ++s) {
+    for (int pi = threadIdx.x; pi < pairs; pi += NT) {
+        const int s = pi >= nrows ? 1 : 0, ry = pi - s * nrows;
+        if (roi[s].active && rowcnt[s * wh_cap + ry] != 0)
+            roi_row<true, VEC4>(mask + (size_t)(r0 + ry) * w, roi[s].a, roi[s].b, r0 + ry, pix + (size_t)s * maxpix,
+                                n_out[s] + (int)rowoff[s * (wh_cap + 1) + ry], maxpix, mom[s], y0c, x0c);
+    }
+    for (int s = 0; s < 2; ++s) {   // uniform bookkeeping (every thread keeps the same copy)
         if (!roi[s].active) continue;
-        const int base = n_out[s];
-        for (int ry = wv; ry < nrows; ry += NW) {
-            unsigned run = rowoff[s * (wh_cap + 1) + ry];
-            const int y = r0 + ry;
-            for (int x = roi[s].a + lane; x - lane < roi[s].b; x += 64) {
-                const bool nz = x < roi[s].b && mask[(size_t)y * w + x] != 0;
-                const unsigned long long bal = __ballot(nz);
-                if (nz) {
-                    const unsigned rank = __popcll(bal & ((1ull << lane) - 1ull));
-                    const int idx = base + (int)(run + rank);
-                    if (idx < maxpix) pix[(size_t)s * maxpix + idx] = ((uint32_t)y << 16) | (uint32_t)x;
-                    mom[s].add(y, x, y0c, x0c);
-                }
-                run += __popcll(bal);
-            }
-        }
-        // uniform bookkeeping (every thread keeps the same copy)
         int d = 0;
         for (int ry = 0; ry < nrows; ++ry) d += rowcnt[s * wh_cap + ry] != 0;
         distinct[s] += d;
-        n_out[s] = base + (int)rowoff[s * (wh_cap + 1) + nrows];
+        n_out[s] += (int)rowoff[s * (wh_cap + 1) + nrows];
     }
     __syncthreads();
 }
@@ -242,7 +302,9 @@ __device__ void reduce_and_fit(Moments* mom, const int* distinct, long long* s_m
 }
 
 // ---------------------------------------------------------------------------------------------------
+template <bool VEC4>
 __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+                                               const uint32_t* __restrict__ band_sums,
                                                uint32_t* __restrict__ pix_all, int32_t* __restrict__ cent_all,
                                                lt_lane_record* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -254,6 +316,7 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
 
     const int frame = blockIdx.x;
     const uint8_t* mask = masks + (size_t)frame * mask_stride;
+    const uint32_t* fsums = band_sums + (size_t)frame * g.nbands * g.w;   // [band][w], band 0 = start slice
     uint32_t* pix = pix_all + (size_t)frame * 2 * g.maxpix;
     int32_t* cent = cent_all + (size_t)frame * 2 * (g.maxlev + 2);   // [side][0] = count, then entries
     const int W = g.w, ww = g.ww, wh = g.wh, hw = g.hw, H1 = g.img_height;
@@ -276,7 +339,7 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
         bool found = false;
         int first = 0, last = 0;
         if (c1 > c0 && H1 > g.y_start) {
-            column_sums(mask, W, max(g.y_start, 0), H1, c0, c1, sums);
+            load_sums(fsums + c0, c1 - c0, sums);                    // :290 / :310
             wave0_exclusive_scan(sums, prefix, c1 - c0);
             __syncthreads();
             found = box_argmax(prefix, c1 - c0, ww, 0, (c1 - c0) + ww - 1, first, last);
@@ -299,12 +362,12 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
         hi[s] = g.search_range;
     }
     if (H1 - wh >= 0)
-        extract_windows(mask, W, H1 - wh, H1, roi, rowcnt, rowoff, wh, pix, g.maxpix, n_out, mom, distinct, y0c, x0c);
+        extract_windows<VEC4>(mask, W, H1 - wh, H1, roi, rowcnt, rowoff, wh, pix, g.maxpix, n_out, mom, distinct, y0c, x0c);
 
     // ---- levels 1 .. nlevels-1 (:346-430)
     for (int level = 1; level < g.nlevels; ++level) {
         const int r0 = H1 - (1 + level) * wh, r1 = H1 - level * wh;
-        column_sums(mask, W, r0, r1, 0, W, sums);                    // :350
+        load_sums(fsums + (size_t)level * W, W, sums);               // :350
         wave0_exclusive_scan(sums, prefix, W);
         __syncthreads();
         const int conv_len = W + ww - 1;                             // :351
@@ -344,7 +407,7 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
         }
         __syncthreads();
         if (roi[0].active || roi[1].active)
-            extract_windows(mask, W, r0, r1, roi, rowcnt, rowoff, wh, pix, g.maxpix, n_out, mom, distinct, y0c, x0c);
+            extract_windows<VEC4>(mask, W, r0, r1, roi, rowcnt, rowoff, wh, pix, g.maxpix, n_out, mom, distinct, y0c, x0c);
     }
     if (threadIdx.x == 0) {
         cent[0] = ncent[0];
@@ -510,12 +573,17 @@ void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, do
     hipLaunchKernelGGL(k_fit_list, dim3(1), dim3(NT), 0, s, pix, n, h, w, out4);
 }
 
-void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* pix,
-                    int32_t* cent, lt_lane_record* rec, int n) {
+void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* band_sums,
+                    uint32_t* pix, int32_t* cent, lt_lane_record* rec, int n) {
     if (n <= 0) return;
+    const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
+    dim3 sgrid(((vec4 ? g.w / 4 : g.w) + 63) / 64, g.nbands, n);
+    if (vec4) hipLaunchKernelGGL(k_band_sums<true>, sgrid, dim3(64), 0, s, masks, mask_stride, g, band_sums);
+    else hipLaunchKernelGGL(k_band_sums<false>, sgrid, dim3(64), 0, s, masks, mask_stride, g, band_sums);
     const size_t words = (size_t)(2 * g.w + 1 + 4 * g.wh + 2);
     const size_t lds = ((words * 4 + 15) & ~(size_t)15) + 16 * sizeof(long long);
-    hipLaunchKernelGGL(k_sws_fit, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, pix, cent, rec);
+    if (vec4) hipLaunchKernelGGL(k_sws_fit<true>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, band_sums, pix, cent, rec);
+    else hipLaunchKernelGGL(k_sws_fit<false>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, band_sums, pix, cent, rec);
 }
 
 void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,

@@ -1,0 +1,391 @@
+// Thresholds, merge and the 5x5 open of filter_lane_points(), on bit-packed planes, gfx950.
+//
+//   k_bilateral_tile  bilateral_adaptive_threshold x2 (+ greenery mask) + OR-merge
+//                     lane_tracker.py:14-83, 214-215, 221-235   -> 1 bit per pixel
+//   k_pack_merge      same merge for already-thresholded u8 planes ('neighborhood' branch, :217-218)
+//   k_erode5_bits / k_dilate5_mask   morphologyEx(MORPH_OPEN, 5x5 ellipse)   lane_tracker.py:205, 238
+//
+// Bit plane layout: row-major, `wpr` = ceil(w/64) 64-bit words per row, bit i of word j = pixel
+// x = 64*j + i.  A wave produces one word per row with a single ballot.
+//
+// Bilateral threshold: for a pixel p with k neighbours per side,
+//     pass  <=>  (k*p > S_left + C*k  and  k*p > S_right + C*k)  or  (same for up / down)
+// S_* are sums of the k pixels on that side, zero outside the image.
+//
+// One 256-thread workgroup owns a 64x64 tile.  Its cross-shaped neighbourhood is staged in LDS per
+// plane as a row band (64 rows x (64+2k) columns) and a column band ((64+2k) rows x 64 columns).
+// Each of the four waves then runs one sliding-window phase:
+//   H phase: lane <-> row.  The lane walks along x keeping S_left / S_right as running sums in
+//            registers (3 LDS byte reads per pixel) and shifts its 64 verdicts into one u64 -- which
+//            is exactly the bit-plane word of that row.  Row pitch is 4 x odd, so the 32 lanes of a
+//            DS lane group hit 32 different banks.
+//   V phase: lane <-> column, walking down y with S_up / S_down; one ballot per row gives the word.
+// R-top-hat H/V and b-top-hat H/V run concurrently on the 4 waves; the words are OR-ed at the end
+// (plus the greenery term, lane_tracker.py:223-231, in a second round when mask_noise is on).
+#include "lt_internal.h"
+
+namespace lt {
+namespace {
+
+constexpr int TW = 64, TH = 64;
+
+struct BilateralPlane {
+    const uint8_t* src;  // nullptr: plane unused
+    int k, C;
+};
+
+struct BilateralArgs {
+    BilateralPlane pl[3];   // [0] R top-hat, [1] Lab-b top-hat, [2] raw Lab-b for the greenery mask (optional)
+    int noise_thresh;
+    int h, w, wpr;
+    int tiles_x, tiles_y, ntiles;      // per-frame tile grid and the total over all frames
+    size_t plane_stride, bits_stride;  // bytes per frame of the u8 planes / u64 words per frame of the bit plane
+};
+
+// Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).  Remap
+// the linear id so that each XCD gets one contiguous range of tiles: neighbouring tiles share
+// their halo through that XCD's L2 instead of fetching it once per XCD.  Bijective for any n.
+__device__ __forceinline__ int xcd_contiguous(int id, int n) {
+    const int q = n >> 3, r = n & 7, xcd = id & 7, k = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+__host__ __device__ __forceinline__ int hband_pitch(int k) {   // >= 64 + 2k, multiple of 4, (pitch/4) odd
+    int p = (TW + 2 * k + 3 + 3) & ~3;   // up to 3 extra columns on the left from aligning the band start
+    if (((p >> 2) & 1) == 0) p += 4;
+    return p;
+}
+__host__ __device__ __forceinline__ int plane_lds_bytes(int k) { return TH * hband_pitch(k) + (TH + 2 * k + 1) * TW; }
+
+__device__ long long g_dbg_cycles[16];
+
+__global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigned long long* __restrict__ bits) {
+    const long long t_begin = clock64();
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_words[7][TH];   // [2q] H words, [2q+1] V words of plane q; [6] inRange words
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = xcd_contiguous(blockIdx.x, a.ntiles);
+    const int frame = tile / (a.tiles_x * a.tiles_y), tin = tile - frame * (a.tiles_x * a.tiles_y);
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const size_t fo = (size_t)frame * a.plane_stride;
+    const int x0 = txi * TW, y0 = tyi * TH;
+
+    // ---- stage the bands of every active plane (zero outside the image = BORDER_CONSTANT 0) ----
+    // The row band starts at the 4-aligned column xa <= x0-k, so that (for w % 4 == 0) every band
+    // dword is one aligned global dword, entirely inside or entirely outside the image.
+    uint8_t* hband[3];
+    uint8_t* vband[3];
+    int koff[3];   // index of tile column 0 inside the row band (k .. k+3)
+    int off = 0;
+    const bool aligned = (a.w & 3) == 0 && (a.plane_stride & 3) == 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        hband[q] = vband[q] = nullptr;
+        koff[q] = 0;
+        if (!a.pl[q].src) continue;
+        const int k = a.pl[q].k, pitch = hband_pitch(k);
+        const int xa = (x0 - k) & ~3;
+        koff[q] = x0 - xa;
+        hband[q] = smem + off;
+        vband[q] = hband[q] + TH * pitch;
+        off += plane_lds_bytes(k);
+        const uint8_t* s = a.pl[q].src + fo;
+        if (aligned) {
+            // Loads are unconditional on clamped addresses and masked afterwards: a guarded load
+            // compiles to branch + load + s_waitcnt vmcnt(0) and serialises the whole staging loop.
+            const int dpr = pitch >> 2;                                   // dwords per band row
+            uint32_t* hb = reinterpret_cast<uint32_t*>(hband[q]);
+            const int nh = TH * dpr;
+            for (int base = threadIdx.x; base < nh; base += 256 * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = min(base + u * 256, nh - 1);
+                    const int r = i / dpr, cd = i - r * dpr;
+                    const int gy = y0 + r, gx = xa + cd * 4;
+                    const bool in = gy < a.h && gx >= 0 && gx < a.w;
+                    const uint32_t t = *reinterpret_cast<const uint32_t*>(s + (size_t)min(gy, a.h - 1) * a.w + min(max(gx, 0), a.w - 4));
+                    v[u] = in ? t : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (base + u * 256 < nh) hb[base + u * 256] = v[u];
+            }
+            uint32_t* vb = reinterpret_cast<uint32_t*>(vband[q]);
+            const int nv = (TH + 2 * k) * (TW / 4);
+            for (int base = threadIdx.x; base < nv; base += 256 * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = min(base + u * 256, nv - 1);
+                    const int r = i >> 4, cd = i & 15;
+                    const int gy = y0 - k + r, gx = x0 + cd * 4;
+                    const bool in = gy >= 0 && gy < a.h && gx < a.w;
+                    const uint32_t t = *reinterpret_cast<const uint32_t*>(s + (size_t)min(max(gy, 0), a.h - 1) * a.w + min(gx, a.w - 4));
+                    v[u] = in ? t : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (base + u * 256 < nv) vb[base + u * 256] = v[u];
+            }
+        } else {
+            for (int r = wv; r < TH; r += 4) {                            // row band: rows y0+r, columns xa+c
+                const int gy = y0 + r;
+                for (int c = lane; c < pitch; c += 64) {
+                    const int gx = xa + c;
+                    hband[q][r * pitch + c] = (gy < a.h && gx >= 0 && gx < a.w) ? s[(size_t)gy * a.w + gx] : 0;
+                }
+            }
+            const int gx = x0 + lane;
+            for (int r = wv; r < TH + 2 * k; r += 4) {                    // column band: rows y0-k+r, columns x0+lane
+                const int gy = y0 - k + r;
+                vband[q][r * TW + lane] = (gx < a.w && gy >= 0 && gy < a.h) ? s[(size_t)gy * a.w + gx] : 0;
+            }
+        }
+    }
+    __syncthreads();
+    const long long t_staged = clock64();
+
+    // ---- sliding-window phases: phase 2q = H of plane q, 2q+1 = V of plane q ----
+    for (int ph = wv; ph < 6; ph += 4) {
+        const int q = ph >> 1;
+        if (!a.pl[q].src) continue;
+        const int k = a.pl[q].k, C = a.pl[q].C, Ck = C * k;
+        if ((ph & 1) == 0) {
+            // lane <-> row; b[c] <-> column x0-k+c (the band itself starts up to 3 columns earlier)
+            const uint8_t* b = hband[q] + lane * hband_pitch(k) + (koff[q] - k);
+            int sl = 0, sr = 0;
+#pragma unroll 8
+            for (int c = 0; c < k; ++c) { sl += b[c]; sr += b[k + 1 + c]; }
+            unsigned long long word = 0;
+#pragma unroll 8
+            for (int t = 0; t < TW - 1; ++t) {
+                const int p = b[k + t];
+                const int thr = k * p - Ck;
+                word |= (unsigned long long)(sl < thr && sr < thr) << t;
+                sl += p - b[t];                      // slide both windows one column to the right
+                sr += b[2 * k + 1 + t] - b[k + 1 + t];
+            }
+            {
+                const int p = b[k + TW - 1];
+                const int thr = k * p - Ck;
+                word |= (unsigned long long)(sl < thr && sr < thr) << (TW - 1);
+            }
+            s_words[ph][lane] = word;
+        } else {
+            const uint8_t* b = vband[q] + lane;                    // lane <-> column; b[r*64] <-> row y0-k+r
+            int su = 0, sd = 0;
+#pragma unroll 8
+            for (int r = 0; r < k; ++r) { su += b[r * TW]; sd += b[(k + 1 + r) * TW]; }
+            unsigned long long mine = 0, mine_range = 0;
+#pragma unroll 8
+            for (int t = 0; t < TH; ++t) {
+                const int p = b[(k + t) * TW];
+                const int thr = k * p - Ck;
+                const unsigned long long bal = __ballot(su < thr && sd < thr);
+                if (lane == t) mine = bal;
+                if (q == 2) {                                       // inRange(lab_b, noise_thresh, 255)
+                    const unsigned long long br = __ballot(p >= a.noise_thresh);
+                    if (lane == t) mine_range = br;
+                }
+                // slide both windows one row down; the band has one spare row so that the last,
+                // unused update stays inside it
+                su += p - b[t * TW];
+                sd += b[(2 * k + 1 + t) * TW] - b[(k + 1 + t) * TW];
+            }
+            s_words[ph][lane] = mine;
+            if (q == 2) s_words[6][lane] = mine_range;
+        }
+    }
+    const long long t_phase = clock64();
+    __syncthreads();
+    if (a.noise_thresh == -12345 && (threadIdx.x & 63) == 0) {   // timing probe (tools/dbg only)
+        atomicAdd((unsigned long long*)&g_dbg_cycles[wv], (unsigned long long)(t_staged - t_begin));
+        atomicAdd((unsigned long long*)&g_dbg_cycles[4 + wv], (unsigned long long)(t_phase - t_staged));
+        atomicAdd((unsigned long long*)&g_dbg_cycles[8 + wv], 1ull);
+    }
+    if (threadIdx.x < TH) {
+        const int r = threadIdx.x, gy = y0 + r;
+        if (gy < a.h) {
+            unsigned long long m = 0;
+            if (a.pl[0].src) m |= s_words[0][r] | s_words[1][r];
+            if (a.pl[1].src) m |= s_words[2][r] | s_words[3][r];
+            if (a.pl[2].src) m &= ~s_words[6][r] | s_words[4][r] | s_words[5][r];   // (r|b) & (!part1 | part2)
+            const int nvalid = a.w - x0;
+            if (nvalid < 64) m &= (1ull << nvalid) - 1ull;
+            bits[(size_t)frame * a.bits_stride + (size_t)gy * a.wpr + txi] = m;
+        }
+    }
+}
+
+// merge of already-thresholded u8 planes into the bit plane
+__global__ __launch_bounds__(256) void k_pack_merge(const uint8_t* __restrict__ tr, const uint8_t* __restrict__ tb,
+                                                   const uint8_t* __restrict__ labb, const uint8_t* __restrict__ nb,
+                                                   int noise_thresh, int use_noise, int h, int w, int wpr,
+                                                   size_t plane_stride, size_t bits_stride,
+                                                   unsigned long long* __restrict__ bits) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int word = blockIdx.x * 4 + wv, y = blockIdx.y;
+    if (word >= wpr) return;
+    const int x = word * 64 + lane;
+    const size_t o = (size_t)blockIdx.z * plane_stride + (size_t)y * w + x;
+    bool v = false;
+    if (x < w) {
+        v = tr[o] || tb[o];
+        if (use_noise) v = v && (!(labb[o] >= noise_thresh) || nb[o]);
+    }
+    const unsigned long long b = __ballot(v);
+    if (lane == 0) bits[(size_t)blockIdx.z * bits_stride + (size_t)y * wpr + word] = b;
+}
+
+// ---- 5x5 ellipse on bit planes: rows -2,+2 contribute the centre column, rows -1,0,+1 five columns ----
+__device__ __forceinline__ unsigned long long load_word(const unsigned long long* p, int y, int j, int h, int wpr,
+                                                       unsigned long long outside) {
+    return (y >= 0 && y < h && j >= 0 && j < wpr) ? p[(size_t)y * wpr + j] : outside;
+}
+
+template <bool DIL>
+__device__ __forceinline__ unsigned long long hspan5(unsigned long long l, unsigned long long m,
+                                                    unsigned long long r) {
+    const unsigned long long a1 = (m << 1) | (l >> 63), a2 = (m << 2) | (l >> 62);
+    const unsigned long long b1 = (m >> 1) | (r << 63), b2 = (m >> 2) | (r << 62);
+    return DIL ? (m | a1 | a2 | b1 | b2) : (m & a1 & a2 & b1 & b2);
+}
+
+// valid-pixel mask of word j (pixels >= w do not exist)
+__device__ __forceinline__ unsigned long long valid_bits(int j, int w) {
+    const int n = w - j * 64;
+    return n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+}
+
+// erode: out-of-image taps are ignored = treated as set.  Output bits beyond w are cleared.
+__global__ __launch_bounds__(256) void k_erode5_bits(const unsigned long long* __restrict__ in,
+                                                    unsigned long long* __restrict__ out, int h, int w, int wpr,
+                                                    size_t bits_stride) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= h * wpr) return;
+    const int y = idx / wpr, j = idx - y * wpr;
+    const unsigned long long* p = in + (size_t)blockIdx.z * bits_stride;
+    auto ld = [&](int yy, int jj) {
+        unsigned long long v = load_word(p, yy, jj, h, wpr, ~0ull);
+        if (yy >= 0 && yy < h && jj >= 0 && jj < wpr) v |= ~valid_bits(jj, w);   // pixels past the right edge count as set
+        return v;
+    };
+    unsigned long long e = ld(y - 2, j) & ld(y + 2, j);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) e &= hspan5<false>(ld(y + dy, j - 1), ld(y + dy, j), ld(y + dy, j + 1));
+    out[(size_t)blockIdx.z * bits_stride + idx] = e & valid_bits(j, w);
+}
+
+// dilate of the eroded bits (out-of-image = clear) and expansion to the u8 {0,255} mask.
+// A block owns DR rows: its threads first build the dilated words of those rows in LDS, then
+// every thread expands 4 pixels at a time into one coalesced dword store.
+constexpr int DR = 16, DW_MAX = 64;   // rows per block, max words per row handled by the LDS buffer (w <= 4096)
+__global__ __launch_bounds__(256) void k_dilate5_mask(const unsigned long long* __restrict__ in,
+                                                     uint8_t* __restrict__ mask, int h, int w, int wpr,
+                                                     size_t bits_stride, size_t plane_stride) {
+    __shared__ unsigned long long s_d[DR * DW_MAX];
+    const int yb = blockIdx.x * DR, rows = min(DR, h - yb);
+    const unsigned long long* p = in + (size_t)blockIdx.z * bits_stride;
+    auto ld = [&](int yy, int jj) { return load_word(p, yy, jj, h, wpr, 0ull); };
+    for (int i = threadIdx.x; i < rows * wpr; i += 256) {
+        const int r = i / wpr, j = i - r * wpr, y = yb + r;
+        unsigned long long d = ld(y - 2, j) | ld(y + 2, j);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) d |= hspan5<true>(ld(y + dy, j - 1), ld(y + dy, j), ld(y + dy, j + 1));
+        s_d[r * wpr + j] = d;
+    }
+    __syncthreads();
+    uint8_t* out = mask + (size_t)blockIdx.z * plane_stride;
+    if ((w & 3) == 0 && (plane_stride & 3) == 0) {
+        const int qpr = w >> 2;   // dwords per row
+        for (int i = threadIdx.x; i < rows * qpr; i += 256) {
+            const int r = i / qpr, qd = i - r * qpr, x = qd * 4;
+            const unsigned nib = (unsigned)(s_d[r * wpr + (x >> 6)] >> (x & 63)) & 0xfu;
+            // 4 bits -> 4 bytes of 0x00 / 0xff
+            const unsigned spread = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+            reinterpret_cast<uint32_t*>(out + (size_t)(yb + r) * w)[qd] = spread * 0xffu;
+        }
+    } else {
+        for (int i = threadIdx.x; i < rows * w; i += 256) {
+            const int r = i / w, x = i - r * w;
+            out[(size_t)(yb + r) * w + x] = ((s_d[r * wpr + (x >> 6)] >> (x & 63)) & 1ull) ? 255 : 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bits_to_u8(const unsigned long long* __restrict__ in, uint8_t* __restrict__ out,
+                                                   int h, int w, int wpr, size_t bits_stride, size_t plane_stride) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wv, y = blockIdx.y;
+    if (j >= wpr) return;
+    const unsigned long long d = in[(size_t)blockIdx.z * bits_stride + (size_t)y * wpr + j];
+    const int x = j * 64 + lane;
+    if (x < w) out[(size_t)blockIdx.z * plane_stride + (size_t)y * w + x] = ((d >> lane) & 1ull) ? 255 : 0;
+}
+
+}  // namespace
+
+void debug_read_cycles(long long out[16], bool reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_cycles), sizeof(long long) * 16);
+    if (reset) { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_cycles), z, sizeof z); }
+}
+
+int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
+                          const uint8_t* labb, int k_n, int C_n, int noise_thresh, int use_noise,
+                          unsigned long long* bits, int h, int w, size_t plane_stride, size_t bits_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    BilateralArgs a;
+    a.pl[0] = {thr, k_r, C_r};
+    a.pl[1] = {thb, k_b, C_b};
+    a.pl[2] = {use_noise ? labb : nullptr, k_n, C_n};
+    a.noise_thresh = noise_thresh;
+    a.h = h;
+    a.w = w;
+    a.wpr = (w + 63) / 64;
+    a.plane_stride = plane_stride;
+    a.bits_stride = bits_stride;
+    size_t lds = 0;
+    for (int q = 0; q < 3; ++q)
+        if (a.pl[q].src) lds += (size_t)plane_lds_bytes(a.pl[q].k);
+    if (lds + sizeof(unsigned long long) * 7 * TH > 160 * 1024) return -1;  // caller runs one plane at a time
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return -1;
+    a.tiles_x = (w + TW - 1) / TW;
+    a.tiles_y = (h + TH - 1) / TH;
+    a.ntiles = a.tiles_x * a.tiles_y * n;
+    hipLaunchKernelGGL(k_bilateral_tile, dim3(a.ntiles), dim3(256), lds, s, a, bits);
+    return 0;
+}
+
+void launch_pack_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uint8_t* labb, const uint8_t* nb,
+                       int noise_thresh, int use_noise, unsigned long long* bits, int h, int w, size_t plane_stride,
+                       size_t bits_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return;
+    const int wpr = (w + 63) / 64;
+    dim3 grid((wpr + 3) / 4, h, n);
+    hipLaunchKernelGGL(k_pack_merge, grid, dim3(256), 0, s, tr, tb, labb, nb, noise_thresh, use_noise, h, w, wpr,
+                       plane_stride, bits_stride, bits);
+}
+
+void launch_open5_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded, uint8_t* mask, int h,
+                       int w, size_t plane_stride, size_t bits_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return;
+    const int wpr = (w + 63) / 64;
+    hipLaunchKernelGGL(k_erode5_bits, dim3((h * wpr + 255) / 256, 1, n), dim3(256), 0, s, merged, eroded, h, w, wpr,
+                       bits_stride);
+    hipLaunchKernelGGL(k_dilate5_mask, dim3((h + DR - 1) / DR, 1, n), dim3(256), 0, s, eroded, mask, h, w, wpr, bits_stride,
+                       plane_stride);
+}
+
+void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,
+                       size_t bits_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return;
+    const int wpr = (w + 63) / 64;
+    hipLaunchKernelGGL(k_bits_to_u8, dim3((wpr + 3) / 4, h, n), dim3(256), 0, s, bits, out, h, w, wpr, bits_stride,
+                       plane_stride);
+}
+
+}  // namespace lt

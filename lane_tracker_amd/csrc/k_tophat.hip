@@ -133,16 +133,17 @@ struct RunsGeom {
     size_t plane_stride;
 };
 
+// one chain entry = pixels (col_a, col_a + 64) of a row, packed.  The loads are unconditional on
+// clamped addresses and masked afterwards, so that they can stay in flight across the chain
+// (a guarded load compiles to branch + load + s_waitcnt vmcnt(0)).
 template <class SE>
 __device__ __forceinline__ uint32_t load_entry(const uint8_t* __restrict__ row, bool row_ok, int col_a, int w,
                                               uint32_t neutral) {
     const int col_b = col_a + 64;
     const uint32_t n8 = neutral & 0xffu;  // `neutral` is the packed pair; each half defaults to the 8-bit value
-    uint32_t a = n8, b = n8;
-    if (row_ok) {
-        if (col_a >= 0 && col_a < w) a = row[col_a];
-        if (col_b >= 0 && col_b < w) b = row[col_b];
-    }
+    const uint32_t ra = row[min(max(col_a, 0), w - 1)], rb = row[min(max(col_b, 0), w - 1)];
+    const uint32_t a = (row_ok && col_a >= 0 && col_a < w) ? ra : n8;
+    const uint32_t b = (row_ok && col_b >= 0 && col_b < w) ? rb : n8;
     return a | (b << 16);
 }
 

@@ -59,13 +59,18 @@ struct lt_ctx {
     // slots
     int capacity = 0;
     size_t frame_bytes = 0, und_bytes = 0, plane_bytes = 0, bev_bytes = 0;
-    uint8_t *d_frames = nullptr, *d_und = nullptr, *d_bev = nullptr;
+    uint8_t *d_frames = nullptr, *d_bev = nullptr;
+    uint32_t* d_und = nullptr;        // undistorted camera rows [r0, r0+nrows), one RGBX dword per pixel
+    size_t und_px = 0;                // pixels per slot of d_und
     uint8_t* d_plane[P_COUNT] = {};
+    unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
+    size_t bits_stride = 0;                                                  // u64 words per slot
     lt_lane_record* d_rec = nullptr;
     double* d_prev = nullptr;
     uint32_t* d_pix = nullptr;
     int32_t* d_cent = nullptr;
-    int maxpix = 0, maxlev = 0;
+    uint32_t* d_band_sums = nullptr;  // [slot][band][warp_w] column sums of the search bands
+    int maxpix = 0, maxlev = 0, maxbands = 0;
     bool have_mask = false;
     bool brute_tophat = false;
     // timing
@@ -152,10 +157,14 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_und);
     dev_free(c->d_bev);
     for (auto& p : c->d_plane) dev_free(p);
+    dev_free(c->d_bits_merged);
+    dev_free(c->d_bits_eroded);
     dev_free(c->d_rec);
     dev_free(c->d_prev);
     dev_free(c->d_pix);
     dev_free(c->d_cent);
+    dev_free(c->d_band_sums);
+    c->maxbands = 0;
     c->capacity = 0;
     c->maxpix = 0;
     c->maxlev = 0;
@@ -194,8 +203,8 @@ int validate_filter(const lt_filter_params* p) {
         return fail(LT_ERR_INVALID, "filter sizes must be >= 1");
     if (p->filter_type == 1 && ((p->ksize_r & 1) == 0 || (p->ksize_b & 1) == 0))
         return fail(LT_ERR_INVALID, "'neighborhood' block sizes must be odd (cv2.adaptiveThreshold requirement)");
-    if (p->ksize_r > 400 || p->ksize_b > 400 || p->ksize_noise > 400)
-        return fail(LT_ERR_INVALID, "filter size too large (max 400)");
+    if (p->ksize_r > 128 || p->ksize_b > 128 || p->ksize_noise > 128)
+        return fail(LT_ERR_INVALID, "filter size too large (max 128)");
     return LT_OK;
 }
 
@@ -225,23 +234,35 @@ int run_filter_chain(lt_ctx* c, int first, int n, const lt_filter_params* p, int
             { StageScope t(c, ST_ERODE_B);  launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n); }
             { StageScope t(c, ST_TOPHAT_B); launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n); }
         }
-        { StageScope t(c, ST_THRESHOLD);
-          launch_bilateral(s, thR, t1, h, w, p->ksize_r, p->C_r, 0, 255, 0, ps, n);
-          launch_bilateral(s, thB, t2, h, w, p->ksize_b, p->C_b, 0, 255, 0, ps, n); }
+    }
+    unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
+    unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
+    bool merged_done = false;
+    if (p->filter_type == 0) {
+        StageScope t(c, ST_THRESHOLD);   // both bilateral thresholds, the greenery mask and the OR-merge in one kernel
+        merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
+                                            p->C_noise, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps,
+                                            c->bits_stride, n) == 0;
+        if (!merged_done) {              // tile + halo exceeds the LDS: one plane at a time
+            launch_bilateral(s, thR, t1, h, w, p->ksize_r, p->C_r, 0, 255, 0, ps, n);
+            launch_bilateral(s, thB, t2, h, w, p->ksize_b, p->C_b, 0, 255, 0, ps, n);
+        }
     } else {
         StageScope t(c, ST_THRESHOLD);
         launch_adaptive_mean(s, R, t1, h, w, p->ksize_r, p->C_r, ps, n);
         launch_adaptive_mean(s, B, t2, h, w, p->ksize_b, p->C_b, ps, n);
     }
-    if (p->mask_noise) {
-        StageScope t(c, ST_THRESHOLD);
-        launch_bilateral(s, B, t3, h, w, p->ksize_noise, p->C_noise, 0, 255, 0, ps, n);
+    if (!merged_done) {
+        if (p->mask_noise) {
+            StageScope t(c, ST_THRESHOLD);
+            launch_bilateral(s, B, t3, h, w, p->ksize_noise, p->C_noise, 0, 255, 0, ps, n);
+        }
+        StageScope t(c, ST_MERGE);
+        launch_pack_merge(s, t1, t2, B, t3, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps, c->bits_stride, n);
     }
-    { StageScope t(c, ST_MERGE);
-      launch_merge(s, t1, t2, B, t3, p->noise_thresh, p->mask_noise ? 1 : 0, merged, (size_t)h * w, ps, n); }
     { StageScope t(c, ST_OPEN);
-      launch_morph_ellipse(s, merged, t0, nullptr, h, w, c->se5, false, ps, n);
-      launch_morph_ellipse(s, t0, mask, nullptr, h, w, c->se5, true, ps, n); }
+      launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n); }
+    (void)merged; (void)t0;
     HIP_TRY(hipGetLastError());
     return LT_OK;
 }
@@ -286,6 +307,7 @@ int make_search_geom(lt_ctx* c, const lt_search_params* p, bool band, SearchGeom
     const long long need = (long long)std::max(g.nlevels, 1) * g.wh * std::min(2 * g.hw, w);
     g.maxpix = (int)std::max<long long>(need, 64);
     g.maxlev = std::max(g.nlevels, 1) + 1;
+    g.nbands = std::max(g.nlevels, 1);
     return LT_OK;
 }
 
@@ -308,8 +330,8 @@ const char* lt_stage_name(int stage) { return stage >= 0 && stage < LT_NUM_STAGE
 int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     if (!calib || !out) return fail(LT_ERR_INVALID, "null argument");
     if (calib->img_w < 2 || calib->img_h < 2 || calib->warp_w < 2 || calib->warp_h < 2 || calib->img_w > 16384 ||
-        calib->img_h > 16384 || calib->warp_w > 16384 || calib->warp_h > 16384)
-        return fail(LT_ERR_INVALID, "image sizes must be in [2, 16384]");
+        calib->img_h > 16384 || calib->warp_w > 4096 || calib->warp_h > 16384)
+        return fail(LT_ERR_INVALID, "camera size must be in [2, 16384], bird's-eye width in [2, 4096], height in [2, 16384]");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(LT_ERR_HIP, "no HIP device visible: the lane-tracker kernels need a GPU (gfx950)");
@@ -374,7 +396,8 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     if (e != hipSuccess) return bail(fail(LT_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
 
     c->frame_bytes = (size_t)calib->img_h * calib->img_w * 3;
-    c->und_bytes = (size_t)c->fe.nrows * calib->img_w * 3;
+    c->und_bytes = (size_t)c->fe.nrows * calib->img_w * 3;   // as returned by lt_download_undistorted (RGB)
+    c->und_px = (size_t)c->fe.nrows * calib->img_w;
     c->plane_bytes = (size_t)calib->warp_h * calib->warp_w;
     c->bev_bytes = c->plane_bytes * 3;
     *out = c;
@@ -411,9 +434,12 @@ int lt_reserve(lt_ctx* c, int capacity) {
     c->capacity = capacity;
     const size_t n = (size_t)capacity;
     if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes))) { free_slots(c); return rc; }
-    if ((rc = dev_alloc(&c->d_und, n * c->und_bytes))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_und, n * c->und_px))) { free_slots(c); return rc; }
     for (int i = 0; i < P_COUNT; ++i)
         if ((rc = dev_alloc(&c->d_plane[i], n * c->plane_bytes))) { free_slots(c); return rc; }
+    c->bits_stride = (size_t)c->calib.warp_h * ((c->calib.warp_w + 63) / 64);
+    if ((rc = dev_alloc(&c->d_bits_merged, n * c->bits_stride))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_bits_eroded, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_prev, n * 6))) { free_slots(c); return rc; }
     c->capacity = capacity;
@@ -503,6 +529,12 @@ int lt_download_plane(lt_ctx* c, int plane, int first, int n, uint8_t* out) {
     if (rc) return rc;
     static const int map[6] = {P_R, P_B, P_THR, P_THB, P_MERGED, P_MASK};
     if (plane < 0 || plane > 5) return fail(LT_ERR_INVALID, "unknown plane %d", plane);
+    if (plane == LT_PLANE_MERGED) {   // kept bit-packed on the device; expand on demand
+        if ((rc = set_device(c))) return rc;
+        launch_bits_to_u8(c->stream, c->d_bits_merged + (size_t)first * c->bits_stride,
+                          c->d_plane[P_MERGED] + (size_t)first * c->plane_bytes, c->calib.warp_h, c->calib.warp_w,
+                          c->plane_bytes, c->bits_stride, n);
+    }
     return download(c, c->d_plane[map[plane]] + (size_t)first * c->plane_bytes, out, (size_t)n * c->plane_bytes);
 }
 
@@ -514,7 +546,7 @@ int lt_download_undistorted(lt_ctx* c, int first, int n, uint8_t* out) {
     if ((rc = set_device(c))) return rc;
     uint8_t* tmp = nullptr;
     if ((rc = dev_alloc(&tmp, (size_t)n * c->und_bytes))) return rc;
-    launch_undistorted_to_rgb(c->stream, c->d_und + (size_t)first * c->und_bytes, c->und_bytes, c->fe.nrows,
+    launch_undistorted_to_rgb(c->stream, c->d_und + (size_t)first * c->und_px, c->und_px, c->fe.nrows,
                               c->fe.img_w, tmp, n);
     rc = download(c, tmp, out, (size_t)n * c->und_bytes);
     dev_free(tmp);
@@ -597,9 +629,9 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     const size_t ps = c->plane_bytes;
     { StageScope t(c, ST_UNDISTORT);
       launch_undistort_rows(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->frame_bytes, c->d_uxy,
-                            c->d_ufrac, c->fe, c->d_und + (size_t)first * c->und_bytes, c->und_bytes, n); }
+                            c->d_ufrac, c->fe, c->d_und + (size_t)first * c->und_px, c->und_px, n); }
     { StageScope t(c, ST_WARP_SPLIT);
-      launch_warp_split(c->stream, c->d_und + (size_t)first * c->und_bytes, c->und_bytes, c->d_wxy, c->d_wfrac, c->fe,
+      launch_warp_split(c->stream, c->d_und + (size_t)first * c->und_px, c->und_px, c->d_wxy, c->d_wfrac, c->fe,
                         c->d_gamma, c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)first * ps,
                         c->d_plane[P_B] + (size_t)first * ps, ps, n); }
     if ((rc = run_filter_chain(c, first, n, p, c->calib.warp_h, c->calib.warp_w))) return rc;
@@ -631,12 +663,18 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     SearchGeom g;
     if ((rc = make_search_geom(c, p, false, g))) return rc;
     if ((rc = ensure_search_buffers(c, g.maxpix, g.maxlev))) return rc;
+    if (g.nbands > c->maxbands) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dev_free(c->d_band_sums);
+        if ((rc = dev_alloc(&c->d_band_sums, (size_t)c->capacity * g.nbands * c->calib.warp_w))) return rc;
+        c->maxbands = g.nbands;
+    }
     g.maxpix = c->maxpix;
     g.maxlev = c->maxlev;
     if (n == 0) return LT_OK;
     { StageScope t(c, ST_SWS_FIT);
       launch_sws_fit(c->stream, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, g,
-                     c->d_pix + (size_t)first * 2 * c->maxpix, c->d_cent + (size_t)first * 2 * (c->maxlev + 2),
+                     c->d_band_sums + (size_t)first * g.nbands * c->calib.warp_w, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_cent + (size_t)first * 2 * (c->maxlev + 2),
                      c->d_rec + first, n); }
     HIP_TRY(hipGetLastError());
     return LT_OK;
@@ -696,7 +734,7 @@ int lt_bilateral_adaptive_threshold(lt_ctx* c, const uint8_t* img, int h, int w,
                                     int fv, uint8_t* out) {
     if (!c || !img || !out) return fail(LT_ERR_INVALID, "null argument");
     if (mode != 0 && mode != 1) return fail(LT_ERR_INVALID, "Unexpected mode value. Expected value is 'floor' or 'ceil'.");
-    if (h < 1 || w < 1 || ksize < 1 || ksize > 400) return fail(LT_ERR_INVALID, "bad image size or ksize");
+    if (h < 1 || w < 1 || ksize < 1 || ksize > 128) return fail(LT_ERR_INVALID, "bad image size or ksize (1..128)");
     if (tv < 0 || tv > 255 || fv < 0 || fv > 255) return fail(LT_ERR_INVALID, "true/false values must be in [0,255]");
     int rc = set_device(c);
     if (rc) return rc;
@@ -721,7 +759,7 @@ int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_
     if (!c || !bev || !mask) return fail(LT_ERR_INVALID, "null argument");
     int rc = validate_filter(p);
     if (rc) return rc;
-    if (h < 1 || w < 1 || h > 16384 || w > 16384) return fail(LT_ERR_INVALID, "bad image size");
+    if (h < 1 || w < 1 || h > 16384 || w > 4096) return fail(LT_ERR_INVALID, "bad image size (width <= 4096, height <= 16384)");
     if ((rc = set_device(c))) return rc;
     // a private one-slot arena of the requested size (the image may differ from the calibration's BEV size)
     lt_ctx tmp;
@@ -730,16 +768,21 @@ int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_
     tmp.se5 = c->se5; tmp.se29 = c->se29; tmp.se55 = c->se55;
     tmp.brute_tophat = c->brute_tophat;
     tmp.plane_bytes = (size_t)h * w;
+    tmp.bits_stride = (size_t)h * ((w + 63) / 64);
     tmp.capacity = 1;
     uint8_t* d_bev = nullptr;
     auto cleanup = [&]() {
         for (auto& q : tmp.d_plane) dev_free(q);
+        dev_free(tmp.d_bits_merged);
+        dev_free(tmp.d_bits_eroded);
         dev_free(d_bev);
         tmp.stream = nullptr;
     };
     for (int i = 0; i < P_COUNT; ++i)
         if ((rc = dev_alloc(&tmp.d_plane[i], tmp.plane_bytes))) { cleanup(); return rc; }
     if ((rc = dev_alloc(&d_bev, tmp.plane_bytes * 3))) { cleanup(); return rc; }
+    if ((rc = dev_alloc(&tmp.d_bits_merged, tmp.bits_stride))) { cleanup(); return rc; }
+    if ((rc = dev_alloc(&tmp.d_bits_eroded, tmp.bits_stride))) { cleanup(); return rc; }
     hipError_t e = hipMemcpyAsync(d_bev, bev, tmp.plane_bytes * 3, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         launch_split_bev(c->stream, d_bev, tmp.plane_bytes * 3, (int)tmp.plane_bytes, c->d_gamma, c->d_cbrt, c->d_coef,
@@ -813,6 +856,15 @@ int lt_fit_poly2(lt_ctx* c, const int32_t* ys, const int32_t* xs, int n, int h, 
     if (e != hipSuccess) return fail(LT_ERR_HIP, "fit_poly2 failed: %s", hipGetErrorString(e));
     coef[0] = out[0]; coef[1] = out[1]; coef[2] = out[2];
     *rank_deficient = out[3] != 0.0;
+    return LT_OK;
+}
+
+// undocumented probe used by tools/dbg_*.py (not part of the public header)
+extern "C" int lt_debug_cycles(lt_ctx* c, long long* out16, int reset) {
+    if (!c || !out16) return LT_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    debug_read_cycles(out16, reset != 0);
     return LT_OK;
 }
 

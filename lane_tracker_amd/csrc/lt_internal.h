@@ -33,14 +33,14 @@ struct FrontEndGeom {
     int img_h, img_w, warp_h, warp_w, r0, nrows;
 };
 void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
-                           const uint16_t* ufrac, FrontEndGeom g, uint8_t* und, size_t und_stride, int n);
-void launch_warp_split(hipStream_t s, const uint8_t* und, size_t und_stride, const int16_t* wxy,
+                           const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_stride_px, int n);
+void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy,
                        const uint16_t* wfrac, FrontEndGeom g, const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
                        const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB, size_t plane_stride, int n);
 void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int npix, const uint16_t* gamma_tab,
                       const uint16_t* cbrt_tab, const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB,
                       size_t plane_stride, int n);
-void launch_undistorted_to_rgb(hipStream_t s, const uint8_t* und, size_t und_stride, int nrows, int w, uint8_t* out,
+void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, int nrows, int w, uint8_t* out,
                                int n);
 
 // dst = erode/dilate(src) with the ellipse; if minuend != nullptr: dst = sat(minuend - result)
@@ -58,18 +58,33 @@ void launch_adaptive_mean(hipStream_t s, const uint8_t* src, uint8_t* dst, int h
 void launch_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uint8_t* labb, const uint8_t* noise_bil,
                   int noise_thresh, int use_noise, uint8_t* merged, size_t npix, size_t plane_stride, int n);
 
+// bit-plane path (k_threshold.hip): fused bilateral thresholds + merge, u8->bits merge, 5x5 open on bits
+int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
+                          const uint8_t* labb, int k_n, int C_n, int noise_thresh, int use_noise,
+                          unsigned long long* bits, int h, int w, size_t plane_stride, size_t bits_stride, int n);
+void launch_pack_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uint8_t* labb, const uint8_t* nb,
+                       int noise_thresh, int use_noise, unsigned long long* bits, int h, int w, size_t plane_stride,
+                       size_t bits_stride, int n);
+void launch_open5_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded, uint8_t* mask, int h,
+                       int w, size_t plane_stride, size_t bits_stride, int n);
+void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,
+                       size_t bits_stride, int n);
+
+void debug_read_cycles(long long out[16], bool reset);
+
 struct SearchGeom {
     int h, w;                    // mask size
     int ww, wh, hw;              // window
     int img_height;              // h - ignore_bottom
     int img_center, y_start, nlevels, limit;
+    int nbands;                  // column-sum bands per frame: max(nlevels, 1); band 0 = start slice
     int ignore_sides, search_range, def_left, def_right;
     int band_top, band_bottom;   // band search rows [top, bottom)
     double mu, bandwidth;
     int maxpix, maxlev;
 };
-void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* pix,
-                    int32_t* cent, lt_lane_record* rec, int n);
+void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* band_sums,
+                    uint32_t* pix, int32_t* cent, lt_lane_record* rec, int n);
 void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
                      uint32_t* pix, lt_lane_record* rec, int n);
 

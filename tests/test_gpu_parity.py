@@ -73,17 +73,22 @@ def test_front_end_bit_exact(ctx, oracle, ref_calib, frames):
 
 @pytest.mark.parametrize("kw", [dict(), dict(filter_type="neighborhood", C_r=5),
                                 dict(mask_noise=True), dict(ksize_r=20, C_r=5),
-                                dict(filter_type="neighborhood", ksize_r=3, ksize_b=7, C_r=0, C_b=1)],
-                         ids=["bilateral_default", "neighborhood_try2", "mask_noise", "demo2", "neighborhood_small"])
+                                dict(filter_type="neighborhood", ksize_r=3, ksize_b=7, C_r=0, C_b=1),
+                                dict(filter_type="neighborhood", mask_noise=True, noise_thresh=120),
+                                dict(ksize_r=100, C_r=2, ksize_b=128, C_b=1), dict(ksize_r=1, C_r=0, ksize_b=2, C_b=0)],
+                         ids=["bilateral_default", "neighborhood_try2", "mask_noise", "demo2", "neighborhood_small",
+                              "neighborhood_noise", "huge_k_fallback", "tiny_k"])
 def test_mask_chain_bit_exact(ctx, nat, oracle, ref_calib, frames, kw):
     n = frames.shape[0]
     ctx.upload_frames(frames)
     ctx.mask_run(n, nat.filter_params(**kw))
     masks = ctx.download_masks(n)
     thr, thb = ctx.download_plane(2, n), ctx.download_plane(3, n)
+    merged = ctx.download_plane(4, n)
     for k in range(n):
         bev = oracle.front_end(ref_calib, frames[k])
         want, planes = oracle.filter_lane_points(bev, oracle.filter_params(**kw), want_planes=True)
+        assert_same(oracle.morph_open(merged[k], 5), want, f"open(merged plane), frame {k}")
         if kw.get("filter_type", "bilateral") == "bilateral":
             assert_same(thr[k], planes[2], f"tophat R, frame {k}")
             assert_same(thb[k], planes[3], f"tophat b, frame {k}")
