@@ -1,0 +1,68 @@
+"""The N > 1 path on CPU: world_size-2 gloo processes shard a block of frames, compute their lane
+records and all-gather them; the gathered array must equal the single-process result bit for bit
+(SURVEY.md section 8(e)).  Record computation here is the oracle (test infrastructure): the
+sharding and the collective are what is under test -- the GPU compute is covered by -m gpu."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from lane_tracker_amd import _native, distributed
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 256, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            spans = [distributed.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(distributed.shard_sizes(n, world)) - min(distributed.shard_sizes(n, world)) <= 1
+    with pytest.raises(ValueError):
+        distributed.shard_range(10, 2, 2)
+
+
+def _records_for(indices):
+    """Deterministic stand-in workload: seeded masks -> oracle search + fit -> lane records."""
+    from lane_tracker_amd import synth
+    from oracle import oracle as O
+    rec = np.zeros(len(indices), _native.RECORD_DTYPE)
+    for j, i in enumerate(indices):
+        mask = synth.synth_mask(1000 + i, noise=1e-3)[0]
+        r = O.sliding_window_search(mask)
+        rec[j]["detected"] = r["detected"]
+        rec[j]["n_left"], rec[j]["n_right"] = len(r["left_x"]), len(r["right_x"])
+        if r["detected"]:
+            rec[j]["left_coeffs"] = O.polyfit2(r["left_y"], r["left_x"])
+            rec[j]["right_coeffs"] = O.polyfit2(r["right_y"], r["right_x"])
+        rec[j]["frame"] = i
+    return rec
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = distributed.shard_range(n_frames, rank, world)
+        local = _records_for(range(lo, hi))
+        allrec = distributed.gather_records(local, n_frames)
+        np.save(os.path.join(out_dir, f"rank{rank}.npy"), allrec)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [5, 6])
+def test_two_rank_gather_equals_single_process(tmp_path, n_frames):
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
+    want = _records_for(range(n_frames))
+    for rank in range(2):
+        got = np.load(os.path.join(str(tmp_path), f"rank{rank}.npy"))
+        assert got.dtype == _native.RECORD_DTYPE and got.shape == want.shape
+        assert got.tobytes() == want.tobytes()          # bitwise, frame order preserved
+        assert got["frame"].tolist() == list(range(n_frames))
