@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigne
     const long long t_begin = clock64();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_words[7][TH];   // [2q] H words, [2q+1] V words of plane q; [6] inRange words
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
     const int tile = xcd_contiguous(blockIdx.x, a.ntiles);
     const int frame = tile / (a.tiles_x * a.tiles_y), tin = tile - frame * (a.tiles_x * a.tiles_y);
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
@@ -91,42 +91,45 @@ __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigne
         off += plane_lds_bytes(k);
         const uint8_t* s = a.pl[q].src + fo;
         if (aligned) {
-            // Loads are unconditional on clamped addresses and masked afterwards: a guarded load
-            // compiles to branch + load + s_waitcnt vmcnt(0) and serialises the whole staging loop.
-            const int dpr = pitch >> 2;                                   // dwords per band row
+            // Loads are unconditional on clamped addresses and masked afterwards (a guarded load
+            // compiles to branch + load + s_waitcnt vmcnt(0) and serialises the staging loop), and
+            // the thread -> (row, dword) mapping needs no division: lane <-> dword column, wave <-> row.
+            const int dpr = pitch >> 2;                                   // dwords per band row (<= 81)
             uint32_t* hb = reinterpret_cast<uint32_t*>(hband[q]);
-            const int nh = TH * dpr;
-            for (int base = threadIdx.x; base < nh; base += 256 * 8) {
-                uint32_t v[8];
+            for (int cd0 = 0; cd0 < dpr; cd0 += 64) {
+                const int cd = min(cd0 + lane, dpr - 1), gx = xa + cd * 4;
+                const bool xin = gx >= 0 && gx < a.w && cd0 + lane < dpr;
+                const uint8_t* colp = s + min(max(gx, 0), a.w - 4);
+                for (int r0 = wv; r0 < TH; r0 += 32) {                    // 8 rows of this wave per batch
+                    uint32_t v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = min(base + u * 256, nh - 1);
-                    const int r = i / dpr, cd = i - r * dpr;
-                    const int gy = y0 + r, gx = xa + cd * 4;
-                    const bool in = gy < a.h && gx >= 0 && gx < a.w;
-                    const uint32_t t = *reinterpret_cast<const uint32_t*>(s + (size_t)min(gy, a.h - 1) * a.w + min(max(gx, 0), a.w - 4));
-                    v[u] = in ? t : 0u;
+                    for (int u = 0; u < 8; ++u) {
+                        const int gy = y0 + r0 + 4 * u;
+                        v[u] = *reinterpret_cast<const uint32_t*>(colp + (size_t)min(gy, a.h - 1) * a.w);
+                        v[u] = (xin && gy < a.h) ? v[u] : 0u;
+                    }
+                    if (cd0 + lane < dpr) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) hb[(r0 + 4 * u) * dpr + cd] = v[u];
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (base + u * 256 < nh) hb[base + u * 256] = v[u];
             }
             uint32_t* vb = reinterpret_cast<uint32_t*>(vband[q]);
-            const int nv = (TH + 2 * k) * (TW / 4);
-            for (int base = threadIdx.x; base < nv; base += 256 * 8) {
+            const int nrows = TH + 2 * k, cdv = lane & 15, rsub = wv * 4 + (lane >> 4);   // 16 rows per block pass
+            const int gxv = x0 + cdv * 4;
+            const bool xinv = gxv < a.w;
+            const uint8_t* colv = s + min(gxv, a.w - 4);
+            for (int r0 = rsub; r0 < nrows; r0 += 16 * 8) {
                 uint32_t v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int i = min(base + u * 256, nv - 1);
-                    const int r = i >> 4, cd = i & 15;
-                    const int gy = y0 - k + r, gx = x0 + cd * 4;
-                    const bool in = gy >= 0 && gy < a.h && gx < a.w;
-                    const uint32_t t = *reinterpret_cast<const uint32_t*>(s + (size_t)min(max(gy, 0), a.h - 1) * a.w + min(gx, a.w - 4));
-                    v[u] = in ? t : 0u;
+                    const int gy = y0 - k + r0 + 16 * u;
+                    v[u] = *reinterpret_cast<const uint32_t*>(colv + (size_t)min(max(gy, 0), a.h - 1) * a.w);
+                    v[u] = (xinv && gy >= 0 && gy < a.h) ? v[u] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (base + u * 256 < nv) vb[base + u * 256] = v[u];
+                    if (r0 + 16 * u < nrows) vb[(r0 + 16 * u) * 16 + cdv] = v[u];
             }
         } else {
             for (int r = wv; r < TH; r += 4) {                            // row band: rows y0+r, columns xa+c

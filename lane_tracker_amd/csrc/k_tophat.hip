@@ -21,6 +21,8 @@
 //     of the window is free because the instruction has a separate destination -- and A[0] is a
 //     finished output row.
 // Out-of-image taps are neutral (255 for erode, 0 for dilate), as in OpenCV's default border.
+#include <cstdlib>
+
 #include "lt_internal.h"
 
 namespace lt {
@@ -133,18 +135,33 @@ struct RunsGeom {
     size_t plane_stride;
 };
 
-// one chain entry = pixels (col_a, col_a + 64) of a row, packed.  The loads are unconditional on
-// clamped addresses and masked afterwards, so that they can stay in flight across the chain
-// (a guarded load compiles to branch + load + s_waitcnt vmcnt(0)).
-template <class SE>
-__device__ __forceinline__ uint32_t load_entry(const uint8_t* __restrict__ row, bool row_ok, int col_a, int w,
-                                              uint32_t neutral) {
-    const int col_b = col_a + 64;
-    const uint32_t n8 = neutral & 0xffu;  // `neutral` is the packed pair; each half defaults to the 8-bit value
-    const uint32_t ra = row[min(max(col_a, 0), w - 1)], rb = row[min(max(col_b, 0), w - 1)];
-    const uint32_t a = (row_ok && col_a >= 0 && col_a < w) ? ra : n8;
-    const uint32_t b = (row_ok && col_b >= 0 && col_b < w) ? rb : n8;
-    return a | (b << 16);
+// Per-lane column bookkeeping, loop invariant: clamped byte offsets of the (up to) four pixels a
+// lane fetches per row, and which of them exist.  Loads are unconditional on the clamped offsets
+// and masked afterwards, so they stay in flight across the chain (a guarded load compiles to
+// branch + load + s_waitcnt vmcnt(0)).
+struct LaneCols {
+    int off[4];        // entry 0: (a, a+64); entry 1: (a+64, a+128)
+    uint32_t keep[2];  // per entry: 0xffff / 0xffff0000 bits set where the pixel exists
+    uint32_t fill[2];  // per entry: neutral value in the halves that do not exist
+};
+
+__device__ __forceinline__ LaneCols lane_cols(int col0, int w, bool second, uint32_t n8) {
+    LaneCols c;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int ca = col0 + 64 * e, cb = ca + 64;
+        const bool va = ca >= 0 && ca < w && (e == 0 || second), vb = cb >= 0 && cb < w && (e == 0 || second);
+        c.off[2 * e] = min(max(ca, 0), w - 1);
+        c.off[2 * e + 1] = min(max(cb, 0), w - 1);
+        c.keep[e] = (va ? 0xffffu : 0u) | (vb ? 0xffff0000u : 0u);
+        c.fill[e] = (va ? 0u : n8) | (vb ? 0u : (n8 << 16));
+    }
+    return c;
+}
+
+__device__ __forceinline__ uint32_t fetch_entry(const uint8_t* __restrict__ row, const LaneCols& c, int e) {
+    const uint32_t a = row[c.off[2 * e]], b = row[c.off[2 * e + 1]];
+    return ((a | (b << 16)) & c.keep[e]) | c.fill[e];
 }
 
 // DIL = false: dst = erode(src);  DIL = true: dst = dilate(src), or minuend - dilate(src) (top-hat)
@@ -155,7 +172,9 @@ __global__ __launch_bounds__(256) void k_morph_runs(const uint8_t* __restrict__ 
     constexpr int K = SE::K, R = SE::R, NH = SE::NH;
     constexpr uint32_t NEUTRAL = DIL ? 0u : 0x00ff00ffu;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int task = blockIdx.x * 4 + wv;
+    // wave-uniform by construction; readfirstlane tells the compiler, so that the row loop, its bounds
+    // and every row base address live in SGPRs and the loads take the scalar-base + lane-offset form
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
     if (task >= g.ntasks) return;  // whole wave exits together; no block-level barriers are used
     const int strip = task % g.nstrips;
     const int band = (task / g.nstrips) % g.nbands;
@@ -167,53 +186,211 @@ __global__ __launch_bounds__(256) void k_morph_runs(const uint8_t* __restrict__ 
     const int x0 = strip * 128;
     const int yb0 = band * g.band_rows, yb1 = min(yb0 + g.band_rows, g.h);
     const int xa = x0 + lane, xb = xa + 64;
+    const bool va = xa < g.w, vb = xb < g.w;
+    const int oa = min(xa, g.w - 1), ob = min(xb, g.w - 1);   // clamped output / minuend columns
 
     uint32_t A[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) A[j] = NEUTRAL;
 
     const int y_first = yb0 - R, y_last = yb1 - 1 + R;
-    const bool second = lane + 64 < 64 + 2 * R;  // does this lane own a second chain entry?
-    // software prefetch of the next row's raw entries
-    bool ok = y_first >= 0 && y_first < g.h;
-    uint32_t e0 = load_entry<SE>(s + (size_t)max(y_first, 0) * g.w, ok, x0 - R + lane, g.w, NEUTRAL);
-    uint32_t e1 = second ? load_entry<SE>(s + (size_t)max(y_first, 0) * g.w, ok, x0 - R + lane + 64, g.w, NEUTRAL) : NEUTRAL;
+    const LaneCols cols = lane_cols(x0 - R + lane, g.w, lane + 64 < 64 + 2 * R, NEUTRAL & 0xffu);
+    // software prefetch: the raw entries of the next input row and the minuend of the next output row
+    const uint8_t* row = s + (size_t)min(max(y_first, 0), g.h - 1) * g.w;
+    uint32_t e0 = fetch_entry(row, cols, 0), e1 = fetch_entry(row, cols, 1);
+    uint32_t ma = 0, mb = 0;
     for (int yy = y_first; yy <= y_last; ++yy) {
-        chain[MARGIN + lane] = e0;
-        chain[MARGIN + lane + 64] = e1;
-        wave_lds_fence();
         const bool in_img = yy >= 0 && yy < g.h;
-        // issue the next row's loads before the chain so that their latency overlaps it
-        const int yn = yy + 1;
-        const bool okn = yn >= 0 && yn < g.h && yn <= y_last;
-        const uint8_t* rown = s + (size_t)min(max(yn, 0), g.h - 1) * g.w;
-        e0 = load_entry<SE>(rown, okn, x0 - R + lane, g.w, NEUTRAL);
-        e1 = second ? load_entry<SE>(rown, okn, x0 - R + lane + 64, g.w, NEUTRAL) : NEUTRAL;
+        chain[MARGIN + lane] = in_img ? e0 : NEUTRAL;
+        chain[MARGIN + lane + 64] = in_img ? e1 : NEUTRAL;
+        wave_lds_fence();
+        // issue the next iteration's loads before the chain so that their latency overlaps it
+        row = s + (size_t)min(max(yy + 1, 0), g.h - 1) * g.w;
+        e0 = fetch_entry(row, cols, 0);
+        e1 = fetch_entry(row, cols, 1);
+        const int y = yy - R;                  // the output row this iteration completes
+        const uint32_t ma_cur = ma, mb_cur = mb;
+        if (m) {
+            const uint8_t* mrow = m + (size_t)min(max(y + 1, 0), g.h - 1) * g.w;
+            ma = mrow[oa];
+            mb = mrow[ob];
+        }
 
         uint32_t H[NH];
-        if (in_img) {
-            SE::template row_windows<DIL>(chain, lane, H);
-        } else {
-#pragma unroll
-            for (int i = 0; i < NH; ++i) H[i] = NEUTRAL;
-        }
+        // rows outside the image enter the chain as all-neutral entries and come out neutral: no branch
+        SE::template row_windows<DIL>(chain, lane, H);
         wave_lds_fence();  // the chain planes are rewritten by the next iteration
 #pragma unroll
         for (int j = 0; j < K - 1; ++j) A[j] = pk<DIL>(A[j + 1], H[SE::slot(j)]);
         A[K - 1] = H[SE::slot(K - 1)];
-        const int y = yy - R;
         if (y >= yb0 && y < yb1) {
-            const uint32_t va = A[0] & 0xffffu, vb = A[0] >> 16;
-            const size_t o = (size_t)y * g.w;
-            if (xa < g.w) {
-                uint32_t v = va;
-                if (m) { const uint32_t mm = m[o + xa]; v = mm > v ? mm - v : 0u; }
-                d[o + xa] = (uint8_t)v;
+            uint32_t oa_v = A[0] & 0xffffu, ob_v = A[0] >> 16;
+            if (m) {   // TOPHAT: src - open(src), saturating
+                oa_v = ma_cur > oa_v ? ma_cur - oa_v : 0u;
+                ob_v = mb_cur > ob_v ? mb_cur - ob_v : 0u;
             }
-            if (xb < g.w) {
-                uint32_t v = vb;
-                if (m) { const uint32_t mm = m[o + xb]; v = mm > v ? mm - v : 0u; }
-                d[o + xb] = (uint8_t)v;
+            const size_t o = (size_t)y * g.w;
+            if (va) d[o + xa] = (uint8_t)oa_v;
+            if (vb) d[o + xb] = (uint8_t)ob_v;
+        }
+    }
+}
+
+// ================================================================================================
+// Two input rows per iteration, 3-input packed min/max.
+//
+// gfx950 has v_pk_minimum3_f16 / v_pk_maximum3_f16.  A u8 value v stored as the 16-bit pattern
+// 0x0400 | v is a positive *normal* f16 number, and positive f16 numbers order exactly like their
+// bit patterns, so the f16 min/max of such patterns is the integer min/max, bit for bit (the result
+// is always one of the inputs).  Processing rows (yy, yy+1) together turns two accumulator steps
+//     A1[j] = min(A[j+1], Ha[s(j)]);  A2[j] = min(A1[j+1], Hb[s(j)])
+// into one instruction  A2[j] = min3(A[j+2], Ha[s(j+1)], Hb[s(j)])  for two pixels: 27.5 instead of
+// 54 accumulate ops per row, and half the loop overhead and LDS round trips per row.
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t BIAS2 = 0x04000400u;
+
+template <bool DIL>
+__device__ __forceinline__ uint32_t op2(uint32_t a, uint32_t b) {
+    const h16x2 x = __builtin_bit_cast(h16x2, a), y = __builtin_bit_cast(h16x2, b);
+    return __builtin_bit_cast(uint32_t, DIL ? __builtin_elementwise_maximum(x, y) : __builtin_elementwise_minimum(x, y));
+}
+template <bool DIL>
+__device__ __forceinline__ uint32_t op3(uint32_t a, uint32_t b, uint32_t c) {
+    const h16x2 x = __builtin_bit_cast(h16x2, a), y = __builtin_bit_cast(h16x2, b), z = __builtin_bit_cast(h16x2, c);
+    return __builtin_bit_cast(uint32_t, DIL ? __builtin_elementwise_maximum(x, __builtin_elementwise_maximum(y, z))
+                                            : __builtin_elementwise_minimum(x, __builtin_elementwise_minimum(y, z)));
+}
+template <bool DIL>
+__device__ __forceinline__ uint2 op2v(uint2 a, uint2 b) { return make_uint2(op2<DIL>(a.x, b.x), op2<DIL>(a.y, b.y)); }
+template <bool DIL>
+__device__ __forceinline__ uint2 op3v(uint2 a, uint2 b, uint2 c) {
+    return make_uint2(op3<DIL>(a.x, b.x, c.x), op3<DIL>(a.y, b.y, c.y));
+}
+
+// Chain of one row PAIR: entries are uint2 (.x = row yy, .y = row yy+1).  With 3-input ops the
+// chain is shorter than in the one-row kernel: half-widths 0 -> 1 -> 4 -> 13 (55x55) or
+// 0 -> 1 -> 4 -> 7 (29x29), i.e. three dependent LDS round trips.  A window of half-width d is
+// the union of 2 or 3 shifted windows of a chain plane:
+//   from S4  (hw 4):  d = 4 + t  as {p-t, p+t}          for t <= 4,  as {p-t, p, p+t} for t <= 9
+//   from S13 (hw 13): d = 13 + t as {p-t, p+t}          for t <= 13, as {p-t, p, p+t} for t = 14
+//   from S7  (hw 7):  d = 7 + t  as {p-t, p+t}          for t <= 7
+// Valid entry ranges (55x55, entries 0..117): S1 [1,116], S4 [4,113], S13 [13,104]; the lane's own
+// entries p = 27..90 read S13 at p +- 14 and S4 at p +- 8.  (29x29, entries 0..91): S1 [1,90],
+// S4 [4,87], S7 [7,84]; p = 14..77 reads S7 at p +- 7.
+template <class SE, bool DIL>
+__device__ __forceinline__ void row_windows2(uint2* s, int lane, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH]) {
+    uint2* S0 = s + MARGIN;
+    uint2* S1 = S0 + PLANE;
+    uint2* S4 = S0 + 2 * PLANE;
+    uint2* SL = S0 + 3 * PLANE;   // S13 (55x55) or S7 (29x29)
+    const int pa = lane, pb = lane + 64;
+    S1[pa] = op3v<DIL>(S0[pa - 1], S0[pa], S0[pa + 1]);
+    S1[pb] = op3v<DIL>(S0[pb - 1], S0[pb], S0[pb + 1]);
+    wave_lds_fence();
+    S4[pa] = op3v<DIL>(S1[pa - 3], S1[pa], S1[pa + 3]);
+    S4[pb] = op3v<DIL>(S1[pb - 3], S1[pb], S1[pb + 3]);
+    wave_lds_fence();
+    const int p = SE::R + lane;
+    uint2 t;
+    if (SE::K == 55) {
+        SL[pa] = op3v<DIL>(S4[pa - 9], S4[pa], S4[pa + 9]);
+        SL[pb] = op3v<DIL>(S4[pb - 9], S4[pb], S4[pb + 9]);
+        wave_lds_fence();
+        const uint2 c4 = S4[p], c13 = SL[p];
+        t = S0[p];                                         Ha[0] = t.x; Hb[0] = t.y;    // 0
+        t = op2v<DIL>(S4[p - 3], S4[p + 3]);               Ha[1] = t.x; Hb[1] = t.y;    // 7
+        t = op3v<DIL>(S4[p - 6], c4, S4[p + 6]);           Ha[2] = t.x; Hb[2] = t.y;    // 10
+        t = op3v<DIL>(S4[p - 8], c4, S4[p + 8]);           Ha[3] = t.x; Hb[3] = t.y;    // 12
+        t = op2v<DIL>(SL[p - 1], SL[p + 1]);               Ha[4] = t.x; Hb[4] = t.y;    // 14
+#pragma unroll
+        for (int q = 3; q <= 13; ++q) { t = op2v<DIL>(SL[p - q], SL[p + q]); Ha[2 + q] = t.x; Hb[2 + q] = t.y; }   // 16..26
+        t = op3v<DIL>(SL[p - 14], c13, SL[p + 14]);        Ha[16] = t.x; Hb[16] = t.y;  // 27
+    } else {
+        SL[pa] = op2v<DIL>(S4[pa - 3], S4[pa + 3]);
+        SL[pb] = op2v<DIL>(S4[pb - 3], S4[pb + 3]);
+        wave_lds_fence();
+        t = S0[p];                                         Ha[0] = t.x; Hb[0] = t.y;    // 0
+        t = op2v<DIL>(S4[p - 1], S4[p + 1]);               Ha[1] = t.x; Hb[1] = t.y;    // 5
+        t = SL[p];                                         Ha[2] = t.x; Hb[2] = t.y;    // 7
+#pragma unroll
+        for (int q = 2; q <= 7; ++q) { t = op2v<DIL>(SL[p - q], SL[p + q]); Ha[1 + q] = t.x; Hb[1 + q] = t.y; }   // 9..14
+    }
+}
+
+template <class SE, bool DIL>
+__global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                    const uint8_t* __restrict__ minuend, RunsGeom g) {
+    __shared__ uint2 s_chain[4][4 * PLANE];   // S0, S1, S4, S13|S7
+    constexpr int K = SE::K, R = SE::R, NH = SE::NH;
+    constexpr uint32_t NEUTRAL = (DIL ? 0u : 0x00ff00ffu) | BIAS2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);   // wave-uniform: keeps the loop scalar
+    if (task >= g.ntasks) return;
+    const int strip = task % g.nstrips;
+    const int band = (task / g.nstrips) % g.nbands;
+    const int frame = task / (g.nstrips * g.nbands);
+    const uint8_t* s = src + (size_t)frame * g.plane_stride;
+    uint8_t* d = dst + (size_t)frame * g.plane_stride;
+    const uint8_t* m = minuend ? minuend + (size_t)frame * g.plane_stride : nullptr;
+    uint2* chain = s_chain[wv];
+    const int x0 = strip * 128;
+    const int yb0 = band * g.band_rows, yb1 = min(yb0 + g.band_rows, g.h);
+    const int xa = x0 + lane, xb = xa + 64;
+    const bool va = xa < g.w, vb = xb < g.w;
+    const int oa = min(xa, g.w - 1), ob = min(xb, g.w - 1);
+
+    uint32_t A[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) A[j] = NEUTRAL;
+
+    const int y_first = yb0 - R, y_last = yb1 - 1 + R;
+    const LaneCols cols = lane_cols(x0 - R + lane, g.w, lane + 64 < 64 + 2 * R, DIL ? 0u : 0xffu);
+    auto row_ptr = [&](int y) { return s + (size_t)min(max(y, 0), g.h - 1) * g.w; };
+    auto rows_ok = [&](int y) { return y >= 0 && y < g.h; };
+    // software prefetch: raw entries of the next row pair, minuend of the next output row pair
+    uint32_t ea0 = fetch_entry(row_ptr(y_first), cols, 0), ea1 = fetch_entry(row_ptr(y_first), cols, 1);
+    uint32_t eb0 = fetch_entry(row_ptr(y_first + 1), cols, 0), eb1 = fetch_entry(row_ptr(y_first + 1), cols, 1);
+    uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // minuend (xa, xb) of output rows y and y+1
+    for (int yy = y_first; yy <= y_last; yy += 2) {
+        const bool ina = rows_ok(yy), inb = rows_ok(yy + 1);
+        chain[MARGIN + lane] = make_uint2(ina ? (ea0 | BIAS2) : NEUTRAL, inb ? (eb0 | BIAS2) : NEUTRAL);
+        chain[MARGIN + lane + 64] = make_uint2(ina ? (ea1 | BIAS2) : NEUTRAL, inb ? (eb1 | BIAS2) : NEUTRAL);
+        wave_lds_fence();
+        ea0 = fetch_entry(row_ptr(yy + 2), cols, 0);
+        ea1 = fetch_entry(row_ptr(yy + 2), cols, 1);
+        eb0 = fetch_entry(row_ptr(yy + 3), cols, 0);
+        eb1 = fetch_entry(row_ptr(yy + 3), cols, 1);
+        const int y = yy - R;                       // output rows y and y+1 complete in this iteration
+        const uint32_t ca0 = ma0, cb0 = mb0, ca1 = ma1, cb1 = mb1;
+        if (m) {
+            const uint8_t* r0 = m + (size_t)min(max(y + 2, 0), g.h - 1) * g.w;
+            const uint8_t* r1 = m + (size_t)min(max(y + 3, 0), g.h - 1) * g.w;
+            ma0 = r0[oa]; mb0 = r0[ob];
+            ma1 = r1[oa]; mb1 = r1[ob];
+        }
+        uint32_t Ha[NH], Hb[NH];
+        row_windows2<SE, DIL>(chain, lane, Ha, Hb);
+        wave_lds_fence();   // the chain planes are rewritten by the next iteration
+        const uint32_t out_a = op2<DIL>(A[1], Ha[SE::slot(0)]);                       // row y
+#pragma unroll
+        for (int j = 0; j < K - 2; ++j) A[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
+        A[K - 2] = op2<DIL>(Ha[SE::slot(K - 1)], Hb[SE::slot(K - 2)]);
+        A[K - 1] = Hb[SE::slot(K - 1)];
+        const uint32_t out_b = A[0];                                                  // row y + 1
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int yo = y + rr;
+            if (yo >= yb0 && yo < yb1) {
+                const uint32_t o2 = rr == 0 ? out_a : out_b;
+                uint32_t oa_v = o2 & 0xffu, ob_v = (o2 >> 16) & 0xffu;
+                if (m) {   // TOPHAT: src - open(src), saturating
+                    const uint32_t qa = rr == 0 ? ca0 : ca1, qb = rr == 0 ? cb0 : cb1;
+                    oa_v = qa > oa_v ? qa - oa_v : 0u;
+                    ob_v = qb > ob_v ? qb - ob_v : 0u;
+                }
+                const size_t o = (size_t)yo * g.w;
+                if (va) d[o + xa] = (uint8_t)oa_v;
+                if (vb) d[o + xb] = (uint8_t)ob_v;
             }
         }
     }
@@ -243,10 +420,14 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.nbands = (h + g.band_rows - 1) / g.band_rows;
     g.ntasks = n * g.nstrips * g.nbands;
     dim3 grid((g.ntasks + 3) / 4);
-    if (dilate)
-        hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
-    else
-        hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
+    static const bool one_row = [] { const char* e = std::getenv("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
+    if (one_row) {   // previous formulation (one row per iteration, u16 min/max), kept for A/B measurements
+        if (dilate) hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
+        else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
+    } else {
+        if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
+        else hipLaunchKernelGGL((k_morph_runs2<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
+    }
 }
 
 }  // namespace
