@@ -22,6 +22,9 @@
 //   V phase: lane <-> column, walking down y with S_up / S_down; one ballot per row gives the word.
 // R-top-hat H/V and b-top-hat H/V run concurrently on the 4 waves; the words are OR-ed at the end
 // (plus the greenery term, lane_tracker.py:223-231, in a second round when mask_noise is on).
+#include <algorithm>
+#include <cstdlib>
+
 #include "lt_internal.h"
 
 namespace lt {
@@ -221,6 +224,211 @@ __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigne
     }
 }
 
+// ================================================================================================
+// Packed variant (default): 128x128 tile, two rows (H) / two columns (V) per lane in one VGPR.
+//
+// All window sums are < 2^15 for k <= 128 (k*255 <= 32640), so they live in 16-bit halves and the
+// whole test is packed 16-bit arithmetic:   thr = k*p - C*k  (v_pk_mad_i16),
+//   d = (S_a - thr) & (S_b - thr)  -> the sign bit of each half says "both sides below thr".
+// H phase (lane <-> rows l and l+64, walking 64 columns): the two sign bits are shifted into a
+// packed pair of 16-bit shift registers (2 ops per step for both rows); every 16 steps the
+// registers are flushed into the lane's two 64-bit row words.  V phase (lane <-> columns l and
+// l+64, walking 64 rows): one ballot per half gives the two row words of that row.
+// The four waves run H(cols 0-63), H(cols 64-127), V(rows 0-63), V(rows 64-127) of one plane
+// concurrently; planes are processed one after the other and OR-ed into LDS accumulators.
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2t __attribute__((ext_vector_type(2)));
+constexpr int T2 = 128;
+
+__host__ __device__ __forceinline__ int hband2_pitch(int k) {   // >= 128 + 2k + 3, multiple of 4, (pitch/4) odd
+    int p = (T2 + 2 * k + 3 + 3) & ~3;
+    if (((p >> 2) & 1) == 0) p += 4;
+    return p;
+}
+__host__ __device__ __forceinline__ int plane2_lds_bytes(int k) { return T2 * hband2_pitch(k) + (T2 + 2 * k + 1) * T2; }
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) + __builtin_bit_cast(u16x2t, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) - __builtin_bit_cast(u16x2t, b)));
+}
+__device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) * __builtin_bit_cast(u16x2t, b)));
+}
+__device__ __forceinline__ uint32_t pk_shr1(uint32_t a) {
+    return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) >> (u16x2t){1, 1}));
+}
+
+struct Bilateral2Args {
+    BilateralPlane pl[3];
+    int noise_thresh;
+    int h, w, wpr;
+    int tiles_x, tiles_y, ntiles;
+    size_t plane_stride, bits_stride;
+};
+
+__global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsigned long long* __restrict__ bits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_or[T2][2];      // (R | b) verdict words: [row][column half]
+    __shared__ unsigned long long s_noise[T2][2];   // bilateral verdict of the raw Lab-b plane (greenery part 2)
+    __shared__ unsigned long long s_range[T2][2];   // inRange(lab_b, noise_thresh, 255)             (part 1)
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = xcd_contiguous(blockIdx.x, a.ntiles);
+    const int frame = tile / (a.tiles_x * a.tiles_y), tin = tile - frame * (a.tiles_x * a.tiles_y);
+    const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
+    const size_t fo = (size_t)frame * a.plane_stride;
+    const int x0 = txi * T2, y0 = tyi * T2;
+    (&s_or[0][0])[threadIdx.x] = 0;
+    (&s_noise[0][0])[threadIdx.x] = 0;
+    (&s_range[0][0])[threadIdx.x] = 0;
+    const bool aligned = (a.w & 3) == 0 && (a.plane_stride & 3) == 0;
+
+    for (int q = 0; q < 3; ++q) {
+        if (!a.pl[q].src) continue;
+        const int k = a.pl[q].k, C = a.pl[q].C, pitch = hband2_pitch(k);
+        const int xa = (x0 - k) & ~3, koff = x0 - xa;   // band column of tile column 0
+        uint8_t* hband = smem;
+        uint8_t* vband = smem + T2 * pitch;
+        const uint8_t* s = a.pl[q].src + fo;
+        __syncthreads();   // previous plane's phases are done with the bands
+        if (aligned) {
+            const int dpr = pitch >> 2;
+            uint32_t* hb = reinterpret_cast<uint32_t*>(hband);
+            for (int cd0 = 0; cd0 < dpr; cd0 += 64) {
+                const int cd = min(cd0 + lane, dpr - 1), gx = xa + cd * 4;
+                const bool xin = gx >= 0 && gx < a.w && cd0 + lane < dpr;
+                const uint8_t* colp = s + min(max(gx, 0), a.w - 4);
+                for (int r0 = wv; r0 < T2; r0 += 32) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int gy = y0 + r0 + 4 * u;
+                        v[u] = *reinterpret_cast<const uint32_t*>(colp + (size_t)min(gy, a.h - 1) * a.w);
+                        v[u] = (xin && gy < a.h) ? v[u] : 0u;
+                    }
+                    if (cd0 + lane < dpr) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) hb[(r0 + 4 * u) * dpr + cd] = v[u];
+                    }
+                }
+            }
+            uint32_t* vb = reinterpret_cast<uint32_t*>(vband);
+            const int nrows = T2 + 2 * k + 1, cdv = lane & 31, rsub = wv * 2 + (lane >> 5);   // 8 rows per block pass
+            const int gxv = x0 + cdv * 4;
+            const bool xinv = gxv < a.w;
+            const uint8_t* colv = s + min(gxv, a.w - 4);
+            for (int r0 = rsub; r0 < nrows; r0 += 8 * 8) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int gy = y0 - k + r0 + 8 * u;
+                    v[u] = *reinterpret_cast<const uint32_t*>(colv + (size_t)min(max(gy, 0), a.h - 1) * a.w);
+                    v[u] = (xinv && gy >= 0 && gy < a.h) ? v[u] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (r0 + 8 * u < nrows) vb[(r0 + 8 * u) * 32 + cdv] = v[u];
+            }
+        } else {
+            for (int i = threadIdx.x; i < T2 * pitch; i += 256) {
+                const int r = i / pitch, c = i - r * pitch, gy = y0 + r, gx = xa + c;
+                hband[i] = (gy < a.h && gx >= 0 && gx < a.w) ? s[(size_t)gy * a.w + gx] : 0;
+            }
+            for (int i = threadIdx.x; i < (T2 + 2 * k + 1) * T2; i += 256) {
+                const int r = i >> 7, c = i & 127, gy = y0 - k + r, gx = x0 + c;
+                vband[i] = (gx < a.w && gy >= 0 && gy < a.h) ? s[(size_t)gy * a.w + gx] : 0;
+            }
+        }
+        __syncthreads();
+
+        const uint32_t kk = (uint32_t)k | ((uint32_t)k << 16);
+        const uint32_t ck = (uint32_t)((C * k) & 0xffff) * 0x10001u;
+        unsigned long long (*dst)[2] = q == 2 ? s_noise : s_or;
+        if (wv < 2) {
+            // ---- H phase: rows (lane, lane+64), tile columns 64*wv .. 64*wv+63
+            const uint8_t* b0 = hband + lane * pitch + koff - k + 64 * wv;   // b[c] <-> tile column 64*wv - k + c
+            const uint8_t* b1 = b0 + 64 * pitch;
+            uint32_t sl = 0, sr = 0;
+#pragma unroll 4
+            for (int c = 0; c < k; ++c) {
+                sl += (uint32_t)b0[c] | ((uint32_t)b1[c] << 16);
+                sr += (uint32_t)b0[k + 1 + c] | ((uint32_t)b1[k + 1 + c] << 16);
+            }
+            unsigned long long w0 = 0, w1 = 0;
+            uint32_t P = (uint32_t)b0[k] | ((uint32_t)b1[k] << 16);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int t = g * 16 + u;
+                    const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
+                    const uint32_t m = pk_sub(sl, thr) & pk_sub(sr, thr);          // sign bits: both sides < thr
+                    acc = pk_shr1(acc) | (m & 0x80008000u);
+                    const uint32_t outl = (uint32_t)b0[t] | ((uint32_t)b1[t] << 16);
+                    const uint32_t in = (uint32_t)b0[2 * k + 1 + t] | ((uint32_t)b1[2 * k + 1 + t] << 16);
+                    const uint32_t Pn = (uint32_t)b0[k + 1 + t] | ((uint32_t)b1[k + 1 + t] << 16);
+                    sl = pk_sub(pk_add(sl, P), outl);
+                    sr = pk_sub(pk_add(sr, in), Pn);
+                    P = Pn;
+                }
+                w0 |= (unsigned long long)(acc & 0xffffu) << (16 * g);
+                w1 |= (unsigned long long)(acc >> 16) << (16 * g);
+            }
+            atomicOr(&dst[lane][wv], w0);
+            atomicOr(&dst[lane + 64][wv], w1);
+        } else {
+            // ---- V phase: columns (lane, lane+64), tile rows 64*(wv-2) .. +63
+            const int rbase = 64 * (wv - 2);
+            const uint8_t* b = vband + rbase * T2 + lane;   // b[r*128] <-> tile row rbase - k + r
+            uint32_t su = 0, sd = 0;
+#pragma unroll 4
+            for (int r = 0; r < k; ++r) {
+                su += (uint32_t)b[r * T2] | ((uint32_t)b[r * T2 + 64] << 16);
+                sd += (uint32_t)b[(k + 1 + r) * T2] | ((uint32_t)b[(k + 1 + r) * T2 + 64] << 16);
+            }
+            unsigned long long m0 = 0, m1 = 0, g0 = 0, g1 = 0;
+            uint32_t P = (uint32_t)b[k * T2] | ((uint32_t)b[k * T2 + 64] << 16);
+#pragma unroll 8
+            for (int t = 0; t < 64; ++t) {
+                const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
+                const uint32_t m = pk_sub(su, thr) & pk_sub(sd, thr);
+                const unsigned long long bal0 = __ballot((m & 0x8000u) != 0), bal1 = __ballot((m & 0x80000000u) != 0);
+                if (lane == t) { m0 = bal0; m1 = bal1; }
+                if (q == 2) {   // inRange(lab_b, noise_thresh, 255) on the raw plane
+                    const unsigned long long r0 = __ballot((int)(P & 0xffffu) >= a.noise_thresh),
+                                             r1 = __ballot((int)(P >> 16) >= a.noise_thresh);
+                    if (lane == t) { g0 = r0; g1 = r1; }
+                }
+                const uint32_t outu = (uint32_t)b[t * T2] | ((uint32_t)b[t * T2 + 64] << 16);
+                const uint32_t in = (uint32_t)b[(2 * k + 1 + t) * T2] | ((uint32_t)b[(2 * k + 1 + t) * T2 + 64] << 16);
+                const uint32_t Pn = (uint32_t)b[(k + 1 + t) * T2] | ((uint32_t)b[(k + 1 + t) * T2 + 64] << 16);
+                su = pk_sub(pk_add(su, P), outu);
+                sd = pk_sub(pk_add(sd, in), Pn);
+                P = Pn;
+            }
+            atomicOr(&dst[rbase + lane][0], m0);
+            atomicOr(&dst[rbase + lane][1], m1);
+            if (q == 2) {
+                s_range[rbase + lane][0] = g0;
+                s_range[rbase + lane][1] = g1;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int r = threadIdx.x >> 1, half = threadIdx.x & 1, gy = y0 + r, xw = x0 + 64 * half;
+        if (gy < a.h && xw < a.w) {
+            unsigned long long m = s_or[r][half];
+            if (a.pl[2].src) m &= ~s_range[r][half] | s_noise[r][half];   // (r|b) & (!part1 | part2)
+            const int nvalid = a.w - xw;
+            if (nvalid < 64) m &= (1ull << nvalid) - 1ull;
+            bits[(size_t)frame * a.bits_stride + (size_t)gy * a.wpr + (xw >> 6)] = m;
+        }
+    }
+}
+
 // merge of already-thresholded u8 planes into the bit plane
 __global__ __launch_bounds__(256) void k_pack_merge(const uint8_t* __restrict__ tr, const uint8_t* __restrict__ tb,
                                                    const uint8_t* __restrict__ labb, const uint8_t* __restrict__ nb,
@@ -338,6 +546,33 @@ int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
                           const uint8_t* labb, int k_n, int C_n, int noise_thresh, int use_noise,
                           unsigned long long* bits, int h, int w, size_t plane_stride, size_t bits_stride, int n) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
+    static const bool unpacked = [] { const char* e = std::getenv("LT_BILATERAL_UNPACKED"); return e && e[0] == '1'; }();
+    const int kmax = std::max(k_r, std::max(k_b, use_noise ? k_n : 0));
+    const int cmax = std::max(std::abs(C_r), std::max(std::abs(C_b), use_noise ? std::abs(C_n) : 0));
+    // packed 16-bit arithmetic is exact while every |S - (k*p - C*k)| < 2^15
+    const bool fits16 = (long long)kmax * (255 + cmax) < 32768 && C_r >= 0 && C_b >= 0 && (!use_noise || C_n >= 0);
+    if (!unpacked && fits16) {
+        Bilateral2Args a;
+        a.pl[0] = {thr, k_r, C_r};
+        a.pl[1] = {thb, k_b, C_b};
+        a.pl[2] = {use_noise ? labb : nullptr, k_n, C_n};
+        a.noise_thresh = noise_thresh;
+        a.h = h; a.w = w; a.wpr = (w + 63) / 64;
+        a.plane_stride = plane_stride;
+        a.bits_stride = bits_stride;
+        a.tiles_x = (w + T2 - 1) / T2;
+        a.tiles_y = (h + T2 - 1) / T2;
+        a.ntiles = a.tiles_x * a.tiles_y * n;
+        const size_t lds = (size_t)plane2_lds_bytes(kmax);
+        if (lds + 3 * T2 * 2 * sizeof(unsigned long long) <= 160 * 1024) {
+            if (lds > 48 * 1024 &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile2),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return -1;
+            hipLaunchKernelGGL(k_bilateral_tile2, dim3(a.ntiles), dim3(256), lds, s, a, bits);
+            return 0;
+        }
+    }
     BilateralArgs a;
     a.pl[0] = {thr, k_r, C_r};
     a.pl[1] = {thb, k_b, C_b};
