@@ -291,30 +291,80 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint32_t (&Ha)[
     S4[pb] = op3v<DIL>(S1[pb - 3], S1[pb], S1[pb + 3]);
     wave_lds_fence();
     const int p = SE::R + lane;
-    uint2 t;
+    // Final windows: single-address ds_read_b64 (256 B/clk in the LDS pipe) issued by hand.  Left to
+    // the compiler these become ds_read2_b64, which moves the same bytes at half the rate, and the
+    // kernel is LDS-pipe bound (SQ_WAIT_INST_LDS ~28 % with read2).  One s_waitcnt covers them all;
+    // the results are threaded through the wait statement so nothing is consumed before it.
+#define LT_RD64(dst, base, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
+    auto lds_addr = [](const uint2* q) { return (uint32_t)(uintptr_t)q; };   // low 32 bits of a flat LDS address = LDS offset
+    auto lo = [](unsigned long long v) { return (uint32_t)v; };
+    auto hi = [](unsigned long long v) { return (uint32_t)(v >> 32); };
     if (SE::K == 55) {
         SL[pa] = op3v<DIL>(S4[pa - 9], S4[pa], S4[pa + 9]);
         SL[pb] = op3v<DIL>(S4[pb - 9], S4[pb], S4[pb + 9]);
         wave_lds_fence();
-        const uint2 c4 = S4[p], c13 = SL[p];
-        t = S0[p];                                         Ha[0] = t.x; Hb[0] = t.y;    // 0
-        t = op2v<DIL>(S4[p - 3], S4[p + 3]);               Ha[1] = t.x; Hb[1] = t.y;    // 7
-        t = op3v<DIL>(S4[p - 6], c4, S4[p + 6]);           Ha[2] = t.x; Hb[2] = t.y;    // 10
-        t = op3v<DIL>(S4[p - 8], c4, S4[p + 8]);           Ha[3] = t.x; Hb[3] = t.y;    // 12
-        t = op2v<DIL>(SL[p - 1], SL[p + 1]);               Ha[4] = t.x; Hb[4] = t.y;    // 14
+        const uint32_t a0 = lds_addr(S0 + p), a4 = lds_addr(S4 + p - 8), a13 = lds_addr(SL + p - 14);
+        unsigned long long r0, f[7], g[29];
+        LT_RD64(r0, a0, 0);
+        LT_RD64(f[0], a4, 0);    // p-8
+        LT_RD64(f[1], a4, 16);   // p-6
+        LT_RD64(f[2], a4, 40);   // p-3
+        LT_RD64(f[3], a4, 64);   // p
+        LT_RD64(f[4], a4, 88);   // p+3
+        LT_RD64(f[5], a4, 112);  // p+6
+        LT_RD64(f[6], a4, 128);  // p+8
+        // g[i] = S13[p - 14 + i]; i = 1 and 27 (p -+ 13 ... ) are all used except p-+2 (i = 12, 16)
+#define LT_G(i) LT_RD64(g[i], a13, (i) * 8)
+        LT_G(0); LT_G(1); LT_G(2); LT_G(3); LT_G(4); LT_G(5); LT_G(6); LT_G(7); LT_G(8); LT_G(9); LT_G(10); LT_G(11);
+        LT_G(13); LT_G(14); LT_G(15);
+        LT_G(17); LT_G(18); LT_G(19); LT_G(20); LT_G(21); LT_G(22); LT_G(23); LT_G(24); LT_G(25); LT_G(26); LT_G(27); LT_G(28);
+#undef LT_G
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(r0), "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]),
+                       "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[6]), "+v"(g[7]),
+                       "+v"(g[8]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[13]), "+v"(g[14]), "+v"(g[15])
+                     :: "memory");
+        asm volatile("" : "+v"(g[17]), "+v"(g[18]), "+v"(g[19]), "+v"(g[20]), "+v"(g[21]), "+v"(g[22]), "+v"(g[23]),
+                          "+v"(g[24]), "+v"(g[25]), "+v"(g[26]), "+v"(g[27]), "+v"(g[28]) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        Ha[0] = lo(r0); Hb[0] = hi(r0);                                                                  // 0
+        Ha[1] = op2<DIL>(lo(f[2]), lo(f[4])); Hb[1] = op2<DIL>(hi(f[2]), hi(f[4]));                      // 7
+        Ha[2] = op3<DIL>(lo(f[1]), lo(f[3]), lo(f[5])); Hb[2] = op3<DIL>(hi(f[1]), hi(f[3]), hi(f[5]));  // 10
+        Ha[3] = op3<DIL>(lo(f[0]), lo(f[3]), lo(f[6])); Hb[3] = op3<DIL>(hi(f[0]), hi(f[3]), hi(f[6]));  // 12
+        Ha[4] = op2<DIL>(lo(g[13]), lo(g[15])); Hb[4] = op2<DIL>(hi(g[13]), hi(g[15]));                  // 14
 #pragma unroll
-        for (int q = 3; q <= 13; ++q) { t = op2v<DIL>(SL[p - q], SL[p + q]); Ha[2 + q] = t.x; Hb[2 + q] = t.y; }   // 16..26
-        t = op3v<DIL>(SL[p - 14], c13, SL[p + 14]);        Ha[16] = t.x; Hb[16] = t.y;  // 27
+        for (int q = 3; q <= 13; ++q) {                                                                  // 16..26
+            Ha[2 + q] = op2<DIL>(lo(g[14 - q]), lo(g[14 + q]));
+            Hb[2 + q] = op2<DIL>(hi(g[14 - q]), hi(g[14 + q]));
+        }
+        Ha[16] = op3<DIL>(lo(g[0]), lo(g[14]), lo(g[28])); Hb[16] = op3<DIL>(hi(g[0]), hi(g[14]), hi(g[28]));   // 27
     } else {
         SL[pa] = op2v<DIL>(S4[pa - 3], S4[pa + 3]);
         SL[pb] = op2v<DIL>(S4[pb - 3], S4[pb + 3]);
         wave_lds_fence();
-        t = S0[p];                                         Ha[0] = t.x; Hb[0] = t.y;    // 0
-        t = op2v<DIL>(S4[p - 1], S4[p + 1]);               Ha[1] = t.x; Hb[1] = t.y;    // 5
-        t = SL[p];                                         Ha[2] = t.x; Hb[2] = t.y;    // 7
+        const uint32_t a0 = lds_addr(S0 + p), a4 = lds_addr(S4 + p - 1), a7 = lds_addr(SL + p - 7);
+        unsigned long long r0, f0, f1, g[15];
+        LT_RD64(r0, a0, 0);
+        LT_RD64(f0, a4, 0);     // S4[p-1]
+        LT_RD64(f1, a4, 16);    // S4[p+1]
+#define LT_G(i) LT_RD64(g[i], a7, (i) * 8)
+        LT_G(0); LT_G(1); LT_G(2); LT_G(3); LT_G(4); LT_G(5); LT_G(7); LT_G(9); LT_G(10); LT_G(11); LT_G(12); LT_G(13); LT_G(14);
+#undef LT_G
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(r0), "+v"(f0), "+v"(f1), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]),
+                       "+v"(g[7]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]), "+v"(g[13]), "+v"(g[14])
+                     :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        Ha[0] = lo(r0); Hb[0] = hi(r0);                                          // 0
+        Ha[1] = op2<DIL>(lo(f0), lo(f1)); Hb[1] = op2<DIL>(hi(f0), hi(f1));      // 5
+        Ha[2] = lo(g[7]); Hb[2] = hi(g[7]);                                      // 7
 #pragma unroll
-        for (int q = 2; q <= 7; ++q) { t = op2v<DIL>(SL[p - q], SL[p + q]); Ha[1 + q] = t.x; Hb[1 + q] = t.y; }   // 9..14
+        for (int q = 2; q <= 7; ++q) {                                           // 9..14
+            Ha[1 + q] = op2<DIL>(lo(g[7 - q]), lo(g[7 + q]));
+            Hb[1 + q] = op2<DIL>(hi(g[7 - q]), hi(g[7 + q]));
+        }
     }
+#undef LT_RD64
 }
 
 template <class SE, bool DIL>
@@ -412,15 +462,36 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.w = w;
     g.plane_stride = plane_stride;
     g.nstrips = (w + 127) / 128;
-    // enough wave-tasks to fill 256 CUs x ~16 waves, but bands no shorter than ~2x the halo
-    const int min_rows = 4 * SE::R;
-    int nbands = 1;
-    while ((long long)n * g.nstrips * nbands < 6144 && (h + nbands) / (nbands + 1) >= min_rows) ++nbands;
-    g.band_rows = (h + nbands - 1) / nbands;
+    static const bool one_row = [] { const char* e = std::getenv("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
+    // Band count: every task walks band_rows + 2R rows, and the chip holds `slots` waves at once, so
+    // the makespan is ~ ceil(tasks / slots) * (band_rows + 2R).  Pick the band count that minimises
+    // it (a grid of 2.25 rounds costs 3 rounds); bands no shorter than 2R keep the halo overhead sane.
+    int dev = 0, cus = 256, blocks_per_cu = 3;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    {
+        const void* fn = one_row ? (dilate ? (const void*)k_morph_runs<SE, true> : (const void*)k_morph_runs<SE, false>)
+                                 : (dilate ? (const void*)k_morph_runs2<SE, true> : (const void*)k_morph_runs2<SE, false>);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) blocks_per_cu = nb;
+    }
+    const long long slots = (long long)cus * blocks_per_cu * 4;
+    int best_nb = 1;
+    double best_cost = 1e300;
+    for (int nb = 1; nb <= 64; ++nb) {
+        const int rows = (h + nb - 1) / nb;
+        if (nb > 1 && rows < 2 * SE::R) break;
+        const int real_nb = (h + rows - 1) / rows;
+        const long long tasks = (long long)n * g.nstrips * real_nb;
+        const double rounds = (double)((tasks + slots - 1) / slots);
+        // small grids cannot fill the chip: prefer more, shorter tasks there
+        const double cost = (tasks < slots ? (double)(rows + 2 * SE::R) : rounds * (rows + 2 * SE::R));
+        if (cost < best_cost - 1e-9) { best_cost = cost; best_nb = nb; }
+    }
+    g.band_rows = (h + best_nb - 1) / best_nb;
     g.nbands = (h + g.band_rows - 1) / g.band_rows;
     g.ntasks = n * g.nstrips * g.nbands;
     dim3 grid((g.ntasks + 3) / 4);
-    static const bool one_row = [] { const char* e = std::getenv("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
     if (one_row) {   // previous formulation (one row per iteration, u16 min/max), kept for A/B measurements
         if (dilate) hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
         else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
