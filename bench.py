@@ -33,19 +33,24 @@ def cpu_baseline(frames, cal, max_seconds=25.0):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     oc = O.make_calib(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0])
-    cores = os.cpu_count() or 1
-    t0 = time.perf_counter()
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 64))                      # threads actually used
     O.frame_sws_fit(oc, frames[0])                      # warms the per-calibration tables
+    t0 = time.perf_counter()
+    O.frame_sws_fit(oc, frames[0])
     one = time.perf_counter() - t0
-    n = int(max(cores, min(len(frames), (max_seconds * cores) / max(one, 1e-3) * 0.6)))
-    n = min(n, len(frames))
+    n = int(min(len(frames), max(cores, (max_seconds * cores) / max(one, 1e-3) * 0.5)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:               # ctypes releases the GIL
         list(ex.map(lambda f: O.frame_sws_fit(oc, f), [frames[i] for i in range(n)]))
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d of the same synthetic frames through oracle/lt_oracle.c (mask + sliding window + fit), "
-                      "one frame per thread on %d threads; single-thread %.1f ms/frame" % (n, cores, one * 1e3)}
+            "sample": "%d of the same synthetic frames through oracle/lt_oracle.c (mask + sliding window + fit), one frame "
+                      "per thread on %d threads (%d CPUs visible); single-thread %.1f ms/frame = %.1f frames/s, so the "
+                      "threaded run is %.1fx one thread" % (n, cores, avail, one * 1e3, 1.0 / one, (n / dt) * one)}
 
 
 def main():
@@ -131,6 +136,13 @@ def main():
         alg = info.alg_bytes_mask * B                                      # algorithmic bytes of the stage per step
         achieved = alg / (mask_ms * 1e-3) / 1e9 if mask_ms > 0 else 0.0
         dom = max(MASK_STAGES, key=lambda s: stages[s][0])
+        traffic = None                                     # HBM bytes per launch of the stage, from the committed PMC run
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tj["frames_per_launch"] == B and world == 1:
+                traffic = int(tj["mask_stage_traffic_bytes_per_launch"])
+        except Exception:
+            pass
         out = {
             "metric": "frames/sec at 1280x720 (end-to-end hot path: undistort+warp+filter_lane_points+sliding_window_search+fit_poly)",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -142,11 +154,13 @@ def main():
                        "detected_fraction": round(float(np.mean(rec_all["detected"])), 4)},
             "roofline": {"bound": "hbm", "kernel": "warp+threshold stage (%d kernels: %s)" % (len(MASK_STAGES), ",".join(MASK_STAGES)),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_note": "FETCH_SIZE+WRITE_SIZE of the 9 kernels, rocprofv3 --pmc, profiles/r01_traffic.json; "
+                                         "12x the algorithmic bytes because the chain materialises u8 planes between kernels",
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 6),
                          "alg_bytes_per_frame": int(info.alg_bytes_mask), "frames_per_launch": B,
                          "stage_ms_per_launch": round(mask_ms, 4), "dominant_kernel": dom,
-                         "note": "the stage is VALU/LDS-bound (two elliptical top-hats), see DESIGN.md"},
+                         "note": "the stage is integer-VALU / LDS-pipe bound (SQ counters in profiles/), not HBM bound; see DESIGN.md"},
             "kernels_ms_per_step": {k: round(v[0] / K, 4) for k, v in stages.items() if v[1]},
             "search_fit": {"ms_per_step": round(search_ms, 4),
                            "achieved_GBs": round(info.alg_bytes_search * B / (search_ms * 1e-3) / 1e9, 3) if search_ms > 0 else None},
