@@ -66,7 +66,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = torch = None
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -88,20 +89,20 @@ def main():
     fp, sp = _native.filter_params(), _native.search_params()
 
     gather_buf = send_buf = None
-    if world > 1:
+    if use_dist:
         send_buf = torch.empty(B * 64, dtype=torch.uint8, device="cuda")
         gather_buf = torch.empty(world * B * 64, dtype=torch.uint8, device="cuda")
 
     def step():
         ctx.mask_run(B, fp)
         ctx.sws_fit_run(B, sp)
-        if world > 1:
+        if use_dist:
             ctx.copy_records_to_device(B, send_buf.data_ptr())       # syncs the context's stream
             dist.all_gather_into_tensor(gather_buf, send_buf)
 
     def fence():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -119,7 +120,7 @@ def main():
     stages = ctx.stage_ms()
     ctx.set_stage_timing(False)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -172,7 +173,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames, cal)
         print(json.dumps(out))
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -13,7 +13,7 @@
 namespace lt {
 namespace {
 
-constexpr int NT = 256, NW = NT / 64;
+constexpr int NT = 256;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -418,6 +418,19 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Integer column range [a, b) of the pixels with lo < x < hi, clipped to [0, W).  x is an integer, so
+// x > lo <=> x >= floor(lo)+1 and x < hi <=> x < ceil(hi): the same set the reference's f64
+// comparisons select (:474-489).  NaN / empty bands give a >= b.
+__device__ __forceinline__ void band_columns(double lo, double hi, int W, int& a, int& b) {
+    a = 0;
+    b = 0;
+    if (!(lo < hi) || !(hi > 0.0) || !(lo < (double)(W - 1))) return;
+    a = lo < 0.0 ? 0 : (int)floor(lo) + 1;
+    b = hi > (double)W ? W : (int)ceil(hi);
+    b = min(b, W);
+}
+
+template <bool VEC4>
 __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
                                                 const double* __restrict__ prev, uint32_t* __restrict__ pix_all,
                                                 lt_lane_record* __restrict__ recs) {
@@ -432,28 +445,23 @@ __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ mas
     const int W = g.w, top = g.band_top, bottom = g.band_bottom, nrows = max(bottom - top, 0);
     const int y0c = g.h / 2, x0c = g.w / 2;
     const double bw = g.bandwidth;
+    Moments mom[2];
+    mom[0].clear();
+    mom[1].clear();
 
-    // pass 1: per-row counts for both lanes.  The predicate is the reference's f64 expression
-    // ((a*y^2 + b*y) + c) -/+ bw with strict comparisons (:474-489); no FMA contraction.
-    for (int ry = wv; ry < nrows; ry += NW) {
-        const int y = top + ry;
+    // one thread per (side, row): the band of a row is the reference's f64 expression
+    // ((a*y^2 + b*y) + c) -/+ bw, evaluated without FMA contraction
+    auto columns = [&](int s, int y, int& a, int& b) {
         const double y2 = (double)((long long)y * y), yd = (double)y;
-        for (int s = 0; s < 2; ++s) {
-            const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];
-            const double lo = t - bw, hi = t + bw;
-            // integer columns that can satisfy lo < x < hi, clipped to the image (NaN-safe)
-            int xa = 0, xb = -1;
-            if (lo < hi && hi > 0.0 && lo < (double)(W - 1)) {
-                xa = lo < 0.0 ? 0 : (int)floor(lo);
-                xb = hi > (double)(W - 1) ? W - 1 : (int)ceil(hi);
-            }
-            unsigned c = 0;
-            for (int x = xa + lane; x - lane <= xb; x += 64) {
-                const bool in = x <= xb && (double)x > lo && (double)x < hi && mask[(size_t)y * W + x] != 0;
-                c += __popcll(__ballot(in));
-            }
-            if (lane == 0) rowcnt[s * g.h + ry] = c;
-        }
+        const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];
+        band_columns(t - bw, t + bw, W, a, b);
+    };
+    const int pairs = 2 * nrows;
+    for (int pi = threadIdx.x; pi < pairs; pi += NT) {
+        const int s = pi >= nrows ? 1 : 0, ry = pi - s * nrows, y = top + ry;
+        int a, b;
+        columns(s, y, a, b);
+        rowcnt[s * g.h + ry] = b > a ? roi_row<false, VEC4>(mask + (size_t)y * W, a, b, y, nullptr, 0, 0, mom[s], y0c, x0c) : 0;
     }
     __syncthreads();
     if (wv < 2) {
@@ -477,41 +485,20 @@ __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ mas
         if (lane == 63) rowoff[s * (g.h + 1) + nrows] = incl;
     }
     __syncthreads();
-    Moments mom[2];
-    mom[0].clear();
-    mom[1].clear();
-    // pass 2: ordered write (row-major, like nonzero())
-    for (int ry = wv; ry < nrows; ry += NW) {
-        const int y = top + ry;
-        const double y2 = (double)((long long)y * y), yd = (double)y;
-        for (int s = 0; s < 2; ++s) {
-            const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];
-            const double lo = t - bw, hi = t + bw;
-            int xa = 0, xb = -1;
-            if (lo < hi && hi > 0.0 && lo < (double)(W - 1)) {
-                xa = lo < 0.0 ? 0 : (int)floor(lo);
-                xb = hi > (double)(W - 1) ? W - 1 : (int)ceil(hi);
-            }
-            unsigned run = rowoff[s * (g.h + 1) + ry];
-            for (int x = xa + lane; x - lane <= xb; x += 64) {
-                const bool in = x <= xb && (double)x > lo && (double)x < hi && mask[(size_t)y * W + x] != 0;
-                const unsigned long long bal = __ballot(in);
-                if (in) {
-                    const unsigned idx = run + __popcll(bal & ((1ull << lane) - 1ull));
-                    if (idx < (unsigned)g.maxpix) pix[(size_t)s * g.maxpix + idx] = ((uint32_t)y << 16) | (uint32_t)x;
-                    mom[s].add(y, x, y0c, x0c);
-                }
-                run += __popcll(bal);
-            }
-        }
+    // ordered write (row-major, like nonzero()): each (side, row) thread emits its own pixels
+    for (int pi = threadIdx.x; pi < pairs; pi += NT) {
+        const int s = pi >= nrows ? 1 : 0, ry = pi - s * nrows, y = top + ry;
+        if (rowcnt[s * g.h + ry] == 0) continue;
+        int a, b;
+        columns(s, y, a, b);
+        roi_row<true, VEC4>(mask + (size_t)y * W, a, b, y, pix + (size_t)s * g.maxpix, (int)rowoff[s * (g.h + 1) + ry],
+                            g.maxpix, mom[s], y0c, x0c);
     }
     int distinct[2] = {0, 0};
     for (int s = 0; s < 2; ++s) {
         int d = 0;
         for (int i = threadIdx.x; i < nrows; i += NT) d += rowcnt[s * g.h + i] != 0;
-        // cheap block reduction through the (now free) moments scratch is overkill: use ballots
         int tot = (int)wave_sum_i64(d);
-        // combine the 4 waves through LDS
         __syncthreads();
         if (lane == 0) rowoff[2 * (g.h + 1) + wv] = (unsigned)tot;   // 4 spare words reserved by the launcher
         __syncthreads();
@@ -591,7 +578,10 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Se
     if (n <= 0) return;
     const size_t words = (size_t)(4 * g.h + 2) + 4;  // + 4 words for the distinct-row reduction
     const size_t lds = ((words * 4 + 15) & ~(size_t)15) + 16 * sizeof(long long);
-    hipLaunchKernelGGL(k_band_fit, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);
+    if ((g.w & 3) == 0 && (mask_stride & 3) == 0)
+        hipLaunchKernelGGL(k_band_fit<true>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);
+    else
+        hipLaunchKernelGGL(k_band_fit<false>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);
 }
 
 }  // namespace lt

@@ -103,6 +103,7 @@ class LaneTracker:
         self._ctx = _native.Context(img_size, warped_size, cam_matrix, dist_coeffs, self.M, device=device, capacity=1)
         self._aux_ctx = {}          # contexts for images that are not the calibration's BEV size
         self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search
+        self._pending = None        # (ctx, slot, want_centroids): pixel lists not downloaded yet
         self._overlay = None
 
     # ------------------------------------------------------------------------------------------
@@ -125,26 +126,45 @@ class LaneTracker:
                                                  device=self.device, capacity=1)
         return self._aux_ctx[key]
 
-    def _collect_search(self, ctx, want_centroids):
-        """Pull the lane record (and, if lanes were found, the pixel lists) of slot 0."""
-        rec = ctx.download_records(1)[0]
+    def _collect_search(self, ctx, want_centroids, slot=0, lazy=False):
+        """Pull the lane record of `slot`.  The pixel lists (self.left_y/left_x/right_y/right_x) and
+        window centroids are fetched right away, or -- in the stream pipeline, `lazy=True` -- only if
+        somebody reads them before the slot is reused (the state machine itself needs the record only)."""
+        rec = ctx.download_records(1, first=slot)[0]
         self.detected_pixels = bool(rec["detected"])
         if not self.detected_pixels:
-            self._fit = None
+            self._fit = None        # like the reference, a failed search leaves the previous pixel lists in place
             return
-        self.left_y, self.left_x = ctx.download_pixels(0, 0)
-        self.right_y, self.right_x = ctx.download_pixels(0, 1)
-        if want_centroids:
-            self.left_window_centroids = ctx.download_centroids(0, 0)
-            self.right_window_centroids = ctx.download_centroids(0, 1)
+        self._pending = None
         lf = np.array(rec["left_coeffs"], np.float64)
         rf = np.array(rec["right_coeffs"], np.float64)
         flags = int(rec["fit_flags"])
+        if lazy and not flags:
+            self._pending = (ctx, slot, want_centroids)
+            self._fit = ("pending", None, lf, rf)
+            return
+        self._fetch_pixels(ctx, slot, want_centroids)
         if flags & 1:
             lf = _minimum_norm_parabola(self.left_y, self.left_x)
         if flags & 2:
             rf = _minimum_norm_parabola(self.right_y, self.right_x)
         self._fit = (self.left_y, self.right_y, lf, rf)
+
+    def _fetch_pixels(self, ctx, slot, want_centroids):
+        self.left_y, self.left_x = ctx.download_pixels(slot, 0)
+        self.right_y, self.right_x = ctx.download_pixels(slot, 1)
+        if want_centroids:
+            self.left_window_centroids = ctx.download_centroids(slot, 0)
+            self.right_window_centroids = ctx.download_centroids(slot, 1)
+
+    def _materialise_pending(self):
+        """Download the lane pixels of the most recent lazily collected search (stream pipeline)."""
+        if self._pending is not None:
+            ctx, slot, want_centroids = self._pending
+            self._pending = None
+            self._fetch_pixels(ctx, slot, want_centroids)
+            if self._fit is not None and self._fit[0] == "pending":
+                self._fit = (self.left_y, self.right_y, self._fit[2], self._fit[3])
 
     # ---- filter_lane_points (reference :183-240) ------------------------------------------------
     def filter_lane_points(self, img, filter_type='bilateral', ksize_r=25, C_r=8, ksize_b=35, C_b=5,
@@ -181,14 +201,16 @@ class LaneTracker:
         self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
                               diagnostics)
 
-    def _search_uploaded(self, ctx, mode, kw, diagnostics):
+    def _search_uploaded(self, ctx, mode, kw, diagnostics, slot=0, lazy=False):
+        if self._pending is not None and self._pending[0] is ctx and self._pending[1] == slot:
+            self._materialise_pending()      # this search reuses the slot whose lists were not fetched yet
         if mode == 'sws':
-            ctx.sws_fit_run(1, _native.search_params(**kw))
+            ctx.sws_fit_run(1, _native.search_params(**kw), first=slot)
         else:
             prev = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
                                    np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
-            ctx.band_fit_run(1, prev, _native.search_params(**kw))
-        self._collect_search(ctx, want_centroids=(mode == 'sws'))
+            ctx.band_fit_run(1, prev, _native.search_params(**kw), first=slot)
+        self._collect_search(ctx, want_centroids=(mode == 'sws'), slot=slot, lazy=lazy)
         if diagnostics:
             print("Lane pixels found." if self.detected_pixels else "No lane pixels found.")
 
@@ -196,7 +218,8 @@ class LaneTracker:
     def fit_poly(self):
         """Second-degree least-squares fits x(y) of the current left/right lane pixels.  The fit is
         produced by the search kernel (exact int64 moments, 3x3 normal equations in f64)."""
-        if self._fit is not None and self._fit[0] is self.left_y and self._fit[1] is self.right_y:
+        if self._fit is not None and (self._fit[0] == "pending" if isinstance(self._fit[0], str)
+                                      else (self._fit[0] is self.left_y and self._fit[1] is self.right_y)):
             return self._fit[2].copy(), self._fit[3].copy()
         # pixel arrays were replaced by the caller: fit them on the device from the lists
         lf = self._ctx.fit_poly2(self.left_y, self.left_x)
@@ -308,12 +331,13 @@ class LaneTracker:
     def _find_lane_points_device(self, img, ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh,
                                  ksize_noise, C_noise, window_width, window_height, search_range, mu,
                                  no_success_limit, start_slice, ignore_sides, ignore_bottom, bandwidth, partial,
-                                 diagnostics, reuse_frame=False):
+                                 diagnostics, reuse_frame=False, slot=0, have_mask=False, lazy=False):
         ctx = self._ctx
         if not reuse_frame:
-            ctx.upload_frames(img)
-        ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
-                                              ksize_noise, C_noise))
+            ctx.upload_frames(img, first=slot)
+        if not have_mask:
+            ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
+                                                  ksize_noise, C_noise), first=slot)
         if self.last_detection > self.n_reset:                       # :851
             if diagnostics:
                 print("Using sliding window search.")
@@ -321,12 +345,12 @@ class LaneTracker:
                                                    search_range=search_range, mu=mu,
                                                    no_success_limit=no_success_limit, start_slice=start_slice,
                                                    ignore_sides=ignore_sides, ignore_bottom=ignore_bottom,
-                                                   partial=partial), diagnostics)
+                                                   partial=partial), diagnostics, slot=slot, lazy=lazy)
             return 'sws'
         if diagnostics:
             print("Using band search.")
         self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
-                              diagnostics)
+                              diagnostics, slot=slot, lazy=lazy)
         return 'bs'
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
@@ -345,15 +369,66 @@ class LaneTracker:
         if visualize_search or split_view:
             raise NotImplementedError("search visualisation / split view are presentation features outside the "
                                       "accelerated path (SURVEY.md section 8(f), row N1)")
+        first_try = (ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh, ksize_noise, C_noise,
+                     window_width, window_height, search_range, mu, no_success_limit, start_slice, ignore_sides,
+                     ignore_bottom, bandwidth, partial)
+        return self._step(img, first_try, n_tries, diagnostics, slot=0, have_mask=False, lazy=False, annotate=True)
+
+    def process_batch(self, frames, annotate=True, **kwargs):
+        """The same result as calling `process()` on each frame of `frames` in order (one stateful
+        stream), arranged for throughput:
+
+          * all frames are uploaded once and the first-try masks (undistort + warp + filter) of the
+            whole window are computed ahead in one batched launch -- that stage is stateless;
+          * the search / fit / validity state machine then trails frame by frame: per frame one search
+            kernel on the resident mask and one 64-byte record back to the host;
+          * the second-try mask (different filter parameters) is computed lazily, only for a frame
+            whose first try failed;
+          * lane-pixel lists stay on the device unless somebody reads them.
+
+        `kwargs` are `process()`'s keywords.  Returns the list of annotated frames, or None for every
+        frame when `annotate=False` (state and attributes are updated identically)."""
+        import inspect
+        sig = inspect.signature(LaneTracker.process)
+        defaults = {k: v.default for k, v in sig.parameters.items() if k not in ("self", "img")}
+        unknown = set(kwargs) - set(defaults)
+        if unknown:
+            raise TypeError("unexpected keyword(s): " + ", ".join(sorted(unknown)))
+        defaults.update(kwargs)
+        k = defaults
+        if k["visualize_search"] or k["split_view"]:
+            raise NotImplementedError("search visualisation / split view are not available in the stream pipeline")
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if frames.ndim != 4:
+            raise ValueError("process_batch expects frames of shape (n, H, W, 3)")
+        n = frames.shape[0]
+        first_try = (k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"], k["filter_type"], k["mask_noise"], k["noise_thresh"],
+                     k["ksize_noise"], k["C_noise"], k["window_width"], k["window_height"], k["search_range"], k["mu"],
+                     k["no_success_limit"], k["start_slice"], k["ignore_sides"], k["ignore_bottom"], k["bandwidth"],
+                     k["partial"])
+        ctx = self._ctx
+        ctx.reserve(max(n, 1))
+        ctx.upload_frames(frames)
+        ctx.mask_run(n, _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],
+                                              k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"]))
+        out = []
+        for i in range(n):
+            res = self._step(frames[i], first_try, k["n_tries"], k["diagnostics"], slot=i, have_mask=True, lazy=True,
+                             annotate=annotate)
+            out.append(res)
+        self._materialise_pending()      # the attributes describe the last frame, as after process()
+        return out
+
+    def _step(self, img, first_try, n_tries, diagnostics, slot, have_mask, lazy, annotate):
+        """One frame of the per-stream state machine (reference :1026-1209)."""
+        partial = first_try[-1]
         self.counter += 1
         self.detected_pixels = False
         self.valid_lane_lines = False
         left_fit_coeffs = right_fit_coeffs = None
 
-        first_try = (ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh, ksize_noise, C_noise,
-                     window_width, window_height, search_range, mu, no_success_limit, start_slice, ignore_sides,
-                     ignore_bottom, bandwidth, partial)
-        self._find_lane_points_device(img, *first_try, diagnostics)
+        self._find_lane_points_device(img, *first_try, diagnostics, reuse_frame=have_mask, slot=slot,
+                                      have_mask=have_mask, lazy=lazy)
         if self.detected_pixels:
             left_fit_coeffs, right_fit_coeffs = self.fit_poly()
             self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
@@ -366,7 +441,7 @@ class LaneTracker:
             partial = 1.0                                               # the second parameter set (:1081-1099)
             second_try = (15, 5, 35, 5, 'neighborhood', False, 140, 65, 10, 30, 40, 20, 0.1, 50, 0.25, 360, 30, 30,
                           partial)
-            self._find_lane_points_device(img, *second_try, diagnostics, reuse_frame=True)
+            self._find_lane_points_device(img, *second_try, diagnostics, reuse_frame=True, slot=slot, lazy=lazy)
             if self.detected_pixels:
                 left_fit_coeffs, right_fit_coeffs = self.fit_poly()
                 self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
@@ -385,6 +460,8 @@ class LaneTracker:
             if len(self.average_curve_radii) > self.n_average:
                 self.average_curve_radii.pop(0)
             self.last_detection += 1
+            if not annotate:
+                return None
             if (self.left_avg_y.size != 0) and (self.last_detection <= self.n_fail):
                 return self.draw_lane(img)
             return self.print_failure(img)
@@ -405,7 +482,7 @@ class LaneTracker:
             self.left_avg_coeffs, self.right_avg_coeffs, partial)
         self.get_curve_radius()
         self.get_eccentricity()
-        return self.draw_lane(img)
+        return self.draw_lane(img) if annotate else None
 
 
 def _minimum_norm_parabola(y, x):

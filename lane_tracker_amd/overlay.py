@@ -19,44 +19,62 @@ class LaneOverlay:
         ok = np.isfinite(bx) & np.isfinite(by) & (np.abs(den) > 1e-12)
         ok &= (bx >= 0) & (bx < self.bw) & (by >= 0) & (by < self.bh)
         self.cam_idx = np.flatnonzero(ok.ravel())
-        self.bev_idx = (by[ok].astype(np.int64) * self.bw + bx[ok].astype(np.int64))
+        self.bx = bx[ok].astype(np.int32)      # bird's-eye pixel under each camera pixel that sees the road plane
+        self.by = by[ok].astype(np.int32)
+        self.cam_g = self.cam_idx * 3 + 1      # flat offset of the green byte of those camera pixels
 
     def draw(self, img, left_y, left_x, right_y, right_x, alpha=0.3):
         """Green lane polygon between the two averaged curves, blended like addWeighted(img,1,lane,0.3,0)."""
         out = np.array(img, dtype=np.uint8, copy=True)
-        lane = np.zeros(self.bh * self.bw, bool)
         ly, lx = np.asarray(left_y, np.int64), np.asarray(left_x, np.int64)
         ry, rx = np.asarray(right_y, np.int64), np.asarray(right_x, np.int64)
         if ly.size and ry.size:
-            lrow = np.full(self.bh, -1, np.int64)
-            rrow = np.full(self.bh, -1, np.int64)
+            # per bird's-eye row: the span between the two averaged curves (rows where both exist)
+            lo = np.full(self.bh, 1 << 30, np.int32)
+            hi = np.full(self.bh, -1, np.int32)
+            lrow = np.full(self.bh, -1, np.int32)
+            rrow = np.full(self.bh, -1, np.int32)
             lrow[np.clip(ly, 0, self.bh - 1)] = lx
             rrow[np.clip(ry, 0, self.bh - 1)] = rx
-            rows = np.flatnonzero((lrow >= 0) & (rrow >= 0))
-            lane2d = lane.reshape(self.bh, self.bw)
-            cols = np.arange(self.bw)[None, :]
-            a = np.minimum(lrow[rows], rrow[rows])[:, None]
-            b = np.maximum(lrow[rows], rrow[rows])[:, None]
-            lane2d[rows] = (cols >= a) & (cols <= b)
-        hit = lane[self.bev_idx]
-        g = out.reshape(-1, 3)[:, 1]
-        sel = self.cam_idx[hit]
-        g[sel] = np.minimum(255, g[sel].astype(np.int64) + int(np.rint(255 * alpha))).astype(np.uint8)
+            both = (lrow >= 0) & (rrow >= 0)
+            lo[both] = np.minimum(lrow, rrow)[both]
+            hi[both] = np.maximum(lrow, rrow)[both]
+            # evaluated only at the camera pixels, not over the whole bird's-eye image
+            hit = (self.bx >= lo[self.by]) & (self.bx <= hi[self.by])
+            sel = self.cam_g[hit]
+            flat = out.reshape(-1)
+            flat[sel] = np.minimum(255, flat[sel].astype(np.int16) + int(np.rint(255 * alpha))).astype(np.uint8)
         return out
 
 
+_FONT = None
+
+
+def _font():
+    global _FONT
+    if _FONT is None:
+        from PIL import ImageFont
+        try:
+            _FONT = ImageFont.load_default(size=28)
+        except Exception:
+            _FONT = ImageFont.load_default()
+    return _FONT
+
+
 def put_lines(img, lines, origin=(20, 8), step=35):
-    """White text lines at the reference's positions ((20,35), (20,70), ... baselines)."""
+    """White text lines at the reference's positions ((20,35), (20,70), ... baselines).  Only the text
+    strip goes through Pillow."""
     try:
-        from PIL import Image, ImageDraw, ImageFont
+        from PIL import Image, ImageDraw
     except Exception:
         return img
-    try:
-        font = ImageFont.load_default(size=28)
-    except Exception:
-        font = ImageFont.load_default()
-    pil = Image.fromarray(np.ascontiguousarray(img))
+    img = np.ascontiguousarray(img)
+    strip_h = min(img.shape[0], origin[1] + len(lines) * step + 8)
+    pil = Image.fromarray(img[:strip_h])
     d = ImageDraw.Draw(pil)
     for i, text in enumerate(lines):
-        d.text((origin[0], origin[1] + i * step), text, fill=(255, 255, 255), font=font)
-    return np.asarray(pil).copy()
+        d.text((origin[0], origin[1] + i * step), text, fill=(255, 255, 255), font=_font())
+    if not img.flags.writeable:
+        img = img.copy()
+    img[:strip_h] = np.asarray(pil)
+    return img
