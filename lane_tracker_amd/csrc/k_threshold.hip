@@ -245,7 +245,11 @@ __host__ __device__ __forceinline__ int hband2_pitch(int k) {   // >= 128 + 2k +
     if (((p >> 2) & 1) == 0) p += 4;
     return p;
 }
-__host__ __device__ __forceinline__ int plane2_lds_bytes(int k) { return T2 * hband2_pitch(k) + (T2 + 2 * k + 1) * T2; }
+// the row band and the column band are staged one after the other into the same buffer
+__host__ __device__ __forceinline__ int plane2_lds_bytes(int k) {
+    const int hb = T2 * hband2_pitch(k), vb = (T2 + 2 * k + 1) * T2;
+    return hb > vb ? hb : vb;
+}
 
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) + __builtin_bit_cast(u16x2t, b)));
@@ -268,6 +272,9 @@ struct Bilateral2Args {
     size_t plane_stride, bits_stride;
 };
 
+// Per plane: stage the row band -> H phase on all four waves (32 columns each) -> stage the column
+// band into the same LDS -> V phase on all four waves (32 rows each).  One band in LDS at a time
+// keeps the workgroup at ~32 KB, i.e. four workgroups per CU instead of two.
 __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsigned long long* __restrict__ bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_or[T2][2];      // (R | b) verdict words: [row][column half]
@@ -288,13 +295,17 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
         if (!a.pl[q].src) continue;
         const int k = a.pl[q].k, C = a.pl[q].C, pitch = hband2_pitch(k);
         const int xa = (x0 - k) & ~3, koff = x0 - xa;   // band column of tile column 0
-        uint8_t* hband = smem;
-        uint8_t* vband = smem + T2 * pitch;
+        uint8_t* band = smem;
         const uint8_t* s = a.pl[q].src + fo;
-        __syncthreads();   // previous plane's phases are done with the bands
+        const uint32_t kk = (uint32_t)k | ((uint32_t)k << 16);
+        const uint32_t ck = (uint32_t)((C * k) & 0xffff) * 0x10001u;
+        unsigned long long (*dst)[2] = q == 2 ? s_noise : s_or;
+
+        // ---------------- row band: rows y0..y0+127, columns xa..xa+pitch-1 ----------------
+        __syncthreads();   // the previous phase is done with the buffer
         if (aligned) {
             const int dpr = pitch >> 2;
-            uint32_t* hb = reinterpret_cast<uint32_t*>(hband);
+            uint32_t* hb = reinterpret_cast<uint32_t*>(band);
             for (int cd0 = 0; cd0 < dpr; cd0 += 64) {
                 const int cd = min(cd0 + lane, dpr - 1), gx = xa + cd * 4;
                 const bool xin = gx >= 0 && gx < a.w && cd0 + lane < dpr;
@@ -313,7 +324,53 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
                     }
                 }
             }
-            uint32_t* vb = reinterpret_cast<uint32_t*>(vband);
+        } else {
+            for (int i = threadIdx.x; i < T2 * pitch; i += 256) {
+                const int r = i / pitch, c = i - r * pitch, gy = y0 + r, gx = xa + c;
+                band[i] = (gy < a.h && gx >= 0 && gx < a.w) ? s[(size_t)gy * a.w + gx] : 0;
+            }
+        }
+        __syncthreads();
+        {
+            // ---- H phase: rows (lane, lane+64), tile columns 32*wv .. 32*wv+31
+            const uint8_t* b0 = band + lane * pitch + koff - k + 32 * wv;   // b[c] <-> tile column 32*wv - k + c
+            const uint8_t* b1 = b0 + 64 * pitch;
+            uint32_t sl = 0, sr = 0;
+#pragma unroll 4
+            for (int c = 0; c < k; ++c) {
+                sl += (uint32_t)b0[c] | ((uint32_t)b1[c] << 16);
+                sr += (uint32_t)b0[k + 1 + c] | ((uint32_t)b1[k + 1 + c] << 16);
+            }
+            uint32_t w0 = 0, w1 = 0;
+            uint32_t P = (uint32_t)b0[k] | ((uint32_t)b1[k] << 16);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int t = g * 16 + u;
+                    const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
+                    const uint32_t m = pk_sub(sl, thr) & pk_sub(sr, thr);          // sign bits: both sides < thr
+                    acc = pk_shr1(acc) | (m & 0x80008000u);
+                    const uint32_t outl = (uint32_t)b0[t] | ((uint32_t)b1[t] << 16);
+                    const uint32_t in = (uint32_t)b0[2 * k + 1 + t] | ((uint32_t)b1[2 * k + 1 + t] << 16);
+                    const uint32_t Pn = (uint32_t)b0[k + 1 + t] | ((uint32_t)b1[k + 1 + t] << 16);
+                    sl = pk_sub(pk_add(sl, P), outl);
+                    sr = pk_sub(pk_add(sr, in), Pn);
+                    P = Pn;
+                }
+                w0 |= (acc & 0xffffu) << (16 * g);
+                w1 |= (acc >> 16) << (16 * g);
+            }
+            const int sh = 32 * (wv & 1), half = wv >> 1;
+            atomicOr(&dst[lane][half], (unsigned long long)w0 << sh);
+            atomicOr(&dst[lane + 64][half], (unsigned long long)w1 << sh);
+        }
+
+        // ---------------- column band: rows y0-k..y0+127+k+1, columns x0..x0+127 ----------------
+        __syncthreads();   // every H wave is done with the row band
+        if (aligned) {
+            uint32_t* vb = reinterpret_cast<uint32_t*>(band);
             const int nrows = T2 + 2 * k + 1, cdv = lane & 31, rsub = wv * 2 + (lane >> 5);   // 8 rows per block pass
             const int gxv = x0 + cdv * 4;
             const bool xinv = gxv < a.w;
@@ -331,57 +388,16 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
                     if (r0 + 8 * u < nrows) vb[(r0 + 8 * u) * 32 + cdv] = v[u];
             }
         } else {
-            for (int i = threadIdx.x; i < T2 * pitch; i += 256) {
-                const int r = i / pitch, c = i - r * pitch, gy = y0 + r, gx = xa + c;
-                hband[i] = (gy < a.h && gx >= 0 && gx < a.w) ? s[(size_t)gy * a.w + gx] : 0;
-            }
             for (int i = threadIdx.x; i < (T2 + 2 * k + 1) * T2; i += 256) {
                 const int r = i >> 7, c = i & 127, gy = y0 - k + r, gx = x0 + c;
-                vband[i] = (gx < a.w && gy >= 0 && gy < a.h) ? s[(size_t)gy * a.w + gx] : 0;
+                band[i] = (gx < a.w && gy >= 0 && gy < a.h) ? s[(size_t)gy * a.w + gx] : 0;
             }
         }
         __syncthreads();
-
-        const uint32_t kk = (uint32_t)k | ((uint32_t)k << 16);
-        const uint32_t ck = (uint32_t)((C * k) & 0xffff) * 0x10001u;
-        unsigned long long (*dst)[2] = q == 2 ? s_noise : s_or;
-        if (wv < 2) {
-            // ---- H phase: rows (lane, lane+64), tile columns 64*wv .. 64*wv+63
-            const uint8_t* b0 = hband + lane * pitch + koff - k + 64 * wv;   // b[c] <-> tile column 64*wv - k + c
-            const uint8_t* b1 = b0 + 64 * pitch;
-            uint32_t sl = 0, sr = 0;
-#pragma unroll 4
-            for (int c = 0; c < k; ++c) {
-                sl += (uint32_t)b0[c] | ((uint32_t)b1[c] << 16);
-                sr += (uint32_t)b0[k + 1 + c] | ((uint32_t)b1[k + 1 + c] << 16);
-            }
-            unsigned long long w0 = 0, w1 = 0;
-            uint32_t P = (uint32_t)b0[k] | ((uint32_t)b1[k] << 16);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint32_t acc = 0;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int t = g * 16 + u;
-                    const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
-                    const uint32_t m = pk_sub(sl, thr) & pk_sub(sr, thr);          // sign bits: both sides < thr
-                    acc = pk_shr1(acc) | (m & 0x80008000u);
-                    const uint32_t outl = (uint32_t)b0[t] | ((uint32_t)b1[t] << 16);
-                    const uint32_t in = (uint32_t)b0[2 * k + 1 + t] | ((uint32_t)b1[2 * k + 1 + t] << 16);
-                    const uint32_t Pn = (uint32_t)b0[k + 1 + t] | ((uint32_t)b1[k + 1 + t] << 16);
-                    sl = pk_sub(pk_add(sl, P), outl);
-                    sr = pk_sub(pk_add(sr, in), Pn);
-                    P = Pn;
-                }
-                w0 |= (unsigned long long)(acc & 0xffffu) << (16 * g);
-                w1 |= (unsigned long long)(acc >> 16) << (16 * g);
-            }
-            atomicOr(&dst[lane][wv], w0);
-            atomicOr(&dst[lane + 64][wv], w1);
-        } else {
-            // ---- V phase: columns (lane, lane+64), tile rows 64*(wv-2) .. +63
-            const int rbase = 64 * (wv - 2);
-            const uint8_t* b = vband + rbase * T2 + lane;   // b[r*128] <-> tile row rbase - k + r
+        {
+            // ---- V phase: columns (lane, lane+64), tile rows 32*wv .. 32*wv+31
+            const int rbase = 32 * wv;
+            const uint8_t* b = band + rbase * T2 + lane;   // b[r*128] <-> tile row rbase - k + r
             uint32_t su = 0, sd = 0;
 #pragma unroll 4
             for (int r = 0; r < k; ++r) {
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
             unsigned long long m0 = 0, m1 = 0, g0 = 0, g1 = 0;
             uint32_t P = (uint32_t)b[k * T2] | ((uint32_t)b[k * T2 + 64] << 16);
 #pragma unroll 8
-            for (int t = 0; t < 64; ++t) {
+            for (int t = 0; t < 32; ++t) {
                 const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
                 const uint32_t m = pk_sub(su, thr) & pk_sub(sd, thr);
                 const unsigned long long bal0 = __ballot((m & 0x8000u) != 0), bal1 = __ballot((m & 0x80000000u) != 0);
@@ -408,11 +424,13 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
                 sd = pk_sub(pk_add(sd, in), Pn);
                 P = Pn;
             }
-            atomicOr(&dst[rbase + lane][0], m0);
-            atomicOr(&dst[rbase + lane][1], m1);
-            if (q == 2) {
-                s_range[rbase + lane][0] = g0;
-                s_range[rbase + lane][1] = g1;
+            if (lane < 32) {
+                atomicOr(&dst[rbase + lane][0], m0);
+                atomicOr(&dst[rbase + lane][1], m1);
+                if (q == 2) {
+                    s_range[rbase + lane][0] = g0;
+                    s_range[rbase + lane][1] = g1;
+                }
             }
         }
     }
