@@ -43,19 +43,24 @@ __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restric
     const bool y0 = sy >= 0 && sy < g.img_h, y1 = sy + 1 >= 0 && sy + 1 < g.img_h;
     const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
     const int cy0 = min(max(sy, 0), g.img_h - 1), cy1 = min(max(sy + 1, 0), g.img_h - 1);
-    const int cx0 = min(max(sx, 0), g.img_w - 1), cx1 = min(max(sx + 1, 0), g.img_w - 1);
-    const uint8_t* p00 = src + ((size_t)cy0 * g.img_w + cx0) * 3;
-    const uint8_t* p01 = src + ((size_t)cy0 * g.img_w + cx1) * 3;
-    const uint8_t* p10 = src + ((size_t)cy1 * g.img_w + cx0) * 3;
-    const uint8_t* p11 = src + ((size_t)cy1 * g.img_w + cx1) * 3;
-    int t[12];
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) { t[ch] = p00[ch]; t[3 + ch] = p01[ch]; t[6 + ch] = p10[ch]; t[9 + ch] = p11[ch]; }
+    // The two taps of a row are 6 consecutive bytes (RGB RGB) at byte offset 3*sx: one unaligned 8-byte
+    // load per row instead of six byte loads (the frame buffer is padded by 8 bytes for the overrun).
+    // When sx or sx+1 is outside the frame the row is fetched from the clamped column and the taps
+    // are masked, exactly as before.
+    struct __attribute__((packed, aligned(1))) Row8 { uint64_t v; };
+    const int cxl = min(max(sx, 0), g.img_w - 2);          // leftmost column of the 6-byte window we fetch
+    // 32-bit offsets (a frame is far below 2^31 bytes) keep the address math on full-rate 24-bit multiplies
+    const uint64_t q0 = reinterpret_cast<const Row8*>(src + (uint32_t)((__mul24(cy0, g.img_w) + cxl) * 3))->v;
+    const uint64_t q1 = reinterpret_cast<const Row8*>(src + (uint32_t)((__mul24(cy1, g.img_w) + cxl) * 3))->v;
+    // column sx sits at byte 3*(sx-cxl) of the window when it is inside the frame; sx+1 three bytes later
+    const int sh0 = 24 * (min(max(sx, 0), g.img_w - 1) - cxl), sh1 = 24 * (min(max(sx + 1, 0), g.img_w - 1) - cxl);
+    const uint32_t a0 = (uint32_t)(q0 >> sh0), a1 = (uint32_t)(q0 >> sh1);
+    const uint32_t b0 = (uint32_t)(q1 >> sh0), b1 = (uint32_t)(q1 >> sh1);
     uint32_t out = 0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const int v00 = (y0 && x0) ? t[ch] : 0, v01 = (y0 && x1) ? t[3 + ch] : 0;
-        const int v10 = (y1 && x0) ? t[6 + ch] : 0, v11 = (y1 && x1) ? t[9 + ch] : 0;
+        const int v00 = (y0 && x0) ? (int)((a0 >> (8 * ch)) & 255u) : 0, v01 = (y0 && x1) ? (int)((a1 >> (8 * ch)) & 255u) : 0;
+        const int v10 = (y1 && x0) ? (int)((b0 >> (8 * ch)) & 255u) : 0, v11 = (y1 && x1) ? (int)((b1 >> (8 * ch)) & 255u) : 0;
         out |= (uint32_t)bilerp(v00, v01, v10, v11, fx, fy) << (8 * ch);
     }
     und[(size_t)blockIdx.z * und_stride_px + o] = out;

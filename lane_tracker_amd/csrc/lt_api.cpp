@@ -433,7 +433,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     free_slots(c);
     c->capacity = capacity;
     const size_t n = (size_t)capacity;
-    if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes + 16))) { free_slots(c); return rc; }   // +16: k_undistort_rows reads 8-byte windows
     if ((rc = dev_alloc(&c->d_und, n * c->und_px))) { free_slots(c); return rc; }
     for (int i = 0; i < P_COUNT; ++i)
         if ((rc = dev_alloc(&c->d_plane[i], n * c->plane_bytes))) { free_slots(c); return rc; }
