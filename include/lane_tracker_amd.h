@@ -107,6 +107,10 @@ void lt_destroy(lt_ctx* ctx);
 int  lt_reserve(lt_ctx* ctx, int capacity);
 int  lt_get_info(lt_ctx* ctx, lt_info* out);
 int  lt_sync(lt_ctx* ctx);
+/* Number of HIP streams (1..8, default 1) the context spreads its slots over.  Slot s always runs on
+ * stream s*k/capacity, so the stages of one frame stay ordered while slices overlap: the latency-bound
+ * search of one slice hides under the mask chain of another.  Every transfer / sync waits for all streams. */
+int  lt_set_streams(lt_ctx* ctx, int nstreams);
 
 /* ---- frames in, results out ------------------------------------------------------------------ */
 /* frames: n * img_h * img_w * 3 bytes, RGB interleaved, as LaneTracker.process() receives them (:876) */

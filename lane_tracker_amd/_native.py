@@ -68,6 +68,7 @@ _SIGNATURES = {
     "lt_reserve": (C.c_int, [_P, C.c_int]),
     "lt_get_info": (C.c_int, [_P, C.POINTER(Info)]),
     "lt_sync": (C.c_int, [_P]),
+    "lt_set_streams": (C.c_int, [_P, C.c_int]),
     "lt_upload_frames": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_masks": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_download_masks": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -203,6 +204,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.lt_sync(self._h))
+
+    def set_streams(self, n):
+        """Spread the slots over n HIP streams (slices of the capacity overlap each other's stages)."""
+        _check(self.lib.lt_set_streams(self._h, int(n)))
 
     # -- data movement
     def upload_frames(self, frames, first=0):

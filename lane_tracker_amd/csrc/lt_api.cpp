@@ -48,7 +48,9 @@ enum Plane { P_R = 0, P_B, P_THR, P_THB, P_MERGED, P_MASK, P_T0, P_T1, P_T2, P_T
 struct lt_ctx {
     lt_calib calib{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;             // = streams[0]
+    std::vector<hipStream_t> streams;         // slot s runs on streams[s * nstreams / capacity]
+    int nstreams = 1;
     hipDeviceProp_t prop{};
     FrontEndGeom fe{};
     EllipseSE se5{}, se29{}, se55{};
@@ -99,9 +101,30 @@ void dev_free(T*& p) {
     p = nullptr;
 }
 
+int sync_all(lt_ctx* c) {
+    for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
+    return LT_OK;
+}
+
+// Slot -> stream mapping is fixed (contiguous slices of the capacity), so consecutive stages of one
+// slot stay ordered on one stream while different slices overlap: the latency-bound search of one
+// slice runs under the mask chain of another.  Calls fn(stream, first, n) for every non-empty piece.
+template <class F>
+int for_each_slice(lt_ctx* c, int first, int n, F fn) {
+    const int k = std::max(1, std::min(c->nstreams, c->capacity));
+    for (int si = 0; si < k; ++si) {
+        const int lo = (int)((long long)c->capacity * si / k), hi = (int)((long long)c->capacity * (si + 1) / k);
+        const int a = std::max(first, lo), b = std::min(first + n, hi);
+        if (b <= a) continue;
+        int rc = fn(c->streams[si], a, b - a);
+        if (rc) return rc;
+    }
+    return LT_OK;
+}
+
 int flush_stage_events(lt_ctx* c) {
     if (c->pending.empty()) return LT_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    { int rc = sync_all(c); if (rc) return rc; }
     for (auto& p : c->pending) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.a, p.b));
@@ -117,8 +140,9 @@ int flush_stage_events(lt_ctx* c) {
 struct StageScope {
     lt_ctx* c;
     int stage;
+    hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    StageScope(lt_ctx* c_, int stage_) : c(c_), stage(stage_) {
+    StageScope(lt_ctx* c_, int stage_, hipStream_t st_ = nullptr) : c(c_), stage(stage_), st(st_ ? st_ : c_->stream) {
         if (!c->stage_timing) return;
         if (c->ev_used + 2 > c->ev_pool.size()) {
             if (flush_stage_events(c) != LT_OK) return;
@@ -131,11 +155,11 @@ struct StageScope {
         if (c->ev_used + 2 > c->ev_pool.size()) return;
         a = c->ev_pool[c->ev_used++];
         b = c->ev_pool[c->ev_used++];
-        (void)hipEventRecord(a, c->stream);
+        (void)hipEventRecord(a, st);
     }
     ~StageScope() {
         if (!a) return;
-        (void)hipEventRecord(b, c->stream);
+        (void)hipEventRecord(b, st);
         c->pending.push_back({stage, a, b});
     }
 };
@@ -173,14 +197,14 @@ void free_slots(lt_ctx* c) {
 
 int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev) {
     if (maxpix > c->maxpix) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        { int rc = sync_all(c); if (rc) return rc; }
         dev_free(c->d_pix);
         int rc = dev_alloc(&c->d_pix, (size_t)c->capacity * 2 * maxpix);
         if (rc) return rc;
         c->maxpix = maxpix;
     }
     if (maxlev > c->maxlev) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        { int rc = sync_all(c); if (rc) return rc; }
         dev_free(c->d_cent);
         int rc = dev_alloc(&c->d_cent, (size_t)c->capacity * 2 * (maxlev + 2));
         if (rc) return rc;
@@ -209,7 +233,7 @@ int validate_filter(const lt_filter_params* p) {
 }
 
 // filter_lane_points() on planes P_R / P_B of the given slots (lane_tracker.py:210-238)
-int run_filter_chain(lt_ctx* c, int first, int n, const lt_filter_params* p, int h, int w) {
+int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter_params* p, int h, int w) {
     const size_t ps = c->plane_bytes, off = (size_t)first * ps;
     uint8_t* R = c->d_plane[P_R] + off;
     uint8_t* B = c->d_plane[P_B] + off;
@@ -221,25 +245,24 @@ int run_filter_chain(lt_ctx* c, int first, int n, const lt_filter_params* p, int
     uint8_t* t3 = c->d_plane[P_T3] + off;
     uint8_t* merged = c->d_plane[P_MERGED] + off;
     uint8_t* mask = c->d_plane[P_MASK] + off;
-    hipStream_t s = c->stream;
     if (p->filter_type == 0) {
         if (c->brute_tophat) {   // debugging aid (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
-            { StageScope t(c, ST_ERODE_R);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
-            { StageScope t(c, ST_TOPHAT_R); launch_morph_ellipse(s, t0, thR, R, h, w, c->se29, true, ps, n); }
-            { StageScope t(c, ST_ERODE_B);  launch_morph_ellipse(s, B, t0, nullptr, h, w, c->se55, false, ps, n); }
-            { StageScope t(c, ST_TOPHAT_B); launch_morph_ellipse(s, t0, thB, B, h, w, c->se55, true, ps, n); }
+            { StageScope t(c, ST_ERODE_R, s);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_R, s); launch_morph_ellipse(s, t0, thR, R, h, w, c->se29, true, ps, n); }
+            { StageScope t(c, ST_ERODE_B, s);  launch_morph_ellipse(s, B, t0, nullptr, h, w, c->se55, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_B, s); launch_morph_ellipse(s, t0, thB, B, h, w, c->se55, true, ps, n); }
         } else {
-            { StageScope t(c, ST_ERODE_R);  launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n); }
-            { StageScope t(c, ST_TOPHAT_R); launch_morph_runs(s, t0, thR, R, h, w, 29, true, ps, n); }
-            { StageScope t(c, ST_ERODE_B);  launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n); }
-            { StageScope t(c, ST_TOPHAT_B); launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n); }
+            { StageScope t(c, ST_ERODE_R, s);  launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_R, s); launch_morph_runs(s, t0, thR, R, h, w, 29, true, ps, n); }
+            { StageScope t(c, ST_ERODE_B, s);  launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n); }
+            { StageScope t(c, ST_TOPHAT_B, s); launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n); }
         }
     }
     unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
     unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
     bool merged_done = false;
     if (p->filter_type == 0) {
-        StageScope t(c, ST_THRESHOLD);   // both bilateral thresholds, the greenery mask and the OR-merge in one kernel
+        StageScope t(c, ST_THRESHOLD, s);   // both bilateral thresholds, the greenery mask and the OR-merge in one kernel
         merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
                                             p->C_noise, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps,
                                             c->bits_stride, n) == 0;
@@ -248,19 +271,19 @@ int run_filter_chain(lt_ctx* c, int first, int n, const lt_filter_params* p, int
             launch_bilateral(s, thB, t2, h, w, p->ksize_b, p->C_b, 0, 255, 0, ps, n);
         }
     } else {
-        StageScope t(c, ST_THRESHOLD);
+        StageScope t(c, ST_THRESHOLD, s);
         launch_adaptive_mean(s, R, t1, h, w, p->ksize_r, p->C_r, ps, n);
         launch_adaptive_mean(s, B, t2, h, w, p->ksize_b, p->C_b, ps, n);
     }
     if (!merged_done) {
         if (p->mask_noise) {
-            StageScope t(c, ST_THRESHOLD);
+            StageScope t(c, ST_THRESHOLD, s);
             launch_bilateral(s, B, t3, h, w, p->ksize_noise, p->C_noise, 0, 255, 0, ps, n);
         }
-        StageScope t(c, ST_MERGE);
+        StageScope t(c, ST_MERGE, s);
         launch_pack_merge(s, t1, t2, B, t3, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps, c->bits_stride, n);
     }
-    { StageScope t(c, ST_OPEN);
+    { StageScope t(c, ST_OPEN, s);
       launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n); }
     (void)merged; (void)t0;
     HIP_TRY(hipGetLastError());
@@ -346,6 +369,8 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     if (hipSetDevice(device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipSetDevice(%d) failed", device));
     if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipGetDeviceProperties failed"));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipStreamCreate failed"));
+    c->streams.assign(1, c->stream);
+    c->nstreams = 1;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipEventCreate failed"));
 
     // host tables
@@ -407,7 +432,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
 void lt_destroy(lt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto st : c->streams) if (st) (void)hipStreamSynchronize(st);
     free_slots(c);
     dev_free(c->d_uxy);
     dev_free(c->d_wxy);
@@ -419,7 +444,8 @@ void lt_destroy(lt_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto st : c->streams) if (st) (void)hipStreamDestroy(st);
+    if (c->streams.empty() && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -429,7 +455,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     int rc = set_device(c);
     if (rc) return rc;
     if (capacity <= c->capacity) return LT_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = sync_all(c))) return rc;
     free_slots(c);
     c->capacity = capacity;
     const size_t n = (size_t)capacity;
@@ -469,7 +495,22 @@ int lt_get_info(lt_ctx* c, lt_info* out) {
 
 int lt_sync(lt_ctx* c) {
     if (!c) return fail(LT_ERR_INVALID, "null context");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    return sync_all(c);
+}
+
+int lt_set_streams(lt_ctx* c, int nstreams) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (nstreams < 1 || nstreams > 8) return fail(LT_ERR_INVALID, "nstreams must be in [1, 8]");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
+    if ((rc = flush_stage_events(c))) return rc;
+    while ((int)c->streams.size() < nstreams) {
+        hipStream_t st = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c->streams.push_back(st);
+    }
+    c->nstreams = nstreams;
     return LT_OK;
 }
 
@@ -479,6 +520,7 @@ int lt_upload_frames(lt_ctx* c, const uint8_t* frames, int first, int n) {
     if (rc) return rc;
     if (!frames) return fail(LT_ERR_INVALID, "null frames");
     if ((rc = set_device(c))) return rc;
+    if ((rc = sync_all(c))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_frames + (size_t)first * c->frame_bytes, frames, (size_t)n * c->frame_bytes,
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -490,6 +532,7 @@ int lt_upload_masks(lt_ctx* c, const uint8_t* masks, int first, int n) {
     if (rc) return rc;
     if (!masks) return fail(LT_ERR_INVALID, "null masks");
     if ((rc = set_device(c))) return rc;
+    if ((rc = sync_all(c))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, masks, (size_t)n * c->plane_bytes,
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -503,6 +546,7 @@ int lt_upload_bev(lt_ctx* c, const uint8_t* bev, int first, int n) {
     if (!bev) return fail(LT_ERR_INVALID, "null image");
     if ((rc = set_device(c))) return rc;
     if ((rc = ensure_bev(c))) return rc;
+    if ((rc = sync_all(c))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_bev + (size_t)first * c->bev_bytes, bev, (size_t)n * c->bev_bytes,
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -513,6 +557,7 @@ static int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
     if (!dst) return fail(LT_ERR_INVALID, "null output buffer");
     int rc = set_device(c);
     if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;      // results may come from any of the context's streams
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
@@ -531,6 +576,7 @@ int lt_download_plane(lt_ctx* c, int plane, int first, int n, uint8_t* out) {
     if (plane < 0 || plane > 5) return fail(LT_ERR_INVALID, "unknown plane %d", plane);
     if (plane == LT_PLANE_MERGED) {   // kept bit-packed on the device; expand on demand
         if ((rc = set_device(c))) return rc;
+        if ((rc = sync_all(c))) return rc;
         launch_bits_to_u8(c->stream, c->d_bits_merged + (size_t)first * c->bits_stride,
                           c->d_plane[P_MERGED] + (size_t)first * c->plane_bytes, c->calib.warp_h, c->calib.warp_w,
                           c->plane_bytes, c->bits_stride, n);
@@ -545,6 +591,7 @@ int lt_download_undistorted(lt_ctx* c, int first, int n, uint8_t* out) {
     if (n == 0 || c->und_bytes == 0) return LT_OK;
     if ((rc = set_device(c))) return rc;
     uint8_t* tmp = nullptr;
+    if ((rc = sync_all(c))) return rc;
     if ((rc = dev_alloc(&tmp, (size_t)n * c->und_bytes))) return rc;
     launch_undistorted_to_rgb(c->stream, c->d_und + (size_t)first * c->und_px, c->und_px, c->fe.nrows,
                               c->fe.img_w, tmp, n);
@@ -601,6 +648,7 @@ int lt_copy_records_to_device(lt_ctx* c, int first, int n, void* dst) {
     if (rc) return rc;
     if (!dst) return fail(LT_ERR_INVALID, "null destination");
     if ((rc = set_device(c))) return rc;
+    if ((rc = sync_all(c))) return rc;
     HIP_TRY(hipMemcpyAsync(dst, c->d_rec + first, (size_t)n * sizeof(lt_lane_record), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
@@ -627,14 +675,17 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     if ((rc = set_device(c))) return rc;
     if (n == 0) return LT_OK;
     const size_t ps = c->plane_bytes;
-    { StageScope t(c, ST_UNDISTORT);
-      launch_undistort_rows(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->frame_bytes, c->d_uxy,
-                            c->d_ufrac, c->fe, c->d_und + (size_t)first * c->und_px, c->und_px, n); }
-    { StageScope t(c, ST_WARP_SPLIT);
-      launch_warp_split(c->stream, c->d_und + (size_t)first * c->und_px, c->und_px, c->d_wxy, c->d_wfrac, c->fe,
-                        c->d_gamma, c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)first * ps,
-                        c->d_plane[P_B] + (size_t)first * ps, ps, n); }
-    if ((rc = run_filter_chain(c, first, n, p, c->calib.warp_h, c->calib.warp_w))) return rc;
+    rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
+        { StageScope t(c, ST_UNDISTORT, st);
+          launch_undistort_rows(st, c->d_frames + (size_t)f0 * c->frame_bytes, c->frame_bytes, c->d_uxy, c->d_ufrac,
+                                c->fe, c->d_und + (size_t)f0 * c->und_px, c->und_px, m); }
+        { StageScope t(c, ST_WARP_SPLIT, st);
+          launch_warp_split(st, c->d_und + (size_t)f0 * c->und_px, c->und_px, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
+                            c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
+                            ps, m); }
+        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w);
+    });
+    if (rc) return rc;
     c->have_mask = true;
     return LT_OK;
 }
@@ -647,10 +698,13 @@ int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     if (!c->d_bev) return fail(LT_ERR_STATE, "lt_upload_bev has not been called");
     if (n == 0) return LT_OK;
     const size_t ps = c->plane_bytes;
-    { StageScope t(c, ST_SPLIT_BEV);
-      launch_split_bev(c->stream, c->d_bev + (size_t)first * c->bev_bytes, c->bev_bytes, (int)ps, c->d_gamma, c->d_cbrt,
-                       c->d_coef, c->d_plane[P_R] + (size_t)first * ps, c->d_plane[P_B] + (size_t)first * ps, ps, n); }
-    if ((rc = run_filter_chain(c, first, n, p, c->calib.warp_h, c->calib.warp_w))) return rc;
+    rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
+        { StageScope t(c, ST_SPLIT_BEV, st);
+          launch_split_bev(st, c->d_bev + (size_t)f0 * c->bev_bytes, c->bev_bytes, (int)ps, c->d_gamma, c->d_cbrt,
+                           c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps, ps, m); }
+        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w);
+    });
+    if (rc) return rc;
     c->have_mask = true;
     return LT_OK;
 }
@@ -664,7 +718,7 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     if ((rc = make_search_geom(c, p, false, g))) return rc;
     if ((rc = ensure_search_buffers(c, g.maxpix, g.maxlev))) return rc;
     if (g.nbands > c->maxbands) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if ((rc = sync_all(c))) return rc;
         dev_free(c->d_band_sums);
         if ((rc = dev_alloc(&c->d_band_sums, (size_t)c->capacity * g.nbands * c->calib.warp_w))) return rc;
         c->maxbands = g.nbands;
@@ -672,10 +726,14 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     g.maxpix = c->maxpix;
     g.maxlev = c->maxlev;
     if (n == 0) return LT_OK;
-    { StageScope t(c, ST_SWS_FIT);
-      launch_sws_fit(c->stream, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, g,
-                     c->d_band_sums + (size_t)first * g.nbands * c->calib.warp_w, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_cent + (size_t)first * 2 * (c->maxlev + 2),
-                     c->d_rec + first, n); }
+    rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
+        StageScope t(c, ST_SWS_FIT, st);
+        launch_sws_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, g,
+                       c->d_band_sums + (size_t)f0 * g.nbands * c->calib.warp_w, c->d_pix + (size_t)f0 * 2 * c->maxpix,
+                       c->d_cent + (size_t)f0 * 2 * (c->maxlev + 2), c->d_rec + f0, m);
+        return (int)LT_OK;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return LT_OK;
 }
@@ -691,11 +749,16 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
     if ((rc = ensure_search_buffers(c, g.maxpix, 1))) return rc;
     g.maxpix = c->maxpix;
     if (n == 0) return LT_OK;
+    if ((rc = sync_all(c))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_prev + (size_t)first * 6, prev, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // prev is caller memory: do not keep reading it after return
-    { StageScope t(c, ST_BAND_FIT);
-      launch_band_fit(c->stream, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, g,
-                      c->d_prev + (size_t)first * 6, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n); }
+    rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
+        StageScope t(c, ST_BAND_FIT, st);
+        launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, g, c->d_prev + (size_t)f0 * 6,
+                        c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
+        return (int)LT_OK;
+    });
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return LT_OK;
 }
@@ -787,7 +850,7 @@ int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_
     if (e == hipSuccess) {
         launch_split_bev(c->stream, d_bev, tmp.plane_bytes * 3, (int)tmp.plane_bytes, c->d_gamma, c->d_cbrt, c->d_coef,
                          tmp.d_plane[P_R], tmp.d_plane[P_B], tmp.plane_bytes, 1);
-        rc = run_filter_chain(&tmp, 0, 1, p, h, w);
+        rc = run_filter_chain(&tmp, c->stream, 0, 1, p, h, w);
         if (rc == LT_OK) e = hipMemcpyAsync(mask, tmp.d_plane[P_MASK], tmp.plane_bytes, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -871,12 +934,14 @@ extern "C" int lt_debug_cycles(lt_ctx* c, long long* out16, int reset) {
 // ---- measurement ---------------------------------------------------------------------------------------
 int lt_timer_start(lt_ctx* c) {
     if (!c) return fail(LT_ERR_INVALID, "null context");
+    { int rc = sync_all(c); if (rc) return rc; }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     return LT_OK;
 }
 
 int lt_timer_stop(lt_ctx* c, float* ms) {
     if (!c || !ms) return fail(LT_ERR_INVALID, "null argument");
+    { int rc = sync_all(c); if (rc) return rc; }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));

@@ -332,3 +332,44 @@ def test_morph_ellipse_footprint_probe(ctx, oracle):
             img[70, x] = 0
             assert_same(ctx.morph_ellipse(img, k, "erode"), oracle.erode(img, k), f"erode probe {k} x={x}")
             assert_same(ctx.morph_ellipse(255 - img, k, "dilate"), oracle.dilate(255 - img, k), f"dilate probe {k} x={x}")
+
+
+def test_multi_stream_context_gives_identical_results(nat, cal, frames):
+    """lt_set_streams: slot slices on different HIP streams must not change a single bit, whatever
+    the slice boundaries do to the batch (also partial ranges and a band search on top)."""
+    from lane_tracker_amd import synth
+    r = synth.SceneRenderer()
+    batch = np.concatenate([frames, np.stack([r.render(700 + i)[0] for i in range(5)], 0)], 0)   # 11 frames
+    n = batch.shape[0]
+    ref = None
+    for k in (1, 2, 3, 8):
+        c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
+                        cal["warp_matrices"][0], device=0, capacity=n)
+        try:
+            c.set_streams(k)
+            c.upload_frames(batch)
+            c.mask_run(n)
+            c.sws_fit_run(n)
+            c.mask_run(4, nat.filter_params(filter_type="neighborhood", C_r=5), first=3)     # partial range, other params
+            c.sws_fit_run(4, nat.search_params(no_success_limit=50), first=3)
+            masks, rec = c.download_masks(n), c.download_records(n)
+            prev = np.tile(np.concatenate([rec[8]["left_coeffs"], rec[8]["right_coeffs"]]), (n, 1))
+            c.band_fit_run(n, prev)
+            rec_b = c.download_records(n)
+            pix = [c.download_pixels(i, s) for i in (0, 5, 10) for s in (0, 1)]
+            got = (masks, rec, rec_b, pix)
+        finally:
+            c.close()
+        if ref is None:
+            ref = got
+            continue
+        assert np.array_equal(got[0], ref[0]), k
+        assert got[1].tobytes() == ref[1].tobytes() and got[2].tobytes() == ref[2].tobytes(), k
+        for (y, x), (ry, rx) in zip(got[3], ref[3]):
+            assert np.array_equal(y, ry) and np.array_equal(x, rx), k
+    with pytest.raises(ValueError):
+        c2 = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0])
+        try:
+            c2.set_streams(0)
+        finally:
+            c2.close()
