@@ -373,3 +373,74 @@ def test_multi_stream_context_gives_identical_results(nat, cal, frames):
             c2.set_streams(0)
         finally:
             c2.close()
+
+
+def test_odd_sizes_take_the_generic_paths(nat, oracle):
+    """Camera 641x361 and bird's-eye 541x551: nothing is a multiple of 4, so the dword fast paths
+    (4 px/thread warp, aligned band staging, vectorised band sums / window extraction, dword mask
+    expansion) all fall back to their generic variants.  Same bar: bit-exact against the oracle."""
+    from lane_tracker_amd import calib
+    S = np.diag([0.5, 0.5, 1.0])
+    K = S @ calib.CAM_MATRIX
+    M = S @ calib.M @ np.diag([2.0, 2.0, 1.0])
+    img_size, warped = (641, 361), (541, 551)
+    oc = oracle.make_calib(img_size, warped, K, calib.DIST_COEFFS, M)
+    c = nat.Context(img_size, warped, K, calib.DIST_COEFFS, M, device=0, capacity=3)
+    try:
+        rng = np.random.default_rng(12)
+        frames = rng.integers(0, 256, (3, 361, 641, 3), dtype=np.uint8)
+        frames[1] = np.clip(90 + rng.integers(-10, 11, (361, 641, 1)), 0, 255).astype(np.uint8)
+        frames[1, 200:, 250:262] = (235, 235, 235)                      # two bright stripes on grey
+        frames[1, 200:, 380:392] = (220, 190, 60)
+        c.upload_frames(frames)
+        i = c.info()
+        assert (i.src_row0, i.src_row1) == oracle.warp_source_rows(oc)
+        for kw in (dict(), dict(filter_type="neighborhood", C_r=5), dict(mask_noise=True)):
+            c.mask_run(3, nat.filter_params(**kw))
+            masks = c.download_masks(3)
+            R, B = c.download_plane(0, 3), c.download_plane(1, 3)
+            for k in range(3):
+                bev = oracle.front_end(oc, frames[k])
+                assert_same(R[k], bev[:, :, 0], f"odd R {k}")
+                assert_same(B[k], oracle.lab_b(bev), f"odd Lab-b {k}")
+                assert_same(masks[k], oracle.filter_lane_points(bev, oracle.filter_params(**kw)), f"odd mask {k} {kw}")
+        sp = dict(window_width=14, window_height=20, search_range=10, ignore_sides=180, ignore_bottom=15)
+        c.mask_run(3)
+        c.sws_fit_run(3, nat.search_params(**sp))
+        masks = c.download_masks(3)
+        rec = c.download_records(3)
+        for k in range(3):
+            o = oracle.sliding_window_search(masks[k], oracle.search_params(**sp))
+            assert bool(rec[k]["detected"]) == o["detected"]
+            for side, (ky, kx) in enumerate((("left_y", "left_x"), ("right_y", "right_x"))):
+                y, x = c.download_pixels(k, side)
+                assert_same(y, o[ky], f"odd {ky} {k}"); assert_same(x, o[kx], f"odd {kx} {k}")
+            assert c.download_centroids(k, 0) == o["left_centroids"] and c.download_centroids(k, 1) == o["right_centroids"]
+        prev = np.tile(np.array([0.0, 0.0, 200.0, 0.0, 0.0, 330.0]), (3, 1))
+        bp = dict(bandwidth=12, ignore_bottom=15)
+        c.band_fit_run(3, prev, nat.search_params(**bp))
+        rec = c.download_records(3)
+        for k in range(3):
+            o = oracle.band_search(masks[k], prev[k, :3], prev[k, 3:], oracle.search_params(**bp))
+            assert bool(rec[k]["detected"]) == o["detected"]
+            if o["detected"]:
+                y, x = c.download_pixels(k, 1)
+                assert_same(y, o["right_y"], f"odd band right_y {k}"); assert_same(x, o["right_x"], f"odd band right_x {k}")
+    finally:
+        c.close()
+
+
+def test_full_size_morphology_properties(ctx):
+    """Size-independent properties at the bird's-eye size: opening is idempotent and anti-extensive,
+    top-hat + opening reassemble the image, erosion <= image <= dilation."""
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (1100, 1080), dtype=np.uint8)
+    for k in (29, 55):
+        op = ctx.morph_ellipse(img, k, "open")
+        assert np.array_equal(ctx.morph_ellipse(op, k, "open"), op)
+        assert (op <= img).all()
+        th = ctx.morph_ellipse(img, k, "tophat")
+        assert np.array_equal(th.astype(np.int32) + op, img)
+        er, di = ctx.morph_ellipse(img, k, "erode"), ctx.morph_ellipse(img, k, "dilate")
+        assert (er <= img).all() and (img <= di).all()
+        assert np.array_equal(255 - ctx.morph_ellipse(255 - img, k, "dilate"), er)     # duality
