@@ -29,14 +29,16 @@ __device__ __forceinline__ int bilerp(int v00, int v01, int v10, int v11, int fx
 // dword per pixel, so that the warp fetches a whole tap with a single aligned load.  All loads are
 // unconditional on clamped addresses and masked afterwards (a guarded load serialises on its own
 // s_waitcnt).
+constexpr int UND_FPB = 4;   // frames per thread: the table entry and the tap offsets are frame-independent
+
 __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restrict__ frames, size_t frame_stride,
                                                        const int16_t* __restrict__ uxy,
                                                        const uint16_t* __restrict__ ufrac, FrontEndGeom g,
-                                                       uint32_t* __restrict__ und, size_t und_stride_px) {
+                                                       uint32_t* __restrict__ und, size_t und_stride_px, int n) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;  // relative to g.r0
     if (x >= g.img_w) return;
-    const uint8_t* src = frames + (size_t)blockIdx.z * frame_stride;
+    const int z0 = blockIdx.z * UND_FPB, z1 = min(z0 + UND_FPB, n);
     const size_t o = (size_t)row * g.img_w + x;
     const int sx = uxy[o * 2], sy = uxy[o * 2 + 1];
     const int f = ufrac[o], fx = f & 31, fy = f >> 5;
@@ -46,24 +48,34 @@ __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restric
     // The two taps of a row are 6 consecutive bytes (RGB RGB) at byte offset 3*sx: one unaligned 8-byte
     // load per row instead of six byte loads (the frame buffer is padded by 8 bytes for the overrun).
     // When sx or sx+1 is outside the frame the row is fetched from the clamped column and the taps
-    // are masked, exactly as before.
+    // are masked.
     struct __attribute__((packed, aligned(1))) Row8 { uint64_t v; };
     const int cxl = min(max(sx, 0), g.img_w - 2);          // leftmost column of the 6-byte window we fetch
     // 32-bit offsets (a frame is far below 2^31 bytes) keep the address math on full-rate 24-bit multiplies
-    const uint64_t q0 = reinterpret_cast<const Row8*>(src + (uint32_t)((__mul24(cy0, g.img_w) + cxl) * 3))->v;
-    const uint64_t q1 = reinterpret_cast<const Row8*>(src + (uint32_t)((__mul24(cy1, g.img_w) + cxl) * 3))->v;
+    const uint32_t off0 = (uint32_t)((__mul24(cy0, g.img_w) + cxl) * 3), off1 = (uint32_t)((__mul24(cy1, g.img_w) + cxl) * 3);
     // column sx sits at byte 3*(sx-cxl) of the window when it is inside the frame; sx+1 three bytes later
     const int sh0 = 24 * (min(max(sx, 0), g.img_w - 1) - cxl), sh1 = 24 * (min(max(sx + 1, 0), g.img_w - 1) - cxl);
-    const uint32_t a0 = (uint32_t)(q0 >> sh0), a1 = (uint32_t)(q0 >> sh1);
-    const uint32_t b0 = (uint32_t)(q1 >> sh0), b1 = (uint32_t)(q1 >> sh1);
-    uint32_t out = 0;
+    const uint32_t m00 = (y0 && x0) ? 255u : 0u, m01 = (y0 && x1) ? 255u : 0u;
+    const uint32_t m10 = (y1 && x0) ? 255u : 0u, m11 = (y1 && x1) ? 255u : 0u;
+    const uint8_t* src = frames + (size_t)z0 * frame_stride;
+    uint64_t q0 = reinterpret_cast<const Row8*>(src + off0)->v, q1 = reinterpret_cast<const Row8*>(src + off1)->v;
+    for (int z = z0; z < z1; ++z) {
+        // the next frame's taps are in flight while this one is blended
+        const uint8_t* nsrc = frames + (size_t)min(z + 1, z1 - 1) * frame_stride;
+        const uint64_t n0 = reinterpret_cast<const Row8*>(nsrc + off0)->v, n1 = reinterpret_cast<const Row8*>(nsrc + off1)->v;
+        const uint32_t a0 = (uint32_t)(q0 >> sh0), a1 = (uint32_t)(q0 >> sh1);
+        const uint32_t b0 = (uint32_t)(q1 >> sh0), b1 = (uint32_t)(q1 >> sh1);
+        uint32_t out = 0;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const int v00 = (y0 && x0) ? (int)((a0 >> (8 * ch)) & 255u) : 0, v01 = (y0 && x1) ? (int)((a1 >> (8 * ch)) & 255u) : 0;
-        const int v10 = (y1 && x0) ? (int)((b0 >> (8 * ch)) & 255u) : 0, v11 = (y1 && x1) ? (int)((b1 >> (8 * ch)) & 255u) : 0;
-        out |= (uint32_t)bilerp(v00, v01, v10, v11, fx, fy) << (8 * ch);
+        for (int ch = 0; ch < 3; ++ch) {
+            const int v00 = (int)((a0 >> (8 * ch)) & m00), v01 = (int)((a1 >> (8 * ch)) & m01);
+            const int v10 = (int)((b0 >> (8 * ch)) & m10), v11 = (int)((b1 >> (8 * ch)) & m11);
+            out |= (uint32_t)bilerp(v00, v01, v10, v11, fx, fy) << (8 * ch);
+        }
+        und[(size_t)z * und_stride_px + o] = out;
+        q0 = n0;
+        q1 = n1;
     }
-    und[(size_t)blockIdx.z * und_stride_px + o] = out;
 }
 
 struct LabLut {
@@ -130,43 +142,34 @@ __device__ __forceinline__ void warp_pixel(const uint32_t* __restrict__ src, con
     b_out = lab_b_of(rgb[0], rgb[1], rgb[2], gt, ct, C);
 }
 
-// all four taps inside the staged rows: no clamps, no masks, 32-bit offsets from a scalar base
-__device__ __forceinline__ void warp_pixel_inside(const uint32_t* __restrict__ src, int img_w, int r0, int sx, int sy,
-                                                  int f, const uint16_t* gt, const uint16_t* ct, const int32_t* C,
-                                                  int& r_out, int& b_out) {
-    // the two taps of a row are adjacent dwords: one 8-byte load each (4-byte aligned)
-    struct __attribute__((packed, aligned(4))) Tap2 { uint32_t a, b; };
-    const int o = __mul24(sy - r0, img_w) + sx;
-    const Tap2 top = *reinterpret_cast<const Tap2*>(src + o), bot = *reinterpret_cast<const Tap2*>(src + o + img_w);
-    const uint32_t t00 = top.a, t01 = top.b, t10 = bot.a, t11 = bot.b;
-    int rgb[3];
-    blend_taps(t00, t01, t10, t11, f & 31, f >> 5, rgb);
-    r_out = rgb[0];
-    b_out = lab_b_of(rgb[0], rgb[1], rgb[2], gt, ct, C);
-}
-
 // Four adjacent bird's-eye pixels per thread: bilinear samples of the RGBX undistorted rows, then
 // one dword store to the R plane and one to the Lab-b plane.  `quads` = pixels / 4 (w % 4 == 0).
+// The remap table entry of a quad is the same for every frame, so a thread keeps it (and the tap
+// offsets derived from it) in registers and walks WARP_FPB consecutive frames with it; the taps of
+// frame z+1 are in flight while frame z is blended (the kernel is bound by gather latency).
+constexpr int WARP_FPB = 4;
+
 __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict__ und, size_t und_stride_px,
                                                     const int16_t* __restrict__ wxy,
                                                     const uint16_t* __restrict__ wfrac, FrontEndGeom g,
                                                     const uint16_t* __restrict__ gamma_tab,
                                                     const uint16_t* __restrict__ cbrt_tab,
                                                     const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
-                                                    uint8_t* __restrict__ planeB, size_t plane_stride) {
+                                                    uint8_t* __restrict__ planeB, size_t plane_stride, int n) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_cbrt[3072];
     __shared__ int32_t s_coef[9];
-    stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
     const size_t quads = ((size_t)g.warp_h * g.warp_w) >> 2;
     const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t qc = qi < quads ? qi : quads - 1;
+    // the table entry is requested before the Lab tables are staged: both latencies overlap
+    const uint4 xy = reinterpret_cast<const uint4*>(wxy)[qc];        // 4 x (sx, sy) int16 pairs
+    const uint2 fr = reinterpret_cast<const uint2*>(wfrac)[qc];      // 4 x u16
+    stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
     if (qi >= quads) return;
-    const uint32_t* src = und + (size_t)blockIdx.z * und_stride_px;
-    const uint4 xy = reinterpret_cast<const uint4*>(wxy)[qi];        // 4 x (sx, sy) int16 pairs
-    const uint2 fr = reinterpret_cast<const uint2*>(wfrac)[qi];      // 4 x u16
+    const int z0 = blockIdx.z * WARP_FPB, z1 = min(z0 + WARP_FPB, n);
     const uint32_t xyv[4] = {xy.x, xy.y, xy.z, xy.w};
     const uint32_t frv[4] = {fr.x & 0xffffu, fr.x >> 16, fr.y & 0xffffu, fr.y >> 16};
-    uint32_t outR = 0, outB = 0;
     // 87 % of the bird's-eye view samples strictly inside the staged rows: skip every border test there
     bool inside = true;
 #pragma unroll
@@ -174,21 +177,68 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
         const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
         inside = inside && sx >= 0 && sx + 1 < g.img_w && sy >= g.r0 && sy + 1 < g.r0 + g.nrows && sy + 1 < g.img_h;
     }
+    if (inside) {
+        // the two taps of a row are adjacent dwords: one 8-byte load each (4-byte aligned)
+        struct __attribute__((packed, aligned(4))) Tap2 { uint32_t a, b; };
+        int off[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
-        int r, b;
-        if (inside) warp_pixel_inside(src, g.img_w, g.r0, sx, sy, (int)frv[i], s_gamma, s_cbrt, s_coef, r, b);
-        else warp_pixel(src, g, sx, sy, (int)frv[i], s_gamma, s_cbrt, s_coef, r, b);
-        // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
-        // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the
-        // third pixel (caught by the parity test); the barrier costs nothing at run time.
-        asm volatile("" : "+v"(r), "+v"(b));
-        outR |= ((uint32_t)r & 255u) << (8 * i);
-        outB |= ((uint32_t)b & 255u) << (8 * i);
+        for (int i = 0; i < 4; ++i) {
+            const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
+            off[i] = __mul24(sy - g.r0, g.img_w) + sx;
+        }
+        Tap2 top[4], bot[4];
+        const uint32_t* src = und + (size_t)z0 * und_stride_px;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            top[i] = *reinterpret_cast<const Tap2*>(src + off[i]);
+            bot[i] = *reinterpret_cast<const Tap2*>(src + off[i] + g.img_w);
+        }
+        for (int z = z0; z < z1; ++z) {
+            Tap2 ntop[4], nbot[4];
+            const uint32_t* nsrc = und + (size_t)min(z + 1, z1 - 1) * und_stride_px;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ntop[i] = *reinterpret_cast<const Tap2*>(nsrc + off[i]);
+                nbot[i] = *reinterpret_cast<const Tap2*>(nsrc + off[i] + g.img_w);
+            }
+            uint32_t outR = 0, outB = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int rgb[3];
+                blend_taps(top[i].a, top[i].b, bot[i].a, bot[i].b, (int)(frv[i] & 31u), (int)(frv[i] >> 5), rgb);
+                int r = rgb[0], b = lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, s_coef);
+                // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
+                // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the
+                // third pixel (caught by the parity test); the barrier costs nothing at run time.
+                asm volatile("" : "+v"(r), "+v"(b));
+                outR |= ((uint32_t)r & 255u) << (8 * i);
+                outB |= ((uint32_t)b & 255u) << (8 * i);
+            }
+            reinterpret_cast<uint32_t*>(planeR + (size_t)z * plane_stride)[qi] = outR;
+            reinterpret_cast<uint32_t*>(planeB + (size_t)z * plane_stride)[qi] = outB;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                top[i] = ntop[i];
+                bot[i] = nbot[i];
+            }
+        }
+        return;
     }
-    reinterpret_cast<uint32_t*>(planeR + (size_t)blockIdx.z * plane_stride)[qi] = outR;
-    reinterpret_cast<uint32_t*>(planeB + (size_t)blockIdx.z * plane_stride)[qi] = outB;
+    for (int z = z0; z < z1; ++z) {
+        const uint32_t* src = und + (size_t)z * und_stride_px;
+        uint32_t outR = 0, outB = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
+            int r, b;
+            warp_pixel(src, g, sx, sy, (int)frv[i], s_gamma, s_cbrt, s_coef, r, b);
+            asm volatile("" : "+v"(r), "+v"(b));
+            outR |= ((uint32_t)r & 255u) << (8 * i);
+            outB |= ((uint32_t)b & 255u) << (8 * i);
+        }
+        reinterpret_cast<uint32_t*>(planeR + (size_t)z * plane_stride)[qi] = outR;
+        reinterpret_cast<uint32_t*>(planeB + (size_t)z * plane_stride)[qi] = outB;
+    }
 }
 
 // any width: one pixel per thread
@@ -248,8 +298,8 @@ __global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint32_t* __re
 void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
                            const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_stride_px, int n) {
     if (n <= 0 || g.nrows <= 0) return;
-    dim3 grid((g.img_w + 255) / 256, g.nrows, n);
-    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px);
+    dim3 grid((g.img_w + 255) / 256, g.nrows, (n + UND_FPB - 1) / UND_FPB);
+    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px, n);
 }
 
 void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy,
@@ -258,9 +308,9 @@ void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px,
     if (n <= 0 || g.nrows <= 0) return;
     const size_t npix = (size_t)g.warp_h * g.warp_w;
     if ((g.warp_w & 3) == 0 && (plane_stride & 3) == 0) {
-        dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, n);
+        dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, (n + WARP_FPB - 1) / WARP_FPB);
         hipLaunchKernelGGL(k_warp_split4, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
-                           coeffs, planeR, planeB, plane_stride);
+                           coeffs, planeR, planeB, plane_stride, n);
     } else {
         dim3 grid((unsigned)((npix + 255) / 256), 1, n);
         hipLaunchKernelGGL(k_warp_split1, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
