@@ -169,6 +169,26 @@ int  lt_morph_ellipse(lt_ctx* ctx, const uint8_t* img, int h, int w, int k, int 
 int  lt_fit_poly2(lt_ctx* ctx, const int32_t* ys, const int32_t* xs, int n, int h, int w, double coef[3],
                   int* rank_deficient);
 
+/* ---- presentation stage (next row after the hot path) ------------------------ */
+/* Minv: the pickled inverse perspective matrix the reference hands to warpPerspective in draw_lane
+ * (lane_tracker.py:648); builds the camera-sized remap table once. */
+int  lt_overlay_configure(lt_ctx* ctx, const double* Minv /* 9 */);
+/* draw_lane() without the text (lane_tracker.py:637-662) for the frames in slots [first, first+n):
+ * fillPoly of the polygon left points + reversed right points in (0,255,0), warpPerspective with Minv,
+ * addWeighted(frame, 1, lane, alpha, 0).  left_n/right_n: points per slot; left_yx/right_yx: (y, x)
+ * int32 pairs of all slots, concatenated.  A slot with no points yields a copy of its frame. */
+int  lt_overlay_run(lt_ctx* ctx, int first_slot, int n, const int32_t* left_n, const int32_t* right_n,
+                    const int32_t* left_yx, const int32_t* right_yx, double alpha);
+/* Host-only helper (no GPU needed): the (lo, hi) column interval per bird's-eye row that cv2.fillPoly
+ * paints for that polygon; empty rows are (32767, -32768).  spans: warp_h * 2 int16. */
+int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,
+                           int16_t* spans);
+/* annotated frames, RGB interleaved, n * img_h * img_w * 3 bytes */
+int  lt_download_overlay(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+/* the bird's-eye RGB image of the slots' frames (lane_tracker.py:834, :1035): n * warp_h * warp_w * 3;
+ * needs lt_mask_run on those slots first (it reuses their undistorted rows) */
+int  lt_download_bev(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* hipEvent pair on the context's stream */
 int  lt_timer_start(lt_ctx* ctx);

@@ -78,6 +78,11 @@ _SIGNATURES = {
     "lt_download_pixels": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "lt_download_centroids": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "lt_copy_records_to_device": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_overlay_configure": (C.c_int, [_P, _P]),
+    "lt_overlay_run": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double]),
+    "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
+    "lt_download_overlay": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_download_bev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
@@ -241,6 +246,34 @@ class Context:
         _check(self.lib.lt_download_undistorted(self._h, first, n, out.ctypes.data))
         return out
 
+    # ---- presentation stage (draw_lane overlay, bird's-eye image) ----
+    def overlay_configure(self, Minv):
+        m = np.ascontiguousarray(Minv, np.float64).reshape(9)
+        _check(self.lib.lt_overlay_configure(self._h, m.ctypes.data))
+
+    def overlay_run(self, polygons, first=0, alpha=0.3):
+        """polygons: one (left_y, left_x, right_y, right_x) tuple per slot (empty arrays: plain copy)."""
+        n = len(polygons)
+        ln = np.array([len(p[0]) for p in polygons], np.int32)
+        rn = np.array([len(p[2]) for p in polygons], np.int32)
+        lyx = np.ascontiguousarray(np.concatenate([np.stack([np.asarray(p[0]), np.asarray(p[1])], 1).reshape(-1, 2)
+                                                   for p in polygons] or [np.zeros((0, 2))]), np.int32)
+        ryx = np.ascontiguousarray(np.concatenate([np.stack([np.asarray(p[2]), np.asarray(p[3])], 1).reshape(-1, 2)
+                                                   for p in polygons] or [np.zeros((0, 2))]), np.int32)
+        _check(self.lib.lt_overlay_run(self._h, first, n, ln.ctypes.data, rn.ctypes.data,
+                                       lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None,
+                                       float(alpha)))
+
+    def download_overlay(self, n, first=0):
+        out = np.empty((n, self.img_h, self.img_w, 3), np.uint8)
+        _check(self.lib.lt_download_overlay(self._h, first, n, out.ctypes.data))
+        return out
+
+    def download_bev(self, n, first=0):
+        out = np.empty((n, self.warp_h, self.warp_w, 3), np.uint8)
+        _check(self.lib.lt_download_bev(self._h, first, n, out.ctypes.data))
+        return out
+
     def download_records(self, n, first=0):
         out = np.zeros(n, RECORD_DTYPE)
         _check(self.lib.lt_download_records(self._h, first, n, out.ctypes.data))
@@ -357,3 +390,14 @@ def device_count():
     n = C.c_int(0)
     _check(load().lt_device_count(C.byref(n)))
     return n.value
+
+
+def lane_polygon_spans(warp_h, left_y, left_x, right_y, right_x):
+    """(warp_h, 2) int16 (lo, hi) column interval per bird's-eye row of draw_lane's filled polygon
+    (host-only helper of the overlay stage; rows the polygon does not touch are (32767, -32768))."""
+    lyx = np.ascontiguousarray(np.stack([np.asarray(left_y), np.asarray(left_x)], 1).reshape(-1, 2), np.int32)
+    ryx = np.ascontiguousarray(np.stack([np.asarray(right_y), np.asarray(right_x)], 1).reshape(-1, 2), np.int32)
+    out = np.empty((int(warp_h), 2), np.int16)
+    _check(load().lt_lane_polygon_spans(int(warp_h), lyx.ctypes.data if len(lyx) else None, len(lyx),
+                                        ryx.ctypes.data if len(ryx) else None, len(ryx), out.ctypes.data))
+    return out

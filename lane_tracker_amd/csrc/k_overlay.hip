@@ -1,0 +1,143 @@
+// Presentation stage on the device, gfx950.
+//
+//   k_overlay_lane   draw_lane()  lane_tracker.py:629-662 without the text:
+//                    fillPoly((0,255,0)) on a blank bird's-eye image, warpPerspective(.., Minv, camera size),
+//                    addWeighted(img, 1, lane, 0.3, 0)
+//   k_warp_rgb       the bird's-eye RGB image itself (lane_tracker.py:1035) for split_view
+//
+// The filled polygon is never rasterised: it is y-monotone (both lane curves are functions of y), so
+// it is described by one column interval [lo, hi] per bird's-eye row (built on the host from the
+// 8-connected edge lines, lt_api.cpp).  The inverse warp is OpenCV's fixed-point bilinear remap of that
+// 0/255 image: each camera pixel tests its four taps against the row intervals.  Only the green byte
+// changes; 0.3*lane is added in f32 and rounded half-to-even like cv::addWeighted's saturate_cast.
+#include "lt_internal.h"
+
+namespace lt {
+namespace {
+
+__device__ __forceinline__ int tap_in(const short2* __restrict__ spans, int bh, int bw, int x, int y) {
+    const short2 s = spans[min(max(y, 0), bh - 1)];
+    return (y >= 0 && y < bh && x >= 0 && x < bw && x >= s.x && x <= s.y) ? 255 : 0;
+}
+
+__device__ __forceinline__ int lane_value(const short2* __restrict__ spans, int bh, int bw, int sx, int sy, int f) {
+    const int fx = f & 31, fy = f >> 5, gx = 32 - fx, gy = 32 - fy;
+    const int v00 = tap_in(spans, bh, bw, sx, sy), v01 = tap_in(spans, bh, bw, sx + 1, sy);
+    const int v10 = tap_in(spans, bh, bw, sx, sy + 1), v11 = tap_in(spans, bh, bw, sx + 1, sy + 1);
+    const int h0 = __mul24(v00, gx) + __mul24(v01, fx), h1 = __mul24(v10, gx) + __mul24(v11, fx);
+    return (__mul24(h0, gy) + __mul24(h1, fy) + 512) >> 10;      // == (sum w_i v_i + 2^14) >> 15
+}
+
+__device__ __forceinline__ uint32_t blend_green(uint32_t g, int lane, float alpha) {
+    const float t = __fadd_rn((float)g, __fmul_rn((float)lane, alpha));   // no fma: cv::addWeighted rounds the product
+    const int r = (int)rintf(t);
+    return (uint32_t)min(max(r, 0), 255);
+}
+
+// One thread per camera pixel; `spans` = (lo, hi) int16 per bird's-eye row of this slot.
+__global__ __launch_bounds__(256) void k_overlay_lane(const uint8_t* __restrict__ frames, uint8_t* __restrict__ out,
+                                                     size_t frame_stride, const int16_t* __restrict__ oxy,
+                                                     const uint16_t* __restrict__ ofrac,
+                                                     const short2* __restrict__ spans, size_t span_stride, int npix,
+                                                     int bh, int bw, float alpha) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= npix) return;
+    const uint8_t* src = frames + (size_t)blockIdx.z * frame_stride + (size_t)o * 3;
+    uint8_t* dst = out + (size_t)blockIdx.z * frame_stride + (size_t)o * 3;
+    const int sx = oxy[2 * o], sy = oxy[2 * o + 1];
+    const int v = lane_value(spans + (size_t)blockIdx.z * span_stride, bh, bw, sx, sy, ofrac[o]);
+    const uint32_t r = src[0], g = src[1], b = src[2];
+    dst[0] = (uint8_t)r;
+    dst[1] = (uint8_t)(v ? blend_green(g, v, alpha) : g);
+    dst[2] = (uint8_t)b;
+}
+
+// Four pixels (12 bytes = three dwords) per thread when the row length allows it.
+__global__ __launch_bounds__(256) void k_overlay_lane4(const uint32_t* __restrict__ frames, uint32_t* __restrict__ out,
+                                                      size_t frame_stride_dw, const int16_t* __restrict__ oxy,
+                                                      const uint16_t* __restrict__ ofrac,
+                                                      const short2* __restrict__ spans, size_t span_stride, int nquads,
+                                                      int bh, int bw, float alpha) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nquads) return;
+    const uint32_t* src = frames + (size_t)blockIdx.z * frame_stride_dw + (size_t)q * 3;
+    uint32_t* dst = out + (size_t)blockIdx.z * frame_stride_dw + (size_t)q * 3;
+    uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+    const uint4 xy = reinterpret_cast<const uint4*>(oxy)[q];
+    const uint2 fr = reinterpret_cast<const uint2*>(ofrac)[q];
+    const uint32_t xyv[4] = {xy.x, xy.y, xy.z, xy.w};
+    const uint32_t frv[4] = {fr.x & 0xffffu, fr.x >> 16, fr.y & 0xffffu, fr.y >> 16};
+    const short2* sp = spans + (size_t)blockIdx.z * span_stride;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = lane_value(sp, bh, bw, (int16_t)(xyv[i] & 0xffffu), (int16_t)(xyv[i] >> 16), (int)frv[i]);
+    // byte layout of the three dwords: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    if (v[0]) d0 = (d0 & 0xffff00ffu) | (blend_green((d0 >> 8) & 255u, v[0], alpha) << 8);
+    if (v[1]) d1 = (d1 & 0xffffff00u) | blend_green(d1 & 255u, v[1], alpha);
+    if (v[2]) d1 = (d1 & 0x00ffffffu) | (blend_green(d1 >> 24, v[2], alpha) << 24);
+    if (v[3]) d2 = (d2 & 0xff00ffffu) | (blend_green((d2 >> 16) & 255u, v[3], alpha) << 16);
+    dst[0] = d0;
+    dst[1] = d1;
+    dst[2] = d2;
+}
+
+// Bird's-eye RGB of the undistorted rows (same taps and blend as k_warp_split, colour kept).
+__global__ __launch_bounds__(256) void k_warp_rgb(const uint32_t* __restrict__ und, size_t und_stride_px,
+                                                 const int16_t* __restrict__ wxy, const uint16_t* __restrict__ wfrac,
+                                                 FrontEndGeom g, uint8_t* __restrict__ bev, size_t bev_stride) {
+    const size_t npix = (size_t)g.warp_h * g.warp_w;
+    const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= npix) return;
+    const uint32_t* src = und + (size_t)blockIdx.z * und_stride_px;
+    const int sx = wxy[o * 2], sy = wxy[o * 2 + 1], f = wfrac[o];
+    const int fx = f & 31, fy = f >> 5, gx = 32 - fx, gy = 32 - fy;
+    const int ry0 = sy - g.r0, ry1 = sy + 1 - g.r0;
+    const bool y0 = sy >= 0 && sy < g.img_h && ry0 >= 0 && ry0 < g.nrows;
+    const bool y1 = sy + 1 >= 0 && sy + 1 < g.img_h && ry1 >= 0 && ry1 < g.nrows;
+    const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
+    const int cy0 = min(max(ry0, 0), g.nrows - 1), cy1 = min(max(ry1, 0), g.nrows - 1);
+    const int cx0 = min(max(sx, 0), g.img_w - 1), cx1 = min(max(sx + 1, 0), g.img_w - 1);
+    uint32_t t00 = src[__mul24(cy0, g.img_w) + cx0], t01 = src[__mul24(cy0, g.img_w) + cx1];
+    uint32_t t10 = src[__mul24(cy1, g.img_w) + cx0], t11 = src[__mul24(cy1, g.img_w) + cx1];
+    t00 = (y0 && x0) ? t00 : 0u;
+    t01 = (y0 && x1) ? t01 : 0u;
+    t10 = (y1 && x0) ? t10 : 0u;
+    t11 = (y1 && x1) ? t11 : 0u;
+    uint8_t* dst = bev + (size_t)blockIdx.z * bev_stride + o * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int h0 = __mul24((int)((t00 >> (8 * ch)) & 255u), gx) + __mul24((int)((t01 >> (8 * ch)) & 255u), fx);
+        const int h1 = __mul24((int)((t10 >> (8 * ch)) & 255u), gx) + __mul24((int)((t11 >> (8 * ch)) & 255u), fx);
+        dst[ch] = (uint8_t)((__mul24(h0, gy) + __mul24(h1, fy) + 512) >> 10);
+    }
+}
+
+}  // namespace
+
+void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
+                         const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
+                         int bh, int bw, float alpha, int n) {
+    if (n <= 0) return;
+    const int npix = img_h * img_w;
+    const short2* sp = reinterpret_cast<const short2*>(spans);
+    if ((img_w & 3) == 0 && (frame_stride & 3) == 0) {
+        const int nq = npix >> 2;
+        hipLaunchKernelGGL(k_overlay_lane4, dim3((nq + 255) / 256, 1, n), dim3(256), 0, s,
+                           reinterpret_cast<const uint32_t*>(frames), reinterpret_cast<uint32_t*>(out), frame_stride >> 2,
+                           oxy, ofrac, sp, span_stride_rows, nq, bh, bw, alpha);
+    } else {
+        hipLaunchKernelGGL(k_overlay_lane, dim3((npix + 255) / 256, 1, n), dim3(256), 0, s, frames, out, frame_stride, oxy,
+                           ofrac, sp, span_stride_rows, npix, bh, bw, alpha);
+    }
+}
+
+void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy, const uint16_t* wfrac,
+                     FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n) {
+    if (n <= 0) return;
+    const size_t npix = (size_t)g.warp_h * g.warp_w;
+    hipLaunchKernelGGL(k_warp_rgb, dim3((unsigned)((npix + 255) / 256), 1, n), dim3(256), 0, s, und, und_stride_px, wxy,
+                       wfrac, g, bev, bev_stride);
+}
+
+}  // namespace lt

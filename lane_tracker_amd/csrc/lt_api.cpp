@@ -1,6 +1,7 @@
 // C-ABI layer of liblane_tracker_amd.so (see include/lane_tracker_amd.h).
 // Owns the context: HIP stream, calibration tables, frame slots; sequences the kernel chain of
 // LaneTracker.find_lane_points() (lane_tracker.py:795-874) for a batch of independent frames.
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -75,6 +76,13 @@ struct lt_ctx {
     int maxpix = 0, maxlev = 0, maxbands = 0;
     bool have_mask = false;
     bool brute_tophat = false;
+    // presentation stage (lt_overlay_*): inverse-warp table, per-slot row intervals, annotated frames
+    int16_t* d_oxy = nullptr;
+    uint16_t* d_ofrac = nullptr;
+    bool have_overlay = false;
+    int16_t* d_spans = nullptr;       // [slot][warp_h] (lo, hi)
+    uint8_t* d_annot = nullptr;
+    std::vector<int16_t> h_spans;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stage_timing = false;
@@ -188,6 +196,8 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_pix);
     dev_free(c->d_cent);
     dev_free(c->d_band_sums);
+    dev_free(c->d_spans);
+    dev_free(c->d_annot);
     c->maxbands = 0;
     c->capacity = 0;
     c->maxpix = 0;
@@ -441,6 +451,8 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_gamma);
     dev_free(c->d_cbrt);
     dev_free(c->d_coef);
+    dev_free(c->d_oxy);
+    dev_free(c->d_ofrac);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -598,6 +610,141 @@ int lt_download_undistorted(lt_ctx* c, int first, int n, uint8_t* out) {
     rc = download(c, tmp, out, (size_t)n * c->und_bytes);
     dev_free(tmp);
     return rc;
+}
+
+// ---- presentation stage: draw_lane() overlay and the bird's-eye image ----------------
+namespace {
+
+// Row intervals of cv2.fillPoly's result for a polygon whose two chains are functions of y: the
+// union of the 8-connected edge lines and the even-odd interior is, per row, the hull of the edge
+// pixels on that row.  The walk is OpenCV's LineIterator (left end point first, error term
+// dx - 2 dy, one major-axis step per pixel).
+void span_line(int16_t* spans, int bh, int xa, int ya, int xb, int yb) {
+    if (xb < xa) { std::swap(xa, xb); std::swap(ya, yb); }
+    const int adx = xb - xa, ady = std::abs(yb - ya), ystep = yb < ya ? -1 : 1;
+    const bool tall = ady > adx;
+    const int len = tall ? ady : adx, across = tall ? adx : ady;
+    int err = len - 2 * across;
+    for (int i = 0, x = xa, y = ya; i <= len; ++i) {
+        if (y >= 0 && y < bh) {
+            const int16_t xc = (int16_t)std::min(std::max(x, -32768), 32767);
+            if (xc < spans[2 * y]) spans[2 * y] = xc;
+            if (xc > spans[2 * y + 1]) spans[2 * y + 1] = xc;
+        }
+        const bool turn = err < 0;
+        err -= 2 * across;
+        if (turn) err += 2 * len;
+        if (tall) { y += ystep; x += turn ? 1 : 0; }
+        else { x += 1; y += turn ? ystep : 0; }
+    }
+}
+
+void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int nl, const int32_t* ryx, int nr) {
+    for (int y = 0; y < bh; ++y) { spans[2 * y] = 32767; spans[2 * y + 1] = -32768; }
+    const int np = nl + nr;
+    if (np <= 0) return;
+    // vertex k of the closed polygon: the left points in order, then the right points reversed (np.flipud)
+    auto vx = [&](int k) { return k < nl ? lyx[2 * k + 1] : ryx[2 * (nr - 1 - (k - nl)) + 1]; };
+    auto vy = [&](int k) { return k < nl ? lyx[2 * k] : ryx[2 * (nr - 1 - (k - nl))]; };
+    for (int k = 0; k < np; ++k) {
+        const int j = (k + np - 1) % np;
+        span_line(spans, bh, vx(j), vy(j), vx(k), vy(k));
+    }
+}
+
+}  // namespace
+
+int lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,
+                          int16_t* spans) {
+    if (warp_h < 1 || n_left < 0 || n_right < 0 || !spans || (n_left && !left_yx) || (n_right && !right_yx))
+        return fail(LT_ERR_INVALID, "bad polygon arguments");
+    lane_polygon_spans(spans, warp_h, left_yx, n_left, right_yx, n_right);
+    return LT_OK;
+}
+
+int lt_overlay_configure(lt_ctx* c, const double* Minv) {
+    if (!c || !Minv) return fail(LT_ERR_INVALID, "null argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
+    // cv2.warpPerspective(lane, Minv, (img_w, img_h)): the same table builder with M := Minv and the
+    // camera frame as the destination
+    lt_calib u = c->calib;
+    std::memcpy(u.M, Minv, sizeof u.M);
+    u.warp_w = c->calib.img_w;
+    u.warp_h = c->calib.img_h;
+    RemapTable t;
+    build_warp_table(u, t);
+    dev_free(c->d_oxy);
+    dev_free(c->d_ofrac);
+    c->have_overlay = false;
+    if ((rc = dev_alloc(&c->d_oxy, t.xy.size()))) return rc;
+    if ((rc = dev_alloc(&c->d_ofrac, t.frac.size()))) return rc;
+    HIP_TRY(hipMemcpy(c->d_oxy, t.xy.data(), t.xy.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ofrac, t.frac.data(), t.frac.size() * 2, hipMemcpyHostToDevice));
+    c->have_overlay = true;
+    return LT_OK;
+}
+
+int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                   const int32_t* right_yx, double alpha) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_run before lt_overlay_configure");
+    if (n == 0) return LT_OK;
+    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
+    long long tl = 0, tr = 0;
+    for (int i = 0; i < n; ++i) {
+        if (left_n[i] < 0 || right_n[i] < 0) return fail(LT_ERR_INVALID, "negative point count");
+        tl += left_n[i];
+        tr += right_n[i];
+    }
+    if ((tl && !left_yx) || (tr && !right_yx)) return fail(LT_ERR_INVALID, "null point list");
+    if ((rc = set_device(c))) return rc;
+    const int bh = c->calib.warp_h;
+    if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
+    if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
+    if ((rc = sync_all(c))) return rc;     // the previous call's staging buffer is free again
+    c->h_spans.resize((size_t)n * bh * 2);
+    size_t ol = 0, orr = 0;
+    for (int i = 0; i < n; ++i) {
+        lane_polygon_spans(c->h_spans.data() + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
+                           right_yx ? right_yx + 2 * orr : nullptr, right_n[i]);
+        ol += (size_t)left_n[i];
+        orr += (size_t)right_n[i];
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_spans + (size_t)first * bh * 2, c->h_spans.data(), c->h_spans.size() * sizeof(int16_t),
+                           hipMemcpyHostToDevice, c->stream));
+    launch_overlay_lane(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
+                        c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
+                        c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay before lt_overlay_run");
+    return download(c, c->d_annot + (size_t)first * c->frame_bytes, out, (size_t)n * c->frame_bytes);
+}
+
+int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!c->have_mask) return fail(LT_ERR_STATE, "lt_download_bev before lt_mask_run");
+    if (n == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = ensure_bev(c))) return rc;
+    if ((rc = sync_all(c))) return rc;
+    uint8_t* dst = c->d_bev + (size_t)first * c->bev_bytes;
+    if (c->fe.nrows <= 0) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * c->bev_bytes, c->stream));
+    else
+        launch_warp_rgb(c->stream, c->d_und + (size_t)first * c->und_px, c->und_px, c->d_wxy, c->d_wfrac, c->fe, dst,
+                        c->bev_bytes, n);
+    HIP_TRY(hipGetLastError());
+    return download(c, dst, out, (size_t)n * c->bev_bytes);
 }
 
 int lt_download_records(lt_ctx* c, int first, int n, lt_lane_record* out) {

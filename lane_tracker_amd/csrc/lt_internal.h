@@ -43,6 +43,13 @@ void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int 
 void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, int nrows, int w, uint8_t* out,
                                int n);
 
+// presentation stage (k_overlay.hip)
+void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
+                         const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
+                         int bh, int bw, float alpha, int n);
+void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy, const uint16_t* wfrac,
+                     FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n);
+
 // dst = erode/dilate(src) with the ellipse; if minuend != nullptr: dst = sat(minuend - result)
 void launch_morph_ellipse(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w,
                           const EllipseSE& se, bool dilate, size_t plane_stride, int n);

@@ -15,6 +15,7 @@ import numpy as np
 
 from . import _native
 from . import overlay as _overlay
+from . import utils as _utils
 
 __all__ = ["LaneTracker", "bilateral_adaptive_threshold"]
 
@@ -104,7 +105,8 @@ class LaneTracker:
         self._aux_ctx = {}          # contexts for images that are not the calibration's BEV size
         self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search
         self._pending = None        # (ctx, slot, want_centroids): pixel lists not downloaded yet
-        self._overlay = None
+        self._overlay_ready = False
+        self._resident = None       # (frame array, slot) of the camera frame last uploaded to the main context
 
     # ------------------------------------------------------------------------------------------
     def get_success_ratio(self):
@@ -299,22 +301,71 @@ class LaneTracker:
         mid = int(self.warped_size[0] / 2)
         self.eccentricity = (((mid - left) - (right - mid)) / 2) * self.mpph
 
-    # ---- presentation (reference :629-673) -----------------------------------------
-    def draw_lane(self, img):
-        if self._overlay is None:
-            self._overlay = _overlay.LaneOverlay(self.img_size, self.warped_size, self.M)
-        out = self._overlay.draw(img, self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x)
+    # ---- presentation (reference :629-793) ------------------------------------------
+    def _lane_text(self):
         lines = ["Curve Radius: {} m".format(self.average_curve_radius),
                  "Eccentricity: {:.2f} m".format(self.eccentricity)]
         if self.print_frame_count:
             lines.append("Frame: {}".format(self.counter - 1))
-        return _overlay.put_lines(out, lines)
+        return lines
 
-    def print_failure(self, img):
+    def _failure_text(self):
         lines = ["Lane Line Detection Failed"]
         if self.print_frame_count:
             lines.append("Frame: {}".format(self.counter - 1))
-        return _overlay.put_lines(np.array(img, copy=True), lines)
+        return lines
+
+    def _overlay_slot(self, img):
+        """Slot of the main context that holds `img` (uploading it if it is not the resident frame)."""
+        if not self._overlay_ready:
+            self._ctx.overlay_configure(self.Minv)
+            self._overlay_ready = True
+        if self._resident is not None and self._resident[0] is img:
+            return self._resident[1]
+        self._ctx.upload_frames(img, first=0)
+        self._resident = (img, 0)
+        return 0
+
+    def draw_lane(self, img):
+        """Highlight the lane between the averaged curves and print radius / eccentricity.  The polygon
+        fill, its inverse warp with `Minv` and the 0.3 blend run on the GPU (lt_overlay_run); unlike
+        upstream the caller's array is not written to."""
+        slot = self._overlay_slot(img)
+        self._ctx.overlay_run([(self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x)], first=slot)
+        return _overlay.put_lines(self._ctx.download_overlay(1, first=slot)[0], self._lane_text())
+
+    def print_failure(self, img):
+        return _overlay.put_lines(np.array(img, copy=True), self._failure_text())
+
+    def window_mask(self, img, window_width, window_height, center, level, ignore_bottom):
+        return _overlay.window_mask(img, window_width, window_height, center, level, ignore_bottom)
+
+    def visualize_sliding_window_search(self, binary_img, left_fit_coeffs, right_fit_coeffs, window_width,
+                                        window_height, ignore_bottom):
+        """Search windows, detected pixels and the fitted curves drawn over the mask (debugging aid)."""
+        self._materialise_pending()
+        return _overlay.visualize_sliding_window_search(
+            binary_img, self.left_window_centroids, self.right_window_centroids, (self.left_y, self.left_x),
+            (self.right_y, self.right_x), self.get_poly_points(left_fit_coeffs, right_fit_coeffs), window_width,
+            window_height, ignore_bottom)
+
+    def visualize_band_search(self, binary_img, left_fit_coeffs, right_fit_coeffs, bandwidth, partial):
+        """Search bands around the previous curves, detected pixels and the new fitted curves (debugging aid)."""
+        self._materialise_pending()
+        return _overlay.visualize_band_search(
+            binary_img, (self.left_y, self.left_x), (self.right_y, self.right_x),
+            self.get_poly_points(self.last_left_coeffs, self.last_right_coeffs, partial),
+            self.get_poly_points(left_fit_coeffs, right_fit_coeffs), bandwidth)
+
+    def triple_split_view(self, images):
+        """Annotated frame on top, bird's-eye image and search visualisation side by side below it."""
+        img1_size = (images[0].shape[1], images[0].shape[0])
+        img2_size = (images[1].shape[1], images[1].shape[0])
+        positions = [(0, 0), (0, img1_size[1]), (round(0.5 * img1_size[0]), img1_size[1])]
+        scale_factor = img2_size[0] / (0.5 * img1_size[0])
+        scaled_size = (round(img2_size[0] / scale_factor), round(img2_size[1] / scale_factor))
+        target_size = (img1_size[0], img1_size[1] + scaled_size[1])
+        return _utils.create_split_view(target_size, images, positions, [img1_size, scaled_size, scaled_size])
 
     # ---- find_lane_points (reference :795-874) ---------------------------------------------------------------
     def find_lane_points(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=True,
@@ -335,6 +386,7 @@ class LaneTracker:
         ctx = self._ctx
         if not reuse_frame:
             ctx.upload_frames(img, first=slot)
+        self._resident = (img, slot)
         if not have_mask:
             ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
                                                   ksize_noise, C_noise), first=slot)
@@ -366,13 +418,11 @@ class LaneTracker:
         last averaged lane for up to `n_fail` frames and falls back from band search to
         sliding-window search after `n_reset` misses.
         """
-        if visualize_search or split_view:
-            raise NotImplementedError("search visualisation / split view are presentation features outside the "
-                                      "accelerated path (SURVEY.md section 8(f), row N1)")
         first_try = (ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh, ksize_noise, C_noise,
                      window_width, window_height, search_range, mu, no_success_limit, start_slice, ignore_sides,
                      ignore_bottom, bandwidth, partial)
-        return self._step(img, first_try, n_tries, diagnostics, slot=0, have_mask=False, lazy=False, annotate=True)
+        return self._step(img, first_try, n_tries, diagnostics, slot=0, have_mask=False, lazy=False, annotate=True,
+                          visualize_search=visualize_search, split_view=split_view)
 
     def process_batch(self, frames, annotate=True, **kwargs):
         """The same result as calling `process()` on each frame of `frames` in order (one stateful
@@ -411,24 +461,36 @@ class LaneTracker:
         ctx.upload_frames(frames)
         ctx.mask_run(n, _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],
                                               k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"]))
-        out = []
+        deferred = []
         for i in range(n):
-            res = self._step(frames[i], first_try, k["n_tries"], k["diagnostics"], slot=i, have_mask=True, lazy=True,
-                             annotate=annotate)
-            out.append(res)
+            self._step(frames[i], first_try, k["n_tries"], k["diagnostics"], slot=i, have_mask=True, lazy=True,
+                       annotate=annotate, defer=deferred)
         self._materialise_pending()      # the attributes describe the last frame, as after process()
-        return out
+        if not annotate:
+            return [None] * n
+        # one overlay launch and one download for the whole window; a failed frame has no polygon (plain copy)
+        if not self._overlay_ready:
+            ctx.overlay_configure(self.Minv)
+            self._overlay_ready = True
+        empty = np.zeros(0, np.int64)
+        ctx.overlay_run([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in deferred])
+        annotated = ctx.download_overlay(n)
+        return [_overlay.put_lines(annotated[i], deferred[i][2]) for i in range(n)]
 
-    def _step(self, img, first_try, n_tries, diagnostics, slot, have_mask, lazy, annotate):
-        """One frame of the per-stream state machine (reference :1026-1209)."""
+    def _step(self, img, first_try, n_tries, diagnostics, slot, have_mask, lazy, annotate, visualize_search=False,
+              split_view=False, defer=None):
+        """One frame of the per-stream state machine (reference :1026-1209).  With `defer` (a list) the
+        annotated frame is not produced here: ('lane', polygon, text) or ('fail', None, text) is appended
+        and the caller renders all frames of the window in one overlay launch."""
         partial = first_try[-1]
         self.counter += 1
         self.detected_pixels = False
         self.valid_lane_lines = False
         left_fit_coeffs = right_fit_coeffs = None
+        used = first_try                      # the parameter set of the most recent attempt
 
-        self._find_lane_points_device(img, *first_try, diagnostics, reuse_frame=have_mask, slot=slot,
-                                      have_mask=have_mask, lazy=lazy)
+        search_mode = self._find_lane_points_device(img, *first_try, diagnostics, reuse_frame=have_mask, slot=slot,
+                                                    have_mask=have_mask, lazy=lazy)
         if self.detected_pixels:
             left_fit_coeffs, right_fit_coeffs = self.fit_poly()
             self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
@@ -441,12 +503,38 @@ class LaneTracker:
             partial = 1.0                                               # the second parameter set (:1081-1099)
             second_try = (15, 5, 35, 5, 'neighborhood', False, 140, 65, 10, 30, 40, 20, 0.1, 50, 0.25, 360, 30, 30,
                           partial)
-            self._find_lane_points_device(img, *second_try, diagnostics, reuse_frame=True, slot=slot, lazy=lazy)
+            used = second_try
+            search_mode = self._find_lane_points_device(img, *second_try, diagnostics, reuse_frame=True, slot=slot,
+                                                        lazy=lazy)
             if self.detected_pixels:
                 left_fit_coeffs, right_fit_coeffs = self.fit_poly()
                 self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
                 if diagnostics and self.valid_lane_lines:
                     print("Success at second attempt!")
+
+        search_visualization = warped_img = None
+        if visualize_search or split_view:                              # :1130-1137
+            binary_img = self._ctx.download_masks(1, first=slot)[0]
+            if self.detected_pixels:
+                if search_mode == 'sws':
+                    search_visualization = self.visualize_sliding_window_search(binary_img, left_fit_coeffs,
+                                                                                right_fit_coeffs, used[9], used[10],
+                                                                                used[16])
+                else:
+                    search_visualization = self.visualize_band_search(binary_img, left_fit_coeffs, right_fit_coeffs,
+                                                                      used[17], used[18])
+            else:
+                search_visualization = binary_img
+            if split_view:
+                # the bird's-eye image the detector saw (upstream warps the raw, still distorted frame here, :1035)
+                warped_img = self._ctx.download_bev(1, first=slot)[0]
+
+        def present(annotated):
+            if visualize_search:
+                return annotated, search_visualization
+            if split_view:
+                return self.triple_split_view([annotated, warped_img, search_visualization])
+            return annotated
 
         if not self.valid_lane_lines:                                   # :1142-1173
             if diagnostics:
@@ -462,9 +550,12 @@ class LaneTracker:
             self.last_detection += 1
             if not annotate:
                 return None
-            if (self.left_avg_y.size != 0) and (self.last_detection <= self.n_fail):
-                return self.draw_lane(img)
-            return self.print_failure(img)
+            redraw = (self.left_avg_y.size != 0) and (self.last_detection <= self.n_fail)
+            if defer is not None:
+                defer.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
+                              self._lane_text()) if redraw else ('fail', None, self._failure_text()))
+                return None
+            return present(self.draw_lane(img) if redraw else self.print_failure(img))
 
         # success (:1178-1209)
         self.left_fit_coeffs.append(left_fit_coeffs)
@@ -482,7 +573,13 @@ class LaneTracker:
             self.left_avg_coeffs, self.right_avg_coeffs, partial)
         self.get_curve_radius()
         self.get_eccentricity()
-        return self.draw_lane(img) if annotate else None
+        if not annotate:
+            return None
+        if defer is not None:
+            defer.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
+                          self._lane_text()))
+            return None
+        return present(self.draw_lane(img))
 
 
 def _minimum_norm_parabola(y, x):

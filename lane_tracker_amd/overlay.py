@@ -1,50 +1,87 @@
-"""Presentation of the result on the camera frame (reference draw_lane / print_failure,
-lane_tracker.py:629-673).  SURVEY.md section 8(f) row N1: outside the accelerated path and not
-bit-matched -- OpenCV's fillPoly rasteriser, its inverse warp of the polygon and its anti-aliased
-Hershey text cannot be reproduced without OpenCV.  This is plain NumPy (+ Pillow for text when it
-is installed) so that `LaneTracker.process()` returns an annotated frame like the reference."""
+"""Presentation helpers around the accelerated path.
+
+* The lane overlay of `draw_lane()` (lane_tracker.py:629-662: fillPoly -> warpPerspective(Minv) ->
+  addWeighted) runs on the GPU (`lt_overlay_run`, csrc/k_overlay.hip); this module only adds the text.
+* The search visualisations (`visualize_sliding_window_search` :687-729, `visualize_band_search`
+  :731-771) are debugging aids made of NumPy indexing plus three cv2 calls (merge, fillPoly,
+  addWeighted); they are restated here in NumPy, the polygon through the library's host-side
+  `lt_lane_polygon_spans`.
+* Text: OpenCV's anti-aliased Hershey glyphs cannot be reproduced without OpenCV; the lines are drawn
+  with Pillow's default font at the reference's positions when Pillow is installed."""
 import numpy as np
 
+from . import _native
 
-class LaneOverlay:
-    def __init__(self, img_size, warped_size, M):
-        self.w, self.h = int(img_size[0]), int(img_size[1])
-        self.bw, self.bh = int(warped_size[0]), int(warped_size[1])
-        M = np.asarray(M, np.float64)
-        u, v = np.meshgrid(np.arange(self.w, dtype=np.float64), np.arange(self.h, dtype=np.float64))
-        den = M[2, 0] * u + M[2, 1] * v + M[2, 2]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            bx = np.rint((M[0, 0] * u + M[0, 1] * v + M[0, 2]) / den)
-            by = np.rint((M[1, 0] * u + M[1, 1] * v + M[1, 2]) / den)
-        ok = np.isfinite(bx) & np.isfinite(by) & (np.abs(den) > 1e-12)
-        ok &= (bx >= 0) & (bx < self.bw) & (by >= 0) & (by < self.bh)
-        self.cam_idx = np.flatnonzero(ok.ravel())
-        self.bx = bx[ok].astype(np.int32)      # bird's-eye pixel under each camera pixel that sees the road plane
-        self.by = by[ok].astype(np.int32)
-        self.cam_g = self.cam_idx * 3 + 1      # flat offset of the green byte of those camera pixels
 
-    def draw(self, img, left_y, left_x, right_y, right_x, alpha=0.3):
-        """Green lane polygon between the two averaged curves, blended like addWeighted(img,1,lane,0.3,0)."""
-        out = np.array(img, dtype=np.uint8, copy=True)
-        ly, lx = np.asarray(left_y, np.int64), np.asarray(left_x, np.int64)
-        ry, rx = np.asarray(right_y, np.int64), np.asarray(right_x, np.int64)
-        if ly.size and ry.size:
-            # per bird's-eye row: the span between the two averaged curves (rows where both exist)
-            lo = np.full(self.bh, 1 << 30, np.int32)
-            hi = np.full(self.bh, -1, np.int32)
-            lrow = np.full(self.bh, -1, np.int32)
-            rrow = np.full(self.bh, -1, np.int32)
-            lrow[np.clip(ly, 0, self.bh - 1)] = lx
-            rrow[np.clip(ry, 0, self.bh - 1)] = rx
-            both = (lrow >= 0) & (rrow >= 0)
-            lo[both] = np.minimum(lrow, rrow)[both]
-            hi[both] = np.maximum(lrow, rrow)[both]
-            # evaluated only at the camera pixels, not over the whole bird's-eye image
-            hit = (self.bx >= lo[self.by]) & (self.bx <= hi[self.by])
-            sel = self.cam_g[hit]
-            flat = out.reshape(-1)
-            flat[sel] = np.minimum(255, flat[sel].astype(np.int16) + int(np.rint(255 * alpha))).astype(np.uint8)
-        return out
+def add_weighted(a, alpha, b, beta, gamma=0.0):
+    """cv2.addWeighted on u8 arrays: f32 products and sums, round-half-even, saturate."""
+    t = a.astype(np.float32) * np.float32(alpha) + b.astype(np.float32) * np.float32(beta)
+    t = t + np.float32(gamma)
+    return np.clip(np.rint(t), 0, 255).astype(np.uint8)
+
+
+def fill_band(img, ys, x_lo, x_hi, color):
+    """cv2.fillPoly of the polygon (x_lo, ys) followed by the reversed (x_hi, ys), in place."""
+    h, w = img.shape[:2]
+    spans = _native.lane_polygon_spans(h, ys, x_lo, ys, x_hi)
+    rows = np.flatnonzero(spans[:, 0] <= spans[:, 1])
+    for y in rows:
+        lo, hi = max(int(spans[y, 0]), 0), min(int(spans[y, 1]), w - 1)
+        if lo <= hi:
+            img[y, lo:hi + 1] = color
+    return img
+
+
+def _window_box(shape, window_width, window_height, center, level, ignore_bottom):
+    """Row and column slices of search window `level` (lane_tracker.py:684, same int() truncations)."""
+    img_height = shape[0] - ignore_bottom
+    return (slice(int(img_height - (level + 1) * window_height), int(img_height - level * window_height)),
+            slice(max(int(center - window_width / 2), 0), min(int(center + window_width / 2), shape[1])))
+
+
+def window_mask(img, window_width, window_height, center, level, ignore_bottom):
+    """lane_tracker.py:675-685: 1 inside the search window, 0 elsewhere."""
+    output = np.zeros_like(img)
+    output[_window_box(img.shape, window_width, window_height, center, level, ignore_bottom)] = 1
+    return output
+
+
+def visualize_sliding_window_search(binary_img, left_centroids, right_centroids, left_yx, right_yx, fit_points,
+                                    window_width, window_height, ignore_bottom):
+    """lane_tracker.py:687-729: windows in half-transparent green over the mask, lane pixels red / blue,
+    fitted curves yellow."""
+    sides = []
+    for cents in (left_centroids, right_centroids):
+        pts = np.zeros_like(binary_img)
+        for level, center in enumerate(cents):
+            pts[_window_box(binary_img.shape, window_width, window_height, center, level, ignore_bottom)] = 255
+        sides.append(pts)
+    green = (sides[1] + sides[0]).astype(np.uint8)                # u8 wrap-around (254) where both overlap, as upstream
+    out = np.repeat(binary_img[:, :, None], 3, axis=2)
+    out[:, :, 1] = add_weighted(binary_img, 1, green, 0.5, 0.0)   # the template's red and blue channels are zero
+    out[left_yx[0], left_yx[1]] = (255, 0, 0)
+    out[right_yx[0], right_yx[1]] = (0, 0, 255)
+    left_fit_y, left_fit_x, right_fit_y, right_fit_x = fit_points
+    out[left_fit_y, left_fit_x] = (255, 235, 0)
+    out[right_fit_y, right_fit_x] = (255, 235, 0)
+    return out
+
+
+def visualize_band_search(binary_img, left_yx, right_yx, band_points, fit_points, bandwidth):
+    """lane_tracker.py:731-771: lane pixels red / blue, the two search bands (previous curves +- bandwidth)
+    in transparent green, the new fitted curves yellow."""
+    out = np.repeat(binary_img[:, :, None], 3, axis=2)
+    out[left_yx[0], left_yx[1]] = (255, 0, 0)
+    out[right_yx[0], right_yx[1]] = (0, 0, 255)
+    band = np.zeros(binary_img.shape, np.uint8)
+    left_band_y, left_band_x, right_band_y, right_band_x = band_points
+    fill_band(band, left_band_y, left_band_x - bandwidth, left_band_x + bandwidth, 255)
+    fill_band(band, right_band_y, right_band_x - bandwidth, right_band_x + bandwidth, 255)
+    out[:, :, 1] = add_weighted(out[:, :, 1], 1, band, 0.3, 0)
+    left_fit_y, left_fit_x, right_fit_y, right_fit_x = fit_points
+    out[left_fit_y, left_fit_x] = (255, 235, 0)
+    out[right_fit_y, right_fit_x] = (255, 235, 0)
+    return out
 
 
 _FONT = None

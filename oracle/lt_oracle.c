@@ -815,3 +815,156 @@ int lto_frame_sws_fit(const lto_calib* c, const uint8_t* frame, const lto_filter
     if (!mask_out) free(mask);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------- */
+/* Presentation stage (draw_lane, lane_tracker.py:629-662; create_split_view, utils.py:57-103).   */
+/* OpenCV drawing.cpp restated from memory [M]: Line() walks the 8-connected LineIterator from the
+ * leftmost end point; fillPoly = CollectPolyEdges (draws every edge, records non-horizontal edges
+ * in 16.16 fixed point) + FillEdgeCollection (even-odd spans, top-inclusive/bottom-exclusive).     */
+static void put_px(uint8_t* img, int h, int w, int ch, int x, int y, const uint8_t* color) {
+    if (x < 0 || x >= w || y < 0 || y >= h) return;
+    for (int c = 0; c < ch; ++c) img[((size_t)y * w + x) * ch + c] = color[c];
+}
+
+static void draw_line8(uint8_t* img, int h, int w, int ch, int x0, int y0, int x1, int y1, const uint8_t* color) {
+    if (x1 < x0) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }   /* leftToRight */
+    int dx = x1 - x0, dy = y1 - y0;
+    int sy = dy < 0 ? -1 : 1;
+    if (dy < 0) dy = -dy;
+    int steep = dy > dx;
+    int major = steep ? dy : dx, minor = steep ? dx : dy;
+    int err = major - 2 * minor, x = x0, y = y0;
+    for (int i = 0; i <= major; ++i) {
+        put_px(img, h, w, ch, x, y, color);
+        int neg = err < 0;
+        err += -2 * minor + (neg ? 2 * major : 0);
+        if (steep) { y += sy; if (neg) x += 1; }
+        else { x += 1; if (neg) y += sy; }
+    }
+}
+
+typedef struct { int y0, y1; int64_t x, dx; } poly_edge;
+static int cmp_i64(const void* a, const void* b) {
+    int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+    return x < y ? -1 : x > y;
+}
+
+void lto_fill_poly(uint8_t* img, int h, int w, int ch, const int32_t* pts, int npts, const uint8_t* color) {
+    if (npts <= 0) return;
+    poly_edge* edges = malloc(sizeof(poly_edge) * (size_t)npts);
+    int ne = 0, ymin = INT_MAX, ymax = INT_MIN;
+    for (int i = 0; i < npts; ++i) {
+        int j = (i + npts - 1) % npts;                      /* edge from the previous vertex to this one */
+        int xa = pts[2 * j], ya = pts[2 * j + 1], xb = pts[2 * i], yb = pts[2 * i + 1];
+        draw_line8(img, h, w, ch, xa, ya, xb, yb, color);
+        if (ya == yb) continue;
+        poly_edge e;
+        if (ya < yb) { e.y0 = ya; e.y1 = yb; e.x = (int64_t)xa << 16; }
+        else { e.y0 = yb; e.y1 = ya; e.x = (int64_t)xb << 16; }
+        e.dx = (((int64_t)(ya < yb ? xb - xa : xa - xb)) << 16) / (e.y1 - e.y0);
+        edges[ne++] = e;
+        if (e.y0 < ymin) ymin = e.y0;
+        if (e.y1 > ymax) ymax = e.y1;
+    }
+    int64_t* xs = malloc(sizeof(int64_t) * (size_t)(ne + 1));
+    for (int y = ymin; y < ymax; ++y) {
+        int k = 0;
+        for (int i = 0; i < ne; ++i)
+            if (edges[i].y0 <= y && y < edges[i].y1) xs[k++] = edges[i].x + (int64_t)(y - edges[i].y0) * edges[i].dx;
+        qsort(xs, (size_t)k, sizeof(int64_t), cmp_i64);
+        if (y < 0 || y >= h) continue;
+        for (int i = 0; i + 1 < k; i += 2) {
+            int64_t xa = (xs[i] + 0xffff) >> 16, xb = xs[i + 1] >> 16;    /* ceil .. floor */
+            for (int64_t x = xa < 0 ? 0 : xa; x <= xb && x < w; ++x) put_px(img, h, w, ch, (int)x, y, color);
+        }
+    }
+    free(xs);
+    free(edges);
+}
+
+void lto_add_weighted_u8(const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma,
+                         size_t n, uint8_t* out) {
+    const float fa = (float)alpha, fb = (float)beta, fg = (float)gamma;
+    for (size_t i = 0; i < n; ++i) {
+        volatile float t0 = (float)a[i] * fa;          /* volatile: no fused multiply-add, f32 roundings as written */
+        volatile float t1 = (float)b[i] * fb;
+        volatile float t = t0 + t1;
+        t = t + fg;
+        long r = lrintf(t);                            /* round-half-even (default rounding mode) */
+        out[i] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+    }
+}
+
+void lto_draw_lane(const lto_calib* c, const double Minv[9], const uint8_t* img,
+                   const int32_t* left_y, const int32_t* left_x, int n_left,
+                   const int32_t* right_y, const int32_t* right_x, int n_right, uint8_t* out) {
+    const int bh = c->warp_h, bw = c->warp_w, ih = c->img_h, iw = c->img_w;
+    uint8_t* lane = calloc((size_t)bh * bw, 3);
+    int npts = n_left + n_right;
+    int32_t* pts = malloc(sizeof(int32_t) * 2 * (size_t)(npts > 0 ? npts : 1));
+    for (int i = 0; i < n_left; ++i) { pts[2 * i] = left_x[i]; pts[2 * i + 1] = left_y[i]; }
+    for (int i = 0; i < n_right; ++i) {                          /* np.flipud of the right-hand points */
+        pts[2 * (n_left + i)] = right_x[n_right - 1 - i];
+        pts[2 * (n_left + i) + 1] = right_y[n_right - 1 - i];
+    }
+    const uint8_t green[3] = {0, 255, 0};
+    lto_fill_poly(lane, bh, bw, 3, pts, npts, green);
+    /* warpPerspective(lane, Minv, (iw, ih)): the generic map builder with M := Minv, output := camera size */
+    lto_calib u = *c;
+    memcpy(u.M, Minv, sizeof u.M);
+    u.warp_w = iw;
+    u.warp_h = ih;
+    size_t n = (size_t)iw * ih;
+    int16_t* xy = malloc(n * 4);
+    uint16_t* al = malloc(n * 2);
+    lto_warp_map(&u, xy, al);
+    uint8_t* unwarped = malloc(n * 3);
+    lto_remap_bilinear_c3(lane, bh, bw, xy, al, ih, iw, unwarped);
+    lto_add_weighted_u8(img, 1.0, unwarped, 0.3, 0.0, n * 3, out);
+    free(unwarped); free(al); free(xy); free(pts); free(lane);
+}
+
+/* cv::resize INTER_LINEAR, 8-bit: src coordinate (d + 0.5) * scale - 0.5, floor -> tap + fraction,
+ * left clamp (fraction 0), right clamp (tap sw-1, fraction... taps replicate); coefficients
+ * saturate_cast<short>(f * 2048); result (sum of 4 products + 2^21) >> 22 evaluated as OpenCV's
+ * two-stage: rows in int with 11-bit x coefficients, then ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2. */
+void lto_resize_linear_u8(const uint8_t* src, int sh, int sw, int ch, int dh, int dw, uint8_t* dst) {
+    int* xo = malloc(sizeof(int) * (size_t)dw);
+    int* yo = malloc(sizeof(int) * (size_t)dh);
+    short* xa = malloc(sizeof(short) * 2 * (size_t)dw);
+    short* ya = malloc(sizeof(short) * 2 * (size_t)dh);
+    const double sx = (double)sw / dw, sy = (double)sh / dh;
+    for (int d = 0; d < dw; ++d) {
+        float f = (float)((d + 0.5) * sx - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (s < 0) { s = 0; f = 0; }
+        if (s >= sw - 1) { s = sw - 1; f = 0; }
+        xo[d] = s;
+        xa[2 * d] = (short)lrintf((1.f - f) * 2048);
+        xa[2 * d + 1] = (short)lrintf(f * 2048);
+    }
+    for (int d = 0; d < dh; ++d) {
+        float f = (float)((d + 0.5) * sy - 0.5);
+        int s = (int)floorf(f);
+        f -= s;
+        if (s < 0) { s = 0; f = 0; }
+        if (s >= sh - 1) { s = sh - 1; f = 0; }
+        yo[d] = s;
+        ya[2 * d] = (short)lrintf((1.f - f) * 2048);
+        ya[2 * d + 1] = (short)lrintf(f * 2048);
+    }
+    for (int y = 0; y < dh; ++y) {
+        const int y0 = yo[y], y1 = y0 + 1 < sh ? y0 + 1 : sh - 1;
+        for (int x = 0; x < dw; ++x) {
+            const int x0 = xo[x], x1 = x0 + 1 < sw ? x0 + 1 : sw - 1;
+            for (int c = 0; c < ch; ++c) {
+                int S0 = src[((size_t)y0 * sw + x0) * ch + c] * xa[2 * x] + src[((size_t)y0 * sw + x1) * ch + c] * xa[2 * x + 1];
+                int S1 = src[((size_t)y1 * sw + x0) * ch + c] * xa[2 * x] + src[((size_t)y1 * sw + x1) * ch + c] * xa[2 * x + 1];
+                int v = (((ya[2 * y] * (S0 >> 4)) >> 16) + ((ya[2 * y + 1] * (S1 >> 4)) >> 16) + 2) >> 2;
+                dst[((size_t)y * dw + x) * ch + c] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+            }
+        }
+    }
+    free(ya); free(xa); free(yo); free(xo);
+}

@@ -25,6 +25,7 @@
  */
 #ifndef LT_ORACLE_H
 #define LT_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -116,6 +117,24 @@ int  lto_polyfit2(const int32_t* y, const int32_t* x, int n, double coef[3]);
 int  lto_frame_sws_fit(const lto_calib* c, const uint8_t* frame, const lto_filter_params* fp,
                        const lto_search_params* sp, uint8_t* mask_out, double coef[6],
                        int32_t counts[3]);
+
+/* ---- presentation (cv2 calls, parity unpinned) ------------------------------ */
+/* cv2.fillPoly(img, [pts], color) for ONE polygon on an interleaved u8 image with `ch` channels,
+ * lineType 8, shift 0: every edge drawn with the 8-connected line iterator, interior filled by
+ * the even-odd scanline rule.  pts = npts (x, y) int32 pairs; pixels outside the image are clipped. */
+void lto_fill_poly(uint8_t* img, int h, int w, int ch, const int32_t* pts, int npts, const uint8_t* color);
+/* cv2.addWeighted(a, alpha, b, beta, gamma) on u8: f32 arithmetic, round-half-even, saturate */
+void lto_add_weighted_u8(const uint8_t* a, double alpha, const uint8_t* b, double beta, double gamma,
+                         size_t n, uint8_t* out);
+/* draw_lane (lane_tracker.py:629-662) without the text: polygon between the averaged lane points,
+ * filled (0,255,0) on a blank bird's-eye image, warpPerspective(.., Minv, (img_w,img_h)), then
+ * addWeighted(img, 1, lane, 0.3, 0).  c->M is unused; Minv is the pickled inverse matrix. */
+void lto_draw_lane(const lto_calib* c, const double Minv[9], const uint8_t* img,
+                   const int32_t* left_y, const int32_t* left_x, int n_left,
+                   const int32_t* right_y, const int32_t* right_x, int n_right, uint8_t* out);
+/* cv2.resize(src, (dw, dh)) INTER_LINEAR on u8 with `ch` interleaved channels (fixed-point 11-bit
+ * coefficients, half-pixel centres) -- used by create_split_view (utils.py:89) */
+void lto_resize_linear_u8(const uint8_t* src, int sh, int sw, int ch, int dh, int dw, uint8_t* dst);
 
 #ifdef __cplusplus
 }

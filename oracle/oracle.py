@@ -303,3 +303,53 @@ def check_validity(warped_size, lf, rf):
     s = lambda c, y: 2 * c[0] * y + c[1]
     norm1, norm2 = abs(s(lf, y1) - s(rf, y1)), abs(s(lf, y3) - s(rf, y3))
     return not ((norm1 >= 0.25) | (norm2 >= 0.25))
+
+
+# ---- presentation stage (draw_lane :629-662, create_split_view utils.py:57-103; cv2, unpinned) ------
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(C.c_void_p)
+
+
+def fill_poly(img, pts, color):
+    """cv2.fillPoly(img, [pts], color) in place for one polygon; pts = (n, 2) (x, y)."""
+    assert img.dtype == np.uint8 and img.flags.c_contiguous
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    pts, pp = _i32(np.asarray(pts).reshape(-1, 2))
+    col = (C.c_uint8 * 4)(*([int(c) for c in np.atleast_1d(color)] + [0] * 4)[:4])
+    lib().lto_fill_poly(img.ctypes.data_as(C.c_void_p), img.shape[0], img.shape[1], ch, pp, len(pts), col)
+    return img
+
+
+def add_weighted(a, alpha, b, beta, gamma):
+    a, pa = _u8(a)
+    b, pb = _u8(b)
+    assert a.shape == b.shape
+    out = np.empty_like(a)
+    f = lib().lto_add_weighted_u8
+    f.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_size_t, C.c_void_p]
+    f(pa, alpha, pb, beta, gamma, a.size, out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def draw_lane(calib, Minv, img, left_y, left_x, right_y, right_x):
+    """The lane overlay of draw_lane() without the text lines."""
+    img, pi = _u8(img)
+    ly, ply = _i32(left_y)
+    lx, plx = _i32(left_x)
+    ry, pry = _i32(right_y)
+    rx, prx = _i32(right_x)
+    out = np.empty_like(img)
+    mv = (C.c_double * 9)(*np.asarray(Minv, np.float64).ravel())
+    lib().lto_draw_lane(C.byref(calib), mv, pi, ply, plx, len(ly), pry, prx, len(ry), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def resize_linear(img, dsize):
+    """cv2.resize(img, dsize=(w, h)) with the default INTER_LINEAR, u8."""
+    img, pi = _u8(img)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    dw, dh = int(dsize[0]), int(dsize[1])
+    out = np.empty((dh, dw) if img.ndim == 2 else (dh, dw, ch), np.uint8)
+    lib().lto_resize_linear_u8(pi, img.shape[0], img.shape[1], ch, dh, dw, out.ctypes.data_as(C.c_void_p))
+    return out

@@ -6,6 +6,9 @@ What is pinned, and how:
   * sws_*.npz / band_*.npz -- LaneTracker.sliding_window_search / band_search / fit_poly /
     check_validity / get_poly_points of the reference run UNMODIFIED on seeded binary masks
     (inputs stored bit-packed, outputs stored as arrays).  These methods are plain NumPy.
+  * viz_*.npz -- visualize_sliding_window_search / visualize_band_search / triple_split_view of the
+    reference on the searches above.  Their NumPy indexing is the reference's; the three cv2 calls
+    inside (merge, fillPoly, addWeighted, resize) are answered by the oracle, i.e. unpinned.
   * process_trace.npz -- the reference's process() state machine run over a synthetic stream.
     process() needs cv2, which does not exist in this image.  The harness registers a stand-in
     `cv2` module whose functions are answered by this repo's CPU oracle (oracle/), so this fixture
@@ -84,19 +87,21 @@ def make_cv2_stub():
         return (((a >= lo) & (a <= hi)).astype(np.uint8)) * 255
 
     def fillPoly(img, pts, color):
+        for poly in pts:
+            O.fill_poly(img, np.asarray(poly).reshape(-1, 2), color)
         return img
 
     def putText(img, *a, **k):
         return img
 
     def addWeighted(a, alpha, b, beta, gamma):
-        return np.clip(np.rint(a.astype(np.float64) * alpha + b.astype(np.float64) * beta + gamma), 0, 255).astype(np.uint8)
+        return O.add_weighted(a, alpha, b, beta, gamma)
 
     for f in (warpPerspective, undistort, getStructuringElement, cvtColor, morphologyEx, filter2D,
               adaptiveThreshold, inRange, fillPoly, putText, addWeighted):
         setattr(cv2, f.__name__, f)
     cv2.merge = lambda chans: np.stack(chans, axis=2)
-    cv2.resize = lambda img, dsize: img
+    cv2.resize = lambda img, dsize: O.resize_linear(img, dsize)
     return cv2
 
 
@@ -289,6 +294,54 @@ def run_trace(ref):
     return out
 
 
+def run_viz(ref, out_dir):
+    """Search visualisations and the split view (lane_tracker.py:687-793)."""
+    names = []
+    for name, seed, params in [("sws_a", 11, {}), ("sws_curvy", 21, dict(search_range=60)),
+                               ("sws_overlap", 39, dict(ignore_sides=0, window_width=400))]:
+        kw = dict(curv=3e-4, slope=0.2) if name == "sws_curvy" else {}
+        if name == "sws_overlap":
+            kw = dict(left_base=(500, 520), sep=(545, 575), slope=0.0, curv=0.0)
+        mask = synth.synth_mask(seed, noise=1e-3, **kw)[0]
+        lt = new_tracker(ref)
+        p = dict(SWS_DEFAULT)
+        p.update(params)
+        lt.sliding_window_search(mask, **p)
+        assert lt.detected_pixels, name
+        lf, rf = lt.fit_poly()
+        vis = lt.visualize_sliding_window_search(mask, lf, rf, p["window_width"], p["window_height"], p["ignore_bottom"])
+        d = pack(mask)
+        d.update({"param_" + k: np.asarray(v) for k, v in p.items()})
+        d.update(kind=np.asarray("sws"), vis=vis, left_coeffs=np.asarray(lf), right_coeffs=np.asarray(rf))
+        np.savez_compressed(os.path.join(out_dir, f"viz_{name}.npz"), **d)
+        names.append(name)
+    for name, seed, bw, shift, partial in [("band_a", 61, 25, (0.0, 0.0), 1), ("band_wide", 62, 60, (5.0, -3.0), 1),
+                                           ("band_edge", 63, 40, (-430.0, 380.0), 1)]:
+        mask, lc, rc = synth.synth_mask(seed, noise=1e-3)
+        lc, rc = lc.copy(), rc.copy()
+        lc[2] += shift[0]
+        rc[2] += shift[1]
+        lt = new_tracker(ref)
+        lt.last_left_coeffs, lt.last_right_coeffs = lc, rc
+        lt.band_search(mask, bandwidth=bw, ignore_bottom=30, partial=partial)
+        d = pack(mask)
+        d.update(kind=np.asarray("band"), prev_left=lc, prev_right=rc, param_bandwidth=np.asarray(bw),
+                 param_partial=np.asarray(partial), detected=np.bool_(lt.detected_pixels))
+        if lt.detected_pixels:
+            lf, rf = lt.fit_poly()
+            vis = lt.visualize_band_search(mask, lf, rf, bw, partial)
+            d.update(vis=vis, left_coeffs=np.asarray(lf), right_coeffs=np.asarray(rf))
+        np.savez_compressed(os.path.join(out_dir, f"viz_{name}.npz"), **d)
+        names.append((name, bool(lt.detected_pixels)))
+    rng = np.random.default_rng(5)
+    imgs = [rng.integers(0, 256, (72, 128, 3), dtype=np.uint8), rng.integers(0, 256, (110, 108, 3), dtype=np.uint8),
+            rng.integers(0, 256, (110, 108, 3), dtype=np.uint8)]
+    lt = new_tracker(ref)
+    np.savez_compressed(os.path.join(out_dir, "viz_split.npz"), img0=imgs[0], img1=imgs[1], img2=imgs[2],
+                        out=lt.triple_split_view(imgs))
+    print("viz:", names)
+
+
 def pack(mask):
     return dict(mask_bits=np.packbits(mask != 0), mask_shape=np.asarray(mask.shape, np.int64),
                 mask_value=np.asarray(int(mask.max()) if mask.any() else 255, np.int64))
@@ -321,6 +374,7 @@ def main():
         np.savez_compressed(os.path.join(a.out, f"{name}.npz"), **d)
         names.append((name, bool(out["detected"]), int(out.get("left_x", np.zeros(0)).size)))
     print("band:", names)
+    run_viz(ref, a.out)
     if not a.skip_trace:
         tr = run_trace(ref)
         np.savez_compressed(os.path.join(a.out, "process_trace.npz"), **tr)
