@@ -228,6 +228,8 @@ def main(argv=None):
     ap.add_argument("--window", type=int, default=64, help="frames per GPU batch")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--frame-count", action="store_true", help="print the frame number onto each image")
+    ap.add_argument("--settings", choices=("default", "demo1", "demo2", "demo3"), default="default",
+                    help="parameter set of tracker_settings.md (process() keywords + validity limits)")
     a = ap.parse_args(argv)
     from .lane_tracker import LaneTracker
     from .utils import load_camera_calib, load_warp_params
@@ -239,7 +241,11 @@ def main(argv=None):
                      print_frame_count=a.frame_count, device=a.device)
     try:
         sink = None if a.output == "-" else FrameSink(a.output, src.size, n=len(src))
-        n, dt = process_frames(lt, src, sink, window=a.window)
+        kw = {}
+        if a.settings != "default":
+            from . import settings
+            kw = settings.apply(lt, settings.DEMOS[a.settings])
+        n, dt = process_frames(lt, src, sink, window=a.window, **kw)
         if sink is not None:
             sink.close()
         ratio, success, total = lt.get_success_ratio() if lt.counter else (0.0, 0, 0)

@@ -289,8 +289,12 @@ def get_poly_points(warped_size, left_fit_coeffs, right_fit_coeffs, partial=1):
             right_fit_y.astype(np.int64), right_fit_x.astype(np.int64))
 
 
-def check_validity(warped_size, lf, rf):
-    """lane_tracker.py:561-627 -> bool (the reference stores it in self.valid_lane_lines)."""
+def check_validity(warped_size, lf, rf, limits=None):
+    """lane_tracker.py:561-627 -> bool (the reference stores it in self.valid_lane_lines).  `limits`:
+    the seven numbers upstream hard-codes at :588-593, :617 (tracker_settings.md lists them per demo)."""
+    L = dict(min_dist_y1=150, max_dist_y1=230, min_dist_y2=110, max_dist_y2=230, min_dist_y3=80, max_dist_y3=200,
+             thresh=0.25)
+    L.update(limits or {})
     ly, _, ry, _ = get_poly_points(warped_size, lf, rf)
     n = min(len(ly), len(ry))
     y1 = warped_size[0] - 1
@@ -298,11 +302,12 @@ def check_validity(warped_size, lf, rf):
     y3 = warped_size[0] - int(n * 0.75)
     ev = lambda c, y: c[0] * (y ** 2) + c[1] * y + c[2]
     d1, d2, d3 = abs(ev(lf, y1) - ev(rf, y1)), abs(ev(lf, y2) - ev(rf, y2)), abs(ev(lf, y3) - ev(rf, y3))
-    if (d1 < 150) | (d1 > 230) | (d2 < 110) | (d2 > 230) | (d3 < 80) | (d3 > 200):
+    if ((d1 < L["min_dist_y1"]) | (d1 > L["max_dist_y1"]) | (d2 < L["min_dist_y2"]) | (d2 > L["max_dist_y2"])
+            | (d3 < L["min_dist_y3"]) | (d3 > L["max_dist_y3"])):
         return False
     s = lambda c, y: 2 * c[0] * y + c[1]
     norm1, norm2 = abs(s(lf, y1) - s(rf, y1)), abs(s(lf, y3) - s(rf, y3))
-    return not ((norm1 >= 0.25) | (norm2 >= 0.25))
+    return not ((norm1 >= L["thresh"]) | (norm2 >= L["thresh"]))
 
 
 # ---- presentation stage (draw_lane :629-662, create_split_view utils.py:57-103; cv2, unpinned) ------

@@ -9,6 +9,9 @@ What is pinned, and how:
   * viz_*.npz -- visualize_sliding_window_search / visualize_band_search / triple_split_view of the
     reference on the searches above.  Their NumPy indexing is the reference's; the three cv2 calls
     inside (merge, fillPoly, addWeighted, resize) are answered by the oracle, i.e. unpinned.
+  * photo_*.png / photo_*.npz -- three frames of the reference's test_images/ (decoded with Pillow, stored
+    losslessly) and what the reference's process() makes of them: masks of each try, search mode, pixel
+    counts, coefficients, validity (BASELINE config 1; cv2 answered by the oracle as above).
   * process_trace.npz -- the reference's process() state machine run over a synthetic stream.
     process() needs cv2, which does not exist in this image.  The harness registers a stand-in
     `cv2` module whose functions are answered by this repo's CPU oracle (oracle/), so this fixture
@@ -342,6 +345,42 @@ def run_viz(ref, out_dir):
     print("viz:", names)
 
 
+def run_photos(ref, ref_dir, out_dir):
+    """BASELINE config 1: real camera frames from the reference's test_images/ through the reference's
+    process() (cv2 answered by the oracle).  The decoded frame is stored losslessly next to the results."""
+    from PIL import Image
+    names = []
+    for name in ("test4", "straight_lines1", "test5"):
+        frame = np.asarray(Image.open(os.path.join(ref_dir, "test_images", name + ".jpg")).convert("RGB"), np.uint8)
+        Image.fromarray(frame).save(os.path.join(out_dir, f"photo_{name}.png"), optimize=True)
+        lt = new_tracker(ref)
+        captured = {}
+        _flp = lt.find_lane_points
+
+        def spy(img, **kw):
+            binary, mode = _flp(img, **kw)
+            captured.setdefault("masks", []).append(binary.copy())
+            captured.setdefault("modes", []).append(mode)
+            captured.setdefault("counts", []).append((len(lt.left_x), len(lt.right_x)) if lt.detected_pixels else (0, 0))
+            return binary, mode
+        lt.find_lane_points = spy
+        lt.process(frame.copy(), partial=1)
+        d = dict(frame_sha1=np.asarray(hashlib.sha1(frame.tobytes()).hexdigest()),
+                 n_tries=np.asarray(len(captured["masks"])), modes=np.asarray(captured["modes"]),
+                 counts=np.asarray(captured["counts"], np.int64),
+                 detected=np.bool_(lt.detected_pixels), valid=np.bool_(lt.valid_lane_lines),
+                 last_detection=np.asarray(lt.last_detection), success=np.asarray(lt.success))
+        for i, m in enumerate(captured["masks"]):
+            d[f"mask{i}_bits"] = np.packbits(m != 0)
+            d[f"mask{i}_sha256"] = np.asarray(hashlib.sha256(m.tobytes()).hexdigest())
+        if lt.valid_lane_lines:
+            d.update(left_coeffs=np.asarray(lt.last_left_coeffs, np.float64), right_coeffs=np.asarray(lt.last_right_coeffs, np.float64),
+                     curve_radius=np.asarray(int(lt.average_curve_radius)), eccentricity=np.asarray(float(lt.eccentricity)))
+        np.savez_compressed(os.path.join(out_dir, f"photo_{name}.npz"), **d)
+        names.append((name, bool(lt.detected_pixels), bool(lt.valid_lane_lines), captured["modes"], captured["counts"]))
+    print("photos:", names)
+
+
 def pack(mask):
     return dict(mask_bits=np.packbits(mask != 0), mask_shape=np.asarray(mask.shape, np.int64),
                 mask_value=np.asarray(int(mask.max()) if mask.any() else 255, np.int64))
@@ -375,6 +414,7 @@ def main():
         names.append((name, bool(out["detected"]), int(out.get("left_x", np.zeros(0)).size)))
     print("band:", names)
     run_viz(ref, a.out)
+    run_photos(ref, a.ref, a.out)
     if not a.skip_trace:
         tr = run_trace(ref)
         np.savez_compressed(os.path.join(a.out, "process_trace.npz"), **tr)
