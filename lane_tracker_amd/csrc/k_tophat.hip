@@ -280,29 +280,40 @@ __device__ __forceinline__ uint2 op3v(uint2 a, uint2 b, uint2 c) {
 template <class SE, bool DIL>
 __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH]) {
     uint2* S0 = s + MARGIN;
-    uint2* S1 = S0 + PLANE;
     uint2* S4 = S0 + 2 * PLANE;
     uint2* SL = S0 + 3 * PLANE;   // S13 (55x55) or S7 (29x29)
     const int pa = lane, pb = lane + 64;
-    S1[pa] = op3v<DIL>(S0[pa - 1], S0[pa], S0[pa + 1]);
-    S1[pb] = op3v<DIL>(S0[pb - 1], S0[pb], S0[pb + 1]);
-    wave_lds_fence();
-    S4[pa] = op3v<DIL>(S1[pa - 3], S1[pa], S1[pa + 3]);
-    S4[pb] = op3v<DIL>(S1[pb - 3], S1[pb], S1[pb + 3]);
-    wave_lds_fence();
-    const int p = SE::R + lane;
-    // Final windows: single-address ds_read_b64 (256 B/clk in the LDS pipe) issued by hand.  Left to
-    // the compiler these become ds_read2_b64, which moves the same bytes at half the rate, and the
-    // kernel is LDS-pipe bound (SQ_WAIT_INST_LDS ~28 % with read2).  One s_waitcnt covers them all;
-    // the results are threaded through the wait statement so nothing is consumed before it.
+    // Every LDS read of this function is a single-address ds_read_b64 issued by hand (256 B/clk in the LDS
+    // pipe).  Left to the compiler they become ds_read2_b64, which moves the same bytes at half the rate,
+    // and the kernel is LDS-pipe bound (SQ_WAIT_INST_LDS ~28 % with read2).  One s_waitcnt covers each
+    // batch; the results are threaded through the wait statement so nothing is consumed before it.
 #define LT_RD64(dst, base, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
+    const uint32_t cb = (uint32_t)(uintptr_t)(s + lane);   // low 32 bits of a flat LDS address = LDS offset
+    auto pair = [](unsigned long long v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); };
+    // One chain step with three taps: DST[p] = op(SRC[p - D], SRC[p], SRC[p + D]) for p = pa, pb; entry p of
+    // plane q lives (q * PLANE + MARGIN + p) * 8 bytes from the wave's chain base.
+#define LT_STEP3(SRC, DST, D)                                                                                        \
+    {                                                                                                                \
+        unsigned long long a0, a1, a2, b0, b1, b2;                                                                   \
+        LT_RD64(a0, cb, ((SRC) * PLANE + MARGIN - (D)) * 8);                                                         \
+        LT_RD64(a1, cb, ((SRC) * PLANE + MARGIN) * 8);                                                               \
+        LT_RD64(a2, cb, ((SRC) * PLANE + MARGIN + (D)) * 8);                                                         \
+        LT_RD64(b0, cb, ((SRC) * PLANE + MARGIN + 64 - (D)) * 8);                                                    \
+        LT_RD64(b1, cb, ((SRC) * PLANE + MARGIN + 64) * 8);                                                          \
+        LT_RD64(b2, cb, ((SRC) * PLANE + MARGIN + 64 + (D)) * 8);                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2)::"memory"); \
+        (S0 + (DST) * PLANE)[pa] = op3v<DIL>(pair(a0), pair(a1), pair(a2));                                          \
+        (S0 + (DST) * PLANE)[pb] = op3v<DIL>(pair(b0), pair(b1), pair(b2));                                          \
+        wave_lds_fence();                                                                                            \
+    }
+    LT_STEP3(0, 1, 1)
+    LT_STEP3(1, 2, 3)
+    const int p = SE::R + lane;
     auto lds_addr = [](const uint2* q) { return (uint32_t)(uintptr_t)q; };   // low 32 bits of a flat LDS address = LDS offset
     auto lo = [](unsigned long long v) { return (uint32_t)v; };
     auto hi = [](unsigned long long v) { return (uint32_t)(v >> 32); };
     if (SE::K == 55) {
-        SL[pa] = op3v<DIL>(S4[pa - 9], S4[pa], S4[pa + 9]);
-        SL[pb] = op3v<DIL>(S4[pb - 9], S4[pb], S4[pb + 9]);
-        wave_lds_fence();
+        LT_STEP3(2, 3, 9)
         const uint32_t a0 = lds_addr(S0 + p), a4 = lds_addr(S4 + p - 8), a13 = lds_addr(SL + p - 14);
         unsigned long long r0, f[7], g[29];
         LT_RD64(r0, a0, 0);
@@ -339,9 +350,17 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint32_t (&Ha)[
         }
         Ha[16] = op3<DIL>(lo(g[0]), lo(g[14]), lo(g[28])); Hb[16] = op3<DIL>(hi(g[0]), hi(g[14]), hi(g[28]));   // 27
     } else {
-        SL[pa] = op2v<DIL>(S4[pa - 3], S4[pa + 3]);
-        SL[pb] = op2v<DIL>(S4[pb - 3], S4[pb + 3]);
-        wave_lds_fence();
+        {
+            unsigned long long a0, a2, b0, b2;
+            LT_RD64(a0, cb, (2 * PLANE + MARGIN - 3) * 8);
+            LT_RD64(a2, cb, (2 * PLANE + MARGIN + 3) * 8);
+            LT_RD64(b0, cb, (2 * PLANE + MARGIN + 64 - 3) * 8);
+            LT_RD64(b2, cb, (2 * PLANE + MARGIN + 64 + 3) * 8);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a2), "+v"(b0), "+v"(b2)::"memory");
+            SL[pa] = op2v<DIL>(pair(a0), pair(a2));
+            SL[pb] = op2v<DIL>(pair(b0), pair(b2));
+            wave_lds_fence();
+        }
         const uint32_t a0 = lds_addr(S0 + p), a4 = lds_addr(S4 + p - 1), a7 = lds_addr(SL + p - 7);
         unsigned long long r0, f0, f1, g[15];
         LT_RD64(r0, a0, 0);
@@ -364,6 +383,7 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint32_t (&Ha)[
             Hb[1 + q] = op2<DIL>(hi(g[7 - q]), hi(g[7 + q]));
         }
     }
+#undef LT_STEP3
 #undef LT_RD64
 }
 
