@@ -25,6 +25,9 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <type_traits>
+#include <utility>
+
 #include "lt_internal.h"
 
 namespace lt {
@@ -264,6 +267,28 @@ __device__ __forceinline__ uint32_t pk_shr1(uint32_t a) {
     return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) >> (u16x2t){1, 1}));
 }
 
+// Two ballots (four wave-uniform dwords) into lane LANE of four VGPRs with v_writelane_b32.  The operands
+// come straight from v_cmp; on gfx950 a VALU write of an SGPR needs wait states before another VALU
+// instruction may read it, and the compiler's hazard recogniser does not look inside inline assembly (without
+// the s_nop the parity test fails on a handful of pixels), so the wait states are part of the statement.
+template <int LANE>
+__device__ __forceinline__ void write_lane_words(uint32_t& al, uint32_t& ah, uint32_t& bl, uint32_t& bh,
+                                                 unsigned long long a, unsigned long long b) {
+    asm("s_nop 3\n\t"
+        "v_writelane_b32 %0, %4, %8\n\t"
+        "v_writelane_b32 %1, %5, %8\n\t"
+        "v_writelane_b32 %2, %6, %8\n\t"
+        "v_writelane_b32 %3, %7, %8"
+        : "+v"(al), "+v"(ah), "+v"(bl), "+v"(bh)
+        : "s"((uint32_t)a), "s"((uint32_t)(a >> 32)), "s"((uint32_t)b), "s"((uint32_t)(b >> 32)), "n"(LANE));
+}
+template <class F, int... I>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+constexpr int SB = 16;   // staging loads in flight per lane: the bands are latency-bound, not bandwidth-bound
+
 struct Bilateral2Args {
     BilateralPlane pl[3];
     int noise_thresh;
@@ -310,17 +335,17 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
                 const int cd = min(cd0 + lane, dpr - 1), gx = xa + cd * 4;
                 const bool xin = gx >= 0 && gx < a.w && cd0 + lane < dpr;
                 const uint8_t* colp = s + min(max(gx, 0), a.w - 4);
-                for (int r0 = wv; r0 < T2; r0 += 32) {
-                    uint32_t v[8];
+                for (int r0 = wv; r0 < T2; r0 += 4 * SB) {
+                    uint32_t v[SB];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < SB; ++u) {
                         const int gy = y0 + r0 + 4 * u;
                         v[u] = *reinterpret_cast<const uint32_t*>(colp + (size_t)min(gy, a.h - 1) * a.w);
                         v[u] = (xin && gy < a.h) ? v[u] : 0u;
                     }
                     if (cd0 + lane < dpr) {
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) hb[(r0 + 4 * u) * dpr + cd] = v[u];
+                        for (int u = 0; u < SB; ++u) hb[(r0 + 4 * u) * dpr + cd] = v[u];
                     }
                 }
             }
@@ -375,16 +400,16 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
             const int gxv = x0 + cdv * 4;
             const bool xinv = gxv < a.w;
             const uint8_t* colv = s + min(gxv, a.w - 4);
-            for (int r0 = rsub; r0 < nrows; r0 += 8 * 8) {
-                uint32_t v[8];
+            for (int r0 = rsub; r0 < nrows; r0 += 8 * SB) {
+                uint32_t v[SB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < SB; ++u) {
                     const int gy = y0 - k + r0 + 8 * u;
                     v[u] = *reinterpret_cast<const uint32_t*>(colv + (size_t)min(max(gy, 0), a.h - 1) * a.w);
                     v[u] = (xinv && gy >= 0 && gy < a.h) ? v[u] : 0u;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
+                for (int u = 0; u < SB; ++u)
                     if (r0 + 8 * u < nrows) vb[(r0 + 8 * u) * 32 + cdv] = v[u];
             }
         } else {
@@ -404,32 +429,40 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
                 su += (uint32_t)b[r * T2] | ((uint32_t)b[r * T2 + 64] << 16);
                 sd += (uint32_t)b[(k + 1 + r) * T2] | ((uint32_t)b[(k + 1 + r) * T2 + 64] << 16);
             }
-            unsigned long long m0 = 0, m1 = 0, g0 = 0, g1 = 0;
             uint32_t P = (uint32_t)b[k * T2] | ((uint32_t)b[k * T2 + 64] << 16);
-#pragma unroll 8
-            for (int t = 0; t < 32; ++t) {
-                const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
-                const uint32_t m = pk_sub(su, thr) & pk_sub(sd, thr);
-                const unsigned long long bal0 = __ballot((m & 0x8000u) != 0), bal1 = __ballot((m & 0x80000000u) != 0);
-                if (lane == t) { m0 = bal0; m1 = bal1; }
-                if (q == 2) {   // inRange(lab_b, noise_thresh, 255) on the raw plane
-                    const unsigned long long r0 = __ballot((int)(P & 0xffffu) >= a.noise_thresh),
-                                             r1 = __ballot((int)(P >> 16) >= a.noise_thresh);
-                    if (lane == t) { g0 = r0; g1 = r1; }
-                }
-                const uint32_t outu = (uint32_t)b[t * T2] | ((uint32_t)b[t * T2 + 64] << 16);
-                const uint32_t in = (uint32_t)b[(2 * k + 1 + t) * T2] | ((uint32_t)b[(2 * k + 1 + t) * T2 + 64] << 16);
-                const uint32_t Pn = (uint32_t)b[(k + 1 + t) * T2] | ((uint32_t)b[(k + 1 + t) * T2 + 64] << 16);
-                su = pk_sub(pk_add(su, P), outu);
-                sd = pk_sub(pk_add(sd, in), Pn);
-                P = Pn;
-            }
+            // Row t's verdict word is wave-uniform (a ballot) and belongs in lane t: v_writelane puts an SGPR
+            // into one lane of a VGPR in a single instruction.  The greenery range test only exists for the
+            // third plane; keeping it out of the other two loops keeps them free of branches, so the 32
+            // steps unroll into one block and the LDS reads are issued ahead of their use.
+            uint32_t m0l = 0, m0h = 0, m1l = 0, m1h = 0, g0l = 0, g0h = 0, g1l = 0, g1h = 0;
+            auto vsteps = [&](auto with_range) {
+                for_each_const([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
+                    const uint32_t m = pk_sub(su, thr) & pk_sub(sd, thr);
+                    const unsigned long long bal0 = __ballot((int16_t)(m & 0xffffu) < 0), bal1 = __ballot((int32_t)m < 0);
+                    write_lane_words<t>(m0l, m0h, m1l, m1h, bal0, bal1);
+                    if (decltype(with_range)::value) {   // inRange(lab_b, noise_thresh, 255) on the raw plane
+                        const unsigned long long r0 = __ballot((int)(P & 0xffffu) >= a.noise_thresh),
+                                                 r1 = __ballot((int)(P >> 16) >= a.noise_thresh);
+                        write_lane_words<t>(g0l, g0h, g1l, g1h, r0, r1);
+                    }
+                    const uint32_t outu = (uint32_t)b[t * T2] | ((uint32_t)b[t * T2 + 64] << 16);
+                    const uint32_t in = (uint32_t)b[(2 * k + 1 + t) * T2] | ((uint32_t)b[(2 * k + 1 + t) * T2 + 64] << 16);
+                    const uint32_t Pn = (uint32_t)b[(k + 1 + t) * T2] | ((uint32_t)b[(k + 1 + t) * T2 + 64] << 16);
+                    su = pk_sub(pk_add(su, P), outu);
+                    sd = pk_sub(pk_add(sd, in), Pn);
+                    P = Pn;
+                }, std::make_integer_sequence<int, 32>{});
+            };
+            if (q == 2) vsteps(std::true_type{});
+            else vsteps(std::false_type{});
             if (lane < 32) {
-                atomicOr(&dst[rbase + lane][0], m0);
-                atomicOr(&dst[rbase + lane][1], m1);
+                atomicOr(&dst[rbase + lane][0], (unsigned long long)m0l | ((unsigned long long)m0h << 32));
+                atomicOr(&dst[rbase + lane][1], (unsigned long long)m1l | ((unsigned long long)m1h << 32));
                 if (q == 2) {
-                    s_range[rbase + lane][0] = g0;
-                    s_range[rbase + lane][1] = g1;
+                    s_range[rbase + lane][0] = (unsigned long long)g0l | ((unsigned long long)g0h << 32);
+                    s_range[rbase + lane][1] = (unsigned long long)g1l | ((unsigned long long)g1h << 32);
                 }
             }
         }
