@@ -11,6 +11,8 @@
 // once (one RGBX dword per pixel, rows x W x 4 bytes per frame: it stays in L2 for the warp).
 // The bird's-eye RGB image itself is never written: the warp emits the R plane and the Lab-b
 // plane directly.
+#include <cstdlib>
+
 #include "lt_internal.h"
 
 namespace lt {
@@ -29,16 +31,15 @@ __device__ __forceinline__ int bilerp(int v00, int v01, int v10, int v11, int fx
 // dword per pixel, so that the warp fetches a whole tap with a single aligned load.  All loads are
 // unconditional on clamped addresses and masked afterwards (a guarded load serialises on its own
 // s_waitcnt).
-constexpr int UND_FPB = 4;   // frames per thread: the table entry and the tap offsets are frame-independent
 
 __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restrict__ frames, size_t frame_stride,
                                                        const int16_t* __restrict__ uxy,
                                                        const uint16_t* __restrict__ ufrac, FrontEndGeom g,
-                                                       uint32_t* __restrict__ und, size_t und_stride_px, int n) {
+                                                       uint32_t* __restrict__ und, size_t und_stride_px, int n, int fpb) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int row = blockIdx.y;  // relative to g.r0
     if (x >= g.img_w) return;
-    const int z0 = blockIdx.z * UND_FPB, z1 = min(z0 + UND_FPB, n);
+    const int z0 = blockIdx.z * fpb, z1 = min(z0 + fpb, n);   // fpb frames per thread: table entry and offsets are frame-independent
     const size_t o = (size_t)row * g.img_w + x;
     const int sx = uxy[o * 2], sy = uxy[o * 2 + 1];
     const int f = ufrac[o], fx = f & 31, fy = f >> 5;
@@ -145,9 +146,8 @@ __device__ __forceinline__ void warp_pixel(const uint32_t* __restrict__ src, con
 // Four adjacent bird's-eye pixels per thread: bilinear samples of the RGBX undistorted rows, then
 // one dword store to the R plane and one to the Lab-b plane.  `quads` = pixels / 4 (w % 4 == 0).
 // The remap table entry of a quad is the same for every frame, so a thread keeps it (and the tap
-// offsets derived from it) in registers and walks WARP_FPB consecutive frames with it; the taps of
+// offsets derived from it) in registers and walks `fpb` consecutive frames with it; the taps of
 // frame z+1 are in flight while frame z is blended (the kernel is bound by gather latency).
-constexpr int WARP_FPB = 4;
 
 __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict__ und, size_t und_stride_px,
                                                     const int16_t* __restrict__ wxy,
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
                                                     const uint16_t* __restrict__ gamma_tab,
                                                     const uint16_t* __restrict__ cbrt_tab,
                                                     const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
-                                                    uint8_t* __restrict__ planeB, size_t plane_stride, int n) {
+                                                    uint8_t* __restrict__ planeB, size_t plane_stride, int n, int fpb) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_cbrt[3072];
     __shared__ int32_t s_coef[9];
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
     const uint2 fr = reinterpret_cast<const uint2*>(wfrac)[qc];      // 4 x u16
     stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
     if (qi >= quads) return;
-    const int z0 = blockIdx.z * WARP_FPB, z1 = min(z0 + WARP_FPB, n);
+    const int z0 = blockIdx.z * fpb, z1 = min(z0 + fpb, n);
     const uint32_t xyv[4] = {xy.x, xy.y, xy.z, xy.w};
     const uint32_t frv[4] = {fr.x & 0xffffu, fr.x >> 16, fr.y & 0xffffu, fr.y >> 16};
     // 87 % of the bird's-eye view samples strictly inside the staged rows: skip every border test there
@@ -295,11 +295,21 @@ __global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint32_t* __re
 
 }  // namespace
 
+// Frames one thread walks with its remap-table entry: as many as possible (the table read, the tap address
+// arithmetic and one memory round trip are paid once per walk) while the launch still has a few groups of
+// frames, so that small batches keep their parallelism.
+static int frames_per_thread(int n) {
+    static const int cap = [] { const char* e = std::getenv("LT_FRONTEND_FPB"); int v = e ? std::atoi(e) : 16; return v < 1 ? 1 : v; }();
+    int fpb = n / 8;
+    return fpb < 1 ? 1 : (fpb > cap ? cap : fpb);
+}
+
 void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
                            const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_stride_px, int n) {
     if (n <= 0 || g.nrows <= 0) return;
-    dim3 grid((g.img_w + 255) / 256, g.nrows, (n + UND_FPB - 1) / UND_FPB);
-    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px, n);
+    const int fpb = frames_per_thread(n);
+    dim3 grid((g.img_w + 255) / 256, g.nrows, (n + fpb - 1) / fpb);
+    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px, n, fpb);
 }
 
 void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy,
@@ -308,9 +318,10 @@ void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px,
     if (n <= 0 || g.nrows <= 0) return;
     const size_t npix = (size_t)g.warp_h * g.warp_w;
     if ((g.warp_w & 3) == 0 && (plane_stride & 3) == 0) {
-        dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, (n + WARP_FPB - 1) / WARP_FPB);
+        const int fpb = frames_per_thread(n);
+        dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, (n + fpb - 1) / fpb);
         hipLaunchKernelGGL(k_warp_split4, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
-                           coeffs, planeR, planeB, plane_stride, n);
+                           coeffs, planeR, planeB, plane_stride, n, fpb);
     } else {
         dim3 grid((unsigned)((npix + 255) / 256), 1, n);
         hipLaunchKernelGGL(k_warp_split1, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
