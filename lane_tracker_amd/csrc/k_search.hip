@@ -8,6 +8,8 @@
 // per-lane 3x3 normal-equations solve on exact int64 moments taken about the image centre.
 // Lane pixels are emitted in the reference's order (level-major, then row-major inside a window;
 // row-major for the band search) as packed (y << 16) | x.
+#include <cstdlib>
+
 #include "lt_internal.h"
 
 namespace lt {
@@ -18,10 +20,44 @@ constexpr int NT = 256;
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane steps on DPP (a few cycles each) instead of ds_bpermute shuffles (an LDS round trip each): the
+// recurrence is one wave walking a dependent chain, so every round trip is on the critical path.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xf, BOUND);
+}
+// max over the wave, returned wave-uniform: rotate-and-max inside each row of 16, then four readlanes
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v) {
+    v = max(v, dpp_u32<0x121, 0xf, false>(v, v));   // row_ror:1
+    v = max(v, dpp_u32<0x122, 0xf, false>(v, v));   // row_ror:2
+    v = max(v, dpp_u32<0x124, 0xf, false>(v, v));   // row_ror:4
+    v = max(v, dpp_u32<0x128, 0xf, false>(v, v));   // row_ror:8
+    const unsigned r0 = (unsigned)__builtin_amdgcn_readlane((int)v, 0), r1 = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = (unsigned)__builtin_amdgcn_readlane((int)v, 32), r3 = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+// inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row (row_shr 1, 2, 4, 8 with zero fill),
+// then the row totals with row_bcast:15 (into rows 1, 3) and row_bcast:31 (into rows 2, 3)
+__device__ __forceinline__ unsigned wave_inclusive_sum_dpp(unsigned v) {
+    v += dpp_u32<0x111, 0xf, true>(0u, v);
+    v += dpp_u32<0x112, 0xf, true>(0u, v);
+    v += dpp_u32<0x114, 0xf, true>(0u, v);
+    v += dpp_u32<0x118, 0xf, true>(0u, v);
+    v += dpp_u32<0x142, 0xa, false>(0u, v);
+    v += dpp_u32<0x143, 0xc, false>(0u, v);
     return v;
+}
+
+// sum of a 64-bit value over the wave (wave-uniform result, two's complement): three limbs of 22/22/20
+// bits, so that each limb's 64-lane sum fits 32 bits and can use the DPP scan
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    const unsigned long long u = (unsigned long long)v;
+    const unsigned s0 = wave_inclusive_sum_dpp((unsigned)(u & 0x3fffffu));
+    const unsigned s1 = wave_inclusive_sum_dpp((unsigned)((u >> 22) & 0x3fffffu));
+    const unsigned s2 = wave_inclusive_sum_dpp((unsigned)(u >> 44));
+    const unsigned long long t0 = (unsigned)__builtin_amdgcn_readlane((int)s0, 63), t1 = (unsigned)__builtin_amdgcn_readlane((int)s1, 63),
+                             t2 = (unsigned)__builtin_amdgcn_readlane((int)s2, 63);
+    return (long long)(t0 + (t1 << 22) + (t2 << 44));
 }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 #pragma unroll
@@ -113,38 +149,47 @@ __device__ void wave0_exclusive_scan(const unsigned* in, unsigned* out, int n) {
 // np.sum(img[r0:r1, :], axis=0) (lane_tracker.py:290, 310, 350) for band 0 = the start slice
 // [y_start, img_height) and bands 1..nlevels-1 = the level rows.  One thread per 4 columns
 // (dword loads, unconditional and batched), sums[frame][band][w] as u32.
+constexpr int BS_RG = 8;   // row groups per workgroup: the start slice is hundreds of rows tall, and a single
+                           // frame must not spend them one after the other in one thread
 template <bool VEC4>
-__global__ __launch_bounds__(64) void k_band_sums(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
-                                                 uint32_t* __restrict__ sums) {
-    const int band = blockIdx.y, frame = blockIdx.z;
-    const int r0 = band == 0 ? max(g.y_start, 0) : g.img_height - (1 + band) * g.wh;
+__global__ __launch_bounds__(64 * BS_RG) void k_band_sums(const uint8_t* __restrict__ masks, size_t mask_stride,
+                                                         SearchGeom g, uint32_t* __restrict__ sums) {
+    __shared__ uint4 part[BS_RG][64];
+    const int band = blockIdx.y, frame = blockIdx.z, tx = threadIdx.x, ty = threadIdx.y;
+    const int r0 = max(band == 0 ? max(g.y_start, 0) : g.img_height - (1 + band) * g.wh, 0);
     const int r1 = band == 0 ? g.img_height : g.img_height - band * g.wh;
     const uint8_t* m = masks + (size_t)frame * mask_stride;
     uint32_t* out = sums + ((size_t)frame * g.nbands + band) * g.w;
+    uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     if (VEC4) {
-        const int q = blockIdx.x * 64 + threadIdx.x, nq = g.w >> 2;
-        if (q >= nq) return;
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        const int nq = g.w >> 2, q = min(blockIdx.x * 64 + tx, nq - 1);
         const uint32_t* col = reinterpret_cast<const uint32_t*>(m) + q;
-        int y = max(r0, 0);
-        for (; y + 8 <= r1; y += 8) {
+        for (int y = r0 + ty; y < r1; y += BS_RG * 8) {      // rows y, y + 8, ..., all in flight
             uint32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(y + u) * nq];
+            for (int u = 0; u < 8; ++u) v[u] = col[(size_t)min(y + BS_RG * u, g.h - 1) * nq];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a0 += v[u] & 255u; a1 += (v[u] >> 8) & 255u; a2 += (v[u] >> 16) & 255u; a3 += v[u] >> 24; }
+            for (int u = 0; u < 8; ++u)
+                if (y + BS_RG * u < r1) { a0 += v[u] & 255u; a1 += (v[u] >> 8) & 255u; a2 += (v[u] >> 16) & 255u; a3 += v[u] >> 24; }
         }
-        for (; y < r1; ++y) {
-            const uint32_t v = col[(size_t)y * nq];
-            a0 += v & 255u; a1 += (v >> 8) & 255u; a2 += (v >> 16) & 255u; a3 += v >> 24;
-        }
-        reinterpret_cast<uint4*>(out)[q] = make_uint4(a0, a1, a2, a3);
     } else {
-        const int x = blockIdx.x * 64 + threadIdx.x;
-        if (x >= g.w) return;
-        uint32_t acc = 0;
-        for (int y = max(r0, 0); y < r1; ++y) acc += m[(size_t)y * g.w + x];
-        out[x] = acc;
+        const int x = min(blockIdx.x * 64 + tx, g.w - 1);
+        for (int y = r0 + ty; y < r1; y += BS_RG) a0 += m[(size_t)y * g.w + x];
+    }
+    part[ty][tx] = make_uint4(a0, a1, a2, a3);
+    __syncthreads();
+    if (ty != 0) return;
+#pragma unroll
+    for (int j = 1; j < BS_RG; ++j) {
+        const uint4 p = part[j][tx];
+        a0 += p.x; a1 += p.y; a2 += p.z; a3 += p.w;
+    }
+    if (VEC4) {
+        const int q = blockIdx.x * 64 + tx;
+        if (q < (g.w >> 2)) reinterpret_cast<uint4*>(out)[q] = make_uint4(a0, a1, a2, a3);
+    } else {
+        const int x = blockIdx.x * 64 + tx;
+        if (x < g.w) out[x] = a0;
     }
 }
 
@@ -417,6 +462,330 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
     reduce_and_fit(mom, distinct, s_mom, g.h, g.w, n_out[0], n_out[1], detected, 0, recs + frame);
 }
 
+// ===================================================================================================
+// k_sws_fit2: the same search with the dependent chain taken off global memory.
+//
+// k_sws_fit walks the levels one by one and pays, per level, a global round trip for the band sums, a
+// 1080-wide scan, and two more dependent round trips for the count and emit passes of the windows --
+// about 13 us per level, 340 us per frame, almost all of it latency.  Here
+//   A  every band sum of the frame is brought into LDS at once (levels as u16; the start slice as u32);
+//   B  wave 0 alone runs the recurrence over the levels on LDS data (a scan over just the columns a
+//      level can reach, two argmax passes), recording each level's window [a, b) per side;
+//   C  all windows are then read in parallel: one wave per (level, side, 64-row chunk), one lane per
+//      row, the row's window as aligned dwords -> a bit per column; lane order is the reference's
+//      row-major order, so a wave scan gives the offsets inside a window and a short scan over the
+//      window totals the offsets between windows.  Pixels and moments are emitted from the bit masks,
+//      which stay in registers (nothing is read twice).
+// Needs w % 4 == 0, window width <= 64 and at most SWS2_TPW tasks per wave; launch_sws_fit falls back
+// to k_sws_fit otherwise.
+constexpr int SWS2_TPW = 16;
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// first/last argmax of conv[a:b), conv = np.convolve(ones(ww), src[0:ncnt)) ('full').  Only the entries a
+// level can reach are touched: the exclusive prefix of src[pl .. ph) is built 64 entries at a time (one
+// entry per lane, DPP scan) into q, conv[k] = q[hi] - q[lo], one wave-max, and the positions of the maxima
+// come from ballots.  q: scratch of >= ph - pl + 1 entries.  false <=> np.any false.
+template <class T>
+__device__ bool box_argmax_window(const T* src, int ncnt, int ww, int a, int b, unsigned* q, int& first, int& last) {
+    const int pl = max(a - ww + 1, 0), ph = min(b, ncnt);
+    if (ph <= pl) return false;                      // every window sum is empty -> np.any false
+    const int lane = lane_id(), n = ph - pl;
+    unsigned run = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const unsigned v = i < n ? (unsigned)src[pl + i] : 0u;
+        const unsigned incl = wave_inclusive_sum_dpp(v);
+        if (i < n) q[i] = run + incl - v;
+        run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (lane == 0) q[n] = run;
+    if (run == 0) return false;                      // nothing in reach (uniform)
+    wave_sync();
+    unsigned best = 0;
+    for (int base = a; base < b; base += 64) {
+        const int k = base + lane;
+        if (k < b) {
+            const int lo = max(k - ww + 1, 0), hi = min(k + 1, ncnt);
+            best = max(best, hi > lo ? q[hi - pl] - q[lo - pl] : 0u);
+        }
+    }
+    best = wave_max_u32_dpp(best);                   // > 0: some window contains a non-zero entry
+    int f = -1, l = -1;
+    for (int base = a; base < b; base += 64) {
+        const int k = base + lane;
+        unsigned v = 0;
+        if (k < b) {
+            const int lo = max(k - ww + 1, 0), hi = min(k + 1, ncnt);
+            v = hi > lo ? q[hi - pl] - q[lo - pl] : 0u;
+        }
+        const unsigned long long hit = __ballot(k < b && v == best);
+        if (hit) {
+            if (f < 0) f = base + (int)__builtin_ctzll(hit);
+            l = base + 63 - (int)__builtin_clzll(hit);
+        }
+    }
+    wave_sync();                                     // q is rewritten by the next call
+    first = f - a;
+    last = l - a;
+    return best != 0;
+}
+
+// Phase B of k_sws_fit2: the serial part of sliding_window_search (lane_tracker.py:290-430), run by one
+// wave on the LDS image of the band sums.  Kept out of line on purpose: inlined into the large unrolled
+// kernel body, the build (hipcc, ROCm 7.2) returned 32 instead of 432 as the default centre of an undetected
+// left line -- caught by the golden tests, and correct again with a printf next to the assignment, i.e. a
+// code-generation problem, not a data race.  As a separate function it is correct and costs one call.
+__device__ __noinline__ void sws2_recurrence(const SearchGeom& g, int nlev, const unsigned* sum0, unsigned* prefix,
+                                             const uint16_t* lev, int* roi_ab, int* state, int32_t* cent) {
+    const int lane = lane_id();
+    const int W = g.w, ww = g.ww, wh = g.wh, hw = g.hw, H1 = g.img_height;
+
+    int c[2], ns[2] = {0, 0}, lo[2], hi[2], ndiff[2] = {0, 0}, last_diff[2] = {0, 0}, ncent[2] = {0, 0}, nroi[2] = {0, 0};
+    auto set_roi = [&](int s, int level, int center) {
+        const int ra = center - hw, rb = min(center + hw, W);
+        if (lane == 0) {
+            roi_ab[(s * nlev + level) * 2] = ra < 0 ? rb : ra;       // negative start: NumPy slice is empty
+            roi_ab[(s * nlev + level) * 2 + 1] = rb;
+        }
+        nroi[s]++;
+    };
+    for (int s = 0; s < 2; ++s) {                                    // level 0 (:290-332)
+        const int c0 = s == 0 ? g.ignore_sides : g.img_center;
+        const int c1 = s == 0 ? g.img_center : W - g.ignore_sides;
+        bool found = false;
+        int first = 0, last = 0;
+        if (c1 > c0 && H1 > g.y_start)
+            found = box_argmax_window(sum0 + c0, c1 - c0, ww, 0, (c1 - c0) + ww - 1, prefix, first, last);
+        if (found) {
+            c[s] = ((first + last) >> 1) - hw + c0;                  // :296-297 / :316-317
+            if (H1 - wh >= 0) set_roi(s, 0, c[s]);
+            else nroi[s]++;
+        } else {
+            c[s] = s == 0 ? g.def_left : g.def_right;                // :308 / :328
+        }
+        if (lane == 0) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = c[s];
+        ncent[s]++;
+        lo[s] = -g.search_range;
+        hi[s] = g.search_range;
+    }
+    const int conv_len = W + ww - 1;                                 // :351
+    for (int level = 1; level < g.nlevels; ++level) {                // :346-430
+        const uint16_t* sums = lev + (size_t)(level - 1) * W;
+        for (int s = 0; s < 2; ++s) {                                // left first, then right (:354, :395)
+            if (ns[s] >= g.limit) continue;
+            const int lo_i = max(c[s] + lo[s] + hw, 0);              // :356
+            const int hi_i = min(c[s] + hi[s] + hw, W);              // :357
+            const int a = min(lo_i, conv_len);                       // conv[lo_i:hi_i], Python slice rules
+            const int b = hi_i < 0 ? max(conv_len + hi_i, 0) : min(hi_i, conv_len);
+            int first = 0, last = 0;
+            const bool found = b > a && box_argmax_window(sums, W, ww, a, b, prefix, first, last);   // :360
+            if (found) {
+                const int newc = ((first + last + 1) >> 1) + lo_i - hw;   // ceil, :363-364
+                if (lane == 0 && ncent[s] < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = newc;
+                ncent[s]++;
+                last_diff[s] = newc - c[s];                          // :366
+                ndiff[s]++;
+                c[s] = newc;
+                ns[s] = 0;                                           // :368
+                set_roi(s, level, c[s]);
+                const int t = (int)(g.mu * (double)last_diff[s]);    // :380-381, truncation toward zero
+                lo[s] += t;
+                hi[s] += t;
+            } else {
+                const int o = 1 - s;
+                if (ndiff[o] > 0 && ns[o] == 0) c[s] += last_diff[o]; // :385-387 / :423-425
+                if (lane == 0 && ncent[s] < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = c[s];
+                ncent[s]++;
+                ns[s]++;                                             // :390
+                if (ns[s] >= g.limit) ncent[s] -= min(g.limit > 0 ? g.limit : ncent[s], ncent[s]);   // :391-392
+            }
+        }
+    }
+    if (lane == 0) {
+        cent[0] = ncent[0];
+        cent[g.maxlev + 2] = ncent[1];
+        state[0] = nroi[0];
+        state[1] = nroi[1];
+    }
+}
+
+struct Sws2Layout {       // byte offsets into dynamic LDS
+    int sum0, prefix, lev, roi, ttot, tbase, state, mom, total;
+    int nlev, nchunk, ntask;
+};
+__host__ __device__ inline Sws2Layout sws2_layout(const SearchGeom& g) {
+    Sws2Layout L;
+    L.nlev = g.nlevels > 1 ? g.nlevels : 1;
+    L.nchunk = (g.wh + 63) / 64;
+    L.ntask = L.nlev * 2 * L.nchunk;
+    int o = 0;
+    auto take = [&o](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };   // 16-byte aligned sections
+    L.sum0 = take(g.w * 4);
+    L.prefix = take((g.w + g.ww + 64) * 4);           // window sums of one level: up to w + ww - 1 entries
+    L.lev = take((L.nlev - 1) * g.w * 2);
+    L.roi = take(L.nlev * 2 * 2 * 4);                // (a, b) per (side, level)
+    L.ttot = take(L.ntask * 4);
+    L.tbase = take(L.ntask * 4);
+    L.state = take(8 * 4);                           // nroi[2], distinct[2], n_out[2]
+    L.mom = take(16 * 8);
+    L.total = o;
+    return L;
+}
+
+template <int ND>   // dwords that cover one window row: 9 for widths <= 32, 17 for widths <= 64
+__global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+                                                const uint32_t* __restrict__ band_sums, uint32_t* __restrict__ pix_all,
+                                                int32_t* __restrict__ cent_all, lt_lane_record* __restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Sws2Layout L = sws2_layout(g);
+    unsigned* sum0 = reinterpret_cast<unsigned*>(smem + L.sum0);
+    unsigned* prefix = reinterpret_cast<unsigned*>(smem + L.prefix);
+    uint16_t* lev = reinterpret_cast<uint16_t*>(smem + L.lev);
+    int* roi_ab = reinterpret_cast<int*>(smem + L.roi);            // [(s * nlev + level) * 2 + {0,1}]
+    unsigned* ttot = reinterpret_cast<unsigned*>(smem + L.ttot);
+    unsigned* tbase = reinterpret_cast<unsigned*>(smem + L.tbase);
+    int* state = reinterpret_cast<int*>(smem + L.state);
+    long long* s_mom = reinterpret_cast<long long*>(smem + L.mom);
+
+    const int frame = blockIdx.x, lane = lane_id(), wv = wave_id();
+    const uint8_t* mask = masks + (size_t)frame * mask_stride;
+    const uint32_t* fsums = band_sums + (size_t)frame * g.nbands * g.w;   // [band][w], band 0 = start slice
+    uint32_t* pix = pix_all + (size_t)frame * 2 * g.maxpix;
+    int32_t* cent = cent_all + (size_t)frame * 2 * (g.maxlev + 2);
+    const int W = g.w, wh = g.wh, H1 = g.img_height, nlev = L.nlev;
+    const int y0c = g.h / 2, x0c = g.w / 2;
+
+    // ---- A: band sums -> LDS ---------------------------------------------------------------------
+    {
+        const int nq0 = W >> 2, nq = (nlev - 1) * nq0;                 // uint4 groups (W % 4 == 0)
+        const uint4* src = reinterpret_cast<const uint4*>(fsums);
+        for (int i = threadIdx.x; i < nq0; i += NT) reinterpret_cast<uint4*>(sum0)[i] = src[i];
+        const uint4* lsrc = src + nq0;
+        for (int base = threadIdx.x; base < nq; base += NT * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = lsrc[min(base + u * NT, nq - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * NT < nq)
+                    reinterpret_cast<uint2*>(lev)[base + u * NT] = make_uint2(v[u].x | (v[u].y << 16), v[u].z | (v[u].w << 16));
+        }
+        for (int i = threadIdx.x; i < nlev * 4; i += NT) roi_ab[i] = 0;  // a = b = 0: no window
+        if (threadIdx.x < 8) state[threadIdx.x] = 0;
+        if (threadIdx.x < 16) s_mom[threadIdx.x] = 0;
+    }
+    __syncthreads();
+
+    // ---- B: the recurrence over the levels, wave 0, LDS only (lane_tracker.py:290-430) -----------
+    if (wv == 0) sws2_recurrence(g, nlev, sum0, prefix, lev, roi_ab, state, cent);
+    __syncthreads();
+
+    // ---- C: all windows in parallel -----------------------------------------------------------------
+    // task ti = (s * nlev + level) * nchunk + chunk; lane = row of the chunk; bits = non-zero columns of [a, b)
+    unsigned long long bits[SWS2_TPW];
+    unsigned loff[SWS2_TPW];
+    const int nchunk = L.nchunk;
+#pragma unroll
+    for (int i = 0; i < SWS2_TPW; ++i) {
+        bits[i] = 0;
+        loff[i] = 0;
+        const int ti = wv + 4 * i, tc = min(ti, L.ntask - 1);
+        const int sl = tc / nchunk, ch = tc - sl * nchunk, level = sl % nlev;
+        const int a = roi_ab[sl * 2], b = roi_ab[sl * 2 + 1];
+        const int ry = ch * 64 + lane;
+        // no branch and no predicated load in this loop (a predicated load would wait on its own): the rows
+        // of all tasks of this wave are in flight together; slots past the task list repeat the last task
+        const bool ok = ti < L.ntask && b > a && ry < wh;
+        const int y = min(max(H1 - (1 + level) * wh + ry, 0), g.h - 1);
+        const int xa = ok ? (a & ~3) : 0, nd = ok ? (b - xa + 3) >> 2 : 1;
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(mask + (size_t)y * W + xa);
+        uint32_t v[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) v[d] = p[min(d, nd - 1)];
+        unsigned long long m = 0;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+            const uint32_t nz = ((v[d] & 0xffu) ? 1u : 0u) | ((v[d] & 0xff00u) ? 2u : 0u) | ((v[d] & 0xff0000u) ? 4u : 0u) |
+                                ((v[d] & 0xff000000u) ? 8u : 0u);
+            const int sh = xa + 4 * d - a;                           // bit index of this dword's first column
+            const unsigned long long piece = sh >= 0 ? (unsigned long long)nz << (sh & 63) : (unsigned long long)nz >> ((-sh) & 63);
+            m |= d < nd ? piece : 0ull;
+        }
+        const int bw = b - a;
+        m &= bw < 64 ? (1ull << (bw & 63)) - 1ull : ~0ull;
+        m = ok ? m : 0ull;
+        bits[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < SWS2_TPW; ++i) {
+        const int ti = wv + 4 * i;
+        if (ti >= L.ntask) continue;     // wave-uniform
+        const unsigned cnt = (unsigned)__popcll(bits[i]);
+        const unsigned incl = wave_inclusive_sum_dpp(cnt);
+        loff[i] = incl - cnt;
+        const unsigned long long rows = __ballot(cnt != 0);
+        if (lane == 63) ttot[ti] = incl;
+        if (lane == 0 && rows) atomicAdd(&state[2 + (ti / nchunk) / nlev], (int)__popcll(rows));   // distinct rows per side
+    }
+    __syncthreads();
+    // offsets between windows: per side, tasks in (level, chunk) order -- every wave computes what it needs
+    {
+        const int per_side = nlev * nchunk;
+        for (int s = 0; s < 2; ++s) {
+            unsigned run = 0;
+            for (int base = 0; base < per_side; base += 64) {
+                const int k = base + lane;
+                const unsigned v = k < per_side ? ttot[s * per_side + k] : 0u;
+                const unsigned incl = wave_inclusive_sum_dpp(v);
+                if (wv == 0 && k < per_side) tbase[s * per_side + k] = run + incl - v;
+                run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            if (wv == 0 && lane == 0) state[4 + s] = (int)run;          // n_out[s]
+        }
+    }
+    __syncthreads();
+    Moments mom[2];
+    mom[0].clear();
+    mom[1].clear();
+#pragma unroll
+    for (int i = 0; i < SWS2_TPW; ++i) {
+        const int ti = wv + 4 * i;
+        if (ti >= L.ntask) continue;
+        unsigned long long m = bits[i];
+        if (!m) continue;
+        const int sl = ti / nchunk, ch = ti - sl * nchunk, level = sl % nlev, s = sl / nlev;
+        const int a = roi_ab[sl * 2];
+        const int y = H1 - (1 + level) * wh + ch * 64 + lane;
+        uint32_t* out = pix + (size_t)s * g.maxpix;
+        int idx = (int)(tbase[ti] + loff[i]);
+        // moments of this row's pixels in closed form: y is fixed, so only the count and the sum of the
+        // columns are needed; sum of the set bit positions = sum_b 2^b popcount(m & {positions with bit b})
+        const long long cnt = __popcll(m);
+        const long long sj = __popcll(m & 0xaaaaaaaaaaaaaaaaull) + 2 * __popcll(m & 0xccccccccccccccccull) +
+                             4 * __popcll(m & 0xf0f0f0f0f0f0f0f0ull) + 8 * __popcll(m & 0xff00ff00ff00ff00ull) +
+                             16 * __popcll(m & 0xffff0000ffff0000ull) + 32 * __popcll(m & 0xffffffff00000000ull);
+        const long long dy = y - y0c, dy2 = dy * dy, sdx = sj + cnt * (a - x0c);
+        Moments& mm = s == 0 ? mom[0] : mom[1];
+        mm.m[0] += cnt; mm.m[1] += cnt * dy; mm.m[2] += cnt * dy2; mm.m[3] += cnt * dy2 * dy; mm.m[4] += cnt * dy2 * dy2;
+        mm.m[5] += sdx; mm.m[6] += sdx * dy; mm.m[7] += sdx * dy2;
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            if (idx < g.maxpix) out[idx] = ((uint32_t)y << 16) | (uint32_t)(a + j);
+            ++idx;
+        }
+    }
+    const int n_left = state[4], n_right = state[5];
+    const int distinct[2] = {state[2], state[3]};
+    const bool detected = state[0] > 0 && state[1] > 0 && n_left > 0 && n_right > 0;   // :432-447
+    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, n_left, n_right, detected, 0, recs + frame);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Integer column range [a, b) of the pixels with lo < x < hi, clipped to [0, W).  x is an integer, so
 // x > lo <=> x >= floor(lo)+1 and x < hi <=> x < ceil(hi): the same set the reference's f64
@@ -565,8 +934,33 @@ void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Sea
     if (n <= 0) return;
     const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
     dim3 sgrid(((vec4 ? g.w / 4 : g.w) + 63) / 64, g.nbands, n);
-    if (vec4) hipLaunchKernelGGL(k_band_sums<true>, sgrid, dim3(64), 0, s, masks, mask_stride, g, band_sums);
-    else hipLaunchKernelGGL(k_band_sums<false>, sgrid, dim3(64), 0, s, masks, mask_stride, g, band_sums);
+    if (vec4) hipLaunchKernelGGL(k_band_sums<true>, sgrid, dim3(64, BS_RG), 0, s, masks, mask_stride, g, band_sums);
+    else hipLaunchKernelGGL(k_band_sums<false>, sgrid, dim3(64, BS_RG), 0, s, masks, mask_stride, g, band_sums);
+    // k_sws_fit2: dword rows, window width <= 64 bits, level sums that fit u16, a bounded task list and
+    // an LDS image of all band sums; anything else takes the level-by-level kernel
+    static const bool v1 = [] { const char* e = std::getenv("LT_SWS_V1"); return e && e[0] == '1'; }();
+    static const bool dbg_skip = [] { const char* e = std::getenv("LT_DBG_SKIP_FIT"); return e && e[0] == '1'; }();
+    if (dbg_skip) return;
+    const Sws2Layout L = sws2_layout(g);
+    const bool v2 = !v1 && vec4 && 2 * g.hw <= 64 && g.wh * 255 <= 65535 && (L.ntask + 3) / 4 <= SWS2_TPW &&
+                    L.total <= 150 * 1024 && g.img_height - g.wh >= 0 && g.nlevels * g.wh <= g.img_height;
+    if (v2) {
+        static int attr_bytes = 0;
+        if (L.total > 48 * 1024 && L.total > attr_bytes) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sws_fit2<9>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    150 * 1024) == hipSuccess &&
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_sws_fit2<17>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    150 * 1024) == hipSuccess)
+                attr_bytes = 150 * 1024;
+        }
+        if (L.total <= 48 * 1024 || attr_bytes >= L.total) {
+            if (2 * g.hw <= 32)
+                hipLaunchKernelGGL(k_sws_fit2<9>, dim3(n), dim3(NT), (size_t)L.total, s, masks, mask_stride, g, band_sums, pix, cent, rec);
+            else
+                hipLaunchKernelGGL(k_sws_fit2<17>, dim3(n), dim3(NT), (size_t)L.total, s, masks, mask_stride, g, band_sums, pix, cent, rec);
+            return;
+        }
+    }
     const size_t words = (size_t)(2 * g.w + 1 + 4 * g.wh + 2);
     const size_t lds = ((words * 4 + 15) & ~(size_t)15) + 16 * sizeof(long long);
     if (vec4) hipLaunchKernelGGL(k_sws_fit<true>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, band_sums, pix, cent, rec);
