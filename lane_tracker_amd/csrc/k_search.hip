@@ -315,7 +315,7 @@ __device__ void extract_windows(const uint8_t* mask, int w, int r0, int r1, cons
 }
 
 __device__ void reduce_and_fit(Moments* mom, const int* distinct, long long* s_mom, int h, int w, int n_left,
-                               int n_right, bool detected, int mode, lt_lane_record* rec) {
+                               int n_right, bool detected, int mode, lt_lane_record* rec, int pix_format = 0) {
     // block-reduce the per-thread moments: wave shuffle, then LDS atomics
     for (int i = threadIdx.x; i < 16; i += NT) s_mom[i] = 0;
     __syncthreads();
@@ -340,7 +340,7 @@ __device__ void reduce_and_fit(Moments* mom, const int* distinct, long long* s_m
         r.detected = detected ? 1 : 0;
         r.fit_flags = (uint8_t)flags;
         r.mode = (uint8_t)mode;
-        r._pad = 0;
+        r._pad = (uint8_t)pix_format;   // 0: packed (y << 16) | x lists; 1: per-row column masks (k_sws_fit2)
         r.frame = rec->frame;  // keep the caller's tag
         *rec = r;
     }
@@ -471,14 +471,12 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
 //   A  every band sum of the frame is brought into LDS at once (levels as u16; the start slice as u32);
 //   B  wave 0 alone runs the recurrence over the levels on LDS data (a scan over just the columns a
 //      level can reach, two argmax passes), recording each level's window [a, b) per side;
-//   C  all windows are then read in parallel: one wave per (level, side, 64-row chunk), one lane per
-//      row, the row's window as aligned dwords -> a bit per column; lane order is the reference's
-//      row-major order, so a wave scan gives the offsets inside a window and a short scan over the
-//      window totals the offsets between windows.  Pixels and moments are emitted from the bit masks,
-//      which stay in registers (nothing is read twice).
-// Needs w % 4 == 0, window width <= 64 and at most SWS2_TPW tasks per wave; launch_sws_fit falls back
-// to k_sws_fit otherwise.
-constexpr int SWS2_TPW = 16;
+//   C  all windows are then read in parallel, coalesced, as 16-byte pieces dealt to the 256 threads; the
+//      non-zero flags of a piece are OR-ed into one 64-bit column mask per window row (LDS atomics); a row's
+//      count and moments follow from its mask in closed form, and the masks themselves are what is stored:
+//      the reference's pixel lists are expanded from them on demand (lt_download_pixels).
+// Needs w % 4 == 0, window width <= 64, window height * 255 <= 65535; launch_sws_fit falls back to k_sws_fit
+// otherwise.
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -486,12 +484,22 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS pointers keep their address space through the out-of-line call (a generic pointer would turn every
+// access into a flat_load / flat_store)
+#define LT_LDS __attribute__((address_space(3)))
+typedef LT_LDS unsigned lds_u32;
+typedef LT_LDS const unsigned lds_cu32;
+typedef LT_LDS const uint16_t lds_cu16;
+typedef LT_LDS int lds_i32;
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // first/last argmax of conv[a:b), conv = np.convolve(ones(ww), src[0:ncnt)) ('full').  Only the entries a
 // level can reach are touched: the exclusive prefix of src[pl .. ph) is built 64 entries at a time (one
 // entry per lane, DPP scan) into q, conv[k] = q[hi] - q[lo], one wave-max, and the positions of the maxima
-// come from ballots.  q: scratch of >= ph - pl + 1 entries.  false <=> np.any false.
-template <class T>
-__device__ bool box_argmax_window(const T* src, int ncnt, int ww, int a, int b, unsigned* q, int& first, int& last) {
+// come from ballots.  q: scratch of >= ph - pl + 1 entries.  false <=> np.any false.  All arguments and
+// results are wave-uniform.
+template <class SRC>
+__device__ __forceinline__ bool box_argmax_window(SRC src, int ncnt, int ww, int a, int b, lds_u32* q, int& first, int& last) {
     const int pl = max(a - ww + 1, 0), ph = min(b, ncnt);
     if (ph <= pl) return false;                      // every window sum is empty -> np.any false
     const int lane = lane_id(), n = ph - pl;
@@ -504,35 +512,37 @@ __device__ bool box_argmax_window(const T* src, int ncnt, int ww, int a, int b, 
         run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     }
     if (lane == 0) q[n] = run;
-    if (run == 0) return false;                      // nothing in reach (uniform)
+    if (run == 0) return false;                      // nothing in reach
     wave_sync();
-    unsigned best = 0;
-    for (int base = a; base < b; base += 64) {
-        const int k = base + lane;
-        if (k < b) {
-            const int lo = max(k - ww + 1, 0), hi = min(k + 1, ncnt);
-            best = max(best, hi > lo ? q[hi - pl] - q[lo - pl] : 0u);
-        }
-    }
-    best = wave_max_u32_dpp(best);                   // > 0: some window contains a non-zero entry
-    int f = -1, l = -1;
-    for (int base = a; base < b; base += 64) {
-        const int k = base + lane;
-        unsigned v = 0;
-        if (k < b) {
-            const int lo = max(k - ww + 1, 0), hi = min(k + 1, ncnt);
-            v = hi > lo ? q[hi - pl] - q[lo - pl] : 0u;
-        }
-        const unsigned long long hit = __ballot(k < b && v == best);
-        if (hit) {
-            if (f < 0) f = base + (int)__builtin_ctzll(hit);
-            l = base + 63 - (int)__builtin_clzll(hit);
+    auto window = [&](int k) {
+        const int lo = max(k - ww + 1, 0), hi = min(k + 1, ncnt);
+        return (k < b && hi > lo) ? q[hi - pl] - q[lo - pl] : 0u;
+    };
+    int f, l;
+    if (b - a <= 64) {                               // the usual case: one candidate per lane
+        const unsigned v = window(a + lane);
+        const unsigned best = wave_max_u32_dpp(v);
+        const unsigned long long hit = __ballot(a + lane < b && v == best);
+        f = a + (int)__builtin_ctzll(hit);
+        l = a + 63 - (int)__builtin_clzll(hit);
+    } else {
+        unsigned best = 0;
+        for (int base = a; base < b; base += 64) best = max(best, window(base + lane));
+        best = wave_max_u32_dpp(best);
+        f = -1;
+        l = -1;
+        for (int base = a; base < b; base += 64) {
+            const unsigned long long hit = __ballot(base + lane < b && window(base + lane) == best);
+            if (hit) {
+                if (f < 0) f = base + (int)__builtin_ctzll(hit);
+                l = base + 63 - (int)__builtin_clzll(hit);
+            }
         }
     }
     wave_sync();                                     // q is rewritten by the next call
     first = f - a;
     last = l - a;
-    return best != 0;
+    return true;                                     // run > 0: some window in [a, b) holds a non-zero entry
 }
 
 // Phase B of k_sws_fit2: the serial part of sliding_window_search (lane_tracker.py:290-430), run by one
@@ -540,21 +550,28 @@ __device__ bool box_argmax_window(const T* src, int ncnt, int ww, int a, int b, 
 // kernel body, the build (hipcc, ROCm 7.2) returned 32 instead of 432 as the default centre of an undetected
 // left line -- caught by the golden tests, and correct again with a printf next to the assignment, i.e. a
 // code-generation problem, not a data race.  As a separate function it is correct and costs one call.
-__device__ __noinline__ void sws2_recurrence(const SearchGeom& g, int nlev, const unsigned* sum0, unsigned* prefix,
-                                             const uint16_t* lev, int* roi_ab, int* state, int32_t* cent) {
+// The per-side state lives in scalar registers (every value is wave-uniform; readfirstlane says so).
+__device__ __noinline__ void sws2_recurrence(SearchGeom g, int nlev, lds_cu32* sum0, lds_u32* prefix, lds_cu16* lev,
+                                             lds_i32* roi_ab, lds_i32* state, int32_t* cent) {
     const int lane = lane_id();
     const int W = g.w, ww = g.ww, wh = g.wh, hw = g.hw, H1 = g.img_height;
-
-    int c[2], ns[2] = {0, 0}, lo[2], hi[2], ndiff[2] = {0, 0}, last_diff[2] = {0, 0}, ncent[2] = {0, 0}, nroi[2] = {0, 0};
-    auto set_roi = [&](int s, int level, int center) {
-        const int ra = center - hw, rb = min(center + hw, W);
+    struct Side { int c, ns, lo, hi, ndiff, last_diff, ncent, nroi; };
+    Side sd[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
+    auto set_roi = [&](int s, Side& me, int level) {
+        const int ra = me.c - hw, rb = min(me.c + hw, W);
         if (lane == 0) {
             roi_ab[(s * nlev + level) * 2] = ra < 0 ? rb : ra;       // negative start: NumPy slice is empty
             roi_ab[(s * nlev + level) * 2 + 1] = rb;
         }
-        nroi[s]++;
+        me.nroi++;
     };
+    auto put_centroid = [&](int s, Side& me, int value) {
+        if (lane == 0 && me.ncent < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + me.ncent] = value;
+        me.ncent++;
+    };
+#pragma unroll
     for (int s = 0; s < 2; ++s) {                                    // level 0 (:290-332)
+        Side& me = sd[s];
         const int c0 = s == 0 ? g.ignore_sides : g.img_center;
         const int c1 = s == 0 ? g.img_center : W - g.ignore_sides;
         bool found = false;
@@ -562,104 +579,113 @@ __device__ __noinline__ void sws2_recurrence(const SearchGeom& g, int nlev, cons
         if (c1 > c0 && H1 > g.y_start)
             found = box_argmax_window(sum0 + c0, c1 - c0, ww, 0, (c1 - c0) + ww - 1, prefix, first, last);
         if (found) {
-            c[s] = ((first + last) >> 1) - hw + c0;                  // :296-297 / :316-317
-            if (H1 - wh >= 0) set_roi(s, 0, c[s]);
-            else nroi[s]++;
+            me.c = uniform(((first + last) >> 1) - hw + c0);         // :296-297 / :316-317
+            if (H1 - wh >= 0) set_roi(s, me, 0);
+            else me.nroi++;
         } else {
-            c[s] = s == 0 ? g.def_left : g.def_right;                // :308 / :328
+            me.c = s == 0 ? g.def_left : g.def_right;                // :308 / :328
         }
-        if (lane == 0) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = c[s];
-        ncent[s]++;
-        lo[s] = -g.search_range;
-        hi[s] = g.search_range;
+        put_centroid(s, me, me.c);
+        me.lo = -g.search_range;
+        me.hi = g.search_range;
     }
     const int conv_len = W + ww - 1;                                 // :351
     for (int level = 1; level < g.nlevels; ++level) {                // :346-430
-        const uint16_t* sums = lev + (size_t)(level - 1) * W;
+        lds_cu16* sums = lev + (size_t)(level - 1) * W;
+#pragma unroll
         for (int s = 0; s < 2; ++s) {                                // left first, then right (:354, :395)
-            if (ns[s] >= g.limit) continue;
-            const int lo_i = max(c[s] + lo[s] + hw, 0);              // :356
-            const int hi_i = min(c[s] + hi[s] + hw, W);              // :357
+            Side& me = sd[s];
+            const Side& other = sd[1 - s];
+            if (me.ns >= g.limit) continue;
+            const int lo_i = max(me.c + me.lo + hw, 0);              // :356
+            const int hi_i = min(me.c + me.hi + hw, W);              // :357
             const int a = min(lo_i, conv_len);                       // conv[lo_i:hi_i], Python slice rules
             const int b = hi_i < 0 ? max(conv_len + hi_i, 0) : min(hi_i, conv_len);
             int first = 0, last = 0;
             const bool found = b > a && box_argmax_window(sums, W, ww, a, b, prefix, first, last);   // :360
             if (found) {
-                const int newc = ((first + last + 1) >> 1) + lo_i - hw;   // ceil, :363-364
-                if (lane == 0 && ncent[s] < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = newc;
-                ncent[s]++;
-                last_diff[s] = newc - c[s];                          // :366
-                ndiff[s]++;
-                c[s] = newc;
-                ns[s] = 0;                                           // :368
-                set_roi(s, level, c[s]);
-                const int t = (int)(g.mu * (double)last_diff[s]);    // :380-381, truncation toward zero
-                lo[s] += t;
-                hi[s] += t;
+                const int newc = uniform(((first + last + 1) >> 1) + lo_i - hw);   // ceil, :363-364
+                put_centroid(s, me, newc);
+                me.last_diff = newc - me.c;                          // :366
+                me.ndiff++;
+                me.c = newc;
+                me.ns = 0;                                           // :368
+                set_roi(s, me, level);
+                const int t = uniform((int)(g.mu * (double)me.last_diff));   // :380-381, truncation toward zero
+                me.lo += t;
+                me.hi += t;
             } else {
-                const int o = 1 - s;
-                if (ndiff[o] > 0 && ns[o] == 0) c[s] += last_diff[o]; // :385-387 / :423-425
-                if (lane == 0 && ncent[s] < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + ncent[s]] = c[s];
-                ncent[s]++;
-                ns[s]++;                                             // :390
-                if (ns[s] >= g.limit) ncent[s] -= min(g.limit > 0 ? g.limit : ncent[s], ncent[s]);   // :391-392
+                if (other.ndiff > 0 && other.ns == 0) me.c += other.last_diff;   // :385-387 / :423-425
+                put_centroid(s, me, me.c);
+                me.ns++;                                             // :390
+                if (me.ns >= g.limit) me.ncent -= min(g.limit > 0 ? g.limit : me.ncent, me.ncent);   // :391-392
             }
         }
     }
     if (lane == 0) {
-        cent[0] = ncent[0];
-        cent[g.maxlev + 2] = ncent[1];
-        state[0] = nroi[0];
-        state[1] = nroi[1];
+        cent[0] = sd[0].ncent;
+        cent[g.maxlev + 2] = sd[1].ncent;
+        state[0] = sd[0].nroi;
+        state[1] = sd[1].nroi;
     }
 }
 
 struct Sws2Layout {       // byte offsets into dynamic LDS
-    int sum0, prefix, lev, roi, ttot, tbase, state, mom, total;
-    int nlev, nchunk, ntask;
+    int sum0, prefix, lev, roi, rowbits, state, mom, total;
+    int nlev;
 };
 __host__ __device__ inline Sws2Layout sws2_layout(const SearchGeom& g) {
     Sws2Layout L;
     L.nlev = g.nlevels > 1 ? g.nlevels : 1;
-    L.nchunk = (g.wh + 63) / 64;
-    L.ntask = L.nlev * 2 * L.nchunk;
     int o = 0;
     auto take = [&o](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };   // 16-byte aligned sections
     L.sum0 = take(g.w * 4);
     L.prefix = take((g.w + g.ww + 64) * 4);           // window sums of one level: up to w + ww - 1 entries
     L.lev = take((L.nlev - 1) * g.w * 2);
     L.roi = take(L.nlev * 2 * 2 * 4);                // (a, b) per (side, level)
-    L.ttot = take(L.ntask * 4);
-    L.tbase = take(L.ntask * 4);
+    L.rowbits = take(2 * L.nlev * g.wh * 8);         // one 64-bit column mask per window row
     L.state = take(8 * 4);                           // nroi[2], distinct[2], n_out[2]
     L.mom = take(16 * 8);
     L.total = o;
     return L;
 }
 
+// -DLT_SWS2_PROBE: wave 0 of frame 0 prints the 100 MHz ticks between the phases (measurement builds only)
+#ifdef LT_SWS2_PROBE
+#define SWS2_DECL long long sws2_t[7];
+#define SWS2_T(i) sws2_t[i] = wall_clock64();
+#define SWS2_REPORT                                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x == 0)                                                                     \
+        printf("sws2 ticks: A %lld  B %lld  C-load %lld  C-flags %lld  C-rows %lld  fit %lld\n", sws2_t[1] - sws2_t[0],     \
+               sws2_t[2] - sws2_t[1], sws2_t[3] - sws2_t[2], sws2_t[4] - sws2_t[3], sws2_t[5] - sws2_t[4], sws2_t[6] - sws2_t[5]);
+#else
+#define SWS2_DECL
+#define SWS2_T(i)
+#define SWS2_REPORT
+#endif
+
 template <int ND>   // dwords that cover one window row: 9 for widths <= 32, 17 for widths <= 64
 __global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
                                                 const uint32_t* __restrict__ band_sums, uint32_t* __restrict__ pix_all,
                                                 int32_t* __restrict__ cent_all, lt_lane_record* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    SWS2_DECL
     const Sws2Layout L = sws2_layout(g);
     unsigned* sum0 = reinterpret_cast<unsigned*>(smem + L.sum0);
     unsigned* prefix = reinterpret_cast<unsigned*>(smem + L.prefix);
     uint16_t* lev = reinterpret_cast<uint16_t*>(smem + L.lev);
     int* roi_ab = reinterpret_cast<int*>(smem + L.roi);            // [(s * nlev + level) * 2 + {0,1}]
-    unsigned* ttot = reinterpret_cast<unsigned*>(smem + L.ttot);
-    unsigned* tbase = reinterpret_cast<unsigned*>(smem + L.tbase);
     int* state = reinterpret_cast<int*>(smem + L.state);
     long long* s_mom = reinterpret_cast<long long*>(smem + L.mom);
 
     const int frame = blockIdx.x, lane = lane_id(), wv = wave_id();
     const uint8_t* mask = masks + (size_t)frame * mask_stride;
     const uint32_t* fsums = band_sums + (size_t)frame * g.nbands * g.w;   // [band][w], band 0 = start slice
-    uint32_t* pix = pix_all + (size_t)frame * 2 * g.maxpix;
     int32_t* cent = cent_all + (size_t)frame * 2 * (g.maxlev + 2);
     const int W = g.w, wh = g.wh, H1 = g.img_height, nlev = L.nlev;
     const int y0c = g.h / 2, x0c = g.w / 2;
 
+    SWS2_T(0)
     // ---- A: band sums -> LDS ---------------------------------------------------------------------
     {
         const int nq0 = W >> 2, nq = (nlev - 1) * nq0;                 // uint4 groups (W % 4 == 0)
@@ -676,114 +702,111 @@ __global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ mas
                     reinterpret_cast<uint2*>(lev)[base + u * NT] = make_uint2(v[u].x | (v[u].y << 16), v[u].z | (v[u].w << 16));
         }
         for (int i = threadIdx.x; i < nlev * 4; i += NT) roi_ab[i] = 0;  // a = b = 0: no window
+        for (int i = threadIdx.x; i < 2 * nlev * wh; i += NT) reinterpret_cast<unsigned long long*>(smem + L.rowbits)[i] = 0ull;
         if (threadIdx.x < 8) state[threadIdx.x] = 0;
         if (threadIdx.x < 16) s_mom[threadIdx.x] = 0;
     }
     __syncthreads();
 
+    SWS2_T(1)
     // ---- B: the recurrence over the levels, wave 0, LDS only (lane_tracker.py:290-430) -----------
-    if (wv == 0) sws2_recurrence(g, nlev, sum0, prefix, lev, roi_ab, state, cent);
+    if (wv == 0)
+        sws2_recurrence(g, nlev, (lds_cu32*)sum0, (lds_u32*)prefix, (lds_cu16*)lev, (lds_i32*)roi_ab, (lds_i32*)state, cent);
     __syncthreads();
 
+    SWS2_T(2)
     // ---- C: all windows in parallel -----------------------------------------------------------------
-    // task ti = (s * nlev + level) * nchunk + chunk; lane = row of the chunk; bits = non-zero columns of [a, b)
-    unsigned long long bits[SWS2_TPW];
-    unsigned loff[SWS2_TPW];
-    const int nchunk = L.nchunk;
+    // Window row r = (s * nlev + level) * wh + ry.
+    //  1. every row is read as NQ aligned 16-byte pieces; the pieces of all rows are dealt to the 256 threads
+    //     round-robin, so consecutive lanes read consecutive pieces (a row per lane would touch 64 cache
+    //     lines per load instruction) and LOADS_IN_FLIGHT of them are outstanding per thread;
+    //  2. the 16 non-zero flags of a piece are OR-ed into the row's 64-bit column mask in LDS;
+    //  3. the rows are dealt to the threads: count, moments in closed form, and the mask itself goes to global
+    //     memory -- the pixel lists of the reference (level-major, row-major, ascending x) are expanded from
+    //     the masks on demand (lt_download_pixels), so nothing is scattered from here.
+    constexpr int NQ = ND == 9 ? 3 : 5, LOADS_IN_FLIGHT = 16;
+    struct __attribute__((packed, aligned(4))) Piece { uint32_t w[4]; };
+    unsigned long long* rowbits = reinterpret_cast<unsigned long long*>(smem + L.rowbits);
+    uint32_t* hdr = pix_all + (size_t)frame * 2 * g.maxpix;
+    unsigned long long* gmask = reinterpret_cast<unsigned long long*>(hdr + sws2_mask_offset(nlev));
+    if (threadIdx.x == 0) { hdr[0] = (uint32_t)nlev; hdr[1] = (uint32_t)wh; hdr[2] = (uint32_t)H1; hdr[3] = 0u; }
+    for (int i = threadIdx.x; i < nlev * 4; i += NT) hdr[4 + i] = (uint32_t)roi_ab[i];
+    const int rows_total = 2 * nlev * wh, pieces = rows_total * NQ;
+    const unsigned inv_wh = (unsigned)((0x100000000ull + (unsigned)wh - 1) / (unsigned)wh);   // r / wh == umulhi(r, inv_wh)
+    SWS2_T(3)
+    for (int g0 = 0; g0 < pieces; g0 += NT * LOADS_IN_FLIGHT) {
+        Piece v[LOADS_IN_FLIGHT];
+        int prow[LOADS_IN_FLIGHT], psh[LOADS_IN_FLIGHT], pbw[LOADS_IN_FLIGHT];
 #pragma unroll
-    for (int i = 0; i < SWS2_TPW; ++i) {
-        bits[i] = 0;
-        loff[i] = 0;
-        const int ti = wv + 4 * i, tc = min(ti, L.ntask - 1);
-        const int sl = tc / nchunk, ch = tc - sl * nchunk, level = sl % nlev;
-        const int a = roi_ab[sl * 2], b = roi_ab[sl * 2 + 1];
-        const int ry = ch * 64 + lane;
-        // no branch and no predicated load in this loop (a predicated load would wait on its own): the rows
-        // of all tasks of this wave are in flight together; slots past the task list repeat the last task
-        const bool ok = ti < L.ntask && b > a && ry < wh;
-        const int y = min(max(H1 - (1 + level) * wh + ry, 0), g.h - 1);
-        const int xa = ok ? (a & ~3) : 0, nd = ok ? (b - xa + 3) >> 2 : 1;
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(mask + (size_t)y * W + xa);
-        uint32_t v[ND];
-#pragma unroll
-        for (int d = 0; d < ND; ++d) v[d] = p[min(d, nd - 1)];
-        unsigned long long m = 0;
-#pragma unroll
-        for (int d = 0; d < ND; ++d) {
-            const uint32_t nz = ((v[d] & 0xffu) ? 1u : 0u) | ((v[d] & 0xff00u) ? 2u : 0u) | ((v[d] & 0xff0000u) ? 4u : 0u) |
-                                ((v[d] & 0xff000000u) ? 8u : 0u);
-            const int sh = xa + 4 * d - a;                           // bit index of this dword's first column
-            const unsigned long long piece = sh >= 0 ? (unsigned long long)nz << (sh & 63) : (unsigned long long)nz >> ((-sh) & 63);
-            m |= d < nd ? piece : 0ull;
+        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {           // loads only: no branch, clamped addresses
+            const int gi = g0 + u * NT + (int)threadIdx.x, gc = min(gi, pieces - 1);
+            const int r = gc / NQ, q = gc - r * NQ;
+            const int sl = (int)__umulhi((unsigned)r, inv_wh), ry = r - sl * wh, level = sl >= nlev ? sl - nlev : sl;
+            const int a = roi_ab[sl * 2], b = roi_ab[sl * 2 + 1];
+            const int y = H1 - (1 + level) * wh + ry;
+            const int x = min(max((a & ~3) + 16 * q, 0), W - 16);
+            v[u] = *reinterpret_cast<const Piece*>(mask + (size_t)y * W + x);
+            prow[u] = r;
+            psh[u] = x - a;                                    // bit index of the piece's first column
+            pbw[u] = (gi < pieces && b > a) ? b - a : 0;       // 0: nothing to keep
         }
-        const int bw = b - a;
-        m &= bw < 64 ? (1ull << (bw & 63)) - 1ull : ~0ull;
-        m = ok ? m : 0ull;
-        bits[i] = m;
-    }
 #pragma unroll
-    for (int i = 0; i < SWS2_TPW; ++i) {
-        const int ti = wv + 4 * i;
-        if (ti >= L.ntask) continue;     // wave-uniform
-        const unsigned cnt = (unsigned)__popcll(bits[i]);
-        const unsigned incl = wave_inclusive_sum_dpp(cnt);
-        loff[i] = incl - cnt;
-        const unsigned long long rows = __ballot(cnt != 0);
-        if (lane == 63) ttot[ti] = incl;
-        if (lane == 0 && rows) atomicAdd(&state[2 + (ti / nchunk) / nlev], (int)__popcll(rows));   // distinct rows per side
-    }
-    __syncthreads();
-    // offsets between windows: per side, tasks in (level, chunk) order -- every wave computes what it needs
-    {
-        const int per_side = nlev * nchunk;
-        for (int s = 0; s < 2; ++s) {
-            unsigned run = 0;
-            for (int base = 0; base < per_side; base += 64) {
-                const int k = base + lane;
-                const unsigned v = k < per_side ? ttot[s * per_side + k] : 0u;
-                const unsigned incl = wave_inclusive_sum_dpp(v);
-                if (wv == 0 && k < per_side) tbase[s * per_side + k] = run + incl - v;
-                run += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {
+            uint32_t flags = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // high bit of every non-zero byte, then the four high bits gathered into a nibble
+                const uint32_t w4 = v[u].w[k];
+                const uint32_t hb = ((w4 | ((w4 & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
+                flags |= ((hb * 0x00204081u) >> 21 & 0xfu) << (4 * k);
             }
-            if (wv == 0 && lane == 0) state[4 + s] = (int)run;          // n_out[s]
+            const int sh = psh[u];
+            unsigned long long piece = sh >= 64 ? 0ull : sh >= 0 ? (unsigned long long)flags << sh : (unsigned long long)flags >> min(-sh, 63);
+            piece &= pbw[u] < 64 ? (1ull << (pbw[u] & 63)) - 1ull : ~0ull;
+            if (piece) atomicOr(&rowbits[prow[u]], piece);
         }
     }
     __syncthreads();
+    SWS2_T(4)
     Moments mom[2];
     mom[0].clear();
     mom[1].clear();
-#pragma unroll
-    for (int i = 0; i < SWS2_TPW; ++i) {
-        const int ti = wv + 4 * i;
-        if (ti >= L.ntask) continue;
-        unsigned long long m = bits[i];
-        if (!m) continue;
-        const int sl = ti / nchunk, ch = ti - sl * nchunk, level = sl % nlev, s = sl / nlev;
+    unsigned n_rows[2] = {0, 0}, n_pix[2] = {0, 0};
+    for (int r = threadIdx.x; r < rows_total; r += NT) {      // lane-per-row: counts and moments in closed form
+        const int sl = (int)__umulhi((unsigned)r, inv_wh), ry = r - sl * wh, s = sl >= nlev ? 1 : 0, level = sl - s * nlev;
+        const unsigned long long m = rowbits[r];
+        gmask[r] = m;
+        // y is fixed, so only the count and the sum of the columns are needed;
+        // sum of the set bit positions = sum_b 2^b popcount(m & {positions with bit b})
         const int a = roi_ab[sl * 2];
-        const int y = H1 - (1 + level) * wh + ch * 64 + lane;
-        uint32_t* out = pix + (size_t)s * g.maxpix;
-        int idx = (int)(tbase[ti] + loff[i]);
-        // moments of this row's pixels in closed form: y is fixed, so only the count and the sum of the
-        // columns are needed; sum of the set bit positions = sum_b 2^b popcount(m & {positions with bit b})
-        const long long cnt = __popcll(m);
-        const long long sj = __popcll(m & 0xaaaaaaaaaaaaaaaaull) + 2 * __popcll(m & 0xccccccccccccccccull) +
-                             4 * __popcll(m & 0xf0f0f0f0f0f0f0f0ull) + 8 * __popcll(m & 0xff00ff00ff00ff00ull) +
-                             16 * __popcll(m & 0xffff0000ffff0000ull) + 32 * __popcll(m & 0xffffffff00000000ull);
-        const long long dy = y - y0c, dy2 = dy * dy, sdx = sj + cnt * (a - x0c);
+        const int cnt = __popcll(m);
+        const int sj = __popcll(m & 0xaaaaaaaaaaaaaaaaull) + 2 * __popcll(m & 0xccccccccccccccccull) +
+                       4 * __popcll(m & 0xf0f0f0f0f0f0f0f0ull) + 8 * __popcll(m & 0xff00ff00ff00ff00ull) +
+                       16 * __popcll(m & 0xffff0000ffff0000ull) + 32 * __popcll(m & 0xffffffff00000000ull);
+        // |dy| <= 8192, cnt <= 64, |sdx| < 2^22: the 32-bit products below cannot overflow
+        const int dy = H1 - (1 + level) * wh + ry - y0c, dy2 = dy * dy, sdx = sj + cnt * (a - x0c), cdy2 = cnt * dy2;
         Moments& mm = s == 0 ? mom[0] : mom[1];
-        mm.m[0] += cnt; mm.m[1] += cnt * dy; mm.m[2] += cnt * dy2; mm.m[3] += cnt * dy2 * dy; mm.m[4] += cnt * dy2 * dy2;
-        mm.m[5] += sdx; mm.m[6] += sdx * dy; mm.m[7] += sdx * dy2;
-        while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            if (idx < g.maxpix) out[idx] = ((uint32_t)y << 16) | (uint32_t)(a + j);
-            ++idx;
+        mm.m[0] += cnt; mm.m[1] += cnt * dy; mm.m[2] += cdy2; mm.m[3] += (long long)cdy2 * dy; mm.m[4] += (long long)cdy2 * dy2;
+        mm.m[5] += sdx; mm.m[6] += (long long)sdx * dy; mm.m[7] += (long long)sdx * dy2;
+        n_pix[s] += (unsigned)cnt;
+        n_rows[s] += cnt != 0 ? 1u : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned rows = wave_inclusive_sum_dpp(n_rows[s]), pixels = wave_inclusive_sum_dpp(n_pix[s]);
+        if (lane == 63) {
+            if (rows) atomicAdd(&state[2 + s], (int)rows);     // distinct rows per side
+            if (pixels) atomicAdd(&state[4 + s], (int)pixels); // n_out per side
         }
     }
+    __syncthreads();
+    SWS2_T(5)
     const int n_left = state[4], n_right = state[5];
     const int distinct[2] = {state[2], state[3]};
     const bool detected = state[0] > 0 && state[1] > 0 && n_left > 0 && n_right > 0;   // :432-447
-    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, n_left, n_right, detected, 0, recs + frame);
+    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, n_left, n_right, detected, 0, recs + frame, 1);
+    SWS2_T(6)
+    SWS2_REPORT
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -939,11 +962,10 @@ void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Sea
     // k_sws_fit2: dword rows, window width <= 64 bits, level sums that fit u16, a bounded task list and
     // an LDS image of all band sums; anything else takes the level-by-level kernel
     static const bool v1 = [] { const char* e = std::getenv("LT_SWS_V1"); return e && e[0] == '1'; }();
-    static const bool dbg_skip = [] { const char* e = std::getenv("LT_DBG_SKIP_FIT"); return e && e[0] == '1'; }();
-    if (dbg_skip) return;
     const Sws2Layout L = sws2_layout(g);
-    const bool v2 = !v1 && vec4 && 2 * g.hw <= 64 && g.wh * 255 <= 65535 && (L.ntask + 3) / 4 <= SWS2_TPW &&
-                    L.total <= 150 * 1024 && g.img_height - g.wh >= 0 && g.nlevels * g.wh <= g.img_height;
+    const bool v2 = !v1 && vec4 && 2 * g.hw <= 64 && g.wh * 255 <= 65535 && g.h <= 8192 && g.w >= 16 &&
+                    L.total <= 150 * 1024 && g.img_height - g.wh >= 0 && g.nlevels * g.wh <= g.img_height &&
+                    sws2_block_words(L.nlev, g.wh) <= 2LL * g.maxpix;
     if (v2) {
         static int attr_bytes = 0;
         if (L.total > 48 * 1024 && L.total > attr_bytes) {

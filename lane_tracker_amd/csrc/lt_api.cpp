@@ -760,6 +760,39 @@ int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, 
     if (!c->d_pix) return fail(LT_ERR_STATE, "no search has run yet");
     lt_lane_record r;
     if ((rc = download(c, c->d_rec + slot, &r, sizeof r))) return rc;
+    if (r._pad == 1) {
+        // k_sws_fit2 leaves one column mask per window row (lt_internal.h: sws2_mask_offset); the lists
+        // self.left_y / left_x (level-major, row-major inside a window, ascending x) are expanded here
+        const uint32_t* block = c->d_pix + (size_t)slot * 2 * c->maxpix;
+        uint32_t hdr[4];
+        if ((rc = download(c, block, hdr, sizeof hdr))) return rc;
+        const int nlev = (int)hdr[0], wh = (int)hdr[1], H1 = (int)hdr[2];
+        const long long words = sws2_block_words(nlev, wh);
+        if (nlev < 1 || wh < 1 || words > 2LL * c->maxpix) return fail(LT_ERR_STATE, "corrupt lane-pixel block");
+        std::vector<uint32_t> blk((size_t)words);
+        if ((rc = download(c, block, blk.data(), (size_t)words * 4))) return rc;
+        const int32_t* roi = reinterpret_cast<const int32_t*>(blk.data() + 4);
+        const uint32_t* masks = blk.data() + sws2_mask_offset(nlev);
+        int n = 0;
+        for (int level = 0; level < nlev; ++level) {
+            const int sl = side * nlev + level, a = roi[sl * 2], b = roi[sl * 2 + 1];
+            if (b <= a) continue;
+            for (int ry = 0; ry < wh; ++ry) {
+                const size_t mi = ((size_t)sl * wh + ry) * 2;
+                unsigned long long m = (unsigned long long)masks[mi] | ((unsigned long long)masks[mi + 1] << 32);
+                const int y = H1 - (1 + level) * wh + ry;
+                while (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    if (n < cap && ys && xs) { ys[n] = y; xs[n] = a + j; }
+                    ++n;
+                }
+            }
+        }
+        *count = n;
+        if (n > 0 && cap > 0 && (!ys || !xs)) return fail(LT_ERR_INVALID, "null pixel buffers");
+        return LT_OK;
+    }
     int n = side == 0 ? r.n_left : r.n_right;
     if (n > c->maxpix) n = c->maxpix;
     *count = n;

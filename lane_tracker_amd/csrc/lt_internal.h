@@ -90,6 +90,11 @@ struct SearchGeom {
     double mu, bandwidth;
     int maxpix, maxlev;
 };
+// Per-frame block k_sws_fit2 leaves in the pixel buffer (u32 units): [0] nlev, [1] window height, [2] image
+// height minus ignore_bottom, [3] 0; [4 ...) the (a, b) column range per (side, level); then, 8-byte aligned,
+// one 64-bit column mask per (side, level, row): bit j = pixel (row, a + j) is set.
+__host__ __device__ inline int sws2_mask_offset(int nlev) { return (4 + 4 * nlev + 1) & ~1; }
+__host__ __device__ inline long long sws2_block_words(int nlev, int wh) { return sws2_mask_offset(nlev) + 4LL * nlev * wh; }
 void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* band_sums,
                     uint32_t* pix, int32_t* cent, lt_lane_record* rec, int n);
 void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
