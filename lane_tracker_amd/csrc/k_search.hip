@@ -8,6 +8,7 @@
 // per-lane 3x3 normal-equations solve on exact int64 moments taken about the image centre.
 // Lane pixels are emitted in the reference's order (level-major, then row-major inside a window;
 // row-major for the band search) as packed (y << 16) | x.
+#include <algorithm>
 #include <cstdlib>
 
 #include "lt_internal.h"
@@ -478,6 +479,10 @@ __global__ __launch_bounds__(NT) void k_sws_fit(const uint8_t* __restrict__ mask
 // Needs w % 4 == 0, window width <= 64, window height * 255 <= 65535; launch_sws_fit falls back to k_sws_fit
 // otherwise.
 
+// n / d for 0 <= n < 2^31 / d with a precomputed multiplier (exact: n * (magic * d - 2^32) < 2^32)
+__device__ __forceinline__ unsigned div_magic(int d) { return d > 1 ? (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d) : 0u; }
+__device__ __forceinline__ int div_by(int n, int d, unsigned magic) { return d > 1 ? (int)__umulhi((unsigned)n, magic) : n; }
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ mas
     if (threadIdx.x == 0) { hdr[0] = (uint32_t)nlev; hdr[1] = (uint32_t)wh; hdr[2] = (uint32_t)H1; hdr[3] = 0u; }
     for (int i = threadIdx.x; i < nlev * 4; i += NT) hdr[4 + i] = (uint32_t)roi_ab[i];
     const int rows_total = 2 * nlev * wh, pieces = rows_total * NQ;
-    const unsigned inv_wh = (unsigned)((0x100000000ull + (unsigned)wh - 1) / (unsigned)wh);   // r / wh == umulhi(r, inv_wh)
+    const unsigned inv_wh = div_magic(wh);
     SWS2_T(3)
     for (int g0 = 0; g0 < pieces; g0 += NT * LOADS_IN_FLIGHT) {
         Piece v[LOADS_IN_FLIGHT];
@@ -741,7 +746,7 @@ __global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ mas
         for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {           // loads only: no branch, clamped addresses
             const int gi = g0 + u * NT + (int)threadIdx.x, gc = min(gi, pieces - 1);
             const int r = gc / NQ, q = gc - r * NQ;
-            const int sl = (int)__umulhi((unsigned)r, inv_wh), ry = r - sl * wh, level = sl >= nlev ? sl - nlev : sl;
+            const int sl = div_by(r, wh, inv_wh), ry = r - sl * wh, level = sl >= nlev ? sl - nlev : sl;
             const int a = roi_ab[sl * 2], b = roi_ab[sl * 2 + 1];
             const int y = H1 - (1 + level) * wh + ry;
             const int x = min(max((a & ~3) + 16 * q, 0), W - 16);
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ mas
     mom[1].clear();
     unsigned n_rows[2] = {0, 0}, n_pix[2] = {0, 0};
     for (int r = threadIdx.x; r < rows_total; r += NT) {      // lane-per-row: counts and moments in closed form
-        const int sl = (int)__umulhi((unsigned)r, inv_wh), ry = r - sl * wh, s = sl >= nlev ? 1 : 0, level = sl - s * nlev;
+        const int sl = div_by(r, wh, inv_wh), ry = r - sl * wh, s = sl >= nlev ? 1 : 0, level = sl - s * nlev;
         const unsigned long long m = rowbits[r];
         gmask[r] = m;
         // y is fixed, so only the count and the sum of the columns are needed;
@@ -902,6 +907,117 @@ __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ mas
     reduce_and_fit(mom, distinct, s_mom, g.h, g.w, nl, nr, detected, 1, recs + frame);
 }
 
+// k_band_fit2: the band search with the same row-mask scheme as k_sws_fit2.  Every (side, row) has a column
+// interval [a, b) of at most 64 pixels; its non-zero pixels are one 64-bit mask, built from coalesced 16-byte
+// pieces dealt to the 256 threads; counts and moments follow from the masks in closed form; the masks (and the
+// a of every row) are what is stored -- lt_download_pixels expands them (row-major, ascending x).
+// Per-frame block in the pixel buffer (u32 units): [0] rows per side, [1] first row, [2] 0, [3] 0; then the
+// a of every (side, row) as int32; then, 8-byte aligned, one u64 mask per (side, row).
+__global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+                                                 const double* __restrict__ prev, uint32_t* __restrict__ pix_all,
+                                                 lt_lane_record* __restrict__ recs, int nq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int frame = blockIdx.x, lane = lane_id();
+    const int W = g.w, top = g.band_top, nrows = max(g.band_bottom - top, 0), rows_total = 2 * nrows;
+    unsigned long long* rowbits = reinterpret_cast<unsigned long long*>(smem);          // rows_total
+    int* row_a = reinterpret_cast<int*>(rowbits + rows_total);                          // rows_total
+    int* row_w = row_a + rows_total;                                                    // rows_total
+    int* state = row_w + rows_total;                                                    // distinct[2], n[2]
+    long long* s_mom = reinterpret_cast<long long*>(smem + band2_mom_offset(nrows));
+    const uint8_t* mask = masks + (size_t)frame * mask_stride;
+    uint32_t* hdr = pix_all + (size_t)frame * 2 * g.maxpix;
+    int32_t* g_a = reinterpret_cast<int32_t*>(hdr + 4);
+    unsigned long long* gmask = reinterpret_cast<unsigned long long*>(hdr + band2_mask_offset(nrows));
+    const double* pc = prev + (size_t)frame * 6;
+    const int y0c = g.h / 2, x0c = g.w / 2;
+    const double bw = g.bandwidth;
+    if (threadIdx.x == 0) { hdr[0] = (uint32_t)nrows; hdr[1] = (uint32_t)top; hdr[2] = 0u; hdr[3] = 0u; }
+    if (threadIdx.x < 4) state[threadIdx.x] = 0;
+    if (threadIdx.x < 16) s_mom[threadIdx.x] = 0;
+    // the band of a row is the reference's f64 expression ((a*y^2 + b*y) + c) -/+ bw, evaluated without FMA
+    // contraction (lane_tracker.py:474-489)
+    for (int r = threadIdx.x; r < rows_total; r += NT) {
+        const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
+        const double y2 = (double)((long long)y * y), yd = (double)y;
+        const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];
+        int a, b;
+        band_columns(t - bw, t + bw, W, a, b);
+        row_a[r] = a;
+        row_w[r] = max(b - a, 0);
+        g_a[r] = a;
+        rowbits[r] = 0ull;
+    }
+    __syncthreads();
+    constexpr int LOADS_IN_FLIGHT = 16;
+    struct __attribute__((packed, aligned(4))) Piece { uint32_t w[4]; };
+    const int pieces = rows_total * nq;
+    const unsigned inv_nq = div_magic(nq);
+    for (int g0 = 0; g0 < pieces; g0 += NT * LOADS_IN_FLIGHT) {
+        Piece v[LOADS_IN_FLIGHT];
+        int prow[LOADS_IN_FLIGHT], psh[LOADS_IN_FLIGHT], pbw[LOADS_IN_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {           // loads only: no branch, clamped addresses
+            const int gi = g0 + u * NT + (int)threadIdx.x, gc = min(gi, pieces - 1);
+            const int r = div_by(gc, nq, inv_nq), q = gc - r * nq;
+            const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
+            const int a = row_a[r];
+            const int x = min(max((a & ~3) + 16 * q, 0), W - 16);
+            v[u] = *reinterpret_cast<const Piece*>(mask + (size_t)y * W + x);
+            prow[u] = r;
+            psh[u] = x - a;
+            pbw[u] = gi < pieces ? row_w[r] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {
+            uint32_t flags = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t w4 = v[u].w[k];
+                const uint32_t hb = ((w4 | ((w4 & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
+                flags |= ((hb * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+            }
+            const int sh = psh[u];
+            unsigned long long piece = sh >= 64 ? 0ull : sh >= 0 ? (unsigned long long)flags << sh : (unsigned long long)flags >> min(-sh, 63);
+            piece &= pbw[u] < 64 ? (1ull << (pbw[u] & 63)) - 1ull : ~0ull;
+            if (piece) atomicOr(&rowbits[prow[u]], piece);
+        }
+    }
+    __syncthreads();
+    Moments mom[2];
+    mom[0].clear();
+    mom[1].clear();
+    unsigned n_rows[2] = {0, 0}, n_pix[2] = {0, 0};
+    for (int r = threadIdx.x; r < rows_total; r += NT) {
+        const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
+        const unsigned long long m = rowbits[r];
+        gmask[r] = m;
+        const int a = row_a[r];
+        const int cnt = __popcll(m);
+        const int sj = __popcll(m & 0xaaaaaaaaaaaaaaaaull) + 2 * __popcll(m & 0xccccccccccccccccull) +
+                       4 * __popcll(m & 0xf0f0f0f0f0f0f0f0ull) + 8 * __popcll(m & 0xff00ff00ff00ff00ull) +
+                       16 * __popcll(m & 0xffff0000ffff0000ull) + 32 * __popcll(m & 0xffffffff00000000ull);
+        const int dy = y - y0c, dy2 = dy * dy, sdx = sj + cnt * (a - x0c), cdy2 = cnt * dy2;   // 32-bit safe: h <= 8192
+        Moments& mm = s == 0 ? mom[0] : mom[1];
+        mm.m[0] += cnt; mm.m[1] += cnt * dy; mm.m[2] += cdy2; mm.m[3] += (long long)cdy2 * dy; mm.m[4] += (long long)cdy2 * dy2;
+        mm.m[5] += sdx; mm.m[6] += (long long)sdx * dy; mm.m[7] += (long long)sdx * dy2;
+        n_pix[s] += (unsigned)cnt;
+        n_rows[s] += cnt != 0 ? 1u : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const unsigned rows = wave_inclusive_sum_dpp(n_rows[s]), pixels = wave_inclusive_sum_dpp(n_pix[s]);
+        if (lane == 63) {
+            if (rows) atomicAdd(&state[s], (int)rows);
+            if (pixels) atomicAdd(&state[2 + s], (int)pixels);
+        }
+    }
+    __syncthreads();
+    const int distinct[2] = {state[0], state[1]};
+    const int nl = state[2], nr = state[3];
+    const bool detected = nl != 0 && nr != 0;                        // :491
+    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, nl, nr, detected, 1, recs + frame, 2);
+}
+
 // fit_poly() on an explicit pixel list: moments by all threads, one Cholesky solve
 __global__ __launch_bounds__(NT) void k_fit_list(const uint32_t* __restrict__ pix, int n, int h, int w,
                                                 double* __restrict__ out4) {
@@ -992,9 +1108,27 @@ void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Sea
 void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
                      uint32_t* pix, lt_lane_record* rec, int n) {
     if (n <= 0) return;
+    const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
+    static const bool v1 = [] { const char* e = std::getenv("LT_BAND_V1"); return e && e[0] == '1'; }();
+    // k_band_fit2: a band of at most 64 columns (2 * bandwidth + 2), dword rows, 32-bit row moments
+    const int nrows = std::max(g.band_bottom - g.band_top, 0);
+    const long long width = 2LL * (long long)g.bandwidth + 2;
+    const size_t lds2 = band2_mom_offset(nrows) + 16 * sizeof(long long);
+    if (!v1 && vec4 && width <= 64 && g.h <= 8192 && g.w >= 16 && lds2 <= 150 * 1024 &&
+        band2_block_words(nrows) <= 2LL * g.maxpix) {
+        static bool attr_set = false;
+        if (lds2 > 48 * 1024 && !attr_set)
+            attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_fit2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           150 * 1024) == hipSuccess;
+        if (lds2 <= 48 * 1024 || attr_set) {
+            const int nq = (int)((width + 3 + 15) / 16);           // 16-byte pieces that cover a row's band from (a & ~3)
+            hipLaunchKernelGGL(k_band_fit2, dim3(n), dim3(NT), lds2, s, masks, mask_stride, g, prev, pix, rec, nq);
+            return;
+        }
+    }
     const size_t words = (size_t)(4 * g.h + 2) + 4;  // + 4 words for the distinct-row reduction
     const size_t lds = ((words * 4 + 15) & ~(size_t)15) + 16 * sizeof(long long);
-    if ((g.w & 3) == 0 && (mask_stride & 3) == 0)
+    if (vec4)
         hipLaunchKernelGGL(k_band_fit<true>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);
     else
         hipLaunchKernelGGL(k_band_fit<false>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);

@@ -793,6 +793,32 @@ int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, 
         if (n > 0 && cap > 0 && (!ys || !xs)) return fail(LT_ERR_INVALID, "null pixel buffers");
         return LT_OK;
     }
+    if (r._pad == 2) {
+        // k_band_fit2: one column mask and one first column per (side, row); row-major, ascending x
+        const uint32_t* block = c->d_pix + (size_t)slot * 2 * c->maxpix;
+        uint32_t hdr[4];
+        if ((rc = download(c, block, hdr, sizeof hdr))) return rc;
+        const int nrows = (int)hdr[0], top = (int)hdr[1];
+        const long long words = band2_block_words(nrows);
+        if (nrows < 0 || words > 2LL * c->maxpix) return fail(LT_ERR_STATE, "corrupt lane-pixel block");
+        std::vector<uint32_t> blk((size_t)words);
+        if ((rc = download(c, block, blk.data(), (size_t)words * 4))) return rc;
+        const int32_t* row_a = reinterpret_cast<const int32_t*>(blk.data() + 4) + (size_t)side * nrows;
+        const uint32_t* masks = blk.data() + band2_mask_offset(nrows) + (size_t)side * nrows * 2;
+        int n = 0;
+        for (int ry = 0; ry < nrows; ++ry) {
+            unsigned long long m = (unsigned long long)masks[2 * ry] | ((unsigned long long)masks[2 * ry + 1] << 32);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                if (n < cap && ys && xs) { ys[n] = top + ry; xs[n] = row_a[ry] + j; }
+                ++n;
+            }
+        }
+        *count = n;
+        if (n > 0 && cap > 0 && (!ys || !xs)) return fail(LT_ERR_INVALID, "null pixel buffers");
+        return LT_OK;
+    }
     int n = side == 0 ? r.n_left : r.n_right;
     if (n > c->maxpix) n = c->maxpix;
     *count = n;

@@ -95,6 +95,11 @@ struct SearchGeom {
 // one 64-bit column mask per (side, level, row): bit j = pixel (row, a + j) is set.
 __host__ __device__ inline int sws2_mask_offset(int nlev) { return (4 + 4 * nlev + 1) & ~1; }
 __host__ __device__ inline long long sws2_block_words(int nlev, int wh) { return sws2_mask_offset(nlev) + 4LL * nlev * wh; }
+// k_band_fit2's per-frame block: [0] rows per side, [1] first row, [2..3] 0; int32 a per (side, row); then,
+// 8-byte aligned, one u64 column mask per (side, row).  LDS: masks, a, width per row, 4 counters, 16 moments.
+__host__ __device__ inline int band2_mask_offset(int nrows) { return (4 + 2 * nrows + 1) & ~1; }
+__host__ __device__ inline long long band2_block_words(int nrows) { return band2_mask_offset(nrows) + 4LL * nrows; }
+__host__ __device__ inline size_t band2_mom_offset(int nrows) { return ((size_t)2 * nrows * 16 + 16 + 15) & ~(size_t)15; }
 void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* band_sums,
                     uint32_t* pix, int32_t* cent, lt_lane_record* rec, int n);
 void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
