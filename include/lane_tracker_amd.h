@@ -70,7 +70,7 @@ typedef struct lt_lane_record {
     uint8_t detected;            /* self.detected_pixels (:438, :496) */
     uint8_t fit_flags;           /* bit0: left fit rank-deficient (<3 distinct y), bit1: right */
     uint8_t mode;                /* 0 sliding-window, 1 band */
-    uint8_t _pad;
+    uint8_t _pad;                /* reserved (the library records how the slot's lane pixels are stored) */
     int32_t frame;               /* caller-defined global frame index */
 } lt_lane_record;
 

@@ -829,7 +829,7 @@ __device__ __forceinline__ void band_columns(double lo, double hi, int W, int& a
 
 template <bool VEC4>
 __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
-                                                const double* __restrict__ prev, uint32_t* __restrict__ pix_all,
+                                                const double* __restrict__ prev, BandPrev bp, uint32_t* __restrict__ pix_all,
                                                 lt_lane_record* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* rowcnt = reinterpret_cast<unsigned*>(smem);        // 2 * h
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ mas
     const int frame = blockIdx.x, lane = lane_id(), wv = wave_id();
     const uint8_t* mask = masks + (size_t)frame * mask_stride;
     uint32_t* pix = pix_all + (size_t)frame * 2 * g.maxpix;
-    const double* pc = prev + (size_t)frame * 6;
+    const double* pc = bp.by_value ? bp.c : prev + (size_t)frame * 6;
     const int W = g.w, top = g.band_top, bottom = g.band_bottom, nrows = max(bottom - top, 0);
     const int y0c = g.h / 2, x0c = g.w / 2;
     const double bw = g.bandwidth;
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ mas
 // Per-frame block in the pixel buffer (u32 units): [0] rows per side, [1] first row, [2] 0, [3] 0; then the
 // a of every (side, row) as int32; then, 8-byte aligned, one u64 mask per (side, row).
 __global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
-                                                 const double* __restrict__ prev, uint32_t* __restrict__ pix_all,
+                                                 const double* __restrict__ prev, BandPrev bp, uint32_t* __restrict__ pix_all,
                                                  lt_lane_record* __restrict__ recs, int nq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int frame = blockIdx.x, lane = lane_id();
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ ma
     uint32_t* hdr = pix_all + (size_t)frame * 2 * g.maxpix;
     int32_t* g_a = reinterpret_cast<int32_t*>(hdr + 4);
     unsigned long long* gmask = reinterpret_cast<unsigned long long*>(hdr + band2_mask_offset(nrows));
-    const double* pc = prev + (size_t)frame * 6;
+    const double* pc = bp.by_value ? bp.c : prev + (size_t)frame * 6;
     const int y0c = g.h / 2, x0c = g.w / 2;
     const double bw = g.bandwidth;
     if (threadIdx.x == 0) { hdr[0] = (uint32_t)nrows; hdr[1] = (uint32_t)top; hdr[2] = 0u; hdr[3] = 0u; }
@@ -1081,7 +1081,7 @@ void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Sea
     const Sws2Layout L = sws2_layout(g);
     const bool v2 = !v1 && vec4 && 2 * g.hw <= 64 && g.wh * 255 <= 65535 && g.h <= 8192 && g.w >= 16 &&
                     L.total <= 150 * 1024 && g.img_height - g.wh >= 0 && g.nlevels * g.wh <= g.img_height &&
-                    sws2_block_words(L.nlev, g.wh) <= 2LL * g.maxpix;
+                    sws2_block_words(L.nlev, g.wh) <= (long long)g.maxpix;   // inside the first of the slot's two rows
     if (v2) {
         static int attr_bytes = 0;
         if (L.total > 48 * 1024 && L.total > attr_bytes) {
@@ -1106,7 +1106,7 @@ void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Sea
 }
 
 void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
-                     uint32_t* pix, lt_lane_record* rec, int n) {
+                     const BandPrev& bp, uint32_t* pix, lt_lane_record* rec, int n) {
     if (n <= 0) return;
     const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
     static const bool v1 = [] { const char* e = std::getenv("LT_BAND_V1"); return e && e[0] == '1'; }();
@@ -1115,23 +1115,23 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Se
     const long long width = 2LL * (long long)g.bandwidth + 2;
     const size_t lds2 = band2_mom_offset(nrows) + 16 * sizeof(long long);
     if (!v1 && vec4 && width <= 64 && g.h <= 8192 && g.w >= 16 && lds2 <= 150 * 1024 &&
-        band2_block_words(nrows) <= 2LL * g.maxpix) {
+        band2_block_words(nrows) <= (long long)g.maxpix) {
         static bool attr_set = false;
         if (lds2 > 48 * 1024 && !attr_set)
             attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_fit2), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            150 * 1024) == hipSuccess;
         if (lds2 <= 48 * 1024 || attr_set) {
             const int nq = (int)((width + 3 + 15) / 16);           // 16-byte pieces that cover a row's band from (a & ~3)
-            hipLaunchKernelGGL(k_band_fit2, dim3(n), dim3(NT), lds2, s, masks, mask_stride, g, prev, pix, rec, nq);
+            hipLaunchKernelGGL(k_band_fit2, dim3(n), dim3(NT), lds2, s, masks, mask_stride, g, prev, bp, pix, rec, nq);
             return;
         }
     }
     const size_t words = (size_t)(4 * g.h + 2) + 4;  // + 4 words for the distinct-row reduction
     const size_t lds = ((words * 4 + 15) & ~(size_t)15) + 16 * sizeof(long long);
     if (vec4)
-        hipLaunchKernelGGL(k_band_fit<true>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);
+        hipLaunchKernelGGL(k_band_fit<true>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, bp, pix, rec);
     else
-        hipLaunchKernelGGL(k_band_fit<false>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, pix, rec);
+        hipLaunchKernelGGL(k_band_fit<false>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, bp, pix, rec);
 }
 
 }  // namespace lt

@@ -205,20 +205,35 @@ void free_slots(lt_ctx* c) {
     c->have_mask = false;
 }
 
+// Grow the per-slot result buffers.  Results of earlier searches stay readable (a tracker may fetch its lane
+// pixels lazily, after a later search with other parameters enlarged the buffers): the old rows -- one per
+// (slot, side) -- are copied to their new positions.
+template <class T>
+int grow_rows(lt_ctx* c, T** buf, size_t old_row, size_t new_row) {
+    T* fresh = nullptr;
+    int rc = dev_alloc(&fresh, (size_t)c->capacity * 2 * new_row);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(fresh, 0, (size_t)c->capacity * 2 * new_row * sizeof(T), c->stream));
+    if (*buf && old_row)
+        HIP_TRY(hipMemcpy2DAsync(fresh, new_row * sizeof(T), *buf, old_row * sizeof(T), old_row * sizeof(T),
+                                 (size_t)c->capacity * 2, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(*buf);
+    *buf = fresh;
+    return LT_OK;
+}
+
 int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev) {
     if (maxpix > c->maxpix) {
         { int rc = sync_all(c); if (rc) return rc; }
-        dev_free(c->d_pix);
-        int rc = dev_alloc(&c->d_pix, (size_t)c->capacity * 2 * maxpix);
+        int rc = grow_rows(c, &c->d_pix, (size_t)c->maxpix, (size_t)maxpix);
         if (rc) return rc;
         c->maxpix = maxpix;
     }
     if (maxlev > c->maxlev) {
         { int rc = sync_all(c); if (rc) return rc; }
-        dev_free(c->d_cent);
-        int rc = dev_alloc(&c->d_cent, (size_t)c->capacity * 2 * (maxlev + 2));
+        int rc = grow_rows(c, &c->d_cent, c->maxlev ? (size_t)c->maxlev + 2 : 0, (size_t)maxlev + 2);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_cent, 0, (size_t)c->capacity * 2 * (maxlev + 2) * sizeof(int32_t), c->stream));
         c->maxlev = maxlev;
     }
     return LT_OK;
@@ -955,12 +970,19 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
     if ((rc = ensure_search_buffers(c, g.maxpix, 1))) return rc;
     g.maxpix = c->maxpix;
     if (n == 0) return LT_OK;
-    if ((rc = sync_all(c))) return rc;
-    HIP_TRY(hipMemcpyAsync(c->d_prev + (size_t)first * 6, prev, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // prev is caller memory: do not keep reading it after return
+    BandPrev bp;
+    std::memset(&bp, 0, sizeof bp);
+    if (n == 1) {   // the stateful stream: one frame at a time, coefficients by value
+        std::memcpy(bp.c, prev, sizeof bp.c);
+        bp.by_value = 1;
+    } else {
+        if ((rc = sync_all(c))) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_prev + (size_t)first * 6, prev, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // prev is caller memory: do not keep reading it after return
+    }
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         StageScope t(c, ST_BAND_FIT, st);
-        launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, g, c->d_prev + (size_t)f0 * 6,
+        launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, g, c->d_prev + (size_t)f0 * 6, bp,
                         c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
         return (int)LT_OK;
     });

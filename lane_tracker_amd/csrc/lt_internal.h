@@ -102,8 +102,14 @@ __host__ __device__ inline long long band2_block_words(int nrows) { return band2
 __host__ __device__ inline size_t band2_mom_offset(int nrows) { return ((size_t)2 * nrows * 16 + 16 + 15) & ~(size_t)15; }
 void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* band_sums,
                     uint32_t* pix, int32_t* cent, lt_lane_record* rec, int n);
+// previous coefficients of a single frame travel as a kernel argument (no upload, no synchronisation);
+// batches read them from device memory
+struct BandPrev {
+    double c[6];
+    int by_value;
+};
 void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
-                     uint32_t* pix, lt_lane_record* rec, int n);
+                     const BandPrev& bp, uint32_t* pix, lt_lane_record* rec, int n);
 
 // fit of one explicit pixel list (packed (y<<16)|x); out: 3 doubles + 1 flag double (1.0 = rank deficient)
 void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, double* out4);

@@ -85,12 +85,10 @@ class LaneTracker:
         self.left_avg_x = np.array([])
         self.right_avg_y = np.array([])
         self.right_avg_x = np.array([])
-        self.left_y = None
-        self.left_x = None
-        self.right_y = None
-        self.right_x = None
-        self.left_window_centroids = None
-        self.right_window_centroids = None
+        # lane pixels and window centroids of the last search: public attributes like upstream's, fetched from
+        # the device on first read (properties below)
+        self._lp = dict(left_y=None, left_x=None, right_y=None, right_x=None, left_window_centroids=None,
+                        right_window_centroids=None)
         self.left_curve_radius = None
         self.right_curve_radius = None
         self.average_curve_radius = None
@@ -101,7 +99,8 @@ class LaneTracker:
 
         # device side
         self.device = device
-        self._ctx = _native.Context(img_size, warped_size, cam_matrix, dist_coeffs, self.M, device=device, capacity=1)
+        self._ctx = _native.Context(img_size, warped_size, cam_matrix, dist_coeffs, self.M, device=device, capacity=2)
+        self._slot = 0              # process() alternates between two slots (see process())
         self._aux_ctx = {}          # contexts for images that are not the calibration's BEV size
         self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search
         self._pending = None        # (ctx, slot, want_centroids): pixel lists not downloaded yet
@@ -111,6 +110,25 @@ class LaneTracker:
     # ------------------------------------------------------------------------------------------
     def get_success_ratio(self):
         return self.success / self.counter, self.success, self.counter
+
+
+    def _lane_pixel_property(name):
+        def get(self):
+            self._materialise_pending()
+            return self._lp[name]
+
+        def put(self, value):
+            self._materialise_pending()
+            self._lp[name] = value
+        return property(get, put, doc="lane pixels / window centroids of the last search (reference :434-440, :492-495)")
+
+    left_y = _lane_pixel_property("left_y")
+    left_x = _lane_pixel_property("left_x")
+    right_y = _lane_pixel_property("right_y")
+    right_x = _lane_pixel_property("right_x")
+    left_window_centroids = _lane_pixel_property("left_window_centroids")
+    right_window_centroids = _lane_pixel_property("right_window_centroids")
+    del _lane_pixel_property
 
     def close(self):
         self._ctx.close()
@@ -147,17 +165,17 @@ class LaneTracker:
             return
         self._fetch_pixels(ctx, slot, want_centroids)
         if flags & 1:
-            lf = _minimum_norm_parabola(self.left_y, self.left_x)
+            lf = _minimum_norm_parabola(self._lp['left_y'], self._lp['left_x'])
         if flags & 2:
-            rf = _minimum_norm_parabola(self.right_y, self.right_x)
-        self._fit = (self.left_y, self.right_y, lf, rf)
+            rf = _minimum_norm_parabola(self._lp['right_y'], self._lp['right_x'])
+        self._fit = (self._lp['left_y'], self._lp['right_y'], lf, rf)
 
     def _fetch_pixels(self, ctx, slot, want_centroids):
-        self.left_y, self.left_x = ctx.download_pixels(slot, 0)
-        self.right_y, self.right_x = ctx.download_pixels(slot, 1)
+        self._lp['left_y'], self._lp['left_x'] = ctx.download_pixels(slot, 0)
+        self._lp['right_y'], self._lp['right_x'] = ctx.download_pixels(slot, 1)
         if want_centroids:
-            self.left_window_centroids = ctx.download_centroids(slot, 0)
-            self.right_window_centroids = ctx.download_centroids(slot, 1)
+            self._lp['left_window_centroids'] = ctx.download_centroids(slot, 0)
+            self._lp['right_window_centroids'] = ctx.download_centroids(slot, 1)
 
     def _materialise_pending(self):
         """Download the lane pixels of the most recent lazily collected search (stream pipeline)."""
@@ -165,8 +183,8 @@ class LaneTracker:
             ctx, slot, want_centroids = self._pending
             self._pending = None
             self._fetch_pixels(ctx, slot, want_centroids)
-            if self._fit is not None and self._fit[0] == "pending":
-                self._fit = (self.left_y, self.right_y, self._fit[2], self._fit[3])
+            if self._fit is not None and isinstance(self._fit[0], str):
+                self._fit = (self._lp['left_y'], self._lp['right_y'], self._fit[2], self._fit[3])
 
     # ---- filter_lane_points (reference :183-240) ------------------------------------------------
     def filter_lane_points(self, img, filter_type='bilateral', ksize_r=25, C_r=8, ksize_b=35, C_b=5,
@@ -221,11 +239,11 @@ class LaneTracker:
         """Second-degree least-squares fits x(y) of the current left/right lane pixels.  The fit is
         produced by the search kernel (exact int64 moments, 3x3 normal equations in f64)."""
         if self._fit is not None and (self._fit[0] == "pending" if isinstance(self._fit[0], str)
-                                      else (self._fit[0] is self.left_y and self._fit[1] is self.right_y)):
+                                      else (self._fit[0] is self._lp['left_y'] and self._fit[1] is self._lp['right_y'])):
             return self._fit[2].copy(), self._fit[3].copy()
         # pixel arrays were replaced by the caller: fit them on the device from the lists
-        lf = self._ctx.fit_poly2(self.left_y, self.left_x)
-        rf = self._ctx.fit_poly2(self.right_y, self.right_x)
+        lf = self._ctx.fit_poly2(self._lp['left_y'], self._lp['left_x'])
+        rf = self._ctx.fit_poly2(self._lp['right_y'], self._lp['right_x'])
         return lf, rf
 
     # ---- host geometry (reference :511-528, 561-627) ---------------------------------------------------
@@ -421,7 +439,11 @@ class LaneTracker:
         first_try = (ksize_r, C_r, ksize_b, C_b, filter_type, mask_noise, noise_thresh, ksize_noise, C_noise,
                      window_width, window_height, search_range, mu, no_success_limit, start_slice, ignore_sides,
                      ignore_bottom, bandwidth, partial)
-        return self._step(img, first_try, n_tries, diagnostics, slot=0, have_mask=False, lazy=False, annotate=True,
+        # The lane-pixel lists stay on the device until somebody reads lt.left_x & co.  Frames alternate between
+        # two slots, so that the lists of the previous search are still there when this frame's searches find
+        # nothing (upstream keeps the old lists in that case).
+        self._slot ^= 1
+        return self._step(img, first_try, n_tries, diagnostics, slot=self._slot, have_mask=False, lazy=True, annotate=True,
                           visualize_search=visualize_search, split_view=split_view)
 
     def process_batch(self, frames, annotate=True, **kwargs):
@@ -457,6 +479,7 @@ class LaneTracker:
                      k["no_success_limit"], k["start_slice"], k["ignore_sides"], k["ignore_bottom"], k["bandwidth"],
                      k["partial"])
         ctx = self._ctx
+        self._materialise_pending()      # growing the context below drops what is still on the device
         ctx.reserve(max(n, 1))
         ctx.upload_frames(frames)
         ctx.mask_run(n, _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],

@@ -94,7 +94,7 @@ def test_gpu_process_on_real_frames(oracle, ref_calib, name):
         assert bool(lt.detected_pixels) == bool(d["detected"]) and bool(lt.valid_lane_lines) == bool(d["valid"])
         assert lt.last_detection == int(d["last_detection"]) + 0 and lt.success == int(d["success"])
         assert (len(lt.left_x), len(lt.right_x)) == tuple(d["counts"][1])
-        assert np.array_equal(lt._ctx.download_masks(1)[0], fixture_mask(d, 1))
+        assert np.array_equal(lt._ctx.download_masks(1, first=lt._slot)[0], fixture_mask(d, 1))
     finally:
         lt.close()
     # the demo-1 parameter set (the video these frames come from) accepts them
@@ -104,7 +104,7 @@ def test_gpu_process_on_real_frames(oracle, ref_calib, name):
         lt.process(frame, **kw)
         assert lt.valid_lane_lines and lt.success == 1
         mask = oracle.mask_from_frame(ref_calib, frame, oracle.filter_params(mask_noise=True))
-        assert np.array_equal(lt._ctx.download_masks(1)[0], mask)
+        assert np.array_equal(lt._ctx.download_masks(1, first=lt._slot)[0], mask)
         r = oracle.sliding_window_search(mask, oracle.search_params(no_success_limit=50, bandwidth=30))
         assert coeff_close(lt.last_left_coeffs, oracle.polyfit2(r["left_y"], r["left_x"]))
         assert coeff_close(lt.last_right_coeffs, oracle.polyfit2(r["right_y"], r["right_x"]))
