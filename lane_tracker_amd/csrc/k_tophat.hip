@@ -500,9 +500,11 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     double best_cost = 1e300;
     for (int nb = 1; nb <= 64; ++nb) {
         const int rows = (h + nb - 1) / nb;
-        if (nb > 1 && rows < 2 * SE::R) break;
         const int real_nb = (h + rows - 1) / rows;
         const long long tasks = (long long)n * g.nstrips * real_nb;
+        // full grids: bands no shorter than 2R keep the halo overhead sane; a grid that cannot fill the chip
+        // anyway (a single frame) is latency-bound, so it may trade redundant halo rows for shorter walks
+        if (nb > 1 && rows < (tasks <= slots ? (SE::R + 1) / 2 : 2 * SE::R)) break;
         const double rounds = (double)((tasks + slots - 1) / slots);
         // small grids cannot fill the chip: prefer more, shorter tasks there
         const double cost = (tasks < slots ? (double)(rows + 2 * SE::R) : rounds * (rows + 2 * SE::R));
