@@ -179,6 +179,15 @@ int  lt_overlay_configure(lt_ctx* ctx, const double* Minv /* 9 */);
  * int32 pairs of all slots, concatenated.  A slot with no points yields a copy of its frame. */
 int  lt_overlay_run(lt_ctx* ctx, int first_slot, int n, const int32_t* left_n, const int32_t* right_n,
                     const int32_t* left_yx, const int32_t* right_yx, double alpha);
+/* Text on the annotated frames (putText in draw_lane / print_failure, :653-672).  OpenCV's Hershey glyphs are
+ * not reproduced: the caller supplies its own glyph atlas once -- n_glyphs alpha cells of glyph_w x glyph_h bytes
+ * for the characters first_char, first_char + 1, ..., and each character's advance width (<= glyph_w). */
+int  lt_overlay_set_font(lt_ctx* ctx, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs,
+                         int glyph_w, int glyph_h);
+/* Blend n_lines white text lines into the annotated frame of every slot in [first, first+n) (after lt_overlay_run).
+ * lines: n * n_lines * line_len bytes, zero-padded; line i of a slot starts at (x0, y0 + i * step). */
+int  lt_overlay_text(lt_ctx* ctx, int first_slot, int n, const char* lines, int n_lines, int line_len, int x0, int y0,
+                     int step);
 /* Host-only helper (no GPU needed): the (lo, hi) column interval per bird's-eye row that cv2.fillPoly
  * paints for that polygon; empty rows are (32767, -32768).  spans: warp_h * 2 int16. */
 int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,

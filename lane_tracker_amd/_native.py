@@ -80,6 +80,8 @@ _SIGNATURES = {
     "lt_copy_records_to_device": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_overlay_configure": (C.c_int, [_P, _P]),
     "lt_overlay_run": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double]),
+    "lt_overlay_set_font": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lt_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "lt_download_overlay": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_bev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -263,6 +265,27 @@ class Context:
         _check(self.lib.lt_overlay_run(self._h, first, n, ln.ctypes.data, rn.ctypes.data,
                                        lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None,
                                        float(alpha)))
+
+    def overlay_set_font(self, atlas, advance, first_char=32):
+        """atlas: (n_glyphs, glyph_h, glyph_w) u8 alpha cells; advance: (n_glyphs,) u8."""
+        atlas = np.ascontiguousarray(atlas, np.uint8)
+        advance = np.ascontiguousarray(advance, np.uint8)
+        _check(self.lib.lt_overlay_set_font(self._h, atlas.ctypes.data, advance.ctypes.data, int(first_char),
+                                            atlas.shape[0], atlas.shape[2], atlas.shape[1]))
+
+    def overlay_text(self, lines_per_slot, first=0, origin=(20, 8), step=35, line_len=40):
+        """lines_per_slot: one list of strings per slot (ASCII)."""
+        n = len(lines_per_slot)
+        nl = max((len(l) for l in lines_per_slot), default=0)
+        if n == 0 or nl == 0:
+            return
+        buf = np.zeros((n, nl, line_len), np.uint8)
+        for i, lines in enumerate(lines_per_slot):
+            for j, text in enumerate(lines):
+                b = text.encode("ascii", "replace")[:line_len]
+                buf[i, j, :len(b)] = np.frombuffer(b, np.uint8)
+        _check(self.lib.lt_overlay_text(self._h, first, n, buf.ctypes.data, nl, line_len, int(origin[0]), int(origin[1]),
+                                        int(step)))
 
     def download_overlay(self, n, first=0):
         out = np.empty((n, self.img_h, self.img_w, 3), np.uint8)

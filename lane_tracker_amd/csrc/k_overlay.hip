@@ -113,7 +113,43 @@ __global__ __launch_bounds__(256) void k_warp_rgb(const uint32_t* __restrict__ u
     }
 }
 
+// Text lines blended in white onto the annotated frames from a glyph atlas (one alpha cell of gw x gh bytes
+// per character; the cell of character ch is used up to its advance width).  One thread per cell pixel of
+// every character of every line: lines[(slot * nl + line) * len + k] is the character, xpos[...] its left edge.
+__global__ __launch_bounds__(256) void k_overlay_text(uint8_t* __restrict__ out, size_t frame_stride, int img_h, int img_w,
+                                                     const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ advance,
+                                                     int first_char, int n_glyphs, int gw, int gh,
+                                                     const uint8_t* __restrict__ lines, const int16_t* __restrict__ xpos,
+                                                     int nl, int len, int y0, int step) {
+    const int cell = gw * gh, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= len * cell) return;
+    const int k = t / cell, rem = t - k * cell, gy = rem / gw, gx = rem - gy * gw;
+    const int line = blockIdx.y, slot = blockIdx.z;
+    const size_t li = ((size_t)slot * nl + line) * len + k;
+    const int ch = (int)lines[li] - first_char;
+    if (ch < 0 || ch >= n_glyphs || gx >= advance[ch]) return;
+    const int alpha = atlas[((size_t)ch * gh + gy) * gw + gx];
+    if (alpha == 0) return;
+    const int x = xpos[li] + gx, y = y0 + line * step + gy;
+    if (x < 0 || x >= img_w || y < 0 || y >= img_h) return;
+    uint8_t* px = out + (size_t)slot * frame_stride + ((size_t)y * img_w + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int v = px[c];
+        px[c] = (uint8_t)(v + ((255 - v) * alpha + 127) / 255);      // white over the frame
+    }
+}
+
 }  // namespace
+
+void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
+                         const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
+                         const int16_t* xpos, int nl, int len, int y0, int step, int n) {
+    if (n <= 0 || nl <= 0 || len <= 0) return;
+    dim3 grid((unsigned)((len * gw * gh + 255) / 256), (unsigned)nl, (unsigned)n);
+    hipLaunchKernelGGL(k_overlay_text, grid, dim3(256), 0, s, out, frame_stride, img_h, img_w, atlas, advance, first_char,
+                       n_glyphs, gw, gh, lines, xpos, nl, len, y0, step);
+}
 
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
                          const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,

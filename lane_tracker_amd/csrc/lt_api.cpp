@@ -83,6 +83,13 @@ struct lt_ctx {
     int16_t* d_spans = nullptr;       // [slot][warp_h] (lo, hi)
     uint8_t* d_annot = nullptr;
     std::vector<int16_t> h_spans;
+    // text: glyph atlas (set once) and the per-slot lines of the current call
+    uint8_t *d_atlas = nullptr, *d_advance = nullptr, *d_lines = nullptr;
+    int16_t* d_xpos = nullptr;
+    std::vector<uint8_t> h_advance;
+    std::vector<int16_t> h_xpos;
+    int font_first = 0, font_glyphs = 0, font_gw = 0, font_gh = 0;
+    size_t text_cap = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stage_timing = false;
@@ -468,6 +475,10 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_coef);
     dev_free(c->d_oxy);
     dev_free(c->d_ofrac);
+    dev_free(c->d_atlas);
+    dev_free(c->d_advance);
+    dev_free(c->d_lines);
+    dev_free(c->d_xpos);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -733,6 +744,70 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     launch_overlay_lane(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+int lt_overlay_set_font(lt_ctx* c, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
+                        int glyph_h) {
+    if (!c || !atlas || !advance) return fail(LT_ERR_INVALID, "null argument");
+    if (n_glyphs < 1 || n_glyphs > 256 || glyph_w < 1 || glyph_w > 255 || glyph_h < 1 || glyph_h > 255 || first_char < 0)
+        return fail(LT_ERR_INVALID, "bad font geometry");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
+    dev_free(c->d_atlas);
+    dev_free(c->d_advance);
+    c->font_glyphs = 0;
+    const size_t bytes = (size_t)n_glyphs * glyph_w * glyph_h;
+    if ((rc = dev_alloc(&c->d_atlas, bytes))) return rc;
+    if ((rc = dev_alloc(&c->d_advance, (size_t)n_glyphs))) return rc;
+    HIP_TRY(hipMemcpy(c->d_atlas, atlas, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_advance, advance, (size_t)n_glyphs, hipMemcpyHostToDevice));
+    c->h_advance.assign(advance, advance + n_glyphs);
+    c->font_first = first_char;
+    c->font_glyphs = n_glyphs;
+    c->font_gw = glyph_w;
+    c->font_gh = glyph_h;
+    return LT_OK;
+}
+
+int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines, int line_len, int x0, int y0, int step) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!c->font_glyphs) return fail(LT_ERR_STATE, "lt_overlay_text before lt_overlay_set_font");
+    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_overlay_text before lt_overlay_run");
+    if (n == 0 || n_lines <= 0 || line_len <= 0) return LT_OK;
+    if (!lines) return fail(LT_ERR_INVALID, "null text");
+    if ((rc = set_device(c))) return rc;
+    const size_t count = (size_t)n * n_lines * line_len;
+    if ((rc = sync_all(c))) return rc;     // the previous call's staging buffers are free again
+    if (count > c->text_cap) {
+        dev_free(c->d_lines);
+        dev_free(c->d_xpos);
+        c->text_cap = 0;
+        if ((rc = dev_alloc(&c->d_lines, count))) return rc;
+        if ((rc = dev_alloc(&c->d_xpos, count))) return rc;
+        c->text_cap = count;
+    }
+    c->h_xpos.resize(count);
+    for (size_t l = 0; l < (size_t)n * n_lines; ++l) {     // left edge of every character: running sum of advances
+        int x = x0;
+        bool ended = false;
+        for (int k = 0; k < line_len; ++k) {
+            const unsigned char ch = (unsigned char)lines[l * line_len + k];
+            ended = ended || ch == 0;
+            c->h_xpos[l * line_len + k] = (int16_t)std::min(x, 32767);
+            const int g = (int)ch - c->font_first;
+            if (!ended && g >= 0 && g < c->font_glyphs) x += c->h_advance[(size_t)g];
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_lines, lines, count, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_xpos, c->h_xpos.data(), count * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));              // `lines` is caller memory
+    launch_overlay_text(c->stream, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
+                        c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, c->d_lines, c->d_xpos,
+                        n_lines, line_len, y0, step, n);
     HIP_TRY(hipGetLastError());
     return LT_OK;
 }

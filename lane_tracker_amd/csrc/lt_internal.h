@@ -47,6 +47,9 @@ void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_st
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
                          const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
                          int bh, int bw, float alpha, int n);
+void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
+                         const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
+                         const int16_t* xpos, int nl, int len, int y0, int step, int n);
 void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy, const uint16_t* wfrac,
                      FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n);
 

@@ -105,6 +105,7 @@ class LaneTracker:
         self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search
         self._pending = None        # (ctx, slot, want_centroids): pixel lists not downloaded yet
         self._overlay_ready = False
+        self._have_font = False
         self._resident = None       # (frame array, slot) of the camera frame last uploaded to the main context
 
     # ------------------------------------------------------------------------------------------
@@ -333,11 +334,27 @@ class LaneTracker:
             lines.append("Frame: {}".format(self.counter - 1))
         return lines
 
-    def _overlay_slot(self, img):
-        """Slot of the main context that holds `img` (uploading it if it is not the resident frame)."""
+    def _configure_overlay(self):
         if not self._overlay_ready:
             self._ctx.overlay_configure(self.Minv)
+            font = _overlay.font_atlas()
+            self._have_font = font is not None
+            if font is not None:
+                self._ctx.overlay_set_font(font[0], font[1], font[2])
             self._overlay_ready = True
+
+    def _annotate(self, polygons, texts, first=0):
+        """Lane polygons (an empty one = plain copy) and text lines for the frames resident in slots
+        first .. first + n - 1 -> the annotated frames (n, H, W, 3)."""
+        ctx = self._ctx
+        ctx.overlay_run(polygons, first=first)
+        if self._have_font:
+            ctx.overlay_text(texts, first=first)
+        return ctx.download_overlay(len(polygons), first=first)
+
+    def _overlay_slot(self, img):
+        """Slot of the main context that holds `img` (uploading it if it is not the resident frame)."""
+        self._configure_overlay()
         if self._resident is not None and self._resident[0] is img:
             return self._resident[1]
         self._ctx.upload_frames(img, first=0)
@@ -346,14 +363,17 @@ class LaneTracker:
 
     def draw_lane(self, img):
         """Highlight the lane between the averaged curves and print radius / eccentricity.  The polygon
-        fill, its inverse warp with `Minv` and the 0.3 blend run on the GPU (lt_overlay_run); unlike
+        fill, its inverse warp with `Minv`, the 0.3 blend and the text run on the GPU (lt_overlay_run / lt_overlay_text); unlike
         upstream the caller's array is not written to."""
         slot = self._overlay_slot(img)
-        self._ctx.overlay_run([(self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x)], first=slot)
-        return _overlay.put_lines(self._ctx.download_overlay(1, first=slot)[0], self._lane_text())
+        return self._annotate([(self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x)], [self._lane_text()],
+                              first=slot)[0]
 
     def print_failure(self, img):
-        return _overlay.put_lines(np.array(img, copy=True), self._failure_text())
+        """The failure message on a copy of the frame (upstream writes into the caller's array, :664-673)."""
+        slot = self._overlay_slot(img)
+        empty = np.zeros(0, np.int64)
+        return self._annotate([(empty, empty, empty, empty)], [self._failure_text()], first=slot)[0]
 
     def window_mask(self, img, window_width, window_height, center, level, ignore_bottom):
         return _overlay.window_mask(img, window_width, window_height, center, level, ignore_bottom)
@@ -492,13 +512,11 @@ class LaneTracker:
         if not annotate:
             return [None] * n
         # one overlay launch and one download for the whole window; a failed frame has no polygon (plain copy)
-        if not self._overlay_ready:
-            ctx.overlay_configure(self.Minv)
-            self._overlay_ready = True
+        self._configure_overlay()
         empty = np.zeros(0, np.int64)
-        ctx.overlay_run([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in deferred])
-        annotated = ctx.download_overlay(n)
-        return [_overlay.put_lines(annotated[i], deferred[i][2]) for i in range(n)]
+        annotated = self._annotate([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in deferred],
+                                   [d[2] for d in deferred])
+        return list(annotated)
 
     def _step(self, img, first_try, n_tries, diagnostics, slot, have_mask, lazy, annotate, visualize_search=False,
               split_view=False, defer=None):

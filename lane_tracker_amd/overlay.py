@@ -84,34 +84,34 @@ def visualize_band_search(binary_img, left_yx, right_yx, band_points, fit_points
     return out
 
 
-_FONT = None
+_ATLAS = None
 
 
-def _font():
-    global _FONT
-    if _FONT is None:
-        from PIL import ImageFont
+def font_atlas(size=28, first_char=32, last_char=126):
+    """Glyph atlas for the text lines of draw_lane / print_failure (lt_overlay_set_font): alpha cells of the
+    printable ASCII characters rendered once with Pillow's default font, and each character's advance.
+    Returns (atlas (n, gh, gw) u8, advance (n,) u8, first_char), or None when Pillow is not installed.
+    OpenCV's anti-aliased Hershey glyphs cannot be reproduced without OpenCV; this is the build's own font."""
+    global _ATLAS
+    if _ATLAS is None:
         try:
-            _FONT = ImageFont.load_default(size=28)
+            from PIL import Image, ImageDraw, ImageFont
         except Exception:
-            _FONT = ImageFont.load_default()
-    return _FONT
-
-
-def put_lines(img, lines, origin=(20, 8), step=35):
-    """White text lines at the reference's positions ((20,35), (20,70), ... baselines).  Only the text
-    strip goes through Pillow."""
-    try:
-        from PIL import Image, ImageDraw
-    except Exception:
-        return img
-    img = np.ascontiguousarray(img)
-    strip_h = min(img.shape[0], origin[1] + len(lines) * step + 8)
-    pil = Image.fromarray(img[:strip_h])
-    d = ImageDraw.Draw(pil)
-    for i, text in enumerate(lines):
-        d.text((origin[0], origin[1] + i * step), text, fill=(255, 255, 255), font=_font())
-    if not img.flags.writeable:
-        img = img.copy()
-    img[:strip_h] = np.asarray(pil)
-    return img
+            _ATLAS = False
+            return None
+        try:
+            font = ImageFont.load_default(size=size)
+        except Exception:
+            font = ImageFont.load_default()
+        chars = [chr(c) for c in range(first_char, last_char + 1)]
+        ascent, descent = font.getmetrics() if hasattr(font, "getmetrics") else (size, size // 4)
+        gh = int(ascent + descent)
+        adv = [max(1, int(np.ceil(font.getlength(ch)))) if hasattr(font, "getlength") else size // 2 for ch in chars]
+        gw = int(max(adv)) + 2
+        atlas = np.zeros((len(chars), gh, gw), np.uint8)
+        for i, ch in enumerate(chars):
+            cell = Image.new("L", (gw, gh), 0)
+            ImageDraw.Draw(cell).text((0, 0), ch, fill=255, font=font)
+            atlas[i] = np.asarray(cell)
+        _ATLAS = (atlas, np.minimum(np.asarray(adv), gw).astype(np.uint8), first_char)
+    return _ATLAS or None

@@ -220,3 +220,41 @@ def test_process_batch_annotations_equal_process(cal):
     finally:
         a.close()
         b.close()
+
+
+def test_overlay_text_matches_the_atlas_blend(nat, cal):
+    """lt_overlay_text: every glyph cell of the build's atlas blended in white at its advance position."""
+    from lane_tracker_amd import overlay, synth
+    font = overlay.font_atlas()
+    if font is None:
+        pytest.skip("Pillow is not installed: no glyph atlas")
+    atlas, adv, first_char = font
+    frames = np.stack([synth.frame_uniform(3), np.zeros((720, 1280, 3), np.uint8)], 0)
+    texts = [["Curve Radius: 1234 m", "Eccentricity: -0.25 m", "Frame: 17"], ["Lane Line Detection Failed"]]
+    e = np.zeros(0, np.int64)
+    c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                    device=0, capacity=2)
+    try:
+        c.overlay_configure(cal["warp_matrices"][1])
+        c.upload_frames(frames)
+        with pytest.raises(nat.NativeError):
+            c.overlay_text(texts)                              # no font yet
+        c.overlay_set_font(atlas, adv, first_char)
+        c.overlay_run([(e, e, e, e)] * 2)
+        c.overlay_text(texts, origin=(20, 8), step=35)
+        out = c.download_overlay(2)
+        for k in range(2):
+            want = frames[k].astype(np.int32)
+            for j, line in enumerate(texts[k]):
+                x = 20
+                for ch in line:
+                    g = ord(ch) - first_char
+                    cell = atlas[g][:, :adv[g]].astype(np.int32)
+                    y = 8 + 35 * j
+                    reg = want[y:y + cell.shape[0], x:x + cell.shape[1]]
+                    reg += ((255 - reg) * cell[:, :, None] + 127) // 255
+                    x += int(adv[g])
+            assert_same(out[k], want.astype(np.uint8), f"text frame {k}")
+        assert (out[1] == 255).any()                           # fully opaque glyph cores on the black frame
+    finally:
+        c.close()
