@@ -86,6 +86,9 @@ def main():
     t0 = time.perf_counter()
     ctx.upload_frames(frames)
     h2d_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ctx.upload_frame_rows(frames)                 # what a host-fed pipeline moves: the rows the path reads
+    h2d_rows_s = time.perf_counter() - t0
     ctx.set_frame_base(B, rank * B)
     fp, sp = _native.filter_params(), _native.search_params()
 
@@ -183,7 +186,9 @@ def main():
             "search_fit": {"ms_per_step": round(search_ms, 4),
                            "achieved_GBs": round(info.alg_bytes_search * B / (search_ms * 1e-3) / 1e9, 3) if search_ms > 0 else None},
             "host_fed": {"h2d_seconds_for_batch": round(h2d_s, 4),
-                         "pcie_inclusive_frames_per_s": round(B / (h2d_s + dt / K), 2)},
+                         "pcie_inclusive_frames_per_s": round(B / (h2d_s + dt / K), 2),
+                         "h2d_seconds_source_rows_only": round(h2d_rows_s, 4), "source_rows": list(ctx.source_rows()),
+                         "pcie_inclusive_frames_per_s_source_rows_only": round(B / (h2d_rows_s + dt / K), 2)},
             "device": info.device_name.decode(errors="replace"),
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -115,6 +115,11 @@ int  lt_set_streams(lt_ctx* ctx, int nstreams);
 /* ---- frames in, results out ------------------------------------------------------------------ */
 /* frames: n * img_h * img_w * 3 bytes, RGB interleaved, as LaneTracker.process() receives them (:876) */
 int  lt_upload_frames(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
+/* Camera rows [row0, row1) that undistort + warp actually read (a third of a 720-row frame at the reference
+ * calibration).  lt_upload_frame_rows takes the same full-size host frames as lt_upload_frames but moves only
+ * those rows: enough for lt_mask_run and the searches, not for lt_overlay_run, which shows the whole frame. */
+int  lt_get_source_rows(lt_ctx* ctx, int* row0, int* row1);
+int  lt_upload_frame_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
 /* masks: n * warp_h * warp_w bytes; lets the search stages run on caller-supplied binary images */
 int  lt_upload_masks(lt_ctx* ctx, const uint8_t* masks, int first_slot, int n);
 int  lt_download_masks(lt_ctx* ctx, int first_slot, int n, uint8_t* masks);

@@ -70,6 +70,8 @@ _SIGNATURES = {
     "lt_sync": (C.c_int, [_P]),
     "lt_set_streams": (C.c_int, [_P, C.c_int]),
     "lt_upload_frames": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_get_source_rows": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lt_upload_frame_rows": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_masks": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_download_masks": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_plane": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
@@ -217,6 +219,17 @@ class Context:
         _check(self.lib.lt_set_streams(self._h, int(n)))
 
     # -- data movement
+    def source_rows(self):
+        """Camera rows [row0, row1) the path reads."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(self.lib.lt_get_source_rows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def upload_frame_rows(self, frames, first=0):
+        """Like upload_frames, but only the camera rows the path reads cross the bus (not enough for the overlay)."""
+        f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
+        _check(self.lib.lt_upload_frame_rows(self._h, f.ctypes.data, first, f.shape[0]))
+
     def upload_frames(self, frames, first=0):
         f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
         _check(self.lib.lt_upload_frames(self._h, f.ctypes.data, first, f.shape[0]))

@@ -54,6 +54,7 @@ struct lt_ctx {
     int nstreams = 1;
     hipDeviceProp_t prop{};
     FrontEndGeom fe{};
+    int cam_r0 = 0, cam_r1 = 0;               // camera rows the undistortion reads (its taps for rows [fe.r0, fe.r0 + nrows))
     EllipseSE se5{}, se29{}, se55{};
     // device tables
     int16_t *d_uxy = nullptr, *d_wxy = nullptr;
@@ -412,6 +413,17 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     warp_source_rows(*calib, warp, r0, r1);
     build_undistort_table(*calib, r0, r1, und);
     c->fe = FrontEndGeom{calib->img_h, calib->img_w, calib->warp_h, calib->warp_w, r0, r1 - r0};
+    {
+        int lo = calib->img_h, hi = 0;
+        for (size_t o = 0; o < (size_t)und.rows * und.cols; ++o) {   // (the vectors carry one padding entry)
+            const int sx = und.xy[o * 2], sy = und.xy[o * 2 + 1];
+            if (sy < -1 || sy >= calib->img_h || sx < -1 || sx >= calib->img_w) continue;   // every tap outside: reads as 0
+            lo = std::min(lo, std::max(sy, 0));
+            hi = std::max(hi, std::min(sy + 2, calib->img_h));
+        }
+        c->cam_r0 = hi > lo ? lo : 0;
+        c->cam_r1 = hi > lo ? hi : 0;
+    }
     uint16_t gamma_tab[256], cbrt_tab[3072];
     int32_t coef[9];
     build_lab_tables(gamma_tab, cbrt_tab, coef);
@@ -561,6 +573,27 @@ int lt_upload_frames(lt_ctx* c, const uint8_t* frames, int first, int n) {
     if ((rc = sync_all(c))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_frames + (size_t)first * c->frame_bytes, frames, (size_t)n * c->frame_bytes,
                            hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_get_source_rows(lt_ctx* c, int* row0, int* row1) {
+    if (!c || !row0 || !row1) return fail(LT_ERR_INVALID, "null argument");
+    *row0 = c->cam_r0;
+    *row1 = c->cam_r1;
+    return LT_OK;
+}
+
+int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!frames) return fail(LT_ERR_INVALID, "null frames");
+    if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = sync_all(c))) return rc;
+    const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
+    HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
+                             (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
 }

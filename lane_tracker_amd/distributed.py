@@ -80,7 +80,7 @@ def process_shard(ctx, frames, first_frame, fp=None, sp=None, batch=256):
     ctx.reserve(min(batch, max(n, 1)))
     for lo in range(0, n, batch):
         m = min(batch, n - lo)
-        ctx.upload_frames(frames[lo:lo + m])
+        ctx.upload_frame_rows(frames[lo:lo + m])      # only the camera rows the path reads cross the bus
         ctx.set_frame_base(m, first_frame + lo)
         ctx.mask_run(m, fp)
         ctx.sws_fit_run(m, sp)

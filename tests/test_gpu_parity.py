@@ -444,3 +444,26 @@ def test_full_size_morphology_properties(ctx):
         er, di = ctx.morph_ellipse(img, k, "erode"), ctx.morph_ellipse(img, k, "dilate")
         assert (er <= img).all() and (img <= di).all()
         assert np.array_equal(255 - ctx.morph_ellipse(255 - img, k, "dilate"), er)     # duality
+
+
+def test_source_row_upload_is_enough_for_the_path(nat, cal, frames):
+    """lt_upload_frame_rows moves only the camera rows undistort + warp read; masks and fits are unchanged."""
+    a = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                    device=0, capacity=len(frames))
+    b = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                    device=0, capacity=len(frames))
+    try:
+        r0, r1 = a.source_rows()
+        assert 0 <= r0 < r1 <= 720 and r1 - r0 < 400       # about a third of the frame (rows 450..689 here)
+        a.upload_frames(frames)
+        b.upload_frames(255 - frames)                     # stale content everywhere ...
+        b.upload_frame_rows(frames)                       # ... except the rows that matter
+        for c in (a, b):
+            c.mask_run(len(frames))
+            c.sws_fit_run(len(frames))
+        assert_same(b.download_masks(len(frames)), a.download_masks(len(frames)), "masks after a source-row upload")
+        ra, rb = a.download_records(len(frames)), b.download_records(len(frames))
+        assert ra.tobytes() == rb.tobytes()
+    finally:
+        a.close()
+        b.close()
