@@ -7,7 +7,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/$name.log 2>&1
+  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o $name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --streams 1 > $out/$name.log 2>&1
   echo "== $name rc=$?"
   python3 $GRAFT_REPO_ROOT/tools/pmc_summary.py $out/$name > $out/$name.summary.txt 2>&1
   cat $out/$name.summary.txt
