@@ -92,33 +92,38 @@ def main():
     ctx.set_frame_base(B, rank * B)
     fp, sp = _native.filter_params(), _native.search_params()
 
+    # N > 1: every step's records go, stream-ordered and without a host wait, into one send buffer; the timed
+    # region ends with ONE RCCL all-gather of all of them (the path has no other exchange step)
     gather_buf = send_buf = None
+    nsteps = max(a.steps, a.warmup, 1)
     if use_dist:
-        send_buf = torch.empty(B * 64, dtype=torch.uint8, device="cuda")
-        gather_buf = torch.empty(world * B * 64, dtype=torch.uint8, device="cuda")
+        send_buf = torch.empty(nsteps * B * 64, dtype=torch.uint8, device="cuda")
+        gather_buf = torch.empty(world * nsteps * B * 64, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
 
-    def step():
+    def step(k=0):
         ctx.mask_run(B, fp)
         ctx.sws_fit_run(B, sp)
         if use_dist:
-            ctx.copy_records_to_device(B, send_buf.data_ptr())       # syncs the context's stream
-            dist.all_gather_into_tensor(gather_buf, send_buf)
+            ctx.enqueue_records_to_device(B, send_buf.data_ptr() + k * B * 64)
 
-    def fence():
+    def fence(gather=False):
         ctx.sync()
         if use_dist:
+            if gather:
+                dist.all_gather_into_tensor(gather_buf, send_buf)
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
 
     ctx.set_streams(a.streams)
-    for _ in range(a.warmup):
-        step()
-    fence()
+    for k in range(a.warmup):
+        step(k)
+    fence(gather=True)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
+    for k in range(a.steps):
+        step(k)
+    fence(gather=True)
     dt = time.perf_counter() - t0
 
     # Per-kernel durations for the roofline: the same steps again on ONE stream with a hipEvent pair
@@ -139,7 +144,8 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        rec_all = np.frombuffer(gather_buf.cpu().numpy().tobytes(), dtype=_native.RECORD_DTYPE)
+        rec_all = np.frombuffer(gather_buf.cpu().numpy().tobytes(), dtype=_native.RECORD_DTYPE).reshape(world, nsteps, B)
+        rec_all = rec_all[:, max(a.steps, 1) - 1, :].reshape(-1)          # the last timed step of every rank
     else:
         rec_all = ctx.download_records(B)
 

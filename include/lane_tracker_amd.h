@@ -134,6 +134,9 @@ int  lt_download_pixels(lt_ctx* ctx, int slot, int side, int32_t* ys, int32_t* x
 int  lt_download_centroids(lt_ctx* ctx, int slot, int side, int32_t* out, int cap, int* count);
 /* device-to-device copy of n records into caller-owned device memory (e.g. a collective's send buffer) */
 int  lt_copy_records_to_device(lt_ctx* ctx, int first_slot, int n, void* dst_device);
+/* the same copy enqueued behind the slots' searches on the context's streams, without waiting: the records are in
+ * dst_device after the next lt_sync (several steps can fill one send buffer and be gathered once) */
+int  lt_enqueue_records_to_device(lt_ctx* ctx, int first_slot, int n, void* dst_device);
 
 /* ---- the hot path, device resident ----------------------------------------------------------- */
 /* find_lane_points() part 1 (:832-846): undistort -> warpPerspective -> filter_lane_points. */

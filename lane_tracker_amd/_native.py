@@ -80,6 +80,7 @@ _SIGNATURES = {
     "lt_download_pixels": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "lt_download_centroids": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
     "lt_copy_records_to_device": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_enqueue_records_to_device": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_overlay_configure": (C.c_int, [_P, _P]),
     "lt_overlay_run": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double]),
     "lt_overlay_set_font": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -333,6 +334,10 @@ class Context:
 
     def copy_records_to_device(self, n, dst_ptr, first=0):
         _check(self.lib.lt_copy_records_to_device(self._h, first, n, C.c_void_p(int(dst_ptr))))
+
+    def enqueue_records_to_device(self, n, dst_ptr, first=0):
+        """Stream-ordered copy (no host wait): valid in dst after the next sync()."""
+        _check(self.lib.lt_enqueue_records_to_device(self._h, first, n, C.c_void_p(int(dst_ptr))))
 
     def set_frame_base(self, n, first_frame, first=0):
         _check(self.lib.lt_set_frame_base(self._h, first, n, int(first_frame)))

@@ -983,6 +983,20 @@ int lt_copy_records_to_device(lt_ctx* c, int first, int n, void* dst) {
     return LT_OK;
 }
 
+int lt_enqueue_records_to_device(lt_ctx* c, int first, int n, void* dst) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!dst) return fail(LT_ERR_INVALID, "null destination");
+    if ((rc = set_device(c))) return rc;
+    // stream-ordered behind the searches of each slot slice; no host synchronisation
+    rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
+        HIP_TRY(hipMemcpyAsync(static_cast<lt_lane_record*>(dst) + (f0 - first), c->d_rec + f0, (size_t)m * sizeof(lt_lane_record),
+                               hipMemcpyDeviceToDevice, st));
+        return (int)LT_OK;
+    });
+    return rc;
+}
+
 int lt_set_frame_base(lt_ctx* c, int first, int n, int first_frame) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;

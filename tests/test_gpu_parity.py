@@ -467,3 +467,47 @@ def test_source_row_upload_is_enough_for_the_path(nat, cal, frames):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.parametrize("ww,wh", [(64, 40), (65, 40), (66, 40), (32, 64), (33, 65), (20, 130), (4, 7)])
+def test_search_kernel_limits_both_versions(nat, plane_ctxs, oracle, ww, wh):
+    """Window sizes around the limits of k_sws_fit2 (2 * int(ww / 2) <= 64 columns; any height): whichever kernel the
+    launcher picks, the result is the oracle's."""
+    from lane_tracker_amd import synth
+    c = _ctx_for(nat, plane_ctxs, (1100, 1080))
+    for seed in (5, 6):
+        m = synth.synth_mask(seed, noise=2e-3, curv=2e-4, slope=0.1)[0]
+        p = dict(window_width=ww, window_height=wh, search_range=25, ignore_sides=200)
+        c.upload_masks(m)
+        c.sws_fit_run(1, nat.search_params(**p))
+        o = oracle.sliding_window_search(m, oracle.search_params(**p))
+        rec = c.download_records(1)[0]
+        assert bool(rec["detected"]) == o["detected"], p
+        for side, (ky, kx) in enumerate((("left_y", "left_x"), ("right_y", "right_x"))):
+            y, x = c.download_pixels(0, side)
+            assert_same(y, o[ky], f"{ky} {p}"); assert_same(x, o[kx], f"{kx} {p}")
+        assert c.download_centroids(0, 0) == o["left_centroids"] and c.download_centroids(0, 1) == o["right_centroids"], p
+        if o["detected"] and len(set(o["left_y"].tolist())) >= 3 and len(set(o["right_y"].tolist())) >= 3:
+            assert coeff_close(rec["left_coeffs"], oracle.polyfit2(o["left_y"], o["left_x"]))
+            assert coeff_close(rec["right_coeffs"], oracle.polyfit2(o["right_y"], o["right_x"]))
+
+
+@pytest.mark.parametrize("bandwidth", [0, 1, 30, 31, 32, 200])
+def test_band_kernel_limits_both_versions(nat, plane_ctxs, oracle, bandwidth):
+    """Band widths around the 64-column limit of k_band_fit2 (2 * bandwidth + 2 <= 64)."""
+    from lane_tracker_amd import synth
+    c = _ctx_for(nat, plane_ctxs, (1100, 1080))
+    m, lc, rc = synth.synth_mask(77, noise=5e-3)
+    lc, rc = lc + np.array([0, 0, 0.4]), rc + np.array([0, 0, -0.6])
+    for partial, ib in ((1.0, 30), (0.5, 0)):
+        p = dict(bandwidth=bandwidth, ignore_bottom=ib, partial=partial)
+        c.upload_masks(m)
+        c.band_fit_run(1, np.concatenate([lc, rc]), nat.search_params(**p))
+        o = oracle.band_search(m, lc, rc, oracle.search_params(**p))
+        rec = c.download_records(1)[0]
+        assert bool(rec["detected"]) == o["detected"], p
+        for side, (ky, kx) in enumerate((("left_y", "left_x"), ("right_y", "right_x"))):
+            y, x = c.download_pixels(0, side)
+            assert_same(y, o[ky], f"{ky} {p}"); assert_same(x, o[kx], f"{kx} {p}")
+        if o["detected"] and bandwidth > 0:
+            assert coeff_close(rec["left_coeffs"], oracle.polyfit2(o["left_y"], o["left_x"]))
