@@ -23,6 +23,9 @@
 // Out-of-image taps are neutral (255 for erode, 0 for dilate), as in OpenCV's default border.
 #include <cstdlib>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "lt_internal.h"
 
 namespace lt {
@@ -509,6 +512,15 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         // small grids cannot fill the chip: prefer more, shorter tasks there
         const double cost = (tasks < slots ? (double)(rows + 2 * SE::R) : rounds * (rows + 2 * SE::R));
         if (cost < best_cost - 1e-9) { best_cost = cost; best_nb = nb; }
+    }
+    // Measured on the full 256-frame grid (tools/nb_sweep.sh): both 29x29 kernels are fastest with 4 bands of 275
+    // rows (the model above picks 5 and 2: it trusts an occupancy figure the kernels do not reach); 55x55: 4 too.
+    if (SE::K == 29 && (long long)n * g.nstrips * 4 >= slots && h / 4 >= 2 * SE::R) best_nb = 4;
+    {   // measurement override: LT_MORPH_NB_<k><E|D>=<bands>, e.g. LT_MORPH_NB_55D=5
+        char name[32];
+        std::snprintf(name, sizeof name, "LT_MORPH_NB_%d%c", SE::K, dilate ? 'D' : 'E');
+        const char* e = std::getenv(name);
+        if (e && std::atoi(e) > 0) best_nb = std::atoi(e);
     }
     g.band_rows = (h + best_nb - 1) / best_nb;
     g.nbands = (h + g.band_rows - 1) / g.band_rows;
