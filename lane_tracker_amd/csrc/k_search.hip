@@ -194,6 +194,54 @@ __global__ __launch_bounds__(64 * BS_RG) void k_band_sums(const uint8_t* __restr
     }
 }
 
+// The same sums from the opened bit plane: counts of set pixels (the searches only compare and maximise the
+// sums, so the factor 255 of a {0,255} mask drops out).  The rows of a band are contiguous in the bit plane: a
+// workgroup copies them to LDS (coalesced, a few instructions), then each wave takes a 64-column word, a lane
+// per column, and walks the rows with broadcast LDS reads (all lanes read the same word).
+constexpr int BSB_ROWS = 256;   // rows staged at a time (35 KB at 17 words per row)
+constexpr int BSB_NT = 1024;    // 16 waves: the start slice of a single frame is one workgroup's job
+__global__ __launch_bounds__(BSB_NT) void k_band_sums_bits(MaskBits mb, SearchGeom g, uint32_t* __restrict__ sums) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* sw = reinterpret_cast<unsigned long long*>(smem);
+    const int band = blockIdx.y, frame = blockIdx.z, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r0 = max(band == 0 ? max(g.y_start, 0) : g.img_height - (1 + band) * g.wh, 0);
+    const int r1 = band == 0 ? g.img_height : g.img_height - band * g.wh;
+    const unsigned long long* fb = mb.bits + (size_t)frame * mb.bits_stride;
+    uint32_t* out = sums + ((size_t)frame * g.nbands + band) * g.w;
+    constexpr int NW = BSB_NT / 64;
+    const int wpr = mb.wpr, jpw = (wpr + NW - 1) / NW;     // words per row; words handled by each wave
+    uint32_t acc[4];                                       // jpw <= 4 (w <= 4096)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = 0;
+    for (int c0 = r0; c0 < r1; c0 += BSB_ROWS) {
+        const int nr = min(BSB_ROWS, r1 - c0), nw = nr * wpr;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nw; i += BSB_NT) sw[i] = fb[(size_t)c0 * wpr + i];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = wv + NW * q;
+            if (q >= jpw || j >= wpr) break;
+            uint32_t a = 0;
+            int r = 0;
+            for (; r + 8 <= nr; r += 8) {                      // eight broadcast reads in flight
+                unsigned long long v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = sw[(r + u) * wpr + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (uint32_t)(v[u] >> lane) & 1u;
+            }
+            for (; r < nr; ++r) a += (uint32_t)(sw[r * wpr + j] >> lane) & 1u;
+            acc[q] += a;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = wv + NW * q, x = j * 64 + lane;
+        if (q < jpw && j < wpr && x < g.w) out[x] = acc[q];
+    }
+}
+
 // copy n band sums (global) into LDS, coalesced and batched
 __device__ void load_sums(const uint32_t* __restrict__ src, int n, unsigned* dst) {
     for (int base = threadIdx.x; base < n; base += NT * 4) {
@@ -669,8 +717,8 @@ __host__ __device__ inline Sws2Layout sws2_layout(const SearchGeom& g) {
 #define SWS2_REPORT
 #endif
 
-template <int ND>   // dwords that cover one window row: 9 for widths <= 32, 17 for widths <= 64
-__global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+template <int ND, bool BITS>   // ND dwords cover one window row of a u8 mask: 9 for widths <= 32, 17 for <= 64
+__global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, MaskBits mb, SearchGeom g,
                                                 const uint32_t* __restrict__ band_sums, uint32_t* __restrict__ pix_all,
                                                 int32_t* __restrict__ cent_all, lt_lane_record* __restrict__ recs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -739,36 +787,51 @@ __global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ mas
     const int rows_total = 2 * nlev * wh, pieces = rows_total * NQ;
     const unsigned inv_wh = div_magic(wh);
     SWS2_T(3)
-    for (int g0 = 0; g0 < pieces; g0 += NT * LOADS_IN_FLIGHT) {
-        Piece v[LOADS_IN_FLIGHT];
-        int prow[LOADS_IN_FLIGHT], psh[LOADS_IN_FLIGHT], pbw[LOADS_IN_FLIGHT];
-#pragma unroll
-        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {           // loads only: no branch, clamped addresses
-            const int gi = g0 + u * NT + (int)threadIdx.x, gc = min(gi, pieces - 1);
-            const int r = gc / NQ, q = gc - r * NQ;
+    if constexpr (BITS) {
+        // bit-plane input: a window row is at most 64 columns = two consecutive words of its mask row, funnel-shifted
+        const unsigned long long* fb = mb.bits + (size_t)frame * mb.bits_stride;
+        for (int r = threadIdx.x; r < rows_total; r += NT) {
             const int sl = div_by(r, wh, inv_wh), ry = r - sl * wh, level = sl >= nlev ? sl - nlev : sl;
             const int a = roi_ab[sl * 2], b = roi_ab[sl * 2 + 1];
-            const int y = H1 - (1 + level) * wh + ry;
-            const int x = min(max((a & ~3) + 16 * q, 0), W - 16);
-            v[u] = *reinterpret_cast<const Piece*>(mask + (size_t)y * W + x);
-            prow[u] = r;
-            psh[u] = x - a;                                    // bit index of the piece's first column
-            pbw[u] = (gi < pieces && b > a) ? b - a : 0;       // 0: nothing to keep
+            const int y = H1 - (1 + level) * wh + ry, j0 = min(a >> 6, mb.wpr - 1), sh = a & 63;
+            const unsigned long long w0 = fb[(size_t)y * mb.wpr + j0], w1 = fb[(size_t)y * mb.wpr + min(j0 + 1, mb.wpr - 1)];
+            unsigned long long m = sh ? (w0 >> sh) | ((j0 + 1 < mb.wpr ? w1 : 0ull) << (64 - sh)) : w0;
+            const int bw = b - a;
+            m &= bw <= 0 ? 0ull : bw < 64 ? (1ull << bw) - 1ull : ~0ull;
+            rowbits[r] = m;
         }
+    } else {
+        for (int g0 = 0; g0 < pieces; g0 += NT * LOADS_IN_FLIGHT) {
+            Piece v[LOADS_IN_FLIGHT];
+            int prow[LOADS_IN_FLIGHT], psh[LOADS_IN_FLIGHT], pbw[LOADS_IN_FLIGHT];
 #pragma unroll
-        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {
-            uint32_t flags = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                // high bit of every non-zero byte, then the four high bits gathered into a nibble
-                const uint32_t w4 = v[u].w[k];
-                const uint32_t hb = ((w4 | ((w4 & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
-                flags |= ((hb * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+            for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {           // loads only: no branch, clamped addresses
+                const int gi = g0 + u * NT + (int)threadIdx.x, gc = min(gi, pieces - 1);
+                const int r = gc / NQ, q = gc - r * NQ;
+                const int sl = div_by(r, wh, inv_wh), ry = r - sl * wh, level = sl >= nlev ? sl - nlev : sl;
+                const int a = roi_ab[sl * 2], b = roi_ab[sl * 2 + 1];
+                const int y = H1 - (1 + level) * wh + ry;
+                const int x = min(max((a & ~3) + 16 * q, 0), W - 16);
+                v[u] = *reinterpret_cast<const Piece*>(mask + (size_t)y * W + x);
+                prow[u] = r;
+                psh[u] = x - a;                                    // bit index of the piece's first column
+                pbw[u] = (gi < pieces && b > a) ? b - a : 0;       // 0: nothing to keep
             }
-            const int sh = psh[u];
-            unsigned long long piece = sh >= 64 ? 0ull : sh >= 0 ? (unsigned long long)flags << sh : (unsigned long long)flags >> min(-sh, 63);
-            piece &= pbw[u] < 64 ? (1ull << (pbw[u] & 63)) - 1ull : ~0ull;
-            if (piece) atomicOr(&rowbits[prow[u]], piece);
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {
+                uint32_t flags = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // high bit of every non-zero byte, then the four high bits gathered into a nibble
+                    const uint32_t w4 = v[u].w[k];
+                    const uint32_t hb = ((w4 | ((w4 & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
+                    flags |= ((hb * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+                }
+                const int sh = psh[u];
+                unsigned long long piece = sh >= 64 ? 0ull : sh >= 0 ? (unsigned long long)flags << sh : (unsigned long long)flags >> min(-sh, 63);
+                piece &= pbw[u] < 64 ? (1ull << (pbw[u] & 63)) - 1ull : ~0ull;
+                if (piece) atomicOr(&rowbits[prow[u]], piece);
+            }
         }
     }
     __syncthreads();
@@ -913,7 +976,8 @@ __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ mas
 // a of every row) are what is stored -- lt_download_pixels expands them (row-major, ascending x).
 // Per-frame block in the pixel buffer (u32 units): [0] rows per side, [1] first row, [2] 0, [3] 0; then the
 // a of every (side, row) as int32; then, 8-byte aligned, one u64 mask per (side, row).
-__global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, SearchGeom g,
+template <bool BITS>
+__global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, MaskBits mb, SearchGeom g,
                                                  const double* __restrict__ prev, BandPrev bp, uint32_t* __restrict__ pix_all,
                                                  lt_lane_record* __restrict__ recs, int nq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -948,38 +1012,51 @@ __global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ ma
         rowbits[r] = 0ull;
     }
     __syncthreads();
-    constexpr int LOADS_IN_FLIGHT = 16;
-    struct __attribute__((packed, aligned(4))) Piece { uint32_t w[4]; };
-    const int pieces = rows_total * nq;
-    const unsigned inv_nq = div_magic(nq);
-    for (int g0 = 0; g0 < pieces; g0 += NT * LOADS_IN_FLIGHT) {
-        Piece v[LOADS_IN_FLIGHT];
-        int prow[LOADS_IN_FLIGHT], psh[LOADS_IN_FLIGHT], pbw[LOADS_IN_FLIGHT];
-#pragma unroll
-        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {           // loads only: no branch, clamped addresses
-            const int gi = g0 + u * NT + (int)threadIdx.x, gc = min(gi, pieces - 1);
-            const int r = div_by(gc, nq, inv_nq), q = gc - r * nq;
+    if constexpr (BITS) {
+        // bit-plane input: the band of a row is at most 64 columns = two consecutive words, funnel-shifted
+        const unsigned long long* fb = mb.bits + (size_t)frame * mb.bits_stride;
+        for (int r = threadIdx.x; r < rows_total; r += NT) {
             const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
-            const int a = row_a[r];
-            const int x = min(max((a & ~3) + 16 * q, 0), W - 16);
-            v[u] = *reinterpret_cast<const Piece*>(mask + (size_t)y * W + x);
-            prow[u] = r;
-            psh[u] = x - a;
-            pbw[u] = gi < pieces ? row_w[r] : 0;
+            const int a = row_a[r], bw = row_w[r], j0 = min(a >> 6, mb.wpr - 1), sh = a & 63;
+            const unsigned long long w0 = fb[(size_t)y * mb.wpr + j0], w1 = fb[(size_t)y * mb.wpr + min(j0 + 1, mb.wpr - 1)];
+            unsigned long long m = sh ? (w0 >> sh) | ((j0 + 1 < mb.wpr ? w1 : 0ull) << (64 - sh)) : w0;
+            m &= bw <= 0 ? 0ull : bw < 64 ? (1ull << bw) - 1ull : ~0ull;
+            rowbits[r] = m;
         }
+    } else {
+        constexpr int LOADS_IN_FLIGHT = 16;
+        struct __attribute__((packed, aligned(4))) Piece { uint32_t w[4]; };
+        const int pieces = rows_total * nq;
+        const unsigned inv_nq = div_magic(nq);
+        for (int g0 = 0; g0 < pieces; g0 += NT * LOADS_IN_FLIGHT) {
+            Piece v[LOADS_IN_FLIGHT];
+            int prow[LOADS_IN_FLIGHT], psh[LOADS_IN_FLIGHT], pbw[LOADS_IN_FLIGHT];
 #pragma unroll
-        for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {
-            uint32_t flags = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint32_t w4 = v[u].w[k];
-                const uint32_t hb = ((w4 | ((w4 & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
-                flags |= ((hb * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+            for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {           // loads only: no branch, clamped addresses
+                const int gi = g0 + u * NT + (int)threadIdx.x, gc = min(gi, pieces - 1);
+                const int r = div_by(gc, nq, inv_nq), q = gc - r * nq;
+                const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
+                const int a = row_a[r];
+                const int x = min(max((a & ~3) + 16 * q, 0), W - 16);
+                v[u] = *reinterpret_cast<const Piece*>(mask + (size_t)y * W + x);
+                prow[u] = r;
+                psh[u] = x - a;
+                pbw[u] = gi < pieces ? row_w[r] : 0;
             }
-            const int sh = psh[u];
-            unsigned long long piece = sh >= 64 ? 0ull : sh >= 0 ? (unsigned long long)flags << sh : (unsigned long long)flags >> min(-sh, 63);
-            piece &= pbw[u] < 64 ? (1ull << (pbw[u] & 63)) - 1ull : ~0ull;
-            if (piece) atomicOr(&rowbits[prow[u]], piece);
+#pragma unroll
+            for (int u = 0; u < LOADS_IN_FLIGHT; ++u) {
+                uint32_t flags = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w4 = v[u].w[k];
+                    const uint32_t hb = ((w4 | ((w4 & 0x7f7f7f7fu) + 0x7f7f7f7fu)) & 0x80808080u) >> 7;
+                    flags |= ((hb * 0x00204081u) >> 21 & 0xfu) << (4 * k);
+                }
+                const int sh = psh[u];
+                unsigned long long piece = sh >= 64 ? 0ull : sh >= 0 ? (unsigned long long)flags << sh : (unsigned long long)flags >> min(-sh, 63);
+                piece &= pbw[u] < 64 ? (1ull << (pbw[u] & 63)) - 1ull : ~0ull;
+                if (piece) atomicOr(&rowbits[prow[u]], piece);
+            }
         }
     }
     __syncthreads();
@@ -1068,34 +1145,74 @@ void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, do
     hipLaunchKernelGGL(k_fit_list, dim3(1), dim3(NT), 0, s, pix, n, h, w, out4);
 }
 
-void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* band_sums,
+namespace {
+bool env_flag(const char* name) { const char* e = std::getenv(name); return e && e[0] == '1'; }
+
+template <class K>
+bool allow_big_lds(K kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+}
+bool sws2_big_lds() {
+    static const bool ok = allow_big_lds(k_sws_fit2<9, false>) && allow_big_lds(k_sws_fit2<17, false>) &&
+                           allow_big_lds(k_sws_fit2<9, true>) && allow_big_lds(k_sws_fit2<17, true>);
+    return ok;
+}
+bool band2_big_lds() {
+    static const bool ok = allow_big_lds(k_band_fit2<false>) && allow_big_lds(k_band_fit2<true>);
+    return ok;
+}
+
+// k_sws_fit2: dword rows, window width <= 64 bits, level sums that fit u16, 32-bit row moments and an LDS image of
+// all band sums; anything else takes the level-by-level kernel
+bool sws2_eligible(const SearchGeom& g, size_t mask_stride) {
+    static const bool v1 = env_flag("LT_SWS_V1");
+    const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
+    const Sws2Layout L = sws2_layout(g);
+    return !v1 && vec4 && 2 * g.hw <= 64 && g.wh * 255 <= 65535 && g.h <= 8192 && g.w >= 16 && L.total <= 150 * 1024 &&
+           g.img_height - g.wh >= 0 && g.nlevels * g.wh <= g.img_height && sws2_block_words(L.nlev, g.wh) <= (long long)g.maxpix &&
+           (L.total <= 48 * 1024 || sws2_big_lds());
+}
+
+// k_band_fit2: a band of at most 64 columns (2 * bandwidth + 2), dword rows, 32-bit row moments
+bool band2_eligible(const SearchGeom& g, size_t mask_stride) {
+    static const bool v1 = env_flag("LT_BAND_V1");
+    const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
+    const int nrows = std::max(g.band_bottom - g.band_top, 0);
+    const long long width = 2LL * (long long)g.bandwidth + 2;
+    const size_t lds = band2_mom_offset(nrows) + 16 * sizeof(long long);
+    return !v1 && vec4 && width <= 64 && g.h <= 8192 && g.w >= 16 && lds <= 150 * 1024 && band2_block_words(nrows) <= (long long)g.maxpix &&
+           (lds <= 48 * 1024 || band2_big_lds());
+}
+
+}  // namespace
+
+bool sws_fit_takes_bits(const SearchGeom& g, size_t mask_stride) { return sws2_eligible(g, mask_stride) && !env_flag("LT_SEARCH_U8"); }
+bool band_fit_takes_bits(const SearchGeom& g, size_t mask_stride) { return band2_eligible(g, mask_stride) && !env_flag("LT_SEARCH_U8"); }
+
+void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, uint32_t* band_sums,
                     uint32_t* pix, int32_t* cent, lt_lane_record* rec, int n) {
     if (n <= 0) return;
-    const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
-    dim3 sgrid(((vec4 ? g.w / 4 : g.w) + 63) / 64, g.nbands, n);
-    if (vec4) hipLaunchKernelGGL(k_band_sums<true>, sgrid, dim3(64, BS_RG), 0, s, masks, mask_stride, g, band_sums);
-    else hipLaunchKernelGGL(k_band_sums<false>, sgrid, dim3(64, BS_RG), 0, s, masks, mask_stride, g, band_sums);
-    // k_sws_fit2: dword rows, window width <= 64 bits, level sums that fit u16, a bounded task list and
-    // an LDS image of all band sums; anything else takes the level-by-level kernel
-    static const bool v1 = [] { const char* e = std::getenv("LT_SWS_V1"); return e && e[0] == '1'; }();
-    const Sws2Layout L = sws2_layout(g);
-    const bool v2 = !v1 && vec4 && 2 * g.hw <= 64 && g.wh * 255 <= 65535 && g.h <= 8192 && g.w >= 16 &&
-                    L.total <= 150 * 1024 && g.img_height - g.wh >= 0 && g.nlevels * g.wh <= g.img_height &&
-                    sws2_block_words(L.nlev, g.wh) <= (long long)g.maxpix;   // inside the first of the slot's two rows
+    const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0, v2 = sws2_eligible(g, mask_stride);
+    if (mb.bits && v2) {
+        const size_t lds = (size_t)BSB_ROWS * mb.wpr * sizeof(unsigned long long);   // <= 128 KB at w = 4096
+        static const bool big = allow_big_lds(k_band_sums_bits);
+        (void)big;
+        hipLaunchKernelGGL(k_band_sums_bits, dim3(1, g.nbands, n), dim3(BSB_NT), lds, s, mb, g, band_sums);
+    } else {
+        dim3 sgrid(((vec4 ? g.w / 4 : g.w) + 63) / 64, g.nbands, n);
+        if (vec4) hipLaunchKernelGGL(k_band_sums<true>, sgrid, dim3(64, BS_RG), 0, s, masks, mask_stride, g, band_sums);
+        else hipLaunchKernelGGL(k_band_sums<false>, sgrid, dim3(64, BS_RG), 0, s, masks, mask_stride, g, band_sums);
+    }
     if (v2) {
-        static int attr_bytes = 0;
-        if (L.total > 48 * 1024 && L.total > attr_bytes) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sws_fit2<9>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    150 * 1024) == hipSuccess &&
-                hipFuncSetAttribute(reinterpret_cast<const void*>(k_sws_fit2<17>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    150 * 1024) == hipSuccess)
-                attr_bytes = 150 * 1024;
-        }
-        if (L.total <= 48 * 1024 || attr_bytes >= L.total) {
-            if (2 * g.hw <= 32)
-                hipLaunchKernelGGL(k_sws_fit2<9>, dim3(n), dim3(NT), (size_t)L.total, s, masks, mask_stride, g, band_sums, pix, cent, rec);
-            else
-                hipLaunchKernelGGL(k_sws_fit2<17>, dim3(n), dim3(NT), (size_t)L.total, s, masks, mask_stride, g, band_sums, pix, cent, rec);
+        const Sws2Layout L = sws2_layout(g);
+        {
+            const bool narrow = 2 * g.hw <= 32;
+            const size_t lds = (size_t)L.total;
+#define LT_LAUNCH_SWS2(ND_, BITS_) \
+    hipLaunchKernelGGL((k_sws_fit2<ND_, BITS_>), dim3(n), dim3(NT), lds, s, masks, mask_stride, mb, g, band_sums, pix, cent, rec)
+            if (mb.bits) { if (narrow) LT_LAUNCH_SWS2(9, true); else LT_LAUNCH_SWS2(17, true); }
+            else { if (narrow) LT_LAUNCH_SWS2(9, false); else LT_LAUNCH_SWS2(17, false); }
+#undef LT_LAUNCH_SWS2
             return;
         }
     }
@@ -1105,24 +1222,17 @@ void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Sea
     else hipLaunchKernelGGL(k_sws_fit<false>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, band_sums, pix, cent, rec);
 }
 
-void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
+void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const double* prev,
                      const BandPrev& bp, uint32_t* pix, lt_lane_record* rec, int n) {
     if (n <= 0) return;
     const bool vec4 = (g.w & 3) == 0 && (mask_stride & 3) == 0;
-    static const bool v1 = [] { const char* e = std::getenv("LT_BAND_V1"); return e && e[0] == '1'; }();
-    // k_band_fit2: a band of at most 64 columns (2 * bandwidth + 2), dword rows, 32-bit row moments
-    const int nrows = std::max(g.band_bottom - g.band_top, 0);
-    const long long width = 2LL * (long long)g.bandwidth + 2;
-    const size_t lds2 = band2_mom_offset(nrows) + 16 * sizeof(long long);
-    if (!v1 && vec4 && width <= 64 && g.h <= 8192 && g.w >= 16 && lds2 <= 150 * 1024 &&
-        band2_block_words(nrows) <= (long long)g.maxpix) {
-        static bool attr_set = false;
-        if (lds2 > 48 * 1024 && !attr_set)
-            attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(k_band_fit2), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           150 * 1024) == hipSuccess;
-        if (lds2 <= 48 * 1024 || attr_set) {
-            const int nq = (int)((width + 3 + 15) / 16);           // 16-byte pieces that cover a row's band from (a & ~3)
-            hipLaunchKernelGGL(k_band_fit2, dim3(n), dim3(NT), lds2, s, masks, mask_stride, g, prev, bp, pix, rec, nq);
+    if (band2_eligible(g, mask_stride)) {
+        const int nrows = std::max(g.band_bottom - g.band_top, 0);
+        const size_t lds2 = band2_mom_offset(nrows) + 16 * sizeof(long long);
+        {
+            const int nq = (int)((2LL * (long long)g.bandwidth + 2 + 3 + 15) / 16);   // 16-byte pieces covering a row's band from (a & ~3)
+            if (mb.bits) hipLaunchKernelGGL(k_band_fit2<true>, dim3(n), dim3(NT), lds2, s, masks, mask_stride, mb, g, prev, bp, pix, rec, nq);
+            else hipLaunchKernelGGL(k_band_fit2<false>, dim3(n), dim3(NT), lds2, s, masks, mask_stride, mb, g, prev, bp, pix, rec, nq);
             return;
         }
     }

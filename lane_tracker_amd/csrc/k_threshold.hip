@@ -576,6 +576,34 @@ __global__ __launch_bounds__(256) void k_dilate5_mask(const unsigned long long* 
     }
 }
 
+// The same dilation, bit plane out: what the searches read (one word per thread, like k_erode5_bits)
+__global__ __launch_bounds__(256) void k_dilate5_bits(const unsigned long long* __restrict__ in,
+                                                     unsigned long long* __restrict__ out, int h, int w, int wpr,
+                                                     size_t bits_stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * wpr) return;
+    const int y = i / wpr, j = i - y * wpr;
+    const unsigned long long* p = in + (size_t)blockIdx.z * bits_stride;
+    auto ld = [&](int yy, int jj) { return load_word(p, yy, jj, h, wpr, 0ull); };
+    unsigned long long d = ld(y - 2, j) | ld(y + 2, j);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) d |= hspan5<true>(ld(y + dy, j - 1), ld(y + dy, j), ld(y + dy, j + 1));
+    const int nvalid = w - j * 64;
+    if (nvalid < 64) d &= (1ull << nvalid) - 1ull;           // no pixels beyond the image width
+    out[(size_t)blockIdx.z * bits_stride + i] = d;
+}
+
+// bit plane -> u8 {0, 255}: four pixels per thread, one dword store (w % 4 == 0), else one pixel per thread
+__global__ __launch_bounds__(256) void k_bits_to_u8x4(const unsigned long long* __restrict__ in, uint8_t* __restrict__ out,
+                                                     int h, int w, int wpr, size_t bits_stride, size_t plane_stride) {
+    const int qpr = w >> 2, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h * qpr) return;
+    const int y = i / qpr, qd = i - y * qpr, x = qd * 4;
+    const unsigned nib = (unsigned)(in[(size_t)blockIdx.z * bits_stride + (size_t)y * wpr + (x >> 6)] >> (x & 63)) & 0xfu;
+    const unsigned spread = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+    reinterpret_cast<uint32_t*>(out + (size_t)blockIdx.z * plane_stride + (size_t)y * w)[qd] = spread * 0xffu;
+}
+
 __global__ __launch_bounds__(256) void k_bits_to_u8(const unsigned long long* __restrict__ in, uint8_t* __restrict__ out,
                                                    int h, int w, int wpr, size_t bits_stride, size_t plane_stride) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -669,10 +697,25 @@ void launch_open5_bits(hipStream_t s, const unsigned long long* merged, unsigned
                        plane_stride);
 }
 
+void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded,
+                          unsigned long long* opened, int h, int w, size_t bits_stride, int n) {
+    if (n <= 0 || h <= 0 || w <= 0) return;
+    const int wpr = (w + 63) / 64;
+    hipLaunchKernelGGL(k_erode5_bits, dim3((h * wpr + 255) / 256, 1, n), dim3(256), 0, s, merged, eroded, h, w, wpr,
+                       bits_stride);
+    hipLaunchKernelGGL(k_dilate5_bits, dim3((h * wpr + 255) / 256, 1, n), dim3(256), 0, s, eroded, opened, h, w, wpr,
+                       bits_stride);
+}
+
 void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,
                        size_t bits_stride, int n) {
     if (n <= 0 || h <= 0 || w <= 0) return;
     const int wpr = (w + 63) / 64;
+    if ((w & 3) == 0 && (plane_stride & 3) == 0) {
+        hipLaunchKernelGGL(k_bits_to_u8x4, dim3((h * (w >> 2) + 255) / 256, 1, n), dim3(256), 0, s, bits, out, h, w, wpr,
+                           bits_stride, plane_stride);
+        return;
+    }
     hipLaunchKernelGGL(k_bits_to_u8, dim3((wpr + 3) / 4, h, n), dim3(256), 0, s, bits, out, h, w, wpr, bits_stride,
                        plane_stride);
 }

@@ -68,6 +68,10 @@ struct lt_ctx {
     size_t und_px = 0;                // pixels per slot of d_und
     uint8_t* d_plane[P_COUNT] = {};
     unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
+    unsigned long long* d_bits_open = nullptr;    // the opened mask as the mask chain leaves it (what the searches read)
+    // per slot: which forms of the mask are current.  The chain writes the bit plane only; the u8 mask
+    // (d_plane[P_MASK]) is expanded from it when somebody asks for it; lt_upload_masks provides u8 only.
+    std::vector<uint8_t> mask_bits_ok, mask_u8_ok;
     size_t bits_stride = 0;                                                  // u64 words per slot
     lt_lane_record* d_rec = nullptr;
     double* d_prev = nullptr;
@@ -199,6 +203,9 @@ void free_slots(lt_ctx* c) {
     for (auto& p : c->d_plane) dev_free(p);
     dev_free(c->d_bits_merged);
     dev_free(c->d_bits_eroded);
+    dev_free(c->d_bits_open);
+    c->mask_bits_ok.clear();
+    c->mask_u8_ok.clear();
     dev_free(c->d_rec);
     dev_free(c->d_prev);
     dev_free(c->d_pix);
@@ -252,6 +259,38 @@ int ensure_bev(lt_ctx* c) {
     return dev_alloc(&c->d_bev, (size_t)c->capacity * c->bev_bytes);
 }
 
+void mark_masks(lt_ctx* c, int first, int n, int bits_ok, int u8_ok) {
+    for (int i = first; i < first + n && i < (int)c->mask_bits_ok.size(); ++i) {
+        c->mask_bits_ok[(size_t)i] = (uint8_t)bits_ok;
+        c->mask_u8_ok[(size_t)i] = (uint8_t)u8_ok;
+    }
+}
+bool masks_have_bits(const lt_ctx* c, int first, int n) {
+    for (int i = first; i < first + n; ++i)
+        if (!c->mask_bits_ok[(size_t)i]) return false;
+    return true;
+}
+// make d_plane[P_MASK] current for the slots (expands the bit plane where only that exists)
+int ensure_u8_masks(lt_ctx* c, int first, int n) {
+    bool any = false;
+    for (int i = first; i < first + n; ++i) any = any || !c->mask_u8_ok[(size_t)i];
+    if (!any) return LT_OK;
+    int rc = sync_all(c);
+    if (rc) return rc;
+    for (int i = first; i < first + n;) {
+        if (c->mask_u8_ok[(size_t)i]) { ++i; continue; }
+        int j = i;
+        while (j < first + n && !c->mask_u8_ok[(size_t)j]) ++j;
+        launch_bits_to_u8(c->stream, c->d_bits_open + (size_t)i * c->bits_stride, c->d_plane[P_MASK] + (size_t)i * c->plane_bytes,
+                          c->calib.warp_h, c->calib.warp_w, c->plane_bytes, c->bits_stride, j - i);
+        for (int k = i; k < j; ++k) c->mask_u8_ok[(size_t)k] = 1;
+        i = j;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
 int validate_filter(const lt_filter_params* p) {
     if (!p) return fail(LT_ERR_INVALID, "null filter params");
     if (p->filter_type != 0 && p->filter_type != 1)
@@ -266,7 +305,7 @@ int validate_filter(const lt_filter_params* p) {
 }
 
 // filter_lane_points() on planes P_R / P_B of the given slots (lane_tracker.py:210-238)
-int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter_params* p, int h, int w) {
+int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter_params* p, int h, int w, bool u8_mask = false) {
     const size_t ps = c->plane_bytes, off = (size_t)first * ps;
     uint8_t* R = c->d_plane[P_R] + off;
     uint8_t* B = c->d_plane[P_B] + off;
@@ -317,7 +356,8 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
         launch_pack_merge(s, t1, t2, B, t3, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps, c->bits_stride, n);
     }
     { StageScope t(c, ST_OPEN, s);
-      launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n); }
+      if (u8_mask) launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n);
+      else launch_open5_to_bits(s, mbits, ebits, c->d_bits_open + (size_t)first * c->bits_stride, h, w, c->bits_stride, n); }
     (void)merged; (void)t0;
     HIP_TRY(hipGetLastError());
     return LT_OK;
@@ -516,6 +556,9 @@ int lt_reserve(lt_ctx* c, int capacity) {
     c->bits_stride = (size_t)c->calib.warp_h * ((c->calib.warp_w + 63) / 64);
     if ((rc = dev_alloc(&c->d_bits_merged, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_bits_eroded, n * c->bits_stride))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_bits_open, n * c->bits_stride))) { free_slots(c); return rc; }
+    c->mask_bits_ok.assign(n, 0);
+    c->mask_u8_ok.assign(n, 1);          // zero-filled below
     if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_prev, n * 6))) { free_slots(c); return rc; }
     c->capacity = capacity;
@@ -608,6 +651,7 @@ int lt_upload_masks(lt_ctx* c, const uint8_t* masks, int first, int n) {
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->have_mask = true;
+    mark_masks(c, first, n, 0, 1);
     return LT_OK;
 }
 
@@ -637,6 +681,8 @@ static int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
 int lt_download_masks(lt_ctx* c, int first, int n, uint8_t* masks) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = ensure_u8_masks(c, first, n))) return rc;
     return download(c, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, masks, (size_t)n * c->plane_bytes);
 }
 
@@ -645,6 +691,10 @@ int lt_download_plane(lt_ctx* c, int plane, int first, int n, uint8_t* out) {
     if (rc) return rc;
     static const int map[6] = {P_R, P_B, P_THR, P_THB, P_MERGED, P_MASK};
     if (plane < 0 || plane > 5) return fail(LT_ERR_INVALID, "unknown plane %d", plane);
+    if (plane == LT_PLANE_MASK) {
+        if ((rc = set_device(c))) return rc;
+        if ((rc = ensure_u8_masks(c, first, n))) return rc;
+    }
     if (plane == LT_PLANE_MERGED) {   // kept bit-packed on the device; expand on demand
         if ((rc = set_device(c))) return rc;
         if ((rc = sync_all(c))) return rc;
@@ -1030,6 +1080,7 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     });
     if (rc) return rc;
     c->have_mask = true;
+    mark_masks(c, first, n, 1, 0);
     return LT_OK;
 }
 
@@ -1049,6 +1100,7 @@ int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     });
     if (rc) return rc;
     c->have_mask = true;
+    mark_masks(c, first, n, 1, 0);
     return LT_OK;
 }
 
@@ -1069,9 +1121,14 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     g.maxpix = c->maxpix;
     g.maxlev = c->maxlev;
     if (n == 0) return LT_OK;
+    // the searches read the opened bit plane when the slots have one and the kernel that will run takes it
+    const bool use_bits = masks_have_bits(c, first, n) && sws_fit_takes_bits(g, c->plane_bytes);
+    if (!use_bits && (rc = ensure_u8_masks(c, first, n))) return rc;
+    const int wpr = (c->calib.warp_w + 63) / 64;
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         StageScope t(c, ST_SWS_FIT, st);
-        launch_sws_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, g,
+        const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
+        launch_sws_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g,
                        c->d_band_sums + (size_t)f0 * g.nbands * c->calib.warp_w, c->d_pix + (size_t)f0 * 2 * c->maxpix,
                        c->d_cent + (size_t)f0 * 2 * (c->maxlev + 2), c->d_rec + f0, m);
         return (int)LT_OK;
@@ -1102,9 +1159,13 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
         HIP_TRY(hipMemcpyAsync(c->d_prev + (size_t)first * 6, prev, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));  // prev is caller memory: do not keep reading it after return
     }
+    const bool use_bits = masks_have_bits(c, first, n) && band_fit_takes_bits(g, c->plane_bytes);
+    if (!use_bits && (rc = ensure_u8_masks(c, first, n))) return rc;
+    const int wpr = (c->calib.warp_w + 63) / 64;
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         StageScope t(c, ST_BAND_FIT, st);
-        launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, g, c->d_prev + (size_t)f0 * 6, bp,
+        const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
+        launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g, c->d_prev + (size_t)f0 * 6, bp,
                         c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
         return (int)LT_OK;
     });
@@ -1200,7 +1261,7 @@ int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_
     if (e == hipSuccess) {
         launch_split_bev(c->stream, d_bev, tmp.plane_bytes * 3, (int)tmp.plane_bytes, c->d_gamma, c->d_cbrt, c->d_coef,
                          tmp.d_plane[P_R], tmp.d_plane[P_B], tmp.plane_bytes, 1);
-        rc = run_filter_chain(&tmp, c->stream, 0, 1, p, h, w);
+        rc = run_filter_chain(&tmp, c->stream, 0, 1, p, h, w, true);
         if (rc == LT_OK) e = hipMemcpyAsync(mask, tmp.d_plane[P_MASK], tmp.plane_bytes, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

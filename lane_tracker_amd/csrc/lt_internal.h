@@ -77,6 +77,9 @@ void launch_pack_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, cons
                        size_t bits_stride, int n);
 void launch_open5_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded, uint8_t* mask, int h,
                        int w, size_t plane_stride, size_t bits_stride, int n);
+// erode + dilate with the 5x5 ellipse, bit plane in, bit plane out
+void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded,
+                          unsigned long long* opened, int h, int w, size_t bits_stride, int n);
 void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,
                        size_t bits_stride, int n);
 
@@ -103,7 +106,17 @@ __host__ __device__ inline long long sws2_block_words(int nlev, int wh) { return
 __host__ __device__ inline int band2_mask_offset(int nrows) { return (4 + 2 * nrows + 1) & ~1; }
 __host__ __device__ inline long long band2_block_words(int nrows) { return band2_mask_offset(nrows) + 4LL * nrows; }
 __host__ __device__ inline size_t band2_mom_offset(int nrows) { return ((size_t)2 * nrows * 16 + 16 + 15) & ~(size_t)15; }
-void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, uint32_t* band_sums,
+// Mask input of the searches: u8 planes, or -- when `bits` is not null -- the opened bit plane the mask chain
+// leaves (wpr words per row, bits_stride words per frame).  *_takes_bits tells whether the kernel version that
+// would run for this geometry reads bit planes (the first-version kernels need u8 masks).
+struct MaskBits {
+    const unsigned long long* bits;
+    size_t bits_stride;
+    int wpr;
+};
+bool sws_fit_takes_bits(const SearchGeom& g, size_t mask_stride);
+bool band_fit_takes_bits(const SearchGeom& g, size_t mask_stride);
+void launch_sws_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, uint32_t* band_sums,
                     uint32_t* pix, int32_t* cent, lt_lane_record* rec, int n);
 // previous coefficients of a single frame travel as a kernel argument (no upload, no synchronisation);
 // batches read them from device memory
@@ -111,7 +124,7 @@ struct BandPrev {
     double c[6];
     int by_value;
 };
-void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, SearchGeom g, const double* prev,
+void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const double* prev,
                      const BandPrev& bp, uint32_t* pix, lt_lane_record* rec, int n);
 
 // fit of one explicit pixel list (packed (y<<16)|x); out: 3 doubles + 1 flag double (1.0 = rank deficient)
