@@ -186,6 +186,19 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
             const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
             off[i] = __mul24(sy - g.r0, g.img_w) + sx;
         }
+        // The four tap weights of a pixel (products of the 5-bit fractions, <= 1024) are frame-independent.  They
+        // are masked to 11 bits on purpose: the compiler folds (a gx + b fx) gy into a (gx gy) + b (fx gy) anyway,
+        // and unless it can see that the weight products are small it multiplies with v_mul_lo_u32 (quarter rate)
+        // instead of v_mul_u32_u24 -- six of them per pixel in the previous version of this loop.
+        uint32_t w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t fx = frv[i] & 31u, fy = frv[i] >> 5, gx = 32u - fx, gy = 32u - fy;
+            w00[i] = (gx * gy) & 0x7ffu;
+            w01[i] = (fx * gy) & 0x7ffu;
+            w10[i] = (gx * fy) & 0x7ffu;
+            w11[i] = (fx * fy) & 0x7ffu;
+        }
         Tap2 top[4], bot[4];
         const uint32_t* src = und + (size_t)z0 * und_stride_px;
 #pragma unroll
@@ -205,7 +218,10 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int rgb[3];
-                blend_taps(top[i].a, top[i].b, bot[i].a, bot[i].b, (int)(frv[i] & 31u), (int)(frv[i] >> 5), rgb);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch)     // (sum_i w_i p_i + 2^9) >> 10: the same integer as the two-stage blend
+                    rgb[ch] = (int)((((top[i].a >> (8 * ch)) & 255u) * w00[i] + ((top[i].b >> (8 * ch)) & 255u) * w01[i] +
+                                     ((bot[i].a >> (8 * ch)) & 255u) * w10[i] + ((bot[i].b >> (8 * ch)) & 255u) * w11[i] + 512u) >> 10);
                 int r = rgb[0], b = lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, s_coef);
                 // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
                 // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigne
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const int gy = y0 + r0 + 4 * u;
-                        v[u] = *reinterpret_cast<const uint32_t*>(colp + (size_t)min(gy, a.h - 1) * a.w);
+                        v[u] = *reinterpret_cast<const uint32_t*>(colp + (uint32_t)__mul24(min(gy, a.h - 1), a.w));   // < 2^24: a full-rate multiply
                         v[u] = (xin && gy < a.h) ? v[u] : 0u;
                     }
                     if (cd0 + lane < dpr) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigne
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int gy = y0 - k + r0 + 16 * u;
-                    v[u] = *reinterpret_cast<const uint32_t*>(colv + (size_t)min(max(gy, 0), a.h - 1) * a.w);
+                    v[u] = *reinterpret_cast<const uint32_t*>(colv + (uint32_t)__mul24(min(max(gy, 0), a.h - 1), a.w));
                     v[u] = (xinv && gy >= 0 && gy < a.h) ? v[u] : 0u;
                 }
 #pragma unroll
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
 #pragma unroll
                     for (int u = 0; u < SB; ++u) {
                         const int gy = y0 + r0 + 4 * u;
-                        v[u] = *reinterpret_cast<const uint32_t*>(colp + (size_t)min(gy, a.h - 1) * a.w);
+                        v[u] = *reinterpret_cast<const uint32_t*>(colp + (uint32_t)__mul24(min(gy, a.h - 1), a.w));   // < 2^24: a full-rate multiply
                         v[u] = (xin && gy < a.h) ? v[u] : 0u;
                     }
                     if (cd0 + lane < dpr) {
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
 #pragma unroll
                 for (int u = 0; u < SB; ++u) {
                     const int gy = y0 - k + r0 + 8 * u;
-                    v[u] = *reinterpret_cast<const uint32_t*>(colv + (size_t)min(max(gy, 0), a.h - 1) * a.w);
+                    v[u] = *reinterpret_cast<const uint32_t*>(colv + (uint32_t)__mul24(min(max(gy, 0), a.h - 1), a.w));
                     v[u] = (xinv && gy >= 0 && gy < a.h) ? v[u] : 0u;
                 }
 #pragma unroll
