@@ -248,17 +248,29 @@ class LaneTracker:
         return lf, rf
 
     # ---- host geometry (reference :511-528, 561-627) ---------------------------------------------------
+    def _plot_rows(self, partial):
+        """ploty and ploty ** 2 of get_poly_points for this `partial` (they only depend on the image height)."""
+        cache = self.__dict__.setdefault("_ploty_cache", {})
+        if partial not in cache:
+            img_height = self.warped_size[1]
+            ploty = np.linspace(img_height * (1 - partial), img_height - 1, _as_index(img_height * partial))
+            cache[partial] = (ploty, ploty ** 2)
+        return cache[partial]
+
+    def _poly_inside(self, coeffs, partial):
+        """x values of one parabola over the plot rows and the mask of those inside [0, W-1] (reference :519-524)."""
+        ploty, ploty2 = self._plot_rows(partial)
+        fitx = coeffs[0] * ploty2 + coeffs[1] * ploty + coeffs[2]
+        return fitx, (fitx <= self.warped_size[0] - 1) & (fitx >= 0)
+
     def get_poly_points(self, left_fit_coeffs, right_fit_coeffs, partial=1):
-        img_height, img_width = self.warped_size[1], self.warped_size[0]
-        ploty = np.linspace(img_height * (1 - partial), img_height - 1, _as_index(img_height * partial))
-        left_fitx = left_fit_coeffs[0] * ploty ** 2 + left_fit_coeffs[1] * ploty + left_fit_coeffs[2]
-        right_fitx = right_fit_coeffs[0] * ploty ** 2 + right_fit_coeffs[1] * ploty + right_fit_coeffs[2]
-        left_fit_x = left_fitx[(left_fitx <= img_width - 1) & (left_fitx >= 0)]
-        right_fit_x = right_fitx[(right_fitx <= img_width - 1) & (right_fitx >= 0)]
-        left_fit_y = np.linspace(img_height - len(left_fit_x), img_height - 1, len(left_fit_x))
-        right_fit_y = np.linspace(img_height - len(right_fit_x), img_height - 1, len(right_fit_x))
-        return (left_fit_y.astype(np.int64), left_fit_x.astype(np.int64),
-                right_fit_y.astype(np.int64), right_fit_x.astype(np.int64))
+        img_height = self.warped_size[1]
+        left_fitx, lin = self._poly_inside(left_fit_coeffs, partial)
+        right_fitx, rin = self._poly_inside(right_fit_coeffs, partial)
+        left_fit_x, right_fit_x = left_fitx[lin], right_fitx[rin]
+        # np.linspace(H - n, H - 1, n) of the reference is exactly the integers H - n ... H - 1
+        return (np.arange(img_height - len(left_fit_x), img_height, dtype=np.int64), left_fit_x.astype(np.int64),
+                np.arange(img_height - len(right_fit_x), img_height, dtype=np.int64), right_fit_x.astype(np.int64))
 
     # separation limits at y1, y2, y3 and the tangent threshold: the values hard-coded upstream
     # (:588-593, :617; the "Demo 2" set of tracker_settings.md).  Overridable per instance.
@@ -267,8 +279,9 @@ class LaneTracker:
 
     def check_validity(self, left_fit_coeffs, right_fit_coeffs, diagnostics=False):
         lim = self.validity_limits
-        left_fit_y, _, right_fit_y, _ = self.get_poly_points(left_fit_coeffs, right_fit_coeffs)
-        n = min(len(left_fit_y), len(right_fit_y))
+        # only the number of plot points inside the image matters here (:565-569)
+        n = min(int(np.count_nonzero(self._poly_inside(left_fit_coeffs, 1)[1])),
+                int(np.count_nonzero(self._poly_inside(right_fit_coeffs, 1)[1])))
         # NB: the reference takes the image WIDTH as the bottom y (:571-573); reproduced as is
         y1 = self.warped_size[0] - 1
         y2 = self.warped_size[0] - int(n * 0.35)
