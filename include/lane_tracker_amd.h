@@ -120,6 +120,10 @@ int  lt_upload_frames(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, in
  * those rows: enough for lt_mask_run and the searches, not for lt_overlay_run, which shows the whole frame. */
 int  lt_get_source_rows(lt_ctx* ctx, int* row0, int* row1);
 int  lt_upload_frame_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
+/* The complement: every other row of the same frames, enqueued on a copy stream of its own so that it runs beside
+ * the mask chain (call it after lt_mask_run).  The host buffer must stay valid until the next lt_sync or download;
+ * lt_overlay_run waits for it. */
+int  lt_upload_frame_rest(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
 /* masks: n * warp_h * warp_w bytes; lets the search stages run on caller-supplied binary images */
 int  lt_upload_masks(lt_ctx* ctx, const uint8_t* masks, int first_slot, int n);
 int  lt_download_masks(lt_ctx* ctx, int first_slot, int n, uint8_t* masks);

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "lt_upload_frames": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_get_source_rows": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lt_upload_frame_rows": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_upload_frame_rest": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_masks": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_download_masks": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_plane": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
@@ -230,6 +231,13 @@ class Context:
         """Like upload_frames, but only the camera rows the path reads cross the bus (not enough for the overlay)."""
         f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
         _check(self.lib.lt_upload_frame_rows(self._h, f.ctypes.data, first, f.shape[0]))
+
+    def upload_frame_rest(self, frames, first=0):
+        """The rows upload_frame_rows left out, on a copy stream beside the compute streams (for the overlay).
+        Returns the array actually handed to the library: keep it alive until the next sync() / download."""
+        f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
+        _check(self.lib.lt_upload_frame_rest(self._h, f.ctypes.data, first, f.shape[0]))
+        return f
 
     def upload_frames(self, frames, first=0):
         f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)

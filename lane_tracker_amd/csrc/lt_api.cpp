@@ -51,6 +51,7 @@ struct lt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;             // = streams[0]
     std::vector<hipStream_t> streams;         // slot s runs on streams[s * nstreams / capacity]
+    hipStream_t copy = nullptr;               // lt_upload_frame_rest: the rows the path does not read, off the critical path
     hipStream_t side = nullptr;               // second branch of a one- or two-frame chain (R and b top-hats side by side)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nstreams = 1;
@@ -125,6 +126,7 @@ void dev_free(T*& p) {
 
 int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
+    if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
     return LT_OK;
 }
 
@@ -459,7 +461,8 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     c->streams.assign(1, c->stream);
     c->nstreams = 1;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipEventCreate failed"));
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
         return bail(fail(LT_ERR_HIP, "side stream / event creation failed"));
@@ -550,6 +553,7 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_lines);
     dev_free(c->d_xpos);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -659,6 +663,29 @@ int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                              (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!frames) return fail(LT_ERR_INVALID, "null frames");
+    if (n == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    // no synchronisation with the compute streams: these rows are read by nobody but the overlay, which waits
+    // for this stream (lt_sync / every download does)
+    const size_t row_bytes = (size_t)c->calib.img_w * 3;
+    const size_t head = (size_t)c->cam_r0 * row_bytes, tail0 = (size_t)c->cam_r1 * row_bytes;
+    uint8_t* dst = c->d_frames + (size_t)first * c->frame_bytes;
+    if (c->cam_r1 <= c->cam_r0) {
+        HIP_TRY(hipMemcpyAsync(dst, frames, (size_t)n * c->frame_bytes, hipMemcpyHostToDevice, c->copy));
+        return LT_OK;
+    }
+    if (head)
+        HIP_TRY(hipMemcpy2DAsync(dst, c->frame_bytes, frames, c->frame_bytes, head, (size_t)n, hipMemcpyHostToDevice, c->copy));
+    if (tail0 < c->frame_bytes)
+        HIP_TRY(hipMemcpy2DAsync(dst + tail0, c->frame_bytes, frames + tail0, c->frame_bytes, c->frame_bytes - tail0, (size_t)n,
+                                 hipMemcpyHostToDevice, c->copy));
     return LT_OK;
 }
 

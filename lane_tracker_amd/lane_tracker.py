@@ -436,11 +436,15 @@ class LaneTracker:
                                  diagnostics, reuse_frame=False, slot=0, have_mask=False, lazy=False):
         ctx = self._ctx
         if not reuse_frame:
-            ctx.upload_frames(img, first=slot)
+            # only the camera rows the path reads are on the critical path; the rest of the frame (the overlay
+            # shows it) follows on a copy stream while the mask chain runs
+            ctx.upload_frame_rows(img, first=slot)
         self._resident = (img, slot)
         if not have_mask:
             ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
                                                   ksize_noise, C_noise), first=slot)
+        if not reuse_frame:
+            self._upload_keepalive = ctx.upload_frame_rest(img, first=slot)
         if self.last_detection > self.n_reset:                       # :851
             if diagnostics:
                 print("Using sliding window search.")
@@ -514,9 +518,11 @@ class LaneTracker:
         ctx = self._ctx
         self._materialise_pending()      # growing the context below drops what is still on the device
         ctx.reserve(max(n, 1))
-        ctx.upload_frames(frames)
+        ctx.upload_frame_rows(frames)        # the camera rows the path reads; the rest only if frames are annotated
         ctx.mask_run(n, _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],
                                               k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"]))
+        if annotate:
+            self._upload_keepalive = ctx.upload_frame_rest(frames)     # beside the mask chain, for the overlay
         deferred = []
         for i in range(n):
             self._step(frames[i], first_try, k["n_tries"], k["diagnostics"], slot=i, have_mask=True, lazy=True,
