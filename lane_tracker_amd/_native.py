@@ -280,10 +280,17 @@ class Context:
         n = len(polygons)
         ln = np.array([len(p[0]) for p in polygons], np.int32)
         rn = np.array([len(p[2]) for p in polygons], np.int32)
-        lyx = np.ascontiguousarray(np.concatenate([np.stack([np.asarray(p[0]), np.asarray(p[1])], 1).reshape(-1, 2)
-                                                   for p in polygons] or [np.zeros((0, 2))]), np.int32)
-        ryx = np.ascontiguousarray(np.concatenate([np.stack([np.asarray(p[2]), np.asarray(p[3])], 1).reshape(-1, 2)
-                                                   for p in polygons] or [np.zeros((0, 2))]), np.int32)
+
+        def pairs(ys, xs, counts):
+            out = np.empty((int(counts.sum()), 2), np.int32)
+            at = 0
+            for y, x, m in zip(ys, xs, counts):
+                out[at:at + m, 0] = y
+                out[at:at + m, 1] = x
+                at += m
+            return out
+        lyx = pairs([p[0] for p in polygons], [p[1] for p in polygons], ln)
+        ryx = pairs([p[2] for p in polygons], [p[3] for p in polygons], rn)
         _check(self.lib.lt_overlay_run(self._h, first, n, ln.ctypes.data, rn.ctypes.data,
                                        lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None,
                                        float(alpha)))

@@ -14,10 +14,10 @@ for name, cal in (("1280x720", calib.reference_calibration()), ("1920x1080_confi
     frames = frames + frames[::-1] + frames + frames[::-1] + frames      # 200 frames, smooth at the turning points
     lt = LaneTracker(**cal)
     for f in frames[:5]:
-        lt.process(f.copy())
+        lt.process(f)
     t0 = time.perf_counter()
     for f in frames[5:]:
-        lt.process(f.copy())
+        lt.process(f)
     dt = time.perf_counter() - t0
     ratio = lt.get_success_ratio()
     # the same without the presentation step (GPU overlay + 2.8 MB download + Pillow text)
