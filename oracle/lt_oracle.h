@@ -15,7 +15,7 @@
  *
  * PARITY STATUS
  *   - sliding_window_search / band_search / fit_poly: PINNED.  The reference's own NumPy code was
- *     imported in the build container (tools/gen_golden.py) and its outputs are committed under
+ *     imported in the build container (tests/gen_golden.py) and its outputs are committed under
  *     tests/golden/; tests/test_oracle_golden.py checks this file against them.
  *   - every cv2-backed stage (undistort, warpPerspective, RGB2LAB, morphologyEx, filter2D,
  *     adaptiveThreshold): PARITY UNPINNED.  OpenCV (unversioned dependency of the reference, a

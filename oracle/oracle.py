@@ -1,9 +1,10 @@
 """ctypes front end of the CPU oracle (oracle/lt_oracle.c).  TEST INFRASTRUCTURE ONLY.
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+Only tests/ (the parity tests, the fixture generator tests/gen_golden.py, the fuzz driver tests/fuzz_gpu.py),
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
 product (lane_tracker_amd/) never does.  See lt_oracle.h for what is restated and the parity
 status of each stage (cv2-backed stages: parity unpinned; NumPy-only stages: pinned by
-tests/golden/, generated from the reference by tools/gen_golden.py).
+tests/golden/, generated from the reference by tests/gen_golden.py).
 
 The Python-level pieces of the reference that are plain NumPy on a handful of scalars
 (get_poly_points lane_tracker.py:511-528, check_validity :561-627) are restated here in NumPy.

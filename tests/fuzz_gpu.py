@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised differential run of the HIP path against the CPU oracle (run on the GPU box):
-   python tools/fuzz_gpu.py [iterations] [seed]
+   python tests/fuzz_gpu.py [iterations] [seed]
 Mask chain with random filter parameters on random frames (reference calibration), filter_lane_points on random
 small images of random sizes, both searches with random parameters.  Prints the first mismatch and exits 1."""
 import sys

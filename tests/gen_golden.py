@@ -23,7 +23,7 @@ Harness-side shims (the reference source is not modified): `np.int = int`; `np.l
 float `num` (2017 NumPy truncated it); integral float `partial` is passed as int to band_search /
 get_poly_points (2017 NumPy accepted float slice bounds).  SURVEY.md F5.
 
-Usage: python tools/gen_golden.py [--ref /root/reference] [--out tests/golden]
+Usage: python tests/gen_golden.py [--ref /root/reference] [--out tests/golden]
 """
 import argparse
 import hashlib

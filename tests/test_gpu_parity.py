@@ -514,11 +514,11 @@ def test_band_kernel_limits_both_versions(nat, plane_ctxs, oracle, bandwidth):
 
 
 def test_randomised_differential_run():
-    """A short run of tools/fuzz_gpu.py (random filter parameters, frames, image sizes, search parameters; the
+    """A short run of tests/fuzz_gpu.py (random filter parameters, frames, image sizes, search parameters; the
     700-iteration campaign of the round is recorded in DESIGN.md)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_gpu.py"), "8", "123"], cwd=root, capture_output=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_gpu.py"), "8", "123"], cwd=root, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout

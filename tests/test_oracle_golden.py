@@ -1,4 +1,4 @@
-"""The CPU oracle against the fixtures generated from the reference itself (tools/gen_golden.py):
+"""The CPU oracle against the fixtures generated from the reference itself (tests/gen_golden.py):
 sliding_window_search / band_search (bit-exact index arrays, centroid lists), fit_poly,
 check_validity, get_poly_points.  Reference: lane_tracker.py:242-528, 561-627."""
 import os

@@ -1,5 +1,5 @@
 """Container-only fuzz: the CPU oracle against the reference's own NumPy methods, imported from
-/root/reference (tools/gen_golden.py harness).  Skipped wherever the reference is absent (it never
+/root/reference (tests/gen_golden.py harness).  Skipped wherever the reference is absent (it never
 travels to the GPU box); the committed fixtures in tests/golden/ carry the same pin there."""
 import os
 import sys
@@ -14,7 +14,7 @@ pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "lane_track
 
 @pytest.fixture(scope="module")
 def ref():
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import gen_golden
     saved = np.linspace
     mod = gen_golden.import_reference(REF)

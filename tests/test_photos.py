@@ -1,6 +1,6 @@
 """BASELINE config 1: real camera frames (the reference's test_images/, stored losslessly under
 tests/golden/photo_*.png) against what the reference's own process() made of them
-(tools/gen_golden.py; cv2 answered by the oracle, so this pins the reference's op order, control flow and
+(tests/gen_golden.py; cv2 answered by the oracle, so this pins the reference's op order, control flow and
 NumPy arithmetic on real data, not OpenCV's numerics)."""
 import hashlib
 import os

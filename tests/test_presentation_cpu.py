@@ -1,7 +1,7 @@
 """Presentation stage, host side: the polygon row intervals the overlay kernel consumes,
 the NumPy visualisations and the split view, checked against the oracle's generic fillPoly / addWeighted /
 resize restatements and against fixtures produced by the reference's own visualisation methods
-(tools/gen_golden.py; their cv2 calls answered by the oracle, so those three calls stay unpinned)."""
+(tests/gen_golden.py; their cv2 calls answered by the oracle, so those three calls stay unpinned)."""
 import numpy as np
 import pytest
 
