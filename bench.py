@@ -159,10 +159,17 @@ def main():
         achieved = alg / (mask_ms * 1e-3) / 1e9 if mask_ms > 0 else 0.0
         dom = max(MASK_STAGES, key=lambda s: stages[s][0])
         traffic = None                                     # HBM bytes per launch of the stage, from the committed PMC run
+        valu_issue = None                                  # and its VALU instruction count (what actually binds the stage)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             if tj["frames_per_launch"] == B and world == 1:
                 traffic = int(tj["mask_stage_traffic_bytes_per_launch"])
+                lane_ops = float(tj["mask_stage_valu_wave_insts_per_launch"]) * 64.0
+                peak = info.cu_count * 4 * 16 * 2.4e9            # CUs x SIMDs x lanes/clk x 2.4 GHz
+                valu_issue = {"achieved": round(lane_ops / (mask_ms * 1e-3) / 1e12, 3), "peak": round(peak / 1e12, 3),
+                              "unit": "T lane-ops/s", "frac": round(lane_ops / (mask_ms * 1e-3) / peak, 4),
+                              "note": "SQ_INSTS_VALU of the mask-stage kernels (profiles/r01_traffic.json) x 64 lanes / stage time; "
+                                      "the integer-issue ceiling is what this chain runs against, see DESIGN.md"}
         except Exception:
             pass
         out = {
@@ -182,7 +189,7 @@ def main():
                                          "about 10x the algorithmic bytes because the chain materialises u8 planes between kernels",
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 6),
                          "alg_bytes_per_frame": int(info.alg_bytes_mask), "frames_per_launch": B,
-                         "stage_ms_per_launch": round(mask_ms, 4), "dominant_kernel": dom,
+                         "stage_ms_per_launch": round(mask_ms, 4), "dominant_kernel": dom, "valu_issue": valu_issue,
                          "note": "the stage is integer-VALU / LDS-pipe bound (SQ counters in profiles/), not HBM bound; see DESIGN.md"},
             "kernels_ms_per_step": {k: round(v[0] / KS, 4) for k, v in stages.items() if v[1]},
             "timing_note": "value / ms_per_step: %d steps on %d HIP streams per GPU (slot slices overlap: the latency-bound "
