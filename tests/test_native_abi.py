@@ -106,3 +106,43 @@ def test_calibration_literals_match_reference_pickles():
     assert np.array_equal(K, calib.CAM_MATRIX) and np.array_equal(D, calib.DIST_COEFFS)
     assert np.array_equal(M, calib.M) and np.array_equal(Minv, calib.MINV)
     assert (isz, wsz, mppv, mpph) == (calib.IMAGE_WIDTH_HEIGHT, calib.WARPED_WIDTH_HEIGHT, calib.MPPV, calib.MPPH)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/lane_tracker_amd.h compiles as C99 (no torch / C++ types in the signatures) and a C program links
+    against the shared library and can call the entry points that need no GPU."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_dir = os.path.join(root, "lane_tracker_amd")
+    src = tmp_path / "abi.c"
+    src.write_text('''
+#include <stdio.h>
+#include <string.h>
+#include "lane_tracker_amd.h"
+int main(void) {
+    lt_calib cal;
+    lt_ctx* ctx = 0;
+    int16_t spans[8];
+    int32_t left[4] = {0, 3, 1, 3}, right[4] = {0, 6, 1, 7};      /* (y, x) pairs */
+    memset(&cal, 0, sizeof cal);
+    if (lt_abi_version() != LT_ABI_VERSION) return 1;
+    if (sizeof(lt_lane_record) != 64) return 2;
+    if (lt_create(0, 0, &ctx) == 0) return 3;                      /* null calibration: an error code, no crash */
+    if (lt_last_error()[0] == 0) return 4;
+    if (lt_lane_polygon_spans(4, left, 2, right, 2, spans) != 0) return 5;
+    if (spans[0] != 3 || spans[1] != 6 || spans[2] != 3 || spans[3] != 7) return 6;
+    if (spans[4] <= spans[5]) return 7;                            /* untouched rows are empty intervals */
+    printf("abi ok\\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-llane_tracker_amd", "-Wl,-rpath," + lib_dir])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = lib_dir + os.pathsep + "/opt/rocm/lib" + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
