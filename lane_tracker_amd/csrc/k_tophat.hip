@@ -26,6 +26,8 @@
 #include <cstdio>
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "lt_internal.h"
 
 namespace lt {
@@ -281,7 +283,7 @@ __device__ __forceinline__ uint2 op3v(uint2 a, uint2 b, uint2 c) {
 // entries p = 27..90 read S13 at p +- 14 and S4 at p +- 8.  (29x29, entries 0..91): S1 [1,90],
 // S4 [4,87], S7 [7,84]; p = 14..77 reads S7 at p +- 7.
 template <class SE, bool DIL>
-__device__ __forceinline__ void row_windows2(uint2* s, int lane, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH]) {
+__device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uint2 e_pb, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH]) {
     uint2* S0 = s + MARGIN;
     uint2* S4 = S0 + 2 * PLANE;
     uint2* SL = S0 + 3 * PLANE;   // S13 (55x55) or S7 (29x29)
@@ -309,7 +311,26 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint32_t (&Ha)[
         (S0 + (DST) * PLANE)[pb] = op3v<DIL>(pair(b0), pair(b1), pair(b2));                                          \
         wave_lds_fence();                                                                                            \
     }
-    LT_STEP3(0, 1, 1)
+    {
+        // First chain step without LDS: the neighbours of entry p = lane (and p = lane + 64) sit in the adjacent
+        // lanes' registers, one whole-wave DPP shift away; lane 63's right neighbour is entry 64 (lane 0's second
+        // entry) and lane 0's left neighbour of entry 64 is entry 63 -- the rotates deliver exactly those.  Entries
+        // 0 and 127 get a wrong neighbour, and are outside every window that is ever consumed.
+        auto dpp = [](auto ctrl, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); };
+        using SHL = std::integral_constant<int, 0x130>; using ROL = std::integral_constant<int, 0x134>;
+        using SHR = std::integral_constant<int, 0x138>; using ROR = std::integral_constant<int, 0x13c>;
+        const uint2 u = make_uint2(dpp(ROL{}, e_pb.x), dpp(ROL{}, e_pb.y));      // lane i <- second entry of lane i + 1
+        const uint2 v = make_uint2(dpp(ROR{}, e_pa.x), dpp(ROR{}, e_pa.y));      // lane i <- first entry of lane i - 1
+        uint2 sl = make_uint2(dpp(SHL{}, e_pa.x), dpp(SHL{}, e_pa.y)), sr = make_uint2(dpp(SHR{}, e_pb.x), dpp(SHR{}, e_pb.y));
+        // The shifts must run with every lane enabled (a DPP source lane that is masked off delivers nothing):
+        // the empty statement keeps the compiler from sinking them under the lane == 63 / lane == 0 selects.
+        asm volatile("" : "+v"(sl.x), "+v"(sl.y), "+v"(sr.x), "+v"(sr.y));
+        const uint2 an = lane == 63 ? u : sl;
+        const uint2 bp = lane == 0 ? v : sr;
+        (S0 + PLANE)[pa] = op3v<DIL>(v, e_pa, an);
+        (S0 + PLANE)[pb] = op3v<DIL>(bp, e_pb, u);
+        wave_lds_fence();
+    }
     LT_STEP3(1, 2, 3)
     const int p = SE::R + lane;
     auto lds_addr = [](const uint2* q) { return (uint32_t)(uintptr_t)q; };   // low 32 bits of a flat LDS address = LDS offset
@@ -426,8 +447,10 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // minuend (xa, xb) of output rows y and y+1
     for (int yy = y_first; yy <= y_last; yy += 2) {
         const bool ina = rows_ok(yy), inb = rows_ok(yy + 1);
-        chain[MARGIN + lane] = make_uint2(ina ? (ea0 | BIAS2) : NEUTRAL, inb ? (eb0 | BIAS2) : NEUTRAL);
-        chain[MARGIN + lane + 64] = make_uint2(ina ? (ea1 | BIAS2) : NEUTRAL, inb ? (eb1 | BIAS2) : NEUTRAL);
+        const uint2 e_pa = make_uint2(ina ? (ea0 | BIAS2) : NEUTRAL, inb ? (eb0 | BIAS2) : NEUTRAL);
+        const uint2 e_pb = make_uint2(ina ? (ea1 | BIAS2) : NEUTRAL, inb ? (eb1 | BIAS2) : NEUTRAL);
+        chain[MARGIN + lane] = e_pa;             // only the half-width-0 window still reads plane 0
+        chain[MARGIN + lane + 64] = e_pb;
         wave_lds_fence();
         ea0 = fetch_entry(row_ptr(yy + 2), cols, 0);
         ea1 = fetch_entry(row_ptr(yy + 2), cols, 1);
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
             ma1 = r1[oa]; mb1 = r1[ob];
         }
         uint32_t Ha[NH], Hb[NH];
-        row_windows2<SE, DIL>(chain, lane, Ha, Hb);
+        row_windows2<SE, DIL>(chain, lane, e_pa, e_pb, Ha, Hb);
         wave_lds_fence();   // the chain planes are rewritten by the next iteration
         const uint32_t out_a = op2<DIL>(A[1], Ha[SE::slot(0)]);                       // row y
 #pragma unroll
