@@ -107,14 +107,19 @@ def main():
         if use_dist:
             ctx.enqueue_records_to_device(B, send_buf.data_ptr() + k * B * 64)
 
+    marks = {}
+
     def fence(gather=False):
         ctx.sync()
+        marks["drained"] = time.perf_counter()
         if use_dist:
             if gather:
                 dist.all_gather_into_tensor(gather_buf, send_buf)
             torch.cuda.synchronize()
+            marks["gathered"] = time.perf_counter()
             dist.barrier()
             torch.cuda.synchronize()
+        marks["fenced"] = time.perf_counter()
 
     ctx.set_streams(a.streams)
     for k in range(a.warmup):
@@ -125,6 +130,10 @@ def main():
         step(k)
     fence(gather=True)
     dt = time.perf_counter() - t0
+    if os.environ.get("LT_BENCH_VERBOSE") and rank == 0:
+        print("timed region: drained %.3f ms, +gather %.3f ms, +barrier %.3f ms" % (
+            (marks["drained"] - t0) * 1e3, (marks.get("gathered", marks["drained"]) - marks["drained"]) * 1e3,
+            (marks["fenced"] - marks.get("gathered", marks["drained"])) * 1e3), file=sys.stderr)
 
     # Per-kernel durations for the roofline: the same steps again on ONE stream with a hipEvent pair
     # around every kernel (with several streams the kernels of different slices overlap, so their
