@@ -27,6 +27,17 @@ __device__ __forceinline__ int bilerp(int v00, int v01, int v10, int v11, int fx
     return (__mul24(h0, gy) + __mul24(h1, fy) + 512) >> 10;
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin in linear launch order (x fastest, then y, then z), and each XCD
+// has its own L2.  `xcd_block` turns the hardware's linear id into the id this workgroup works on, such that every
+// XCD owns one contiguous range of the launch: neighbouring blocks sample overlapping source rows, and with the
+// round-robin order each of the 8 L2s fetched its own copy of them (rocprofv3 FETCH_SIZE of the warp: 2.5x the
+// source bytes).  Bijective for any launch size; speed only, never correctness.  remap == 0: identity.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t lid, uint32_t total, int remap) {
+    if (!remap) return lid;
+    const uint32_t q = total >> 3, r = total & 7u, xcd = lid & 7u, k = lid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
 // One thread per undistorted pixel.  Frames are RGB interleaved (3 B/px); the output is one RGBX
 // dword per pixel, so that the warp fetches a whole tap with a single aligned load.  All loads are
 // unconditional on clamped addresses and masked afterwards (a guarded load serialises on its own
@@ -35,11 +46,15 @@ __device__ __forceinline__ int bilerp(int v00, int v01, int v10, int v11, int fx
 __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restrict__ frames, size_t frame_stride,
                                                        const int16_t* __restrict__ uxy,
                                                        const uint16_t* __restrict__ ufrac, FrontEndGeom g,
-                                                       uint32_t* __restrict__ und, size_t und_stride_px, int n, int fpb) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = blockIdx.y;  // relative to g.r0
+                                                       uint32_t* __restrict__ und, size_t und_stride_px, int n, int fpb,
+                                                       int remap) {
+    const uint32_t per_z = gridDim.x * gridDim.y;
+    const uint32_t id = xcd_block((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, per_z * gridDim.z, remap);
+    const uint32_t bz = id / per_z, by = (id - bz * per_z) / gridDim.x, bx = id - bz * per_z - by * gridDim.x;
+    const int x = bx * blockDim.x + threadIdx.x;
+    const int row = by;  // relative to g.r0
     if (x >= g.img_w) return;
-    const int z0 = blockIdx.z * fpb, z1 = min(z0 + fpb, n);   // fpb frames per thread: table entry and offsets are frame-independent
+    const int z0 = bz * fpb, z1 = min(z0 + fpb, n);   // fpb frames per thread: table entry and offsets are frame-independent
     const size_t o = (size_t)row * g.img_w + x;
     const int sx = uxy[o * 2], sy = uxy[o * 2 + 1];
     const int f = ufrac[o], fx = f & 31, fy = f >> 5;
@@ -155,19 +170,22 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
                                                     const uint16_t* __restrict__ gamma_tab,
                                                     const uint16_t* __restrict__ cbrt_tab,
                                                     const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
-                                                    uint8_t* __restrict__ planeB, size_t plane_stride, int n, int fpb) {
+                                                    uint8_t* __restrict__ planeB, size_t plane_stride, int n, int fpb,
+                                                    int remap) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_cbrt[3072];
     __shared__ int32_t s_coef[9];
     const size_t quads = ((size_t)g.warp_h * g.warp_w) >> 2;
-    const size_t qi = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t id = xcd_block(blockIdx.z * gridDim.x + blockIdx.x, gridDim.x * gridDim.z, remap);
+    const uint32_t bz = id / gridDim.x, bx = id - bz * gridDim.x;
+    const size_t qi = (size_t)bx * blockDim.x + threadIdx.x;
     const size_t qc = qi < quads ? qi : quads - 1;
     // the table entry is requested before the Lab tables are staged: both latencies overlap
     const uint4 xy = reinterpret_cast<const uint4*>(wxy)[qc];        // 4 x (sx, sy) int16 pairs
     const uint2 fr = reinterpret_cast<const uint2*>(wfrac)[qc];      // 4 x u16
     stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
     if (qi >= quads) return;
-    const int z0 = blockIdx.z * fpb, z1 = min(z0 + fpb, n);
+    const int z0 = bz * fpb, z1 = min(z0 + fpb, n);
     const uint32_t xyv[4] = {xy.x, xy.y, xy.z, xy.w};
     const uint32_t frv[4] = {fr.x & 0xffffu, fr.x >> 16, fr.y & 0xffffu, fr.y >> 16};
     // 87 % of the bird's-eye view samples strictly inside the staged rows: skip every border test there
@@ -314,6 +332,11 @@ __global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint32_t* __re
 // Frames one thread walks with its remap-table entry: as many as possible (the table read, the tap address
 // arithmetic and one memory round trip are paid once per walk) while the launch still has a few groups of
 // frames, so that small batches keep their parallelism.
+static int xcd_remap() {
+    static const int v = [] { const char* e = std::getenv("LT_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
+    return v;
+}
+
 static int frames_per_thread(int n) {
     static const int cap = [] { const char* e = std::getenv("LT_FRONTEND_FPB"); int v = e ? std::atoi(e) : 16; return v < 1 ? 1 : v; }();
     int fpb = n / 8;
@@ -325,7 +348,7 @@ void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_st
     if (n <= 0 || g.nrows <= 0) return;
     const int fpb = frames_per_thread(n);
     dim3 grid((g.img_w + 255) / 256, g.nrows, (n + fpb - 1) / fpb);
-    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px, n, fpb);
+    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px, n, fpb, xcd_remap());
 }
 
 void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy,
@@ -337,7 +360,7 @@ void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px,
         const int fpb = frames_per_thread(n);
         dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, (n + fpb - 1) / fpb);
         hipLaunchKernelGGL(k_warp_split4, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
-                           coeffs, planeR, planeB, plane_stride, n, fpb);
+                           coeffs, planeR, planeB, plane_stride, n, fpb, xcd_remap());
     } else {
         dim3 grid((unsigned)((npix + 255) / 256), 1, n);
         hipLaunchKernelGGL(k_warp_split1, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,

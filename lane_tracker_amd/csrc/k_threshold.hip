@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
             }
         }
         __syncthreads();
-        {
+        if (x0 + 32 * wv < a.w) {   // a wave whose 32 columns lie beyond the image has no verdicts to add (wave-uniform)
             // ---- H phase: rows (lane, lane+64), tile columns 32*wv .. 32*wv+31
             const uint8_t* b0 = band + lane * pitch + koff - k + 32 * wv;   // b[c] <-> tile column 32*wv - k + c
             const uint8_t* b1 = b0 + 64 * pitch;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
             }
         }
         __syncthreads();
-        {
+        if (y0 + 32 * wv < a.h) {   // likewise for 32 rows below the image
             // ---- V phase: columns (lane, lane+64), tile rows 32*wv .. 32*wv+31
             const int rbase = 32 * wv;
             const uint8_t* b = band + rbase * T2 + lane;   // b[r*128] <-> tile row rbase - k + r
