@@ -263,6 +263,17 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
 __device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) * __builtin_bit_cast(u16x2t, b)));
 }
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) * __builtin_bit_cast(u16x2t, b) + __builtin_bit_cast(u16x2t, c)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(u16x2t, a), __builtin_bit_cast(u16x2t, b)));
+}
+// four consecutive band bytes from any byte address (LDS serves unaligned dwords)
+__device__ __forceinline__ uint32_t lds_dword(const uint8_t* p) {
+    struct __attribute__((packed, aligned(1))) U { uint32_t v; };
+    return reinterpret_cast<const U*>(p)->v;
+}
 __device__ __forceinline__ uint32_t pk_shr1(uint32_t a) {
     return __builtin_bit_cast(uint32_t, (u16x2t)(__builtin_bit_cast(u16x2t, a) >> (u16x2t){1, 1}));
 }
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
         uint8_t* band = smem;
         const uint8_t* s = a.pl[q].src + fo;
         const uint32_t kk = (uint32_t)k | ((uint32_t)k << 16);
-        const uint32_t ck = (uint32_t)((C * k) & 0xffff) * 0x10001u;
+        const uint32_t ck = (uint32_t)((C * k) & 0xffff) * 0x10001u, nck = (uint32_t)((-C * k) & 0xffff) * 0x10001u;
         unsigned long long (*dst)[2] = q == 2 ? s_noise : s_or;
 
         // ---------------- row band: rows y0..y0+127, columns xa..xa+pitch-1 ----------------
@@ -358,31 +369,54 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
         __syncthreads();
         if (x0 + 32 * wv < a.w) {   // a wave whose 32 columns lie beyond the image has no verdicts to add (wave-uniform)
             // ---- H phase: rows (lane, lane+64), tile columns 32*wv .. 32*wv+31
+            // The band is read a dword (four columns of one row) at a time -- LDS takes unaligned dwords -- and
+            // v_perm_b32 builds the packed pair (row l | row l+64 << 16) of a column from the two rows' dwords in
+            // ONE instruction; byte reads cost an extract and an insert per value.  The test itself is
+            //     thr = k p - C k            (v_pk_mad_u16)
+            //     pass <=> max(S_l, S_r) < thr   (v_pk_max_u16, v_pk_sub_i16: the sign bit is the verdict)
+            // All sums are < 2^15, thr > -2^15: signed 16-bit differences cannot wrap.
             const uint8_t* b0 = band + lane * pitch + koff - k + 32 * wv;   // b[c] <-> tile column 32*wv - k + c
             const uint8_t* b1 = b0 + 64 * pitch;
-            uint32_t sl = 0, sr = 0;
-#pragma unroll 4
-            for (int c = 0; c < k; ++c) {
-                sl += (uint32_t)b0[c] | ((uint32_t)b1[c] << 16);
-                sr += (uint32_t)b0[k + 1 + c] | ((uint32_t)b1[k + 1 + c] << 16);
+            uint32_t sla = 0, slb = 0, sra = 0, srb = 0;   // prologue: v_sad_u8 against 0 adds the four bytes of a dword
+            int c = 0;
+            for (; c + 4 <= k; c += 4) {
+                sla = __builtin_amdgcn_sad_u8(lds_dword(b0 + c), 0u, sla);
+                slb = __builtin_amdgcn_sad_u8(lds_dword(b1 + c), 0u, slb);
+                sra = __builtin_amdgcn_sad_u8(lds_dword(b0 + k + 1 + c), 0u, sra);
+                srb = __builtin_amdgcn_sad_u8(lds_dword(b1 + k + 1 + c), 0u, srb);
             }
+            if (k & 3) {
+                const uint32_t keep = (1u << (8 * (k & 3))) - 1u;   // the band row extends past 2k+32 columns: the read stays inside it
+                sla = __builtin_amdgcn_sad_u8(lds_dword(b0 + c) & keep, 0u, sla);
+                slb = __builtin_amdgcn_sad_u8(lds_dword(b1 + c) & keep, 0u, slb);
+                sra = __builtin_amdgcn_sad_u8(lds_dword(b0 + k + 1 + c) & keep, 0u, sra);
+                srb = __builtin_amdgcn_sad_u8(lds_dword(b1 + k + 1 + c) & keep, 0u, srb);
+            }
+            uint32_t sl = sla | (slb << 16), sr = sra | (srb << 16);
             uint32_t w0 = 0, w1 = 0;
             uint32_t P = (uint32_t)b0[k] | ((uint32_t)b1[k] << 16);
+            const uint8_t *o0 = b0, *o1 = b1, *p0 = b0 + k + 1, *p1 = b1 + k + 1, *i0 = b0 + 2 * k + 1, *i1 = b1 + 2 * k + 1;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 uint32_t acc = 0;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int t = g * 16 + u;
-                    const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
-                    const uint32_t m = pk_sub(sl, thr) & pk_sub(sr, thr);          // sign bits: both sides < thr
-                    acc = pk_shr1(acc) | (m & 0x80008000u);
-                    const uint32_t outl = (uint32_t)b0[t] | ((uint32_t)b1[t] << 16);
-                    const uint32_t in = (uint32_t)b0[2 * k + 1 + t] | ((uint32_t)b1[2 * k + 1 + t] << 16);
-                    const uint32_t Pn = (uint32_t)b0[k + 1 + t] | ((uint32_t)b1[k + 1 + t] << 16);
-                    sl = pk_sub(pk_add(sl, P), outl);
-                    sr = pk_sub(pk_add(sr, in), Pn);
-                    P = Pn;
+                for (int j = 0; j < 4; ++j) {
+                    const int t4 = g * 16 + j * 4;
+                    const uint32_t ao = lds_dword(o0 + t4), bo = lds_dword(o1 + t4);
+                    const uint32_t ap = lds_dword(p0 + t4), bp = lds_dword(p1 + t4);
+                    const uint32_t ai = lds_dword(i0 + t4), bi = lds_dword(i1 + t4);
+                    for_each_const([&](auto uc) {
+                        constexpr uint32_t u = decltype(uc)::value, SEL = 0x0c000c00u | u | ((4u + u) << 16);
+                        const uint32_t thr = pk_mad(P, kk, nck);
+                        const uint32_t m = pk_sub(pk_max(sl, sr), thr);               // sign bits: both sides < thr
+                        acc = pk_shr1(acc) | (m & 0x80008000u);
+                        const uint32_t outl = __builtin_amdgcn_perm(bo, ao, SEL);
+                        const uint32_t in = __builtin_amdgcn_perm(bi, ai, SEL);
+                        const uint32_t Pn = __builtin_amdgcn_perm(bp, ap, SEL);
+                        sl = pk_sub(pk_add(sl, P), outl);
+                        sr = pk_sub(pk_add(sr, in), Pn);
+                        P = Pn;
+                    }, std::make_integer_sequence<int, 4>{});
                 }
                 w0 |= (acc & 0xffffu) << (16 * g);
                 w1 |= (acc >> 16) << (16 * g);
