@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
         uint8_t* band = smem;
         const uint8_t* s = a.pl[q].src + fo;
         const uint32_t kk = (uint32_t)k | ((uint32_t)k << 16);
-        const uint32_t ck = (uint32_t)((C * k) & 0xffff) * 0x10001u, nck = (uint32_t)((-C * k) & 0xffff) * 0x10001u;
+        const uint32_t nck = (uint32_t)((-C * k) & 0xffff) * 0x10001u;
         unsigned long long (*dst)[2] = q == 2 ? s_noise : s_or;
 
         // ---------------- row band: rows y0..y0+127, columns xa..xa+pitch-1 ----------------
@@ -428,42 +428,54 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
 
         // ---------------- column band: rows y0-k..y0+127+k+1, columns x0..x0+127 ----------------
         __syncthreads();   // every H wave is done with the row band
+        // Layout of a band row (128 bytes): byte 2c = tile column c, byte 2c+1 = tile column c + 64, so that the V
+        // phase fetches both of a lane's columns with ONE 16-bit read.
         if (aligned) {
-            uint32_t* vb = reinterpret_cast<uint32_t*>(band);
-            const int nrows = T2 + 2 * k + 1, cdv = lane & 31, rsub = wv * 2 + (lane >> 5);   // 8 rows per block pass
-            const int gxv = x0 + cdv * 4;
-            const bool xinv = gxv < a.w;
-            const uint8_t* colv = s + min(gxv, a.w - 4);
-            for (int r0 = rsub; r0 < nrows; r0 += 8 * SB) {
-                uint32_t v[SB];
+            uint2* vb = reinterpret_cast<uint2*>(band);
+            const int nrows = T2 + 2 * k + 1, cdv = lane & 15, rsub = wv * 4 + (lane >> 4);   // 16 rows per block pass
+            const int gxa = x0 + cdv * 4, gxb = gxa + 64;
+            const bool xina = gxa < a.w, xinb = gxb < a.w;
+            const uint8_t *cola = s + min(gxa, a.w - 4), *colb = s + min(gxb, a.w - 4);
+            constexpr int SV = SB / 2;
+            for (int r0 = rsub; r0 < nrows; r0 += 16 * SV) {
+                uint32_t va[SV], vc[SV];
 #pragma unroll
-                for (int u = 0; u < SB; ++u) {
-                    const int gy = y0 - k + r0 + 8 * u;
-                    v[u] = *reinterpret_cast<const uint32_t*>(colv + (uint32_t)__mul24(min(max(gy, 0), a.h - 1), a.w));
-                    v[u] = (xinv && gy >= 0 && gy < a.h) ? v[u] : 0u;
+                for (int u = 0; u < SV; ++u) {
+                    const int gy = y0 - k + r0 + 16 * u;
+                    const uint32_t ro = (uint32_t)__mul24(min(max(gy, 0), a.h - 1), a.w);
+                    va[u] = *reinterpret_cast<const uint32_t*>(cola + ro);
+                    vc[u] = *reinterpret_cast<const uint32_t*>(colb + ro);
+                    const bool yin = gy >= 0 && gy < a.h;
+                    va[u] = (xina && yin) ? va[u] : 0u;
+                    vc[u] = (xinb && yin) ? vc[u] : 0u;
                 }
 #pragma unroll
-                for (int u = 0; u < SB; ++u)
-                    if (r0 + 8 * u < nrows) vb[(r0 + 8 * u) * 32 + cdv] = v[u];
+                for (int u = 0; u < SV; ++u)
+                    if (r0 + 16 * u < nrows)
+                        vb[(r0 + 16 * u) * 16 + cdv] = make_uint2(__builtin_amdgcn_perm(vc[u], va[u], 0x05010400u),
+                                                                  __builtin_amdgcn_perm(vc[u], va[u], 0x07030602u));
             }
         } else {
             for (int i = threadIdx.x; i < (T2 + 2 * k + 1) * T2; i += 256) {
                 const int r = i >> 7, c = i & 127, gy = y0 - k + r, gx = x0 + c;
-                band[i] = (gx < a.w && gy >= 0 && gy < a.h) ? s[(size_t)gy * a.w + gx] : 0;
+                band[r * T2 + ((c & 63) << 1) + (c >> 6)] = (gx < a.w && gy >= 0 && gy < a.h) ? s[(size_t)gy * a.w + gx] : 0;
             }
         }
         __syncthreads();
         if (y0 + 32 * wv < a.h) {   // likewise for 32 rows below the image
             // ---- V phase: columns (lane, lane+64), tile rows 32*wv .. 32*wv+31
             const int rbase = 32 * wv;
-            const uint8_t* b = band + rbase * T2 + lane;   // b[r*128] <-> tile row rbase - k + r
+            const uint8_t* b = band + rbase * T2 + 2 * lane;   // b[r*128] <-> tile row rbase - k + r, columns (lane, lane+64)
+            auto pair = [](const uint8_t* q) {                  // (col lane | col lane+64 << 16) from the two adjacent bytes
+                return __builtin_amdgcn_perm(0u, (uint32_t)*reinterpret_cast<const uint16_t*>(q), 0x0c010c00u);
+            };
             uint32_t su = 0, sd = 0;
 #pragma unroll 4
             for (int r = 0; r < k; ++r) {
-                su += (uint32_t)b[r * T2] | ((uint32_t)b[r * T2 + 64] << 16);
-                sd += (uint32_t)b[(k + 1 + r) * T2] | ((uint32_t)b[(k + 1 + r) * T2 + 64] << 16);
+                su += pair(b + r * T2);
+                sd += pair(b + (k + 1 + r) * T2);
             }
-            uint32_t P = (uint32_t)b[k * T2] | ((uint32_t)b[k * T2 + 64] << 16);
+            uint32_t P = pair(b + k * T2);
             // Row t's verdict word is wave-uniform (a ballot) and belongs in lane t: v_writelane puts an SGPR
             // into one lane of a VGPR in a single instruction.  The greenery range test only exists for the
             // third plane; keeping it out of the other two loops keeps them free of branches, so the 32
@@ -472,8 +484,8 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
             auto vsteps = [&](auto with_range) {
                 for_each_const([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
-                    const uint32_t thr = pk_sub(pk_mul(P, kk), ck);
-                    const uint32_t m = pk_sub(su, thr) & pk_sub(sd, thr);
+                    const uint32_t thr = pk_mad(P, kk, nck);
+                    const uint32_t m = pk_sub(pk_max(su, sd), thr);
                     const unsigned long long bal0 = __ballot((int16_t)(m & 0xffffu) < 0), bal1 = __ballot((int32_t)m < 0);
                     write_lane_words<t>(m0l, m0h, m1l, m1h, bal0, bal1);
                     if (decltype(with_range)::value) {   // inRange(lab_b, noise_thresh, 255) on the raw plane
@@ -481,9 +493,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
                                                  r1 = __ballot((int)(P >> 16) >= a.noise_thresh);
                         write_lane_words<t>(g0l, g0h, g1l, g1h, r0, r1);
                     }
-                    const uint32_t outu = (uint32_t)b[t * T2] | ((uint32_t)b[t * T2 + 64] << 16);
-                    const uint32_t in = (uint32_t)b[(2 * k + 1 + t) * T2] | ((uint32_t)b[(2 * k + 1 + t) * T2 + 64] << 16);
-                    const uint32_t Pn = (uint32_t)b[(k + 1 + t) * T2] | ((uint32_t)b[(k + 1 + t) * T2 + 64] << 16);
+                    const uint32_t outu = pair(b + t * T2), in = pair(b + (2 * k + 1 + t) * T2), Pn = pair(b + (k + 1 + t) * T2);
                     su = pk_sub(pk_add(su, P), outu);
                     sd = pk_sub(pk_add(sd, in), Pn);
                     P = Pn;
