@@ -272,6 +272,11 @@ __device__ __forceinline__ uint2 op3v(uint2 a, uint2 b, uint2 c) {
     return make_uint2(op3<DIL>(a.x, b.x, c.x), op3<DIL>(a.y, b.y, c.y));
 }
 
+__device__ __forceinline__ uint32_t sub_sat16(uint32_t a, uint32_t b) {   // v_pk_sub_u16 clamp: max(a - b, 0) per half
+    typedef unsigned short u16x2s __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2s, a), __builtin_bit_cast(u16x2s, b)));
+}
+
 // Chain of one row PAIR: entries are uint2 (.x = row yy, .y = row yy+1).  With 3-input ops the
 // chain is shorter than in the one-row kernel: half-widths 0 -> 1 -> 4 -> 13 (55x55) or
 // 0 -> 1 -> 4 -> 7 (29x29), i.e. three dependent LDS round trips.  A window of half-width d is
@@ -411,10 +416,17 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
 #undef LT_RD64
 }
 
-template <class SE, bool DIL>
+// WIDE (w % 4 == 0, planes 4-byte aligned): one byte store per lane and instruction is the expensive way to write a
+// plane (dropping 7/8 of the byte stores: -15 % on the 29x29 kernels, while regrouping the byte LOADS the same way
+// gained nothing).  The wave's 2 x 128 output bytes of a row pair are regrouped through 256 bytes of LDS (two 16-bit
+// writes, one 64-bit read per lane) so that every lane holds four adjacent pixels of one row: ONE dword store and, for
+// the top-hat, ONE dword load of the minuend per row pair instead of 4 + 4.  The read-back and the store of a row
+// pair happen one iteration later, under the next pair's window update, so the LDS round trip is off the critical path.
+template <class SE, bool DIL, bool WIDE>
 __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     const uint8_t* __restrict__ minuend, RunsGeom g) {
     __shared__ uint2 s_chain[4][4 * PLANE];   // S0, S1, S4, S13|S7
+    __shared__ __attribute__((aligned(8))) uint8_t s_out[WIDE ? 4 : 1][WIDE ? 256 : 8];   // [2*col + row] of a row pair
     constexpr int K = SE::K, R = SE::R, NH = SE::NH;
     constexpr uint32_t NEUTRAL = (DIL ? 0u : 0x00ff00ffu) | BIAS2;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -433,6 +445,9 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     const bool va = xa < g.w, vb = xb < g.w;
     const int oa = min(xa, g.w - 1), ob = min(xb, g.w - 1);
 
+    const int wcol = x0 + 4 * (lane & 31), wcol_c = min(wcol, g.w - 4);                 // WIDE: this lane's four output columns
+    const uint32_t row_sel = lane < 32 ? 0x06040200u : 0x07050301u;                     // bytes of row 0 / row 1 of a [2*col + row] group
+
     uint32_t A[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) A[j] = NEUTRAL;
@@ -445,6 +460,21 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     uint32_t ea0 = fetch_entry(row_ptr(y_first), cols, 0), ea1 = fetch_entry(row_ptr(y_first), cols, 1);
     uint32_t eb0 = fetch_entry(row_ptr(y_first + 1), cols, 0), eb1 = fetch_entry(row_ptr(y_first + 1), cols, 1);
     uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // minuend (xa, xb) of output rows y and y+1
+    uint32_t mhold = 0;
+    const uint32_t out_wr = (uint32_t)(uintptr_t)(s_out[wv] + (WIDE ? 2 * lane : 0));         // LDS offsets
+    const uint32_t out_rd = (uint32_t)(uintptr_t)(s_out[wv] + (WIDE ? 8 * (lane & 31) : 0));
+    auto out_issue = [&](unsigned long long& q) { asm volatile("ds_read_b64 %0, %1" : "=v"(q) : "v"(out_rd) : "memory"); };
+    auto out_finish = [&](unsigned long long q, int yp, uint32_t mp) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q) :: "memory");
+        uint32_t v = __builtin_amdgcn_perm((uint32_t)(q >> 32), (uint32_t)q, row_sel);   // this lane's row of 4 columns x 2 rows
+        if (m) {   // TOPHAT: src - open(src), saturating, on the even and the odd bytes as packed 16-bit halves
+            const uint32_t me = mp & 0x00ff00ffu, mo = (mp >> 8) & 0x00ff00ffu;
+            const uint32_t ve = v & 0x00ff00ffu, vo = (v >> 8) & 0x00ff00ffu;
+            v = sub_sat16(me, ve) | (sub_sat16(mo, vo) << 8);
+        }
+        const int yo = yp + (lane >> 5);
+        if (yo >= yb0 && yo < yb1 && wcol < g.w) *reinterpret_cast<uint32_t*>(d + (uint32_t)(__mul24(yo, g.w) + wcol)) = v;
+    };
     for (int yy = y_first; yy <= y_last; yy += 2) {
         const bool ina = rows_ok(yy), inb = rows_ok(yy + 1);
         const uint2 e_pa = make_uint2(ina ? (ea0 | BIAS2) : NEUTRAL, inb ? (eb0 | BIAS2) : NEUTRAL);
@@ -458,21 +488,40 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         eb1 = fetch_entry(row_ptr(yy + 3), cols, 1);
         const int y = yy - R;                       // output rows y and y+1 complete in this iteration
         const uint32_t ca0 = ma0, cb0 = mb0, ca1 = ma1, cb1 = mb1;
+        const uint32_t mprev = mhold;   // WIDE: minuend of rows y-2, y-1 (stored in this iteration)
+        mhold = ma0;                    //       ... of rows y, y+1
         if (m) {
-            const uint8_t* r0 = m + (size_t)min(max(y + 2, 0), g.h - 1) * g.w;
-            const uint8_t* r1 = m + (size_t)min(max(y + 3, 0), g.h - 1) * g.w;
-            ma0 = r0[oa]; mb0 = r0[ob];
-            ma1 = r1[oa]; mb1 = r1[ob];
+            if (WIDE) {   // lane <-> row y + (lane >> 5), columns x0 + 4 (lane & 31) .. + 3: the layout of the dword store
+                const int mr = min(max(y + 2 + (lane >> 5), 0), g.h - 1);
+                ma0 = *reinterpret_cast<const uint32_t*>(m + (uint32_t)(__mul24(mr, g.w) + wcol_c));
+            } else {
+                const uint8_t* r0 = m + (size_t)min(max(y + 2, 0), g.h - 1) * g.w;
+                const uint8_t* r1 = m + (size_t)min(max(y + 3, 0), g.h - 1) * g.w;
+                ma0 = r0[oa]; mb0 = r0[ob];
+                ma1 = r1[oa]; mb1 = r1[ob];
+            }
         }
         uint32_t Ha[NH], Hb[NH];
         row_windows2<SE, DIL>(chain, lane, e_pa, e_pb, Ha, Hb);
         wave_lds_fence();   // the chain planes are rewritten by the next iteration
+        const bool prev_out = WIDE && y - 1 >= yb0 && y - 2 < yb1;   // rows y-2, y-1 wait regrouped in s_out
+        unsigned long long q = 0;
+        if (prev_out) out_issue(q);
+        if (WIDE) __builtin_amdgcn_sched_barrier(0);
         const uint32_t out_a = op2<DIL>(A[1], Ha[SE::slot(0)]);                       // row y
 #pragma unroll
         for (int j = 0; j < K - 2; ++j) A[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
         A[K - 2] = op2<DIL>(Ha[SE::slot(K - 1)], Hb[SE::slot(K - 2)]);
         A[K - 1] = Hb[SE::slot(K - 1)];
         const uint32_t out_b = A[0];                                                  // row y + 1
+        if (WIDE) {
+            __builtin_amdgcn_sched_barrier(0);   // the window update above stays between the read-back and its use
+            if (prev_out) out_finish(q, y - 2, mprev);
+            if (y + 1 >= yb0 && y < yb1) {       // wave-uniform; read back and stored while the next row pair computes
+                const uint32_t W = __builtin_amdgcn_perm(out_b, out_a, 0x06020400u);   // [row y: xa, row y+1: xa, y: xb, y+1: xb]
+                asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:128" :: "v"(out_wr), "v"(W) : "memory");
+            }
+        } else
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int yo = y + rr;
@@ -488,6 +537,14 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
                 if (va) d[o + xa] = (uint8_t)oa_v;
                 if (vb) d[o + xb] = (uint8_t)ob_v;
             }
+        }
+    }
+    if (WIDE) {   // the last row pair is still in s_out
+        const int yl = y_first + ((y_last - y_first) & ~1) - R;
+        if (yl + 1 >= yb0 && yl < yb1) {
+            unsigned long long q;
+            out_issue(q);
+            out_finish(q, yl, mhold);
         }
     }
 }
@@ -509,6 +566,9 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.plane_stride = plane_stride;
     g.nstrips = (w + 127) / 128;
     static const bool one_row = [] { const char* e = std::getenv("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
+    static const bool narrow = [] { const char* e = std::getenv("LT_MORPH_WIDE"); return e && e[0] == '0'; }();
+    const bool wide = !narrow && (w & 3) == 0 && (plane_stride & 3) == 0 && w >= 4 &&
+                      ((uintptr_t)dst & 3) == 0 && ((uintptr_t)minuend & 3) == 0;
     // Band count: every task walks band_rows + 2R rows, and the chip holds `slots` waves at once, so
     // the makespan is ~ ceil(tasks / slots) * (band_rows + 2R).  Pick the band count that minimises
     // it (a grid of 2.25 rounds costs 3 rounds); bands no shorter than 2R keep the halo overhead sane.
@@ -517,7 +577,8 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     {
         const void* fn = one_row ? (dilate ? (const void*)k_morph_runs<SE, true> : (const void*)k_morph_runs<SE, false>)
-                                 : (dilate ? (const void*)k_morph_runs2<SE, true> : (const void*)k_morph_runs2<SE, false>);
+                                 : wide ? (dilate ? (const void*)k_morph_runs2<SE, true, true> : (const void*)k_morph_runs2<SE, false, true>)
+                                        : (dilate ? (const void*)k_morph_runs2<SE, true, false> : (const void*)k_morph_runs2<SE, false, false>);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) blocks_per_cu = nb;
     }
@@ -553,8 +614,13 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         if (dilate) hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
         else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
     } else {
-        if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
-        else hipLaunchKernelGGL((k_morph_runs2<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
+        if (wide) {
+            if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
+            else hipLaunchKernelGGL((k_morph_runs2<SE, false, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
+        } else {
+            if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
+            else hipLaunchKernelGGL((k_morph_runs2<SE, false, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
+        }
     }
 }
 
