@@ -30,6 +30,10 @@
 
 #include "lt_internal.h"
 
+#ifndef LT_FUSED55
+#define LT_FUSED55 1
+#endif
+
 namespace lt {
 namespace {
 
@@ -287,8 +291,26 @@ __device__ __forceinline__ uint32_t sub_sat16(uint32_t a, uint32_t b) {   // v_p
 // Valid entry ranges (55x55, entries 0..117): S1 [1,116], S4 [4,113], S13 [13,104]; the lane's own
 // entries p = 27..90 read S13 at p +- 14 and S4 at p +- 8.  (29x29, entries 0..91): S1 [1,90],
 // S4 [4,87], S7 [7,84]; p = 14..77 reads S7 at p +- 7.
-template <class SE, bool DIL>
-__device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uint2 e_pb, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH]) {
+// 55x55 only -- which stage of the fused finals (below) delivers half-width slot s, and the stage in which window
+// row pair j (A[j] <- A[j+2], Ha[slot(j+1)], Hb[slot(j)]) has both of its slots
+constexpr int fused_stage_of_slot(int s) { return s <= 3 ? 1 : s <= 7 ? 2 : s <= 11 ? 3 : s <= 14 ? 4 : 5; }
+template <class SE>
+constexpr int fused_stage_of_update(int j) {
+    const int a = fused_stage_of_slot(SE::slot(j + 1)), b = fused_stage_of_slot(SE::slot(j));
+    return a > b ? a : b;
+}
+template <class F, int... I>
+__device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// FUSE (55x55): the 35 window reads of a row pair held 74 VGPRs at once, next to the 55 of the vertical pipeline A --
+// 161 VGPRs, three waves per SIMD.  Fused, the reads come in five stages ordered by half-width, and each stage is
+// followed at once by the pipeline updates whose two half-widths it completes (outer rows of the ellipse first), so
+// only one stage of reads and a few half-widths are alive at a time.
+template <class SE, bool DIL, bool FUSE = false>
+__device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uint2 e_pb, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH],
+                                             uint32_t* A = nullptr, uint32_t* out_ab = nullptr) {
     uint2* S0 = s + MARGIN;
     uint2* S4 = S0 + 2 * PLANE;
     uint2* SL = S0 + 3 * PLANE;   // S13 (55x55) or S7 (29x29)
@@ -341,7 +363,86 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
     auto lds_addr = [](const uint2* q) { return (uint32_t)(uintptr_t)q; };   // low 32 bits of a flat LDS address = LDS offset
     auto lo = [](unsigned long long v) { return (uint32_t)v; };
     auto hi = [](unsigned long long v) { return (uint32_t)(v >> 32); };
-    if (SE::K == 55) {
+    if constexpr (SE::K == 55 && FUSE) {
+        constexpr int K = SE::K, R = SE::R;
+        constexpr int O0 = (MARGIN + R) * 8, O4 = (2 * PLANE + MARGIN + R - 8) * 8, O13 = (3 * PLANE + MARGIN + R - 14) * 8;   // from cb
+        uint32_t An[K];
+        auto updates = [&](auto stage) {
+            for_each_const([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                if constexpr (fused_stage_of_update<SE>(j) == decltype(stage)::value) {
+                    An[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
+                    asm volatile("" : "+v"(An[j]));   // pins the update into its stage: the optimiser would sink it below every read
+                }
+            }, std::make_integer_sequence<int, K - 2>{});
+        };
+#define LT_G(i) (O13 + (i) * 8)
+#define LT_PAIR(slot_, x, y) Ha[slot_] = op2<DIL>(lo(x), lo(y)); Hb[slot_] = op2<DIL>(hi(x), hi(y));
+#define LT_WAIT8(n, a, b, c, d, e, f, g, h) \
+    asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h) :: "memory")
+        // The reads of stage k+1 are in flight while stage k is reduced and consumed (LDS returns in order, so
+        // "at most n outstanding" with n = the reads issued after a stage means that stage has arrived).
+        // stage 1: half-widths 0, 7, 10, 12 -- planes S0 and S4, read under the last chain step
+        unsigned long long r0, f0, f1, f2, f3, f4, f5, f6;
+        LT_RD64(r0, cb, O0);
+        LT_RD64(f0, cb, O4 + 0); LT_RD64(f1, cb, O4 + 16); LT_RD64(f2, cb, O4 + 40); LT_RD64(f3, cb, O4 + 64);   // p-8, p-6, p-3, p
+        LT_RD64(f4, cb, O4 + 88); LT_RD64(f5, cb, O4 + 112); LT_RD64(f6, cb, O4 + 128);                          // p+3, p+6, p+8
+        LT_STEP3(2, 3, 9)                                                                                        // waits for everything
+        LT_WAIT8(0, r0, f0, f1, f2, f3, f4, f5, f6);
+        // stage 2: 14, 16, 17, 18   (half-width 13 + q from S13[p - q], S13[p + q])
+        unsigned long long a2, b2, c2, d2, e2, f2_, g2, h2;
+        LT_RD64(a2, cb, LT_G(13)); LT_RD64(b2, cb, LT_G(15)); LT_RD64(c2, cb, LT_G(11)); LT_RD64(d2, cb, LT_G(17));
+        LT_RD64(e2, cb, LT_G(10)); LT_RD64(f2_, cb, LT_G(18)); LT_RD64(g2, cb, LT_G(9)); LT_RD64(h2, cb, LT_G(19));
+        {
+            Ha[0] = lo(r0); Hb[0] = hi(r0);
+            LT_PAIR(1, f2, f4)
+            Ha[2] = op3<DIL>(lo(f1), lo(f3), lo(f5)); Hb[2] = op3<DIL>(hi(f1), hi(f3), hi(f5));
+            Ha[3] = op3<DIL>(lo(f0), lo(f3), lo(f6)); Hb[3] = op3<DIL>(hi(f0), hi(f3), hi(f6));
+            out_ab[0] = op2<DIL>(A[1], Ha[SE::slot(0)]);                       // row y
+            An[K - 2] = op2<DIL>(Ha[SE::slot(K - 1)], Hb[SE::slot(K - 2)]);
+            An[K - 1] = Hb[SE::slot(K - 1)];
+            asm volatile("" : "+v"(out_ab[0]), "+v"(An[K - 2]), "+v"(An[K - 1]));
+            updates(std::integral_constant<int, 1>{});
+        }
+        // stage 3: 19, 20, 21, 22
+        unsigned long long a3, b3, c3, d3, e3, f3_, g3, h3;
+        LT_RD64(a3, cb, LT_G(8)); LT_RD64(b3, cb, LT_G(20)); LT_RD64(c3, cb, LT_G(7)); LT_RD64(d3, cb, LT_G(21));
+        LT_RD64(e3, cb, LT_G(6)); LT_RD64(f3_, cb, LT_G(22)); LT_RD64(g3, cb, LT_G(5)); LT_RD64(h3, cb, LT_G(23));
+        LT_WAIT8(8, a2, b2, c2, d2, e2, f2_, g2, h2);
+        {
+            LT_PAIR(4, a2, b2) LT_PAIR(5, c2, d2) LT_PAIR(6, e2, f2_) LT_PAIR(7, g2, h2)
+            updates(std::integral_constant<int, 2>{});
+        }
+        // stage 4: 23, 24, 25
+        unsigned long long a4, b4, c4, d4, e4, f4_;
+        LT_RD64(a4, cb, LT_G(4)); LT_RD64(b4, cb, LT_G(24)); LT_RD64(c4, cb, LT_G(3)); LT_RD64(d4, cb, LT_G(25));
+        LT_RD64(e4, cb, LT_G(2)); LT_RD64(f4_, cb, LT_G(26));
+        LT_WAIT8(6, a3, b3, c3, d3, e3, f3_, g3, h3);
+        {
+            LT_PAIR(8, a3, b3) LT_PAIR(9, c3, d3) LT_PAIR(10, e3, f3_) LT_PAIR(11, g3, h3)
+            updates(std::integral_constant<int, 3>{});
+        }
+        // stage 5: 26, 27 (= 13 + 14 as S13[p - 14], S13[p], S13[p + 14])
+        unsigned long long a5, b5, c5, d5, e5;
+        LT_RD64(a5, cb, LT_G(1)); LT_RD64(b5, cb, LT_G(27)); LT_RD64(c5, cb, LT_G(0)); LT_RD64(d5, cb, LT_G(14)); LT_RD64(e5, cb, LT_G(28));
+        asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a4), "+v"(b4), "+v"(c4), "+v"(d4), "+v"(e4), "+v"(f4_) :: "memory");
+        {
+            LT_PAIR(12, a4, b4) LT_PAIR(13, c4, d4) LT_PAIR(14, e4, f4_)
+            updates(std::integral_constant<int, 4>{});
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a5), "+v"(b5), "+v"(c5), "+v"(d5), "+v"(e5) :: "memory");
+        {
+            LT_PAIR(15, a5, b5)
+            Ha[16] = op3<DIL>(lo(c5), lo(d5), lo(e5)); Hb[16] = op3<DIL>(hi(c5), hi(d5), hi(e5));
+            updates(std::integral_constant<int, 5>{});
+        }
+#undef LT_WAIT8
+#undef LT_PAIR
+#undef LT_G
+#pragma unroll
+        for (int j = 0; j < K; ++j) A[j] = An[j];
+        out_ab[1] = A[0];                                                      // row y + 1
+    } else if (SE::K == 55) {
         LT_STEP3(2, 3, 9)
         const uint32_t a0 = lds_addr(S0 + p), a4 = lds_addr(S4 + p - 8), a13 = lds_addr(SL + p - 14);
         unsigned long long r0, f[7], g[29];
@@ -502,18 +603,23 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
             }
         }
         uint32_t Ha[NH], Hb[NH];
-        row_windows2<SE, DIL>(chain, lane, e_pa, e_pb, Ha, Hb);
+        constexpr bool FUSE = LT_FUSED55 && K == 55;
+        uint32_t out_ab[2];
+        row_windows2<SE, DIL, FUSE>(chain, lane, e_pa, e_pb, Ha, Hb, A, out_ab);
         wave_lds_fence();   // the chain planes are rewritten by the next iteration
         const bool prev_out = WIDE && y - 1 >= yb0 && y - 2 < yb1;   // rows y-2, y-1 wait regrouped in s_out
         unsigned long long q = 0;
         if (prev_out) out_issue(q);
         if (WIDE) __builtin_amdgcn_sched_barrier(0);
-        const uint32_t out_a = op2<DIL>(A[1], Ha[SE::slot(0)]);                       // row y
+        if (!FUSE) {
+            out_ab[0] = op2<DIL>(A[1], Ha[SE::slot(0)]);                              // row y
 #pragma unroll
-        for (int j = 0; j < K - 2; ++j) A[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
-        A[K - 2] = op2<DIL>(Ha[SE::slot(K - 1)], Hb[SE::slot(K - 2)]);
-        A[K - 1] = Hb[SE::slot(K - 1)];
-        const uint32_t out_b = A[0];                                                  // row y + 1
+            for (int j = 0; j < K - 2; ++j) A[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
+            A[K - 2] = op2<DIL>(Ha[SE::slot(K - 1)], Hb[SE::slot(K - 2)]);
+            A[K - 1] = Hb[SE::slot(K - 1)];
+            out_ab[1] = A[0];                                                         // row y + 1
+        }
+        const uint32_t out_a = out_ab[0], out_b = out_ab[1];
         if (WIDE) {
             __builtin_amdgcn_sched_barrier(0);   // the window update above stays between the read-back and its use
             if (prev_out) out_finish(q, y - 2, mprev);
@@ -597,9 +703,10 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         const double cost = (tasks < slots ? (double)(rows + 2 * SE::R) : rounds * (rows + 2 * SE::R));
         if (cost < best_cost - 1e-9) { best_cost = cost; best_nb = nb; }
     }
-    // Measured on the full 256-frame grid (tools/nb_sweep.sh): both 29x29 kernels are fastest with 4 bands of 275
-    // rows (the model above picks 5 and 2: it trusts an occupancy figure the kernels do not reach); 55x55: 4 too.
-    if (SE::K == 29 && (long long)n * g.nstrips * 4 >= slots && h / 4 >= 2 * SE::R) best_nb = 4;
+    // Measured on the full 256-frame grid (tools/nb_sweep.sh, tools/nb55_sweep.sh): all four kernels are fastest with
+    // 4 bands of 275 rows (the model above picks 5 and 2 for 29x29 and 5 for 55x55: it trusts an occupancy figure
+    // whose extra waves add no throughput -- the kernels are bound by VALU issue and the LDS pipe, not by latency).
+    if ((long long)n * g.nstrips * 4 >= slots && h / 4 >= 2 * SE::R) best_nb = 4;
     {   // measurement override: LT_MORPH_NB_<k><E|D>=<bands>, e.g. LT_MORPH_NB_55D=5
         char name[32];
         std::snprintf(name, sizeof name, "LT_MORPH_NB_%d%c", SE::K, dilate ? 'D' : 'E');
@@ -615,8 +722,9 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
     } else {
         if (wide) {
-            if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
-            else hipLaunchKernelGGL((k_morph_runs2<SE, false, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
+            static const int extra_lds = [] { const char* e = std::getenv("LT_MORPH_EXTRA_LDS"); return e ? std::atoi(e) : 0; }();   // occupancy experiments
+            if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true, true>), grid, dim3(256), extra_lds, s, src, dst, minuend, g);
+            else hipLaunchKernelGGL((k_morph_runs2<SE, false, true>), grid, dim3(256), extra_lds, s, src, dst, minuend, g);
         } else {
             if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
             else hipLaunchKernelGGL((k_morph_runs2<SE, false, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
