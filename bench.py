@@ -195,7 +195,8 @@ def main():
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "traffic_note": "FETCH_SIZE+WRITE_SIZE of the mask-stage kernels, rocprofv3 --pmc, profiles/r01_traffic.json; "
-                                         "about 10x the algorithmic bytes because the chain materialises u8 planes between kernels",
+                                         "%.1fx the algorithmic bytes because the chain materialises u8 planes between kernels"
+                                         % ((traffic or 0) / float(alg) if alg else 0.0),
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 6),
                          "alg_bytes_per_frame": int(info.alg_bytes_mask), "frames_per_launch": B,
                          "stage_ms_per_launch": round(mask_ms, 4), "dominant_kernel": dom, "valu_issue": valu_issue,
