@@ -707,6 +707,10 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     // 4 bands of 275 rows (the model above picks 5 and 2 for 29x29 and 5 for 55x55: it trusts an occupancy figure
     // whose extra waves add no throughput -- the kernels are bound by VALU issue and the LDS pipe, not by latency).
     if ((long long)n * g.nstrips * 4 >= slots && h / 4 >= 2 * SE::R) best_nb = 4;
+    // Launches of a slot slice (85 of 256 frames on three streams) share the chip with the other slices' kernels:
+    // there, too, few long walks beat a grid sized to fill the chip on its own (tools/nb_value_sweep.sh: 3 bands
+    // 66.8 k frames/s, 4 bands 66.5 k, the model's 5-6 bands 65.5 k).
+    else if ((long long)n * g.nstrips * 3 >= slots / 4 && h / 3 >= 2 * SE::R) best_nb = 3;
     {   // measurement override: LT_MORPH_NB_<k><E|D>=<bands>, e.g. LT_MORPH_NB_55D=5
         char name[32];
         std::snprintf(name, sizeof name, "LT_MORPH_NB_%d%c", SE::K, dilate ? 'D' : 'E');
