@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams per context (slot slices overlap each other's stages)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams per context (slot slices overlap each other's stages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
