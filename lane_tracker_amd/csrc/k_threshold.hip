@@ -23,6 +23,7 @@
 // R-top-hat H/V and b-top-hat H/V run concurrently on the 4 waves; the words are OR-ed at the end
 // (plus the greenery term, lane_tracker.py:223-231, in a second round when mask_noise is on).
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include <type_traits>
@@ -692,6 +693,12 @@ int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile2),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return -1;
+            static const bool report = [] { const char* e = std::getenv("LT_REPORT_OCCUPANCY"); return e && e[0] == '1'; }();
+            if (report) {
+                int nb = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_bilateral_tile2), 256, lds);
+                std::fprintf(stderr, "k_bilateral_tile2: %zu B dynamic LDS, %d workgroups per CU\n", lds, nb);
+            }
             hipLaunchKernelGGL(k_bilateral_tile2, dim3(a.ntiles), dim3(256), lds, s, a, bits);
             return 0;
         }
