@@ -149,7 +149,7 @@ struct RunsGeom {
 // and masked afterwards, so they stay in flight across the chain (a guarded load compiles to
 // branch + load + s_waitcnt vmcnt(0)).
 struct LaneCols {
-    int off[4];        // entry 0: (a, a+64); entry 1: (a+64, a+128)
+    uint32_t off[4];   // entry 0: (a, a+64); entry 1: (a+64, a+128); unsigned: the loads take the scalar-base + 32-bit-offset form
     uint32_t keep[2];  // per entry: 0xffff / 0xffff0000 bits set where the pixel exists
     uint32_t fill[2];  // per entry: neutral value in the halves that do not exist
 };
@@ -160,8 +160,8 @@ __device__ __forceinline__ LaneCols lane_cols(int col0, int w, bool second, uint
     for (int e = 0; e < 2; ++e) {
         const int ca = col0 + 64 * e, cb = ca + 64;
         const bool va = ca >= 0 && ca < w && (e == 0 || second), vb = cb >= 0 && cb < w && (e == 0 || second);
-        c.off[2 * e] = min(max(ca, 0), w - 1);
-        c.off[2 * e + 1] = min(max(cb, 0), w - 1);
+        c.off[2 * e] = (uint32_t)min(max(ca, 0), w - 1);
+        c.off[2 * e + 1] = (uint32_t)min(max(cb, 0), w - 1);
         c.keep[e] = (va ? 0xffffu : 0u) | (vb ? 0xffff0000u : 0u);
         c.fill[e] = (va ? 0u : n8) | (vb ? 0u : (n8 << 16));
     }
@@ -170,6 +170,15 @@ __device__ __forceinline__ LaneCols lane_cols(int col0, int w, bool second, uint
 
 __device__ __forceinline__ uint32_t fetch_entry(const uint8_t* __restrict__ row, const LaneCols& c, int e) {
     const uint32_t a = row[c.off[2 * e]], b = row[c.off[2 * e + 1]];
+    return ((a | (b << 16)) & c.keep[e]) | c.fill[e];
+}
+
+// The same entry through a buffer descriptor of the frame's plane: buffer_load_ubyte takes the descriptor, a 32-bit
+// lane offset and a scalar row offset, so a load costs no VALU address arithmetic (the flat form pays one 64-bit
+// add per load) and the row base is one s_mul instead of a 64-bit pointer computation.
+__device__ __forceinline__ uint32_t fetch_entry(__amdgpu_buffer_rsrc_t plane, int row_off, const LaneCols& c, int e) {
+    const uint32_t a = __builtin_amdgcn_raw_buffer_load_b8(plane, (int)c.off[2 * e], row_off, 0);
+    const uint32_t b = __builtin_amdgcn_raw_buffer_load_b8(plane, (int)c.off[2 * e + 1], row_off, 0);
     return ((a | (b << 16)) & c.keep[e]) | c.fill[e];
 }
 
@@ -555,11 +564,16 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
 
     const int y_first = yb0 - R, y_last = yb1 - 1 + R;
     const LaneCols cols = lane_cols(x0 - R + lane, g.w, lane + 64 < 64 + 2 * R, DIL ? 0u : 0xffu);
-    auto row_ptr = [&](int y) { return s + (size_t)min(max(y, 0), g.h - 1) * g.w; };
+    constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle
+    const int plane_bytes = g.h * g.w;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s), 0, plane_bytes, RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, plane_bytes, RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t min_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(m ? m : s), 0, plane_bytes, RSRC_RAW);
+    auto row_ptr = [&](int y) { return __mul24(min(max(y, 0), g.h - 1), g.w); };   // byte offset of the (clamped) row: wave-uniform
     auto rows_ok = [&](int y) { return y >= 0 && y < g.h; };
     // software prefetch: raw entries of the next row pair, minuend of the next output row pair
-    uint32_t ea0 = fetch_entry(row_ptr(y_first), cols, 0), ea1 = fetch_entry(row_ptr(y_first), cols, 1);
-    uint32_t eb0 = fetch_entry(row_ptr(y_first + 1), cols, 0), eb1 = fetch_entry(row_ptr(y_first + 1), cols, 1);
+    uint32_t ea0 = fetch_entry(src_rs, row_ptr(y_first), cols, 0), ea1 = fetch_entry(src_rs, row_ptr(y_first), cols, 1);
+    uint32_t eb0 = fetch_entry(src_rs, row_ptr(y_first + 1), cols, 0), eb1 = fetch_entry(src_rs, row_ptr(y_first + 1), cols, 1);
     uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // minuend (xa, xb) of output rows y and y+1
     uint32_t mhold = 0;
     const uint32_t out_wr = (uint32_t)(uintptr_t)(s_out[wv] + (WIDE ? 2 * lane : 0));         // LDS offsets
@@ -574,7 +588,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
             v = sub_sat16(me, ve) | (sub_sat16(mo, vo) << 8);
         }
         const int yo = yp + (lane >> 5);
-        if (yo >= yb0 && yo < yb1 && wcol < g.w) *reinterpret_cast<uint32_t*>(d + (uint32_t)(__mul24(yo, g.w) + wcol)) = v;
+        if (yo >= yb0 && yo < yb1 && wcol < g.w) __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, __mul24(yo, g.w) + wcol, 0, 0);
     };
     for (int yy = y_first; yy <= y_last; yy += 2) {
         const bool ina = rows_ok(yy), inb = rows_ok(yy + 1);
@@ -583,10 +597,10 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         chain[MARGIN + lane] = e_pa;             // only the half-width-0 window still reads plane 0
         chain[MARGIN + lane + 64] = e_pb;
         wave_lds_fence();
-        ea0 = fetch_entry(row_ptr(yy + 2), cols, 0);
-        ea1 = fetch_entry(row_ptr(yy + 2), cols, 1);
-        eb0 = fetch_entry(row_ptr(yy + 3), cols, 0);
-        eb1 = fetch_entry(row_ptr(yy + 3), cols, 1);
+        ea0 = fetch_entry(src_rs, row_ptr(yy + 2), cols, 0);
+        ea1 = fetch_entry(src_rs, row_ptr(yy + 2), cols, 1);
+        eb0 = fetch_entry(src_rs, row_ptr(yy + 3), cols, 0);
+        eb1 = fetch_entry(src_rs, row_ptr(yy + 3), cols, 1);
         const int y = yy - R;                       // output rows y and y+1 complete in this iteration
         const uint32_t ca0 = ma0, cb0 = mb0, ca1 = ma1, cb1 = mb1;
         const uint32_t mprev = mhold;   // WIDE: minuend of rows y-2, y-1 (stored in this iteration)
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         if (m) {
             if (WIDE) {   // lane <-> row y + (lane >> 5), columns x0 + 4 (lane & 31) .. + 3: the layout of the dword store
                 const int mr = min(max(y + 2 + (lane >> 5), 0), g.h - 1);
-                ma0 = *reinterpret_cast<const uint32_t*>(m + (uint32_t)(__mul24(mr, g.w) + wcol_c));
+                ma0 = __builtin_amdgcn_raw_buffer_load_b32(min_rs, __mul24(mr, g.w) + wcol_c, 0, 0);
             } else {
                 const uint8_t* r0 = m + (size_t)min(max(y + 2, 0), g.h - 1) * g.w;
                 const uint8_t* r1 = m + (size_t)min(max(y + 3, 0), g.h - 1) * g.w;
