@@ -217,20 +217,34 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
             w10[i] = (gx * fy) & 0x7ffu;
             w11[i] = (fx * fy) & 0x7ffu;
         }
+        // Taps and outputs go through buffer descriptors of this walk's frames: descriptor + 32-bit lane offset +
+        // scalar frame offset, so no access pays a 64-bit VALU address add (11 of ~200 VALU instructions per frame).
+        constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle
+        const int nz = z1 - z0, und_stride_b = (int)(und_stride_px * 4);
+        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(und + (size_t)z0 * und_stride_px), 0, nz * und_stride_b, RSRC_RAW);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(planeR + (size_t)z0 * plane_stride, 0, nz * (int)plane_stride, RSRC_RAW);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(planeB + (size_t)z0 * plane_stride, 0, nz * (int)plane_stride, RSRC_RAW);
+        auto tap2 = [&](int byte_off, int frame_off) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b64(urs, byte_off, frame_off, 0);
+            return Tap2{v[0], v[1]};
+        };
+        int toff[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) toff[i] = off[i] * 4;
+        const int row_b = g.img_w * 4, out_off = (int)qi * 4;
         Tap2 top[4], bot[4];
-        const uint32_t* src = und + (size_t)z0 * und_stride_px;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            top[i] = *reinterpret_cast<const Tap2*>(src + off[i]);
-            bot[i] = *reinterpret_cast<const Tap2*>(src + off[i] + g.img_w);
+            top[i] = tap2(toff[i], 0);
+            bot[i] = tap2(toff[i] + row_b, 0);
         }
         for (int z = z0; z < z1; ++z) {
             Tap2 ntop[4], nbot[4];
-            const uint32_t* nsrc = und + (size_t)min(z + 1, z1 - 1) * und_stride_px;
+            const int nfo = (min(z + 1, z1 - 1) - z0) * und_stride_b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ntop[i] = *reinterpret_cast<const Tap2*>(nsrc + off[i]);
-                nbot[i] = *reinterpret_cast<const Tap2*>(nsrc + off[i] + g.img_w);
+                ntop[i] = tap2(toff[i], nfo);
+                nbot[i] = tap2(toff[i] + row_b, nfo);
             }
             uint32_t outR = 0, outB = 0;
 #pragma unroll
@@ -248,8 +262,8 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
                 outR |= ((uint32_t)r & 255u) << (8 * i);
                 outB |= ((uint32_t)b & 255u) << (8 * i);
             }
-            reinterpret_cast<uint32_t*>(planeR + (size_t)z * plane_stride)[qi] = outR;
-            reinterpret_cast<uint32_t*>(planeB + (size_t)z * plane_stride)[qi] = outB;
+            __builtin_amdgcn_raw_buffer_store_b32(outR, rrs, out_off, (z - z0) * (int)plane_stride, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(outB, brs, out_off, (z - z0) * (int)plane_stride, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 top[i] = ntop[i];
