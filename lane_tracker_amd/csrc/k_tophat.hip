@@ -352,7 +352,8 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         // lanes' registers, one whole-wave DPP shift away; lane 63's right neighbour is entry 64 (lane 0's second
         // entry) and lane 0's left neighbour of entry 64 is entry 63 -- the rotates deliver exactly those.  Entries
         // 0 and 127 get a wrong neighbour, and are outside every window that is ever consumed.
-        auto dpp = [](auto ctrl, uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); };
+        // no "old" operand (lanes without a source are overridden below): the move needs no copy of v into its destination first
+        auto dpp = [](auto ctrl, uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, decltype(ctrl)::value, 0xf, 0xf, true); };
         using SHL = std::integral_constant<int, 0x130>; using ROL = std::integral_constant<int, 0x134>;
         using SHR = std::integral_constant<int, 0x138>; using ROR = std::integral_constant<int, 0x13c>;
         const uint2 u = make_uint2(dpp(ROL{}, e_pb.x), dpp(ROL{}, e_pb.y));      // lane i <- second entry of lane i + 1
