@@ -591,7 +591,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         const int yo = yp + (lane >> 5);
         if (yo >= yb0 && yo < yb1 && wcol < g.w) __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, __mul24(yo, g.w) + wcol, 0, 0);
     };
-    for (int yy = y_first; yy <= y_last; yy += 2) {
+    auto row_pair = [&](int yy) __attribute__((always_inline)) {
         const bool ina = rows_ok(yy), inb = rows_ok(yy + 1);
         const uint2 e_pa = make_uint2(ina ? (ea0 | BIAS2) : NEUTRAL, inb ? (eb0 | BIAS2) : NEUTRAL);
         const uint2 e_pb = make_uint2(ina ? (ea1 | BIAS2) : NEUTRAL, inb ? (eb1 | BIAS2) : NEUTRAL);
@@ -659,9 +659,19 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
                 if (vb) d[o + xb] = (uint8_t)ob_v;
             }
         }
+    };
+    // 55x55: two row pairs per loop iteration.  The vertical pipeline A moves by two registers per row pair; with one
+    // pair per iteration the staged update order (outer rows first) left 11 register copies at the loop's back edge,
+    // with two the second pair lands in the first one's registers.  An odd pair count runs one pair past the band
+    // (loads are clamped, stores predicated).
+    constexpr int PAIRS = (LT_FUSED55 && K == 55) ? 2 : 1;
+    const int npairs = (y_last - y_first) / 2 + 1, pairs_run = (npairs + PAIRS - 1) / PAIRS * PAIRS;
+    for (int yy = y_first; yy <= y_last; yy += 2 * PAIRS) {
+        row_pair(yy);
+        if (PAIRS == 2) row_pair(yy + 2);
     }
     if (WIDE) {   // the last row pair is still in s_out
-        const int yl = y_first + ((y_last - y_first) & ~1) - R;
+        const int yl = y_first + 2 * (pairs_run - 1) - R;
         if (yl + 1 >= yb0 && yl < yb1) {
             unsigned long long q;
             out_issue(q);
