@@ -206,6 +206,11 @@ int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const
                            int16_t* spans);
 /* annotated frames, RGB interleaved, n * img_h * img_w * 3 bytes */
 int  lt_download_overlay(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+/* Page-locked host memory for buffers passed to the upload / download entry points (copies from or to pageable
+ * memory run at a fraction of the PCIe rate).  Needs a GPU; lt_host_free(NULL) is a no-op.  The reference has no
+ * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */
+int  lt_host_alloc(size_t bytes, void** out);
+int  lt_host_free(void* p);
 /* the bird's-eye RGB image of the slots' frames (lane_tracker.py:834, :1035): n * warp_h * warp_w * 3;
  * needs lt_mask_run on those slots first (it reuses their undistorted rows) */
 int  lt_download_bev(lt_ctx* ctx, int first_slot, int n, uint8_t* out);

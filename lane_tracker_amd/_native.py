@@ -89,6 +89,8 @@ _SIGNATURES = {
     "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "lt_download_overlay": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_bev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "lt_host_free": (C.c_int, [_P]),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
@@ -151,6 +153,52 @@ def _check(rc):
         if rc == -1:
             raise ValueError(msg)
         raise NativeError(f"lane_tracker_amd error {rc}: {msg}")
+
+
+class _PinnedPool:
+    """Page-locked host blocks behind NumPy arrays (lt_host_alloc).  An array handed out keeps its block until
+    the array and every view of it are gone; the block then goes back to the pool (or to the driver once the pool
+    holds enough of that size).  Beyond `limit` bytes outstanding, or when the allocation fails, callers get a
+    plain NumPy array -- slower copies, same results."""
+
+    def __init__(self, limit=1 << 30, keep_per_size=4):
+        self.limit, self.keep = limit, keep_per_size
+        self.free, self.outstanding = {}, 0
+
+    def empty(self, shape, dtype=np.uint8):
+        import weakref
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        if nbytes == 0 or self.outstanding + nbytes > self.limit:
+            return np.empty(shape, dtype)
+        blocks = self.free.get(nbytes)
+        if blocks:
+            ptr = blocks.pop()
+        else:
+            out = C.c_void_p()
+            if load().lt_host_alloc(nbytes, C.byref(out)) != 0 or not out.value:
+                return np.empty(shape, dtype)
+            ptr = out.value
+        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        self.outstanding += nbytes
+        fin = weakref.finalize(buf, self._release, nbytes, ptr)
+        fin.atexit = False                       # at interpreter exit the driver reclaims everything
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def _release(self, nbytes, ptr):
+        self.outstanding -= nbytes
+        blocks = self.free.setdefault(nbytes, [])
+        if len(blocks) < self.keep:
+            blocks.append(ptr)
+        else:
+            load().lt_host_free(ptr)
+
+
+_pinned = _PinnedPool()
+
+
+def pinned_empty(shape, dtype=np.uint8):
+    """An uninitialised array in page-locked host memory (falls back to np.empty)."""
+    return _pinned.empty(shape, dtype)
 
 
 def _u8(a, shape_tail=None):
@@ -317,12 +365,12 @@ class Context:
                                         int(step)))
 
     def download_overlay(self, n, first=0):
-        out = np.empty((n, self.img_h, self.img_w, 3), np.uint8)
+        out = pinned_empty((n, self.img_h, self.img_w, 3))
         _check(self.lib.lt_download_overlay(self._h, first, n, out.ctypes.data))
         return out
 
     def download_bev(self, n, first=0):
-        out = np.empty((n, self.warp_h, self.warp_w, 3), np.uint8)
+        out = pinned_empty((n, self.warp_h, self.warp_w, 3))
         _check(self.lib.lt_download_bev(self._h, first, n, out.ctypes.data))
         return out
 

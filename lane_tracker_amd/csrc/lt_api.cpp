@@ -956,6 +956,29 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
     return LT_OK;
 }
 
+// Page-locked host memory for the buffers a caller hands to the upload / download entry points: a copy from or to
+// pageable memory is staged by the runtime at a fraction of the PCIe rate (2.8 MB annotated frame: ~0.3 ms against
+// ~0.06 ms).  Plain allocation helpers: no context, usable as soon as a device exists.
+int lt_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(LT_ERR_INVALID, "lt_host_alloc: null output or zero size");
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return fail(LT_ERR_HIP, "hipHostMalloc(%zu) failed", bytes);
+    }
+    return LT_OK;
+}
+
+int lt_host_free(void* p) {
+    if (!p) return LT_OK;
+    if (hipHostFree(p) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(LT_ERR_HIP, "hipHostFree failed");
+    }
+    return LT_OK;
+}
+
 int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;

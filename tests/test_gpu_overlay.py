@@ -258,3 +258,31 @@ def test_overlay_text_matches_the_atlas_blend(nat, cal):
         assert (out[1] == 255).any()                           # fully opaque glyph cores on the black frame
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_pinned_pool_hands_out_writable_arrays_and_reuses_blocks():
+    """lt_host_alloc behind NumPy arrays: writable, correctly shaped, the block returns to the pool when the
+    array and its views are gone, and download_overlay results live in such arrays."""
+    import gc
+    from lane_tracker_amd import _native
+    pool = _native._PinnedPool(limit=64 << 20, keep_per_size=2)
+    a = pool.empty((3, 5, 7, 3))
+    a[...] = 7
+    view = a[1]
+    assert a.shape == (3, 5, 7, 3) and a.dtype == np.uint8 and a.flags.writeable and int(view.sum()) == 7 * 5 * 7 * 3
+    nbytes = a.nbytes
+    assert pool.outstanding == nbytes
+    del a
+    gc.collect()
+    assert pool.outstanding == nbytes                  # the view still holds the block
+    del view
+    gc.collect()
+    assert pool.outstanding == 0 and len(pool.free[nbytes]) == 1
+    b = pool.empty((3, 5, 7, 3))
+    assert pool.free[nbytes] == [] and pool.outstanding == nbytes       # reused, not reallocated
+    big = pool.empty((65 << 20,))                      # over the limit: a plain array, not an error
+    assert big.shape == (65 << 20,) and pool.outstanding == nbytes
+    del b, big
+    gc.collect()
+    assert _native.load().lt_host_free(None) == 0

@@ -50,5 +50,14 @@ for name, cal in (("1280x720", calib.reference_calibration()), ("1920x1080_confi
     for _ in range(3):
         lt.process_batch(frames[32:])
     out2[name]["process_batch_fps_annotated"] = round(96 / (time.perf_counter() - t0), 1)
+    # the same with the input frames in page-locked memory (what lane_tracker_amd.video.FrameSource hands over)
+    from lane_tracker_amd._native import pinned_empty
+    pf = pinned_empty((len(frames),) + frames[0].shape)
+    pf[...] = np.stack(frames, 0)
+    lt.process_batch(pf[:32])
+    t0 = time.perf_counter()
+    for _ in range(3):
+        lt.process_batch(pf[32:])
+    out2[name]["process_batch_fps_annotated_pinned_input"] = round(96 / (time.perf_counter() - t0), 1)
     lt.close()
 print(json.dumps(out2))
