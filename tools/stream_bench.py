@@ -11,7 +11,7 @@ from lane_tracker_amd.lane_tracker import LaneTracker
 out = {}
 for name, cal in (("1280x720", calib.reference_calibration()), ("1920x1080_config5", calib.scaled_calibration(1.5))):
     frames = synth.stream_lanes(40, seed=5, cal=cal)
-    frames = frames + frames[::-1] + frames + frames[::-1] + frames      # 200 frames, smooth at the turning points
+    frames = np.concatenate([frames, frames[::-1], frames, frames[::-1], frames], 0)      # 200 frames, smooth at the turning points
     lt = LaneTracker(**cal)
     for f in frames[:5]:
         lt.process(f)
