@@ -47,7 +47,25 @@ def cpu_baseline(frames, cal, max_seconds=25.0):
     with ThreadPoolExecutor(cores) as ex:               # ctypes releases the GIL
         list(ex.map(lambda f: O.frame_sws_fit(oc, f), [frames[i] for i in range(n)]))
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+
+    def ms(fn, *args):                                  # one call on one thread
+        t = time.perf_counter()
+        r = fn(*args)
+        return r, round((time.perf_counter() - t) * 1e3, 2)
+    f0 = frames[0]
+    und, t_und = ms(O.undistort, oc, f0)
+    bev, t_warp = ms(O.warp, oc, und)
+    R = np.ascontiguousarray(bev[:, :, 0])
+    b, t_lab = ms(O.lab_b, bev)
+    tr, t_th29 = ms(O.tophat, R, 29)
+    tb, t_th55 = ms(O.tophat, b, 55)
+    _, t_thr = ms(lambda: (O.bilateral_adaptive_threshold(tr, 15, 8), O.bilateral_adaptive_threshold(tb, 35, 5)))
+    mask, _ = ms(O.mask_from_frame, oc, f0)
+    _, t_open = ms(O.morph_open, mask, 5)
+    (_, _, _), t_sws = ms(lambda: (O.sliding_window_search(mask), None, None))
+    stages = {"undistort": t_und, "warp": t_warp, "lab_b": t_lab, "tophat_r29": t_th29, "tophat_b55": t_th55,
+              "thresholds": t_thr, "open5": t_open, "sliding_window_search+fit": t_sws}
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "stage_ms_one_thread": stages,
             "sample": "%d of the same synthetic frames through oracle/lt_oracle.c (mask + sliding window + fit), one frame "
                       "per thread on %d threads (%d CPUs visible); single-thread %.1f ms/frame = %.1f frames/s, so the "
                       "threaded run is %.1fx one thread" % (n, cores, avail, one * 1e3, 1.0 / one, (n / dt) * one)}
