@@ -487,7 +487,11 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
                     constexpr int t = decltype(tc)::value;
                     const uint32_t thr = pk_mad(P, kk, nck);
                     const uint32_t m = pk_sub(pk_max(su, sd), thr);
-                    const unsigned long long bal0 = __ballot((int16_t)(m & 0xffffu) < 0), bal1 = __ballot((int32_t)m < 0);
+                    // sign of the low half in ONE compare (v_cmp_gt_i16 looks at bits 15:0); written in C the
+                    // compiler extracts bit 15 first (v_bfe_u32 + v_cmp_ne_u32)
+                    unsigned long long bal0;
+                    asm("v_cmp_gt_i16_e64 %0, 0, %1" : "=s"(bal0) : "v"(m));
+                    const unsigned long long bal1 = __ballot((int32_t)m < 0);
                     write_lane_words<t>(m0l, m0h, m1l, m1h, bal0, bal1);
                     if (decltype(with_range)::value) {   // inRange(lab_b, noise_thresh, 255) on the raw plane
                         const unsigned long long r0 = __ballot((int)(P & 0xffffu) >= a.noise_thresh),

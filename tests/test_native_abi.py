@@ -146,3 +146,17 @@ int main(void) {
     env["LD_LIBRARY_PATH"] = lib_dir + os.pathsep + "/opt/rocm/lib" + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     r = subprocess.run([str(exe)], capture_output=True, text=True, env=env)
     assert r.returncode == 0 and "abi ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_pinned_empty_falls_back_to_pageable_memory_without_gpu():
+    """lt_host_alloc needs a device; without one the pool hands out a plain array (same shape and dtype) and
+    the library reports the failure instead of crashing."""
+    import ctypes as C
+    from lane_tracker_amd import _native
+    a = _native.pinned_empty((4, 6, 3))
+    assert a.shape == (4, 6, 3) and a.dtype == np.uint8 and a.flags.writeable
+    out = C.c_void_p()
+    assert _native.load().lt_host_alloc(64, C.byref(out)) != 0 and not out.value
+    assert _native.load().lt_host_alloc(0, C.byref(out)) != 0
+    assert _native.load().lt_host_free(None) == 0
