@@ -2,13 +2,20 @@
 """Headline benchmark: frames/s of the per-frame hot path on synthetic 1280x720 frames, plus the
 achieved HBM GB/s of the warp+threshold stage against the MI355X memory roofline.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
 
-One step = one pass of the hot path over one batch of 256 independent frames per GPU
-(BASELINE config 3: undistort -> warp -> filter_lane_points -> sliding_window_search (26 levels) ->
-fit_poly), frames resident in HBM before the timed region.  N GPUs: frames sharded, no data-path
-collective, one RCCL all-gather of the 64-byte lane records per step ("scaling": "weak").
-Prints ONE JSON line on rank 0.
+N > 1 without a launcher: this process stays off the GPU and starts N rank processes itself (one per GPU).
+Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks are already there
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment).  Either way the ranks talk through `lt_gather_*` of the C ABI
+(RCCL over xGMI); PyTorch is not imported.  A rank count that does not match --gpus, or more ranks than visible
+GPUs, is an error -- never a silent single-GPU run.
+
+One step = one pass of the hot path over the rank's frames, resident in HBM before the timed region
+(undistort -> warp -> filter_lane_points -> sliding_window_search (26 levels) -> fit_poly):
+  default        BASELINE config 3: 256 independent frames per GPU per step           ("scaling": "weak")
+  --frames 4096  BASELINE config 4: a 4096-frame stream sharded over the GPUs          ("scaling": "strong")
+No data-path collective; every step's 64-byte lane records are staged device to device and the timed region ends
+with ONE RCCL all-gather of all of them.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -26,10 +33,46 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling, same guide
 MASK_STAGES = ["undistort_rows", "warp_split", "erode_r29", "tophat_r29", "erode_b55", "tophat_b55", "threshold",
                "merge", "open5"]
+PROFILE_TAG = "r02"            # profiles/<tag>_traffic.json, <tag>_valu_issue.json: committed counter / calibration runs
 
 
-def cpu_baseline(frames, cal, max_seconds=25.0):
-    """The oracle (CPU port of the same path) on a bounded sample of the same workload, all host cores."""
+def _render_one(i):
+    from lane_tracker_amd import synth
+    global _RENDERER
+    try:
+        r = _RENDERER
+    except NameError:
+        r = _RENDERER = synth.SceneRenderer()
+    return r.render(i)[0]
+
+
+def render_frames(indices):
+    """Fresh synthetic scene per frame index (lane_tracker_amd/synth.py), rendered on the host cores BEFORE this
+    process touches the GPU (worker processes are forked)."""
+    indices = list(indices)
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    workers = max(1, min(32, cpus // max(world, 1), len(indices)))
+    if workers == 1:
+        return np.stack([_render_one(i) for i in indices], 0)
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(workers) as ex:
+        return np.stack(list(ex.map(_render_one, indices, chunksize=max(1, len(indices) // (workers * 4)))), 0)
+
+
+def coeff_close(got, want, h=1100, tol=1e-4):
+    """north_star tolerance: 1e-4 relative per coefficient with the absolute floor of SURVEY 8(a)."""
+    lim = tol * max(1.0, abs(float(want[2])))
+    return (abs(got[0] - want[0]) * h * h <= lim and abs(got[1] - want[1]) * h <= lim and abs(got[2] - want[2]) <= lim)
+
+
+def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
+    """The oracle (CPU port of the same path) on a bounded sample of the same workload, all host cores -- and, since
+    its results are there anyway, the in-run parity check of the GPU records and masks against them."""
+    import zlib
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
     oc = O.make_calib(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0])
@@ -45,8 +88,25 @@ def cpu_baseline(frames, cal, max_seconds=25.0):
     n = int(min(len(frames), max(cores, (max_seconds * cores) / max(one, 1e-3) * 0.5)))
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:               # ctypes releases the GIL
-        list(ex.map(lambda f: O.frame_sws_fit(oc, f), [frames[i] for i in range(n)]))
+        want = list(ex.map(lambda f: O.frame_sws_fit(oc, f), [frames[i] for i in range(n)]))
     dt = time.perf_counter() - t0
+
+    # ---- parity: GPU records of the same frames vs the oracle's; masks of a subset bit for bit ----
+    bad = []
+    for i, w in enumerate(want):
+        g = gpu_records[i]
+        ok = bool(g["detected"]) == w["detected"] and (int(g["n_left"]), int(g["n_right"])) == (w["n_left"], w["n_right"])
+        if ok and w["detected"]:
+            ok = coeff_close(g["left_coeffs"], w["coeffs"][0]) and coeff_close(g["right_coeffs"], w["coeffs"][1])
+        if not ok:
+            bad.append(i)
+    n_masks = min(n, 32)
+    with ThreadPoolExecutor(cores) as ex:
+        crc = list(ex.map(lambda i: zlib.crc32(O.mask_from_frame(oc, frames[i]).tobytes()), range(n_masks)))
+    mask_bad = [i for i in range(n_masks) if zlib.crc32(gpu_mask_of(i).tobytes()) != crc[i]]
+    parity = {"parity_checked": n, "record_mismatches": len(bad), "masks_checked_bit_exact": n_masks,
+              "mask_mismatches": len(mask_bad), "first_bad": (bad + mask_bad)[:4],
+              "rule": "detected flag and lane-pixel counts equal, coefficients within 1e-4 (SURVEY 8(a) floor); masks by CRC32"}
 
     def ms(fn, *args):                                  # one call on one thread
         t = time.perf_counter()
@@ -65,10 +125,62 @@ def cpu_baseline(frames, cal, max_seconds=25.0):
     (_, _, _), t_sws = ms(lambda: (O.sliding_window_search(mask), None, None))
     stages = {"undistort": t_und, "warp": t_warp, "lab_b": t_lab, "tophat_r29": t_th29, "tophat_b55": t_th55,
               "thresholds": t_thr, "open5": t_open, "sliding_window_search+fit": t_sws}
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "stage_ms_one_thread": stages,
-            "sample": "%d of the same synthetic frames through oracle/lt_oracle.c (mask + sliding window + fit), one frame "
-                      "per thread on %d threads (%d CPUs visible); single-thread %.1f ms/frame = %.1f frames/s, so the "
-                      "threaded run is %.1fx one thread" % (n, cores, avail, one * 1e3, 1.0 / one, (n / dt) * one)}
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "stage_ms_one_thread": stages,
+           "sample": "%d of the same synthetic frames through oracle/lt_oracle.c (mask + sliding window + fit), one frame "
+                     "per thread on %d threads (%d CPUs visible); single-thread %.1f ms/frame = %.1f frames/s, so the "
+                     "threaded run is %.1fx one thread" % (n, cores, avail, one * 1e3, 1.0 / one, (n / dt) * one)}
+    try:   # the reference's own NumPy stages (a5-a8), timed in the build container where the reference can be imported
+        out["reference_numpy_container"] = json.load(open(os.path.join(ROOT, "profiles", "reference_numpy_timings.json")))
+    except Exception:
+        pass
+    return out, parity
+
+
+def host_fed_overlapped(cal, frames, fp, sp, streams, resident_records, batches=12):
+    """Double-buffered host-fed pipeline: two page-locked host buffers, the camera rows of batch k+1 cross PCIe on the
+    copy stream while the chain of batch k runs (lt_upload_frame_rows_async).  Returns frames/s, PCIe included."""
+    from lane_tracker_amd import _native
+    B = len(frames)
+    ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
+                          cal["warp_matrices"][0], device=0, capacity=2 * B)
+    try:
+        pin = [_native.pinned_empty(frames.shape), _native.pinned_empty(frames.shape)]
+        pin[0][...] = frames
+        pin[1][...] = frames[::-1]
+        ctx.set_streams(streams)
+
+        def run(nb):
+            for k in range(nb):
+                half = k & 1
+                ctx.upload_frame_rows_async(pin[half], first=half * B)
+                ctx.mask_run(B, fp, first=half * B)
+                ctx.sws_fit_run(B, sp, first=half * B)
+            ctx.sync()
+        run(2)
+        t0 = time.perf_counter()
+        run(batches)
+        dt = time.perf_counter() - t0
+        rec = ctx.download_records(2 * B)
+        same = all(rec[i][f].tobytes() == resident_records[i][f].tobytes() and
+                   rec[B + i][f].tobytes() == resident_records[B - 1 - i][f].tobytes()
+                   for i in range(B) for f in ("left_coeffs", "right_coeffs", "n_left", "n_right", "detected"))
+        return {"overlapped_frames_per_s": round(batches * B / dt, 2), "batches": batches, "frames_per_batch": B,
+                "records_equal_resident_run": bool(same),
+                "how": "two pinned host buffers; rows %d..%d of batch k+1 uploaded on the copy stream under the chain of "
+                       "batch k (slots split in two halves of the context)" % tuple(ctx.source_rows())}
+    finally:
+        ctx.close()
+
+
+def launcher(a):
+    """--gpus N > 1 and no RANK in the environment: start the N ranks.  This process never touches the GPU."""
+    from lane_tracker_amd import distributed
+    have = distributed.visible_gpu_count()
+    if a.gpus > have:
+        print("bench.py: --gpus %d requested but %d GPU(s) visible; refusing to report a %d-GPU number from fewer devices"
+              % (a.gpus, have, a.gpus), file=sys.stderr)
+        return 2
+    return distributed.spawn_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
 
 
 def main():
@@ -76,77 +188,94 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (weak scaling, BASELINE config 3)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="total frames of one stream, sharded over the GPUs (strong scaling; 4096 = BASELINE config 4)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams per context (slot slices overlap each other's stages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true")
     a = ap.parse_args()
+    if a.gpus < 1 or a.steps < 1 or a.warmup < 0:
+        ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = torch = None
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)   # launched by torch.distributed.run
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    in_rank = "RANK" in os.environ
+    if not in_rank and a.gpus > 1:
+        sys.exit(launcher(a))
 
-    from lane_tracker_amd import _native, calib, synth
+    from lane_tracker_amd import _native, calib, distributed
+    rank, local_rank, world = distributed.env_rank()
+    if world != a.gpus:
+        print("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to mislabel the run"
+              % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
     cal = calib.reference_calibration()
-    B = a.batch
-    renderer = synth.SceneRenderer(cal)
-    frames = np.stack([renderer.render(rank * B + i)[0] for i in range(B)], 0)   # fresh scene per frame
+    strong = a.frames > 0
+    if strong:
+        lo, hi = distributed.shard_range(a.frames, rank, world)
+        if a.frames % world:
+            print("bench.py: --frames %d is not a multiple of %d ranks (the one all-gather moves equal blocks)" % (a.frames, world),
+                  file=sys.stderr)
+            sys.exit(2)
+        indices = range(lo, hi)
+    else:
+        indices = range(rank * a.batch, (rank + 1) * a.batch)
+    NL = len(indices)                                   # frames this rank processes per step
+    frames = render_frames(indices)                     # before anything initialises the GPU (forked workers)
 
+    ndev = _native.device_count()
+    if local_rank >= ndev:
+        print("bench.py: rank %d wants GPU %d but %d GPU(s) are visible" % (rank, local_rank, ndev), file=sys.stderr)
+        sys.exit(2)
     ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
-                          cal["warp_matrices"][0], device=local_rank, capacity=B)
+                          cal["warp_matrices"][0], device=local_rank, capacity=NL)
     info = ctx.info()
     t0 = time.perf_counter()
-    ctx.upload_frames(frames)
+    for c0 in range(0, NL, 256):
+        ctx.upload_frames(frames[c0:c0 + 256], first=c0)
     h2d_s = time.perf_counter() - t0
     t0 = time.perf_counter()
-    ctx.upload_frame_rows(frames)                 # what a host-fed pipeline moves: the rows the path reads
+    for c0 in range(0, NL, 256):
+        ctx.upload_frame_rows(frames[c0:c0 + 256], first=c0)   # what a host-fed pipeline moves: the rows the path reads
     h2d_rows_s = time.perf_counter() - t0
-    ctx.set_frame_base(B, rank * B)
+    ctx.set_frame_base(NL, indices[0])
     fp, sp = _native.filter_params(), _native.search_params()
 
-    # N > 1: every step's records go, stream-ordered and without a host wait, into one send buffer; the timed
-    # region ends with ONE RCCL all-gather of all of them (the path has no other exchange step)
-    gather_buf = send_buf = None
+    # ranks: every step's records are staged, stream-ordered and without a host wait, into the gather's send buffer;
+    # the timed region ends with ONE RCCL all-gather of all of them (the path has no other exchange step)
     nsteps = max(a.steps, a.warmup, 1)
-    if use_dist:
-        send_buf = torch.empty(nsteps * B * 64, dtype=torch.uint8, device="cuda")
-        gather_buf = torch.empty(world * nsteps * B * 64, dtype=torch.uint8, device="cuda")
-        torch.cuda.synchronize()
+    gather = None
+    if in_rank:
+        gather = distributed.init_gather(ctx)
+        gather.reserve(nsteps * NL)
 
     def step(k=0):
-        ctx.mask_run(B, fp)
-        ctx.sws_fit_run(B, sp)
-        if use_dist:
-            ctx.enqueue_records_to_device(B, send_buf.data_ptr() + k * B * 64)
+        ctx.mask_run(NL, fp)
+        ctx.sws_fit_run(NL, sp)
+        if gather is not None:
+            gather.stage(NL, at=k * NL)
 
     marks = {}
+    gathered = [None]
 
-    def fence(gather=False):
+    def fence(n_gather=0):
         ctx.sync()
         marks["drained"] = time.perf_counter()
-        if use_dist:
-            if gather:
-                dist.all_gather_into_tensor(gather_buf, send_buf)
-            torch.cuda.synchronize()
+        if gather is not None:
+            if n_gather:
+                gathered[0] = gather.records(n_gather * NL)
             marks["gathered"] = time.perf_counter()
-            dist.barrier()
-            torch.cuda.synchronize()
+            gather.barrier()
         marks["fenced"] = time.perf_counter()
 
     ctx.set_streams(a.streams)
     for k in range(a.warmup):
         step(k)
-    fence(gather=True)
+    fence(a.warmup)
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(k)
-    fence(gather=True)
+    fence(a.steps)
     dt = time.perf_counter() - t0
     if os.environ.get("LT_BENCH_VERBOSE") and rank == 0:
         print("timed region: drained %.3f ms, +gather %.3f ms, +barrier %.3f ms" % (
@@ -161,84 +290,115 @@ def main():
     ctx.stage_reset()
     KS = max(1, min(a.steps, 5))
     for _ in range(KS):
-        ctx.mask_run(B, fp)
-        ctx.sws_fit_run(B, sp)
+        ctx.mask_run(NL, fp)
+        ctx.sws_fit_run(NL, sp)
     ctx.sync()
     stages = ctx.stage_ms()
     ctx.set_stage_timing(False)
 
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        rec_all = np.frombuffer(gather_buf.cpu().numpy().tobytes(), dtype=_native.RECORD_DTYPE).reshape(world, nsteps, B)
-        rec_all = rec_all[:, max(a.steps, 1) - 1, :].reshape(-1)          # the last timed step of every rank
+    my_records = ctx.download_records(NL)
+    if gather is not None:
+        dt = float(gather.host(np.array([dt], np.float64)).max())           # MAX over ranks
+        sizes = gather.host(np.array([NL], np.int64)).reshape(-1)
+        rec_all = gathered[0].reshape(world, a.steps, NL)[:, a.steps - 1, :].reshape(-1)   # last timed step of every rank
+        assert rec_all[rank * NL:(rank + 1) * NL].tobytes() == my_records.tobytes(), "gathered records differ from the rank's own"
+        total_frames = int(sizes.sum())
     else:
-        rec_all = ctx.download_records(B)
+        rec_all, total_frames = my_records, NL
+    if gather is not None:            # the collective part is over: release the communicator before rank 0 reports
+        gather.barrier()
+        gather.close()
 
     if rank == 0:
-        K = max(a.steps, 1)
+        K = a.steps
         ms_step = dt / K * 1e3
-        value = world * B * K / dt
-        mask_ms = sum(stages[s][0] for s in MASK_STAGES) / KS              # per launch of B frames, serial pass
+        value = total_frames * K / dt
+        mask_ms = sum(stages[s][0] for s in MASK_STAGES) / KS              # per launch of NL frames, serial pass
         search_ms = stages["sws_fit"][0] / KS
-        alg = info.alg_bytes_mask * B                                      # algorithmic bytes of the stage per step
+        alg = info.alg_bytes_mask * NL                                     # algorithmic bytes of the stage per launch
         achieved = alg / (mask_ms * 1e-3) / 1e9 if mask_ms > 0 else 0.0
         dom = max(MASK_STAGES, key=lambda s: stages[s][0])
-        traffic = None                                     # HBM bytes per launch of the stage, from the committed PMC run
-        valu_issue = None                                  # and its VALU instruction count (what actually binds the stage)
+        # HBM-side traffic and VALU instruction counts come from a committed rocprofv3 --pmc run of this same command
+        # (profiles/<tag>_traffic.json); they are labelled as such and only attached when the launch shape matches.
+        from_profile = None
+        traffic = None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj["frames_per_launch"] == B and world == 1:
+            tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")))
+            if tj["frames_per_launch"] == NL:
                 traffic = int(tj["mask_stage_traffic_bytes_per_launch"])
+                vi = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu_issue.json")))
+                peak_rate = float(vi["peak_wave_insts_per_cycle_per_simd"])
                 lane_ops = float(tj["mask_stage_valu_wave_insts_per_launch"]) * 64.0
-                peak = info.cu_count * 4 * 16 * 2.4e9            # CUs x SIMDs x lanes/clk x 2.4 GHz
-                valu_issue = {"achieved": round(lane_ops / (mask_ms * 1e-3) / 1e12, 3), "peak": round(peak / 1e12, 3),
-                              "unit": "T lane-ops/s", "frac": round(lane_ops / (mask_ms * 1e-3) / peak, 4),
-                              "note": "SQ_INSTS_VALU of the mask-stage kernels (profiles/r01_traffic.json) x 64 lanes / stage time; "
-                                      "the integer-issue ceiling is what this chain runs against, see DESIGN.md"}
+                peak = info.cu_count * 4 * peak_rate * 64.0 * 2.4e9       # CUs x SIMDs x wave-insts/clk x 64 lanes x 2.4 GHz
+                from_profile = {
+                    "from_profile": PROFILE_TAG, "source": tj.get("source"),
+                    "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": round(traffic / float(alg), 2),
+                    "fetch_write_calibration": tj.get("calibration"),
+                    "valu_issue": {"achieved": round(lane_ops / (mask_ms * 1e-3) / 1e12, 3), "peak": round(peak / 1e12, 3),
+                                   "unit": "T lane-ops/s", "frac": round(lane_ops / (mask_ms * 1e-3) / peak, 4),
+                                   "peak_from": "profiles/%s_valu_issue.json: %s wave64 instructions per cycle per SIMD measured for "
+                                                "the packed-16 / integer instructions of these kernels" % (PROFILE_TAG, peak_rate)}}
         except Exception:
             pass
+        workload = ("BASELINE config 4: %d-frame synthetic stream sharded over %d GPU(s) (%d frames on rank 0), HBM-resident"
+                    % (a.frames, world, NL)) if strong else \
+                   ("BASELINE config 3: batch of %d synthetic lane-like 1280x720 frames per GPU, HBM-resident" % NL)
         out = {
             "metric": "frames/sec at 1280x720 (end-to-end hot path: undistort+warp+filter_lane_points+sliding_window_search+fit_poly)",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: batch of %d synthetic lane-like 1280x720 frames per GPU, HBM-resident; "
-                                   "warp+filter_lane_points chain + sliding_window_search (26 levels) + fit_poly" % B,
-                       "frames_per_gpu_per_step": B, "bev": "1080x1100", "parallelism": "frames sharded x%d" % world,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload + "; warp+filter_lane_points chain + sliding_window_search (26 levels) + fit_poly",
+                       "frames_per_step_all_gpus": total_frames, "frames_per_gpu_per_step": NL, "bev": "1080x1100",
+                       "parallelism": "frames sharded x%d, one process per GPU" % world,
+                       "collective": ("one RCCL all-gather (lt_gather_records) of %d x 64-byte records per rank at the end of the "
+                                      "timed region" % (a.steps * NL)) if gather is not None else "none (single process)",
                        "streams_per_gpu": a.streams,
                        "detected_fraction": round(float(np.mean(rec_all["detected"])), 4)},
             "roofline": {"bound": "hbm", "kernel": "warp+threshold stage (%d kernels: %s)" % (len(MASK_STAGES), ",".join(MASK_STAGES)),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_note": "FETCH_SIZE+WRITE_SIZE of the mask-stage kernels, rocprofv3 --pmc, profiles/r01_traffic.json; "
-                                         "%.1fx the algorithmic bytes because the chain materialises u8 planes between kernels"
-                                         % ((traffic or 0) / float(alg) if alg else 0.0),
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 6),
-                         "alg_bytes_per_frame": int(info.alg_bytes_mask), "frames_per_launch": B,
-                         "stage_ms_per_launch": round(mask_ms, 4), "dominant_kernel": dom, "valu_issue": valu_issue,
-                         "note": "the stage is integer-VALU / LDS-pipe bound (SQ counters in profiles/), not HBM bound; see DESIGN.md"},
+                         "alg_bytes_per_frame": int(info.alg_bytes_mask), "frames_per_launch": NL,
+                         "stage_ms_per_launch": round(mask_ms, 4), "dominant_kernel": dom,
+                         "profile": from_profile,
+                         "note": "achieved = algorithmic bytes / hipEvent time of the stage's kernels, measured in this run; "
+                                 "`traffic` and `profile` are NOT measured in this run: they are the PMC counters of the committed "
+                                 "rocprofv3 run named in profile.from_profile (null when the launch shape differs). The stage is "
+                                 "integer-VALU / LDS bound, not HBM bound; see DESIGN.md"},
             "kernels_ms_per_step": {k: round(v[0] / KS, 4) for k, v in stages.items() if v[1]},
             "timing_note": "value / ms_per_step: %d steps on %d HIP streams per GPU (slot slices overlap: the latency-bound "
                            "search of one slice hides under the mask chain of another). kernels_ms_per_step, roofline and "
                            "search_fit: %d further steps on one stream with hipEvents around every kernel; their sum (%.3f ms) "
                            "is the un-overlapped step" % (a.steps, a.streams, KS, mask_ms + search_ms),
             "search_fit": {"ms_per_step": round(search_ms, 4),
-                           "achieved_GBs": round(info.alg_bytes_search * B / (search_ms * 1e-3) / 1e9, 3) if search_ms > 0 else None},
-            "host_fed": {"h2d_seconds_for_batch": round(h2d_s, 4),
-                         "pcie_inclusive_frames_per_s": round(B / (h2d_s + dt / K), 2),
+                           "achieved_GBs": round(info.alg_bytes_search * NL / (search_ms * 1e-3) / 1e9, 3) if search_ms > 0 else None},
+            "host_fed": {"h2d_seconds_whole_frames": round(h2d_s, 4),
+                         "serial_frames_per_s_whole_frames": round(NL / (h2d_s + dt / K), 2),
                          "h2d_seconds_source_rows_only": round(h2d_rows_s, 4), "source_rows": list(ctx.source_rows()),
-                         "pcie_inclusive_frames_per_s_source_rows_only": round(B / (h2d_rows_s + dt / K), 2)},
+                         "serial_frames_per_s_source_rows_only": round(NL / (h2d_rows_s + dt / K), 2)},
             "device": info.device_name.decode(errors="replace"),
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(frames, cal)
+        single = world == 1 and not strong
+        if single and not a.no_cpu_baseline:
+            masks_cache = {}
+
+            def gpu_mask_of(i):
+                if i not in masks_cache:
+                    masks_cache[i] = ctx.download_masks(1, first=i)[0]
+                return masks_cache.pop(i)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(frames, cal, rec_all, gpu_mask_of)
+        ctx.close()
+        ctx = None
+        if single and not a.no_host_fed:
+            try:
+                out["host_fed"].update(host_fed_overlapped(cal, frames, fp, sp, a.streams, rec_all))
+            except Exception as e:   # the resident number stands on its own
+                out["host_fed"]["overlapped_error"] = repr(e)
         print(json.dumps(out))
-    ctx.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

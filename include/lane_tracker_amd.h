@@ -120,6 +120,11 @@ int  lt_upload_frames(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, in
  * those rows: enough for lt_mask_run and the searches, not for lt_overlay_run, which shows the whole frame. */
 int  lt_get_source_rows(lt_ctx* ctx, int* row0, int* row1);
 int  lt_upload_frame_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
+/* The same rows without the host wait: the copy is enqueued on the context's copy stream behind the work already
+ * enqueued for these slots, and everything enqueued for them afterwards waits for it -- the upload of one slot range
+ * runs under the chain of the others (double-buffered host-fed pipeline).  frames_rgb must stay valid (and should be
+ * page-locked, lt_host_alloc) until the next lt_sync. */
+int  lt_upload_frame_rows_async(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
 /* The complement: every other row of the same frames, enqueued on a copy stream of its own so that it runs beside
  * the mask chain (call it after lt_mask_run).  The host buffer must stay valid until the next lt_sync or download;
  * lt_overlay_run waits for it. */
@@ -214,6 +219,33 @@ int  lt_host_free(void* p);
 /* the bird's-eye RGB image of the slots' frames (lane_tracker.py:834, :1035): n * warp_h * warp_w * 3;
  * needs lt_mask_run on those slots first (it reuses their undistorted rows) */
 int  lt_download_bev(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+
+/* ---- multi-GPU: the gather of the lane records ------------------------------------------------------ */
+/* Independent frames shard over the GPUs of one node by contiguous index blocks with no data-path exchange
+ * (SURVEY 8(e)); the only collective is this all-gather of the 64-byte lane records, run on RCCL (librccl.so is
+ * opened by lt_gather_init, so single-GPU users never load it).  The reference has no counterpart: it is one
+ * Python process (process_video.py:41-44).  One lt_gather per rank = per process = per GPU, bound to the
+ * context whose records it moves.
+ *
+ * lt_gather_init: rank 0 creates the RCCL id and publishes it at id_path (temporary name + rename); the other
+ * ranks wait up to timeout_s (<= 0: 120 s) for that file.  Every rank of the job must call it (collective). */
+typedef struct lt_gather lt_gather;
+int  lt_gather_init(lt_ctx* ctx, int rank, int world, const char* id_path, int timeout_s, lt_gather** out);
+int  lt_gather_world(lt_gather* g, int* rank, int* world);
+/* staging capacity: records per rank (e.g. steps * frames per step); identical on every rank */
+int  lt_gather_reserve(lt_gather* g, int records_per_rank);
+/* Copy the records of context slots [first_slot, first_slot + n) to position `at` of the send buffer,
+ * enqueued behind the slots' searches on the context's streams -- no host wait. */
+int  lt_gather_stage(lt_gather* g, int first_slot, int n, int at);
+/* ONE ncclAllGather of the first n_records staged records of every rank (the same n_records everywhere; pad
+ * uneven shards), after the context's streams have drained the staged copies.  out_host receives
+ * world * n_records records, rank-major.  Collective; synchronises. */
+int  lt_gather_records(lt_gather* g, int n_records, lt_lane_record* out_host);
+/* All-gather of `bytes` host bytes per rank (timings, checksums): out holds world * bytes.  Collective. */
+int  lt_gather_host(lt_gather* g, const void* in, size_t bytes, void* out);
+/* lt_sync of the bound context, then a collective round trip: no rank returns before every rank has arrived */
+int  lt_gather_barrier(lt_gather* g);
+void lt_gather_destroy(lt_gather* g);
 
 /* ---- measurement ------------------------------------------------------------------------------ */
 /* hipEvent pair on the context's stream */

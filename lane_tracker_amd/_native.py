@@ -72,6 +72,7 @@ _SIGNATURES = {
     "lt_upload_frames": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_get_source_rows": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lt_upload_frame_rows": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_upload_frame_rows_async": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_frame_rest": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_masks": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_download_masks": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -105,6 +106,14 @@ _SIGNATURES = {
     "lt_filter_lane_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FilterParams), _P]),
     "lt_morph_ellipse": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "lt_fit_poly2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "lt_gather_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(_P)]),
+    "lt_gather_world": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lt_gather_reserve": (C.c_int, [_P, C.c_int]),
+    "lt_gather_stage": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "lt_gather_records": (C.c_int, [_P, C.c_int, _P]),
+    "lt_gather_host": (C.c_int, [_P, _P, C.c_size_t, _P]),
+    "lt_gather_barrier": (C.c_int, [_P]),
+    "lt_gather_destroy": (None, [_P]),
     "lt_timer_start": (C.c_int, [_P]),
     "lt_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "lt_set_stage_timing": (C.c_int, [_P, C.c_int]),
@@ -279,6 +288,16 @@ class Context:
         """Like upload_frames, but only the camera rows the path reads cross the bus (not enough for the overlay)."""
         f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
         _check(self.lib.lt_upload_frame_rows(self._h, f.ctypes.data, first, f.shape[0]))
+
+    def upload_frame_rows_async(self, frames, first=0):
+        """Stream-ordered upload_frame_rows (no host wait).  `frames` must be a C-contiguous u8 array that stays alive
+        and unchanged until the next sync() -- use pinned_empty() for it; returns the array handed to the library."""
+        f = np.asarray(frames)
+        if f.dtype != np.uint8 or not f.flags["C_CONTIGUOUS"]:
+            raise ValueError("upload_frame_rows_async needs a C-contiguous uint8 array (no hidden copy may be made)")
+        f = f.reshape(-1, self.img_h, self.img_w, 3)
+        _check(self.lib.lt_upload_frame_rows_async(self._h, f.ctypes.data, first, f.shape[0]))
+        return f
 
     def upload_frame_rest(self, frames, first=0):
         """The rows upload_frame_rows left out, on a copy stream beside the compute streams (for the overlay).
@@ -488,6 +507,53 @@ class Context:
         ln = (C.c_int32 * NUM_STAGES)()
         _check(self.lib.lt_stage_ms(self._h, ms, ln, NUM_STAGES))
         return {self.lib.lt_stage_name(i).decode(): (ms[i], ln[i]) for i in range(NUM_STAGES)}
+
+
+class Gather:
+    """The RCCL all-gather of lane records between the ranks of one node (lt_gather_*; one per rank, bound to
+    the rank's Context).  Collective calls: every rank must make them in the same order."""
+
+    def __init__(self, ctx, rank, world, id_path, timeout_s=120):
+        self._g = None
+        self.ctx, self.lib = ctx, ctx.lib
+        g = _P()
+        _check(self.lib.lt_gather_init(ctx._h, int(rank), int(world), os.fsencode(id_path), int(timeout_s), C.byref(g)))
+        self._g = g
+        self.rank, self.world = int(rank), int(world)
+
+    def reserve(self, records_per_rank):
+        _check(self.lib.lt_gather_reserve(self._g, int(records_per_rank)))
+
+    def stage(self, n, at=0, first=0):
+        """Records of slots [first, first+n) -> send buffer position `at`; stream-ordered, no host wait."""
+        _check(self.lib.lt_gather_stage(self._g, int(first), int(n), int(at)))
+
+    def records(self, n_records):
+        """(world, n_records) records: the first n_records staged records of every rank."""
+        out = np.zeros((self.world, int(n_records)), RECORD_DTYPE)
+        _check(self.lib.lt_gather_records(self._g, int(n_records), out.ctypes.data))
+        return out
+
+    def host(self, array):
+        """All-gather of a small host array: (world,) + array.shape."""
+        a = np.ascontiguousarray(array)
+        out = np.empty((self.world,) + a.shape, a.dtype)
+        _check(self.lib.lt_gather_host(self._g, a.ctypes.data, a.nbytes, out.ctypes.data))
+        return out
+
+    def barrier(self):
+        _check(self.lib.lt_gather_barrier(self._g))
+
+    def close(self):
+        if self._g is not None:
+            self.lib.lt_gather_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def device_count():

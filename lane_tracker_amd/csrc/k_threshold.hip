@@ -64,10 +64,7 @@ __host__ __device__ __forceinline__ int hband_pitch(int k) {   // >= 64 + 2k, mu
 }
 __host__ __device__ __forceinline__ int plane_lds_bytes(int k) { return TH * hband_pitch(k) + (TH + 2 * k + 1) * TW; }
 
-__device__ long long g_dbg_cycles[16];
-
 __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigned long long* __restrict__ bits) {
-    const long long t_begin = clock64();
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_words[7][TH];   // [2q] H words, [2q+1] V words of plane q; [6] inRange words
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
@@ -154,7 +151,6 @@ __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigne
         }
     }
     __syncthreads();
-    const long long t_staged = clock64();
 
     // ---- sliding-window phases: phase 2q = H of plane q, 2q+1 = V of plane q ----
     for (int ph = wv; ph < 6; ph += 4) {
@@ -207,13 +203,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile(BilateralArgs a, unsigne
             if (q == 2) s_words[6][lane] = mine_range;
         }
     }
-    const long long t_phase = clock64();
     __syncthreads();
-    if (a.noise_thresh == -12345 && (threadIdx.x & 63) == 0) {   // timing probe (tools/dbg only)
-        atomicAdd((unsigned long long*)&g_dbg_cycles[wv], (unsigned long long)(t_staged - t_begin));
-        atomicAdd((unsigned long long*)&g_dbg_cycles[4 + wv], (unsigned long long)(t_phase - t_staged));
-        atomicAdd((unsigned long long*)&g_dbg_cycles[8 + wv], 1ull);
-    }
     if (threadIdx.x < TH) {
         const int r = threadIdx.x, gy = y0 + r;
         if (gy < a.h) {
@@ -664,11 +654,6 @@ __global__ __launch_bounds__(256) void k_bits_to_u8(const unsigned long long* __
 }
 
 }  // namespace
-
-void debug_read_cycles(long long out[16], bool reset) {
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg_cycles), sizeof(long long) * 16);
-    if (reset) { long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_cycles), z, sizeof z); }
-}
 
 int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
                           const uint8_t* labb, int k_n, int C_n, int noise_thresh, int use_noise,

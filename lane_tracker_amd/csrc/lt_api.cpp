@@ -98,6 +98,9 @@ struct lt_ctx {
     std::vector<int16_t> h_xpos;
     int font_first = 0, font_glyphs = 0, font_gw = 0, font_gh = 0;
     size_t text_cap = 0;
+    // ordering events of lt_upload_frame_rows_async (a ring: an event is reused long after its waits were enqueued)
+    std::vector<hipEvent_t> order_events;
+    size_t order_next = 0;
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stage_timing = false;
@@ -187,6 +190,19 @@ struct StageScope {
         c->pending.push_back({stage, a, b});
     }
 };
+
+hipEvent_t next_order_event(lt_ctx* c) {
+    constexpr size_t RING = 64;
+    if (c->order_events.size() < RING) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        c->order_events.push_back(e);
+        return e;
+    }
+    hipEvent_t e = c->order_events[c->order_next];
+    c->order_next = (c->order_next + 1) % RING;
+    return e;
+}
 
 int check_slots(lt_ctx* c, int first, int n) {
     if (!c) return fail(LT_ERR_INVALID, "null context");
@@ -566,6 +582,7 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_lines);
     dev_free(c->d_xpos);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : c->order_events) (void)hipEventDestroy(e);
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -677,6 +694,35 @@ int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
                              (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
+}
+
+// The same rows, stream-ordered instead of synchronous: the copy runs on the copy stream after the work already
+// enqueued on the streams that own these slots (their previous occupants), and those streams wait for it before
+// anything enqueued later -- so the upload of one slot range overlaps the chain of every other slot range.
+int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int n) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!frames) return fail(LT_ERR_INVALID, "null frames");
+    if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
+        hipEvent_t e = next_order_event(c);
+        if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(e, st));
+        HIP_TRY(hipStreamWaitEvent(c->copy, e, 0));
+        return (int)LT_OK;
+    });
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
+    HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
+                             (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->copy));
+    hipEvent_t up = next_order_event(c);
+    if (!up) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(up, c->copy));
+    return for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
+        HIP_TRY(hipStreamWaitEvent(st, up, 0));
+        return (int)LT_OK;
+    });
 }
 
 int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
@@ -1094,7 +1140,7 @@ int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, 
 int lt_download_centroids(lt_ctx* c, int slot, int side, int32_t* out, int cap, int* count) {
     int rc = check_slots(c, slot, 1);
     if (rc) return rc;
-    if (side < 0 || side > 1 || !count || cap < 0) return fail(LT_ERR_INVALID, "bad side/count/cap");
+    if (side < 0 || side > 1 || !count || cap < 0 || (cap > 0 && !out)) return fail(LT_ERR_INVALID, "bad side/count/cap/out");
     if (!c->d_cent) return fail(LT_ERR_STATE, "no sliding-window search has run yet");
     std::vector<int32_t> tmp((size_t)c->maxlev + 2);
     if ((rc = download(c, c->d_cent + ((size_t)slot * 2 + side) * (c->maxlev + 2), tmp.data(), tmp.size() * 4))) return rc;
@@ -1417,15 +1463,6 @@ int lt_fit_poly2(lt_ctx* c, const int32_t* ys, const int32_t* xs, int n, int h, 
     return LT_OK;
 }
 
-// undocumented probe used by tools/dbg_*.py (not part of the public header)
-extern "C" int lt_debug_cycles(lt_ctx* c, long long* out16, int reset) {
-    if (!c || !out16) return LT_ERR_INVALID;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    debug_read_cycles(out16, reset != 0);
-    return LT_OK;
-}
-
 // ---- measurement ---------------------------------------------------------------------------------------
 int lt_timer_start(lt_ctx* c) {
     if (!c) return fail(LT_ERR_INVALID, "null context");
@@ -1469,3 +1506,23 @@ int lt_stage_ms(lt_ctx* c, float* ms, int32_t* launches, int n) {
 }
 
 }  // extern "C"
+
+namespace lt {
+int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+int ctx_device(lt_ctx* c) { return c->device; }
+int ctx_streams(lt_ctx* c, hipStream_t* out, int cap) {
+    int n = 0;
+    for (int i = 0; i < c->nstreams && i < (int)c->streams.size() && n < cap; ++i) out[n++] = c->streams[(size_t)i];
+    return n;
+}
+int ctx_sync(lt_ctx* c) { return lt_sync(c); }
+int ctx_enqueue_records(lt_ctx* c, int first, int n, lt_lane_record* dst) { return lt_enqueue_records_to_device(c, first, n, dst); }
+}  // namespace lt

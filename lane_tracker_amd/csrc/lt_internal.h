@@ -83,7 +83,6 @@ void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsig
 void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,
                        size_t bits_stride, int n);
 
-void debug_read_cycles(long long out[16], bool reset);
 
 struct SearchGeom {
     int h, w;                    // mask size
@@ -129,5 +128,12 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Ma
 
 // fit of one explicit pixel list (packed (y<<16)|x); out: 3 doubles + 1 flag double (1.0 = rank deficient)
 void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, double* out4);
+
+// ---- internal view of a context for lt_gather.cpp (defined in lt_api.cpp) ----------------------------
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));   // fills lt_last_error(), returns code
+int ctx_device(lt_ctx* c);
+int ctx_streams(lt_ctx* c, hipStream_t* out, int cap);        // the streams the slots currently run on; returns the count
+int ctx_sync(lt_ctx* c);
+int ctx_enqueue_records(lt_ctx* c, int first, int n, lt_lane_record* dst_device);
 
 }  // namespace lt

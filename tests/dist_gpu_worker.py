@@ -1,19 +1,19 @@
-"""Worker of tests/test_gpu_distributed.py: one rank of a sharded run over RCCL (torch.distributed "nccl").
-Every rank processes its block of a 40-frame synthetic set on its GPU and all-gathers the lane records from
-device memory; rank 0 checks them against a straight single-context run of all frames."""
+"""Worker of tests/test_gpu_distributed.py: one rank of a sharded run.  The gather is `lt_gather_*` of the C ABI
+(RCCL); there is no PyTorch in this process.  Every rank processes its block of a 40-frame synthetic set on its
+GPU, stages the records device to device and all-gathers them; rank 0 checks them against a straight
+single-context run of all frames."""
 import os
 import sys
 
 import numpy as np
-import torch
-import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lane_tracker_amd import _native, calib, distributed, synth  # noqa: E402
 
-rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", 0))
-torch.cuda.set_device(local)
-dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+assert "torch" not in sys.modules
+rank, local, world = distributed.env_rank()
+if local >= _native.device_count():
+    raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible" % (rank, local, _native.device_count()))
 cal = calib.reference_calibration()
 N = 40
 r = synth.SceneRenderer(cal)
@@ -21,21 +21,22 @@ frames = np.stack([r.render(500 + i)[0] if i % 5 else np.full((720, 1280, 3), 12
 lo, hi = distributed.shard_range(N, rank, world)
 ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
                       device=local, capacity=16)
-mine = distributed.process_shard(ctx, frames[lo:hi], first_frame=lo, batch=16)       # uneven last batch on purpose
-host = distributed.gather_records(mine, N, device=torch.device("cuda", local))
-# the device-side gather takes the records of the last batch straight from the context's slots
-last = (hi - lo) - ((hi - lo - 1) // 16) * 16
-send = torch.zeros(last * 64, dtype=torch.uint8, device="cuda")
-ctx.copy_records_to_device(last, send.data_ptr())
-assert np.frombuffer(send.cpu().numpy().tobytes(), _native.RECORD_DTYPE).tobytes() == mine[-last:].tobytes()
+g = distributed.init_gather(ctx)
+g.reserve(max(distributed.shard_sizes(N, world)))
+mine = distributed.process_shard(ctx, frames[lo:hi], first_frame=lo, batch=16, gather=g)   # uneven last batch on purpose
+dev = distributed.gather_staged(g, N)                                            # HBM slots -> RCCL -> host
+host = distributed.gather_records(mine, N, distributed.RcclTransport(g))         # host records -> RCCL -> host
+assert dev.tobytes() == host.tobytes(), "device-staged and host-staged gathers differ"
+times = g.host(np.array([float(rank)], np.float64))
+assert times.reshape(-1).tolist() == [float(i) for i in range(world)]
 if rank == 0:
     ref = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
                           device=local, capacity=N)
     want = distributed.process_shard(ref, frames, first_frame=0, batch=N)
-    assert host.tobytes() == want.tobytes(), "gathered records differ from the single-context run"
-    assert list(host["frame"]) == list(range(N)) and int(host["detected"].sum()) == N - N // 5
+    assert dev.tobytes() == want.tobytes(), "gathered records differ from the single-context run"
+    assert list(dev["frame"]) == list(range(N)) and int(dev["detected"].sum()) == N - N // 5
     ref.close()
-    print("distributed gpu ok: %d frames on %d rank(s)" % (N, world))
+    print("distributed gpu ok: %d frames on %d rank(s), torch loaded: %s" % (N, world, "torch" in sys.modules))
+g.barrier()
+g.close()
 ctx.close()
-dist.barrier()
-dist.destroy_process_group()

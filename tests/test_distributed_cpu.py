@@ -47,7 +47,7 @@ def _worker(rank, world, port, n_frames, out_dir):
     try:
         lo, hi = distributed.shard_range(n_frames, rank, world)
         local = _records_for(range(lo, hi))
-        allrec = distributed.gather_records(local, n_frames)
+        allrec = distributed.gather_records(local, n_frames, distributed.GlooTransport())
         np.save(os.path.join(out_dir, f"rank{rank}.npy"), allrec)
     finally:
         dist.destroy_process_group()
