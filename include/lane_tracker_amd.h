@@ -220,6 +220,18 @@ int  lt_host_free(void* p);
  * needs lt_mask_run on those slots first (it reuses their undistorted rows) */
 int  lt_download_bev(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
 
+/* ---- host-only views of the calibration tables (no GPU needed) --------------------------------------- */
+/* What lt_create derives from the calibration, exposed so that it can be checked against independent
+ * generators (tests/test_tables_independent.py): the cv::remap fixed-point maps -- xy: (sx, sy) int16 pairs,
+ * frac: fy*32 + fx -- of cv2.warpPerspective (:834; warp_h*warp_w entries) and of cv2.undistort (:832; rows
+ * [row0,row1) x img_w entries), the camera rows the warp reads, the RGB2LAB tables (:208) and the half-widths
+ * of getStructuringElement(MORPH_ELLIPSE, (k,k)) (:203-205). */
+int  lt_calib_source_rows(const lt_calib* calib, int* row0, int* row1);
+int  lt_calib_warp_table(const lt_calib* calib, int16_t* xy, uint16_t* frac);
+int  lt_calib_undistort_table(const lt_calib* calib, int row0, int row1, int16_t* xy, uint16_t* frac);
+int  lt_calib_lab_tables(uint16_t* gamma256, uint16_t* cbrt3072, int32_t* coeffs9);
+int  lt_calib_ellipse(int k, int32_t* halfwidths /* k */, int* taps);
+
 /* ---- multi-GPU: the gather of the lane records ------------------------------------------------------ */
 /* Independent frames shard over the GPUs of one node by contiguous index blocks with no data-path exchange
  * (SURVEY 8(e)); the only collective is this all-gather of the 64-byte lane records, run on RCCL (librccl.so is

@@ -106,6 +106,11 @@ _SIGNATURES = {
     "lt_filter_lane_points": (C.c_int, [_P, _P, C.c_int, C.c_int, C.POINTER(FilterParams), _P]),
     "lt_morph_ellipse": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "lt_fit_poly2": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "lt_calib_source_rows": (C.c_int, [C.POINTER(Calib), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lt_calib_warp_table": (C.c_int, [C.POINTER(Calib), _P, _P]),
+    "lt_calib_undistort_table": (C.c_int, [C.POINTER(Calib), C.c_int, C.c_int, _P, _P]),
+    "lt_calib_lab_tables": (C.c_int, [_P, _P, _P]),
+    "lt_calib_ellipse": (C.c_int, [C.c_int, _P, C.POINTER(C.c_int)]),
     "lt_gather_init": (C.c_int, [_P, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(_P)]),
     "lt_gather_world": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lt_gather_reserve": (C.c_int, [_P, C.c_int]),
@@ -229,19 +234,47 @@ def search_params(window_width=30, window_height=40, search_range=20, mu=0.1, no
                         float(partial))
 
 
+def make_calib(img_size, warped_size, cam_matrix, dist_coeffs, M):
+    cal = Calib()
+    cal.img_w, cal.img_h = int(img_size[0]), int(img_size[1])
+    cal.warp_w, cal.warp_h = int(warped_size[0]), int(warped_size[1])
+    cal.cam_matrix[:] = [float(v) for v in np.asarray(cam_matrix, np.float64).reshape(9)]
+    d = np.asarray(dist_coeffs, np.float64).reshape(-1)
+    cal.dist_coeffs[:] = [float(v) for v in (list(d[:5]) + [0.0] * 5)[:5]]
+    cal.M[:] = [float(v) for v in np.asarray(M, np.float64).reshape(9)]
+    return cal
+
+
+def calib_tables(cal):
+    """The host-built calibration tables of a `Calib` (no GPU needed): dict with the warp map, the source-row
+    window, the undistortion map of those rows, the Lab tables and the ellipse half-widths."""
+    lib = load()
+    r0, r1 = C.c_int(0), C.c_int(0)
+    _check(lib.lt_calib_source_rows(C.byref(cal), C.byref(r0), C.byref(r1)))
+    wxy = np.empty((cal.warp_h, cal.warp_w, 2), np.int16)
+    wfr = np.empty((cal.warp_h, cal.warp_w), np.uint16)
+    _check(lib.lt_calib_warp_table(C.byref(cal), wxy.ctypes.data, wfr.ctypes.data))
+    uxy = np.empty((r1.value - r0.value, cal.img_w, 2), np.int16)
+    ufr = np.empty((r1.value - r0.value, cal.img_w), np.uint16)
+    _check(lib.lt_calib_undistort_table(C.byref(cal), r0.value, r1.value, uxy.ctypes.data, ufr.ctypes.data))
+    gamma, cbrt, coef = np.empty(256, np.uint16), np.empty(3072, np.uint16), np.empty(9, np.int32)
+    _check(lib.lt_calib_lab_tables(gamma.ctypes.data, cbrt.ctypes.data, coef.ctypes.data))
+    ell = {}
+    for k in (5, 29, 55):
+        dx, taps = np.empty(k, np.int32), C.c_int(0)
+        _check(lib.lt_calib_ellipse(k, dx.ctypes.data, C.byref(taps)))
+        ell[k] = (dx, taps.value)
+    return dict(source_rows=(r0.value, r1.value), warp_xy=wxy, warp_frac=wfr, und_xy=uxy, und_frac=ufr, gamma=gamma,
+                cbrt=cbrt, lab_coeffs=coef, ellipse=ell)
+
+
 class Context:
     """One device context = one HIP stream + calibration tables + `capacity` frame slots in HBM."""
 
     def __init__(self, img_size, warped_size, cam_matrix, dist_coeffs, M, device=0, capacity=1):
         self._h = None
         lib = load()
-        cal = Calib()
-        cal.img_w, cal.img_h = int(img_size[0]), int(img_size[1])
-        cal.warp_w, cal.warp_h = int(warped_size[0]), int(warped_size[1])
-        cal.cam_matrix[:] = [float(v) for v in np.asarray(cam_matrix, np.float64).reshape(9)]
-        d = np.asarray(dist_coeffs, np.float64).reshape(-1)
-        cal.dist_coeffs[:] = [float(v) for v in (list(d[:5]) + [0.0] * 5)[:5]]
-        cal.M[:] = [float(v) for v in np.asarray(M, np.float64).reshape(9)]
+        cal = make_calib(img_size, warped_size, cam_matrix, dist_coeffs, M)
         h = _P()
         _check(lib.lt_create(C.byref(cal), int(device), C.byref(h)))
         self._h = h

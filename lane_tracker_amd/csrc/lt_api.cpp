@@ -870,6 +870,50 @@ void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int nl, cons
 
 }  // namespace
 
+// ---- host-only views of the calibration tables lt_create builds (no GPU needed) --------------------------------
+int lt_calib_source_rows(const lt_calib* calib, int* row0, int* row1) {
+    if (!calib || !row0 || !row1) return fail(LT_ERR_INVALID, "null argument");
+    RemapTable warp;
+    build_warp_table(*calib, warp);
+    warp_source_rows(*calib, warp, *row0, *row1);
+    return LT_OK;
+}
+
+int lt_calib_warp_table(const lt_calib* calib, int16_t* xy, uint16_t* frac) {
+    if (!calib || !xy || !frac) return fail(LT_ERR_INVALID, "null argument");
+    RemapTable t;
+    build_warp_table(*calib, t);
+    const size_t n = (size_t)t.rows * t.cols;
+    std::memcpy(xy, t.xy.data(), n * 2 * sizeof(int16_t));
+    std::memcpy(frac, t.frac.data(), n * sizeof(uint16_t));
+    return LT_OK;
+}
+
+int lt_calib_undistort_table(const lt_calib* calib, int row0, int row1, int16_t* xy, uint16_t* frac) {
+    if (!calib || !xy || !frac) return fail(LT_ERR_INVALID, "null argument");
+    if (row0 < 0 || row1 < row0 || row1 > calib->img_h) return fail(LT_ERR_INVALID, "rows [%d, %d) outside the image", row0, row1);
+    RemapTable t;
+    build_undistort_table(*calib, row0, row1, t);
+    const size_t n = (size_t)t.rows * t.cols;
+    std::memcpy(xy, t.xy.data(), n * 2 * sizeof(int16_t));
+    std::memcpy(frac, t.frac.data(), n * sizeof(uint16_t));
+    return LT_OK;
+}
+
+int lt_calib_lab_tables(uint16_t* gamma256, uint16_t* cbrt3072, int32_t* coeffs9) {
+    if (!gamma256 || !cbrt3072 || !coeffs9) return fail(LT_ERR_INVALID, "null argument");
+    build_lab_tables(gamma256, cbrt3072, coeffs9);
+    return LT_OK;
+}
+
+int lt_calib_ellipse(int k, int32_t* halfwidths, int* taps) {
+    if (k < 1 || k > 63 || !(k & 1) || !halfwidths || !taps) return fail(LT_ERR_INVALID, "k must be odd, 1..63");
+    int dx[64];
+    *taps = ellipse_halfwidths(k, dx);
+    for (int i = 0; i < k; ++i) halfwidths[i] = dx[i];
+    return LT_OK;
+}
+
 int lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,
                           int16_t* spans) {
     if (warp_h < 1 || n_left < 0 || n_right < 0 || !spans || (n_left && !left_yx) || (n_right && !right_yx))

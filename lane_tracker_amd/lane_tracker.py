@@ -311,15 +311,23 @@ class LaneTracker:
 
     # ---- metrics (reference :530-559) -------------------------------------------------------------------
     def get_curve_radius(self):
-        """Curve radius in metres.  The reference refits the pixels in metric units with two more
-        np.polyfit calls; a least-squares parabola is equivariant under axis scaling, so the metric
-        coefficients follow from the pixel fit exactly: a_m = a*mpph/mppv^2, b_m = b*mpph/mppv."""
+        """Curve radius in metres, the reference's integers (:530-549).  The reference refits the pixels in metric
+        units with two more np.polyfit calls.  A least-squares parabola is equivariant under axis scaling, so the
+        metric coefficients follow from the pixel fit (a_m = a*mpph/mppv^2, b_m = b*mpph/mppv) up to floating-point
+        rounding (~1e-12 relative); only when that value lies so close to an integer that `int()` could truncate
+        differently are the lane pixels fetched and refitted exactly as upstream does."""
         lf, rf = self.fit_poly()
         y_eval = self.warped_size[1]
+
+        def radius_of(fit_m):
+            return ((1 + (2 * fit_m[0] * y_eval * self.mppv + fit_m[1]) ** 2) ** 1.5) / np.absolute(2 * fit_m[0])
         radii = []
-        for c in (lf, rf):
-            a_m, b_m = c[0] * self.mpph / (self.mppv ** 2), c[1] * self.mpph / self.mppv
-            radii.append(int(((1 + (2 * a_m * y_eval * self.mppv + b_m) ** 2) ** 1.5) / np.absolute(2 * a_m)))
+        for side, c in enumerate((lf, rf)):
+            val = radius_of((c[0] * self.mpph / (self.mppv ** 2), c[1] * self.mpph / self.mppv))
+            if np.isfinite(val) and abs(val - np.rint(val)) <= 1e-7 * max(1.0, abs(val)):
+                ys, xs = (self.left_y, self.left_x) if side == 0 else (self.right_y, self.right_x)
+                val = radius_of(np.polyfit(np.asarray(ys) * self.mppv, np.asarray(xs) * self.mpph, 2))
+            radii.append(int(val))
         self.left_curve_radius, self.right_curve_radius = radii
         average_curve_radius = int(0.5 * (self.left_curve_radius + self.right_curve_radius))
         self.average_curve_radii.append(average_curve_radius)

@@ -40,6 +40,11 @@ class SearchParams(C.Structure):
 
 
 def build(force=False):
+    if os.environ.get("LT_ORACLE_SANITIZED") == "1":   # tests/test_oracle_sanitized.py: the -fsanitize=address,undefined build
+        so = os.path.join(_HERE, "liblt_oracle_asan.so")
+        if not os.path.exists(so):
+            subprocess.check_call(["make", "-C", _HERE, "-s", "asan"])
+        return so
     so = os.path.join(_HERE, "liblt_oracle.so")
     src = [os.path.join(_HERE, f) for f in ("lt_oracle.c", "lt_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):

@@ -58,7 +58,27 @@
 #define I_BFI(i)     "v_bfi_b32 %" #i ", %" #i ", %8, %9\n\t"
 #define I_MOV(i)     "v_mov_b32 %" #i ", %8\n\t"
 #define I_MBCNT(i)   "v_mbcnt_lo_u32_b32 %" #i ", %8, %" #i "\n\t"
-#define I_SALU(i)    "s_add_u32 s20, s20, 1\n\t"
+#define I_AND(i)     "v_and_b32 %" #i ", %" #i ", %8\n\t"
+#define I_OR(i)      "v_or_b32 %" #i ", %" #i ", %8\n\t"
+#define I_SUB(i)     "v_sub_u32 %" #i ", %" #i ", %8\n\t"
+#define I_MINU(i)    "v_min_u32 %" #i ", %" #i ", %8\n\t"
+#define I_MAXU(i)    "v_max_u32 %" #i ", %" #i ", %8\n\t"
+#define I_MAXI16(i)  "v_max_i16 %" #i ", %" #i ", %8\n\t"
+#define I_ADD16(i)   "v_add_u16 %" #i ", %" #i ", %8\n\t"
+#define I_MUL24(i)   "v_mul_u32_u24 %" #i ", %" #i ", %8\n\t"
+#define I_LSHR(i)    "v_lshrrev_b32 %" #i ", 1, %" #i "\n\t"
+#define I_ASHR(i)    "v_ashrrev_i32 %" #i ", 1, %" #i "\n\t"
+#define I_ADDSDWA(i) "v_add_u32_sdwa %" #i ", %" #i ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n\t"
+#define I_ADDCO(i)   "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n\t"
+#define I_ADDF(i)    "v_add_f32 %" #i ", %" #i ", %8\n\t"
+#define I_PKADDF16(i) "v_pk_add_f16 %" #i ", %" #i ", %8\n\t"
+#define I_PKMULLO(i) "v_pk_mul_lo_u16 %" #i ", %" #i ", %8\n\t"
+#define I_MADU16(i)  "v_mad_u16 %" #i ", %" #i ", %8, %9\n\t"
+#define I_BFREV(i)   "v_bfrev_b32 %" #i ", %" #i "\n\t"
+#define I_CNDADD(i)  "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\tv_add_u32 %" #i ", %" #i ", %8\n\tv_add_u32 %" #i ", %" #i ", %9\n\tv_add_u32 %" #i ", %" #i ", %8\n\t"
+#define I_CNDS(i)    "v_cndmask_b32 %" #i ", %" #i ", %8, s[20:21]\n\t"
+#define I_PERMADD(i) "v_perm_b32 %" #i ", %" #i ", %8, %9\n\tv_add_u32 %" #i ", %" #i ", %8\n\t"
+#define I_READLANE(i) "v_readlane_b32 s20, %" #i ", 3\n\t"
 
 #define OPS(F) \
     F(pk_minimum3_f16, I_PKMIN3) F(pk_maximum3_f16, I_PKMAX3) F(pk_mad_u16, I_PKMAD) F(pk_add_u16, I_PKADD) \
@@ -68,7 +88,11 @@
     F(mul_lo_u32, I_MULLO) F(alignbit_b32, I_ALIGN) F(bfe_u32, I_BFE) F(min3_u32, I_MIN3U) F(fma_f32, I_FMA) \
     F(pk_fma_f16, I_PKFMA) F(cndmask_b32, I_CNDMASK) F(cmp_gt_i16_vcc, I_CMP16) F(cmp_lt_i32_sgpr, I_CMP32S) \
     F(writelane_b32, I_WRLANE) F(lshlrev_b32, I_LSHL64) F(xor_b32, I_XOR) F(bfi_b32, I_BFI) F(mov_b32, I_MOV) \
-    F(mbcnt_lo, I_MBCNT) F(s_add_u32, I_SALU)
+    F(mbcnt_lo, I_MBCNT) F(and_b32, I_AND) F(or_b32, I_OR) F(sub_u32, I_SUB) F(min_u32, I_MINU) F(max_u32, I_MAXU) \
+    F(max_i16, I_MAXI16) F(add_u16, I_ADD16) F(mul_u32_u24, I_MUL24) F(lshrrev_b32, I_LSHR) F(ashrrev_i32, I_ASHR) \
+    F(add_u32_sdwa_byte, I_ADDSDWA) F(add_co_u32, I_ADDCO) F(add_f32, I_ADDF) F(pk_add_f16, I_PKADDF16) \
+    F(pk_mul_lo_u16, I_PKMULLO) F(mad_u16, I_MADU16) F(bfrev_b32, I_BFREV) F(cndmask_then_3_adds_x4insts, I_CNDADD) \
+    F(cndmask_sgpr_mask, I_CNDS) F(perm_then_add_x2insts, I_PERMADD) F(readlane_b32, I_READLANE)
 
 extern "C" __global__ void k_dummy() {}
 
