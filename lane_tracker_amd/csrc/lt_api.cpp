@@ -72,6 +72,7 @@ struct lt_ctx {
     uint8_t* d_plane[P_COUNT] = {};
     unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
     unsigned long long* d_bits_open = nullptr;    // the opened mask as the mask chain leaves it (what the searches read)
+    unsigned long long* d_bits_tmp = nullptr;     // fourth partial plane of the walking threshold kernels
     // per slot: which forms of the mask are current.  The chain writes the bit plane only; the u8 mask
     // (d_plane[P_MASK]) is expanded from it when somebody asks for it; lt_upload_masks provides u8 only.
     std::vector<uint8_t> mask_bits_ok, mask_u8_ok;
@@ -224,6 +225,7 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_bits_merged);
     dev_free(c->d_bits_eroded);
     dev_free(c->d_bits_open);
+    dev_free(c->d_bits_tmp);
     c->mask_bits_ok.clear();
     c->mask_u8_ok.clear();
     dev_free(c->d_rec);
@@ -366,8 +368,14 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
     bool merged_done = false;
     if (p->filter_type == 0) {
-        StageScope t(c, ST_THRESHOLD, s);   // both bilateral thresholds, the greenery mask and the OR-merge in one kernel
-        merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
+        StageScope t(c, ST_THRESHOLD, s);   // both bilateral thresholds, the greenery mask and the OR-merge
+        // long-walk kernels for the supported window sizes (the eroded / opened planes are free until the open stage)
+        if (!p->mask_noise && c->d_bits_tmp)
+            merged_done = launch_bilateral_walk(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, mbits, ebits,
+                                                c->d_bits_open + (size_t)first * c->bits_stride,
+                                                c->d_bits_tmp + (size_t)first * c->bits_stride, h, w, ps, c->bits_stride, n) == 0;
+        if (!merged_done)
+          merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
                                             p->C_noise, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps,
                                             c->bits_stride, n) == 0;
         if (!merged_done) {              // tile + halo exceeds the LDS: one plane at a time
@@ -612,6 +620,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     if ((rc = dev_alloc(&c->d_bits_merged, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_bits_eroded, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_bits_open, n * c->bits_stride))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_bits_tmp, n * c->bits_stride))) { free_slots(c); return rc; }
     c->mask_bits_ok.assign(n, 0);
     c->mask_u8_ok.assign(n, 1);          // zero-filled below
     if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }

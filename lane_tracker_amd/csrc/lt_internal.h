@@ -77,6 +77,10 @@ void launch_pack_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, cons
                        size_t bits_stride, int n);
 void launch_open5_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded, uint8_t* mask, int h,
                        int w, size_t plane_stride, size_t bits_stride, int n);
+// both bilateral thresholds + merge through the long-walk kernels (k_threshold_walk.hip); 0 = ran, -1 = outside its limits
+int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
+                          unsigned long long* merged, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
+                          int h, int w, size_t plane_stride, size_t bits_stride, int n);
 // erode + dilate with the 5x5 ellipse, bit plane in, bit plane out
 void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded,
                           unsigned long long* opened, int h, int w, size_t bits_stride, int n);

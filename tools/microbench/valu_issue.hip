@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
     std::vector<unsigned long long> h(cus * 8 * 4);
     const int Ws[] = {1, 2, 3, 4, 5, 6, 8};
     std::printf("{\"device\": \"%s\", \"cus\": %d, \"clock_rate_khz\": %d, \"iters\": %d, \"insts_per_wave\": %d,\n",
-                prop.name, cus, clock_khz, iters, iters * 64);
+                prop.name[0] ? prop.name : prop.gcnArchName, cus, clock_khz, iters, iters * 64);
     std::printf(" \"method\": \"W workgroups of 4 waves per CU (one wave per SIMD each), every wave issues iters*64 copies of one "
                 "instruction; rate = W*insts / cycles of the slowest wave (s_memtime), wave-instructions per cycle per SIMD; "
                 "ghz = insts*W*4*cus/(rate*... ) see wall_ms\",\n \"ops\": {\n");
