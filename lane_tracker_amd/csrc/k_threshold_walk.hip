@@ -14,15 +14,16 @@
 //   * the verdict needs no max and no compare:  with  bias = 0x8000 + C k  folded into both sums,
 //         D = (S + bias) - k p       has bit 15 set   <=>   S + C k >= k p   <=>  this side fails,
 //     so  (D_a | D_b)  carries "fails" in bits 15 / 31.
-//   * horizontal pass: the fail bits are shifted into a packed pair of 16-bit registers (v_lshrrev + v_bfi) and every
-//     16 pixels into the lane's two 64-bit row words; vertical pass: two v_cmp give the row words of a row directly.
-//   * staging: 16 pixels of 128 rows (columns) per chunk, loaded coalesced one chunk ahead and written into a ring of
-//     2k + 18 positions; all ring offsets are compile-time constants because the walk is unrolled over one ring length.
+//   * horizontal pass: the fail bits are shifted into a packed pair of 16-bit registers (v_lshrrev + v_bfi / v_bitop3)
+//     and every 16 pixels into the lane's two 64-bit row words; vertical pass: two v_cmp give the row words of a row.
+//   * staging: coalesced loads one chunk / block ahead, written into a ring of 2k + 18 positions; all ring offsets are
+//     compile-time constants because the walk is unrolled over one ring length.
 //
-// The four passes (R / Lab-b top-hat x horizontal / vertical) write four partial bit planes; k_or4_bits merges them.
-// Window sizes are template parameters (15, 20, 35: process() defaults, second try and the documented settings of
-// tracker_settings.md); any other size, the greenery mask (mask_noise) or a width that is not a multiple of 4 takes
-// k_bilateral_tile2.
+// The planes these kernels read (the two top-hat planes) have a row pitch that is a multiple of 64 bytes, so that every
+// staging load covers whole, aligned lines.  The four passes (R / Lab-b top-hat x horizontal / vertical) write four
+// partial bit planes; k_or4_bits merges them.  Window sizes are template parameters (15, 20, 35: process() defaults,
+// second try and the documented settings of tracker_settings.md); any other size, the greenery mask (mask_noise) or a
+// width that is not a multiple of 4 takes k_bilateral_tile2.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -46,9 +47,10 @@ struct WalkArgs {
     const uint8_t* src;          // u8 plane of frame 0
     unsigned long long* out;     // partial bit plane of frame 0
     int h, w, wpr;
+    int pitch;                   // bytes per row of the plane (a multiple of 64 >= w)
     int C;
     int groups;                  // 128-row groups (horizontal) / 128-column groups (vertical) per frame
-    int segs, seg_len;           // segments per walk, nominal length (multiple of 64)
+    int segs, seg_len;           // segments per walk, nominal length (horizontal: a multiple of 128)
     int ntasks;
     size_t plane_stride, bits_stride;
 };
@@ -62,19 +64,20 @@ struct WalkCfg {                                                    // vertical 
     static constexpr int V_LDS = WIN * 128;
 };
 
-// Horizontal pass: the ring origin is the 64-aligned column at or before the first pixel the walk needs, so that a
-// staging load covers whole 64-byte pieces of 16 rows.  OFF = ring position of that first pixel (ys - K).
+// Horizontal pass: the ring origin is the 128-aligned column at or before the first pixel the walk needs, so that a
+// staging load covers whole 128-byte lines of 8 rows (L2 fetches whole lines: with 64-byte pieces every line crossed the
+// fabric twice).  Segments start at multiples of 128.  OFF = ring position of that first pixel (ys - K).
 template <int K>
 struct WalkCfgH {
     static constexpr int E = (4 - (K & 3)) & 3;                     // pixels walked before the segment start
-    static constexpr int OFF = ((-(E + K)) % 64 + 64) % 64;
+    static constexpr int OFF = ((-(E + K)) % 128 + 128) % 128;
     static constexpr int NPRE = (OFF + 2 * K + 2 + 15) / 16;
     static constexpr int WIN = ((2 * K + 18 + 15) / 16) * 16;
     static constexpr int NCH = WIN / 16;
     static constexpr int WSTEP = 16 * NPRE - (OFF + 2 * K + 2);
     static constexpr int PITCH = (NCH % 2) ? WIN : WIN + 16;        // bytes per ring row, 16 x odd: conflict-free 128-bit reads
     static constexpr int LDS = 128 * PITCH;
-    static_assert(NPRE >= 5 && NPRE <= 7, "the prologue loads two 64-column blocks and leaves the second one in registers");
+    static_assert(NPRE >= 9 && NPRE <= 15, "the prologue loads two 128-column blocks and leaves the second one in registers");
 };
 
 // The ring is written as dwords / dword quads and read as dwords, quads or 16-bit pairs: every LDS access goes through
@@ -83,21 +86,25 @@ typedef uint32_t __attribute__((may_alias)) u32a;
 typedef uint16_t __attribute__((may_alias)) u16a;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 __attribute__((may_alias)) u128a;
-struct __attribute__((packed, aligned(4))) U128Unaligned { u32x4 v; };
 __device__ __forceinline__ uint32_t lds_u32(const uint8_t* p) { return *reinterpret_cast<const u32a*>(p); }
 
-// two wave-uniform 64-bit masks into lane LANE of four VGPRs.  The masks must not come from a VALU instruction issued
-// in the last few cycles (a VALU-written SGPR needs wait states before v_writelane reads it, and the compiler does not
-// look inside inline assembly): the caller passes masks that are at least a whole step old.
+// Two wave-uniform 64-bit masks into lane LANE (< 32) of four VGPRs: v_mov_b32 under a one-lane EXEC mask does what
+// v_writelane_b32 does at half the issue cost (2 cycles against 4, profiles/r02_valu_issue_table.txt).  Every lane of
+// the wave is active around this statement, so EXEC is restored to all ones.  The masks must not come from a VALU
+// instruction issued in the last few cycles (a VALU-written SGPR needs wait states before another VALU instruction
+// reads it, and the compiler does not look inside inline assembly): the caller passes masks that are a whole step old.
 template <int LANE>
 __device__ __forceinline__ void put_lane(uint32_t& m0, uint32_t& m1, uint32_t& m2, uint32_t& m3, unsigned long long a,
                                          unsigned long long b) {
-    asm("v_writelane_b32 %0, %4, %8\n\t"
-        "v_writelane_b32 %1, %5, %8\n\t"
-        "v_writelane_b32 %2, %6, %8\n\t"
-        "v_writelane_b32 %3, %7, %8"
-        : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)
-        : "s"((uint32_t)a), "s"((uint32_t)(a >> 32)), "s"((uint32_t)b), "s"((uint32_t)(b >> 32)), "n"(LANE));
+    static_assert(LANE >= 0 && LANE < 32, "the EXEC mask is written as a 32-bit literal");
+    asm volatile("s_mov_b64 exec, %8\n\t"
+                 "v_mov_b32 %0, %4\n\t"
+                 "v_mov_b32 %1, %5\n\t"
+                 "v_mov_b32 %2, %6\n\t"
+                 "v_mov_b32 %3, %7\n\t"
+                 "s_mov_b64 exec, -1"
+                 : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)
+                 : "s"((uint32_t)a), "s"((uint32_t)(a >> 32)), "s"((uint32_t)b), "s"((uint32_t)(b >> 32)), "n"(1u << LANE));
 }
 
 struct Task {
@@ -133,7 +140,7 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
     const int total = y1 - y0;                        // steps
     const int g0 = t.grp * 128;                       // first column of the group
 
-    // staging: lane -> (row lane>>4 + 4 i, dwords lane&15 of both 64-column halves): 4 rows x (64 + 64) bytes per pair of loads
+    // staging: lane -> (row lane>>4 + 4 i, dwords lane&15 of both 64-column halves): 4 rows x one 128-byte line per pair of loads
     const int ca = g0 + 4 * (lane & 15), cb = ca + 64;
     const bool ain = ca < w, bin = cb < w;
     const uint8_t *pa = src + min(ca, w - 4), *pb = src + min(cb, w - 4);
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = p0 + (lane >> 4) + 4 * i;
-            const uint32_t ro = (uint32_t)__mul24(min(max(row, 0), h - 1), w);
+            const uint32_t ro = (uint32_t)__mul24(min(max(row, 0), h - 1), a.pitch);
             st[2 * i] = *reinterpret_cast<const uint32_t*>(pa + ro);
             st[2 * i + 1] = *reinterpret_cast<const uint32_t*>(pb + ro);
         }
@@ -214,8 +221,8 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
                     // verdict of row y0 + s: both columns at once, "fails" in bits 15 and 31
                     const uint32_t kp = __umul24(qc, (uint32_t)K);
                     const uint32_t v = (sl - kp) | (sr - kp);
-                    // The masks of row s-1 go into lane (s-1) % 16 now: a VALU-written SGPR needs wait states before
-                    // v_writelane may read it as data, and a whole step lies between the compares and this point.
+                    // The masks of row s-1 go into lane (s-1) % 16 now: a whole step lies between the compares that
+                    // wrote the SGPRs and this point (see put_lane).
                     constexpr int tp = (u + 15) % 16;
                     put_lane<tp>(m0, m1, m2, m3, pva, pvb);
                     if constexpr (tp == 15) store_rows(y0 + sb + u - 16);               // the 16 rows before this one
@@ -239,11 +246,12 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Horizontal pass: lanes = rows (l | l + 64) of a 128-row group, the walk goes along the columns.
-// Staging: a block = 64 columns of the 128 rows, eight 16-byte loads per lane (lane -> row lane>>2 + 16 i, 16-byte
-// piece lane&3: 16 rows x 64 contiguous bytes per instruction); the quarter of the lanes that holds the next 16 columns
+// Staging: a block = 128 columns of the 128 rows, sixteen 16-byte loads per lane (lane -> row lane>>3 + 8 i, 16-byte
+// piece lane&7: 8 rows x one whole 128-byte line per instruction); the eighth of the lanes that holds the next 16 columns
 // writes them into the ring every 16 steps with 128-bit stores, and the streams read 128 bits per row and 16 steps.
+// (64 VGPRs for the block: the ring limits a CU to 11 waves at k = 35 anyway, so up to 168 VGPRs cost no occupancy.)
 template <int K>
-__global__ __launch_bounds__(64) void k_bilateral_walk_h(WalkArgs a) {
+__global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) {   // 3 waves per SIMD: <= 168 VGPRs
     using Cfg = WalkCfgH<K>;
     constexpr int WIN = Cfg::WIN, NPRE = Cfg::NPRE, NCH = Cfg::NCH, WSTEP = Cfg::WSTEP, PITCH = Cfg::PITCH, E = Cfg::E,
                   OFF = Cfg::OFF;
@@ -257,34 +265,42 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_h(WalkArgs a) {
     const int y0 = t.y0;
     const int yend = (t.y1 + 63) & ~63;               // whole 64-pixel words
     const int ys = y0 - E;                            // first pixel walked (its verdict is dropped when < y0)
-    const int xs = ys - K - OFF;                      // pixel at ring position 0: a multiple of 64
+    const int xs = ys - K - OFF;                      // pixel at ring position 0: a multiple of 128
     const int total = yend - ys;                      // steps
     const int g0 = t.grp * 128;                       // first row of the group
 
-    const int piece = lane & 3, rsub = lane >> 2;
-    uint32_t rowoff[8];
+    const int piece = lane & 7, rsub = lane >> 3;     // lane -> (row rsub + 8 i, 16-byte piece of a 128-byte line)
+    auto rowoff = [&](int i) { return (uint32_t)__mul24(min(g0 + rsub + 8 * i, h - 1), a.pitch); };
+    auto issue_block = [&](int blk, u32x4 (&r)[16]) { // block b covers pixels xs + 128 b .. + 127
+        // (block 0: the pieces in front of ring position OFF are never read; they re-read the first live piece's line)
+        const int col = max(xs + 128 * blk + 16 * piece, xs + (OFF & ~15));
+        const uint8_t* colp = src + min(max(col, 0), a.pitch - 16);   // 128-byte aligned lines of 64-byte aligned rows
 #pragma unroll
-    for (int i = 0; i < 8; ++i) rowoff[i] = (uint32_t)__mul24(min(g0 + rsub + 16 * i, h - 1), w);
-    auto issue_block = [&](int blk, u32x4 (&r)[8]) {  // block b covers pixels xs + 64 b .. + 63
-        const int col = xs + 64 * blk + 16 * piece;
-        const uint8_t* colp = src + min(max(col, 0), w - 4);   // a piece that starts in the image keeps its address
-#pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = reinterpret_cast<const U128Unaligned*>(colp + rowoff[i])->v;
+        for (int i = 0; i < 16; ++i) r[i] = *reinterpret_cast<const u32x4*>(colp + rowoff(i));
     };
-    auto land = [&](int chunk, int slot, const u32x4 (&r)[8]) {   // chunk c = pixels xs + 16 c .. + 15; slot = c mod NCH (constant)
-        if (piece == (chunk & 3)) {
+    // chunk c = pixels xs + 16 c .. + 15; slot = c mod NCH (a constant at every call site).  The eighth of the lanes
+    // whose piece it is writes it; chunks that lie inside the image and row groups that lie inside it skip the masks.
+    const bool rows_in = g0 + 128 <= h;
+    auto land = [&](int chunk, int slot, const u32x4 (&r)[16]) {
+        if (piece == (chunk & 7)) {
             const int col = xs + 16 * chunk;
-            const bool in0 = col >= 0 && col < w, in1 = col + 4 >= 0 && col + 4 < w, in2 = col + 8 >= 0 && col + 8 < w,
-                       in3 = col + 12 >= 0 && col + 12 < w;
+            unsigned char* dst = ring + rsub * PITCH + slot * 16;
+            if (rows_in && col >= 0 && col + 16 <= w) {        // wave-uniform
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const bool rin = g0 + rsub + 16 * i < h;
-                u32x4 v = r[i];
-                v.x = (rin && in0) ? v.x : 0u;
-                v.y = (rin && in1) ? v.y : 0u;
-                v.z = (rin && in2) ? v.z : 0u;
-                v.w = (rin && in3) ? v.w : 0u;
-                *reinterpret_cast<u128a*>(ring + (rsub + 16 * i) * PITCH + slot * 16) = v;
+                for (int i = 0; i < 16; ++i) *reinterpret_cast<u128a*>(dst + 8 * i * PITCH) = r[i];
+            } else {
+                const bool in0 = col >= 0 && col < w, in1 = col + 4 >= 0 && col + 4 < w, in2 = col + 8 >= 0 && col + 8 < w,
+                           in3 = col + 12 >= 0 && col + 12 < w;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const bool rin = g0 + rsub + 8 * i < h;
+                    u32x4 v = r[i];
+                    v.x = (rin && in0) ? v.x : 0u;
+                    v.y = (rin && in1) ? v.y : 0u;
+                    v.z = (rin && in2) ? v.z : 0u;
+                    v.w = (rin && in3) ? v.w : 0u;
+                    *reinterpret_cast<u128a*>(dst + 8 * i * PITCH) = v;
+                }
             }
         }
     };
@@ -302,18 +318,18 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_h(WalkArgs a) {
         return __builtin_amdgcn_perm(s.b[comp], s.a[comp], 0x0c000c00u | B | ((4u + B) << 16));
     };
 
-    // ---- prologue: two blocks in flight, ring filled up to chunk NPRE-1, initial sums ----
-    u32x4 blk[8];
-    {
-        u32x4 first[8];
-        issue_block(0, first);
-        issue_block(1, blk);
-        static_for([&](auto cc) {
-            constexpr int c = decltype(cc)::value;
-            if constexpr (c < 4) land(c, c % NCH, first);
-            else land(c, c % NCH, blk);
-        }, std::make_integer_sequence<int, NPRE>{});
-    }
+    // ---- prologue: block 0 (its chunks below OFF / 16 are never read), then block 1, which stays in registers ----
+    u32x4 blk[16];
+    issue_block(0, blk);
+    static_for([&](auto cc) {
+        constexpr int c = OFF / 16 + decltype(cc)::value;
+        land(c, c % NCH, blk);
+    }, std::make_integer_sequence<int, 8 - OFF / 16>{});
+    issue_block(1, blk);
+    static_for([&](auto cc) {
+        constexpr int c = 8 + decltype(cc)::value;
+        land(c, c % NCH, blk);
+    }, std::make_integer_sequence<int, NPRE - 8>{});
     const uint32_t kbias = (uint32_t)(0x8000 + a.C * K) * 0x10001u;
     uint32_t sl = kbias, sr = kbias, qc;
     Stream so, sn, si;                                // out (position OFF + s), next (+ K + 1), in (+ 2K + 1)
@@ -321,7 +337,7 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_h(WalkArgs a) {
         // sl = positions OFF .. OFF+K-1, sr = positions OFF+K+1 .. OFF+2K, dword by dword with v_sad_u8
         uint32_t la = 0, lb = 0, ra = 0, rb = 0;
         static_for([&](auto dc) {
-            constexpr int d = OFF / 4 + decltype(dc)::value;     // dword index in the ring row
+            constexpr int d = OFF / 4 + decltype(dc)::value;     // dword index along the walk
             constexpr int lo = d * 4, hi = lo + 4;
             auto part = [&](int from, int to, uint32_t& accA, uint32_t& accB) {   // bytes of this dword inside [from, to)
                 const int f = from > lo ? from : lo, tt = to < hi ? to : hi;
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_h(WalkArgs a) {
                         // the chunk that step u + 1 starts to read replaces the 16 positions the walk has left behind
                         const int c = (sb >> 4) + g + NPRE;
                         land(c, (g + NPRE) % NCH, blk);
-                        if ((c & 3) == 3) issue_block((c >> 2) + 1, blk);   // wave-uniform: the block is used up
+                        if ((c & 7) == 7) issue_block((c >> 3) + 1, blk);   // wave-uniform: the block is used up
                     }
                     constexpr int PO = (u + OFF) % WIN, PN = (u + OFF + K + 1) % WIN, PI = (u + OFF + 2 * K + 1) % WIN;
                     if constexpr (PO % 16 == 0) fetch(so, std::integral_constant<int, PO>{});
@@ -415,17 +431,19 @@ __global__ __launch_bounds__(256) void k_or4_bits(const unsigned long long* __re
 }
 
 template <int K, bool VERT>
-void launch_walk(hipStream_t s, const uint8_t* src, int C, unsigned long long* out, int h, int w, size_t plane_stride,
+void launch_walk(hipStream_t s, const uint8_t* src, int C, unsigned long long* out, int h, int w, int pitch, size_t plane_stride,
                  size_t bits_stride, int n) {
     WalkArgs a;
     a.src = src;
     a.out = out;
     a.h = h; a.w = w; a.wpr = (w + 63) / 64;
+    a.pitch = pitch;
     a.C = C;
     a.groups = ((VERT ? w : h) + 127) / 128;
     const int len = VERT ? h : w;
     a.segs = len > 640 ? 2 : 1;
-    a.seg_len = a.segs == 1 ? ((len + 63) & ~63) : ((len / 2 + 63) & ~63);
+    // horizontal segments start at multiples of 128 (the staging blocks are whole 128-byte lines)
+    a.seg_len = a.segs == 1 ? ((len + 127) & ~127) : (VERT ? (len + 1) / 2 : ((len / 2) & ~127));
     a.ntasks = a.groups * a.segs * n;
     a.plane_stride = plane_stride;
     a.bits_stride = bits_stride;
@@ -435,40 +453,44 @@ void launch_walk(hipStream_t s, const uint8_t* src, int C, unsigned long long* o
 
 template <int K>
 void launch_walk_both(hipStream_t s, const uint8_t* src, int C, unsigned long long* out_h, unsigned long long* out_v, int h, int w,
-                      size_t plane_stride, size_t bits_stride, int n, int passes) {
+                      int pitch, size_t plane_stride, size_t bits_stride, int n, int passes) {
     // `passes` (bit 0 horizontal, bit 1 vertical) is a measurement / debugging switch, LT_WALK_PASSES; default both
     const size_t bytes = ((size_t)(n - 1) * bits_stride + (size_t)h * ((w + 63) / 64)) * 8;
-    if (passes & 1) launch_walk<K, false>(s, src, C, out_h, h, w, plane_stride, bits_stride, n);
+    if (passes & 1) launch_walk<K, false>(s, src, C, out_h, h, w, pitch, plane_stride, bits_stride, n);
     else (void)hipMemsetAsync(out_h, 0, bytes, s);
-    if (passes & 2) launch_walk<K, true>(s, src, C, out_v, h, w, plane_stride, bits_stride, n);
+    if (passes & 2) launch_walk<K, true>(s, src, C, out_v, h, w, pitch, plane_stride, bits_stride, n);
     else (void)hipMemsetAsync(out_v, 0, bytes, s);
 }
 
 bool walk_supports(int k) { return k == 15 || k == 20 || k == 35; }
 
 void dispatch_walk(int k, hipStream_t s, const uint8_t* src, int C, unsigned long long* out_h, unsigned long long* out_v, int h, int w,
-                   size_t plane_stride, size_t bits_stride, int n, int passes) {
+                   int pitch, size_t plane_stride, size_t bits_stride, int n, int passes) {
     switch (k) {
-        case 15: launch_walk_both<15>(s, src, C, out_h, out_v, h, w, plane_stride, bits_stride, n, passes); break;
-        case 20: launch_walk_both<20>(s, src, C, out_h, out_v, h, w, plane_stride, bits_stride, n, passes); break;
-        default: launch_walk_both<35>(s, src, C, out_h, out_v, h, w, plane_stride, bits_stride, n, passes); break;
+        case 15: launch_walk_both<15>(s, src, C, out_h, out_v, h, w, pitch, plane_stride, bits_stride, n, passes); break;
+        case 20: launch_walk_both<20>(s, src, C, out_h, out_v, h, w, pitch, plane_stride, bits_stride, n, passes); break;
+        default: launch_walk_both<35>(s, src, C, out_h, out_v, h, w, pitch, plane_stride, bits_stride, n, passes); break;
     }
 }
 
 }  // namespace
 
+bool bilateral_walk_supported(int k_r, int C_r, int k_b, int C_b, int h, int w, int pitch) {
+    static const bool off = [] { const char* e = std::getenv("LT_BILATERAL_TILES"); return e && e[0] == '1'; }();
+    if (off || !walk_supports(k_r) || !walk_supports(k_b) || C_r < 0 || C_b < 0) return false;
+    if ((w & 3) || (pitch & 63) || pitch < w || w < 8 || h < 1) return false;
+    return (long long)k_r * (255 + C_r) < 32768 && (long long)k_b * (255 + C_b) < 32768;
+}
+
 // Both bilateral thresholds + OR-merge through the walking kernels.  scratch: three more bit planes of the same slots
 // (merged is the fourth partial and the result).  Returns 0 when it ran, -1 when the parameters are outside its limits.
 int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
                           unsigned long long* merged, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
-                          int h, int w, size_t plane_stride, size_t bits_stride, int n) {
-    static const bool off = [] { const char* e = std::getenv("LT_BILATERAL_TILES"); return e && e[0] == '1'; }();
-    if (off || n <= 0 || !walk_supports(k_r) || !walk_supports(k_b) || C_r < 0 || C_b < 0) return -1;
-    if ((w & 3) || (plane_stride & 3) || w < 8 || h < 1) return -1;
-    if ((long long)k_r * (255 + C_r) >= 32768 || (long long)k_b * (255 + C_b) >= 32768) return -1;
+                          int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n) {
+    if (n <= 0 || !bilateral_walk_supported(k_r, C_r, k_b, C_b, h, w, pitch) || (plane_stride & 63)) return -1;
     static const int passes = [] { const char* e = std::getenv("LT_WALK_PASSES"); return e ? std::atoi(e) : 15; }();
-    dispatch_walk(k_r, s, thr, C_r, merged, s1, h, w, plane_stride, bits_stride, n, passes & 3);
-    dispatch_walk(k_b, s, thb, C_b, s2, s3, h, w, plane_stride, bits_stride, n, (passes >> 2) & 3);
+    dispatch_walk(k_r, s, thr, C_r, merged, s1, h, w, pitch, plane_stride, bits_stride, n, passes & 3);
+    dispatch_walk(k_b, s, thb, C_b, s2, s3, h, w, pitch, plane_stride, bits_stride, n, (passes >> 2) & 3);
     const size_t words = (size_t)(n - 1) * bits_stride + (size_t)h * ((w + 63) / 64);
     hipLaunchKernelGGL(k_or4_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, merged, s1, s2, s3, merged, words);
     return 0;

@@ -142,6 +142,8 @@ struct SE29 {
 struct RunsGeom {
     int h, w, nstrips, nbands, band_rows, ntasks;
     size_t plane_stride;
+    int dpitch;                  // row pitch of the destination (w, or a 64-byte multiple for the threshold walks)
+    size_t dst_stride;           // bytes per frame of the destination
 };
 
 // Per-lane column bookkeeping, loop invariant: clamped byte offsets of the (up to) four pixels a
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void k_morph_runs(const uint8_t* __restrict__ 
     const int band = (task / g.nstrips) % g.nbands;
     const int frame = task / (g.nstrips * g.nbands);
     const uint8_t* s = src + (size_t)frame * g.plane_stride;
-    uint8_t* d = dst + (size_t)frame * g.plane_stride;
+    uint8_t* d = dst + (size_t)frame * g.dst_stride;
     const uint8_t* m = minuend ? minuend + (size_t)frame * g.plane_stride : nullptr;
     uint32_t* chain = s_chain[wv];
     const int x0 = strip * 128;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(256) void k_morph_runs(const uint8_t* __restrict__ 
                 oa_v = ma_cur > oa_v ? ma_cur - oa_v : 0u;
                 ob_v = mb_cur > ob_v ? mb_cur - ob_v : 0u;
             }
-            const size_t o = (size_t)y * g.w;
+            const size_t o = (size_t)y * g.dpitch;
             if (va) d[o + xa] = (uint8_t)oa_v;
             if (vb) d[o + xb] = (uint8_t)ob_v;
         }
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     const int band = (task / g.nstrips) % g.nbands;
     const int frame = task / (g.nstrips * g.nbands);
     const uint8_t* s = src + (size_t)frame * g.plane_stride;
-    uint8_t* d = dst + (size_t)frame * g.plane_stride;
+    uint8_t* d = dst + (size_t)frame * g.dst_stride;
     const uint8_t* m = minuend ? minuend + (size_t)frame * g.plane_stride : nullptr;
     uint2* chain = s_chain[wv];
     const int x0 = strip * 128;
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle
     const int plane_bytes = g.h * g.w;
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s), 0, plane_bytes, RSRC_RAW);
-    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, plane_bytes, RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, g.h * g.dpitch, RSRC_RAW);
     const __amdgpu_buffer_rsrc_t min_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(m ? m : s), 0, plane_bytes, RSRC_RAW);
     auto row_ptr = [&](int y) { return __mul24(min(max(y, 0), g.h - 1), g.w); };   // byte offset of the (clamped) row: wave-uniform
     auto rows_ok = [&](int y) { return y >= 0 && y < g.h; };
@@ -589,7 +591,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
             v = sub_sat16(me, ve) | (sub_sat16(mo, vo) << 8);
         }
         const int yo = yp + (lane >> 5);
-        if (yo >= yb0 && yo < yb1 && wcol < g.w) __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, __mul24(yo, g.w) + wcol, 0, 0);
+        if (yo >= yb0 && yo < yb1 && wcol < g.w) __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, __mul24(yo, g.dpitch) + wcol, 0, 0);
     };
     auto row_pair = [&](int yy) __attribute__((always_inline)) {
         const bool ina = rows_ok(yy), inb = rows_ok(yy + 1);
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
                     oa_v = qa > oa_v ? qa - oa_v : 0u;
                     ob_v = qb > ob_v ? qb - ob_v : 0u;
                 }
-                const size_t o = (size_t)yo * g.w;
+                const size_t o = (size_t)yo * g.dpitch;
                 if (va) d[o + xa] = (uint8_t)oa_v;
                 if (vb) d[o + xb] = (uint8_t)ob_v;
             }
@@ -690,15 +692,17 @@ bool table_matches(const EllipseSE& se) {
 
 template <class SE>
 void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, bool dilate,
-                 size_t plane_stride, int n) {
+                 size_t plane_stride, int n, int dpitch, size_t dst_stride) {
     RunsGeom g;
     g.h = h;
     g.w = w;
     g.plane_stride = plane_stride;
+    g.dpitch = dpitch > 0 ? dpitch : w;
+    g.dst_stride = dpitch > 0 ? dst_stride : plane_stride;
     g.nstrips = (w + 127) / 128;
     static const bool one_row = [] { const char* e = std::getenv("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
     static const bool narrow = [] { const char* e = std::getenv("LT_MORPH_WIDE"); return e && e[0] == '0'; }();
-    const bool wide = !narrow && (w & 3) == 0 && (plane_stride & 3) == 0 && w >= 4 &&
+    const bool wide = !narrow && (w & 3) == 0 && (plane_stride & 3) == 0 && w >= 4 && (g.dpitch & 3) == 0 && (g.dst_stride & 3) == 0 &&
                       ((uintptr_t)dst & 3) == 0 && ((uintptr_t)minuend & 3) == 0;
     // Band count: every task walks band_rows + 2R rows, and the chip holds `slots` waves at once, so
     // the makespan is ~ ceil(tasks / slots) * (band_rows + 2R).  Pick the band count that minimises
@@ -769,12 +773,12 @@ bool tophat_tables_match(const EllipseSE& se29, const EllipseSE& se55) {
 }
 
 void launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
-                       bool dilate, size_t plane_stride, int n) {
+                       bool dilate, size_t plane_stride, int n, int dpitch, size_t dst_stride) {
     if (n <= 0 || h <= 0 || w <= 0) return;
     if (k == 55)
-        launch_runs<SE55>(s, src, dst, minuend, h, w, dilate, plane_stride, n);
+        launch_runs<SE55>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride);
     else
-        launch_runs<SE29>(s, src, dst, minuend, h, w, dilate, plane_stride, n);
+        launch_runs<SE29>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride);
 }
 
 }  // namespace lt

@@ -73,6 +73,13 @@ struct lt_ctx {
     unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
     unsigned long long* d_bits_open = nullptr;    // the opened mask as the mask chain leaves it (what the searches read)
     unsigned long long* d_bits_tmp = nullptr;     // fourth partial plane of the walking threshold kernels
+    // Top-hat planes with a 64-byte-multiple row pitch: what the walking threshold kernels read (every 64-byte piece of
+    // a row is one aligned sector; with the image width as pitch the horizontal pass fetched every sector twice).
+    // th_padded[slot] says which copy of the slot's top-hat planes is current (lt_download_plane).
+    uint8_t* d_th_pad[2] = {nullptr, nullptr};
+    size_t th_pad_bytes = 0;
+    int th_pitch = 0;
+    std::vector<uint8_t> th_padded;
     // per slot: which forms of the mask are current.  The chain writes the bit plane only; the u8 mask
     // (d_plane[P_MASK]) is expanded from it when somebody asks for it; lt_upload_masks provides u8 only.
     std::vector<uint8_t> mask_bits_ok, mask_u8_ok;
@@ -226,6 +233,9 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_bits_eroded);
     dev_free(c->d_bits_open);
     dev_free(c->d_bits_tmp);
+    dev_free(c->d_th_pad[0]);
+    dev_free(c->d_th_pad[1]);
+    c->th_padded.clear();
     c->mask_bits_ok.clear();
     c->mask_u8_ok.clear();
     dev_free(c->d_rec);
@@ -339,6 +349,15 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     uint8_t* t3 = c->d_plane[P_T3] + off;
     uint8_t* merged = c->d_plane[P_MERGED] + off;
     uint8_t* mask = c->d_plane[P_MASK] + off;
+    // the walking threshold kernels read the top-hat planes with a padded row pitch: the dilate launches write them so
+    const bool walk = p->filter_type == 0 && !p->mask_noise && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp &&
+                      first + n <= (int)c->th_padded.size() &&
+                      bilateral_walk_supported(p->ksize_r, p->C_r, p->ksize_b, p->C_b, h, w, c->th_pitch);
+    const int dpitch = walk ? c->th_pitch : 0;
+    uint8_t* thRd = walk ? c->d_th_pad[0] + (size_t)first * c->th_pad_bytes : thR;
+    uint8_t* thBd = walk ? c->d_th_pad[1] + (size_t)first * c->th_pad_bytes : thB;
+    if (p->filter_type == 0 && first + n <= (int)c->th_padded.size())
+        for (int i = first; i < first + n; ++i) c->th_padded[(size_t)i] = walk ? 1 : 0;
     if (p->filter_type == 0) {
         if (c->brute_tophat) {   // debugging aid (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
@@ -352,16 +371,16 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             HIP_TRY(hipEventRecord(c->ev_fork, s));
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             launch_morph_runs(c->side, R, t3, nullptr, h, w, 29, false, ps, n);
-            launch_morph_runs(c->side, t3, thR, R, h, w, 29, true, ps, n);
+            launch_morph_runs(c->side, t3, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes);
             HIP_TRY(hipEventRecord(c->ev_join, c->side));
             launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
-            launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n);
+            launch_morph_runs(s, t0, thBd, B, h, w, 55, true, ps, n, dpitch, c->th_pad_bytes);
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
         } else {
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n); }
-            { StageScope t(c, ST_TOPHAT_R, s); launch_morph_runs(s, t0, thR, R, h, w, 29, true, ps, n); }
+            { StageScope t(c, ST_TOPHAT_R, s); launch_morph_runs(s, t0, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes); }
             { StageScope t(c, ST_ERODE_B, s);  launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n); }
-            { StageScope t(c, ST_TOPHAT_B, s); launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n); }
+            { StageScope t(c, ST_TOPHAT_B, s); launch_morph_runs(s, t0, thBd, B, h, w, 55, true, ps, n, dpitch, c->th_pad_bytes); }
         }
     }
     unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
@@ -370,10 +389,11 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     if (p->filter_type == 0) {
         StageScope t(c, ST_THRESHOLD, s);   // both bilateral thresholds, the greenery mask and the OR-merge
         // long-walk kernels for the supported window sizes (the eroded / opened planes are free until the open stage)
-        if (!p->mask_noise && c->d_bits_tmp)
-            merged_done = launch_bilateral_walk(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, mbits, ebits,
+        if (walk)
+            merged_done = launch_bilateral_walk(s, thRd, p->ksize_r, p->C_r, thBd, p->ksize_b, p->C_b, mbits, ebits,
                                                 c->d_bits_open + (size_t)first * c->bits_stride,
-                                                c->d_bits_tmp + (size_t)first * c->bits_stride, h, w, ps, c->bits_stride, n) == 0;
+                                                c->d_bits_tmp + (size_t)first * c->bits_stride, h, w, c->th_pitch,
+                                                c->th_pad_bytes, c->bits_stride, n) == 0;
         if (!merged_done)
           merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
                                             p->C_noise, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps,
@@ -621,6 +641,11 @@ int lt_reserve(lt_ctx* c, int capacity) {
     if ((rc = dev_alloc(&c->d_bits_eroded, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_bits_open, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_bits_tmp, n * c->bits_stride))) { free_slots(c); return rc; }
+    c->th_pitch = (c->calib.warp_w + 63) & ~63;
+    c->th_pad_bytes = (size_t)c->calib.warp_h * c->th_pitch;
+    for (auto& q : c->d_th_pad)
+        if ((rc = dev_alloc(&q, n * c->th_pad_bytes))) { free_slots(c); return rc; }
+    c->th_padded.assign(n, 0);
     c->mask_bits_ok.assign(n, 0);
     c->mask_u8_ok.assign(n, 1);          // zero-filled below
     if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }
@@ -817,6 +842,23 @@ int lt_download_plane(lt_ctx* c, int plane, int first, int n, uint8_t* out) {
         launch_bits_to_u8(c->stream, c->d_bits_merged + (size_t)first * c->bits_stride,
                           c->d_plane[P_MERGED] + (size_t)first * c->plane_bytes, c->calib.warp_h, c->calib.warp_w,
                           c->plane_bytes, c->bits_stride, n);
+    }
+    if (plane == LT_PLANE_TOPHAT_R || plane == LT_PLANE_TOPHAT_B) {   // slot by slot: the current copy may be the padded one
+        if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+        if ((rc = set_device(c))) return rc;
+        if ((rc = sync_all(c))) return rc;
+        const int w = c->calib.warp_w, h = c->calib.warp_h, q = plane == LT_PLANE_TOPHAT_R ? 0 : 1;
+        for (int i = first; i < first + n; ++i) {
+            uint8_t* dst = out + (size_t)(i - first) * c->plane_bytes;
+            if (i < (int)c->th_padded.size() && c->th_padded[(size_t)i])
+                HIP_TRY(hipMemcpy2DAsync(dst, (size_t)w, c->d_th_pad[q] + (size_t)i * c->th_pad_bytes, (size_t)c->th_pitch, (size_t)w,
+                                         (size_t)h, hipMemcpyDeviceToHost, c->stream));
+            else
+                HIP_TRY(hipMemcpyAsync(dst, c->d_plane[map[plane]] + (size_t)i * c->plane_bytes, c->plane_bytes,
+                                       hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return LT_OK;
     }
     return download(c, c->d_plane[map[plane]] + (size_t)first * c->plane_bytes, out, (size_t)n * c->plane_bytes);
 }

@@ -57,8 +57,9 @@ void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, c
 void launch_morph_ellipse(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w,
                           const EllipseSE& se, bool dilate, size_t plane_stride, int n);
 // decomposed 29x29 / 55x55 ellipses (k_tophat.hip); same contract as launch_morph_ellipse
+// dpitch > 0: the destination has its own row pitch and per-frame stride (the padded top-hat planes the threshold walks read)
 void launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
-                       bool dilate, size_t plane_stride, int n);
+                       bool dilate, size_t plane_stride, int n, int dpitch = 0, size_t dst_stride = 0);
 bool tophat_tables_match(const EllipseSE& se29, const EllipseSE& se55);
 void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int ksize, int C, int mode,
                       int tv, int fv, size_t plane_stride, int n);
@@ -77,10 +78,12 @@ void launch_pack_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, cons
                        size_t bits_stride, int n);
 void launch_open5_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded, uint8_t* mask, int h,
                        int w, size_t plane_stride, size_t bits_stride, int n);
-// both bilateral thresholds + merge through the long-walk kernels (k_threshold_walk.hip); 0 = ran, -1 = outside its limits
+// both bilateral thresholds + merge through the long-walk kernels (k_threshold_walk.hip).  The top-hat planes have the row
+// pitch `pitch` (a multiple of 64) and `plane_stride` bytes per frame.  0 = ran, -1 = outside its limits.
+bool bilateral_walk_supported(int k_r, int C_r, int k_b, int C_b, int h, int w, int pitch);
 int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
                           unsigned long long* merged, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
-                          int h, int w, size_t plane_stride, size_t bits_stride, int n);
+                          int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n);
 // erode + dilate with the 5x5 ellipse, bit plane in, bit plane out
 void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded,
                           unsigned long long* opened, int h, int w, size_t bits_stride, int n);
