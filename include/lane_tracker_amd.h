@@ -269,6 +269,10 @@ int  lt_set_stage_timing(lt_ctx* ctx, int enabled);
 int  lt_stage_reset(lt_ctx* ctx);
 int  lt_stage_ms(lt_ctx* ctx, float* ms, int32_t* launches, int n);
 const char* lt_stage_name(int stage);
+/* Which kernels evaluated the bilateral thresholds in the context's last 'bilateral' lt_mask_run / lt_filter_run:
+ * 1 = the long-walk kernels (window sizes 15 / 20 / 35, no greenery mask, width a multiple of 4), 0 = the tile kernel,
+ * -1 = none yet.  Both give identical masks; tests use this to know which one they have exercised. */
+int  lt_last_threshold_path(lt_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -125,6 +125,7 @@ _SIGNATURES = {
     "lt_stage_reset": (C.c_int, [_P]),
     "lt_stage_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]),
     "lt_stage_name": (C.c_char_p, [C.c_int]),
+    "lt_last_threshold_path": (C.c_int, [_P]),
 }
 
 _lib = None
@@ -531,6 +532,10 @@ class Context:
 
     def set_stage_timing(self, enabled):
         _check(self.lib.lt_set_stage_timing(self._h, int(bool(enabled))))
+
+    def last_threshold_path(self):
+        """1 = long-walk threshold kernels, 0 = tile kernel, -1 = no bilateral chain has run yet."""
+        return int(self.lib.lt_last_threshold_path(self._h))
 
     def stage_reset(self):
         _check(self.lib.lt_stage_reset(self._h))

@@ -167,11 +167,12 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
             dst[i * 4 * 128 / 4 + 1] = __builtin_amdgcn_perm(vb, va, 0x07030602u);
         }
     };
-    auto vread = [&](auto pc) -> uint32_t {           // (column l | column l+64 << 16) of ring row P
+    auto vraw = [&](auto pc) -> uint32_t {            // bytes (column l, column l+64) of ring row P
         constexpr int P = decltype(pc)::value;
-        const uint32_t v = *reinterpret_cast<const u16a*>(ring + P * 128 + 2 * lane);
-        return __builtin_amdgcn_perm(0u, v, 0x0c010c00u);
+        return *reinterpret_cast<const u16a*>(ring + P * 128 + 2 * lane);
     };
+    auto spread = [](uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x0c010c00u); };   // -> (column l | column l+64 << 16)
+    auto vread = [&](auto pc) -> uint32_t { return spread(vraw(pc)); };
 
     // ---- prologue: fill the ring, initial sums ----
     uint32_t st[8];
@@ -190,6 +191,10 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
         sr += vread(std::integral_constant<int, K + 1 + p>{});            // rows y0+1 .. y0+K
     }, std::make_integer_sequence<int, K>{});
     qc = vread(std::integral_constant<int, K>{});
+    // The ring reads of a step are issued one step ahead: the inline-assembly statements of a step keep the compiler
+    // from hoisting them, and a read issued right in front of its use costs the LDS latency on every step.
+    uint32_t ro = vraw(std::integral_constant<int, 0>{}), rn = vraw(std::integral_constant<int, (K + 1) % WIN>{}),
+             ri = vraw(std::integral_constant<int, (2 * K + 1) % WIN>{});
 
     // ---- the walk ----
     uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;          // lane t = the two column words of row (16-row batch start + t)
@@ -214,10 +219,12 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
                         land((sb >> 4) + g + NPRE, (g + NPRE) % NCH, st);
                         issue((sb >> 4) + g + NPRE + 1, st);
                     }
-                    constexpr int PO = u % WIN, PN = (u + K + 1) % WIN, PI = (u + 2 * K + 1) % WIN;
-                    const uint32_t qo = vread(std::integral_constant<int, PO>{});
-                    const uint32_t qn = vread(std::integral_constant<int, PN>{});
-                    const uint32_t qi = vread(std::integral_constant<int, PI>{});
+                    // this step's pixels were read during the previous step; read the next step's now (after the landing)
+                    constexpr int PO = (u + 1) % WIN, PN = (u + K + 2) % WIN, PI = (u + 2 * K + 2) % WIN;
+                    const uint32_t ro2 = vraw(std::integral_constant<int, PO>{}), rn2 = vraw(std::integral_constant<int, PN>{}),
+                                   ri2 = vraw(std::integral_constant<int, PI>{});
+                    const uint32_t qo = spread(ro), qn = spread(rn), qi = spread(ri);
+                    ro = ro2; rn = rn2; ri = ri2;
                     // verdict of row y0 + s: both columns at once, "fails" in bits 15 and 31
                     const uint32_t kp = __umul24(qc, (uint32_t)K);
                     const uint32_t v = (sl - kp) | (sr - kp);
@@ -333,6 +340,7 @@ __global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) {   // 3
     const uint32_t kbias = (uint32_t)(0x8000 + a.C * K) * 0x10001u;
     uint32_t sl = kbias, sr = kbias, qc;
     Stream so, sn, si;                                // out (position OFF + s), next (+ K + 1), in (+ 2K + 1)
+    Stream so2, sn2, si2;                             // their next 16 positions, read one step early
     {
         // sl = positions OFF .. OFF+K-1, sr = positions OFF+K+1 .. OFF+2K, dword by dword with v_sad_u8
         uint32_t la = 0, lb = 0, ra = 0, rb = 0;
@@ -357,6 +365,7 @@ __global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) {   // 3
         fetch(so, std::integral_constant<int, OFF % WIN>{});
         fetch(sn, std::integral_constant<int, (OFF + K + 1) % WIN>{});
         fetch(si, std::integral_constant<int, (OFF + 2 * K + 1) % WIN>{});
+        so2 = so; sn2 = sn; si2 = si;                 // step 0 may start a stream on a block boundary
     }
 
     // ---- the walk ----
@@ -379,9 +388,14 @@ __global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) {   // 3
                         if ((c & 7) == 7) issue_block((c >> 3) + 1, blk);   // wave-uniform: the block is used up
                     }
                     constexpr int PO = (u + OFF) % WIN, PN = (u + OFF + K + 1) % WIN, PI = (u + OFF + 2 * K + 1) % WIN;
-                    if constexpr (PO % 16 == 0) fetch(so, std::integral_constant<int, PO>{});
-                    if constexpr (PN % 16 == 0) fetch(sn, std::integral_constant<int, PN>{});
-                    if constexpr (PI % 16 == 0) fetch(si, std::integral_constant<int, PI>{});
+                    // a stream's next 16 positions are read during the step before it enters them (for the in stream
+                    // that is the step whose landing, just above, brought them); the switch is a register rename
+                    if constexpr (PO % 16 == 0) so = so2;
+                    if constexpr (PN % 16 == 0) sn = sn2;
+                    if constexpr (PI % 16 == 0) si = si2;
+                    if constexpr ((PO + 1) % 16 == 0) fetch(so2, std::integral_constant<int, (PO + 1) % WIN>{});
+                    if constexpr ((PN + 1) % 16 == 0) fetch(sn2, std::integral_constant<int, (PN + 1) % WIN>{});
+                    if constexpr ((PI + 1) % 16 == 0) fetch(si2, std::integral_constant<int, (PI + 1) % WIN>{});
                     const uint32_t qo = pick(so, std::integral_constant<int, PO>{});
                     const uint32_t qn = pick(sn, std::integral_constant<int, PN>{});
                     const uint32_t qi = pick(si, std::integral_constant<int, PI>{});

@@ -80,6 +80,7 @@ struct lt_ctx {
     size_t th_pad_bytes = 0;
     int th_pitch = 0;
     std::vector<uint8_t> th_padded;
+    int last_threshold_path = -1;                 // lt_last_threshold_path
     // per slot: which forms of the mask are current.  The chain writes the bit plane only; the u8 mask
     // (d_plane[P_MASK]) is expanded from it when somebody asks for it; lt_upload_masks provides u8 only.
     std::vector<uint8_t> mask_bits_ok, mask_u8_ok;
@@ -353,6 +354,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     const bool walk = p->filter_type == 0 && !p->mask_noise && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp &&
                       first + n <= (int)c->th_padded.size() &&
                       bilateral_walk_supported(p->ksize_r, p->C_r, p->ksize_b, p->C_b, h, w, c->th_pitch);
+    if (p->filter_type == 0) c->last_threshold_path = walk ? 1 : 0;
     const int dpitch = walk ? c->th_pitch : 0;
     uint8_t* thRd = walk ? c->d_th_pad[0] + (size_t)first * c->th_pad_bytes : thR;
     uint8_t* thBd = walk ? c->d_th_pad[1] + (size_t)first * c->th_pad_bytes : thB;
@@ -1573,6 +1575,11 @@ int lt_timer_stop(lt_ctx* c, float* ms) {
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return LT_OK;
+}
+
+int lt_last_threshold_path(lt_ctx* c) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    return c->last_threshold_path;
 }
 
 int lt_set_stage_timing(lt_ctx* c, int enabled) {
