@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblane_tracker_amd.so")
+# LANE_TRACKER_AMD_LIB: load another build of the same library (tools/toolchain_cases.sh compares variant builds)
+LIB_PATH = os.environ.get("LANE_TRACKER_AMD_LIB") or os.path.join(_HERE, "liblane_tracker_amd.so")
 NUM_STAGES = 12
 
 PLANE_R, PLANE_LAB_B, PLANE_TOPHAT_R, PLANE_TOPHAT_B, PLANE_MERGED, PLANE_MASK = range(6)

@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
                 // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
                 // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the
                 // third pixel (caught by the parity test); the barrier costs nothing at run time.
+#ifndef LT_CASE_WARP_NO_BARRIER   // tools/toolchain_cases.sh builds the kernel without it to check whether the case still exists
                 asm volatile("" : "+v"(r), "+v"(b));
+#endif
                 outR |= ((uint32_t)r & 255u) << (8 * i);
                 outB |= ((uint32_t)b & 255u) << (8 * i);
             }

@@ -604,7 +604,12 @@ __device__ __forceinline__ bool box_argmax_window(SRC src, int ncnt, int ww, int
 // left line -- caught by the golden tests, and correct again with a printf next to the assignment, i.e. a
 // code-generation problem, not a data race.  As a separate function it is correct and costs one call.
 // The per-side state lives in scalar registers (every value is wave-uniform; readfirstlane says so).
-__device__ __noinline__ void sws2_recurrence(SearchGeom g, int nlev, lds_cu32* sum0, lds_u32* prefix, lds_cu16* lev,
+#ifdef LT_CASE_SWS2_INLINE         // tools/toolchain_cases.sh: the inlined form, to check whether the case still exists
+#define LT_SWS2_RECURRENCE_LINKAGE __forceinline__
+#else
+#define LT_SWS2_RECURRENCE_LINKAGE __noinline__
+#endif
+__device__ LT_SWS2_RECURRENCE_LINKAGE void sws2_recurrence(SearchGeom g, int nlev, lds_cu32* sum0, lds_u32* prefix, lds_cu16* lev,
                                              lds_i32* roi_ab, lds_i32* state, int32_t* cent) {
     const int lane = lane_id();
     const int W = g.w, ww = g.ww, wh = g.wh, hw = g.hw, H1 = g.img_height;
