@@ -275,36 +275,38 @@ def test_filter_lane_points_any_size(ctx, nat, oracle, shape):
         assert_same(got, oracle.filter_lane_points(bev, oracle.filter_params(**kw)), f"{shape} {kw}")
 
 
-def test_full_batch_256_properties(nat, cal, oracle, ref_calib):
-    """BASELINE config 2/3 size: 256 frames resident in HBM.  Checked through size-independent
-    properties (duplicate frames -> identical masks/records, record counts == list lengths) plus
-    oracle spot checks."""
+def test_full_batch_256_unique_frames_bit_exact(nat, cal, oracle, ref_calib):
+    """BASELINE configs 2 / 3: a batch of 256 DIFFERENT synthetic frames resident in HBM, every mask compared bit for bit
+    with the oracle and every record with its search + fit (the oracle runs one frame per host thread)."""
+    from concurrent.futures import ThreadPoolExecutor
     from lane_tracker_amd import synth
     r = synth.SceneRenderer()
-    uniq = np.stack([r.render(500 + i)[0] for i in range(16)], 0)
-    batch = uniq[np.arange(256) % 16]
+    n = 256
+    batch = np.stack([r.render(500 + i)[0] if i % 16 else synth.frame_uniform(500 + i) for i in range(n)], 0)
     c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
-                    cal["warp_matrices"][0], device=0, capacity=256)
+                    cal["warp_matrices"][0], device=0, capacity=n)
     try:
         c.upload_frames(batch)
-        c.set_frame_base(256, 1000)
-        c.mask_run(256)
-        c.sws_fit_run(256)
-        rec = c.download_records(256)
-        masks = c.download_masks(256)
-        assert rec["frame"].tolist() == list(range(1000, 1256))
-        for i in range(16, 256):
-            assert np.array_equal(masks[i], masks[i % 16])
-            assert rec[i]["left_coeffs"].tobytes() == rec[i % 16]["left_coeffs"].tobytes()
-            assert rec[i]["n_left"] == rec[i % 16]["n_left"] and rec[i]["n_right"] == rec[i % 16]["n_right"]
-        for i in (0, 7, 15):
-            o = oracle.frame_sws_fit(ref_calib, uniq[i], want_mask=True)
-            assert_same(masks[i], o["mask"], f"mask {i}")
-            assert (int(rec[i]["n_left"]), int(rec[i]["n_right"]), bool(rec[i]["detected"])) == (o["n_left"], o["n_right"], o["detected"])
-            assert coeff_close(rec[i]["left_coeffs"], o["coeffs"][0]) and coeff_close(rec[i]["right_coeffs"], o["coeffs"][1])
-            ys, xs = c.download_pixels(240 + i, 0)
+        c.set_frame_base(n, 1000)
+        c.mask_run(n)
+        c.sws_fit_run(n)
+        rec = c.download_records(n)
+        masks = c.download_masks(n)
+        assert rec["frame"].tolist() == list(range(1000, 1000 + n))
+        threads = min(64, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else 8
+        oracle.frame_sws_fit(ref_calib, batch[0])        # builds the oracle's per-calibration tables before the threads start
+        with ThreadPoolExecutor(threads) as ex:          # ctypes releases the GIL
+            want = list(ex.map(lambda i: oracle.frame_sws_fit(ref_calib, batch[i], want_mask=True), range(n)))
+        bad_masks = [i for i in range(n) if not np.array_equal(masks[i], want[i]["mask"])]
+        assert not bad_masks, f"{len(bad_masks)} of {n} masks differ from the oracle, first: frame {bad_masks[0]}"
+        for i, o in enumerate(want):
+            assert (int(rec[i]["n_left"]), int(rec[i]["n_right"]), bool(rec[i]["detected"])) == (o["n_left"], o["n_right"], o["detected"]), i
+            if o["detected"]:
+                assert coeff_close(rec[i]["left_coeffs"], o["coeffs"][0]) and coeff_close(rec[i]["right_coeffs"], o["coeffs"][1]), i
+        assert int(rec["detected"].sum()) >= n - n // 16 - 2     # the lane-like frames are found, the noise frames need not be
+        for i in (3, 77, 255):
+            ys, xs = c.download_pixels(i, 0)
             assert len(ys) == int(rec[i]["n_left"])
-        assert rec["detected"].all()
     finally:
         c.close()
 
