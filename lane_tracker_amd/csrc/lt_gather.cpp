@@ -110,12 +110,33 @@ int ensure_blob(lt_gather* g, size_t bytes) {
 
 }  // namespace
 
+namespace {
+// librccl prints a version banner on stdout when its first communicator comes up; a caller that writes its result to
+// stdout (bench.py prints ONE JSON line) must not find it there.  While this object lives, fd 1 points at stderr.
+struct StdoutToStderr {
+    int saved = -1;
+    StdoutToStderr() {
+        std::fflush(stdout);
+        saved = dup(1);
+        if (saved >= 0) dup2(2, 1);
+    }
+    ~StdoutToStderr() {
+        std::fflush(stdout);
+        if (saved >= 0) {
+            dup2(saved, 1);
+            close(saved);
+        }
+    }
+};
+}  // namespace
+
 extern "C" {
 
 int lt_gather_init(lt_ctx* ctx, int rank, int world, const char* id_path, int timeout_s, lt_gather** out) {
     if (!ctx || !out || !id_path) return set_error(LT_ERR_INVALID, "null argument");
     if (world < 1 || rank < 0 || rank >= world) return set_error(LT_ERR_INVALID, "rank %d outside world %d", rank, world);
     *out = nullptr;
+    StdoutToStderr quiet;
     int rc = load_rccl();
     if (rc) return rc;
     const int device = ctx_device(ctx);
