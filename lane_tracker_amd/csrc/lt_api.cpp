@@ -81,6 +81,12 @@ struct lt_ctx {
     int th_pitch = 0;
     std::vector<uint8_t> th_padded;
     int last_threshold_path = -1;                 // lt_last_threshold_path
+    // The walking threshold kernels are long serial walks (a wave covers half an image row or column): they win once a
+    // call brings enough frames to fill the chip -- measured crossover 70-80 frames of 1100 x 1080 per call
+    // (tools/threshold_crossover.py: 64 frames 232 vs 210 us, 96 frames 255 vs 304 us) -- and lose badly on a single
+    // frame (164 vs 25 us).  Calls below this many pixels take the tile kernel.  LT_WALK_MIN_FRAMES=<n> (read at
+    // lt_create, in frames of this context's bird's-eye size) overrides it; 0 = always walk.
+    long long walk_min_pixels = 80LL * 1100 * 1080;
     // per slot: which forms of the mask are current.  The chain writes the bit plane only; the u8 mask
     // (d_plane[P_MASK]) is expanded from it when somebody asks for it; lt_upload_masks provides u8 only.
     std::vector<uint8_t> mask_bits_ok, mask_u8_ok;
@@ -338,7 +344,8 @@ int validate_filter(const lt_filter_params* p) {
 }
 
 // filter_lane_points() on planes P_R / P_B of the given slots (lane_tracker.py:210-238)
-int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter_params* p, int h, int w, bool u8_mask = false) {
+int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter_params* p, int h, int w, int call_frames,
+                     bool u8_mask = false) {
     const size_t ps = c->plane_bytes, off = (size_t)first * ps;
     uint8_t* R = c->d_plane[P_R] + off;
     uint8_t* B = c->d_plane[P_B] + off;
@@ -352,7 +359,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     uint8_t* mask = c->d_plane[P_MASK] + off;
     // the walking threshold kernels read the top-hat planes with a padded row pitch: the dilate launches write them so
     const bool walk = p->filter_type == 0 && !p->mask_noise && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp &&
-                      first + n <= (int)c->th_padded.size() &&
+                      first + n <= (int)c->th_padded.size() && (long long)call_frames * h * w >= c->walk_min_pixels &&
                       bilateral_walk_supported(p->ksize_r, p->C_r, p->ksize_b, p->C_b, h, w, c->th_pitch);
     if (p->filter_type == 0) c->last_threshold_path = walk ? 1 : 0;
     const int dpitch = walk ? c->th_pitch : 0;
@@ -514,6 +521,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
         lt_destroy(c);
         return rc;
     };
+    if (const char* e = getenv("LT_WALK_MIN_FRAMES")) c->walk_min_pixels = atoll(e) * calib->warp_w * calib->warp_h;
     if (hipSetDevice(device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipSetDevice(%d) failed", device));
     if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipGetDeviceProperties failed"));
     if (create_compute_stream(&c->stream) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipStreamCreate failed"));
@@ -1303,7 +1311,7 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
           launch_warp_split(st, c->d_und + (size_t)f0 * c->und_px, c->und_px, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
                             c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
                             ps, m); }
-        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w);
+        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
     });
     if (rc) return rc;
     c->have_mask = true;
@@ -1323,7 +1331,7 @@ int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
         { StageScope t(c, ST_SPLIT_BEV, st);
           launch_split_bev(st, c->d_bev + (size_t)f0 * c->bev_bytes, c->bev_bytes, (int)ps, c->d_gamma, c->d_cbrt,
                            c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps, ps, m); }
-        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w);
+        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
     });
     if (rc) return rc;
     c->have_mask = true;
@@ -1488,7 +1496,7 @@ int lt_filter_lane_points(lt_ctx* c, const uint8_t* bev, int h, int w, const lt_
     if (e == hipSuccess) {
         launch_split_bev(c->stream, d_bev, tmp.plane_bytes * 3, (int)tmp.plane_bytes, c->d_gamma, c->d_cbrt, c->d_coef,
                          tmp.d_plane[P_R], tmp.d_plane[P_B], tmp.plane_bytes, 1);
-        rc = run_filter_chain(&tmp, c->stream, 0, 1, p, h, w, true);
+        rc = run_filter_chain(&tmp, c->stream, 0, 1, p, h, w, 1, true);
         if (rc == LT_OK) e = hipMemcpyAsync(mask, tmp.d_plane[P_MASK], tmp.plane_bytes, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);

@@ -51,10 +51,11 @@ def test_sliding_window_golden_set_200_times_in_one_process():
             c.close()
 
 
-def test_mask_chain_100_times_in_one_process():
+def test_mask_chain_100_times_in_one_process(monkeypatch):
     """The default mask chain (top-hats, walking thresholds with their inline-assembly lane writes, open) on the same four
     frames 100 times, interleaved with a second parameter set that takes the tile kernel: identical masks every time."""
     import zlib
+    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")          # four frames: force the walking kernels
     from lane_tracker_amd import _native, calib, synth
     cal = calib.reference_calibration()
     r = synth.SceneRenderer(cal)

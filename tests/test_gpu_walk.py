@@ -42,7 +42,8 @@ def _bilateral_np(p, k, C):
 
 
 @pytest.mark.parametrize("size", SIZES)
-def test_walk_kernels_match_the_oracle_on_many_sizes(size):
+def test_walk_kernels_match_the_oracle_on_many_sizes(size, monkeypatch):
+    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")          # read at lt_create: these small calls would take the tile kernel
     from lane_tracker_amd import _native, calib
     from oracle import oracle as O
     w, h = size
@@ -73,8 +74,9 @@ def test_walk_kernels_match_the_oracle_on_many_sizes(size):
         ctx.close()
 
 
-def test_other_parameters_take_the_tile_kernel_and_agree():
+def test_other_parameters_take_the_tile_kernel_and_agree(monkeypatch):
     """Window sizes outside {15, 20, 35}, the greenery mask and LT-internal limits fall back to k_bilateral_tile2."""
+    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")
     from lane_tracker_amd import _native, calib
     from oracle import oracle as O
     cal = calib.reference_calibration()
@@ -90,5 +92,25 @@ def test_other_parameters_take_the_tile_kernel_and_agree():
             assert np.array_equal(ctx.download_masks(1)[0], O.filter_lane_points(bev[0], O.filter_params(**kw)))
             assert np.array_equal(ctx.download_plane(_native.PLANE_TOPHAT_R, 1)[0],
                                   O.filter_lane_points(bev[0], O.filter_params(**kw), want_planes=True)[1][2])
+    finally:
+        ctx.close()
+
+
+def test_small_calls_take_the_tile_kernel_by_default(monkeypatch):
+    """The policy: a call with few frames cannot fill the chip with long walks and takes the tile kernel."""
+    monkeypatch.delenv("LT_WALK_MIN_FRAMES", raising=False)
+    from lane_tracker_amd import _native, calib, synth
+    cal = calib.reference_calibration()
+    ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=96)
+    try:
+        f = synth.SceneRenderer(cal).render(3)[0]
+        ctx.upload_frames(np.broadcast_to(f, (96,) + f.shape))
+        ctx.mask_run(2)
+        assert ctx.last_threshold_path() == 0
+        small = ctx.download_masks(2)
+        ctx.mask_run(96)
+        assert ctx.last_threshold_path() == 1
+        big = ctx.download_masks(96)
+        assert np.array_equal(big[0], small[0]) and np.array_equal(big[95], small[1])
     finally:
         ctx.close()
