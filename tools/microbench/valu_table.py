@@ -17,7 +17,7 @@ print("columns: wave64 instructions per ns per SIMD at W waves per SIMD (all %d 
 print("%-36s" % "instruction / chain" + "".join("%8s" % w for w in Ws) + "   cyc/inst")
 summary = {}
 for name, r in ops.items():
-    m = re.search(r"_x(\d)insts", name)
+    m = re.search(r"_x(\d+)insts", name)
     mult = int(m.group(1)) if m else 1
     best = max(r[w]["wave_insts_per_ns_per_simd"] for w in Ws) * mult
     cyc = clock / (r["8"]["wave_insts_per_ns_per_simd"] * mult)
