@@ -66,3 +66,51 @@ def test_two_rank_gather_equals_single_process(tmp_path, n_frames):
         assert got.dtype == _native.RECORD_DTYPE and got.shape == want.shape
         assert got.tobytes() == want.tobytes()          # bitwise, frame order preserved
         assert got["frame"].tolist() == list(range(n_frames))
+
+
+def test_spawn_ranks_environment_and_failure_propagation(tmp_path):
+    """The launcher half of `bench.py --gpus N` without a GPU: every rank gets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* and one shared rendezvous file name; a failing rank ends the job with a non-zero code instead of leaving
+    the others waiting in a collective."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ok = tmp_path / "rank_ok.py"
+    ok.write_text(textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, %r)
+        from lane_tracker_amd import distributed
+        rank, local, world = distributed.env_rank()
+        assert (rank, world) == (int(os.environ["RANK"]), 3) and local == rank
+        assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+        open(os.path.join(%r, "rank%%d.txt" %% rank), "w").write(distributed.rendezvous_path())
+    """ % (root, str(tmp_path))))
+    code = ("import sys; sys.path.insert(0, %r); from lane_tracker_amd import distributed as d; "
+            "sys.exit(d.spawn_ranks(3, [sys.executable, %r], timeout=120))" % (root, str(ok)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    paths = {(tmp_path / ("rank%d.txt" % i)).read_text() for i in range(3)}
+    assert len(paths) == 1 and "lt_gather_" in paths.pop()
+    bad = tmp_path / "rank_bad.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(60)\n")
+    code = ("import sys; sys.path.insert(0, %r); from lane_tracker_amd import distributed as d; "
+            "sys.exit(d.spawn_ranks(3, [sys.executable, %r], timeout=120))" % (root, str(bad)))
+    t0 = __import__("time").time()
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7 and __import__("time").time() - t0 < 30      # the sleeping ranks were ended, not waited for
+
+
+def test_bench_refuses_a_rank_count_it_cannot_deliver():
+    """`bench.py --gpus N` must never print an n_gpus: 1 line for N > 1: without GPUs it exits 2 with a message, and a
+    launcher environment whose WORLD_SIZE differs from --gpus is refused too."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is visible: covered by tests/test_gpu_distributed.py")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
