@@ -267,7 +267,10 @@ __global__ __launch_bounds__(256) void k_morph_runs(const uint8_t* __restrict__ 
 // into one instruction  A2[j] = min3(A[j+2], Ha[s(j+1)], Hb[s(j)])  for two pixels: 27.5 instead of
 // 54 accumulate ops per row, and half the loop overhead and LDS round trips per row.
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-constexpr uint32_t BIAS2 = 0x04000400u;
+#ifndef LT_MORPH_BIAS
+#define LT_MORPH_BIAS 1
+#endif
+constexpr uint32_t BIAS2 = LT_MORPH_BIAS ? 0x04000400u : 0u;
 
 template <bool DIL>
 __device__ __forceinline__ uint32_t op2(uint32_t a, uint32_t b) {
@@ -319,12 +322,14 @@ __device__ __forceinline__ void for_each_const(F&& f, std::integer_sequence<int,
 // 161 VGPRs, three waves per SIMD.  Fused, the reads come in five stages ordered by half-width, and each stage is
 // followed at once by the pipeline updates whose two half-widths it completes (outer rows of the ellipse first), so
 // only one stage of reads and a few half-widths are alive at a time.
+// Plane 0 holds only the 64 entries the half-width-0 window reads (entry R + lane = the lane's own columns): lane w stores
+// its entry R.. as slot w (see row_pair), lane r reads slot (R + r) mod 64 at LDS address `s0_rd`.
 template <class SE, bool DIL, bool FUSE = false>
-__device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uint2 e_pb, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH],
+__device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uint2 e_pb, uint32_t s0_rd, uint32_t (&Ha)[SE::NH], uint32_t (&Hb)[SE::NH],
                                              uint32_t* A = nullptr, uint32_t* out_ab = nullptr) {
     uint2* S0 = s + MARGIN;
     uint2* S4 = S0 + 2 * PLANE;
-    uint2* SL = S0 + 3 * PLANE;   // S13 (55x55) or S7 (29x29)
+    uint2* SL = S0 + 3 * PLANE;   // S13 (55x55)
     const int pa = lane, pb = lane + 64;
     // Every LDS read of this function is a single-address ds_read_b64 issued by hand (256 B/clk in the LDS
     // pipe).  Left to the compiler they become ds_read2_b64, which moves the same bytes at half the rate,
@@ -377,7 +382,7 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
     auto hi = [](unsigned long long v) { return (uint32_t)(v >> 32); };
     if constexpr (SE::K == 55 && FUSE) {
         constexpr int K = SE::K, R = SE::R;
-        constexpr int O0 = (MARGIN + R) * 8, O4 = (2 * PLANE + MARGIN + R - 8) * 8, O13 = (3 * PLANE + MARGIN + R - 14) * 8;   // from cb
+        constexpr int O4 = (2 * PLANE + MARGIN + R - 8) * 8, O13 = (3 * PLANE + MARGIN + R - 14) * 8;   // from cb
         uint32_t An[K];
         auto updates = [&](auto stage) {
             for_each_const([&](auto jc) {
@@ -396,7 +401,7 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         // "at most n outstanding" with n = the reads issued after a stage means that stage has arrived).
         // stage 1: half-widths 0, 7, 10, 12 -- planes S0 and S4, read under the last chain step
         unsigned long long r0, f0, f1, f2, f3, f4, f5, f6;
-        LT_RD64(r0, cb, O0);
+        LT_RD64(r0, s0_rd, 0);
         LT_RD64(f0, cb, O4 + 0); LT_RD64(f1, cb, O4 + 16); LT_RD64(f2, cb, O4 + 40); LT_RD64(f3, cb, O4 + 64);   // p-8, p-6, p-3, p
         LT_RD64(f4, cb, O4 + 88); LT_RD64(f5, cb, O4 + 112); LT_RD64(f6, cb, O4 + 128);                          // p+3, p+6, p+8
         LT_STEP3(2, 3, 9)                                                                                        // waits for everything
@@ -456,9 +461,9 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         out_ab[1] = A[0];                                                      // row y + 1
     } else if (SE::K == 55) {
         LT_STEP3(2, 3, 9)
-        const uint32_t a0 = lds_addr(S0 + p), a4 = lds_addr(S4 + p - 8), a13 = lds_addr(SL + p - 14);
+        const uint32_t a4 = lds_addr(S4 + p - 8), a13 = lds_addr(SL + p - 14);
         unsigned long long r0, f[7], g[29];
-        LT_RD64(r0, a0, 0);
+        LT_RD64(r0, s0_rd, 0);
         LT_RD64(f[0], a4, 0);    // p-8
         LT_RD64(f[1], a4, 16);   // p-6
         LT_RD64(f[2], a4, 40);   // p-3
@@ -492,38 +497,30 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         }
         Ha[16] = op3<DIL>(lo(g[0]), lo(g[14]), lo(g[28])); Hb[16] = op3<DIL>(hi(g[0]), hi(g[14]), hi(g[28]));   // 27
     } else {
-        {
-            unsigned long long a0, a2, b0, b2;
-            LT_RD64(a0, cb, (2 * PLANE + MARGIN - 3) * 8);
-            LT_RD64(a2, cb, (2 * PLANE + MARGIN + 3) * 8);
-            LT_RD64(b0, cb, (2 * PLANE + MARGIN + 64 - 3) * 8);
-            LT_RD64(b2, cb, (2 * PLANE + MARGIN + 64 + 3) * 8);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a2), "+v"(b0), "+v"(b2)::"memory");
-            SL[pa] = op2v<DIL>(pair(a0), pair(a2));
-            SL[pb] = op2v<DIL>(pair(b0), pair(b2));
-            wave_lds_fence();
-        }
-        const uint32_t a0 = lds_addr(S0 + p), a4 = lds_addr(S4 + p - 1), a7 = lds_addr(SL + p - 7);
-        unsigned long long r0, f0, f1, g[15];
-        LT_RD64(r0, a0, 0);
-        LT_RD64(f0, a4, 0);     // S4[p-1]
-        LT_RD64(f1, a4, 16);    // S4[p+1]
-#define LT_G(i) LT_RD64(g[i], a7, (i) * 8)
-        LT_G(0); LT_G(1); LT_G(2); LT_G(3); LT_G(4); LT_G(5); LT_G(7); LT_G(9); LT_G(10); LT_G(11); LT_G(12); LT_G(13); LT_G(14);
+        // 29x29: every window straight from S4 (half-width 4 + t = S4[p - t] u S4[p + t] for t <= 4, with S4[p] in the
+        // middle for t <= 9, and 14 = 7 u S4[p -+ 10]).  A further chain plane S7 would save nothing in VALU and costs a
+        // 128-entry LDS store per row pair: the LDS pipe, where a 16-byte store takes 13 cycles, is this kernel's bound.
+        const uint32_t a4 = lds_addr(S4 + p - 10);
+        unsigned long long r0, g[21];
+        LT_RD64(r0, s0_rd, 0);
+#define LT_G(i) LT_RD64(g[i], a4, (i) * 8)
+        LT_G(9); LT_G(11); LT_G(7); LT_G(13); LT_G(10); LT_G(5); LT_G(15); LT_G(4); LT_G(16); LT_G(3); LT_G(17); LT_G(2); LT_G(18);
+        LT_G(1); LT_G(19); LT_G(0); LT_G(20);
 #undef LT_G
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(r0), "+v"(f0), "+v"(f1), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]),
-                       "+v"(g[7]), "+v"(g[9]), "+v"(g[10]), "+v"(g[11]), "+v"(g[12]), "+v"(g[13]), "+v"(g[14])
+                     : "+v"(r0), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[7]), "+v"(g[9]),
+                       "+v"(g[10]), "+v"(g[11]), "+v"(g[13]), "+v"(g[15]), "+v"(g[16]), "+v"(g[17]), "+v"(g[18]), "+v"(g[19]), "+v"(g[20])
                      :: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        Ha[0] = lo(r0); Hb[0] = hi(r0);                                          // 0
-        Ha[1] = op2<DIL>(lo(f0), lo(f1)); Hb[1] = op2<DIL>(hi(f0), hi(f1));      // 5
-        Ha[2] = lo(g[7]); Hb[2] = hi(g[7]);                                      // 7
+        Ha[0] = lo(r0); Hb[0] = hi(r0);                                                     // 0
+        Ha[1] = op2<DIL>(lo(g[9]), lo(g[11])); Hb[1] = op2<DIL>(hi(g[9]), hi(g[11]));       // 5
+        Ha[2] = op2<DIL>(lo(g[7]), lo(g[13])); Hb[2] = op2<DIL>(hi(g[7]), hi(g[13]));       // 7
 #pragma unroll
-        for (int q = 2; q <= 7; ++q) {                                           // 9..14
-            Ha[1 + q] = op2<DIL>(lo(g[7 - q]), lo(g[7 + q]));
-            Hb[1 + q] = op2<DIL>(hi(g[7 - q]), hi(g[7 + q]));
+        for (int t = 5; t <= 9; ++t) {                                                      // 9..13
+            Ha[t - 2] = op3<DIL>(lo(g[10 - t]), lo(g[10]), lo(g[10 + t]));
+            Hb[t - 2] = op3<DIL>(hi(g[10 - t]), hi(g[10]), hi(g[10 + t]));
         }
+        Ha[8] = op3<DIL>(Ha[2], lo(g[0]), lo(g[20])); Hb[8] = op3<DIL>(Hb[2], hi(g[0]), hi(g[20]));   // 14
     }
 #undef LT_STEP3
 #undef LT_RD64
@@ -535,7 +532,18 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
 // writes, one 64-bit read per lane) so that every lane holds four adjacent pixels of one row: ONE dword store and, for
 // the top-hat, ONE dword load of the minuend per row pair instead of 4 + 4.  The read-back and the store of a row
 // pair happen one iteration later, under the next pair's window update, so the LDS round trip is off the critical path.
-template <class SE, bool DIL, bool WIDE>
+//
+// Borders without masks.  OpenCV ignores taps outside the image; here rows and columns are CLAMPED instead, which is the
+// same thing for this structuring element: a clamped tap repeats an edge pixel that the true footprint already holds
+// (a horizontal window that sticks out on the left contains column 0 because its centre is inside the image; an SE row
+// that lies above the image repeats row 0 with ITS half-width, and the SE row that really lands on row 0 is nearer to the
+// centre, i.e. at least as wide).  So no neutral fill, no per-lane keep masks and no row-inside-image selects.
+// Outputs and the minuend go through running per-lane offsets into buffer descriptors that cover exactly the band's rows
+// (destination) or the plane (minuend): rows outside them, and lanes right of the image, are out of range, which the
+// hardware turns into dropped stores / zero loads -- no compares, no exec masking, no address clamps in the loop.
+// TOPHAT: src - open(src) can never be negative (an opening is anti-extensive, also with ignored borders), so the
+// saturating subtract of four bytes is one plain 32-bit subtract (no byte ever borrows).
+template <class SE, bool DIL, bool WIDE, bool TH>
 __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     const uint8_t* __restrict__ minuend, RunsGeom g) {
     __shared__ uint2 s_chain[4][4 * PLANE];   // S0, S1, S4, S13|S7
@@ -545,12 +553,15 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);   // wave-uniform: keeps the loop scalar
     if (task >= g.ntasks) return;
+    // Without the bias the pixel patterns 0x00vv are f16 denormals: min/max must not flush them.  FP16 denormals are on
+    // in the kernel descriptor the compiler writes (tests/test_isa_guards.py checks it); set MODE.FP_DENORM[3:2] anyway.
+    if (!LT_MORPH_BIAS) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);
     const int strip = task % g.nstrips;
     const int band = (task / g.nstrips) % g.nbands;
     const int frame = task / (g.nstrips * g.nbands);
     const uint8_t* s = src + (size_t)frame * g.plane_stride;
     uint8_t* d = dst + (size_t)frame * g.dst_stride;
-    const uint8_t* m = minuend ? minuend + (size_t)frame * g.plane_stride : nullptr;
+    const uint8_t* m = TH ? minuend + (size_t)frame * g.plane_stride : nullptr;
     uint2* chain = s_chain[wv];
     const int x0 = strip * 128;
     const int yb0 = band * g.band_rows, yb1 = min(yb0 + g.band_rows, g.h);
@@ -563,55 +574,85 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
 
     uint32_t A[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) A[j] = NEUTRAL;
+    for (int j = 0; j < K; ++j) A[j] = NEUTRAL;   // flushed out of the pipeline before the band's first row
 
     const int y_first = yb0 - R, y_last = yb1 - 1 + R;
-    const LaneCols cols = lane_cols(x0 - R + lane, g.w, lane + 64 < 64 + 2 * R, DIL ? 0u : 0xffu);
-    constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle
+    // the three source columns of a lane (entry 0 = columns (a, b), entry 1 = (b, c)), clamped into the image
+    const int c0 = x0 - R + lane;
+    const uint32_t col_a = (uint32_t)min(max(c0, 0), g.w - 1), col_b = (uint32_t)min(max(c0 + 64, 0), g.w - 1), col_c = (uint32_t)min(max(c0 + 128, 0), g.w - 1);
+    constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle; out-of-range loads return 0, stores are dropped
     const int plane_bytes = g.h * g.w;
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s), 0, plane_bytes, RSRC_RAW);
-    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d, 0, g.h * g.dpitch, RSRC_RAW);
-    const __amdgpu_buffer_rsrc_t min_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(m ? m : s), 0, plane_bytes, RSRC_RAW);
+    // the destination descriptor covers the band's rows only: whatever a lane computes above or below them is dropped
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d + (size_t)yb0 * g.dpitch, 0, (yb1 - yb0) * g.dpitch, RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t min_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(TH ? m : s), 0, plane_bytes, RSRC_RAW);
     auto row_ptr = [&](int y) { return __mul24(min(max(y, 0), g.h - 1), g.w); };   // byte offset of the (clamped) row: wave-uniform
-    auto rows_ok = [&](int y) { return y >= 0 && y < g.h; };
-    // software prefetch: raw entries of the next row pair, minuend of the next output row pair
-    uint32_t ea0 = fetch_entry(src_rs, row_ptr(y_first), cols, 0), ea1 = fetch_entry(src_rs, row_ptr(y_first), cols, 1);
-    uint32_t eb0 = fetch_entry(src_rs, row_ptr(y_first + 1), cols, 0), eb1 = fetch_entry(src_rs, row_ptr(y_first + 1), cols, 1);
-    uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // minuend (xa, xb) of output rows y and y+1
-    uint32_t mhold = 0;
+    // Software prefetch: the three pixels (a, b, c) of each row of the NEXT pair are requested at the top of a pair, and
+    // combined into its two entries (a | b << 16, b | c << 16) by the LAST statements of the pair.  The combine is a
+    // volatile statement: left to the scheduler it is hoisted up to the loads and every pair waits out the memory latency
+    // right there.  WIDE (rows are 4-byte aligned): a pixel arrives as the aligned dword that holds it, and ONE v_perm_b32
+    // per entry, with a per-lane selector, picks the two pixels into the 16-bit halves and zeroes the rest.  Byte loads
+    // cost more: the compiler carries their results as i8 and re-extends each with a v_and before any 32-bit use, and
+    // (x << 16) | y becomes a shift and an SDWA or.
+    struct Raw { uint32_t a, b, c; };
+    // v_perm_b32 D, S0, S1, sel: selector byte 0..3 = that byte of S1, 4..7 = byte of S0, 0x0c = constant 0
+    const uint32_t sel_ab = 0x0c000c00u | ((4u + (col_b & 3u)) << 16) | (col_a & 3u);
+    const uint32_t sel_bc = 0x0c000c00u | ((4u + (col_c & 3u)) << 16) | (col_b & 3u);
+    auto load_row = [&](int y) __attribute__((always_inline)) {
+        const int ro = row_ptr(y);
+        Raw r;
+        if (WIDE) {
+            r.a = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_a & ~3u), ro, 0);
+            r.b = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_b & ~3u), ro, 0);
+            r.c = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_c & ~3u), ro, 0);
+        } else {
+            r.a = __builtin_amdgcn_raw_buffer_load_b8(src_rs, (int)col_a, ro, 0);
+            r.b = __builtin_amdgcn_raw_buffer_load_b8(src_rs, (int)col_b, ro, 0);
+            r.c = __builtin_amdgcn_raw_buffer_load_b8(src_rs, (int)col_c, ro, 0);
+        }
+        return r;
+    };
+    auto combine = [&](const Raw& r, uint32_t& e0, uint32_t& e1) __attribute__((always_inline)) {
+        if (WIDE) {
+            asm volatile("v_perm_b32 %0, %3, %2, %5\n\tv_perm_b32 %1, %4, %3, %6" : "=&v"(e0), "=&v"(e1) : "v"(r.a), "v"(r.b), "v"(r.c), "v"(sel_ab), "v"(sel_bc));
+        } else {
+            e0 = r.a | (r.b << 16);
+            e1 = r.b | (r.c << 16);
+            asm volatile("" : "+v"(e0), "+v"(e1));
+        }
+        if (LT_MORPH_BIAS) { e0 |= BIAS2; e1 |= BIAS2; }
+    };
+    uint32_t ea0, ea1, eb0, eb1;   // the entries of the next row pair
+    combine(load_row(y_first), ea0, ea1);
+    combine(load_row(y_first + 1), eb0, eb1);
+    uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // !WIDE: minuend (xa, xb) of output rows y and y+1
+    // WIDE: running byte offsets of this lane's dword -- row y + (lane >> 5) of the minuend, row y - 2 + (lane >> 5) of the
+    // band (relative to its first row), for the output row y of the current iteration; lanes right of the image stay out of range
+    uint32_t m_off = (uint32_t)(__mul24(yb0 - 2 * R + (lane >> 5), g.w) + wcol_c);
+    uint32_t st_off = wcol < g.w ? (uint32_t)(__mul24(-2 * R - 2 + (lane >> 5), g.dpitch) + wcol) : 0x80000000u;
+    uint32_t mcur = 0;
+    const uint32_t s0_rd = (uint32_t)(uintptr_t)(chain + MARGIN + ((R + lane) & 63));
     const uint32_t out_wr = (uint32_t)(uintptr_t)(s_out[wv] + (WIDE ? 2 * lane : 0));         // LDS offsets
     const uint32_t out_rd = (uint32_t)(uintptr_t)(s_out[wv] + (WIDE ? 8 * (lane & 31) : 0));
     auto out_issue = [&](unsigned long long& q) { asm volatile("ds_read_b64 %0, %1" : "=v"(q) : "v"(out_rd) : "memory"); };
-    auto out_finish = [&](unsigned long long q, int yp, uint32_t mp) {
+    auto out_finish = [&](unsigned long long q, uint32_t mp) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q) :: "memory");
         uint32_t v = __builtin_amdgcn_perm((uint32_t)(q >> 32), (uint32_t)q, row_sel);   // this lane's row of 4 columns x 2 rows
-        if (m) {   // TOPHAT: src - open(src), saturating, on the even and the odd bytes as packed 16-bit halves
-            const uint32_t me = mp & 0x00ff00ffu, mo = (mp >> 8) & 0x00ff00ffu;
-            const uint32_t ve = v & 0x00ff00ffu, vo = (v >> 8) & 0x00ff00ffu;
-            v = sub_sat16(me, ve) | (sub_sat16(mo, vo) << 8);
-        }
-        const int yo = yp + (lane >> 5);
-        if (yo >= yb0 && yo < yb1 && wcol < g.w) __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, __mul24(yo, g.dpitch) + wcol, 0, 0);
+        if (TH) v = mp - v;   // TOPHAT: src - open(src) >= 0 in every byte
+        __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, (int)st_off, 0, 0);
     };
     auto row_pair = [&](int yy) __attribute__((always_inline)) {
-        const bool ina = rows_ok(yy), inb = rows_ok(yy + 1);
-        const uint2 e_pa = make_uint2(ina ? (ea0 | BIAS2) : NEUTRAL, inb ? (eb0 | BIAS2) : NEUTRAL);
-        const uint2 e_pb = make_uint2(ina ? (ea1 | BIAS2) : NEUTRAL, inb ? (eb1 | BIAS2) : NEUTRAL);
-        chain[MARGIN + lane] = e_pa;             // only the half-width-0 window still reads plane 0
-        chain[MARGIN + lane + 64] = e_pb;
+        const uint2 e_pa = make_uint2(ea0, eb0);
+        const uint2 e_pb = make_uint2(ea1, eb1);
+        chain[MARGIN + lane] = lane < R ? e_pb : e_pa;   // entry (lane < R ? lane + 64 : lane): what lane (lane - R) mod 64 owns
         wave_lds_fence();
-        ea0 = fetch_entry(src_rs, row_ptr(yy + 2), cols, 0);
-        ea1 = fetch_entry(src_rs, row_ptr(yy + 2), cols, 1);
-        eb0 = fetch_entry(src_rs, row_ptr(yy + 3), cols, 0);
-        eb1 = fetch_entry(src_rs, row_ptr(yy + 3), cols, 1);
+        const Raw ra = load_row(yy + 2), rb = load_row(yy + 3);
         const int y = yy - R;                       // output rows y and y+1 complete in this iteration
         const uint32_t ca0 = ma0, cb0 = mb0, ca1 = ma1, cb1 = mb1;
-        const uint32_t mprev = mhold;   // WIDE: minuend of rows y-2, y-1 (stored in this iteration)
-        mhold = ma0;                    //       ... of rows y, y+1
-        if (m) {
+        const uint32_t mprev = mcur;    // WIDE: minuend of rows y-2, y-1 (stored in this iteration)
+        if (TH) {
             if (WIDE) {   // lane <-> row y + (lane >> 5), columns x0 + 4 (lane & 31) .. + 3: the layout of the dword store
-                const int mr = min(max(y + 2 + (lane >> 5), 0), g.h - 1);
-                ma0 = __builtin_amdgcn_raw_buffer_load_b32(min_rs, __mul24(mr, g.w) + wcol_c, 0, 0);
+                mcur = __builtin_amdgcn_raw_buffer_load_b32(min_rs, (int)m_off, 0, 0);
             } else {
                 const uint8_t* r0 = m + (size_t)min(max(y + 2, 0), g.h - 1) * g.w;
                 const uint8_t* r1 = m + (size_t)min(max(y + 3, 0), g.h - 1) * g.w;
@@ -622,7 +663,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         uint32_t Ha[NH], Hb[NH];
         constexpr bool FUSE = LT_FUSED55 && K == 55;
         uint32_t out_ab[2];
-        row_windows2<SE, DIL, FUSE>(chain, lane, e_pa, e_pb, Ha, Hb, A, out_ab);
+        row_windows2<SE, DIL, FUSE>(chain, lane, e_pa, e_pb, s0_rd, Ha, Hb, A, out_ab);
         wave_lds_fence();   // the chain planes are rewritten by the next iteration
         const bool prev_out = WIDE && y - 1 >= yb0 && y - 2 < yb1;   // rows y-2, y-1 wait regrouped in s_out
         unsigned long long q = 0;
@@ -639,11 +680,15 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         const uint32_t out_a = out_ab[0], out_b = out_ab[1];
         if (WIDE) {
             __builtin_amdgcn_sched_barrier(0);   // the window update above stays between the read-back and its use
-            if (prev_out) out_finish(q, y - 2, mprev);
+            // unconditional: outside the band the store falls outside dst_rs.  Under a branch the compiler cannot count
+            // it, and the wait for the next pair's bytes at the loop top becomes vmcnt(0) -- a wait for this store
+            out_finish(q, mprev);
             if (y + 1 >= yb0 && y < yb1) {       // wave-uniform; read back and stored while the next row pair computes
                 const uint32_t W = __builtin_amdgcn_perm(out_b, out_a, 0x06020400u);   // [row y: xa, row y+1: xa, y: xb, y+1: xb]
                 asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:128" :: "v"(out_wr), "v"(W) : "memory");
             }
+            m_off += 2u * (uint32_t)g.w;
+            st_off += 2u * (uint32_t)g.dpitch;
         } else
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
@@ -651,34 +696,32 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
             if (yo >= yb0 && yo < yb1) {
                 const uint32_t o2 = rr == 0 ? out_a : out_b;
                 uint32_t oa_v = o2 & 0xffu, ob_v = (o2 >> 16) & 0xffu;
-                if (m) {   // TOPHAT: src - open(src), saturating
+                if (TH) {   // TOPHAT: src - open(src)
                     const uint32_t qa = rr == 0 ? ca0 : ca1, qb = rr == 0 ? cb0 : cb1;
-                    oa_v = qa > oa_v ? qa - oa_v : 0u;
-                    ob_v = qb > ob_v ? qb - ob_v : 0u;
+                    oa_v = qa - oa_v;
+                    ob_v = qb - ob_v;
                 }
                 const size_t o = (size_t)yo * g.dpitch;
                 if (va) d[o + xa] = (uint8_t)oa_v;
                 if (vb) d[o + xb] = (uint8_t)ob_v;
             }
         }
+        combine(ra, ea0, ea1);
+        combine(rb, eb0, eb1);
     };
     // 55x55: two row pairs per loop iteration.  The vertical pipeline A moves by two registers per row pair; with one
     // pair per iteration the staged update order (outer rows first) left 11 register copies at the loop's back edge,
     // with two the second pair lands in the first one's registers.  An odd pair count runs one pair past the band
-    // (loads are clamped, stores predicated).
+    // (loads are clamped, stores fall outside the band's descriptor).
     constexpr int PAIRS = (LT_FUSED55 && K == 55) ? 2 : 1;
-    const int npairs = (y_last - y_first) / 2 + 1, pairs_run = (npairs + PAIRS - 1) / PAIRS * PAIRS;
     for (int yy = y_first; yy <= y_last; yy += 2 * PAIRS) {
         row_pair(yy);
         if (PAIRS == 2) row_pair(yy + 2);
     }
-    if (WIDE) {   // the last row pair is still in s_out
-        const int yl = y_first + 2 * (pairs_run - 1) - R;
-        if (yl + 1 >= yb0 && yl < yb1) {
-            unsigned long long q;
-            out_issue(q);
-            out_finish(q, yl, mhold);
-        }
+    if (WIDE) {   // the last row pair is still in s_out (outside the band if the loop ran past it: dropped by the descriptor)
+        unsigned long long q;
+        out_issue(q);
+        out_finish(q, mcur);
     }
 }
 
@@ -712,8 +755,10 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     {
         const void* fn = one_row ? (dilate ? (const void*)k_morph_runs<SE, true> : (const void*)k_morph_runs<SE, false>)
-                                 : wide ? (dilate ? (const void*)k_morph_runs2<SE, true, true> : (const void*)k_morph_runs2<SE, false, true>)
-                                        : (dilate ? (const void*)k_morph_runs2<SE, true, false> : (const void*)k_morph_runs2<SE, false, false>);
+                                 : wide ? (dilate ? (minuend ? (const void*)k_morph_runs2<SE, true, true, true> : (const void*)k_morph_runs2<SE, true, true, false>)
+                                                  : (const void*)k_morph_runs2<SE, false, true, false>)
+                                        : (dilate ? (minuend ? (const void*)k_morph_runs2<SE, true, false, true> : (const void*)k_morph_runs2<SE, true, false, false>)
+                                                  : (const void*)k_morph_runs2<SE, false, false, false>);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) blocks_per_cu = nb;
     }
@@ -754,14 +799,19 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         if (dilate) hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
         else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
     } else {
+        static const int extra_lds = [] { const char* e = std::getenv("LT_MORPH_EXTRA_LDS"); return e ? std::atoi(e) : 0; }();   // occupancy experiments
+        const bool th = dilate && minuend != nullptr;
+#define LT_LAUNCH(DIL_, WIDE_, TH_) hipLaunchKernelGGL((k_morph_runs2<SE, DIL_, WIDE_, TH_>), grid, dim3(256), extra_lds, s, src, dst, minuend, g)
         if (wide) {
-            static const int extra_lds = [] { const char* e = std::getenv("LT_MORPH_EXTRA_LDS"); return e ? std::atoi(e) : 0; }();   // occupancy experiments
-            if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true, true>), grid, dim3(256), extra_lds, s, src, dst, minuend, g);
-            else hipLaunchKernelGGL((k_morph_runs2<SE, false, true>), grid, dim3(256), extra_lds, s, src, dst, minuend, g);
+            if (th) LT_LAUNCH(true, true, true);
+            else if (dilate) LT_LAUNCH(true, true, false);
+            else LT_LAUNCH(false, true, false);
         } else {
-            if (dilate) hipLaunchKernelGGL((k_morph_runs2<SE, true, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
-            else hipLaunchKernelGGL((k_morph_runs2<SE, false, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
+            if (th) LT_LAUNCH(true, false, true);
+            else if (dilate) LT_LAUNCH(true, false, false);
+            else LT_LAUNCH(false, false, false);
         }
+#undef LT_LAUNCH
     }
 }
 
