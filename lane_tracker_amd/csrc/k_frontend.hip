@@ -11,6 +11,13 @@
 // once (one RGBX dword per pixel, rows x W x 4 bytes per frame: it stays in L2 for the warp).
 // The bird's-eye RGB image itself is never written: the warp emits the R plane and the Lab-b
 // plane directly.
+//
+// Layout of the undistorted rows: slots 2p and 2p+1 are INTERLEAVED per pixel (lt_internal.h: und_slot_base; pixel i
+// of slot s is dword und_slot_base(s) + 2 i).  Both remap kernels are bound by the NUMBER of vector-memory
+// instructions they issue (profiles/r02_vmem_issue.json: ~20 cycles of a CU's memory pipe per wave-instruction whatever
+// its width), and with this layout the two horizontally adjacent taps of a bilinear sample are 16 contiguous bytes that
+// hold them for two frames: one dwordx4 load instead of two dwordx2 loads.
+#include <algorithm>
 #include <cstdlib>
 
 #include "lt_internal.h"
@@ -43,10 +50,14 @@ __device__ __forceinline__ uint32_t xcd_block(uint32_t lid, uint32_t total, int 
 // unconditional on clamped addresses and masked afterwards (a guarded load serialises on its own
 // s_waitcnt).
 
+// ALIGNED4 (frames are 4-byte aligned and so is their stride): the 8-byte window is fetched as the three aligned dwords
+// that hold it and shifted into place with two v_alignbyte_b32 -- an unaligned dwordx2 at 3-byte pitch occupies the
+// memory pipe for ~32 cycles, an aligned dwordx3 for ~20.
+template <bool ALIGNED4>
 __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restrict__ frames, size_t frame_stride,
                                                        const int16_t* __restrict__ uxy,
                                                        const uint16_t* __restrict__ ufrac, FrontEndGeom g,
-                                                       uint32_t* __restrict__ und, size_t und_stride_px, int n, int fpb,
+                                                       uint32_t* __restrict__ und, size_t und_px, int first_slot, int n, int fpb,
                                                        int remap) {
     const uint32_t per_z = gridDim.x * gridDim.y;
     const uint32_t id = xcd_block((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, per_z * gridDim.z, remap);
@@ -61,10 +72,9 @@ __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restric
     const bool y0 = sy >= 0 && sy < g.img_h, y1 = sy + 1 >= 0 && sy + 1 < g.img_h;
     const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
     const int cy0 = min(max(sy, 0), g.img_h - 1), cy1 = min(max(sy + 1, 0), g.img_h - 1);
-    // The two taps of a row are 6 consecutive bytes (RGB RGB) at byte offset 3*sx: one unaligned 8-byte
-    // load per row instead of six byte loads (the frame buffer is padded by 8 bytes for the overrun).
-    // When sx or sx+1 is outside the frame the row is fetched from the clamped column and the taps
-    // are masked.
+    // The two taps of a row are 6 consecutive bytes (RGB RGB) at byte offset 3*sx: one 8-byte window per row instead
+    // of six byte loads (the frame buffer is padded by 8 bytes for the overrun).  When sx or sx+1 is outside the
+    // frame the row is fetched from the clamped column and the taps are masked.
     struct __attribute__((packed, aligned(1))) Row8 { uint64_t v; };
     const int cxl = min(max(sx, 0), g.img_w - 2);          // leftmost column of the 6-byte window we fetch
     // 32-bit offsets (a frame is far below 2^31 bytes) keep the address math on full-rate 24-bit multiplies
@@ -73,22 +83,44 @@ __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restric
     const int sh0 = 24 * (min(max(sx, 0), g.img_w - 1) - cxl), sh1 = 24 * (min(max(sx + 1, 0), g.img_w - 1) - cxl);
     const uint32_t m00 = (y0 && x0) ? 255u : 0u, m01 = (y0 && x1) ? 255u : 0u;
     const uint32_t m10 = (y1 && x0) ? 255u : 0u, m11 = (y1 && x1) ? 255u : 0u;
+    const uint32_t gx = 32u - (uint32_t)fx, gy = 32u - (uint32_t)fy;
+    const uint32_t w00 = (gx * gy) & 0x7ffu, w01 = ((uint32_t)fx * gy) & 0x7ffu, w10 = (gx * (uint32_t)fy) & 0x7ffu, w11 = ((uint32_t)fx * (uint32_t)fy) & 0x7ffu;
     const uint8_t* src = frames + (size_t)z0 * frame_stride;
-    uint64_t q0 = reinterpret_cast<const Row8*>(src + off0)->v, q1 = reinterpret_cast<const Row8*>(src + off1)->v;
+    constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle
+    const int nz = z1 - z0, fstride = (int)frame_stride;
+    // +8: the window of the frame's last pixel ends in the padding behind it
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, nz * fstride + 8, RSRC_RAW);
+    // the slots this thread writes: pairs [pair0, pair1] of the interleaved buffer
+    const int pair0 = (first_slot + z0) >> 1, pair1 = (first_slot + z1 - 1) >> 1, pair_b = (int)(und_px * 8);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(und + (size_t)pair0 * 2 * und_px, 0, (pair1 - pair0 + 1) * pair_b, RSRC_RAW);
+    typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+    auto window = [&](uint32_t off, int frame_off) {
+        if constexpr (ALIGNED4) {
+            const u32x3 d = __builtin_amdgcn_raw_buffer_load_b96(frs, (int)(off & ~3u), frame_off, 0);
+            const uint32_t lo = __builtin_amdgcn_alignbyte(d.y, d.x, off & 3u), hi = __builtin_amdgcn_alignbyte(d.z, d.y, off & 3u);
+            return (uint64_t)lo | ((uint64_t)hi << 32);
+        } else {
+            return reinterpret_cast<const Row8*>(src + (size_t)(unsigned)frame_off + off)->v;
+        }
+    };
+    uint64_t q0 = window(off0, 0), q1 = window(off1, 0);
     for (int z = z0; z < z1; ++z) {
         // the next frame's taps are in flight while this one is blended
-        const uint8_t* nsrc = frames + (size_t)min(z + 1, z1 - 1) * frame_stride;
-        const uint64_t n0 = reinterpret_cast<const Row8*>(nsrc + off0)->v, n1 = reinterpret_cast<const Row8*>(nsrc + off1)->v;
+        const int nfo = (min(z + 1, z1 - 1) - z0) * fstride;
+        const uint64_t n0 = window(off0, nfo), n1 = window(off1, nfo);
         const uint32_t a0 = (uint32_t)(q0 >> sh0), a1 = (uint32_t)(q0 >> sh1);
         const uint32_t b0 = (uint32_t)(q1 >> sh0), b1 = (uint32_t)(q1 >> sh1);
         uint32_t out = 0;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            const int v00 = (int)((a0 >> (8 * ch)) & m00), v01 = (int)((a1 >> (8 * ch)) & m01);
-            const int v10 = (int)((b0 >> (8 * ch)) & m10), v11 = (int)((b1 >> (8 * ch)) & m11);
-            out |= (uint32_t)bilerp(v00, v01, v10, v11, fx, fy) << (8 * ch);
+            const uint32_t v00 = (a0 >> (8 * ch)) & m00, v01 = (a1 >> (8 * ch)) & m01;
+            const uint32_t v10 = (b0 >> (8 * ch)) & m10, v11 = (b1 >> (8 * ch)) & m11;
+            // (sum_i w_i p_i + 2^9) >> 10: the same integer as bilerp(); with the 11-bit weights visible every product is a
+            // v_mul_u32_u24 / v_mad_u32_u24 (the two-stage form was re-associated into quarter-rate 32- and 64-bit multiplies)
+            out |= ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + 512u) >> 10) << (8 * ch);
         }
-        und[(size_t)z * und_stride_px + o] = out;
+        const int slot = first_slot + z;   // wave-uniform: pair and parity go into the scalar offset of the store
+        __builtin_amdgcn_raw_buffer_store_b32(out, urs, (int)o * 8, __builtin_amdgcn_readfirstlane(((slot >> 1) - pair0) * pair_b + (slot & 1) * 4), 0);
         q0 = n0;
         q1 = n1;
     }
@@ -146,8 +178,8 @@ __device__ __forceinline__ void warp_pixel(const uint32_t* __restrict__ src, con
     const int cy0 = min(max(ry0, 0), g.nrows - 1), cy1 = min(max(ry1, 0), g.nrows - 1);
     const int cx0 = min(max(sx, 0), g.img_w - 1), cx1 = min(max(sx + 1, 0), g.img_w - 1);
     const int o0 = __mul24(cy0, g.img_w), o1 = __mul24(cy1, g.img_w);
-    uint32_t t00 = src[o0 + cx0], t01 = src[o0 + cx1];
-    uint32_t t10 = src[o1 + cx0], t11 = src[o1 + cx1];
+    uint32_t t00 = src[2 * (o0 + cx0)], t01 = src[2 * (o0 + cx1)];   // pixels of one slot are two dwords apart
+    uint32_t t10 = src[2 * (o1 + cx0)], t11 = src[2 * (o1 + cx1)];
     t00 = (y0 && x0) ? t00 : 0u;
     t01 = (y0 && x1) ? t01 : 0u;
     t10 = (y1 && x0) ? t10 : 0u;
@@ -161,16 +193,18 @@ __device__ __forceinline__ void warp_pixel(const uint32_t* __restrict__ src, con
 // Four adjacent bird's-eye pixels per thread: bilinear samples of the RGBX undistorted rows, then
 // one dword store to the R plane and one to the Lab-b plane.  `quads` = pixels / 4 (w % 4 == 0).
 // The remap table entry of a quad is the same for every frame, so a thread keeps it (and the tap
-// offsets derived from it) in registers and walks `fpb` consecutive frames with it; the taps of
-// frame z+1 are in flight while frame z is blended (the kernel is bound by gather latency).
+// offsets derived from it) in registers and walks `ppb` consecutive slot PAIRS with it: the two taps of a row are one
+// 16-byte load {left.even, left.odd, right.even, right.odd} that serves both slots of the pair, and the taps of the
+// next pair are in flight while this one is blended (the kernel is bound by the memory pipe's instruction rate).
+// Slots [first_slot, first_slot + n); `und` is the base of the whole buffer, planeR / planeB point at first_slot's planes.
 
-__global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict__ und, size_t und_stride_px,
+__global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict__ und, size_t und_px, int first_slot,
                                                     const int16_t* __restrict__ wxy,
                                                     const uint16_t* __restrict__ wfrac, FrontEndGeom g,
                                                     const uint16_t* __restrict__ gamma_tab,
                                                     const uint16_t* __restrict__ cbrt_tab,
                                                     const int32_t* __restrict__ coeffs, uint8_t* __restrict__ planeR,
-                                                    uint8_t* __restrict__ planeB, size_t plane_stride, int n, int fpb,
+                                                    uint8_t* __restrict__ planeB, size_t plane_stride, int n, int ppb,
                                                     int remap) {
     __shared__ uint16_t s_gamma[256];
     __shared__ uint16_t s_cbrt[3072];
@@ -185,7 +219,13 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
     const uint2 fr = reinterpret_cast<const uint2*>(wfrac)[qc];      // 4 x u16
     stage_lab_tables(s_gamma, s_cbrt, s_coef, gamma_tab, cbrt_tab, coeffs);
     if (qi >= quads) return;
-    const int z0 = bz * fpb, z1 = min(z0 + fpb, n);
+    // this walk: pairs [pa, pb) of the buffer, i.e. slots [2 pa, 2 pb) clipped to [first_slot, first_slot + n)
+    const int pair_lo = first_slot >> 1, pair_hi = (first_slot + n + 1) >> 1;
+    const int pa = pair_lo + (int)bz * ppb, pb = min(pa + ppb, pair_hi);
+    const int s_lo = max(2 * pa, first_slot), s_hi = min(2 * pb, first_slot + n);   // slots this walk writes
+    if (s_hi <= s_lo) return;
+    uint8_t* const outR = planeR + (size_t)(s_lo - first_slot) * plane_stride;
+    uint8_t* const outB = planeB + (size_t)(s_lo - first_slot) * plane_stride;
     const uint32_t xyv[4] = {xy.x, xy.y, xy.z, xy.w};
     const uint32_t frv[4] = {fr.x & 0xffffu, fr.x >> 16, fr.y & 0xffffu, fr.y >> 16};
     // 87 % of the bird's-eye view samples strictly inside the staged rows: skip every border test there
@@ -196,76 +236,71 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
         inside = inside && sx >= 0 && sx + 1 < g.img_w && sy >= g.r0 && sy + 1 < g.r0 + g.nrows && sy + 1 < g.img_h;
     }
     if (inside) {
-        // the two taps of a row are adjacent dwords: one 8-byte load each (4-byte aligned)
-        struct __attribute__((packed, aligned(4))) Tap2 { uint32_t a, b; };
-        int off[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
-            off[i] = __mul24(sy - g.r0, g.img_w) + sx;
-        }
         // The four tap weights of a pixel (products of the 5-bit fractions, <= 1024) are frame-independent.  They
         // are masked to 11 bits on purpose: the compiler folds (a gx + b fx) gy into a (gx gy) + b (fx gy) anyway,
         // and unless it can see that the weight products are small it multiplies with v_mul_lo_u32 (quarter rate)
         // instead of v_mul_u32_u24 -- six of them per pixel in the previous version of this loop.
         uint32_t w00[4], w01[4], w10[4], w11[4];
+        int toff[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
+            toff[i] = (__mul24(sy - g.r0, g.img_w) + sx) * 8;            // byte offset of the left tap inside a pair
             const uint32_t fx = frv[i] & 31u, fy = frv[i] >> 5, gx = 32u - fx, gy = 32u - fy;
             w00[i] = (gx * gy) & 0x7ffu;
             w01[i] = (fx * gy) & 0x7ffu;
             w10[i] = (gx * fy) & 0x7ffu;
             w11[i] = (fx * fy) & 0x7ffu;
         }
-        // Taps and outputs go through buffer descriptors of this walk's frames: descriptor + 32-bit lane offset +
-        // scalar frame offset, so no access pays a 64-bit VALU address add (11 of ~200 VALU instructions per frame).
+        // Taps and outputs go through buffer descriptors of this walk: descriptor + 32-bit lane offset + scalar
+        // pair / frame offset, so no access pays a 64-bit VALU address add.
         constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle
-        const int nz = z1 - z0, und_stride_b = (int)(und_stride_px * 4);
-        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(und + (size_t)z0 * und_stride_px), 0, nz * und_stride_b, RSRC_RAW);
-        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(planeR + (size_t)z0 * plane_stride, 0, nz * (int)plane_stride, RSRC_RAW);
-        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(planeB + (size_t)z0 * plane_stride, 0, nz * (int)plane_stride, RSRC_RAW);
-        auto tap2 = [&](int byte_off, int frame_off) {
-            const auto v = __builtin_amdgcn_raw_buffer_load_b64(urs, byte_off, frame_off, 0);
-            return Tap2{v[0], v[1]};
-        };
-        int toff[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) toff[i] = off[i] * 4;
-        const int row_b = g.img_w * 4, out_off = (int)qi * 4;
-        Tap2 top[4], bot[4];
+        const int pair_b = (int)(und_px * 8);
+        const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(und + (size_t)pa * 2 * und_px), 0, (pb - pa) * pair_b, RSRC_RAW);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(outR, 0, (s_hi - s_lo) * (int)plane_stride, RSRC_RAW);
+        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(outB, 0, (s_hi - s_lo) * (int)plane_stride, RSRC_RAW);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int row_b = g.img_w * 8, out_off = (int)qi * 4;
+        u32x4 top[4], bot[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            top[i] = tap2(toff[i], 0);
-            bot[i] = tap2(toff[i] + row_b, 0);
+            top[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i], 0, 0);
+            bot[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i] + row_b, 0, 0);
         }
-        for (int z = z0; z < z1; ++z) {
-            Tap2 ntop[4], nbot[4];
-            const int nfo = (min(z + 1, z1 - 1) - z0) * und_stride_b;
+        for (int p = pa; p < pb; ++p) {
+            u32x4 ntop[4], nbot[4];
+            const int npo = (min(p + 1, pb - 1) - pa) * pair_b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ntop[i] = tap2(toff[i], nfo);
-                nbot[i] = tap2(toff[i] + row_b, nfo);
+                ntop[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i], npo, 0);
+                nbot[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i] + row_b, npo, 0);
             }
-            uint32_t outR = 0, outB = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int rgb[3];
+            for (int f = 0; f < 2; ++f) {
+                const int slot = 2 * p + f;
+                if (slot < s_lo || slot >= s_hi) continue;     // wave-uniform: the odd slot in front of / behind the range
+                uint32_t oR = 0, oB = 0;
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch)     // (sum_i w_i p_i + 2^9) >> 10: the same integer as the two-stage blend
-                    rgb[ch] = (int)((((top[i].a >> (8 * ch)) & 255u) * w00[i] + ((top[i].b >> (8 * ch)) & 255u) * w01[i] +
-                                     ((bot[i].a >> (8 * ch)) & 255u) * w10[i] + ((bot[i].b >> (8 * ch)) & 255u) * w11[i] + 512u) >> 10);
-                int r = rgb[0], b = lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, s_coef);
-                // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
-                // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the
-                // third pixel (caught by the parity test); the barrier costs nothing at run time.
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t ta = top[i][f], tb = top[i][2 + f], ba = bot[i][f], bb = bot[i][2 + f];
+                    int rgb[3];
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch)     // (sum_i w_i p_i + 2^9) >> 10: the same integer as the two-stage blend
+                        rgb[ch] = (int)((((ta >> (8 * ch)) & 255u) * w00[i] + ((tb >> (8 * ch)) & 255u) * w01[i] +
+                                         ((ba >> (8 * ch)) & 255u) * w10[i] + ((bb >> (8 * ch)) & 255u) * w11[i] + 512u) >> 10);
+                    int r = rgb[0], b = lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, s_coef);
+                    // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
+                    // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the
+                    // third pixel (caught by the parity test); the barrier costs nothing at run time.
 #ifndef LT_CASE_WARP_NO_BARRIER   // tools/toolchain_cases.sh builds the kernel without it to check whether the case still exists
-                asm volatile("" : "+v"(r), "+v"(b));
+                    asm volatile("" : "+v"(r), "+v"(b));
 #endif
-                outR |= ((uint32_t)r & 255u) << (8 * i);
-                outB |= ((uint32_t)b & 255u) << (8 * i);
+                    oR |= ((uint32_t)r & 255u) << (8 * i);
+                    oB |= ((uint32_t)b & 255u) << (8 * i);
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(oR, rrs, out_off, (slot - s_lo) * (int)plane_stride, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(oB, brs, out_off, (slot - s_lo) * (int)plane_stride, 0);
             }
-            __builtin_amdgcn_raw_buffer_store_b32(outR, rrs, out_off, (z - z0) * (int)plane_stride, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(outB, brs, out_off, (z - z0) * (int)plane_stride, 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 top[i] = ntop[i];
@@ -286,32 +321,32 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
         none = none && !((y0 || y1) && (x0 || x1));
     }
     if (none) {
-        const uint32_t outB = (uint32_t)lab_b_of(0, 0, 0, s_gamma, s_cbrt, s_coef) * 0x01010101u;
-        for (int z = z0; z < z1; ++z) {
-            reinterpret_cast<uint32_t*>(planeR + (size_t)z * plane_stride)[qi] = 0u;
-            reinterpret_cast<uint32_t*>(planeB + (size_t)z * plane_stride)[qi] = outB;
+        const uint32_t oB = (uint32_t)lab_b_of(0, 0, 0, s_gamma, s_cbrt, s_coef) * 0x01010101u;
+        for (int slot = s_lo; slot < s_hi; ++slot) {
+            reinterpret_cast<uint32_t*>(outR + (size_t)(slot - s_lo) * plane_stride)[qi] = 0u;
+            reinterpret_cast<uint32_t*>(outB + (size_t)(slot - s_lo) * plane_stride)[qi] = oB;
         }
         return;
     }
-    for (int z = z0; z < z1; ++z) {
-        const uint32_t* src = und + (size_t)z * und_stride_px;
-        uint32_t outR = 0, outB = 0;
+    for (int slot = s_lo; slot < s_hi; ++slot) {
+        const uint32_t* src = und + und_slot_base(und_px, slot);
+        uint32_t oR = 0, oB = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int sx = (int16_t)(xyv[i] & 0xffffu), sy = (int16_t)(xyv[i] >> 16);
             int r, b;
             warp_pixel(src, g, sx, sy, (int)frv[i], s_gamma, s_cbrt, s_coef, r, b);
             asm volatile("" : "+v"(r), "+v"(b));
-            outR |= ((uint32_t)r & 255u) << (8 * i);
-            outB |= ((uint32_t)b & 255u) << (8 * i);
+            oR |= ((uint32_t)r & 255u) << (8 * i);
+            oB |= ((uint32_t)b & 255u) << (8 * i);
         }
-        reinterpret_cast<uint32_t*>(planeR + (size_t)z * plane_stride)[qi] = outR;
-        reinterpret_cast<uint32_t*>(planeB + (size_t)z * plane_stride)[qi] = outB;
+        reinterpret_cast<uint32_t*>(outR + (size_t)(slot - s_lo) * plane_stride)[qi] = oR;
+        reinterpret_cast<uint32_t*>(outB + (size_t)(slot - s_lo) * plane_stride)[qi] = oB;
     }
 }
 
 // any width: one pixel per thread
-__global__ __launch_bounds__(256) void k_warp_split1(const uint32_t* __restrict__ und, size_t und_stride_px,
+__global__ __launch_bounds__(256) void k_warp_split1(const uint32_t* __restrict__ und, size_t und_px, int first_slot,
                                                     const int16_t* __restrict__ wxy,
                                                     const uint16_t* __restrict__ wfrac, FrontEndGeom g,
                                                     const uint16_t* __restrict__ gamma_tab,
@@ -326,7 +361,7 @@ __global__ __launch_bounds__(256) void k_warp_split1(const uint32_t* __restrict_
     const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= npix) return;
     int r, b;
-    warp_pixel(und + (size_t)blockIdx.z * und_stride_px, g, wxy[o * 2], wxy[o * 2 + 1], wfrac[o], s_gamma, s_cbrt,
+    warp_pixel(und + und_slot_base(und_px, first_slot + (int)blockIdx.z), g, wxy[o * 2], wxy[o * 2 + 1], wfrac[o], s_gamma, s_cbrt,
                s_coef, r, b);
     planeR[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)r;
     planeB[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)b;
@@ -350,12 +385,12 @@ __global__ __launch_bounds__(256) void k_split_bev(const uint8_t* __restrict__ b
     planeB[(size_t)blockIdx.z * plane_stride + o] = (uint8_t)lab_b_of(r, gg, b, s_gamma, s_cbrt, s_coef);
 }
 
-__global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint32_t* __restrict__ und, size_t und_stride_px,
+__global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint32_t* __restrict__ und, size_t und_px, int first_slot,
                                                            int nrows, int w, uint8_t* __restrict__ out) {
     const size_t plane = (size_t)nrows * w;
     const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= plane) return;
-    const uint32_t v = und[(size_t)blockIdx.z * und_stride_px + o];
+    const uint32_t v = und[und_slot_base(und_px, first_slot + (int)blockIdx.z) + 2 * o];
     uint8_t* dst = out + (size_t)blockIdx.z * plane * 3 + o * 3;
     dst[0] = (uint8_t)v;
     dst[1] = (uint8_t)(v >> 8);
@@ -379,26 +414,31 @@ static int frames_per_thread(int n) {
 }
 
 void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
-                           const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_stride_px, int n) {
+                           const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_px, int first_slot, int n) {
     if (n <= 0 || g.nrows <= 0) return;
     const int fpb = frames_per_thread(n);
     dim3 grid((g.img_w + 255) / 256, g.nrows, (n + fpb - 1) / fpb);
-    hipLaunchKernelGGL(k_undistort_rows, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_stride_px, n, fpb, xcd_remap());
+    static const bool unaligned = [] { const char* e = std::getenv("LT_UNDISTORT_UNALIGNED"); return e && e[0] == '1'; }();   // A/B
+    if (!unaligned && ((uintptr_t)frames & 3) == 0 && (frame_stride & 3) == 0 && (size_t)fpb * frame_stride < (1u << 30))
+        hipLaunchKernelGGL(k_undistort_rows<true>, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_px, first_slot, n, fpb, xcd_remap());
+    else
+        hipLaunchKernelGGL(k_undistort_rows<false>, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_px, first_slot, n, fpb, xcd_remap());
 }
 
-void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy,
+void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy,
                        const uint16_t* wfrac, FrontEndGeom g, const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
                        const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB, size_t plane_stride, int n) {
     if (n <= 0 || g.nrows <= 0) return;
     const size_t npix = (size_t)g.warp_h * g.warp_w;
     if ((g.warp_w & 3) == 0 && (plane_stride & 3) == 0) {
-        const int fpb = frames_per_thread(n);
-        dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, (n + fpb - 1) / fpb);
-        hipLaunchKernelGGL(k_warp_split4, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
-                           coeffs, planeR, planeB, plane_stride, n, fpb, xcd_remap());
+        const int pairs = ((first_slot + n + 1) >> 1) - (first_slot >> 1);
+        const int ppb = std::max(1, frames_per_thread(n) / 2);
+        dim3 grid((unsigned)(((npix >> 2) + 255) / 256), 1, (pairs + ppb - 1) / ppb);
+        hipLaunchKernelGGL(k_warp_split4, grid, dim3(256), 0, s, und, und_px, first_slot, wxy, wfrac, g, gamma_tab, cbrt_tab,
+                           coeffs, planeR, planeB, plane_stride, n, ppb, xcd_remap());
     } else {
         dim3 grid((unsigned)((npix + 255) / 256), 1, n);
-        hipLaunchKernelGGL(k_warp_split1, grid, dim3(256), 0, s, und, und_stride_px, wxy, wfrac, g, gamma_tab, cbrt_tab,
+        hipLaunchKernelGGL(k_warp_split1, grid, dim3(256), 0, s, und, und_px, first_slot, wxy, wfrac, g, gamma_tab, cbrt_tab,
                            coeffs, planeR, planeB, plane_stride);
     }
 }
@@ -412,11 +452,11 @@ void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int 
                        planeB, plane_stride);
 }
 
-void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, int nrows, int w, uint8_t* out,
+void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, int nrows, int w, uint8_t* out,
                                int n) {
     if (n <= 0 || nrows <= 0) return;
     dim3 grid((unsigned)(((size_t)nrows * w + 255) / 256), 1, n);
-    hipLaunchKernelGGL(k_undistorted_to_rgb, grid, dim3(256), 0, s, und, und_stride_px, nrows, w, out);
+    hipLaunchKernelGGL(k_undistorted_to_rgb, grid, dim3(256), 0, s, und, und_px, first_slot, nrows, w, out);
 }
 
 }  // namespace lt

@@ -83,13 +83,13 @@ __global__ __launch_bounds__(256) void k_overlay_lane4(const uint32_t* __restric
 }
 
 // Bird's-eye RGB of the undistorted rows (same taps and blend as k_warp_split, colour kept).
-__global__ __launch_bounds__(256) void k_warp_rgb(const uint32_t* __restrict__ und, size_t und_stride_px,
+__global__ __launch_bounds__(256) void k_warp_rgb(const uint32_t* __restrict__ und, size_t und_px, int first_slot,
                                                  const int16_t* __restrict__ wxy, const uint16_t* __restrict__ wfrac,
                                                  FrontEndGeom g, uint8_t* __restrict__ bev, size_t bev_stride) {
     const size_t npix = (size_t)g.warp_h * g.warp_w;
     const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= npix) return;
-    const uint32_t* src = und + (size_t)blockIdx.z * und_stride_px;
+    const uint32_t* src = und + und_slot_base(und_px, first_slot + (int)blockIdx.z);   // pixels of a slot are two dwords apart
     const int sx = wxy[o * 2], sy = wxy[o * 2 + 1], f = wfrac[o];
     const int fx = f & 31, fy = f >> 5, gx = 32 - fx, gy = 32 - fy;
     const int ry0 = sy - g.r0, ry1 = sy + 1 - g.r0;
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void k_warp_rgb(const uint32_t* __restrict__ u
     const bool x0 = sx >= 0 && sx < g.img_w, x1 = sx + 1 >= 0 && sx + 1 < g.img_w;
     const int cy0 = min(max(ry0, 0), g.nrows - 1), cy1 = min(max(ry1, 0), g.nrows - 1);
     const int cx0 = min(max(sx, 0), g.img_w - 1), cx1 = min(max(sx + 1, 0), g.img_w - 1);
-    uint32_t t00 = src[__mul24(cy0, g.img_w) + cx0], t01 = src[__mul24(cy0, g.img_w) + cx1];
-    uint32_t t10 = src[__mul24(cy1, g.img_w) + cx0], t11 = src[__mul24(cy1, g.img_w) + cx1];
+    uint32_t t00 = src[2 * (__mul24(cy0, g.img_w) + cx0)], t01 = src[2 * (__mul24(cy0, g.img_w) + cx1)];
+    uint32_t t10 = src[2 * (__mul24(cy1, g.img_w) + cx0)], t11 = src[2 * (__mul24(cy1, g.img_w) + cx1)];
     t00 = (y0 && x0) ? t00 : 0u;
     t01 = (y0 && x1) ? t01 : 0u;
     t10 = (y1 && x0) ? t10 : 0u;
@@ -168,11 +168,11 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
     }
 }
 
-void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy, const uint16_t* wfrac,
+void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy, const uint16_t* wfrac,
                      FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n) {
     if (n <= 0) return;
     const size_t npix = (size_t)g.warp_h * g.warp_w;
-    hipLaunchKernelGGL(k_warp_rgb, dim3((unsigned)((npix + 255) / 256), 1, n), dim3(256), 0, s, und, und_stride_px, wxy,
+    hipLaunchKernelGGL(k_warp_rgb, dim3((unsigned)((npix + 255) / 256), 1, n), dim3(256), 0, s, und, und_px, first_slot, wxy,
                        wfrac, g, bev, bev_stride);
 }
 

@@ -67,7 +67,7 @@ struct lt_ctx {
     int capacity = 0;
     size_t frame_bytes = 0, und_bytes = 0, plane_bytes = 0, bev_bytes = 0;
     uint8_t *d_frames = nullptr, *d_bev = nullptr;
-    uint32_t* d_und = nullptr;        // undistorted camera rows [r0, r0+nrows), one RGBX dword per pixel
+    uint32_t* d_und = nullptr;        // undistorted camera rows [r0, r0+nrows), one RGBX dword per pixel, slots 2p / 2p+1 interleaved (und_slot_base)
     size_t und_px = 0;                // pixels per slot of d_und
     uint8_t* d_plane[P_COUNT] = {};
     unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
@@ -155,7 +155,8 @@ template <class F>
 int for_each_slice(lt_ctx* c, int first, int n, F fn) {
     const int k = std::max(1, std::min(c->nstreams, c->capacity));
     for (int si = 0; si < k; ++si) {
-        const int lo = (int)((long long)c->capacity * si / k), hi = (int)((long long)c->capacity * (si + 1) / k);
+        // even boundaries: the undistorted rows of slots 2p and 2p+1 are interleaved, and the warp serves a pair with one load
+        const int lo = (int)((long long)c->capacity * si / k) & ~1, hi = si + 1 == k ? c->capacity : (int)((long long)c->capacity * (si + 1) / k) & ~1;
         const int a = std::max(first, lo), b = std::min(first + n, hi);
         if (b <= a) continue;
         int rc = fn(c->streams[si], a, b - a);
@@ -643,7 +644,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     c->capacity = capacity;
     const size_t n = (size_t)capacity;
     if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes + 16))) { free_slots(c); return rc; }   // +16: k_undistort_rows reads 8-byte windows
-    if ((rc = dev_alloc(&c->d_und, n * c->und_px))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_und, (size_t)((n + 1) / 2) * 2 * c->und_px))) { free_slots(c); return rc; }
     for (int i = 0; i < P_COUNT; ++i)
         if ((rc = dev_alloc(&c->d_plane[i], n * c->plane_bytes))) { free_slots(c); return rc; }
     c->bits_stride = (size_t)c->calib.warp_h * ((c->calib.warp_w + 63) / 64);
@@ -882,8 +883,7 @@ int lt_download_undistorted(lt_ctx* c, int first, int n, uint8_t* out) {
     uint8_t* tmp = nullptr;
     if ((rc = sync_all(c))) return rc;
     if ((rc = dev_alloc(&tmp, (size_t)n * c->und_bytes))) return rc;
-    launch_undistorted_to_rgb(c->stream, c->d_und + (size_t)first * c->und_px, c->und_px, c->fe.nrows,
-                              c->fe.img_w, tmp, n);
+    launch_undistorted_to_rgb(c->stream, c->d_und, c->und_px, first, c->fe.nrows, c->fe.img_w, tmp, n);
     rc = download(c, tmp, out, (size_t)n * c->und_bytes);
     dev_free(tmp);
     return rc;
@@ -1149,8 +1149,7 @@ int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
     uint8_t* dst = c->d_bev + (size_t)first * c->bev_bytes;
     if (c->fe.nrows <= 0) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * c->bev_bytes, c->stream));
     else
-        launch_warp_rgb(c->stream, c->d_und + (size_t)first * c->und_px, c->und_px, c->d_wxy, c->d_wfrac, c->fe, dst,
-                        c->bev_bytes, n);
+        launch_warp_rgb(c->stream, c->d_und, c->und_px, first, c->d_wxy, c->d_wfrac, c->fe, dst, c->bev_bytes, n);
     HIP_TRY(hipGetLastError());
     return download(c, dst, out, (size_t)n * c->bev_bytes);
 }
@@ -1306,9 +1305,9 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         { StageScope t(c, ST_UNDISTORT, st);
           launch_undistort_rows(st, c->d_frames + (size_t)f0 * c->frame_bytes, c->frame_bytes, c->d_uxy, c->d_ufrac,
-                                c->fe, c->d_und + (size_t)f0 * c->und_px, c->und_px, m); }
+                                c->fe, c->d_und, c->und_px, f0, m); }
         { StageScope t(c, ST_WARP_SPLIT, st);
-          launch_warp_split(st, c->d_und + (size_t)f0 * c->und_px, c->und_px, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
+          launch_warp_split(st, c->d_und, c->und_px, f0, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
                             c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
                             ps, m); }
         return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);

@@ -32,15 +32,23 @@ struct EllipseSE {               // one horizontal run per row
 struct FrontEndGeom {
     int img_h, img_w, warp_h, warp_w, r0, nrows;
 };
+// The undistorted rows of slots 2p and 2p+1 are interleaved per pixel (k_frontend.hip): dword index of pixel 0 of a slot;
+// its pixel i is 2 i dwords further.  The buffer holds ceil(slots / 2) pairs of 2 * und_px dwords.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t und_slot_base(size_t und_px, int slot) { return (size_t)(slot >> 1) * 2 * und_px + (size_t)(slot & 1); }
+// `und` is the base of the whole buffer, `first_slot` the absolute slot of frame 0 of the call; frames / planes point at
+// that slot's data
 void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_stride, const int16_t* uxy,
-                           const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_stride_px, int n);
-void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy,
+                           const uint16_t* ufrac, FrontEndGeom g, uint32_t* und, size_t und_px, int first_slot, int n);
+void launch_warp_split(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy,
                        const uint16_t* wfrac, FrontEndGeom g, const uint16_t* gamma_tab, const uint16_t* cbrt_tab,
                        const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB, size_t plane_stride, int n);
 void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int npix, const uint16_t* gamma_tab,
                       const uint16_t* cbrt_tab, const int32_t* coeffs, uint8_t* planeR, uint8_t* planeB,
                       size_t plane_stride, int n);
-void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, int nrows, int w, uint8_t* out,
+void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, int nrows, int w, uint8_t* out,
                                int n);
 
 // presentation stage (k_overlay.hip)
@@ -50,7 +58,7 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
                          const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
                          const int16_t* xpos, int nl, int len, int y0, int step, int n);
-void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_stride_px, const int16_t* wxy, const uint16_t* wfrac,
+void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy, const uint16_t* wfrac,
                      FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n);
 
 // dst = erode/dilate(src) with the ellipse; if minuend != nullptr: dst = sat(minuend - result)
