@@ -261,20 +261,20 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
         const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(outB, 0, (s_hi - s_lo) * (int)plane_stride, RSRC_RAW);
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         const int row_b = g.img_w * 8, out_off = (int)qi * 4;
-        u32x4 top[4], bot[4];
+        // the six matrix coefficients of Y and Z live in SGPRs for the whole walk (read through LDS they were re-fetched for every pixel)
+        int32_t C[9];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            top[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i], 0, 0);
-            bot[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i] + row_b, 0, 0);
-        }
-        for (int p = pa; p < pb; ++p) {
-            u32x4 ntop[4], nbot[4];
-            const int npo = (min(p + 1, pb - 1) - pa) * pair_b;
+        for (int k = 3; k < 9; ++k) C[k] = __builtin_amdgcn_readfirstlane(s_coef[k]);
+        u32x4 tapA[8], tapB[8];   // [0..3] top row, [4..7] bottom row of the four pixels; A / B alternate between pairs
+        auto fetch = [&](u32x4 (&t)[8], int p) __attribute__((always_inline)) {
+            const int po = (min(p, pb - 1) - pa) * pair_b;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ntop[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i], npo, 0);
-                nbot[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i] + row_b, npo, 0);
+                t[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i], po, 0);
+                t[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i] + row_b, po, 0);
             }
+        };
+        auto blend_pair = [&](const u32x4 (&t)[8], int p) __attribute__((always_inline)) {
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 const int slot = 2 * p + f;
@@ -282,13 +282,13 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
                 uint32_t oR = 0, oB = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint32_t ta = top[i][f], tb = top[i][2 + f], ba = bot[i][f], bb = bot[i][2 + f];
+                    const uint32_t ta = t[i][f], tb = t[i][2 + f], ba = t[4 + i][f], bb = t[4 + i][2 + f];
                     int rgb[3];
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch)     // (sum_i w_i p_i + 2^9) >> 10: the same integer as the two-stage blend
                         rgb[ch] = (int)((((ta >> (8 * ch)) & 255u) * w00[i] + ((tb >> (8 * ch)) & 255u) * w01[i] +
                                          ((ba >> (8 * ch)) & 255u) * w10[i] + ((bb >> (8 * ch)) & 255u) * w11[i] + 512u) >> 10);
-                    int r = rgb[0], b = lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, s_coef);
+                    int r = rgb[0], b = lab_b_of(rgb[0], rgb[1], rgb[2], s_gamma, s_cbrt, C);
                     // Opaque to the optimiser on purpose: with the value ranges visible, hipcc (ROCm 7.2) folded the
                     // four byte inserts into a 16-bit combine that leaked bits 16+ of an unshifted Lab value into the
                     // third pixel (caught by the parity test); the barrier costs nothing at run time.
@@ -301,11 +301,16 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
                 __builtin_amdgcn_raw_buffer_store_b32(oR, rrs, out_off, (slot - s_lo) * (int)plane_stride, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(oB, brs, out_off, (slot - s_lo) * (int)plane_stride, 0);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                top[i] = ntop[i];
-                bot[i] = nbot[i];
-            }
+        };
+        // two pairs per trip, the tap registers alternate: the taps of the next pair are in flight while this one is
+        // blended, and nothing is copied at the back edge
+        fetch(tapA, pa);
+        for (int p = pa; p < pb; p += 2) {
+            fetch(tapB, p + 1);
+            blend_pair(tapA, p);
+            if (p + 1 >= pb) break;
+            fetch(tapA, p + 2);
+            blend_pair(tapB, p + 1);
         }
         return;
     }
