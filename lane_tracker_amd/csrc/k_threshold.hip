@@ -578,6 +578,76 @@ __global__ __launch_bounds__(256) void k_erode5_bits(const unsigned long long* _
     out[(size_t)blockIdx.z * bits_stride + idx] = e & valid_bits(j, w);
 }
 
+// OR-merge of the four partial planes of the walking thresholds + the 5x5 open, one pass (NP = 4), or the open alone of
+// a merged plane (NP = 1).  k_or4_bits + k_erode5_bits + k_dilate5_bits issue 26 loads and 3 stores per 64-pixel word,
+// and all three are bound by exactly that count (profiles/r02_vmem_issue.json: a wave's load costs the CU ~20 cycles
+// whatever its width); here a lane owns one word column of one frame and walks down a band of rows, so every word is
+// loaded once (+ 8 halo rows per band) and stored once.  A wave holds G = 64 / wpr frames side by side (lane = g * wpr
+// + j): the left / right neighbour words of a row are the adjacent lanes (whole-wave DPP shifts; the first and last word
+// of a row take the border value instead).  Rows in flight: m (merged), A = 5-wide horizontal AND of m, e (eroded), O =
+// 5-wide horizontal OR of e;  e[y] = m[y-2] & A[y-1] & A[y] & A[y+1] & m[y+2],  d[y] = e[y-2] | O[y-1] | O[y] | O[y+1] | e[y+2]
+// (the 17-tap ellipse: one pixel in the outer rows, five in the three inner ones).  Erode ignores taps outside the image
+// (= set), dilate too (= clear).  NP = 4 also writes the merged plane over p0 (lt_download_plane(LT_PLANE_MERGED)); a
+// neighbouring band that still reads that row gets the same OR either way.
+template <int NP>
+__global__ __launch_bounds__(64) void k_merge_open5(unsigned long long* p0, const unsigned long long* __restrict__ p1,
+                                                   const unsigned long long* __restrict__ p2, const unsigned long long* __restrict__ p3,
+                                                   unsigned long long* __restrict__ opened, int h, int w, int wpr, size_t bits_stride,
+                                                   int band_rows, int G, int n) {
+    typedef unsigned long long u64;
+    const int lane = threadIdx.x, g = lane / wpr, j = lane - g * wpr;
+    const int frame = blockIdx.x * G + g;
+    const bool active = g < G && frame < n;
+    const size_t base = (size_t)(active ? frame : 0) * bits_stride + (size_t)j;
+    const int yb0 = blockIdx.y * band_rows, yb1 = min(yb0 + band_rows, h);
+    const bool has_left = j > 0, has_right = j < wpr - 1;
+    const u64 vb = valid_bits(j, w);
+    auto shift_in = [&](u64 v, u64 border, u64& l, u64& r) {   // words of lanes -1 / +1, or the border value at the ends of a row
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+        const uint32_t llo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x138, 0xf, 0xf, true);   // wave_shr:1: lane i <- lane i-1
+        const uint32_t lhi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x138, 0xf, 0xf, true);
+        const uint32_t rlo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xf, 0xf, true);   // wave_shl:1: lane i <- lane i+1
+        const uint32_t rhi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x130, 0xf, 0xf, true);
+        l = has_left ? ((u64)lhi << 32 | llo) : border;
+        r = has_right ? ((u64)rhi << 32 | rlo) : border;
+    };
+    auto load_row = [&](int y, u64 (&q)[4]) {
+        const size_t o = base + (size_t)min(max(y, 0), h - 1) * wpr;
+        q[0] = p0[o];
+        if (NP == 4) { q[1] = p1[o]; q[2] = p2[o]; q[3] = p3[o]; }
+    };
+    u64 m0 = ~0ull, m1 = ~0ull, m2 = ~0ull, m3 = ~0ull;     // m[t-4 .. t-1]
+    u64 a1 = ~0ull, a2 = ~0ull, a3 = ~0ull;                  // A[t-3 .. t-1]
+    u64 e0 = 0, e1 = 0, e2 = 0, e3 = 0;                      // e[t-6 .. t-3]
+    u64 o1 = 0, o2 = 0, o3 = 0;                              // O[t-5 .. t-3]
+    u64 q[4], qn[4];
+    load_row(yb0 - 4, q);
+    for (int t = yb0 - 4; t <= yb1 + 3; ++t) {
+        load_row(t + 1, qn);                                  // next row in flight while this one goes through the pipeline
+        const u64 raw = NP == 4 ? (q[0] | q[1] | q[2] | q[3]) : q[0];
+        const bool in_img = t >= 0 && t < h;
+        if (NP == 4 && active && t >= yb0 && t < yb1) p0[base + (size_t)t * wpr] = raw;
+        const u64 m = in_img ? (raw | ~vb) : ~0ull;           // pixels right of / rows outside the image count as set
+        u64 l, r;
+        shift_in(m, ~0ull, l, r);
+        const u64 a = hspan5<false>(l, m, r);
+        const int ye = t - 2;
+        u64 e = m0 & a1 & a2 & a3 & m;
+        e = (ye >= 0 && ye < h) ? (e & vb) : 0ull;
+        shift_in(e, 0ull, l, r);
+        const u64 o = hspan5<true>(l, e, r);
+        const int yd = t - 4;
+        const u64 d = (e0 | o1 | o2 | o3 | e) & vb;
+        if (active && yd >= yb0 && yd < yb1) opened[base + (size_t)yd * wpr] = d;
+        m0 = m1; m1 = m2; m2 = m3; m3 = m;
+        a1 = a2; a2 = a3; a3 = a;
+        e0 = e1; e1 = e2; e2 = e3; e3 = e;
+        o1 = o2; o2 = o3; o3 = o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = qn[k];
+    }
+}
+
 // dilate of the eroded bits (out-of-image = clear) and expansion to the u8 {0,255} mask.
 // A block owns DR rows: its threads first build the dilated words of those rows in LDS, then
 // every thread expands 4 pixels at a time into one coalesced dword store.
@@ -745,6 +815,26 @@ void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsig
                        bits_stride);
     hipLaunchKernelGGL(k_dilate5_bits, dim3((h * wpr + 255) / 256, 1, n), dim3(256), 0, s, eroded, opened, h, w, wpr,
                        bits_stride);
+}
+
+// merged (or the first of four partial planes, OR-ed in place) -> opened, both bit planes; false when the row does not
+// fit a wave (w > 4096): the caller runs the separate kernels
+bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
+                        const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n) {
+    const int wpr = (w + 63) / 64;
+    static const bool off = [] { const char* e = std::getenv("LT_OPEN5_SEPARATE"); return e && e[0] == '1'; }();   // A/B
+    if (off || n <= 0 || h <= 0 || wpr > 64 || opened == p0) return false;
+    const int G = 64 / wpr;
+    static const int rows_env = [] { const char* e = std::getenv("LT_OPEN5_BAND_ROWS"); return e ? std::atoi(e) : 0; }();
+    // enough bands to give every SIMD a few waves, none shorter than 24 rows (8 halo rows per band are recomputed)
+    const int groups = (n + G - 1) / G;
+    int nbands = std::max(1, std::min(h / 24, (4096 + groups - 1) / groups));
+    int band_rows = rows_env > 0 ? rows_env : (h + nbands - 1) / nbands;
+    nbands = (h + band_rows - 1) / band_rows;
+    dim3 grid(groups, nbands);
+    if (p1) hipLaunchKernelGGL(k_merge_open5<4>, grid, dim3(64), 0, s, p0, p1, p2, p3, opened, h, w, wpr, bits_stride, band_rows, G, n);
+    else hipLaunchKernelGGL(k_merge_open5<1>, grid, dim3(64), 0, s, p0, p1, p2, p3, opened, h, w, wpr, bits_stride, band_rows, G, n);
+    return true;
 }
 
 void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,

@@ -496,18 +496,25 @@ bool bilateral_walk_supported(int k_r, int C_r, int k_b, int C_b, int h, int w, 
     return (long long)k_r * (255 + C_r) < 32768 && (long long)k_b * (255 + C_b) < 32768;
 }
 
-// Both bilateral thresholds + OR-merge through the walking kernels.  scratch: three more bit planes of the same slots
-// (merged is the fourth partial and the result).  Returns 0 when it ran, -1 when the parameters are outside its limits.
+// Both bilateral thresholds through the walking kernels: four partial bit planes (merged, s1, s2, s3), OR-ed into `merged`
+// here when `merge` is set -- otherwise the caller merges them (launch_merge_open5 does it on the way into the 5x5 open).
+// Returns 0 when it ran, -1 when the parameters are outside its limits.
 int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
                           unsigned long long* merged, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
-                          int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n) {
+                          int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n, bool merge) {
     if (n <= 0 || !bilateral_walk_supported(k_r, C_r, k_b, C_b, h, w, pitch) || (plane_stride & 63)) return -1;
     static const int passes = [] { const char* e = std::getenv("LT_WALK_PASSES"); return e ? std::atoi(e) : 15; }();
     dispatch_walk(k_r, s, thr, C_r, merged, s1, h, w, pitch, plane_stride, bits_stride, n, passes & 3);
     dispatch_walk(k_b, s, thb, C_b, s2, s3, h, w, pitch, plane_stride, bits_stride, n, (passes >> 2) & 3);
+    if (merge) launch_or4_bits(s, merged, s1, s2, s3, h, w, bits_stride, n);
+    return 0;
+}
+
+void launch_or4_bits(hipStream_t s, unsigned long long* merged, const unsigned long long* s1, const unsigned long long* s2,
+                     const unsigned long long* s3, int h, int w, size_t bits_stride, int n) {
+    if (n <= 0) return;
     const size_t words = (size_t)(n - 1) * bits_stride + (size_t)h * ((w + 63) / 64);
     hipLaunchKernelGGL(k_or4_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, merged, s1, s2, s3, merged, words);
-    return 0;
 }
 
 }  // namespace lt

@@ -72,7 +72,8 @@ struct lt_ctx {
     uint8_t* d_plane[P_COUNT] = {};
     unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
     unsigned long long* d_bits_open = nullptr;    // the opened mask as the mask chain leaves it (what the searches read)
-    unsigned long long* d_bits_tmp = nullptr;     // fourth partial plane of the walking threshold kernels
+    unsigned long long* d_bits_tmp = nullptr;     // third and fourth partial plane of the walking threshold kernels
+    unsigned long long* d_bits_tmp2 = nullptr;
     // Top-hat planes with a 64-byte-multiple row pitch: what the walking threshold kernels read (every 64-byte piece of
     // a row is one aligned sector; with the image width as pitch the horizontal pass fetched every sector twice).
     // th_padded[slot] says which copy of the slot's top-hat planes is current (lt_download_plane).
@@ -241,6 +242,7 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_bits_eroded);
     dev_free(c->d_bits_open);
     dev_free(c->d_bits_tmp);
+    dev_free(c->d_bits_tmp2);
     dev_free(c->d_th_pad[0]);
     dev_free(c->d_th_pad[1]);
     c->th_padded.clear();
@@ -359,7 +361,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     uint8_t* merged = c->d_plane[P_MERGED] + off;
     uint8_t* mask = c->d_plane[P_MASK] + off;
     // the walking threshold kernels read the top-hat planes with a padded row pitch: the dilate launches write them so
-    const bool walk = p->filter_type == 0 && !p->mask_noise && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp &&
+    const bool walk = p->filter_type == 0 && !p->mask_noise && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp && c->d_bits_tmp2 &&
                       first + n <= (int)c->th_padded.size() && (long long)call_frames * h * w >= c->walk_min_pixels &&
                       bilateral_walk_supported(p->ksize_r, p->C_r, p->ksize_b, p->C_b, h, w, c->th_pitch);
     if (p->filter_type == 0) c->last_threshold_path = walk ? 1 : 0;
@@ -395,15 +397,17 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     }
     unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
     unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
-    bool merged_done = false;
+    bool merged_done = false, partials = false;   // partials: mbits, ebits, tmp, tmp2 still wait for their OR
+    unsigned long long* tbits = c->d_bits_tmp + (size_t)first * c->bits_stride;
+    unsigned long long* ubits = c->d_bits_tmp2 + (size_t)first * c->bits_stride;
     if (p->filter_type == 0) {
         StageScope t(c, ST_THRESHOLD, s);   // both bilateral thresholds, the greenery mask and the OR-merge
-        // long-walk kernels for the supported window sizes (the eroded / opened planes are free until the open stage)
-        if (walk)
-            merged_done = launch_bilateral_walk(s, thRd, p->ksize_r, p->C_r, thBd, p->ksize_b, p->C_b, mbits, ebits,
-                                                c->d_bits_open + (size_t)first * c->bits_stride,
-                                                c->d_bits_tmp + (size_t)first * c->bits_stride, h, w, c->th_pitch,
-                                                c->th_pad_bytes, c->bits_stride, n) == 0;
+        // long-walk kernels for the supported window sizes; their four partial planes are merged on the way into the open
+        if (walk) {
+            merged_done = launch_bilateral_walk(s, thRd, p->ksize_r, p->C_r, thBd, p->ksize_b, p->C_b, mbits, ebits, tbits, ubits,
+                                                h, w, c->th_pitch, c->th_pad_bytes, c->bits_stride, n, false) == 0;
+            partials = merged_done;
+        }
         if (!merged_done)
           merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
                                             p->C_noise, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps,
@@ -426,8 +430,15 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
         launch_pack_merge(s, t1, t2, B, t3, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps, c->bits_stride, n);
     }
     { StageScope t(c, ST_OPEN, s);
-      if (u8_mask) launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n);
-      else launch_open5_to_bits(s, mbits, ebits, c->d_bits_open + (size_t)first * c->bits_stride, h, w, c->bits_stride, n); }
+      unsigned long long* obits = c->d_bits_open + (size_t)first * c->bits_stride;
+      bool opened = false;
+      // one pass over the words; a handful of frames is latency-bound and better off with the wide, shallow kernels
+      if (!u8_mask && (partials || n >= 16)) opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, tbits, ubits, obits, h, w, c->bits_stride, n);
+      if (!opened) {
+          if (partials) launch_or4_bits(s, mbits, ebits, tbits, ubits, h, w, c->bits_stride, n);
+          if (u8_mask) launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n);
+          else launch_open5_to_bits(s, mbits, ebits, obits, h, w, c->bits_stride, n);
+      } }
     (void)merged; (void)t0;
     HIP_TRY(hipGetLastError());
     return LT_OK;
@@ -652,6 +663,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     if ((rc = dev_alloc(&c->d_bits_eroded, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_bits_open, n * c->bits_stride))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_bits_tmp, n * c->bits_stride))) { free_slots(c); return rc; }
+    if ((rc = dev_alloc(&c->d_bits_tmp2, n * c->bits_stride))) { free_slots(c); return rc; }
     c->th_pitch = (c->calib.warp_w + 63) & ~63;
     c->th_pad_bytes = (size_t)c->calib.warp_h * c->th_pitch;
     for (auto& q : c->d_th_pad)

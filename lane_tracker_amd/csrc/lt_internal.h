@@ -91,8 +91,12 @@ void launch_open5_bits(hipStream_t s, const unsigned long long* merged, unsigned
 bool bilateral_walk_supported(int k_r, int C_r, int k_b, int C_b, int h, int w, int pitch);
 int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
                           unsigned long long* merged, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
-                          int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n);
+                          int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n, bool merge);
+void launch_or4_bits(hipStream_t s, unsigned long long* merged, const unsigned long long* s1, const unsigned long long* s2,
+                     const unsigned long long* s3, int h, int w, size_t bits_stride, int n);
 // erode + dilate with the 5x5 ellipse, bit plane in, bit plane out
+bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
+                        const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n);
 void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded,
                           unsigned long long* opened, int h, int w, size_t bits_stride, int n);
 void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,
