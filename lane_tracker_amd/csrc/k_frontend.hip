@@ -194,11 +194,19 @@ __device__ __forceinline__ void warp_pixel(const uint32_t* __restrict__ src, con
 // one dword store to the R plane and one to the Lab-b plane.  `quads` = pixels / 4 (w % 4 == 0).
 // The remap table entry of a quad is the same for every frame, so a thread keeps it (and the tap
 // offsets derived from it) in registers and walks `ppb` consecutive slot PAIRS with it: the two taps of a row are one
-// 16-byte load {left.even, left.odd, right.even, right.odd} that serves both slots of the pair, and the taps of the
-// next pair are in flight while this one is blended (the kernel is bound by the memory pipe's instruction rate).
+// 16-byte load {left.even, left.odd, right.even, right.odd} that serves both slots of the pair.
 // Slots [first_slot, first_slot + n); `und` is the base of the whole buffer, planeR / planeB point at first_slot's planes.
 
-__global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict__ und, size_t und_px, int first_slot,
+// Latency is hidden by occupancy, not by prefetch: with the taps of the next slot pair in flight (two sets of 8 x 16 bytes)
+// the kernel needs 97 VGPRs = 4 waves per SIMD; with one set it fits 64 = 8 waves and runs 6 % faster alone and 3 % faster
+// end to end, where it shares the CUs with the other slices' kernels (-DLT_WARP_PREFETCH=1 -DLT_WARP_WAVES=5 for the A/B).
+#ifndef LT_WARP_PREFETCH
+#define LT_WARP_PREFETCH 0
+#endif
+#ifndef LT_WARP_WAVES
+#define LT_WARP_WAVES 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LT_WARP_WAVES, LT_WARP_WAVES))) void k_warp_split4(const uint32_t* __restrict__ und, size_t und_px, int first_slot,
                                                     const int16_t* __restrict__ wxy,
                                                     const uint16_t* __restrict__ wfrac, FrontEndGeom g,
                                                     const uint16_t* __restrict__ gamma_tab,
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
         };
         // two pairs per trip, the tap registers alternate: the taps of the next pair are in flight while this one is
         // blended, and nothing is copied at the back edge
+#if LT_WARP_PREFETCH
         fetch(tapA, pa);
         for (int p = pa; p < pb; p += 2) {
             fetch(tapB, p + 1);
@@ -312,6 +321,13 @@ __global__ __launch_bounds__(256) void k_warp_split4(const uint32_t* __restrict_
             fetch(tapA, p + 2);
             blend_pair(tapB, p + 1);
         }
+#else
+        for (int p = pa; p < pb; ++p) {
+            fetch(tapA, p);
+            blend_pair(tapA, p);
+        }
+        (void)tapB;
+#endif
         return;
     }
     // 13 % of the bird's-eye view (the bottom corner triangles) samples entirely outside the camera frame: every tap
