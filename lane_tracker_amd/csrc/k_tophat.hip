@@ -259,16 +259,18 @@ __global__ __launch_bounds__(256) void k_morph_runs(const uint8_t* __restrict__ 
 // ================================================================================================
 // Two input rows per iteration, 3-input packed min/max.
 //
-// gfx950 has v_pk_minimum3_f16 / v_pk_maximum3_f16.  A u8 value v stored as the 16-bit pattern
-// 0x0400 | v is a positive *normal* f16 number, and positive f16 numbers order exactly like their
-// bit patterns, so the f16 min/max of such patterns is the integer min/max, bit for bit (the result
-// is always one of the inputs).  Processing rows (yy, yy+1) together turns two accumulator steps
+// gfx950 has v_pk_minimum3_f16 / v_pk_maximum3_f16.  A u8 value v as the 16-bit pattern 0x00vv is +0 or a positive
+// f16 denormal, and non-negative f16 numbers order exactly like their bit patterns, so -- with f16 denormals kept, which
+// is the mode HIP kernels run in and which the kernel sets in MODE itself -- the f16 min/max of such patterns is the
+// integer min/max, bit for bit (the result is always one of the inputs).  -DLT_MORPH_BIAS=1 keeps the patterns normal
+// numbers instead (0x0400 | v) at the price of one v_or per entry: 4 of the 83 / 131 VALU instructions per row pair, and
+// these kernels are at 80-85 % of the VALU issue ceiling (profiles/r02_pmc_kernels.txt).  Processing rows (yy, yy+1) together turns two accumulator steps
 //     A1[j] = min(A[j+1], Ha[s(j)]);  A2[j] = min(A1[j+1], Hb[s(j)])
 // into one instruction  A2[j] = min3(A[j+2], Ha[s(j+1)], Hb[s(j)])  for two pixels: 27.5 instead of
 // 54 accumulate ops per row, and half the loop overhead and LDS round trips per row.
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #ifndef LT_MORPH_BIAS
-#define LT_MORPH_BIAS 1
+#define LT_MORPH_BIAS 0
 #endif
 constexpr uint32_t BIAS2 = LT_MORPH_BIAS ? 0x04000400u : 0u;
 

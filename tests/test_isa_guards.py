@@ -39,3 +39,13 @@ def test_no_packed_clamp_shift_instruction_in_the_product():
         if path.endswith("k_threshold_walk.hip"):
             assert "v_cmp_le_i16_e64" in text and "ds_read_b128" in text and "global_load_dwordx4" in text
             assert ".vgpr_spill_count: 0" in text or "vgpr_spill_count:     0" in text
+        # the two-row top-hat kernels compare u8 pixels as f16 denormals: every one of them must run with f16 denormals
+        # kept (kernel descriptor) and set the mode itself before its first min / max
+        if path.endswith("k_tophat.hip"):
+            kernels = re.split(r"\n(?=_ZN2lt[^\n]*k_morph_runs2[^\n]*:)", text)[1:]
+            assert len(kernels) >= 12
+            for k in kernels:
+                body = k.split(".end_amdhsa_kernel")[0]
+                assert re.search(r"s_setreg_imm32_b32 hwreg\(HW_REG_MODE, 6, 2\), 3", body), k.splitlines()[0]
+                assert re.search(r"\.amdhsa_float_denorm_mode_16_64 3", body), k.splitlines()[0]
+                assert "scratch_" not in body.split("s_endpgm")[0], k.splitlines()[0]
