@@ -7,6 +7,7 @@
 //   build: hipcc -O2 --offload-arch=gfx950 vmem_issue.hip -o vmem_issue ;  run: ./vmem_issue [iters]
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -24,11 +25,14 @@ enum Mode {
     LD_B64_TAP,       // buffer_load_dwordx2 at 4-byte aligned offsets 12i (a gather with some reuse: the warp taps)
     LD_B128,          // buffer_load_dwordx4, lane i -> 16 bytes at 16i
     ST_U8, ST_B32, ST_B64, ST_B128,
+    LD_U8_ROWS,       // buffer_load_ubyte, lane i -> byte i of a NEW 1080-byte row per instruction (the old top-hat fetch: L1 misses)
+    LD_B32_SHARE4_ROWS,   // buffer_load_dword, lanes 4k..4k+3 -> dword k of a new row per instruction (the new one)
     N_MODES
 };
 static const char* kNames[N_MODES] = {"load_ubyte", "load_ushort", "load_dword", "load_dword_4lanes_share", "load_dword_unaligned_1B_pitch",
                                       "load_dwordx2", "load_dwordx2_unaligned_3B_pitch", "load_dwordx2_12B_pitch", "load_dwordx4",
-                                      "store_byte", "store_dword", "store_dwordx2", "store_dwordx4"};
+                                      "store_byte", "store_dword", "store_dwordx2", "store_dwordx4",
+                                      "load_ubyte_new_row_each", "load_dword_4lanes_share_new_row_each"};
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -52,6 +56,25 @@ __global__ __launch_bounds__(256) void k_vmem(uint8_t* __restrict__ buf, int ite
         case LD_B128: case ST_B128: voff = 16 * lane; break;
     }
     unsigned acc = magic ^ lane;
+    if constexpr (MODE == LD_U8_ROWS || MODE == LD_B32_SHARE4_ROWS) {
+        // every wave walks down its own 128-byte column of a big plane, one 1080-byte row per load: nothing is in the L1
+        constexpr int PITCH = 1080, ROWS = 3600;           // 3.9 MB per wave, 16 GB in total would not fit: waves share planes of 64 MiB
+        uint8_t* plane = buf + (wave % 16) * (size_t)(64u << 20) / 16 + (wave / 16 % 8) * 128;
+        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(plane, 0, PITCH * ROWS, 0x00027000);
+        const int vo = MODE == LD_U8_ROWS ? lane : (lane & ~3);
+        int row = (int)(wave % 97);
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int o = row * PITCH;
+                row = row + 1 >= ROWS ? 0 : row + 1;
+                if constexpr (MODE == LD_U8_ROWS) acc ^= __builtin_amdgcn_raw_buffer_load_b8(prs, vo, o, 0);
+                else acc ^= __builtin_amdgcn_raw_buffer_load_b32(prs, vo, o, 0);
+            }
+        }
+        if (acc == 0x12345678u) sink[0] = acc;
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         const int so = (it & 3) * 1024;   // scalar offset changes every trip: nothing can be hoisted or merged
 #pragma unroll
@@ -103,7 +126,7 @@ int main(int argc, char** argv) {
     CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev));
     const double ghz = khz * 1e-6;
-    const size_t bytes = (size_t)cus * 16 * 8192;
+    const size_t bytes = std::max((size_t)cus * 16 * 8192, (size_t)(72u << 20));
     uint8_t* buf = nullptr;
     unsigned* sink = nullptr;
     CHECK(hipMalloc(&buf, bytes));
@@ -122,7 +145,9 @@ int main(int argc, char** argv) {
     run<ST_U8>(buf, sink, cus, iters, ghz, false);
     run<ST_B32>(buf, sink, cus, iters, ghz, false);
     run<ST_B64>(buf, sink, cus, iters, ghz, false);
-    run<ST_B128>(buf, sink, cus, iters, ghz, true);
+    run<ST_B128>(buf, sink, cus, iters, ghz, false);
+    run<LD_U8_ROWS>(buf, sink, cus, iters, ghz, false);
+    run<LD_B32_SHARE4_ROWS>(buf, sink, cus, iters, ghz, true);
     std::printf("}}\n");
     return 0;
 }
