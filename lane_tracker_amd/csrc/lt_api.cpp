@@ -376,7 +376,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             { StageScope t(c, ST_TOPHAT_R, s); launch_morph_ellipse(s, t0, thR, R, h, w, c->se29, true, ps, n); }
             { StageScope t(c, ST_ERODE_B, s);  launch_morph_ellipse(s, B, t0, nullptr, h, w, c->se55, false, ps, n); }
             { StageScope t(c, ST_TOPHAT_B, s); launch_morph_ellipse(s, t0, thB, B, h, w, c->se55, true, ps, n); }
-        } else if ((n <= 2 || std::getenv("LT_FORK_ALL")) && !c->stage_timing && c->side && (s == c->stream || std::getenv("LT_FORK_ALL"))) {
+        } else if (n <= 2 && !c->stage_timing && c->side && s == c->stream) {
             // One or two frames cannot fill the chip (a few hundred waves per top-hat kernel), so the two planes'
             // top-hats, which do not depend on each other, run side by side: the R plane on the side stream, the
             // Lab-b plane here; saves the shorter pair's ~40 us of a 160 us chain.  t3 is free until the merge.
