@@ -542,3 +542,44 @@ def test_alternative_kernel_paths_keep_parity(switch):
                               "band_search_vs_reference or multi_stream"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_odd_slot_ranges_and_the_batch_paths_of_the_open_stage(nat, cal, oracle, ref_calib):
+    """Slot pairs share the interleaved undistorted rows and the front-end kernels walk pairs: ranges that start or end on
+    an odd slot, and a batch large enough (>= 16 frames) for the fused merge + open pass on an already merged plane
+    (tile threshold kernel: a window size the walking kernels do not have) must give the oracle's planes slot by slot."""
+    from lane_tracker_amd import synth
+    r = synth.SceneRenderer(cal)
+    n = 21
+    batch = np.stack([r.render(900 + i)[0] if i % 4 else synth.frame_uniform(50 + i) for i in range(n)], 0)
+    c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                    device=0, capacity=n)
+    try:
+        c.set_streams(3)                                   # slices 0-6, 6-14, 14-21: even boundaries inside an odd capacity
+        c.upload_frames(batch)
+        kw = dict(ksize_r=25, C_r=6, ksize_b=31, C_b=4)    # not 15 / 20 / 35: tile kernel, then the fused open of 21 frames
+        c.mask_run(n, nat.filter_params(**kw))
+        assert c.last_threshold_path() == 0
+        masks, merged = c.download_masks(n), c.download_plane(4, n)
+        und = c.download_undistorted(n)
+        r0, r1 = oracle.warp_source_rows(ref_calib)
+        for k in (0, 1, 6, 13, 14, 20):
+            bev = oracle.front_end(ref_calib, batch[k])
+            want, planes = oracle.filter_lane_points(bev, oracle.filter_params(**kw), want_planes=True)
+            assert_same(und[k], oracle.undistort(ref_calib, batch[k])[r0:r1], f"undistorted rows, slot {k}")
+            assert_same(oracle.morph_open(merged[k], 5), want, f"open(merged), slot {k}")
+            assert_same(masks[k], want, f"mask, slot {k}")
+        # an odd range on top: slots 3..7 with the default parameters, everything else untouched
+        c.mask_run(5, first=3)
+        after = c.download_masks(n)
+        for k in range(n):
+            if 3 <= k < 8:
+                assert_same(after[k], oracle.filter_lane_points(oracle.front_end(ref_calib, batch[k])), f"odd range, slot {k}")
+            else:
+                assert np.array_equal(after[k], masks[k]), k
+        # single odd slot through the presentation path that reads the interleaved rows
+        bev7 = c.download_bev(1, first=7)[0] if hasattr(c, "download_bev") else None
+        if bev7 is not None:
+            assert_same(bev7, oracle.front_end(ref_calib, batch[7]), "bird's-eye RGB of slot 7")
+    finally:
+        c.close()
