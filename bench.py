@@ -191,6 +191,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (weak scaling, BASELINE config 3)")
     ap.add_argument("--frames", type=int, default=0,
                     help="total frames of one stream, sharded over the GPUs (strong scaling; 4096 = BASELINE config 4)")
+    ap.add_argument("--single-copy", action="store_true", help="one resident copy of the batch: consecutive steps do not overlap")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams per context (slot slices overlap each other's stages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
@@ -227,8 +228,13 @@ def main():
     if local_rank >= ndev:
         print("bench.py: rank %d wants GPU %d but %d GPU(s) are visible" % (rank, local_rank, ndev), file=sys.stderr)
         sys.exit(2)
+    # Two resident copies of the batch (slots [0, NL) and [NL, 2 NL)) for batches that are not a whole stream anyway: the
+    # steps alternate between them, so the tail of step k and the head of step k+1 overlap the way consecutive batches of
+    # a stream do.  Every step still runs the whole path over NL resident frames; the rate with a single copy (each step
+    # waits in order behind the previous one on the same slots) is reported beside it as single_copy_frames_per_s.
+    two_copies = NL <= 1024 and not a.single_copy
     ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
-                          cal["warp_matrices"][0], device=local_rank, capacity=NL)
+                          cal["warp_matrices"][0], device=local_rank, capacity=2 * NL if two_copies else NL)
     info = ctx.info()
     t0 = time.perf_counter()
     for c0 in range(0, NL, 256):
@@ -239,6 +245,10 @@ def main():
         ctx.upload_frame_rows(frames[c0:c0 + 256], first=c0)   # what a host-fed pipeline moves: the rows the path reads
     h2d_rows_s = time.perf_counter() - t0
     ctx.set_frame_base(NL, indices[0])
+    if two_copies:
+        for c0 in range(0, NL, 256):
+            ctx.upload_frames(frames[c0:c0 + 256], first=NL + c0)
+        ctx.set_frame_base(NL, indices[0], first=NL)
     fp, sp = _native.filter_params(), _native.search_params()
 
     # ranks: every step's records are staged, stream-ordered and without a host wait, into the gather's send buffer;
@@ -249,11 +259,12 @@ def main():
         gather = distributed.init_gather(ctx)
         gather.reserve(nsteps * NL)
 
-    def step(k=0):
-        ctx.mask_run(NL, fp)
-        ctx.sws_fit_run(NL, sp)
-        if gather is not None:
-            gather.stage(NL, at=k * NL)
+    def step(k=0, alternate=True):
+        first = NL * (k & 1) if two_copies and alternate else 0
+        ctx.mask_run(NL, fp, first=first)
+        ctx.sws_fit_run(NL, sp, first=first)
+        if gather is not None and alternate:
+            gather.stage(NL, at=k * NL, first=first)
 
     marks = {}
     gathered = [None]
@@ -281,6 +292,16 @@ def main():
         print("timed region: drained %.3f ms, +gather %.3f ms, +barrier %.3f ms" % (
             (marks["drained"] - t0) * 1e3, (marks.get("gathered", marks["drained"]) - marks["drained"]) * 1e3,
             (marks["fenced"] - marks.get("gathered", marks["drained"])) * 1e3), file=sys.stderr)
+
+    single_copy_fps = None
+    if two_copies and not in_rank:     # the same steps on one copy of the batch (not part of the timed region)
+        step(0, False)
+        ctx.sync()
+        t1 = time.perf_counter()
+        for k in range(a.steps):
+            step(k, False)
+        ctx.sync()
+        single_copy_fps = NL * a.steps / (time.perf_counter() - t1)
 
     # Per-kernel durations for the roofline: the same steps again on ONE stream with a hipEvent pair
     # around every kernel (with several streams the kernels of different slices overlap, so their
@@ -353,7 +374,7 @@ def main():
                        "parallelism": "frames sharded x%d, one process per GPU" % world,
                        "collective": ("one RCCL all-gather (lt_gather_records) of %d x 64-byte records per rank at the end of the "
                                       "timed region" % (a.steps * NL)) if gather is not None else "none (single process)",
-                       "streams_per_gpu": a.streams,
+                       "streams_per_gpu": a.streams, "resident_copies_of_the_batch": 2 if two_copies else 1,
                        "detected_fraction": round(float(np.mean(rec_all["detected"])), 4)},
             "roofline": {"bound": "hbm", "kernel": "warp+threshold stage (%d kernels: %s)" % (len(MASK_STAGES), ",".join(MASK_STAGES)),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -368,9 +389,13 @@ def main():
                                  "integer-VALU / LDS bound, not HBM bound; see DESIGN.md"},
             "kernels_ms_per_step": {k: round(v[0] / KS, 4) for k, v in stages.items() if v[1]},
             "timing_note": "value / ms_per_step: %d steps on %d HIP streams per GPU (slot slices overlap: the latency-bound "
-                           "search of one slice hides under the mask chain of another). kernels_ms_per_step, roofline and "
+                           "search of one slice hides under the mask chain of another)%s. kernels_ms_per_step, roofline and "
                            "search_fit: %d further steps on one stream with hipEvents around every kernel; their sum (%.3f ms) "
-                           "is the un-overlapped step" % (a.steps, a.streams, KS, mask_ms + search_ms),
+                           "is the un-overlapped step" % (a.steps, a.streams,
+                                                          ", alternating between two resident copies of the batch (consecutive steps overlap "
+                                                          "like consecutive batches of a stream; single_copy_frames_per_s: every step on the same slots)"
+                                                          if two_copies else "", KS, mask_ms + search_ms),
+            "single_copy_frames_per_s": round(single_copy_fps, 2) if single_copy_fps else None,
             "search_fit": {"ms_per_step": round(search_ms, 4),
                            "achieved_GBs": round(info.alg_bytes_search * NL / (search_ms * 1e-3) / 1e9, 3) if search_ms > 0 else None},
             "host_fed": {"h2d_seconds_whole_frames": round(h2d_s, 4),
