@@ -144,6 +144,9 @@ struct RunsGeom {
     size_t plane_stride;
     int dpitch;                  // row pitch of the destination (w, or a 64-byte multiple for the threshold walks)
     size_t dst_stride;           // bytes per frame of the destination
+    int nframes;                 // frames of the launch
+    int nstrips_normal;          // strips handled one frame per wave; nstrips - 1 when the last strip is a PAIR strip (below)
+    int n_normal;                // tasks of those strips: nframes * nstrips_normal * nbands; the tasks behind them are pair tasks
 };
 
 // Per-lane column bookkeeping, loop invariant: clamped byte offsets of the (up to) four pixels a
@@ -545,33 +548,32 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
 // hardware turns into dropped stores / zero loads -- no compares, no exec masking, no address clamps in the loop.
 // TOPHAT: src - open(src) can never be negative (an opening is anti-extensive, also with ignored borders), so the
 // saturating subtract of four bytes is one plain 32-bit subtract (no byte ever borrows).
-template <class SE, bool DIL, bool WIDE, bool TH>
-__global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                    const uint8_t* __restrict__ minuend, RunsGeom g) {
-    __shared__ uint2 s_chain[4][4 * PLANE];   // S0, S1, S4, S13|S7
-    __shared__ __attribute__((aligned(8))) uint8_t s_out[WIDE ? 4 : 1][WIDE ? 256 : 8];   // [2*col + row] of a row pair
+//
+// PAIR strip.  A wave's 64 lanes x 2 halves cover 128 columns, and the width is rarely a multiple of that: at 1080 columns the
+// ninth strip has 56 -- its high halves and 8 lanes idle, 6.25 % of every launch.  When the last strip is at most 64
+// columns wide it is therefore processed for TWO frames at once: the low halves carry frame f, the high halves frame
+// f + 1, both at column x0 + lane (the chain shifts both halves alike, so nothing else changes: entry e = columns
+// (x0 - R + e) of the two frames).  Input: four dwords per row instead of three (columns a, b of both frames); output:
+// lanes 0..15 of each half-wave store frame f, lanes 16..31 frame f + 1 (explicit row predicate instead of the band
+// descriptor, which cannot clip two frames).  An odd last frame is processed against itself and not stored twice.
+template <class SE, bool DIL, bool WIDE, bool TH, bool PAIR>
+__device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint8_t* __restrict__ minuend,
+                                           const RunsGeom& g, uint2* chain, uint8_t* s_out_w, int lane, int strip, int band, int frame) {
+    static_assert(WIDE || !PAIR, "pair strips exist for the WIDE kernels only");
     constexpr int K = SE::K, R = SE::R, NH = SE::NH;
     constexpr uint32_t NEUTRAL = (DIL ? 0u : 0x00ff00ffu) | BIAS2;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);   // wave-uniform: keeps the loop scalar
-    if (task >= g.ntasks) return;
-    // Without the bias the pixel patterns 0x00vv are f16 denormals: min/max must not flush them.  FP16 denormals are on
-    // in the kernel descriptor the compiler writes (tests/test_isa_guards.py checks it); set MODE.FP_DENORM[3:2] anyway.
-    if (!LT_MORPH_BIAS) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);
-    const int strip = task % g.nstrips;
-    const int band = (task / g.nstrips) % g.nbands;
-    const int frame = task / (g.nstrips * g.nbands);
     const uint8_t* s = src + (size_t)frame * g.plane_stride;
     uint8_t* d = dst + (size_t)frame * g.dst_stride;
     const uint8_t* m = TH ? minuend + (size_t)frame * g.plane_stride : nullptr;
-    uint2* chain = s_chain[wv];
+    const bool has_b = PAIR && frame + 1 < g.nframes;                                    // wave-uniform
+    const bool lane_b = PAIR && (lane & 16);                                             // this lane stores frame f + 1
     const int x0 = strip * 128;
     const int yb0 = band * g.band_rows, yb1 = min(yb0 + g.band_rows, g.h);
     const int xa = x0 + lane, xb = xa + 64;
     const bool va = xa < g.w, vb = xb < g.w;
     const int oa = min(xa, g.w - 1), ob = min(xb, g.w - 1);
 
-    const int wcol = x0 + 4 * (lane & 31), wcol_c = min(wcol, g.w - 4);                 // WIDE: this lane's four output columns
+    const int wcol = x0 + 4 * (lane & (PAIR ? 15 : 31)), wcol_c = min(wcol, g.w - 4);   // WIDE: this lane's four output columns
     const uint32_t row_sel = lane < 32 ? 0x06040200u : 0x07050301u;                     // bytes of row 0 / row 1 of a [2*col + row] group
 
     uint32_t A[K];
@@ -584,10 +586,12 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     const uint32_t col_a = (uint32_t)min(max(c0, 0), g.w - 1), col_b = (uint32_t)min(max(c0 + 64, 0), g.w - 1), col_c = (uint32_t)min(max(c0 + 128, 0), g.w - 1);
     constexpr int RSRC_RAW = 0x00027000;   // untyped 32-bit buffer, no swizzle; out-of-range loads return 0, stores are dropped
     const int plane_bytes = g.h * g.w;
-    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s), 0, plane_bytes, RSRC_RAW);
+    const int b_src = has_b ? (int)g.plane_stride : 0;   // byte offset of frame f + 1 in the source / minuend (0: the odd last frame against itself)
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s), 0, plane_bytes + b_src, RSRC_RAW);
     // the destination descriptor covers the band's rows only: whatever a lane computes above or below them is dropped
-    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d + (size_t)yb0 * g.dpitch, 0, (yb1 - yb0) * g.dpitch, RSRC_RAW);
-    const __amdgpu_buffer_rsrc_t min_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(TH ? m : s), 0, plane_bytes, RSRC_RAW);
+    // (PAIR: the band of frame f through the band of frame f + 1; rows are tested explicitly there)
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d + (size_t)yb0 * g.dpitch, 0, (yb1 - yb0) * g.dpitch + (has_b ? (int)g.dst_stride : 0), RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t min_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(TH ? m : s), 0, plane_bytes + b_src, RSRC_RAW);
     auto row_ptr = [&](int y) { return __mul24(min(max(y, 0), g.h - 1), g.w); };   // byte offset of the (clamped) row: wave-uniform
     // Software prefetch: the three pixels (a, b, c) of each row of the NEXT pair are requested at the top of a pair, and
     // combined into its two entries (a | b << 16, b | c << 16) by the LAST statements of the pair.  The combine is a
@@ -596,14 +600,22 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     // per entry, with a per-lane selector, picks the two pixels into the 16-bit halves and zeroes the rest.  Byte loads
     // cost more: the compiler carries their results as i8 and re-extends each with a v_and before any 32-bit use, and
     // (x << 16) | y becomes a shift and an SDWA or.
-    struct Raw { uint32_t a, b, c; };
+    struct Raw { uint32_t a, b, c, d; };   // PAIR: a, b of frame f and c, d = a, b of frame f + 1
     // v_perm_b32 D, S0, S1, sel: selector byte 0..3 = that byte of S1, 4..7 = byte of S0, 0x0c = constant 0
     const uint32_t sel_ab = 0x0c000c00u | ((4u + (col_b & 3u)) << 16) | (col_a & 3u);
     const uint32_t sel_bc = 0x0c000c00u | ((4u + (col_c & 3u)) << 16) | (col_b & 3u);
+    const uint32_t sel_pa = 0x0c000c00u | ((4u + (col_a & 3u)) << 16) | (col_a & 3u);
+    const uint32_t sel_pb = 0x0c000c00u | ((4u + (col_b & 3u)) << 16) | (col_b & 3u);
     auto load_row = [&](int y) __attribute__((always_inline)) {
         const int ro = row_ptr(y);
         Raw r;
-        if (WIDE) {
+        r.d = 0;
+        if (PAIR) {
+            r.a = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_a & ~3u), ro, 0);
+            r.b = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_b & ~3u), ro, 0);
+            r.c = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_a & ~3u), ro + b_src, 0);
+            r.d = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_b & ~3u), ro + b_src, 0);
+        } else if (WIDE) {
             r.a = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_a & ~3u), ro, 0);
             r.b = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_b & ~3u), ro, 0);
             r.c = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_c & ~3u), ro, 0);
@@ -615,7 +627,9 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         return r;
     };
     auto combine = [&](const Raw& r, uint32_t& e0, uint32_t& e1) __attribute__((always_inline)) {
-        if (WIDE) {
+        if (PAIR) {   // entry e = (frame f, frame f + 1) at one column: the same byte of the two frames' dwords
+            asm volatile("v_perm_b32 %0, %4, %2, %6\n\tv_perm_b32 %1, %5, %3, %7" : "=&v"(e0), "=&v"(e1) : "v"(r.a), "v"(r.b), "v"(r.c), "v"(r.d), "v"(sel_pa), "v"(sel_pb));
+        } else if (WIDE) {
             asm volatile("v_perm_b32 %0, %3, %2, %5\n\tv_perm_b32 %1, %4, %3, %6" : "=&v"(e0), "=&v"(e1) : "v"(r.a), "v"(r.b), "v"(r.c), "v"(sel_ab), "v"(sel_bc));
         } else {
             e0 = r.a | (r.b << 16);
@@ -630,18 +644,23 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
     uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // !WIDE: minuend (xa, xb) of output rows y and y+1
     // WIDE: running byte offsets of this lane's dword -- row y + (lane >> 5) of the minuend, row y - 2 + (lane >> 5) of the
     // band (relative to its first row), for the output row y of the current iteration; lanes right of the image stay out of range
-    uint32_t m_off = (uint32_t)(__mul24(yb0 - 2 * R + (lane >> 5), g.w) + wcol_c);
-    uint32_t st_off = wcol < g.w ? (uint32_t)(__mul24(-2 * R - 2 + (lane >> 5), g.dpitch) + wcol) : 0x80000000u;
+    uint32_t m_off = (uint32_t)(__mul24(yb0 - 2 * R + (lane >> 5), g.w) + wcol_c + (lane_b ? b_src : 0));
+    uint32_t st_off = wcol < g.w && (!lane_b || has_b) ? (uint32_t)(__mul24(-2 * R - 2 + (lane >> 5), g.dpitch) + wcol + (lane_b ? (int)g.dst_stride : 0))
+                                                      : 0x80000000u;
     uint32_t mcur = 0;
     const uint32_t s0_rd = (uint32_t)(uintptr_t)(chain + MARGIN + ((R + lane) & 63));
-    const uint32_t out_wr = (uint32_t)(uintptr_t)(s_out[wv] + (WIDE ? 2 * lane : 0));         // LDS offsets
-    const uint32_t out_rd = (uint32_t)(uintptr_t)(s_out[wv] + (WIDE ? 8 * (lane & 31) : 0));
+    const uint32_t out_wr = (uint32_t)(uintptr_t)(s_out_w + (WIDE ? 2 * lane : 0));         // LDS offsets
+    const uint32_t out_rd = (uint32_t)(uintptr_t)(s_out_w + (WIDE ? 8 * (lane & 31) : 0));
     auto out_issue = [&](unsigned long long& q) { asm volatile("ds_read_b64 %0, %1" : "=v"(q) : "v"(out_rd) : "memory"); };
-    auto out_finish = [&](unsigned long long q, uint32_t mp) {
+    auto out_finish = [&](unsigned long long q, uint32_t mp, int yp) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(q) :: "memory");
         uint32_t v = __builtin_amdgcn_perm((uint32_t)(q >> 32), (uint32_t)q, row_sel);   // this lane's row of 4 columns x 2 rows
         if (TH) v = mp - v;   // TOPHAT: src - open(src) >= 0 in every byte
-        __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, (int)st_off, 0, 0);
+        if (PAIR) {           // two frames behind one descriptor: the band is tested per lane
+            const int row = yp + (lane >> 5);
+            if (row >= yb0 && row < yb1) __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, (int)st_off, 0, 0);
+        } else
+            __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, (int)st_off, 0, 0);
     };
     auto row_pair = [&](int yy) __attribute__((always_inline)) {
         const uint2 e_pa = make_uint2(ea0, eb0);
@@ -684,7 +703,7 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
             __builtin_amdgcn_sched_barrier(0);   // the window update above stays between the read-back and its use
             // unconditional: outside the band the store falls outside dst_rs.  Under a branch the compiler cannot count
             // it, and the wait for the next pair's bytes at the loop top becomes vmcnt(0) -- a wait for this store
-            out_finish(q, mprev);
+            out_finish(q, mprev, y - 2);
             if (y + 1 >= yb0 && y < yb1) {       // wave-uniform; read back and stored while the next row pair computes
                 const uint32_t W = __builtin_amdgcn_perm(out_b, out_a, 0x06020400u);   // [row y: xa, row y+1: xa, y: xb, y+1: xb]
                 asm volatile("ds_write_b16 %0, %1\n\tds_write_b16_d16_hi %0, %1 offset:128" :: "v"(out_wr), "v"(W) : "memory");
@@ -721,9 +740,40 @@ __global__ __launch_bounds__(256) void k_morph_runs2(const uint8_t* __restrict__
         if (PAIRS == 2) row_pair(yy + 2);
     }
     if (WIDE) {   // the last row pair is still in s_out (outside the band if the loop ran past it: dropped by the descriptor)
+        const int npairs = (y_last - y_first) / 2 + 1, pairs_run = (npairs + PAIRS - 1) / PAIRS * PAIRS;
+        const int y_tail = y_first + 2 * (pairs_run - 1) - R;     // output row y of the last pair the loop ran
         unsigned long long q;
         out_issue(q);
-        out_finish(q, mcur);
+        out_finish(q, mcur, y_tail);
+    }
+}
+
+// Waves per workgroup.  The waves of a workgroup share nothing (no barrier, separate LDS slices); the workgroup is only the
+// unit the dispatcher places.  1, 2 and 4 measure the same (-DLT_MORPH_WPB=n).
+#ifndef LT_MORPH_WPB
+#define LT_MORPH_WPB 4
+#endif
+template <class SE, bool DIL, bool WIDE, bool TH>
+__global__ __launch_bounds__(64 * LT_MORPH_WPB) void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                    const uint8_t* __restrict__ minuend, RunsGeom g) {
+    __shared__ uint2 s_chain[LT_MORPH_WPB][4 * PLANE];   // S0, S1, S4, S13
+    __shared__ __attribute__((aligned(8))) uint8_t s_out[WIDE ? LT_MORPH_WPB : 1][WIDE ? 256 : 8];   // [2*col + row] of a row pair
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * LT_MORPH_WPB + wv);   // wave-uniform: keeps the loop scalar
+    if (task >= g.ntasks) return;
+    // Without the bias the pixel patterns 0x00vv are f16 denormals: min/max must not flush them.  FP16 denormals are on
+    // in the kernel descriptor the compiler writes (tests/test_isa_guards.py checks it); set MODE.FP_DENORM[3:2] anyway.
+    if (!LT_MORPH_BIAS) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);
+    // pair tasks first: they are as long as any other task, and at the end of the launch they would run on a half-empty chip
+    const int n_pair = g.ntasks - g.n_normal;
+    if (!WIDE || task >= n_pair) {
+        const int t = task - n_pair;
+        const int strip = t % g.nstrips_normal;
+        const int band = (t / g.nstrips_normal) % g.nbands;
+        const int frame = t / (g.nstrips_normal * g.nbands);
+        morph_task<SE, DIL, WIDE, TH, false>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, strip, band, frame);
+    } else if constexpr (WIDE) {
+        morph_task<SE, DIL, WIDE, TH, true>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, g.nstrips_normal, task % g.nbands, 2 * (task / g.nbands));
     }
 }
 
@@ -745,6 +795,7 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.dpitch = dpitch > 0 ? dpitch : w;
     g.dst_stride = dpitch > 0 ? dst_stride : plane_stride;
     g.nstrips = (w + 127) / 128;
+    g.nframes = n;
     static const bool one_row = [] { const char* e = std::getenv("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
     static const bool narrow = [] { const char* e = std::getenv("LT_MORPH_WIDE"); return e && e[0] == '0'; }();
     const bool wide = !narrow && (w & 3) == 0 && (plane_stride & 3) == 0 && w >= 4 && (g.dpitch & 3) == 0 && (g.dst_stride & 3) == 0 &&
@@ -762,7 +813,9 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
                                         : (dilate ? (minuend ? (const void*)k_morph_runs2<SE, true, false, true> : (const void*)k_morph_runs2<SE, true, false, false>)
                                                   : (const void*)k_morph_runs2<SE, false, false, false>);
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) blocks_per_cu = nb;
+        const int threads = one_row ? 256 : 64 * LT_MORPH_WPB;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, 0) == hipSuccess && nb > 0) blocks_per_cu = nb * threads / 256;
+        if (blocks_per_cu < 1) blocks_per_cu = 1;
     }
     const long long slots = (long long)cus * blocks_per_cu * 4;
     int best_nb = 1;
@@ -795,15 +848,22 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     }
     g.band_rows = (h + best_nb - 1) / best_nb;
     g.nbands = (h + g.band_rows - 1) / g.band_rows;
-    g.ntasks = n * g.nstrips * g.nbands;
+    // the last strip as a PAIR strip (two frames per wave) when it is at most 64 columns wide
+    static const bool no_pair = [] { const char* e = std::getenv("LT_MORPH_PAIR"); return e && e[0] == '0'; }();   // A/B
+    const bool pair_strip = wide && !one_row && !no_pair && w - 128 * (g.nstrips - 1) <= 64 &&
+                            (long long)plane_stride + (long long)h * w < (1ll << 31) && (long long)g.dst_stride + (long long)h * g.dpitch < (1ll << 31);
+    g.nstrips_normal = pair_strip ? g.nstrips - 1 : g.nstrips;
+    g.n_normal = n * g.nstrips_normal * g.nbands;
+    g.ntasks = g.n_normal + (pair_strip ? (n + 1) / 2 * g.nbands : 0);
     dim3 grid((g.ntasks + 3) / 4);
+    const dim3 grid2((g.ntasks + LT_MORPH_WPB - 1) / LT_MORPH_WPB), block2(64 * LT_MORPH_WPB);
     if (one_row) {   // previous formulation (one row per iteration, u16 min/max), kept for A/B measurements
         if (dilate) hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
         else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
     } else {
         static const int extra_lds = [] { const char* e = std::getenv("LT_MORPH_EXTRA_LDS"); return e ? std::atoi(e) : 0; }();   // occupancy experiments
         const bool th = dilate && minuend != nullptr;
-#define LT_LAUNCH(DIL_, WIDE_, TH_) hipLaunchKernelGGL((k_morph_runs2<SE, DIL_, WIDE_, TH_>), grid, dim3(256), extra_lds, s, src, dst, minuend, g)
+#define LT_LAUNCH(DIL_, WIDE_, TH_) hipLaunchKernelGGL((k_morph_runs2<SE, DIL_, WIDE_, TH_>), grid2, block2, extra_lds, s, src, dst, minuend, g)
         if (wide) {
             if (th) LT_LAUNCH(true, true, true);
             else if (dilate) LT_LAUNCH(true, true, false);
