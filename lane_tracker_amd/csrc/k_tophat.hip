@@ -30,6 +30,9 @@
 
 #include "lt_internal.h"
 
+#ifndef LT_DPP_SELECT
+#define LT_DPP_SELECT 0
+#endif
 #ifndef LT_FUSED55
 #define LT_FUSED55 1
 #endif
@@ -370,6 +373,7 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         using SHR = std::integral_constant<int, 0x138>; using ROR = std::integral_constant<int, 0x13c>;
         const uint2 u = make_uint2(dpp(ROL{}, e_pb.x), dpp(ROL{}, e_pb.y));      // lane i <- second entry of lane i + 1
         const uint2 v = make_uint2(dpp(ROR{}, e_pa.x), dpp(ROR{}, e_pa.y));      // lane i <- first entry of lane i - 1
+#if LT_DPP_SELECT
         uint2 sl = make_uint2(dpp(SHL{}, e_pa.x), dpp(SHL{}, e_pa.y)), sr = make_uint2(dpp(SHR{}, e_pb.x), dpp(SHR{}, e_pb.y));
         // The shifts must run with every lane enabled (a DPP source lane that is masked off delivers nothing):
         // the empty statement keeps the compiler from sinking them under the lane == 63 / lane == 0 selects.
@@ -378,6 +382,18 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         const uint2 bp = lane == 0 ? v : sr;
         (S0 + PLANE)[pa] = op3v<DIL>(v, e_pa, an);
         (S0 + PLANE)[pb] = op3v<DIL>(bp, e_pb, u);
+#else
+        // The one-lane shifts take the rotated value as their "old" operand: the lane without a source (63 for the shift
+        // left, 0 for the shift right) keeps it -- exactly the wrap-around entry -- so no select is needed (four
+        // v_cndmask with an SGPR mask in a row are expensive, §5 issue rates).  bp is built on a copy of v (v is still
+        // needed), an on u itself once u has been consumed.
+        auto dpp_old = [](auto ctrl, uint32_t old, uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)x, decltype(ctrl)::value, 0xf, 0xf, false); };
+        const uint2 bp = make_uint2(dpp_old(SHR{}, v.x, e_pb.x), dpp_old(SHR{}, v.y, e_pb.y));
+        const uint2 s1b = op3v<DIL>(bp, e_pb, u);
+        const uint2 an = make_uint2(dpp_old(SHL{}, u.x, e_pa.x), dpp_old(SHL{}, u.y, e_pa.y));
+        (S0 + PLANE)[pa] = op3v<DIL>(v, e_pa, an);
+        (S0 + PLANE)[pb] = s1b;
+#endif
         wave_lds_fence();
     }
     LT_STEP3(1, 2, 3)
