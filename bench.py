@@ -351,8 +351,24 @@ def main():
                 peak_rate = float(vi["peak_wave_insts_per_cycle_per_simd"])
                 lane_ops = float(tj["mask_stage_valu_wave_insts_per_launch"]) * 64.0
                 peak = info.cu_count * 4 * peak_rate * 64.0 * 2.4e9       # CUs x SIMDs x wave-insts/clk x 64 lanes x 2.4 GHz
+                # per kernel: the committed instruction / byte counts over THIS run's kernel times
+                stage_kernels = {"undistort_rows": ["k_undistort_rows"], "warp_split": ["k_warp_split4"],
+                                 "erode_r29": ["SE29, false"], "tophat_r29": ["SE29, true"], "erode_b55": ["SE55, false"],
+                                 "tophat_b55": ["SE55, true"], "threshold": ["k_bilateral_walk", "k_bilateral_tile"],
+                                 "open5": ["k_merge_open5", "k_erode5_bits", "k_dilate5_bits", "k_or4_bits"]}
+                per_kernel = {}
+                for st, keys in stage_kernels.items():
+                    ms = stages.get(st, (0.0, 0))[0] / KS
+                    ks = [v for n, v in tj.get("per_kernel", {}).items() if any(k in n for k in keys)]
+                    if ms <= 0 or not ks:
+                        continue
+                    insts = sum(v["valu_wave_insts"] for v in ks)
+                    byts = sum(v["fetch_bytes"] + v["write_bytes"] for v in ks)
+                    per_kernel[st] = {"ms": round(ms, 4),
+                                      "valu_issue_frac": round(insts / (ms * 1e-3 * 2.4e9 * info.cu_count * 4 * peak_rate), 3),
+                                      "hbm_side_GBs": round(byts / (ms * 1e-3) / 1e9, 1)}
                 from_profile = {
-                    "from_profile": PROFILE_TAG, "source": tj.get("source"),
+                    "from_profile": PROFILE_TAG, "source": tj.get("source"), "per_kernel": per_kernel,
                     "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": round(traffic / float(alg), 2),
                     "fetch_write_calibration": tj.get("calibration"),
                     "valu_issue": {"achieved": round(lane_ops / (mask_ms * 1e-3) / 1e12, 3), "peak": round(peak / 1e12, 3),
