@@ -21,6 +21,11 @@
 //     of the window is free because the instruction has a separate destination -- and A[0] is a
 //     finished output row.
 // Out-of-image taps are neutral (255 for erode, 0 for dilate), as in OpenCV's default border.
+//
+// The above is the first formulation, k_morph_runs (one row per iteration, kept for A/B measurements).  The kernel the
+// library runs is k_morph_runs2 further down: two rows per iteration on v_pk_minimum3_f16 / v_pk_maximum3_f16, a three-step
+// chain (0 -> 1 by DPP, -> 4 -> 13 through LDS), clamped borders instead of neutral fills, aligned dword loads, outputs
+// regrouped into dword stores, pair strips; its comments describe each of these where it happens.
 #include <cstdlib>
 
 #include <cstdio>
@@ -305,14 +310,14 @@ __device__ __forceinline__ uint32_t sub_sat16(uint32_t a, uint32_t b) {   // v_p
 
 // Chain of one row PAIR: entries are uint2 (.x = row yy, .y = row yy+1).  With 3-input ops the
 // chain is shorter than in the one-row kernel: half-widths 0 -> 1 -> 4 -> 13 (55x55) or
-// 0 -> 1 -> 4 -> 7 (29x29), i.e. three dependent LDS round trips.  A window of half-width d is
-// the union of 2 or 3 shifted windows of a chain plane:
-//   from S4  (hw 4):  d = 4 + t  as {p-t, p+t}          for t <= 4,  as {p-t, p, p+t} for t <= 9
+// 0 -> 1 -> 4 (29x29); the first step is register-only (DPP).  A window of half-width d is
+// the union of 2, 3 or 4 shifted windows of a chain plane:
+//   from S4  (hw 4):  d = 4 + t  as {p-t, p+t}          for t <= 4,  as {p-t, p, p+t} for t <= 9,
+//                     d = 14     as {p-10, p-3, p+3, p+10}  (29x29: = window 7 with S4[p -+ 10])
 //   from S13 (hw 13): d = 13 + t as {p-t, p+t}          for t <= 13, as {p-t, p, p+t} for t = 14
-//   from S7  (hw 7):  d = 7 + t  as {p-t, p+t}          for t <= 7
 // Valid entry ranges (55x55, entries 0..117): S1 [1,116], S4 [4,113], S13 [13,104]; the lane's own
 // entries p = 27..90 read S13 at p +- 14 and S4 at p +- 8.  (29x29, entries 0..91): S1 [1,90],
-// S4 [4,87], S7 [7,84]; p = 14..77 reads S7 at p +- 7.
+// S4 [4,87]; p = 14..77 reads S4 at p +- 10.
 // 55x55 only -- which stage of the fused finals (below) delivers half-width slot s, and the stage in which window
 // row pair j (A[j] <- A[j+2], Ha[slot(j+1)], Hb[slot(j)]) has both of its slots
 constexpr int fused_stage_of_slot(int s) { return s <= 3 ? 1 : s <= 7 ? 2 : s <= 11 ? 3 : s <= 14 ? 4 : 5; }
