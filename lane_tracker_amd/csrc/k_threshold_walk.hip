@@ -24,6 +24,7 @@
 // partial bit planes; k_or4_bits merges them.  Window sizes are template parameters (15, 20, 35: process() defaults,
 // second try and the documented settings of tracker_settings.md); any other size, the greenery mask (mask_noise) or a
 // width that is not a multiple of 4 takes k_bilateral_tile2.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -110,8 +111,8 @@ __device__ __forceinline__ void put_lane(uint32_t& m0, uint32_t& m1, uint32_t& m
 struct Task {
     int seg, grp, frame, y0, y1;
 };
-__device__ __forceinline__ bool decode_task(const WalkArgs& a, int len, Task& t) {
-    const int task = xcd_contiguous(blockIdx.x, a.ntasks);
+__device__ __forceinline__ bool decode_task(const WalkArgs& a, int len, Task& t, int blk) {
+    const int task = xcd_contiguous(blk, a.ntasks);
     t.seg = task % a.segs;
     t.grp = (task / a.segs) % a.groups;
     t.frame = task / (a.segs * a.groups);
@@ -125,14 +126,14 @@ __device__ __forceinline__ bool decode_task(const WalkArgs& a, int len, Task& t)
 // ---------------------------------------------------------------------------------------------------------------
 // Vertical pass: lanes = columns (l | l + 64) of a 128-column group, the walk goes down the rows.
 template <int K>
-__global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
+__device__ __forceinline__ void walk_v_task(const WalkArgs& a, int blk) {
     using Cfg = WalkCfg<K>;
     constexpr int WIN = Cfg::WIN, NPRE = Cfg::NPRE, NCH = Cfg::NCH, WSTEP = Cfg::WSTEP;
     extern __shared__ __attribute__((aligned(16))) unsigned char ring[];
     const int lane = threadIdx.x;
     const int h = a.h, w = a.w;
     Task t;
-    if (!decode_task(a, h, t)) return;
+    if (!decode_task(a, h, t, blk)) return;
     const uint8_t* src = a.src + (size_t)t.frame * a.plane_stride;
     unsigned long long* out = a.out + (size_t)t.frame * a.bits_stride;
     const int y0 = t.y0, y1 = t.y1;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) {
 // writes them into the ring every 16 steps with 128-bit stores, and the streams read 128 bits per row and 16 steps.
 // (64 VGPRs for the block: the ring limits a CU to 11 waves at k = 35 anyway, so up to 168 VGPRs cost no occupancy.)
 template <int K>
-__global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) {   // 3 waves per SIMD: <= 168 VGPRs
+__device__ __forceinline__ void walk_h_task(const WalkArgs& a, int task_blk) {
     using Cfg = WalkCfgH<K>;
     constexpr int WIN = Cfg::WIN, NPRE = Cfg::NPRE, NCH = Cfg::NCH, WSTEP = Cfg::WSTEP, PITCH = Cfg::PITCH, E = Cfg::E,
                   OFF = Cfg::OFF;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) {   // 3
     const int lane = threadIdx.x;
     const int h = a.h, w = a.w;
     Task t;
-    if (!decode_task(a, w, t)) return;
+    if (!decode_task(a, w, t, task_blk)) return;
     const uint8_t* src = a.src + (size_t)t.frame * a.plane_stride;
     unsigned long long* out = a.out + (size_t)t.frame * a.bits_stride;
     const int y0 = t.y0;
@@ -436,6 +437,24 @@ __global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) {   // 3
     }
 }
 
+template <int K>
+__global__ __launch_bounds__(64) void k_bilateral_walk_v(WalkArgs a) { walk_v_task<K>(a, blockIdx.x); }
+template <int K>
+__global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) { walk_h_task<K>(a, blockIdx.x); }   // 3 waves per SIMD: <= 168 VGPRs
+
+// Both passes of a plane in ONE launch, their tasks alternating: the horizontal walks leave more than half of the VALU
+// issue slots free while they wait for their staging, the vertical walks are bound by exactly those slots, so waves of
+// the two kinds on one SIMD fill each other's gaps (separate launches on one stream run back to back).
+template <int K>
+__global__ __launch_bounds__(64, 3) void k_bilateral_walk_hv(WalkArgs ah, WalkArgs av) {
+    const int b = blockIdx.x, pairs = min(ah.ntasks, av.ntasks);
+    if (b < 2 * pairs) {
+        if (b & 1) walk_v_task<K>(av, b >> 1);
+        else walk_h_task<K>(ah, b >> 1);
+    } else if (ah.ntasks > pairs) walk_h_task<K>(ah, b - pairs);
+    else walk_v_task<K>(av, b - pairs);
+}
+
 // partial planes -> merged plane (out may alias p0)
 __global__ __launch_bounds__(256) void k_or4_bits(const unsigned long long* __restrict__ p0, const unsigned long long* __restrict__ p1,
                                                  const unsigned long long* __restrict__ p2, const unsigned long long* __restrict__ p3,
@@ -444,9 +463,8 @@ __global__ __launch_bounds__(256) void k_or4_bits(const unsigned long long* __re
     if (i < n) out[i] = p0[i] | p1[i] | p2[i] | p3[i];
 }
 
-template <int K, bool VERT>
-void launch_walk(hipStream_t s, const uint8_t* src, int C, unsigned long long* out, int h, int w, int pitch, size_t plane_stride,
-                 size_t bits_stride, int n) {
+template <bool VERT>
+WalkArgs walk_args(const uint8_t* src, int C, unsigned long long* out, int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n) {
     WalkArgs a;
     a.src = src;
     a.out = out;
@@ -461,6 +479,13 @@ void launch_walk(hipStream_t s, const uint8_t* src, int C, unsigned long long* o
     a.ntasks = a.groups * a.segs * n;
     a.plane_stride = plane_stride;
     a.bits_stride = bits_stride;
+    return a;
+}
+
+template <int K, bool VERT>
+void launch_walk(hipStream_t s, const uint8_t* src, int C, unsigned long long* out, int h, int w, int pitch, size_t plane_stride,
+                 size_t bits_stride, int n) {
+    const WalkArgs a = walk_args<VERT>(src, C, out, h, w, pitch, plane_stride, bits_stride, n);
     if (VERT) hipLaunchKernelGGL((k_bilateral_walk_v<K>), dim3(a.ntasks), dim3(64), WalkCfg<K>::V_LDS, s, a);
     else hipLaunchKernelGGL((k_bilateral_walk_h<K>), dim3(a.ntasks), dim3(64), WalkCfgH<K>::LDS, s, a);
 }
@@ -470,6 +495,14 @@ void launch_walk_both(hipStream_t s, const uint8_t* src, int C, unsigned long lo
                       int pitch, size_t plane_stride, size_t bits_stride, int n, int passes) {
     // `passes` (bit 0 horizontal, bit 1 vertical) is a measurement / debugging switch, LT_WALK_PASSES; default both
     const size_t bytes = ((size_t)(n - 1) * bits_stride + (size_t)h * ((w + 63) / 64)) * 8;
+    static const bool split = [] { const char* e = std::getenv("LT_WALK_SPLIT"); return e && e[0] == '1'; }();   // A/B: one launch per pass
+    if ((passes & 3) == 3 && !split) {
+        const WalkArgs ah = walk_args<false>(src, C, out_h, h, w, pitch, plane_stride, bits_stride, n);
+        const WalkArgs av = walk_args<true>(src, C, out_v, h, w, pitch, plane_stride, bits_stride, n);
+        const int lds = std::max(WalkCfgH<K>::LDS, WalkCfg<K>::V_LDS);
+        hipLaunchKernelGGL((k_bilateral_walk_hv<K>), dim3(ah.ntasks + av.ntasks), dim3(64), lds, s, ah, av);
+        return;
+    }
     if (passes & 1) launch_walk<K, false>(s, src, C, out_h, h, w, pitch, plane_stride, bits_stride, n);
     else (void)hipMemsetAsync(out_h, 0, bytes, s);
     if (passes & 2) launch_walk<K, true>(s, src, C, out_v, h, w, pitch, plane_stride, bits_stride, n);
