@@ -528,18 +528,21 @@ def test_randomised_differential_run():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("switch", ["LT_MORPH_WIDE=0", "LT_XCD_REMAP=0", "LT_STREAM_PRIORITY=normal", "LT_MORPH_ONE_ROW=1",
-                                    "LT_SEARCH_U8=1", "LT_SWS_V1=1", "LT_BAND_V1=1", "LT_WALK_MIN_FRAMES=0", "LT_BILATERAL_TILES=1"])
+                                    "LT_SEARCH_U8=1", "LT_SWS_V1=1", "LT_BAND_V1=1", "LT_WALK_MIN_FRAMES=0", "LT_BILATERAL_TILES=1",
+                                    "LT_MORPH_PAIR=0", "LT_UNDISTORT_UNALIGNED=1", "LT_WALK_MIN_FRAMES=0,LT_WALK_SPLIT=1",
+                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN5_SEPARATE=1"])
 def test_alternative_kernel_paths_keep_parity(switch):
     """Every measurement switch of DESIGN.md selects a path that stays bit-exact: the mask-chain, top-hat operator and
     search parity tests again in a process started with the switch set (the library reads them once)."""
     import subprocess
     import sys
-    name, value = switch.split("=")
     env = dict(os.environ)
-    env[name] = value
+    for item in switch.split(","):
+        name, value = item.split("=")
+        env[name] = value
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
                         "-k", "mask_chain_bit_exact or morph_ellipse_operators or sliding_window_search_vs_reference or "
-                              "band_search_vs_reference or multi_stream"],
+                              "band_search_vs_reference or multi_stream or front_end_bit_exact or odd_slot_ranges"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
