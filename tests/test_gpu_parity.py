@@ -586,3 +586,32 @@ def test_odd_slot_ranges_and_the_batch_paths_of_the_open_stage(nat, cal, oracle,
             assert_same(bev7, oracle.front_end(ref_calib, batch[7]), "bird's-eye RGB of slot 7")
     finally:
         c.close()
+
+
+def test_config5_1080p_batch_masks_bit_exact(nat, oracle):
+    """BASELINE config 5 geometry through the BATCH path: a 1920x1080 camera (6.2 MB frames, 2.25x the undistorted rows)
+    with an odd number of frames -- the pair-interleaved undistorted rows, the aligned-dword undistortion and the pair strips
+    of the top-hats at a second calibration."""
+    from lane_tracker_amd import calib, synth
+    cal = calib.scaled_calibration(1.5)
+    frames = synth.stream_lanes(7, seed=9, cal=cal)
+    assert frames.shape[1:] == (1080, 1920, 3)
+    oc = oracle.make_calib(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0])
+    c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                    device=0, capacity=7)
+    try:
+        c.set_streams(2)
+        c.upload_frames(frames)
+        c.mask_run(7)
+        c.sws_fit_run(7)
+        masks, rec = c.download_masks(7), c.download_records(7)
+        r0, r1 = oracle.warp_source_rows(oc)
+        und = c.download_undistorted(7)
+        for k in range(7):
+            assert_same(und[k], oracle.undistort(oc, frames[k])[r0:r1], f"undistorted rows, frame {k}")
+            want = oracle.mask_from_frame(oc, frames[k])
+            assert_same(masks[k], want, f"mask, frame {k}")
+            o = oracle.sliding_window_search(want)
+            assert bool(rec[k]["detected"]) == bool(o["detected"]) and int(rec[k]["n_left"]) == len(o["left_y"]), k
+    finally:
+        c.close()
