@@ -80,7 +80,7 @@ def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, min(avail, 64))                      # threads actually used
+    cores = max(1, avail)                               # threads actually used: one frame per thread on every visible CPU
     O.frame_sws_fit(oc, frames[0])                      # warms the per-calibration tables
     t0 = time.perf_counter()
     O.frame_sws_fit(oc, frames[0])
@@ -125,7 +125,17 @@ def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
     (_, _, _), t_sws = ms(lambda: (O.sliding_window_search(mask), None, None))
     stages = {"undistort": t_und, "warp": t_warp, "lab_b": t_lab, "tophat_r29": t_th29, "tophat_b55": t_th55,
               "thresholds": t_thr, "open5": t_open, "sliding_window_search+fit": t_sws}
-    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "stage_ms_one_thread": stages,
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {"value": round(n / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": model,
+           "nproc": os.cpu_count(), "stage_ms_one_thread": stages,
+           "note": "naive O(k)-per-pixel oracle written for fidelity, not a tuned CPU path; never quote the GPU/CPU ratio",
            "sample": "%d of the same synthetic frames through oracle/lt_oracle.c (mask + sliding window + fit), one frame "
                      "per thread on %d threads (%d CPUs visible); single-thread %.1f ms/frame = %.1f frames/s, so the "
                      "threaded run is %.1fx one thread" % (n, cores, avail, one * 1e3, 1.0 / one, (n / dt) * one)}
@@ -176,7 +186,7 @@ def launcher(a):
     """--gpus N > 1 and no RANK in the environment: start the N ranks.  This process never touches the GPU."""
     from lane_tracker_amd import distributed
     have = distributed.visible_gpu_count()
-    if a.gpus > have:
+    if a.gpus > have and not (distributed.shares_devices() and have > 0):
         print("bench.py: --gpus %d requested but %d GPU(s) visible; refusing to report a %d-GPU number from fewer devices"
               % (a.gpus, have, a.gpus), file=sys.stderr)
         return 2
@@ -224,9 +234,10 @@ def main():
     NL = len(indices)                                   # frames this rank processes per step
     frames = render_frames(indices)                     # before anything initialises the GPU (forked workers)
 
-    ndev = _native.device_count()
-    if local_rank >= ndev:
-        print("bench.py: rank %d wants GPU %d but %d GPU(s) are visible" % (rank, local_rank, ndev), file=sys.stderr)
+    try:
+        device = distributed.local_device(local_rank)   # LOCAL_RANK (LT_DEVICE_MODULO: test runs that share a GPU, labelled below)
+    except RuntimeError as e:
+        print("bench.py: rank %d: %s" % (rank, e), file=sys.stderr)
         sys.exit(2)
     # Two resident copies of the batch (slots [0, NL) and [NL, 2 NL)) for batches that are not a whole stream anyway: the
     # steps alternate between them, so the tail of step k and the head of step k+1 overlap the way consecutive batches of
@@ -234,7 +245,7 @@ def main():
     # waits in order behind the previous one on the same slots) is reported beside it as single_copy_frames_per_s.
     two_copies = NL <= 1024 and not a.single_copy
     ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
-                          cal["warp_matrices"][0], device=local_rank, capacity=2 * NL if two_copies else NL)
+                          cal["warp_matrices"][0], device=device, capacity=2 * NL if two_copies else NL)
     info = ctx.info()
     t0 = time.perf_counter()
     for c0 in range(0, NL, 256):
@@ -324,6 +335,8 @@ def main():
         rec_all = gathered[0].reshape(world, a.steps, NL)[:, a.steps - 1, :].reshape(-1)   # last timed step of every rank
         assert rec_all[rank * NL:(rank + 1) * NL].tobytes() == my_records.tobytes(), "gathered records differ from the rank's own"
         total_frames = int(sizes.sum())
+        first_frame = indices[0] - rank * NL              # rank-major = frame order: record i of the job is frame first_frame + i
+        assert list(rec_all["frame"]) == list(range(first_frame, first_frame + total_frames)), "gathered records are not rank-major"
     else:
         rec_all, total_frames = my_records, NL
     if gather is not None:            # the collective part is over: release the communicator before rank 0 reports
@@ -390,6 +403,8 @@ def main():
                        "parallelism": "frames sharded x%d, one process per GPU" % world,
                        "collective": ("one RCCL all-gather (lt_gather_records) of %d x 64-byte records per rank at the end of the "
                                       "timed region" % (a.steps * NL)) if gather is not None else "none (single process)",
+                       "gathered_records_checked": int(len(rec_all)) if gather is not None else 0,
+                       "ranks_share_devices": bool(distributed.shares_devices()) if world > 1 else False,
                        "streams_per_gpu": a.streams, "resident_copies_of_the_batch": 2 if two_copies else 1,
                        "detected_fraction": round(float(np.mean(rec_all["detected"])), 4)},
             "roofline": {"bound": "hbm", "kernel": "warp+threshold stage (%d kernels: %s)" % (len(MASK_STAGES), ",".join(MASK_STAGES)),

@@ -25,8 +25,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden; the declarations below are its whole export list
+ * (tests/test_native_abi.py compares `nm -D` with this header). */
+#pragma GCC visibility push(default)
 
-#define LT_ABI_VERSION 1
+/* 2: + lt_gather_*, lt_band_fit_chain_run, lt_calib_*, lt_upload_frame_rows_async & co.; lt_debug_cycles removed;
+ *    lt_last_threshold_path(NULL) returns LT_NO_CONTEXT instead of -1. */
+#define LT_ABI_VERSION 2
 
 typedef enum lt_status {
     LT_OK = 0,
@@ -271,9 +276,12 @@ int  lt_stage_ms(lt_ctx* ctx, float* ms, int32_t* launches, int n);
 const char* lt_stage_name(int stage);
 /* Which kernels evaluated the bilateral thresholds in the context's last 'bilateral' lt_mask_run / lt_filter_run:
  * 1 = the long-walk kernels (window sizes 15 / 20 / 35, no greenery mask, width a multiple of 4), 0 = the tile kernel,
- * -1 = none yet.  Both give identical masks; tests use this to know which one they have exercised. */
+ * -1 = none yet; LT_NO_CONTEXT for a null context (distinct from every status and from "none yet").  Both give
+ * identical masks; tests use this to know which one they have exercised. */
+#define LT_NO_CONTEXT (-2147483647 - 1)
 int  lt_last_threshold_path(lt_ctx* ctx);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LANE_TRACKER_AMD_LIB: load another build of the same library (tools/toolchain_cases.sh compares variant builds)
 LIB_PATH = os.environ.get("LANE_TRACKER_AMD_LIB") or os.path.join(_HERE, "liblane_tracker_amd.so")
 NUM_STAGES = 12
+ABI_VERSION = 2          # LT_ABI_VERSION of include/lane_tracker_amd.h this table was written against
 
 PLANE_R, PLANE_LAB_B, PLANE_TOPHAT_R, PLANE_TOPHAT_B, PLANE_MERGED, PLANE_MASK = range(6)
 
@@ -153,7 +154,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI and this table ever diverge
         fn.restype = res
         fn.argtypes = args
-    if lib.lt_abi_version() != 1:
+    if lib.lt_abi_version() != ABI_VERSION:
         raise NativeError("ABI version mismatch between _native.py and liblane_tracker_amd.so")
     _lib = lib
     return lib

@@ -908,7 +908,7 @@ namespace {
 // union of the 8-connected edge lines and the even-odd interior is, per row, the hull of the edge
 // pixels on that row.  The walk is OpenCV's LineIterator (left end point first, error term
 // dx - 2 dy, one major-axis step per pixel).
-void span_line(int16_t* spans, int bh, int xa, int ya, int xb, int yb) {
+static void span_line(int16_t* spans, int bh, int xa, int ya, int xb, int yb) {
     if (xb < xa) { std::swap(xa, xb); std::swap(ya, yb); }
     const int adx = xb - xa, ady = std::abs(yb - ya), ystep = yb < ya ? -1 : 1;
     const bool tall = ady > adx;
@@ -928,7 +928,7 @@ void span_line(int16_t* spans, int bh, int xa, int ya, int xb, int yb) {
     }
 }
 
-void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int nl, const int32_t* ryx, int nr) {
+static void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int nl, const int32_t* ryx, int nr) {
     for (int y = 0; y < bh; ++y) { spans[2 * y] = 32767; spans[2 * y + 1] = -32768; }
     const int np = nl + nr;
     if (np <= 0) return;
@@ -1597,7 +1597,7 @@ int lt_timer_stop(lt_ctx* c, float* ms) {
 }
 
 int lt_last_threshold_path(lt_ctx* c) {
-    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (!c) { (void)fail(LT_ERR_INVALID, "null context"); return LT_NO_CONTEXT; }
     return c->last_threshold_path;
 }
 

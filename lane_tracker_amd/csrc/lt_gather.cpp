@@ -11,7 +11,7 @@
 // events, runs ONE ncclAllGather (records of all staged steps) and copies the result into page-locked host memory.
 // 4096 frames on 8 GPUs are 32 KiB per rank: latency-bound, so xGMI ring/link bandwidth does not matter here.
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -29,14 +29,21 @@ using namespace lt;
 
 namespace {
 
+// The six RCCL entry points this file uses, declared here (their ABI is NCCL's and stable) so that building the library
+// needs no RCCL headers; the library itself is found at run time.
+struct ncclUniqueId { char internal[128]; };
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;                 // ncclSuccess == 0
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclUint8 = 1;              // ncclDataType_t
 struct Rccl {
     void* handle = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    decltype(&ncclCommCount) CommCount = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
 };
 
 Rccl g_rccl;
@@ -88,6 +95,7 @@ struct lt_gather {
     hipStream_t stream = nullptr;
     std::vector<hipEvent_t> events;     // one per context stream: the gather waits for the staged copies
     int cap = 0;                        // records per rank the buffers hold
+    int agreed_records = -1;            // the n_records every rank was last seen to pass to lt_gather_records
     lt_lane_record *d_send = nullptr, *d_recv = nullptr, *h_recv = nullptr;
     unsigned char *d_blob = nullptr, *h_blob = nullptr;   // small host-to-host all-gathers (barrier, timing)
     size_t blob_cap = 0;
@@ -145,12 +153,14 @@ int lt_gather_init(lt_ctx* ctx, int rank, int world, const char* id_path, int ti
     std::memset(&id, 0, sizeof id);
     if (rank == 0) {
         NCCL_TRY(g_rccl.GetUniqueId(&id));
+        // a fresh file of our own (never through a symlink or onto somebody else's file), then an atomic rename
         const std::string tmp = std::string(id_path) + ".tmp." + std::to_string((long)getpid());
-        FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (!f) return set_error(LT_ERR_STATE, "cannot write %s", tmp.c_str());
-        const size_t w = std::fwrite(&id, 1, sizeof id, f);
-        std::fclose(f);
-        if (w != sizeof id || std::rename(tmp.c_str(), id_path) != 0) {
+        (void)unlink(tmp.c_str());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        if (fd < 0) return set_error(LT_ERR_STATE, "cannot create %s", tmp.c_str());
+        const ssize_t w = write(fd, &id, sizeof id);
+        close(fd);
+        if (w != (ssize_t)sizeof id || std::rename(tmp.c_str(), id_path) != 0) {
             std::remove(tmp.c_str());
             return set_error(LT_ERR_STATE, "cannot publish the RCCL id at %s", id_path);
         }
@@ -159,11 +169,11 @@ int lt_gather_init(lt_ctx* ctx, int rank, int world, const char* id_path, int ti
         for (;;) {
             struct stat st;
             if (stat(id_path, &st) == 0 && (size_t)st.st_size == sizeof id) {
-                FILE* f = std::fopen(id_path, "rb");
-                if (f) {
-                    const size_t r = std::fread(&id, 1, sizeof id, f);
-                    std::fclose(f);
-                    if (r == sizeof id) break;
+                const int fd = open(id_path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+                if (fd >= 0) {
+                    const ssize_t r = read(fd, &id, sizeof id);
+                    close(fd);
+                    if (r == (ssize_t)sizeof id) break;
                 }
             }
             if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > (timeout_s > 0 ? timeout_s : 120))
@@ -220,6 +230,7 @@ int lt_gather_reserve(lt_gather* g, int records_per_rank) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&g->d_recv), n * g->world * sizeof(lt_lane_record)));
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), n * g->world * sizeof(lt_lane_record), hipHostMallocDefault));
     g->cap = records_per_rank;
+    g->agreed_records = -1;
     return LT_OK;
 }
 
@@ -233,6 +244,22 @@ int lt_gather_stage(lt_gather* g, int first_slot, int n, int at) {
 int lt_gather_records(lt_gather* g, int n_records, lt_lane_record* out_host) {
     if (!g || !out_host) return set_error(LT_ERR_INVALID, "null argument");
     if (n_records < 0 || n_records > g->cap) return set_error(LT_ERR_CAPACITY, "%d records exceed the gather's capacity %d", n_records, g->cap);
+    // Every rank must pass the same count and hold the same capacity: a mismatch would hang or misplace records inside
+    // the collective, so it is checked with one small all-gather whenever the count changes (also for 0, which is a
+    // collective no-op only if it is 0 everywhere).
+    if (n_records != g->agreed_records) {
+        const int32_t mine[2] = {n_records, g->cap};
+        std::vector<int32_t> all(2 * (size_t)g->world);
+        int rc = lt_gather_host(g, mine, sizeof mine, all.data());
+        if (rc) return rc;
+        for (int r = 0; r < g->world; ++r)
+            if (all[2 * (size_t)r] != n_records || all[2 * (size_t)r + 1] != g->cap) {
+                g->agreed_records = -1;
+                return set_error(LT_ERR_STATE, "lt_gather_records: rank %d passes %d records (capacity %d), rank %d passes %d (capacity %d)",
+                                 g->rank, n_records, g->cap, r, all[2 * (size_t)r], all[2 * (size_t)r + 1]);
+            }
+        g->agreed_records = n_records;
+    }
     if (n_records == 0) return LT_OK;
     HIP_TRY(hipSetDevice(g->device));
     // the gather stream waits for whatever the context's streams have enqueued so far (the staged copies)

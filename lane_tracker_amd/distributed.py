@@ -138,11 +138,36 @@ def env_rank():
 
 def rendezvous_path():
     """File through which rank 0 publishes the RCCL id.  All ranks of one launch are children of the same launcher
-    process (torch.distributed.run's agent, or `spawn_ranks`), so its pid names the job; LT_GATHER_ID overrides."""
+    process (torch.distributed.run's agent, or `spawn_ranks`), so its pid names the job; the elastic agent's run id
+    and restart count make the name new for every attempt (a restart keeps the agent's pid and port, and a stale id
+    from an attempt that died before its barrier must never be read).  LT_GATHER_ID overrides -- the caller then owns
+    the file's freshness (`spawn_ranks` removes it before it starts the ranks)."""
     p = os.environ.get("LT_GATHER_ID")
     if p:
         return p
-    return os.path.join(tempfile.gettempdir(), "lt_gather_%d_%s.id" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    attempt = "%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    attempt = "".join(ch if ch.isalnum() else "-" for ch in attempt)[:64]
+    return os.path.join(tempfile.gettempdir(), "lt_gather_%d_%s_%s.id" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), attempt))
+
+
+def shares_devices():
+    """LT_DEVICE_MODULO=1: several ranks may share a GPU (local rank r uses GPU r % visible GPUs).  For the tests that
+    run the world-2 code on a one-GPU box (with tests/fake_rccl.c; the real RCCL refuses two ranks on one device);
+    a run made this way is labelled as such by bench.py and is not an N-GPU measurement."""
+    return os.environ.get("LT_DEVICE_MODULO", "0") not in ("", "0")
+
+
+def local_device(local_rank=None):
+    """The GPU of this rank: LOCAL_RANK (one process per GPU).  More ranks than GPUs is an error unless
+    `shares_devices()`."""
+    if local_rank is None:
+        local_rank = env_rank()[1]
+    ndev = _native.device_count()
+    if shares_devices() and ndev > 0:
+        return local_rank % ndev
+    if local_rank >= ndev:
+        raise RuntimeError("local rank %d but only %d GPU(s) visible" % (local_rank, ndev))
+    return local_rank
 
 
 def init_gather(ctx, timeout_s=120):

@@ -12,10 +12,12 @@ from lane_tracker_amd import _native, calib, distributed, synth  # noqa: E402
 
 assert "torch" not in sys.modules
 rank, local, world = distributed.env_rank()
-if local >= _native.device_count():
-    raise SystemExit("rank %d: local rank %d but only %d GPU(s) visible" % (rank, local, _native.device_count()))
+try:
+    local = distributed.local_device(local)          # LOCAL_RANK, or LOCAL_RANK % GPUs under LT_DEVICE_MODULO (fake-RCCL tests)
+except RuntimeError as e:
+    raise SystemExit("rank %d: %s" % (rank, e))
 cal = calib.reference_calibration()
-N = 40
+N = int(os.environ.get("LT_TEST_FRAMES", "40"))
 r = synth.SceneRenderer(cal)
 frames = np.stack([r.render(500 + i)[0] if i % 5 else np.full((720, 1280, 3), 128, np.uint8) for i in range(N)], 0)
 lo, hi = distributed.shard_range(N, rank, world)
@@ -27,6 +29,15 @@ mine = distributed.process_shard(ctx, frames[lo:hi], first_frame=lo, batch=16, g
 dev = distributed.gather_staged(g, N)                                            # HBM slots -> RCCL -> host
 host = distributed.gather_records(mine, N, distributed.RcclTransport(g))         # host records -> RCCL -> host
 assert dev.tobytes() == host.tobytes(), "device-staged and host-staged gathers differ"
+if os.environ.get("LT_TEST_MISMATCH"):
+    # ranks that disagree on the record count must get an error from the agreement check, not a hang inside RCCL
+    try:
+        g.records(3 + rank)
+        raise SystemExit("rank %d: mismatching counts went unnoticed" % rank)
+    except _native.NativeError as e:
+        if rank == 0:
+            print("mismatch reported on rank 0: %s" % e)
+    assert g.records(2).shape == (world, 2)          # and the communicator is still usable afterwards
 times = g.host(np.array([float(rank)], np.float64))
 assert times.reshape(-1).tolist() == [float(i) for i in range(world)]
 if rank == 0:
@@ -34,9 +45,10 @@ if rank == 0:
                           device=local, capacity=N)
     want = distributed.process_shard(ref, frames, first_frame=0, batch=N)
     assert dev.tobytes() == want.tobytes(), "gathered records differ from the single-context run"
-    assert list(dev["frame"]) == list(range(N)) and int(dev["detected"].sum()) == N - N // 5
+    assert list(dev["frame"]) == list(range(N)) and int(dev["detected"].sum()) == sum(1 for i in range(N) if i % 5)
     ref.close()
-    print("distributed gpu ok: %d frames on %d rank(s), torch loaded: %s" % (N, world, "torch" in sys.modules))
+    print("distributed gpu ok: %d frames on %d rank(s), shards %s, torch loaded: %s"
+          % (N, world, distributed.shard_sizes(N, world), "torch" in sys.modules))
 g.barrier()
 g.close()
 ctx.close()

@@ -24,7 +24,23 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_native.exported_symbols()) == declared
-    assert lib.lt_abi_version() == 1
+    assert lib.lt_abi_version() == _native.ABI_VERSION == 2
+    assert int(re.search(r"#define LT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "lane_tracker_amd.h")).read()).group(1)) == 2
+
+
+def test_library_exports_nothing_but_the_header():
+    """Built with -fvisibility=hidden: the dynamic symbol table holds exactly the header's lt_* names (no mangled
+    internals, no unprefixed helpers)."""
+    import shutil
+    import subprocess
+    from lane_tracker_amd import _native
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    defined = sorted({line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-2] in "TtWwBbDdRrVv"})
+    # the HIP fat-binary registration objects are emitted by hipcc, not by this source tree
+    ours = [n for n in defined if not n.startswith("__hip_")]
+    assert ours == _declared_symbols(), sorted(set(ours) ^ set(_declared_symbols()))
+    assert _native.load().lt_last_threshold_path(None) == -2**31           # LT_NO_CONTEXT, not the "none yet" -1
 
 
 def test_struct_layouts():
