@@ -28,7 +28,7 @@ def _run_spawned(world, tmp_path):
 def test_sharded_run_one_rank_over_rccl(tmp_path):
     r = _run_spawned(1, tmp_path)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
-    assert "distributed gpu ok: 40 frames on 1 rank(s), torch loaded: False" in r.stdout
+    assert "distributed gpu ok: 40 frames on 1 rank(s), shards [40], torch loaded: False" in r.stdout
 
 
 def test_sharded_run_under_torch_distributed_run():
