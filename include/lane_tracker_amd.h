@@ -74,7 +74,7 @@ typedef struct lt_lane_record {
     int32_t n_left, n_right;     /* lane-pixel counts */
     uint8_t detected;            /* self.detected_pixels (:438, :496) */
     uint8_t fit_flags;           /* bit0: left fit rank-deficient (<3 distinct y), bit1: right */
-    uint8_t mode;                /* 0 sliding-window, 1 band */
+    uint8_t mode;                /* 0 sliding-window, 1 band, 255 not searched (lt_band_fit_chain_run stopped before it) */
     uint8_t _pad;                /* reserved (the library records how the slot's lane pixels are stored) */
     int32_t frame;               /* caller-defined global frame index */
 } lt_lane_record;
@@ -162,6 +162,17 @@ int  lt_filter_run(lt_ctx* ctx, int first_slot, int n, const lt_filter_params* p
 int  lt_sws_fit_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p);
 /* band_search() + fit_poly() (:449-509); prev_coeffs: n * 6 doubles (last_left_coeffs, last_right_coeffs) */
 int  lt_band_fit_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p, const double* prev_coeffs);
+/* The warm path of ONE stateful stream, chained on the device (band_search :449-500 + fit_poly :502-509 per frame, with
+ * the cross-frame dependence of :474-489 / :1182-1183 kept in HBM): the slots first_slot .. first_slot + n - 1 hold
+ * consecutive frames of one video; the band of the first is drawn around seed_coeffs (6 doubles: last_left_coeffs,
+ * last_right_coeffs) or, if seed_coeffs is NULL, around the fit in the record of slot first_slot - 1; the band of every
+ * later frame around the fit of the frame before it -- what the reference does as long as every frame is found valid.
+ * Validity (check_validity, :561-627) stays on the host: the caller downloads the n records once, keeps those up to the
+ * first frame it rejects and discards the rest (speculation; results never differ from the frame-by-frame calls).  The
+ * walk stops by itself behind a frame without both lanes or with a rank-deficient fit; the slots it did not search get
+ * detected = 0 and mode = 255.  LT_ERR_STATE if 2 * bandwidth + 2 > 64 or the mask width is not a multiple of 4
+ * (use lt_band_fit_run frame by frame then). */
+int  lt_band_fit_chain_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p, const double* seed_coeffs);
 /* tag records with global frame indices first_frame, first_frame+1, ... */
 int  lt_set_frame_base(lt_ctx* ctx, int first_slot, int n, int first_frame);
 

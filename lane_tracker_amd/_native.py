@@ -99,6 +99,7 @@ _SIGNATURES = {
     "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_sws_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams)]),
     "lt_band_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
+    "lt_band_fit_chain_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
     "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "lt_mask_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(FilterParams), _P]),
     "lt_sws_fit_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(SearchParams), _P]),
@@ -477,6 +478,14 @@ class Context:
         sp = sp or search_params()
         prev = np.ascontiguousarray(prev_coeffs, np.float64).reshape(n, 6)
         _check(self.lib.lt_band_fit_run(self._h, first, n, C.byref(sp), prev.ctypes.data))
+
+    def band_fit_chain_run(self, n, seed_coeffs=None, sp=None, first=0):
+        """Band search + fit of slots first .. first+n-1 as consecutive frames of one stream, chained on the device:
+        frame k+1 searches around frame k's fit; the first around `seed_coeffs` (6 doubles) or, if None, around the
+        record of slot first-1.  Records behind a frame the chain could not build on come back with mode 255."""
+        sp = sp or search_params()
+        seed = None if seed_coeffs is None else np.ascontiguousarray(seed_coeffs, np.float64).reshape(6)
+        _check(self.lib.lt_band_fit_chain_run(self._h, first, n, C.byref(sp), None if seed is None else seed.ctypes.data))
 
     # -- single-image operators
     def bilateral_adaptive_threshold(self, img, ksize, C_, mode, true_value, false_value):

@@ -363,8 +363,11 @@ __device__ void extract_windows(const uint8_t* mask, int w, int r0, int r1, cons
     __syncthreads();
 }
 
+// carry (LDS, 8 doubles, optional): the six coefficients of this fit and, in [6], 1.0 when the next frame of a chained band
+// search may build on them (both lanes found, both fits regular) -- k_band_chain2
 __device__ void reduce_and_fit(Moments* mom, const int* distinct, long long* s_mom, int h, int w, int n_left,
-                               int n_right, bool detected, int mode, lt_lane_record* rec, int pix_format = 0) {
+                               int n_right, bool detected, int mode, lt_lane_record* rec, int pix_format = 0,
+                               double* carry = nullptr) {
     // block-reduce the per-thread moments: wave shuffle, then LDS atomics
     for (int i = threadIdx.x; i < 16; i += NT) s_mom[i] = 0;
     __syncthreads();
@@ -392,6 +395,10 @@ __device__ void reduce_and_fit(Moments* mom, const int* distinct, long long* s_m
         r._pad = (uint8_t)pix_format;   // 0: packed (y << 16) | x lists; 1: per-row column masks (k_sws_fit2)
         r.frame = rec->frame;  // keep the caller's tag
         *rec = r;
+        if (carry) {
+            for (int k = 0; k < 3; ++k) { carry[k] = r.left_coeffs[k]; carry[3 + k] = r.right_coeffs[k]; }
+            carry[6] = detected && flags == 0 ? 1.0 : 0.0;
+        }
     }
 }
 
@@ -982,11 +989,11 @@ __global__ __launch_bounds__(NT) void k_band_fit(const uint8_t* __restrict__ mas
 // Per-frame block in the pixel buffer (u32 units): [0] rows per side, [1] first row, [2] 0, [3] 0; then the
 // a of every (side, row) as int32; then, 8-byte aligned, one u64 mask per (side, row).
 template <bool BITS>
-__global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, MaskBits mb, SearchGeom g,
-                                                 const double* __restrict__ prev, BandPrev bp, uint32_t* __restrict__ pix_all,
-                                                 lt_lane_record* __restrict__ recs, int nq) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int frame = blockIdx.x, lane = lane_id();
+__device__ __forceinline__ void band_fit2_frame(unsigned char* smem, const int frame, const uint8_t* __restrict__ masks, size_t mask_stride,
+                                                const MaskBits& mb, const SearchGeom& g, const double* pc,
+                                                uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int nq,
+                                                double* carry) {
+    const int lane = lane_id();
     const int W = g.w, top = g.band_top, nrows = max(g.band_bottom - top, 0), rows_total = 2 * nrows;
     unsigned long long* rowbits = reinterpret_cast<unsigned long long*>(smem);          // rows_total
     int* row_a = reinterpret_cast<int*>(rowbits + rows_total);                          // rows_total
@@ -997,7 +1004,6 @@ __global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ ma
     uint32_t* hdr = pix_all + (size_t)frame * 2 * g.maxpix;
     int32_t* g_a = reinterpret_cast<int32_t*>(hdr + 4);
     unsigned long long* gmask = reinterpret_cast<unsigned long long*>(hdr + band2_mask_offset(nrows));
-    const double* pc = bp.by_value ? bp.c : prev + (size_t)frame * 6;
     const int y0c = g.h / 2, x0c = g.w / 2;
     const double bw = g.bandwidth;
     if (threadIdx.x == 0) { hdr[0] = (uint32_t)nrows; hdr[1] = (uint32_t)top; hdr[2] = 0u; hdr[3] = 0u; }
@@ -1097,7 +1103,54 @@ __global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ ma
     const int distinct[2] = {state[0], state[1]};
     const int nl = state[2], nr = state[3];
     const bool detected = nl != 0 && nr != 0;                        // :491
-    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, nl, nr, detected, 1, recs + frame, 2);
+    reduce_and_fit(mom, distinct, s_mom, g.h, g.w, nl, nr, detected, 1, recs + frame, 2, carry);
+}
+
+template <bool BITS>
+__global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ masks, size_t mask_stride, MaskBits mb, SearchGeom g,
+                                                 const double* __restrict__ prev, BandPrev bp, uint32_t* __restrict__ pix_all,
+                                                 lt_lane_record* __restrict__ recs, int nq) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int frame = blockIdx.x;
+    band_fit2_frame<BITS>(smem, frame, masks, mask_stride, mb, g, bp.by_value ? bp.c : prev + (size_t)frame * 6, pix_all, recs, nq, nullptr);
+}
+
+// k_band_chain2: the warm path of ONE stateful stream (lane_tracker.py:851-872 with last_detection <= n_reset on every
+// frame): frame k+1's band is drawn around frame k's fit (:474-489 read last_left_coeffs / last_right_coeffs, which a valid
+// frame k sets to its own raw fit, :1182-1183).  The frames are sequentially dependent through those six numbers only, so one
+// workgroup walks the n resident masks in order and hands the coefficients on through LDS -- no host round trip, no launch
+// per frame.  Whether frame k was VALID (check_validity, :561-627) is decided on the host afterwards; the host keeps the
+// records up to the first frame it rejects and discards the rest, so this is speculation, never a change of results.  The
+// walk stops by itself at a frame without both lanes or with a rank-deficient fit (nothing can build on it): the records of
+// the remaining slots get detected = 0, mode = 255 ("not searched").
+template <bool BITS>
+__global__ __launch_bounds__(NT) void k_band_chain2(const uint8_t* __restrict__ masks, size_t mask_stride, MaskBits mb, SearchGeom g,
+                                                   const lt_lane_record* __restrict__ seed_rec, BandPrev seed,
+                                                   uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int nq, int n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double carry[8];
+    if (threadIdx.x < 6)
+        carry[threadIdx.x] = seed.by_value ? seed.c[threadIdx.x]
+                                           : (threadIdx.x < 3 ? seed_rec->left_coeffs[threadIdx.x] : seed_rec->right_coeffs[threadIdx.x - 3]);
+    if (threadIdx.x == 6) carry[6] = seed.by_value || (seed_rec->detected && seed_rec->fit_flags == 0) ? 1.0 : 0.0;
+    __syncthreads();
+    int f = 0;
+    for (; f < n && carry[6] != 0.0; ++f) {
+        // the coefficients the frame reads must not change under it: copy them out of the carry slot first
+        __shared__ double pc[6];
+        if (threadIdx.x < 6) pc[threadIdx.x] = carry[threadIdx.x];
+        __syncthreads();
+        band_fit2_frame<BITS>(smem, f, masks, mask_stride, mb, g, pc, pix_all, recs, nq, carry);
+        __syncthreads();
+    }
+    for (int i = f + (int)threadIdx.x; i < n; i += NT) {
+        lt_lane_record r;
+        for (int k = 0; k < 3; ++k) r.left_coeffs[k] = r.right_coeffs[k] = 0.0;
+        r.n_left = r.n_right = 0;
+        r.detected = 0; r.fit_flags = 0; r.mode = 255; r._pad = 0;
+        r.frame = recs[i].frame;
+        recs[i] = r;
+    }
 }
 
 // fit_poly() on an explicit pixel list: moments by all threads, one Cholesky solve
@@ -1163,7 +1216,8 @@ bool sws2_big_lds() {
     return ok;
 }
 bool band2_big_lds() {
-    static const bool ok = allow_big_lds(k_band_fit2<false>) && allow_big_lds(k_band_fit2<true>);
+    static const bool ok = allow_big_lds(k_band_fit2<false>) && allow_big_lds(k_band_fit2<true>) &&
+                           allow_big_lds(k_band_chain2<false>) && allow_big_lds(k_band_chain2<true>);
     return ok;
 }
 
@@ -1247,6 +1301,18 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Ma
         hipLaunchKernelGGL(k_band_fit<true>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, bp, pix, rec);
     else
         hipLaunchKernelGGL(k_band_fit<false>, dim3(n), dim3(NT), lds, s, masks, mask_stride, g, prev, bp, pix, rec);
+}
+
+bool band_chain_supported(const SearchGeom& g, size_t mask_stride) { return band2_eligible(g, mask_stride); }
+
+void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const lt_lane_record* seed_rec,
+                       const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n) {
+    if (n <= 0) return;
+    const int nrows = std::max(g.band_bottom - g.band_top, 0);
+    const size_t lds2 = band2_mom_offset(nrows) + 16 * sizeof(long long);
+    const int nq = (int)((2LL * (long long)g.bandwidth + 2 + 3 + 15) / 16);
+    if (mb.bits) hipLaunchKernelGGL(k_band_chain2<true>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n);
+    else hipLaunchKernelGGL(k_band_chain2<false>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n);
 }
 
 }  // namespace lt

@@ -117,6 +117,11 @@ struct lt_ctx {
     // ordering events of lt_upload_frame_rows_async (a ring: an event is reused long after its waits were enqueued)
     std::vector<hipEvent_t> order_events;
     size_t order_next = 0;
+    // The kernels that READ the camera frames (d_frames): the undistortion of every slice's stream ([0..7]) and the overlay
+    // ([8]).  A stream-ordered upload into slots of a slice waits for these -- not for the tail of the stream, so the rows of
+    // the next frames cross the bus while the rest of the mask chain of the previous ones still runs.
+    hipEvent_t frames_read[9] = {};
+    bool frames_read_set[9] = {};
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stage_timing = false;
@@ -146,6 +151,22 @@ void dev_free(T*& p) {
 int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
+    for (bool& b : c->frames_read_set) b = false;       // every reader enqueued so far is done
+    return LT_OK;
+}
+
+// a kernel reading d_frames has just been enqueued on `st` (idx 8: the overlay, whatever its stream)
+int mark_frames_read(lt_ctx* c, hipStream_t st, bool overlay = false) {
+    int idx = 8;
+    if (!overlay) {
+        idx = 0;
+        for (int i = 0; i < (int)c->streams.size() && i < 8; ++i)
+            if (c->streams[i] == st) idx = i;
+    }
+    if (!c->frames_read[idx] && hipEventCreateWithFlags(&c->frames_read[idx], hipEventDisableTiming) != hipSuccess)
+        return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(c->frames_read[idx], st));
+    c->frames_read_set[idx] = true;
     return LT_OK;
 }
 
@@ -633,6 +654,7 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_xpos);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
+    for (auto e : c->frames_read) if (e) (void)hipEventDestroy(e);
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -762,14 +784,15 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     if (!frames) return fail(LT_ERR_INVALID, "null frames");
     if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
     if ((rc = set_device(c))) return rc;
+    // the copy waits for the kernels that still read these slots' camera rows -- the undistortion launches of the slices'
+    // streams and the overlay (mark_frames_read) -- not for the rest of their mask chains
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
-        hipEvent_t e = next_order_event(c);
-        if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipEventRecord(e, st));
-        HIP_TRY(hipStreamWaitEvent(c->copy, e, 0));
+        for (int i = 0; i < (int)c->streams.size() && i < 8; ++i)
+            if (c->streams[i] == st && c->frames_read_set[i]) HIP_TRY(hipStreamWaitEvent(c->copy, c->frames_read[i], 0));
         return (int)LT_OK;
     });
     if (rc) return rc;
+    if (c->frames_read_set[8]) HIP_TRY(hipStreamWaitEvent(c->copy, c->frames_read[8], 0));
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                              (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->copy));
@@ -1052,7 +1075,7 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
     HIP_TRY(hipGetLastError());
-    return LT_OK;
+    return mark_frames_read(c, c->stream, true);
 }
 
 int lt_overlay_set_font(lt_ctx* c, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
@@ -1318,6 +1341,7 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
         { StageScope t(c, ST_UNDISTORT, st);
           launch_undistort_rows(st, c->d_frames + (size_t)f0 * c->frame_bytes, c->frame_bytes, c->d_uxy, c->d_ufrac,
                                 c->fe, c->d_und, c->und_px, f0, m); }
+        { int mrc = mark_frames_read(c, st); if (mrc) return mrc; }
         { StageScope t(c, ST_WARP_SPLIT, st);
           launch_warp_split(st, c->d_und, c->und_px, f0, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
                             c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
@@ -1417,6 +1441,61 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
     });
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+
+int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p, const double* seed) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!seed && first < 1) return fail(LT_ERR_INVALID, "a chain without seed coefficients continues from the record of slot first - 1");
+    if ((rc = set_device(c))) return rc;
+    if (!c->have_mask) return fail(LT_ERR_STATE, "no mask in the slots: run lt_mask_run or lt_upload_masks first");
+    SearchGeom g;
+    if ((rc = make_search_geom(c, p, true, g))) return rc;
+    if ((rc = ensure_search_buffers(c, g.maxpix, 1))) return rc;
+    g.maxpix = c->maxpix;
+    if (!band_chain_supported(g, c->plane_bytes))
+        return fail(LT_ERR_STATE, "chained band search needs a band of at most 64 columns (2 * bandwidth + 2) and a mask width that is a multiple of 4");
+    if (n == 0) return LT_OK;
+    BandPrev bp;
+    std::memset(&bp, 0, sizeof bp);
+    if (seed) {
+        std::memcpy(bp.c, seed, sizeof bp.c);
+        bp.by_value = 1;
+    }
+    const bool use_bits = masks_have_bits(c, first, n) && band_fit_takes_bits(g, c->plane_bytes);
+    if (!use_bits && (rc = ensure_u8_masks(c, first, n))) return rc;
+    // One workgroup walks the slots in order on the stream of the FIRST slot.  Slots of other slices get there through
+    // events: that stream waits for what their streams hold so far (their masks), and they wait for the chain.
+    hipStream_t st0 = nullptr;
+    int s_lo = 0, s_hi = 0;
+    (void)for_each_slice(c, first, 1, [&](hipStream_t st, int f0, int) { st0 = st; s_lo = f0; return (int)LT_OK; });
+    std::vector<hipStream_t> others;
+    (void)for_each_slice(c, seed ? first : first - 1, seed ? n : n + 1, [&](hipStream_t st, int, int) {
+        if (st != st0) others.push_back(st);
+        return (int)LT_OK;
+    });
+    (void)s_lo; (void)s_hi;
+    for (hipStream_t st : others) {
+        hipEvent_t e = next_order_event(c);
+        if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(e, st));
+        HIP_TRY(hipStreamWaitEvent(st0, e, 0));
+    }
+    const int wpr = (c->calib.warp_w + 63) / 64;
+    {
+        StageScope t(c, ST_BAND_FIT, st0);
+        const MaskBits mb{use_bits ? c->d_bits_open + (size_t)first * c->bits_stride : nullptr, c->bits_stride, wpr};
+        launch_band_chain(st0, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, mb, g, seed ? nullptr : c->d_rec + first - 1, bp,
+                          c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n);
+    }
+    HIP_TRY(hipGetLastError());
+    if (!others.empty()) {
+        hipEvent_t e = next_order_event(c);
+        if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(e, st0));
+        for (hipStream_t st : others) HIP_TRY(hipStreamWaitEvent(st, e, 0));
+    }
     return LT_OK;
 }
 

@@ -468,6 +468,160 @@ class LaneTracker:
                               diagnostics, slot=slot, lazy=lazy)
         return 'bs'
 
+    # ---- the two outcomes of a frame (reference :1142-1159, :1178-1202) ------------------------------------------
+    def _record_failure(self):
+        self.left_fit_coeffs.append(np.array([]))
+        self.right_fit_coeffs.append(np.array([]))
+        self.average_curve_radii.append(-1)
+        if len(self.left_fit_coeffs) > self.n_average:
+            self.left_fit_coeffs.pop(0)
+            self.right_fit_coeffs.pop(0)
+        if len(self.average_curve_radii) > self.n_average:
+            self.average_curve_radii.pop(0)
+        self.last_detection += 1
+
+    def _record_success(self, left_fit_coeffs, right_fit_coeffs, partial):
+        self.left_fit_coeffs.append(left_fit_coeffs)
+        self.right_fit_coeffs.append(right_fit_coeffs)
+        self.last_left_coeffs = left_fit_coeffs
+        self.last_right_coeffs = right_fit_coeffs
+        if len(self.left_fit_coeffs) > self.n_average:
+            self.left_fit_coeffs.pop(0)
+            self.right_fit_coeffs.pop(0)
+        self.last_detection = 0
+        self.success += 1
+        self.left_avg_coeffs = np.average([c for c in self.left_fit_coeffs if c.size != 0], axis=0)
+        self.right_avg_coeffs = np.average([c for c in self.right_fit_coeffs if c.size != 0], axis=0)
+        self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x = self.get_poly_points(
+            self.left_avg_coeffs, self.right_avg_coeffs, partial)
+        self.get_curve_radius()
+        self.get_eccentricity()
+
+    # ---- the chained stream pipeline (reference :851-872, :1064-1128, :1178-1199) ------------
+    chain_searches = True            # False: process_batch searches frame by frame (one record round trip per frame)
+    chain_chunk = 64                 # frames per upload + mask launch inside a window
+
+    def _valid_many(self, LF, RF):
+        """check_validity (:561-627) for m fits at once: the same f64 operations in the same order, element by element,
+        so every entry equals what `check_validity` would have stored in valid_lane_lines."""
+        lim = self.validity_limits
+        ploty, ploty2 = self._plot_rows(1)
+        W = self.warped_size[0]
+
+        def inside_count(Cf):
+            fitx = Cf[:, 0:1] * ploty2[None, :] + Cf[:, 1:2] * ploty[None, :] + Cf[:, 2:3]
+            return np.count_nonzero((fitx <= W - 1) & (fitx >= 0), axis=1)
+        n = np.minimum(inside_count(LF), inside_count(RF))
+        y1 = np.full(len(LF), W - 1, np.int64)
+        y2 = W - (n * 0.35).astype(np.int64)
+        y3 = W - (n * 0.75).astype(np.int64)
+
+        def at(Cf, y):
+            return Cf[:, 0] * (y ** 2) + Cf[:, 1] * y + Cf[:, 2]
+
+        def slope(Cf, y):
+            return 2 * Cf[:, 0] * y + Cf[:, 1]
+        x1, x2, x3 = (np.abs(at(LF, y) - at(RF, y)) for y in (y1, y2, y3))
+        dist_bad = ((x1 < lim['min_dist_y1']) | (x1 > lim['max_dist_y1']) | (x2 < lim['min_dist_y2'])
+                    | (x2 > lim['max_dist_y2']) | (x3 < lim['min_dist_y3']) | (x3 > lim['max_dist_y3']))
+        norm1 = np.abs(slope(LF, y1) - slope(RF, y1))
+        norm2 = np.abs(slope(LF, y3) - slope(RF, y3))
+        return ~dist_bad & ~((norm1 >= lim['thresh']) | (norm2 >= lim['thresh']))
+
+    def _radius_is_ordinary(self, LF, RF):
+        """True where get_curve_radius (:530-549) takes its plain route for both sides: finite values that are not so
+        close to an integer that the exact refit of the pixel lists decides the truncation."""
+        y_eval = self.warped_size[1]
+        ok = np.ones(len(LF), bool)
+        with np.errstate(all='ignore'):
+            for Cf in (LF, RF):
+                a, b = Cf[:, 0] * self.mpph / (self.mppv ** 2), Cf[:, 1] * self.mpph / self.mppv
+                val = ((1 + (2 * a * y_eval * self.mppv + b) ** 2) ** 1.5) / np.absolute(2 * a)
+                ok &= np.isfinite(val) & (val < 2.0 ** 62) & (np.abs(val - np.rint(val)) > 1e-7 * np.maximum(1.0, np.abs(val)))
+        return ok
+
+    def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred):
+        """process_batch's frame loop with the searches chained on the device.  State after every frame, and every
+        attribute at the end, equal those of `_step` frame by frame (tests/test_gpu_tracker.py)."""
+        ctx, n = self._ctx, frames.shape[0]
+        partial = first_try[-1]
+        sws_kw = dict(window_width=first_try[9], window_height=first_try[10], search_range=first_try[11], mu=first_try[12],
+                      no_success_limit=first_try[13], start_slice=first_try[14], ignore_sides=first_try[15],
+                      ignore_bottom=first_try[16], partial=partial)
+        sp_sws = _native.search_params(**sws_kw)
+        sp_band = _native.search_params(bandwidth=first_try[17], ignore_bottom=first_try[16], partial=partial)
+        chunk = max(2, int(self.chain_chunk)) & ~1
+        masked = 0                       # frames [0, masked) have their upload + first-try mask enqueued
+
+        def feed(upto):                  # keep the device supplied with masks ahead of the searches
+            nonlocal masked
+            while masked < min(n, upto):
+                m = min(chunk, n - masked)
+                ctx.upload_frame_rows_async(frames[masked:masked + m], first=masked)
+                ctx.mask_run(m, fp, first=masked)
+                masked += m
+        feed(2 * chunk)
+        if annotate:
+            self._upload_keepalive = ctx.upload_frame_rest(frames)     # beside the mask chain, for the overlay
+        i = 0
+        run = chunk                      # speculation length: doubles while chains hold, falls back after a break
+        while i < n:
+            feed(i + run + chunk)
+            L = min(run, masked - i)
+            mode = 'sws' if self.last_detection > self.n_reset else 'bs'          # :851
+            try:
+                if mode == 'sws':
+                    ctx.sws_fit_run(1, sp_sws, first=i)
+                    if L > 1:
+                        ctx.band_fit_chain_run(L - 1, None, sp_band, first=i + 1)
+                else:
+                    seed = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
+                                           np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
+                    ctx.band_fit_chain_run(L, seed, sp_band, first=i)
+            except _native.NativeError:  # geometry outside the chain kernel's limits: frame by frame
+                L = 0
+            if L == 0:
+                self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
+                           defer=deferred)
+                i += 1
+                continue
+            rec = ctx.download_records(L, first=i)
+            searched = rec["mode"] != 255
+            good = searched & (rec["detected"] != 0) & (rec["fit_flags"] == 0)
+            LF, RF = rec["left_coeffs"], rec["right_coeffs"]
+            g = int(np.argmin(good)) if not good.all() else L          # frames [0, g) were found with regular fits
+            if g:
+                ok = self._valid_many(LF[:g], RF[:g]) & self._radius_is_ordinary(LF[:g], RF[:g])
+                if not ok.all():
+                    g = int(np.argmin(ok))
+            # frames i .. i+g-1: first try valid.  Without annotation only the last n_average of them leave a trace in
+            # the state (histories are that long; every other attribute is overwritten by each success).
+            skip = 0 if annotate else max(0, g - max(int(self.n_average), 1))
+            if skip:
+                self.counter += skip
+                self.success += skip
+            for j in range(skip, g):
+                self.counter += 1
+                self.detected_pixels = True
+                self.valid_lane_lines = True
+                lf, rf = np.array(LF[j], np.float64), np.array(RF[j], np.float64)
+                self._pending = (ctx, i + j, j == 0 and mode == 'sws')
+                self._fit = ("pending", None, lf, rf)
+                self._resident = (frames[i + j], i + j)
+                self._record_success(lf, rf, partial)
+                if annotate:
+                    deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
+                                     self._lane_text()))
+            i += g
+            if g < L and i < n and searched[g]:
+                # this frame's first try failed (or needs the host's exact fit): the ordinary route, second try included
+                self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
+                           defer=deferred)
+                i += 1
+                run = max(8, chunk // 4)
+            elif g == L:
+                run = min(2 * run, 4 * chunk)
+
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,
                 noise_thresh=140, ksize_noise=65, C_noise=10, window_width=30, window_height=40, search_range=20,
@@ -497,8 +651,12 @@ class LaneTracker:
 
           * all frames are uploaded once and the first-try masks (undistort + warp + filter) of the
             whole window are computed ahead in one batched launch -- that stage is stateless;
-          * the search / fit / validity state machine then trails frame by frame: per frame one search
-            kernel on the resident mask and one 64-byte record back to the host;
+          * the searches of consecutive frames are chained on the device (`lt_band_fit_chain_run`): frame
+            k+1's band is drawn around frame k's fit without a host round trip, speculating that frame k
+            will be found valid; the host downloads the records of a whole run once, replays
+            check_validity / the history exactly as `process()` does, and at the first frame that was
+            not detected, not valid (or whose fit was rank deficient) drops the speculative tail, runs that
+            frame the ordinary way (second try included) and starts the next chain behind it;
           * the second-try mask (different filter parameters) is computed lazily, only for a frame
             whose first try failed;
           * lane-pixel lists stay on the device unless somebody reads them.
@@ -526,15 +684,19 @@ class LaneTracker:
         ctx = self._ctx
         self._materialise_pending()      # growing the context below drops what is still on the device
         ctx.reserve(max(n, 1))
-        ctx.upload_frame_rows(frames)        # the camera rows the path reads; the rest only if frames are annotated
-        ctx.mask_run(n, _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],
-                                              k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"]))
-        if annotate:
-            self._upload_keepalive = ctx.upload_frame_rest(frames)     # beside the mask chain, for the overlay
+        fp = _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],
+                                   k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"])
         deferred = []
-        for i in range(n):
-            self._step(frames[i], first_try, k["n_tries"], k["diagnostics"], slot=i, have_mask=True, lazy=True,
-                       annotate=annotate, defer=deferred)
+        if self.chain_searches and not k["diagnostics"]:
+            self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred)
+        else:
+            ctx.upload_frame_rows(frames)        # the camera rows the path reads; the rest only if frames are annotated
+            ctx.mask_run(n, fp)
+            if annotate:
+                self._upload_keepalive = ctx.upload_frame_rest(frames)     # beside the mask chain, for the overlay
+            for i in range(n):
+                self._step(frames[i], first_try, k["n_tries"], k["diagnostics"], slot=i, have_mask=True, lazy=True,
+                           annotate=annotate, defer=deferred)
         self._materialise_pending()      # the attributes describe the last frame, as after process()
         if not annotate:
             return [None] * n
@@ -607,15 +769,7 @@ class LaneTracker:
         if not self.valid_lane_lines:                                   # :1142-1173
             if diagnostics:
                 print("No success after all attempts.")
-            self.left_fit_coeffs.append(np.array([]))
-            self.right_fit_coeffs.append(np.array([]))
-            self.average_curve_radii.append(-1)
-            if len(self.left_fit_coeffs) > self.n_average:
-                self.left_fit_coeffs.pop(0)
-                self.right_fit_coeffs.pop(0)
-            if len(self.average_curve_radii) > self.n_average:
-                self.average_curve_radii.pop(0)
-            self.last_detection += 1
+            self._record_failure()
             if not annotate:
                 return None
             redraw = (self.left_avg_y.size != 0) and (self.last_detection <= self.n_fail)
@@ -626,21 +780,7 @@ class LaneTracker:
             return present(self.draw_lane(img) if redraw else self.print_failure(img))
 
         # success (:1178-1209)
-        self.left_fit_coeffs.append(left_fit_coeffs)
-        self.right_fit_coeffs.append(right_fit_coeffs)
-        self.last_left_coeffs = left_fit_coeffs
-        self.last_right_coeffs = right_fit_coeffs
-        if len(self.left_fit_coeffs) > self.n_average:
-            self.left_fit_coeffs.pop(0)
-            self.right_fit_coeffs.pop(0)
-        self.last_detection = 0
-        self.success += 1
-        self.left_avg_coeffs = np.average([c for c in self.left_fit_coeffs if c.size != 0], axis=0)
-        self.right_avg_coeffs = np.average([c for c in self.right_fit_coeffs if c.size != 0], axis=0)
-        self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x = self.get_poly_points(
-            self.left_avg_coeffs, self.right_avg_coeffs, partial)
-        self.get_curve_radius()
-        self.get_eccentricity()
+        self._record_success(left_fit_coeffs, right_fit_coeffs, partial)
         if not annotate:
             return None
         if defer is not None:

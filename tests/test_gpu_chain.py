@@ -1,0 +1,182 @@
+"""The device-chained band search of one stateful stream (lt_band_fit_chain_run, SURVEY 8(f) N2 / BASELINE config 5) and the
+stream pipeline built on it (LaneTracker.process_batch).  The reference's behaviour here is `process()` frame by frame
+(lane_tracker.py:851-872, 1064-1128, 1178-1199): every comparison below is against exactly that -- the chained run must
+leave the same records, the same lane pixels and the same tracker state, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(cal, n):
+    from lane_tracker_amd import _native
+    return _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                           device=0, capacity=n)
+
+
+def _coeffs(rec):
+    return np.concatenate([rec["left_coeffs"], rec["right_coeffs"]])
+
+
+@pytest.mark.parametrize("streams", [1, 3])
+def test_chain_records_and_pixels_equal_frame_by_frame_band_search(streams):
+    from lane_tracker_amd import _native, calib, synth
+    cal = calib.reference_calibration()
+    n = 24
+    frames = synth.stream_lanes(n, seed=21)
+    sp = _native.search_params()
+    a, b = _ctx(cal, n), _ctx(cal, n)
+    try:
+        for c in (a, b):
+            c.set_streams(streams)                          # 3 streams: the chain crosses slice boundaries
+            c.upload_frames(frames)
+            c.mask_run(n)
+            c.sws_fit_run(1, sp, first=0)
+        # frame by frame: each band search seeded by the previous frame's record through the host
+        for i in range(1, n):
+            prev = _coeffs(a.download_records(1, first=i - 1)[0])
+            a.band_fit_run(1, prev[None, :], sp, first=i)
+        want = a.download_records(n)
+        assert want["detected"].all() and (want["mode"][1:] == 1).all()
+        # chained: one launch, seeded by the record of slot 0
+        b.band_fit_chain_run(n - 1, None, sp, first=1)
+        got = b.download_records(n)
+        assert got.tobytes() == want.tobytes()
+        for slot in (1, n // 2, n - 1):
+            for side in (0, 1):
+                gy, gx = b.download_pixels(slot, side)
+                wy, wx = a.download_pixels(slot, side)
+                assert np.array_equal(gy, wy) and np.array_equal(gx, wx)
+        # seeded by value from the middle of the stream: the same records from there on
+        b.band_fit_chain_run(n - 10, _coeffs(want[9]), sp, first=10)
+        assert b.download_records(n).tobytes() == want.tobytes()
+        with pytest.raises(ValueError):
+            b.band_fit_chain_run(3, None, sp, first=0)       # nothing to continue from
+    finally:
+        a.close()
+        b.close()
+
+
+def test_chain_stops_behind_a_frame_without_lanes_and_marks_the_rest():
+    from lane_tracker_amd import _native, calib, synth
+    cal = calib.reference_calibration()
+    n = 10
+    frames = synth.stream_lanes(n, seed=22).copy()
+    frames[4] = 0                                            # nothing to find in this frame
+    sp = _native.search_params()
+    c = _ctx(cal, n)
+    try:
+        c.upload_frames(frames)
+        c.mask_run(n)
+        c.set_frame_base(n, 700)
+        c.sws_fit_run(1, sp, first=0)
+        c.band_fit_chain_run(n - 1, None, sp, first=1)
+        rec = c.download_records(n)
+        assert rec["detected"][:4].all() and not rec["detected"][4] and rec["mode"][4] == 1
+        assert (rec["mode"][5:] == 255).all() and not rec["detected"][5:].any()
+        assert list(rec["frame"]) == list(range(700, 700 + n))      # the caller's tags survive
+        # a wide band is outside the chain kernel's limits: an error, not a wrong answer
+        with pytest.raises(_native.NativeError):
+            c.band_fit_chain_run(2, _coeffs(rec[0]), _native.search_params(bandwidth=40), first=1)
+    finally:
+        c.close()
+
+
+def _state(lt):
+    return dict(detected=lt.detected_pixels, valid=lt.valid_lane_lines, last_detection=lt.last_detection, success=lt.success,
+                counter=lt.counter, left_avg=None if lt.left_avg_coeffs is None else lt.left_avg_coeffs.tobytes(),
+                right_avg=None if lt.right_avg_coeffs is None else lt.right_avg_coeffs.tobytes(),
+                last_left=None if lt.last_left_coeffs is None else np.asarray(lt.last_left_coeffs).tobytes(),
+                last_right=None if lt.last_right_coeffs is None else np.asarray(lt.last_right_coeffs).tobytes(),
+                hist=[c.tobytes() for c in lt.left_fit_coeffs] + [c.tobytes() for c in lt.right_fit_coeffs],
+                radii=list(lt.average_curve_radii), radius=lt.average_curve_radius, lr=(lt.left_curve_radius, lt.right_curve_radius),
+                ecc=lt.eccentricity, avg_pts=(lt.left_avg_y.tobytes(), lt.left_avg_x.tobytes(), lt.right_avg_y.tobytes(),
+                                              lt.right_avg_x.tobytes()))
+
+
+def _stream_with_failures(n, every, seed, cal=None):
+    """A drifting lane; every `every`-th frame is replaced in turn by noise, a flat grey frame, or black."""
+    from lane_tracker_amd import synth
+    frames = synth.stream_lanes(n, seed=seed, cal=cal).copy()
+    for k, i in enumerate(range(every - 1, n, every)):
+        if k % 3 == 0:
+            frames[i] = synth.frame_uniform(4000 + i, img_size=(frames.shape[2], frames.shape[1]))
+        elif k % 3 == 1:
+            frames[i] = 128
+        else:
+            frames[i] = 0
+    return frames
+
+
+@pytest.mark.parametrize("every,windows,annotate", [(10, (64,), False), (10, (7, 33, 20, 4), False), (4, (64,), False),
+                                                     (10, (40, 24), True), (1000, (64,), False)])
+def test_process_batch_chained_equals_process_frame_by_frame(every, windows, annotate):
+    """Failures every ~10 (and every 4) frames, several window splits, with and without annotation: the state after every
+    window and the annotated frames equal frame-by-frame process()."""
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    n = sum(windows)
+    frames = _stream_with_failures(n, every, seed=31)
+    seq, bat = LaneTracker(**cal), LaneTracker(**cal)
+    try:
+        assert bat.chain_searches
+        lo = 0
+        for w in windows:
+            outs_seq = [seq.process(f) for f in frames[lo:lo + w]]
+            outs = bat.process_batch(frames[lo:lo + w], annotate=annotate)
+            assert _state(bat) == _state(seq), (lo, w)
+            assert np.array_equal(bat.left_x, seq.left_x) and np.array_equal(bat.left_y, seq.left_y)
+            assert np.array_equal(bat.right_x, seq.right_x) and np.array_equal(bat.right_y, seq.right_y)
+            assert bat.left_window_centroids == seq.left_window_centroids
+            if annotate:
+                for k, (g, s) in enumerate(zip(outs, outs_seq)):
+                    assert np.array_equal(g, s), (lo, k)
+            lo += w
+        if every < 100:
+            assert 0 < bat.success < bat.counter == n        # the stream really had failures and recoveries
+        else:
+            assert bat.success == n
+    finally:
+        seq.close()
+        bat.close()
+
+
+def test_process_batch_chained_equals_unchained_per_frame_state():
+    """Frame-by-frame state: windows of one frame through the chained driver against the unchained driver on a stream with
+    failures (every state of the machine is visited: sws start, band, one-off failure, reset to sws after n_reset misses)."""
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    frames = _stream_with_failures(48, 6, seed=33)
+    frames[20:27] = 0                                        # a long outage: falls back to sliding windows (:851)
+    a, b = LaneTracker(**cal), LaneTracker(**cal)
+    b.chain_searches = False
+    try:
+        for i in range(0, 48, 3):
+            a.process_batch(frames[i:i + 3], annotate=False)
+            b.process_batch(frames[i:i + 3], annotate=False)
+            assert _state(a) == _state(b), i
+        assert a.last_detection == 0 and a.success < a.counter
+    finally:
+        a.close()
+        b.close()
+
+
+def test_config5_1080p_stream_chained():
+    """BASELINE config 5 through the chained pipeline: 1920x1080 camera, band-search warm start, validity on the host."""
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.scaled_calibration(1.5)
+    frames = _stream_with_failures(30, 9, seed=35, cal=cal)
+    seq, bat = LaneTracker(**cal), LaneTracker(**cal)
+    try:
+        for f in frames:
+            seq.process(f)
+        bat.process_batch(frames, annotate=False)
+        assert _state(bat) == _state(seq)
+        assert np.array_equal(bat.left_x, seq.left_x) and np.array_equal(bat.right_y, seq.right_y)
+        assert bat.success >= 24
+    finally:
+        seq.close()
+        bat.close()
