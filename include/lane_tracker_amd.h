@@ -167,12 +167,18 @@ int  lt_band_fit_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params*
  * consecutive frames of one video; the band of the first is drawn around seed_coeffs (6 doubles: last_left_coeffs,
  * last_right_coeffs) or, if seed_coeffs is NULL, around the fit in the record of slot first_slot - 1; the band of every
  * later frame around the fit of the frame before it -- what the reference does as long as every frame is found valid.
- * Validity (check_validity, :561-627) stays on the host: the caller downloads the n records once, keeps those up to the
+ * Validity (check_validity, :561-627) stays on the host: the caller collects the n records once, keeps those up to the
  * first frame it rejects and discards the rest (speculation; results never differ from the frame-by-frame calls).  The
  * walk stops by itself behind a frame without both lanes or with a rank-deficient fit; the slots it did not search get
  * detected = 0 and mode = 255.  LT_ERR_STATE if 2 * bandwidth + 2 > 64 or the mask width is not a multiple of 4
- * (use lt_band_fit_run frame by frame then). */
+ * (use lt_band_fit_run frame by frame then).
+ * The chain is one workgroup: it runs on a stream of its own behind the work already enqueued for its slots, beside the
+ * mask chains of later slots, and leaves its records (with a NULL seed also the seed record of slot first_slot - 1) in
+ * page-locked host memory.  lt_band_fit_chain_collect copies records [first_slot, first_slot + n) of the most recent
+ * chain covering that range to `out`, waiting for that chain only -- not for the device; every lt_download_* / lt_sync
+ * also waits for all chains. */
 int  lt_band_fit_chain_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p, const double* seed_coeffs);
+int  lt_band_fit_chain_collect(lt_ctx* ctx, int first_slot, int n, lt_lane_record* out);
 /* tag records with global frame indices first_frame, first_frame+1, ... */
 int  lt_set_frame_base(lt_ctx* ctx, int first_slot, int n, int first_frame);
 

@@ -100,6 +100,7 @@ _SIGNATURES = {
     "lt_sws_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams)]),
     "lt_band_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
     "lt_band_fit_chain_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
+    "lt_band_fit_chain_collect": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "lt_mask_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(FilterParams), _P]),
     "lt_sws_fit_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(SearchParams), _P]),
@@ -486,6 +487,12 @@ class Context:
         sp = sp or search_params()
         seed = None if seed_coeffs is None else np.ascontiguousarray(seed_coeffs, np.float64).reshape(6)
         _check(self.lib.lt_band_fit_chain_run(self._h, first, n, C.byref(sp), None if seed is None else seed.ctypes.data))
+
+    def band_fit_chain_collect(self, n, first=0):
+        """Records of slots first .. first+n-1 as the most recent chain covering them left them; waits for that chain only."""
+        out = np.zeros(n, RECORD_DTYPE)
+        _check(self.lib.lt_band_fit_chain_collect(self._h, first, n, out.ctypes.data))
+        return out
 
     # -- single-image operators
     def bilateral_adaptive_threshold(self, img, ksize, C_, mode, true_value, false_value):

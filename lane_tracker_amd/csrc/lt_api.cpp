@@ -122,6 +122,18 @@ struct lt_ctx {
     // the next frames cross the bus while the rest of the mask chain of the previous ones still runs.
     hipEvent_t frames_read[9] = {};
     bool frames_read_set[9] = {};
+    // The chained band search of a stream (lt_band_fit_chain_run) is one workgroup walking many frames: it runs on a stream
+    // of its own, beside the mask chains of later frames on the slots' streams.  A chain leaves its records in page-locked
+    // host memory behind an event (lt_band_fit_chain_collect waits for that event only, not for the device).  Work on the
+    // slots' streams that touches slots of a chain still in flight waits for it (for_each_slice).
+    hipStream_t search = nullptr;
+    struct ChainTicket { int first, n; hipEvent_t done; };
+    std::vector<ChainTicket> chains;          // not yet collected, oldest first
+    std::vector<hipEvent_t> chain_event_pool;
+    lt_lane_record* h_rec_stage = nullptr;    // capacity records
+    int h_rec_stage_cap = 0;
+    int chain_lo = 0, chain_hi = 0;           // slots touched by chains enqueued since the last full synchronisation
+    hipEvent_t chain_tail = nullptr;          // end of the most recent chain
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stage_timing = false;
@@ -151,7 +163,9 @@ void dev_free(T*& p) {
 int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
+    if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
     for (bool& b : c->frames_read_set) b = false;       // every reader enqueued so far is done
+    c->chain_lo = c->chain_hi = 0;                      // and every chain
     return LT_OK;
 }
 
@@ -181,6 +195,8 @@ int for_each_slice(lt_ctx* c, int first, int n, F fn) {
         const int lo = (int)((long long)c->capacity * si / k) & ~1, hi = si + 1 == k ? c->capacity : (int)((long long)c->capacity * (si + 1) / k) & ~1;
         const int a = std::max(first, lo), b = std::min(first + n, hi);
         if (b <= a) continue;
+        if (c->chain_hi > c->chain_lo && a < c->chain_hi && b > c->chain_lo && c->chain_tail)
+            HIP_TRY(hipStreamWaitEvent(c->streams[si], c->chain_tail, 0));   // a chain in flight reads / writes these slots
         int rc = fn(c->streams[si], a, b - a);
         if (rc) return rc;
     }
@@ -655,6 +671,10 @@ void lt_destroy(lt_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
     for (auto e : c->frames_read) if (e) (void)hipEventDestroy(e);
+    for (auto& t : c->chains) (void)hipEventDestroy(t.done);
+    for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
+    if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
+    if (c->search) (void)hipStreamDestroy(c->search);
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1465,37 +1485,66 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     }
     const bool use_bits = masks_have_bits(c, first, n) && band_fit_takes_bits(g, c->plane_bytes);
     if (!use_bits && (rc = ensure_u8_masks(c, first, n))) return rc;
-    // One workgroup walks the slots in order on the stream of the FIRST slot.  Slots of other slices get there through
-    // events: that stream waits for what their streams hold so far (their masks), and they wait for the chain.
-    hipStream_t st0 = nullptr;
-    int s_lo = 0, s_hi = 0;
-    (void)for_each_slice(c, first, 1, [&](hipStream_t st, int f0, int) { st0 = st; s_lo = f0; return (int)LT_OK; });
-    std::vector<hipStream_t> others;
-    (void)for_each_slice(c, seed ? first : first - 1, seed ? n : n + 1, [&](hipStream_t st, int, int) {
-        if (st != st0) others.push_back(st);
-        return (int)LT_OK;
-    });
-    (void)s_lo; (void)s_hi;
-    for (hipStream_t st : others) {
+    // The chain runs on the context's search stream, behind whatever the slots' streams hold so far (the masks of these
+    // slots, the search that wrote the seed record); those streams do not wait for it -- the mask chains of later frames run
+    // beside it -- unless they touch its slots (for_each_slice).
+    if (!c->search) HIP_TRY(create_compute_stream(&c->search));
+    const int lo = seed ? first : first - 1, cnt = seed ? n : n + 1;     // with a device seed the seed record is collected too
+    rc = for_each_slice(c, lo, cnt, [&](hipStream_t st, int, int) {
         hipEvent_t e = next_order_event(c);
         if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
         HIP_TRY(hipEventRecord(e, st));
-        HIP_TRY(hipStreamWaitEvent(st0, e, 0));
+        HIP_TRY(hipStreamWaitEvent(c->search, e, 0));
+        return (int)LT_OK;
+    });
+    if (rc) return rc;
+    if (c->h_rec_stage_cap < c->capacity) {
+        HIP_TRY(hipStreamSynchronize(c->search));
+        if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
+        c->h_rec_stage = nullptr;
+        c->h_rec_stage_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_rec_stage), (size_t)c->capacity * sizeof(lt_lane_record), hipHostMallocDefault));
+        c->h_rec_stage_cap = c->capacity;
     }
     const int wpr = (c->calib.warp_w + 63) / 64;
     {
-        StageScope t(c, ST_BAND_FIT, st0);
+        StageScope t(c, ST_BAND_FIT, c->search);
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)first * c->bits_stride : nullptr, c->bits_stride, wpr};
-        launch_band_chain(st0, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, mb, g, seed ? nullptr : c->d_rec + first - 1, bp,
-                          c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n);
+        launch_band_chain(c->search, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, mb, g, seed ? nullptr : c->d_rec + first - 1,
+                          bp, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n);
     }
     HIP_TRY(hipGetLastError());
-    if (!others.empty()) {
-        hipEvent_t e = next_order_event(c);
-        if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipEventRecord(e, st0));
-        for (hipStream_t st : others) HIP_TRY(hipStreamWaitEvent(st, e, 0));
+    HIP_TRY(hipMemcpyAsync(c->h_rec_stage + lo, c->d_rec + lo, (size_t)cnt * sizeof(lt_lane_record), hipMemcpyDeviceToHost, c->search));
+    hipEvent_t done = nullptr;
+    if (!c->chain_event_pool.empty()) { done = c->chain_event_pool.back(); c->chain_event_pool.pop_back(); }
+    else if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(done, c->search));
+    while (c->chains.size() >= 32) {            // tickets nobody collected: the oldest goes (its event is long done or superseded)
+        c->chain_event_pool.push_back(c->chains.front().done);
+        c->chains.erase(c->chains.begin());
     }
+    c->chains.push_back({lo, cnt, done});
+    c->chain_tail = done;
+    if (c->chain_hi <= c->chain_lo) { c->chain_lo = lo; c->chain_hi = lo + cnt; }
+    else { c->chain_lo = std::min(c->chain_lo, lo); c->chain_hi = std::max(c->chain_hi, lo + cnt); }
+    return LT_OK;
+}
+
+int lt_band_fit_chain_collect(lt_ctx* c, int first, int n, lt_lane_record* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (n == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    // the most recent chain that covers the range decides (an older, superseded chain over the same slots is dropped)
+    int hit = -1;
+    for (int i = (int)c->chains.size() - 1; i >= 0; --i)
+        if (c->chains[(size_t)i].first <= first && first + n <= c->chains[(size_t)i].first + c->chains[(size_t)i].n) { hit = i; break; }
+    if (hit < 0) return fail(LT_ERR_STATE, "no chained search covers slots [%d, %d)", first, first + n);
+    HIP_TRY(hipEventSynchronize(c->chains[(size_t)hit].done));
+    std::memcpy(out, c->h_rec_stage + first, (size_t)n * sizeof(lt_lane_record));
+    for (int i = 0; i <= hit; ++i) c->chain_event_pool.push_back(c->chains[(size_t)i].done);   // this ticket and everything older
+    c->chains.erase(c->chains.begin(), c->chains.begin() + hit + 1);
     return LT_OK;
 }
 

@@ -528,18 +528,6 @@ class LaneTracker:
         norm2 = np.abs(slope(LF, y3) - slope(RF, y3))
         return ~dist_bad & ~((norm1 >= lim['thresh']) | (norm2 >= lim['thresh']))
 
-    def _radius_is_ordinary(self, LF, RF):
-        """True where get_curve_radius (:530-549) takes its plain route for both sides: finite values that are not so
-        close to an integer that the exact refit of the pixel lists decides the truncation."""
-        y_eval = self.warped_size[1]
-        ok = np.ones(len(LF), bool)
-        with np.errstate(all='ignore'):
-            for Cf in (LF, RF):
-                a, b = Cf[:, 0] * self.mpph / (self.mppv ** 2), Cf[:, 1] * self.mpph / self.mppv
-                val = ((1 + (2 * a * y_eval * self.mppv + b) ** 2) ** 1.5) / np.absolute(2 * a)
-                ok &= np.isfinite(val) & (val < 2.0 ** 62) & (np.abs(val - np.rint(val)) > 1e-7 * np.maximum(1.0, np.abs(val)))
-        return ok
-
     def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred):
         """process_batch's frame loop with the searches chained on the device.  State after every frame, and every
         attribute at the end, equal those of `_step` frame by frame (tests/test_gpu_tracker.py)."""
@@ -563,39 +551,62 @@ class LaneTracker:
         feed(2 * chunk)
         if annotate:
             self._upload_keepalive = ctx.upload_frame_rest(frames)     # beside the mask chain, for the overlay
-        i = 0
         run = chunk                      # speculation length: doubles while chains hold, falls back after a break
-        while i < n:
-            feed(i + run + chunk)
-            L = min(run, masked - i)
+
+        def launch(at):
+            """Enqueue a chain at frame `at` from the tracker's state (host seed, or a sliding-window search of `at` and a
+            chain behind it).  Returns (first, length, search mode of the first frame) or None (frame by frame)."""
+            feed(at + run + chunk)
+            L = min(run, masked - at)
             mode = 'sws' if self.last_detection > self.n_reset else 'bs'          # :851
             try:
                 if mode == 'sws':
-                    ctx.sws_fit_run(1, sp_sws, first=i)
-                    if L > 1:
-                        ctx.band_fit_chain_run(L - 1, None, sp_band, first=i + 1)
+                    if L < 2:
+                        return None
+                    ctx.sws_fit_run(1, sp_sws, first=at)
+                    ctx.band_fit_chain_run(L - 1, None, sp_band, first=at + 1)
                 else:
                     seed = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
                                            np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
-                    ctx.band_fit_chain_run(L, seed, sp_band, first=i)
-            except _native.NativeError:  # geometry outside the chain kernel's limits: frame by frame
-                L = 0
-            if L == 0:
+                    ctx.band_fit_chain_run(L, seed, sp_band, first=at)
+            except _native.NativeError:  # geometry outside the chain kernel's limits
+                return None
+            return at, L, mode
+
+        def launch_behind(prev):
+            """Speculate further: the chain continues on the device from the last record of `prev` (not yet checked)."""
+            at = prev[0] + prev[1]
+            if at >= n:
+                return None
+            feed(at + run + chunk)
+            L = min(run, masked - at)
+            try:
+                ctx.band_fit_chain_run(L, None, sp_band, first=at)
+            except _native.NativeError:
+                return None
+            return at, L, 'bs'
+
+        i, cur = 0, None
+        while i < n:
+            if cur is None:
+                cur = launch(i)
+            if cur is None:
                 self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
                            defer=deferred)
                 i += 1
                 continue
-            rec = ctx.download_records(L, first=i)
-            searched = rec["mode"] != 255
-            good = searched & (rec["detected"] != 0) & (rec["fit_flags"] == 0)
+            nxt = launch_behind(cur)     # in flight while the host checks `cur`
+            first, L, mode = cur
+            rec = ctx.band_fit_chain_collect(L, first=first)
+            good = (rec["mode"] != 255) & (rec["detected"] != 0) & (rec["fit_flags"] == 0)
             LF, RF = rec["left_coeffs"], rec["right_coeffs"]
-            g = int(np.argmin(good)) if not good.all() else L          # frames [0, g) were found with regular fits
+            g = L if good.all() else int(np.argmin(good))              # frames [0, g) were found, with regular fits
             if g:
-                ok = self._valid_many(LF[:g], RF[:g]) & self._radius_is_ordinary(LF[:g], RF[:g])
+                ok = self._valid_many(LF[:g], RF[:g])
                 if not ok.all():
                     g = int(np.argmin(ok))
-            # frames i .. i+g-1: first try valid.  Without annotation only the last n_average of them leave a trace in
-            # the state (histories are that long; every other attribute is overwritten by each success).
+            # frames first .. first+g-1: first try valid.  Without annotation only the last n_average of them leave a
+            # trace in the state (histories are that long; every other attribute is overwritten by each success).
             skip = 0 if annotate else max(0, g - max(int(self.n_average), 1))
             if skip:
                 self.counter += skip
@@ -605,22 +616,25 @@ class LaneTracker:
                 self.detected_pixels = True
                 self.valid_lane_lines = True
                 lf, rf = np.array(LF[j], np.float64), np.array(RF[j], np.float64)
-                self._pending = (ctx, i + j, j == 0 and mode == 'sws')
+                self._pending = (ctx, first + j, j == 0 and mode == 'sws')
                 self._fit = ("pending", None, lf, rf)
-                self._resident = (frames[i + j], i + j)
+                self._resident = (frames[first + j], first + j)
                 self._record_success(lf, rf, partial)
                 if annotate:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
                                      self._lane_text()))
-            i += g
-            if g < L and i < n and searched[g]:
-                # this frame's first try failed (or needs the host's exact fit): the ordinary route, second try included
+            i = first + g
+            if g == L:
+                cur = nxt                # its seed -- the last record of `cur` -- was a valid frame: the speculation holds
+                run = min(2 * run, 4 * chunk)
+            else:
+                # frame i: first try failed (or needs the host's exact fit): the ordinary route, second try included;
+                # whatever was chained behind it is dropped
                 self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
                            defer=deferred)
                 i += 1
+                cur = None
                 run = max(8, chunk // 4)
-            elif g == L:
-                run = min(2 * run, 4 * chunk)
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,

@@ -157,7 +157,7 @@ def test_process_batch_chained_equals_unchained_per_frame_state():
             a.process_batch(frames[i:i + 3], annotate=False)
             b.process_batch(frames[i:i + 3], annotate=False)
             assert _state(a) == _state(b), i
-        assert a.last_detection == 0 and a.success < a.counter
+        assert 0 < a.success < a.counter and a.last_detection <= 1
     finally:
         a.close()
         b.close()
