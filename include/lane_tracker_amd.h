@@ -179,6 +179,9 @@ int  lt_band_fit_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params*
  * also waits for all chains. */
 int  lt_band_fit_chain_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p, const double* seed_coeffs);
 int  lt_band_fit_chain_collect(lt_ctx* ctx, int first_slot, int n, lt_lane_record* out);
+/* The caller has rejected a frame: every chain enqueued so far stops at its next frame (the slots it has not searched
+ * get mode 255) instead of finishing its speculation.  Chains enqueued afterwards are not affected. */
+int  lt_band_fit_chain_cancel(lt_ctx* ctx);
 /* tag records with global frame indices first_frame, first_frame+1, ... */
 int  lt_set_frame_base(lt_ctx* ctx, int first_slot, int n, int first_frame);
 

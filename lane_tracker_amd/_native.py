@@ -101,6 +101,7 @@ _SIGNATURES = {
     "lt_band_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
     "lt_band_fit_chain_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
     "lt_band_fit_chain_collect": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_band_fit_chain_cancel": (C.c_int, [_P]),
     "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "lt_mask_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(FilterParams), _P]),
     "lt_sws_fit_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(SearchParams), _P]),
@@ -487,6 +488,10 @@ class Context:
         sp = sp or search_params()
         seed = None if seed_coeffs is None else np.ascontiguousarray(seed_coeffs, np.float64).reshape(6)
         _check(self.lib.lt_band_fit_chain_run(self._h, first, n, C.byref(sp), None if seed is None else seed.ctypes.data))
+
+    def band_fit_chain_cancel(self):
+        """Chains enqueued so far stop at their next frame (their speculation has been rejected)."""
+        _check(self.lib.lt_band_fit_chain_cancel(self._h))
 
     def band_fit_chain_collect(self, n, first=0):
         """Records of slots first .. first+n-1 as the most recent chain covering them left them; waits for that chain only."""

@@ -1126,9 +1126,11 @@ __global__ __launch_bounds__(NT) void k_band_fit2(const uint8_t* __restrict__ ma
 template <bool BITS>
 __global__ __launch_bounds__(NT) void k_band_chain2(const uint8_t* __restrict__ masks, size_t mask_stride, MaskBits mb, SearchGeom g,
                                                    const lt_lane_record* __restrict__ seed_rec, BandPrev seed,
-                                                   uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int nq, int n) {
+                                                   uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int nq, int n,
+                                                   const int* cancel_epoch, int my_epoch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double carry[8];
+    __shared__ int s_stop;
     if (threadIdx.x < 6)
         carry[threadIdx.x] = seed.by_value ? seed.c[threadIdx.x]
                                            : (threadIdx.x < 3 ? seed_rec->left_coeffs[threadIdx.x] : seed_rec->right_coeffs[threadIdx.x - 3]);
@@ -1139,7 +1141,10 @@ __global__ __launch_bounds__(NT) void k_band_chain2(const uint8_t* __restrict__ 
         // the coefficients the frame reads must not change under it: copy them out of the carry slot first
         __shared__ double pc[6];
         if (threadIdx.x < 6) pc[threadIdx.x] = carry[threadIdx.x];
+        // the host gave up on this speculation (lt_band_fit_chain_cancel: page-locked host word, read once per frame)
+        if (threadIdx.x == 6) s_stop = __atomic_load_n(cancel_epoch, __ATOMIC_RELAXED) > my_epoch ? 1 : 0;
         __syncthreads();
+        if (s_stop) break;
         band_fit2_frame<BITS>(smem, f, masks, mask_stride, mb, g, pc, pix_all, recs, nq, carry);
         __syncthreads();
     }
@@ -1306,13 +1311,13 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Ma
 bool band_chain_supported(const SearchGeom& g, size_t mask_stride) { return band2_eligible(g, mask_stride); }
 
 void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const lt_lane_record* seed_rec,
-                       const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n) {
+                       const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n, const int* cancel_epoch, int my_epoch) {
     if (n <= 0) return;
     const int nrows = std::max(g.band_bottom - g.band_top, 0);
     const size_t lds2 = band2_mom_offset(nrows) + 16 * sizeof(long long);
     const int nq = (int)((2LL * (long long)g.bandwidth + 2 + 3 + 15) / 16);
-    if (mb.bits) hipLaunchKernelGGL(k_band_chain2<true>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n);
-    else hipLaunchKernelGGL(k_band_chain2<false>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n);
+    if (mb.bits) hipLaunchKernelGGL(k_band_chain2<true>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);
+    else hipLaunchKernelGGL(k_band_chain2<false>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);
 }
 
 }  // namespace lt

@@ -126,10 +126,17 @@ struct lt_ctx {
     // of its own, beside the mask chains of later frames on the slots' streams.  A chain leaves its records in page-locked
     // host memory behind an event (lt_band_fit_chain_collect waits for that event only, not for the device).  Work on the
     // slots' streams that touches slots of a chain still in flight waits for it (for_each_slice).
+    // what the slots' streams have written since the last full synchronisation, by slot range (masks, records): a chain
+    // waits for the entries that touch its slots instead of for the tails of those streams
+    struct Written { int lo, hi; hipEvent_t ev; };
+    Written written[32] = {};
+    unsigned written_count = 0;               // entries since the last full synchronisation (> 32: the ring has wrapped)
     hipStream_t search = nullptr;
     struct ChainTicket { int first, n; hipEvent_t done; };
     std::vector<ChainTicket> chains;          // not yet collected, oldest first
     std::vector<hipEvent_t> chain_event_pool;
+    int* h_cancel = nullptr;                  // page-locked, device-visible: chains launched with an older epoch stop at their next frame
+    int* d_cancel = nullptr;                  // its device address
     lt_lane_record* h_rec_stage = nullptr;    // capacity records
     int h_rec_stage_cap = 0;
     int chain_lo = 0, chain_hi = 0;           // slots touched by chains enqueued since the last full synchronisation
@@ -166,6 +173,18 @@ int sync_all(lt_ctx* c) {
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
     for (bool& b : c->frames_read_set) b = false;       // every reader enqueued so far is done
     c->chain_lo = c->chain_hi = 0;                      // and every chain
+    c->written_count = 0;
+    return LT_OK;
+}
+
+// kernels writing the masks / records of slots [lo, hi) have just been enqueued on `st`
+int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) {
+    lt_ctx::Written& w = c->written[c->written_count % 32];
+    if (!w.ev && hipEventCreateWithFlags(&w.ev, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(w.ev, st));
+    w.lo = lo;
+    w.hi = hi;
+    ++c->written_count;
     return LT_OK;
 }
 
@@ -671,9 +690,11 @@ void lt_destroy(lt_ctx* c) {
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
     for (auto e : c->frames_read) if (e) (void)hipEventDestroy(e);
+    for (auto& w : c->written) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
+    if (c->h_cancel) (void)hipHostFree(c->h_cancel);
     if (c->search) (void)hipStreamDestroy(c->search);
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
@@ -1366,7 +1387,8 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
           launch_warp_split(st, c->d_und, c->und_px, f0, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
                             c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
                             ps, m); }
-        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
+        int frc = run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
+        return frc ? frc : note_written(c, st, f0, f0 + m);
     });
     if (rc) return rc;
     c->have_mask = true;
@@ -1386,7 +1408,8 @@ int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
         { StageScope t(c, ST_SPLIT_BEV, st);
           launch_split_bev(st, c->d_bev + (size_t)f0 * c->bev_bytes, c->bev_bytes, (int)ps, c->d_gamma, c->d_cbrt,
                            c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps, ps, m); }
-        return run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
+        int frc = run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
+        return frc ? frc : note_written(c, st, f0, f0 + m);
     });
     if (rc) return rc;
     c->have_mask = true;
@@ -1421,7 +1444,7 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
         launch_sws_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g,
                        c->d_band_sums + (size_t)f0 * g.nbands * c->calib.warp_w, c->d_pix + (size_t)f0 * 2 * c->maxpix,
                        c->d_cent + (size_t)f0 * 2 * (c->maxlev + 2), c->d_rec + f0, m);
-        return (int)LT_OK;
+        return note_written(c, st, f0, f0 + m);
     });
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -1457,7 +1480,7 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
         launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g, c->d_prev + (size_t)f0 * 6, bp,
                         c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
-        return (int)LT_OK;
+        return note_written(c, st, f0, f0 + m);
     });
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -1489,15 +1512,27 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     // slots, the search that wrote the seed record); those streams do not wait for it -- the mask chains of later frames run
     // beside it -- unless they touch its slots (for_each_slice).
     if (!c->search) HIP_TRY(create_compute_stream(&c->search));
+    if (!c->h_cancel) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_cancel), 64, hipHostMallocMapped));
+        *c->h_cancel = 0;
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cancel), c->h_cancel, 0));
+    }
     const int lo = seed ? first : first - 1, cnt = seed ? n : n + 1;     // with a device seed the seed record is collected too
-    rc = for_each_slice(c, lo, cnt, [&](hipStream_t st, int, int) {
-        hipEvent_t e = next_order_event(c);
-        if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipEventRecord(e, st));
-        HIP_TRY(hipStreamWaitEvent(c->search, e, 0));
-        return (int)LT_OK;
-    });
-    if (rc) return rc;
+    if (c->written_count <= 32) {
+        // everything the slots' streams wrote into these slots since the last full synchronisation (their masks; the search
+        // that left the seed record); a seed record left by an earlier chain is ordered by the search stream itself
+        for (unsigned i = 0; i < c->written_count; ++i)
+            if (c->written[i].lo < lo + cnt && c->written[i].hi > lo) HIP_TRY(hipStreamWaitEvent(c->search, c->written[i].ev, 0));
+    } else {
+        rc = for_each_slice(c, lo, cnt, [&](hipStream_t st, int, int) {      // the ring has wrapped: wait for the streams' tails
+            hipEvent_t e = next_order_event(c);
+            if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e, st));
+            HIP_TRY(hipStreamWaitEvent(c->search, e, 0));
+            return (int)LT_OK;
+        });
+        if (rc) return rc;
+    }
     if (c->h_rec_stage_cap < c->capacity) {
         HIP_TRY(hipStreamSynchronize(c->search));
         if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
@@ -1511,7 +1546,7 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
         StageScope t(c, ST_BAND_FIT, c->search);
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)first * c->bits_stride : nullptr, c->bits_stride, wpr};
         launch_band_chain(c->search, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, mb, g, seed ? nullptr : c->d_rec + first - 1,
-                          bp, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n);
+                          bp, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n, c->d_cancel, *c->h_cancel);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_rec_stage + lo, c->d_rec + lo, (size_t)cnt * sizeof(lt_lane_record), hipMemcpyDeviceToHost, c->search));
@@ -1527,6 +1562,12 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     c->chain_tail = done;
     if (c->chain_hi <= c->chain_lo) { c->chain_lo = lo; c->chain_hi = lo + cnt; }
     else { c->chain_lo = std::min(c->chain_lo, lo); c->chain_hi = std::max(c->chain_hi, lo + cnt); }
+    return LT_OK;
+}
+
+int lt_band_fit_chain_cancel(lt_ctx* c) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (c->h_cancel) __atomic_fetch_add(c->h_cancel, 1, __ATOMIC_RELEASE);   // chains enqueued so far carry an older epoch
     return LT_OK;
 }
 

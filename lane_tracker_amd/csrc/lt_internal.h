@@ -149,7 +149,7 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Ma
 // the first frame around `seed` (by value) or, with seed.by_value == 0, around the fit in *seed_rec (device memory)
 bool band_chain_supported(const SearchGeom& g, size_t mask_stride);
 void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const lt_lane_record* seed_rec,
-                       const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n);
+                       const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n, const int* cancel_epoch, int my_epoch);
 
 // fit of one explicit pixel list (packed (y<<16)|x); out: 3 doubles + 1 flag double (1.0 = rank deficient)
 void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, double* out4);

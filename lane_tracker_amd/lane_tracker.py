@@ -499,7 +499,8 @@ class LaneTracker:
 
     # ---- the chained stream pipeline (reference :851-872, :1064-1128, :1178-1199) ------------
     chain_searches = True            # False: process_batch searches frame by frame (one record round trip per frame)
-    chain_chunk = 64                 # frames per upload + mask launch inside a window
+    chain_chunk = 64                 # frames per upload + mask launch, and per chain, inside a window
+    chain_depth = 3                  # chains kept in flight behind the one the host is checking
 
     def _valid_many(self, LF, RF):
         """check_validity (:561-627) for m fits at once: the same f64 operations in the same order, element by element,
@@ -551,13 +552,13 @@ class LaneTracker:
         feed(2 * chunk)
         if annotate:
             self._upload_keepalive = ctx.upload_frame_rest(frames)     # beside the mask chain, for the overlay
-        run = chunk                      # speculation length: doubles while chains hold, falls back after a break
+        depth = max(1, int(self.chain_depth))
 
         def launch(at):
             """Enqueue a chain at frame `at` from the tracker's state (host seed, or a sliding-window search of `at` and a
             chain behind it).  Returns (first, length, search mode of the first frame) or None (frame by frame)."""
-            feed(at + run + chunk)
-            L = min(run, masked - at)
+            feed(at + (depth + 1) * chunk)
+            L = min(chunk, masked - at)
             mode = 'sws' if self.last_detection > self.n_reset else 'bs'          # :851
             try:
                 if mode == 'sws':
@@ -578,25 +579,32 @@ class LaneTracker:
             at = prev[0] + prev[1]
             if at >= n:
                 return None
-            feed(at + run + chunk)
-            L = min(run, masked - at)
+            feed(at + (depth + 1) * chunk)
+            L = min(chunk, masked - at)
             try:
                 ctx.band_fit_chain_run(L, None, sp_band, first=at)
             except _native.NativeError:
                 return None
             return at, L, 'bs'
 
-        i, cur = 0, None
+        # chains in flight, oldest first: each but the first is seeded on the device by the last record of the one before it,
+        # so each waits for the masks of its own frames only and the host checks one while the next ones run
+        i, flight = 0, []
         while i < n:
-            if cur is None:
-                cur = launch(i)
-            if cur is None:
-                self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
-                           defer=deferred)
-                i += 1
-                continue
-            nxt = launch_behind(cur)     # in flight while the host checks `cur`
-            first, L, mode = cur
+            if not flight:
+                first_chain = launch(i)
+                if first_chain is None:
+                    self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
+                               defer=deferred)
+                    i += 1
+                    continue
+                flight.append(first_chain)
+            while len(flight) < depth + 1:
+                more = launch_behind(flight[-1])
+                if more is None:
+                    break
+                flight.append(more)
+            first, L, mode = flight.pop(0)
             rec = ctx.band_fit_chain_collect(L, first=first)
             good = (rec["mode"] != 255) & (rec["detected"] != 0) & (rec["fit_flags"] == 0)
             LF, RF = rec["left_coeffs"], rec["right_coeffs"]
@@ -624,17 +632,15 @@ class LaneTracker:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
                                      self._lane_text()))
             i = first + g
-            if g == L:
-                cur = nxt                # its seed -- the last record of `cur` -- was a valid frame: the speculation holds
-                run = min(2 * run, 4 * chunk)
-            else:
+            if g < L:
                 # frame i: first try failed (or needs the host's exact fit): the ordinary route, second try included;
-                # whatever was chained behind it is dropped
+                # whatever was chained behind it is dropped (and told to stop)
+                if flight:
+                    ctx.band_fit_chain_cancel()
+                flight = []
                 self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
                            defer=deferred)
                 i += 1
-                cur = None
-                run = max(8, chunk // 4)
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,

@@ -82,6 +82,35 @@ def test_chain_stops_behind_a_frame_without_lanes_and_marks_the_rest():
         c.close()
 
 
+def test_cancelled_chain_stops_and_later_chains_run():
+    from lane_tracker_amd import _native, calib, synth
+    cal = calib.reference_calibration()
+    n = 200
+    base = synth.stream_lanes(20, seed=23)
+    frames = np.concatenate([base, base[::-1]] * 5, 0)
+    sp = _native.search_params()
+    c = _ctx(cal, n)
+    try:
+        c.upload_frames(frames)
+        c.mask_run(n)
+        c.sws_fit_run(1, sp, first=0)
+        c.sync()
+        c.band_fit_chain_run(n - 1, None, sp, first=1)         # ~2.5 ms of device work ...
+        c.band_fit_chain_cancel()                              # ... told to stop right away
+        rec = c.band_fit_chain_collect(n, first=0)
+        stopped = int(np.argmax(rec["mode"] == 255))
+        assert rec["mode"][-1] == 255 and 1 <= stopped < n and (rec["mode"][stopped:] == 255).all()
+        assert rec["detected"][:stopped].all()
+        c.band_fit_chain_run(n - 1, None, sp, first=1)         # a chain enqueued after the cancel is a new speculation
+        full = c.band_fit_chain_collect(n, first=0)
+        assert full["detected"].all() and (full["mode"][1:] == 1).all()
+        assert full[:stopped].tobytes() == rec[:stopped].tobytes()
+        with pytest.raises(_native.NativeError):
+            c.band_fit_chain_collect(4, first=0)               # collected tickets are gone
+    finally:
+        c.close()
+
+
 def _state(lt):
     return dict(detected=lt.detected_pixels, valid=lt.valid_lane_lines, last_detection=lt.last_detection, success=lt.success,
                 counter=lt.counter, left_avg=None if lt.left_avg_coeffs is None else lt.left_avg_coeffs.tobytes(),

@@ -42,6 +42,10 @@ for name, cal in (("1280x720", calib.reference_calibration()), ("1920x1080", cal
         r["process_batch_pageable_fps"] = n / t(lambda: lt.process_batch(frames, annotate=False), 3)
         r["process_batch_pinned_fps"] = n / t(lambda: lt.process_batch(pin, annotate=False), 3)
         r["success_ratio"] = lt.get_success_ratio()[0]
+        bad = frames.copy()
+        bad[9::10] = 0                                      # every tenth frame fails both tries
+        lt.process_batch(bad, annotate=False)
+        r["process_batch_fail_every_10_fps"] = n / t(lambda: lt.process_batch(bad, annotate=False), 3)
         out["%s_n%d" % (name, n)] = {k: round(v, 2) for k, v in r.items()}
         lt.close()
 print(json.dumps(out, indent=1))

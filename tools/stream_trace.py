@@ -14,7 +14,7 @@ lt = LaneTracker(**cal)
 lt.process_batch(frames, annotate=False)
 acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
 ctx = lt._ctx
-for name in ("upload_frame_rows_async", "mask_run", "sws_fit_run", "band_fit_chain_run", "download_records", "download_pixels",
+for name in ("upload_frame_rows_async", "mask_run", "sws_fit_run", "band_fit_chain_run", "band_fit_chain_collect", "download_records", "download_pixels",
              "reserve", "sync", "upload_frame_rest"):
     fn = getattr(ctx, name)
     def wrap(fn=fn, name=name):
