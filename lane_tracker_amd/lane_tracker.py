@@ -542,10 +542,13 @@ class LaneTracker:
         chunk = max(2, int(self.chain_chunk)) & ~1
         masked = 0                       # frames [0, masked) have their upload + first-try mask enqueued
 
+        def span(at):                    # frames per launch at stream position `at`: short at the head of a window (the
+            return min(chunk, max(16, at & ~1))   # first records come back early), then `chunk`
+
         def feed(upto):                  # keep the device supplied with masks ahead of the searches
             nonlocal masked
             while masked < min(n, upto):
-                m = min(chunk, n - masked)
+                m = min(span(masked), n - masked)
                 ctx.upload_frame_rows_async(frames[masked:masked + m], first=masked)
                 ctx.mask_run(m, fp, first=masked)
                 masked += m
@@ -558,7 +561,7 @@ class LaneTracker:
             """Enqueue a chain at frame `at` from the tracker's state (host seed, or a sliding-window search of `at` and a
             chain behind it).  Returns (first, length, search mode of the first frame) or None (frame by frame)."""
             feed(at + (depth + 1) * chunk)
-            L = min(chunk, masked - at)
+            L = min(span(at), masked - at)
             mode = 'sws' if self.last_detection > self.n_reset else 'bs'          # :851
             try:
                 if mode == 'sws':
@@ -580,7 +583,7 @@ class LaneTracker:
             if at >= n:
                 return None
             feed(at + (depth + 1) * chunk)
-            L = min(chunk, masked - at)
+            L = min(span(at), masked - at)
             try:
                 ctx.band_fit_chain_run(L, None, sp_band, first=at)
             except _native.NativeError:
