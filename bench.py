@@ -63,6 +63,71 @@ def render_frames(indices):
         return np.stack(list(ex.map(_render_one, indices, chunksize=max(1, len(indices) // (workers * 4)))), 0)
 
 
+def _render_stream_one(args):
+    from lane_tracker_amd import calib, synth
+    scale, sd, lc, rc, ph = args
+    global _STREAM_RENDERERS
+    try:
+        cache = _STREAM_RENDERERS
+    except NameError:
+        cache = _STREAM_RENDERERS = {}
+    if scale not in cache:
+        cache[scale] = synth.SceneRenderer(calib.reference_calibration() if scale == 1.0 else calib.scaled_calibration(scale))
+    return cache[scale].render(sd, lc, rc, dashed_phase=ph)[0]
+
+
+def render_streams(n_base=32):
+    """One drifting-lane stream per camera size (1280x720, and 1920x1080 = BASELINE config 5), rendered before the GPU is
+    touched: n_base frames each; the stream leg plays them forwards and backwards (smooth at the turning points)."""
+    from concurrent.futures import ProcessPoolExecutor
+    from lane_tracker_amd import synth
+    jobs = [(scale,) + prm for scale in (1.0, 1.5) for prm in synth.stream_lane_params(n_base, seed=5)]
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    with ProcessPoolExecutor(max(1, min(32, cpus, len(jobs)))) as ex:
+        got = list(ex.map(_render_stream_one, jobs, chunksize=2))
+    return {"1280x720": np.stack(got[:n_base], 0), "1920x1080": np.stack(got[n_base:], 0)}
+
+
+def stream_leg(streams, window=256, seconds=1.0):
+    """The stateful stream (BASELINE config 5) through the drop-in API: frames/s of process() frame by frame
+    (annotated frame back, as process_video.py uses it) and of process_batch() (device-chained searches), per camera size."""
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    out = {}
+    for name, base in streams.items():
+        cal = calib.reference_calibration() if name == "1280x720" else calib.scaled_calibration(1.5)
+        frames = np.concatenate([base, base[::-1]] * (window // (2 * len(base)) + 1), 0)[:window].copy()
+        lt = LaneTracker(**cal)
+        try:
+            for f in frames[:4]:
+                lt.process(f)
+            t0, k = time.perf_counter(), 0
+            while time.perf_counter() - t0 < seconds * 0.4:
+                lt.process(frames[4 + k % (window - 4)])
+                k += 1
+            fps_process = k / (time.perf_counter() - t0)
+            res = {"process_fps": round(fps_process, 1)}
+            for key, ann in (("process_batch_fps", False), ("process_batch_annotated_fps", True)):
+                lt.process_batch(frames, annotate=ann)
+                t0, k = time.perf_counter(), 0
+                while time.perf_counter() - t0 < seconds * 0.3 or k == 0:
+                    lt.process_batch(frames, annotate=ann)
+                    k += 1
+                res[key] = round(k * window / (time.perf_counter() - t0), 1)
+            res["success_ratio"] = round(lt.get_success_ratio()[0], 4)
+            out[name] = res
+        finally:
+            lt.close()
+    out["window"] = window
+    out["note"] = ("one stateful stream, host-fed (pageable NumPy frames in, PCIe included): process() = one frame per call, "
+                   "annotated frame returned; process_batch() = windows of %d frames, searches chained on the device "
+                   "(lt_band_fit_chain_run), check_validity / history on the host; 1920x1080 is BASELINE config 5" % window)
+    return out
+
+
 def coeff_close(got, want, h=1100, tol=1e-4):
     """north_star tolerance: 1e-4 relative per coefficient with the absolute floor of SURVEY 8(a)."""
     lim = tol * max(1.0, abs(float(want[2])))
@@ -209,6 +274,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="HIP streams per context (slot slices overlap each other's stages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the stateful-stream leg (process / process_batch frames/s)")
     a = ap.parse_args()
     if a.gpus < 1 or a.steps < 1 or a.warmup < 0:
         ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
@@ -237,6 +303,7 @@ def main():
         indices = range(rank * a.batch, (rank + 1) * a.batch)
     NL = len(indices)                                   # frames this rank processes per step
     frames = render_frames(indices)                     # before anything initialises the GPU (forked workers)
+    streams = render_streams() if (world == 1 and not strong and not a.no_stream) else None
 
     try:
         device = distributed.local_device(local_rank)   # LOCAL_RANK (LT_DEVICE_MODULO: test runs that share a GPU, labelled below)
@@ -455,6 +522,11 @@ def main():
                 out["host_fed"].update(host_fed_overlapped(cal, frames, fp, sp, a.streams, rec_all))
             except Exception as e:   # the resident number stands on its own
                 out["host_fed"]["overlapped_error"] = repr(e)
+        if single and streams is not None:
+            try:
+                out["stream"] = stream_leg(streams)
+            except Exception as e:
+                out["stream"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
     if ctx is not None:

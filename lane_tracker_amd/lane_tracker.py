@@ -499,7 +499,7 @@ class LaneTracker:
 
     # ---- the chained stream pipeline (reference :851-872, :1064-1128, :1178-1199) ------------
     chain_searches = True            # False: process_batch searches frame by frame (one record round trip per frame)
-    chain_chunk = 64                 # frames per upload + mask launch, and per chain, inside a window
+    chain_chunk = 32                 # frames per upload + mask launch, and per chain, inside a window
     chain_depth = 3                  # chains kept in flight behind the one the host is checking
 
     def _valid_many(self, LF, RF):

@@ -122,17 +122,23 @@ def frames_lanes(seeds, cal=None):
     return np.stack([r.render(int(s))[0] for s in seeds], 0)
 
 
-def stream_lanes(n, seed=0, cal=None):
-    """Config-5 style stream: one scene whose lane geometry drifts slowly from frame to frame."""
-    r = SceneRenderer(cal)
+def stream_lane_params(n, seed=0, bh=1100):
+    """The per-frame arguments of `SceneRenderer.render` for a config-5 style stream (one scene whose lane geometry
+    drifts slowly): a list of (render seed, left coeffs, right coeffs, dashed phase)."""
     rng = np.random.default_rng(seed)
     xb, s, a, d = rng.uniform(429, 449), 0.0, 0.0, rng.uniform(170, 195)
-    y0 = r.bh - 1
+    y0 = bh - 1
     out = []
     for i in range(n):
         xb += rng.uniform(-1.0, 1.0)
         s = float(np.clip(s + rng.uniform(-0.004, 0.004), -0.05, 0.05))
         a = float(np.clip(a + rng.uniform(-4e-6, 4e-6), -1e-4, 1e-4))
         ex = lambda b: np.array([a, s - 2 * a * y0, a * y0 * y0 - s * y0 + b])
-        out.append(r.render(seed * 100003 + i, ex(xb), ex(xb + d), dashed_phase=(i * 20) % 150)[0])
-    return np.stack(out, 0)
+        out.append((seed * 100003 + i, ex(xb), ex(xb + d), (i * 20) % 150))
+    return out
+
+
+def stream_lanes(n, seed=0, cal=None):
+    """Config-5 style stream: one scene whose lane geometry drifts slowly from frame to frame."""
+    r = SceneRenderer(cal)
+    return np.stack([r.render(sd, lc, rc, dashed_phase=ph)[0] for sd, lc, rc, ph in stream_lane_params(n, seed, r.bh)], 0)

@@ -2,7 +2,7 @@
 """Where the time of the chained stream pipeline goes (process_batch, annotate=False): each phase alone, per frame."""
 import json, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from lane_tracker_amd import _native, calib, synth
 from lane_tracker_amd.lane_tracker import LaneTracker
 
