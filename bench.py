@@ -146,6 +146,16 @@ def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, avail)                               # threads actually used: one frame per thread on every visible CPU
+    try:
+        # The port allocates its planes per frame; with glibc's defaults every megabyte-sized block is an mmap / munmap pair
+        # and 256 threads serialise on the process's mmap lock.  Keep freed blocks in the per-thread arenas instead
+        # (M_MMAP_THRESHOLD = -3, M_TRIM_THRESHOLD = -1): 2.2x faster on 8 threads, far more on 256.
+        import ctypes
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 1 << 30)
+        libc.mallopt(-1, 1 << 30)
+    except Exception:
+        pass
     O.frame_sws_fit(oc, frames[0])                      # warms the per-calibration tables
     t0 = time.perf_counter()
     O.frame_sws_fit(oc, frames[0])
