@@ -155,6 +155,7 @@ struct RunsGeom {
     int nframes;                 // frames of the launch
     int nstrips_normal;          // strips handled one frame per wave; nstrips - 1 when the last strip is a PAIR strip (below)
     int n_normal;                // tasks of those strips: nframes * nstrips_normal * nbands; the tasks behind them are pair tasks
+    int xcd;                     // 1: workgroups are renumbered so that each XCD (= each L2) owns one contiguous range of tasks
 };
 
 // Per-lane column bookkeeping, loop invariant: clamped byte offsets of the (up to) four pixels a
@@ -780,7 +781,16 @@ __global__ __launch_bounds__(64 * LT_MORPH_WPB) void k_morph_runs2(const uint8_t
     __shared__ uint2 s_chain[LT_MORPH_WPB][4 * PLANE];   // S0, S1, S4, S13
     __shared__ __attribute__((aligned(8))) uint8_t s_out[WIDE ? LT_MORPH_WPB : 1][WIDE ? 256 : 8];   // [2*col + row] of a row pair
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * LT_MORPH_WPB + wv);   // wave-uniform: keeps the loop scalar
+    // Workgroups are dealt to the 8 XCDs round-robin (block b -> XCD b % 8) and every XCD has its own L2.  Tasks are numbered
+    // strip-fastest, so in launch order the two halves of a band's strips, and the bands above and below, run on eight different
+    // L2s and each fetches the shared halo (2R columns / rows) from HBM on its own.  Renumbered, an XCD owns one contiguous
+    // range of tasks: neighbours in the image are neighbours in time on one L2.  Bijective for any grid; speed only.
+    uint32_t bid = blockIdx.x;
+    if (g.xcd) {
+        const uint32_t total = gridDim.x, q = total >> 3, r = total & 7u, xcd = bid & 7u, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int task = __builtin_amdgcn_readfirstlane((int)bid * LT_MORPH_WPB + wv);   // wave-uniform: keeps the loop scalar
     if (task >= g.ntasks) return;
     // Without the bias the pixel patterns 0x00vv are f16 denormals: min/max must not flush them.  FP16 denormals are on
     // in the kernel descriptor the compiler writes (tests/test_isa_guards.py checks it); set MODE.FP_DENORM[3:2] anyway.
@@ -876,6 +886,10 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.nstrips_normal = pair_strip ? g.nstrips - 1 : g.nstrips;
     g.n_normal = n * g.nstrips_normal * g.nbands;
     g.ntasks = g.n_normal + (pair_strip ? (n + 1) / 2 * g.nbands : 0);
+    // measured (tools/ab_fetch.sh LT_MORPH_XCD): the renumbering makes all four launches 1-5 % SLOWER (0.295 -> 0.311 ms
+    // erode 29x29, 0.493 -> 0.508 ms erode 55x55 per 256 frames), so it is off unless asked for
+    static const bool want_xcd = [] { const char* e = std::getenv("LT_MORPH_XCD"); return e && e[0] == '1'; }();
+    g.xcd = want_xcd ? 1 : 0;
     dim3 grid((g.ntasks + 3) / 4);
     const dim3 grid2((g.ntasks + LT_MORPH_WPB - 1) / LT_MORPH_WPB), block2(64 * LT_MORPH_WPB);
     if (one_row) {   // previous formulation (one row per iteration, u16 min/max), kept for A/B measurements
