@@ -181,7 +181,7 @@ class _PinnedPool:
     holds enough of that size).  Beyond `limit` bytes outstanding, or when the allocation fails, callers get a
     plain NumPy array -- slower copies, same results."""
 
-    def __init__(self, limit=1 << 30, keep_per_size=4):
+    def __init__(self, limit=4 << 30, keep_per_size=4):
         self.limit, self.keep = limit, keep_per_size
         self.free, self.outstanding = {}, 0
 

@@ -103,7 +103,9 @@ class LaneTracker:
         self._slot = 0              # process() alternates between two slots (see process())
         self._aux_ctx = {}          # contexts for images that are not the calibration's BEV size
         self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search
-        self._pending = None        # (ctx, slot, want_centroids): pixel lists not downloaded yet
+        self._pending = None        # (ctx, slot): lane-pixel lists of the last search that found pixels, still on the device
+        self._pending_cent = None   # (ctx, slot): window centroids of the last SLIDING-WINDOW search that found pixels (a band
+                                    # search leaves them alone, reference :434-440 vs :492-495), still on the device
         self._overlay_ready = False
         self._have_font = False
         self._resident = None       # (frame array, slot) of the camera frame last uploaded to the main context
@@ -113,13 +115,13 @@ class LaneTracker:
         return self.success / self.counter, self.success, self.counter
 
 
-    def _lane_pixel_property(name):
+    def _lane_pixel_property(name, centroids=False):
         def get(self):
-            self._materialise_pending()
+            (self._materialise_centroids if centroids else self._materialise_pixels)()
             return self._lp[name]
 
         def put(self, value):
-            self._materialise_pending()
+            (self._materialise_centroids if centroids else self._materialise_pixels)()
             self._lp[name] = value
         return property(get, put, doc="lane pixels / window centroids of the last search (reference :434-440, :492-495)")
 
@@ -127,8 +129,8 @@ class LaneTracker:
     left_x = _lane_pixel_property("left_x")
     right_y = _lane_pixel_property("right_y")
     right_x = _lane_pixel_property("right_x")
-    left_window_centroids = _lane_pixel_property("left_window_centroids")
-    right_window_centroids = _lane_pixel_property("right_window_centroids")
+    left_window_centroids = _lane_pixel_property("left_window_centroids", True)
+    right_window_centroids = _lane_pixel_property("right_window_centroids", True)
     del _lane_pixel_property
 
     def close(self):
@@ -156,36 +158,43 @@ class LaneTracker:
         if not self.detected_pixels:
             self._fit = None        # like the reference, a failed search leaves the previous pixel lists in place
             return
-        self._pending = None
         lf = np.array(rec["left_coeffs"], np.float64)
         rf = np.array(rec["right_coeffs"], np.float64)
         flags = int(rec["fit_flags"])
+        self._pending = (ctx, slot)
+        if want_centroids:
+            self._pending_cent = (ctx, slot)
         if lazy and not flags:
-            self._pending = (ctx, slot, want_centroids)
             self._fit = ("pending", None, lf, rf)
             return
-        self._fetch_pixels(ctx, slot, want_centroids)
+        self._materialise_pending()
         if flags & 1:
             lf = _minimum_norm_parabola(self._lp['left_y'], self._lp['left_x'])
         if flags & 2:
             rf = _minimum_norm_parabola(self._lp['right_y'], self._lp['right_x'])
         self._fit = (self._lp['left_y'], self._lp['right_y'], lf, rf)
 
-    def _fetch_pixels(self, ctx, slot, want_centroids):
-        self._lp['left_y'], self._lp['left_x'] = ctx.download_pixels(slot, 0)
-        self._lp['right_y'], self._lp['right_x'] = ctx.download_pixels(slot, 1)
-        if want_centroids:
+    def _materialise_pixels(self):
+        """Download the lane pixels of the most recent lazily collected search."""
+        if self._pending is not None:
+            ctx, slot = self._pending
+            self._pending = None
+            self._lp['left_y'], self._lp['left_x'] = ctx.download_pixels(slot, 0)
+            self._lp['right_y'], self._lp['right_x'] = ctx.download_pixels(slot, 1)
+            if self._fit is not None and isinstance(self._fit[0], str):
+                self._fit = (self._lp['left_y'], self._lp['right_y'], self._fit[2], self._fit[3])
+
+    def _materialise_centroids(self):
+        """Download the window centroids of the most recent lazily collected sliding-window search."""
+        if self._pending_cent is not None:
+            ctx, slot = self._pending_cent
+            self._pending_cent = None
             self._lp['left_window_centroids'] = ctx.download_centroids(slot, 0)
             self._lp['right_window_centroids'] = ctx.download_centroids(slot, 1)
 
     def _materialise_pending(self):
-        """Download the lane pixels of the most recent lazily collected search (stream pipeline)."""
-        if self._pending is not None:
-            ctx, slot, want_centroids = self._pending
-            self._pending = None
-            self._fetch_pixels(ctx, slot, want_centroids)
-            if self._fit is not None and isinstance(self._fit[0], str):
-                self._fit = (self._lp['left_y'], self._lp['right_y'], self._fit[2], self._fit[3])
+        self._materialise_pixels()
+        self._materialise_centroids()
 
     # ---- filter_lane_points (reference :183-240) ------------------------------------------------
     def filter_lane_points(self, img, filter_type='bilateral', ksize_r=25, C_r=8, ksize_b=35, C_b=5,
@@ -224,7 +233,9 @@ class LaneTracker:
 
     def _search_uploaded(self, ctx, mode, kw, diagnostics, slot=0, lazy=False):
         if self._pending is not None and self._pending[0] is ctx and self._pending[1] == slot:
-            self._materialise_pending()      # this search reuses the slot whose lists were not fetched yet
+            self._materialise_pixels()       # this search reuses the slot whose lists were not fetched yet
+        if mode == 'sws' and self._pending_cent is not None and self._pending_cent[0] is ctx and self._pending_cent[1] == slot:
+            self._materialise_centroids()    # ... and a sliding-window search rewrites the slot's centroid lists
         if mode == 'sws':
             ctx.sws_fit_run(1, _native.search_params(**kw), first=slot)
         else:
@@ -563,6 +574,10 @@ class LaneTracker:
             feed(at + (depth + 1) * chunk)
             L = min(span(at), masked - at)
             mode = 'sws' if self.last_detection > self.n_reset else 'bs'          # :851
+            if self._pending is not None and self._pending[0] is ctx and at <= self._pending[1]:
+                self._materialise_pixels()        # (cannot happen inside a window: committed frames lie before `at`)
+            if mode == 'sws' and self._pending_cent is not None and self._pending_cent[0] is ctx and self._pending_cent[1] == at:
+                self._materialise_centroids()
             try:
                 if mode == 'sws':
                     if L < 2:
@@ -619,6 +634,8 @@ class LaneTracker:
             # frames first .. first+g-1: first try valid.  Without annotation only the last n_average of them leave a
             # trace in the state (histories are that long; every other attribute is overwritten by each success).
             skip = 0 if annotate else max(0, g - max(int(self.n_average), 1))
+            if g and mode == 'sws':
+                self._pending_cent = (ctx, first)    # the sliding-window search of the chain's first frame found pixels (:439-440)
             if skip:
                 self.counter += skip
                 self.success += skip
@@ -627,7 +644,7 @@ class LaneTracker:
                 self.detected_pixels = True
                 self.valid_lane_lines = True
                 lf, rf = np.array(LF[j], np.float64), np.array(RF[j], np.float64)
-                self._pending = (ctx, first + j, j == 0 and mode == 'sws')
+                self._pending = (ctx, first + j)
                 self._fit = ("pending", None, lf, rf)
                 self._resident = (frames[first + j], first + j)
                 self._record_success(lf, rf, partial)

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the chained stream pipeline (LaneTracker.process_batch, lt_band_fit_chain_run) against
+frame-by-frame process() on the GPU box:   python tests/fuzz_chain.py [iterations] [seed]
+
+Each iteration builds a stream from a pool of frames -- drifting lanes, lanes that jump sideways (valid masks, but the
+band search of the next frame finds nothing or a fit check_validity rejects), noise, flat grey, black -- with random
+failure bursts, draws random tracker parameters (n_average, n_reset, n_fail, bandwidth, n_tries, partial, window sizes,
+chain chunk / depth), random window splits and annotation on / off, and requires the tracker state, the lane-pixel lists
+and (when annotated) the returned frames to equal those of process() after every window.  Prints the first mismatch and
+exits 1."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lane_tracker_amd import calib, synth  # noqa: E402
+from lane_tracker_amd.lane_tracker import LaneTracker  # noqa: E402
+
+
+def state(lt):
+    b = lambda a: None if a is None else np.asarray(a).tobytes()
+    return dict(detected=lt.detected_pixels, valid=lt.valid_lane_lines, last_detection=lt.last_detection, success=lt.success,
+                counter=lt.counter, left_avg=b(lt.left_avg_coeffs), right_avg=b(lt.right_avg_coeffs), last_left=b(lt.last_left_coeffs),
+                last_right=b(lt.last_right_coeffs), hist=[b(c) for c in lt.left_fit_coeffs] + [b(c) for c in lt.right_fit_coeffs],
+                radii=list(lt.average_curve_radii), radius=lt.average_curve_radius, lr=(lt.left_curve_radius, lt.right_curve_radius),
+                ecc=lt.eccentricity, pts=(b(lt.left_avg_y), b(lt.left_avg_x), b(lt.right_avg_y), b(lt.right_avg_x)),
+                pix=(b(lt.left_y), b(lt.left_x), b(lt.right_y), b(lt.right_x)), cent=(lt.left_window_centroids, lt.right_window_centroids))
+
+
+def main(iters=20, seed=1, cal=None, verbose=True):
+    rng = np.random.default_rng(seed)
+    cal = cal or calib.reference_calibration()
+    h, w = cal["img_size"][1], cal["img_size"][0]
+    # pools: two drifting streams (the second one offset sideways: a jump between them breaks the band search)
+    a = synth.stream_lanes(24, seed=101, cal=cal)
+    bpool = synth.stream_lanes(24, seed=202, cal=cal)
+    noise = [synth.frame_uniform(900 + i, img_size=(w, h)) for i in range(3)]
+    grey, black = np.full((h, w, 3), 128, np.uint8), np.zeros((h, w, 3), np.uint8)
+    bad = 0
+    for it in range(iters):
+        n = int(rng.integers(8, 90))
+        frames, src, pos = [], a, int(rng.integers(0, 24))
+        burst = 0
+        for i in range(n):
+            if burst > 0:
+                burst -= 1
+                frames.append([grey, black, noise[i % 3]][int(rng.integers(0, 3))])
+                continue
+            r = rng.random()
+            if r < 0.06:
+                burst = int(rng.integers(0, 9))             # outage: up to 8 more bad frames (beyond n_reset: back to sliding windows)
+                frames.append(black)
+                continue
+            if r < 0.12:
+                src = bpool if src is a else a               # the lane jumps
+            pos = (pos + 1) % 24
+            frames.append(src[pos] if (pos // 24) % 2 == 0 else src[23 - pos])
+        frames = np.stack(frames, 0)
+        ctor = dict(n_fail=int(rng.integers(1, 10)), n_reset=int(rng.integers(0, 6)), n_average=int(rng.integers(1, 5)),
+                    print_frame_count=bool(rng.random() < 0.3))
+        kw = dict(bandwidth=int(rng.choice([25, 31, 12, 30])), n_tries=int(rng.choice([2, 2, 1, -1])), partial=float(rng.choice([1.0, 1.0, 0.5])),
+                  window_height=int(rng.choice([40, 40, 118])), no_success_limit=int(rng.choice([8, 3, 50])))
+        annotate = bool(rng.random() < 0.3)
+        seq, bat = LaneTracker(**cal, **ctor), LaneTracker(**cal, **ctor)
+        bat.chain_chunk, bat.chain_depth = int(rng.choice([2, 8, 16, 32, 64])), int(rng.choice([1, 2, 3]))
+        try:
+            lo = 0
+            while lo < n:
+                wlen = int(rng.integers(1, 40))
+                win = frames[lo:lo + wlen]
+                outs_seq = [seq.process(f, **kw) for f in win]
+                outs = bat.process_batch(win, annotate=annotate, **kw)
+                s1, s2 = state(seq), state(bat)
+                if s1 != s2:
+                    keys = [k for k in s1 if s1[k] != s2[k]]
+                    print("STATE MISMATCH it", it, "seed", seed, "window", lo, wlen, "keys", keys, ctor, kw, bat.chain_chunk, bat.chain_depth)
+                    bad += 1
+                    break
+                if annotate and any(not np.array_equal(g, s) for g, s in zip(outs, outs_seq)):
+                    print("FRAME MISMATCH it", it, "seed", seed, "window", lo, wlen, ctor, kw)
+                    bad += 1
+                    break
+                lo += wlen
+            if verbose:
+                print("it %d: %d frames, %d/%d valid, chunk %d depth %d%s" % (it, n, bat.success, bat.counter, bat.chain_chunk, bat.chain_depth,
+                                                                             ", annotated" if annotate else ""))
+        finally:
+            seq.close()
+            bat.close()
+        if bad:
+            break
+    return bad
+
+
+if __name__ == "__main__":
+    it = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    big = len(sys.argv) > 3 and sys.argv[3] == "1080"
+    n_bad = main(it, sd, cal=calib.scaled_calibration(1.5) if big else None)
+    print("chain fuzz: %d iterations, %d mismatches" % (it, n_bad))
+    sys.exit(1 if n_bad else 0)

@@ -209,3 +209,10 @@ def test_config5_1080p_stream_chained():
     finally:
         seq.close()
         bat.close()
+
+
+def test_chain_fuzz_short():
+    """A short run of tests/fuzz_chain.py (random streams with jumps and outages, random tracker / chain parameters, random
+    window splits): process_batch == process() after every window."""
+    import fuzz_chain
+    assert fuzz_chain.main(iters=6, seed=11, verbose=False) == 0
