@@ -111,8 +111,11 @@ __device__ __forceinline__ void put_lane(uint32_t& m0, uint32_t& m1, uint32_t& m
 struct Task {
     int seg, grp, frame, y0, y1;
 };
+// blk: the workgroup's id in launch order (renumbered here so that every XCD owns a contiguous range of tasks), or -- with
+// PLACED -- a task number the caller has already placed (k_bilateral_walk_hv)
+template <bool PLACED = false>
 __device__ __forceinline__ bool decode_task(const WalkArgs& a, int len, Task& t, int blk) {
-    const int task = xcd_contiguous(blk, a.ntasks);
+    const int task = PLACED ? blk : xcd_contiguous(blk, a.ntasks);
     t.seg = task % a.segs;
     t.grp = (task / a.segs) % a.groups;
     t.frame = task / (a.segs * a.groups);
@@ -125,7 +128,7 @@ __device__ __forceinline__ bool decode_task(const WalkArgs& a, int len, Task& t,
 
 // ---------------------------------------------------------------------------------------------------------------
 // Vertical pass: lanes = columns (l | l + 64) of a 128-column group, the walk goes down the rows.
-template <int K>
+template <int K, bool PLACED = false>
 __device__ __forceinline__ void walk_v_task(const WalkArgs& a, int blk) {
     using Cfg = WalkCfg<K>;
     constexpr int WIN = Cfg::WIN, NPRE = Cfg::NPRE, NCH = Cfg::NCH, WSTEP = Cfg::WSTEP;
@@ -133,7 +136,7 @@ __device__ __forceinline__ void walk_v_task(const WalkArgs& a, int blk) {
     const int lane = threadIdx.x;
     const int h = a.h, w = a.w;
     Task t;
-    if (!decode_task(a, h, t, blk)) return;
+    if (!decode_task<PLACED>(a, h, t, blk)) return;
     const uint8_t* src = a.src + (size_t)t.frame * a.plane_stride;
     unsigned long long* out = a.out + (size_t)t.frame * a.bits_stride;
     const int y0 = t.y0, y1 = t.y1;
@@ -258,7 +261,7 @@ __device__ __forceinline__ void walk_v_task(const WalkArgs& a, int blk) {
 // piece lane&7: 8 rows x one whole 128-byte line per instruction); the eighth of the lanes that holds the next 16 columns
 // writes them into the ring every 16 steps with 128-bit stores, and the streams read 128 bits per row and 16 steps.
 // (64 VGPRs for the block: the ring limits a CU to 11 waves at k = 35 anyway, so up to 168 VGPRs cost no occupancy.)
-template <int K>
+template <int K, bool PLACED = false>
 __device__ __forceinline__ void walk_h_task(const WalkArgs& a, int task_blk) {
     using Cfg = WalkCfgH<K>;
     constexpr int WIN = Cfg::WIN, NPRE = Cfg::NPRE, NCH = Cfg::NCH, WSTEP = Cfg::WSTEP, PITCH = Cfg::PITCH, E = Cfg::E,
@@ -267,7 +270,7 @@ __device__ __forceinline__ void walk_h_task(const WalkArgs& a, int task_blk) {
     const int lane = threadIdx.x;
     const int h = a.h, w = a.w;
     Task t;
-    if (!decode_task(a, w, t, task_blk)) return;
+    if (!decode_task<PLACED>(a, w, t, task_blk)) return;
     const uint8_t* src = a.src + (size_t)t.frame * a.plane_stride;
     unsigned long long* out = a.out + (size_t)t.frame * a.bits_stride;
     const int y0 = t.y0;
@@ -445,9 +448,24 @@ __global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) { walk_h
 // Both passes of a plane in ONE launch, their tasks alternating: the horizontal walks leave more than half of the VALU
 // issue slots free while they wait for their staging, the vertical walks are bound by exactly those slots, so waves of
 // the two kinds on one SIMD fill each other's gaps (separate launches on one stream run back to back).
+// Placement: workgroup b runs on XCD b % 8.  The launch order is renumbered so that every XCD owns one contiguous range of
+// it, and inside that range horizontal and vertical tasks alternate with the SAME task number -- the same frame -- so both
+// passes of a frame's plane run on one XCD close together and its L2 fetches the plane from HBM once.  (Alternating by the
+// parity of b itself put every horizontal task on the even XCDs and every vertical task on the odd ones: each plane
+// crossed the fabric once per pass.)  xcd = 0: the parity order, for A/B.
 template <int K>
-__global__ __launch_bounds__(64, 3) void k_bilateral_walk_hv(WalkArgs ah, WalkArgs av) {
-    const int b = blockIdx.x, pairs = min(ah.ntasks, av.ntasks);
+__global__ __launch_bounds__(64, 3) void k_bilateral_walk_hv(WalkArgs ah, WalkArgs av, int xcd) {
+    const int pairs = min(ah.ntasks, av.ntasks);
+    if (xcd) {
+        const int b = xcd_contiguous(blockIdx.x, gridDim.x);
+        if (b < 2 * pairs) {
+            if (b & 1) walk_v_task<K, true>(av, b >> 1);
+            else walk_h_task<K, true>(ah, b >> 1);
+        } else if (ah.ntasks > pairs) walk_h_task<K, true>(ah, b - pairs);
+        else walk_v_task<K, true>(av, b - pairs);
+        return;
+    }
+    const int b = blockIdx.x;
     if (b < 2 * pairs) {
         if (b & 1) walk_v_task<K>(av, b >> 1);
         else walk_h_task<K>(ah, b >> 1);
@@ -500,7 +518,8 @@ void launch_walk_both(hipStream_t s, const uint8_t* src, int C, unsigned long lo
         const WalkArgs ah = walk_args<false>(src, C, out_h, h, w, pitch, plane_stride, bits_stride, n);
         const WalkArgs av = walk_args<true>(src, C, out_v, h, w, pitch, plane_stride, bits_stride, n);
         const int lds = std::max(WalkCfgH<K>::LDS, WalkCfg<K>::V_LDS);
-        hipLaunchKernelGGL((k_bilateral_walk_hv<K>), dim3(ah.ntasks + av.ntasks), dim3(64), lds, s, ah, av);
+        static const int xcd = [] { const char* e = std::getenv("LT_WALK_XCD"); return e && e[0] == '0' ? 0 : 1; }();   // A/B
+        hipLaunchKernelGGL((k_bilateral_walk_hv<K>), dim3(ah.ntasks + av.ntasks), dim3(64), lds, s, ah, av, xcd);
         return;
     }
     if (passes & 1) launch_walk<K, false>(s, src, C, out_h, h, w, pitch, plane_stride, bits_stride, n);
