@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling, same guide
 MASK_STAGES = ["undistort_rows", "warp_split", "erode_r29", "tophat_r29", "erode_b55", "tophat_b55", "threshold",
                "merge", "open5"]
-PROFILE_TAG = "r02"            # profiles/<tag>_traffic.json, <tag>_valu_issue.json: committed counter / calibration runs
+PROFILE_TAG = "r03"            # profiles/<tag>_traffic.json, <tag>_kernel_stats_summary.json: the committed counter run of this code
+CALIB_TAG = "r02"              # profiles/<tag>_valu_issue.json, <tag>_fetch_calib.json: the issue-rate / counter calibrations (hardware facts)
 
 
 def _render_one(i):
@@ -441,7 +442,7 @@ def main():
             tj = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_traffic.json")))
             if tj["frames_per_launch"] == NL:
                 traffic = int(tj["mask_stage_traffic_bytes_per_launch"])
-                vi = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_valu_issue.json")))
+                vi = json.load(open(os.path.join(ROOT, "profiles", CALIB_TAG + "_valu_issue.json")))
                 peak_rate = float(vi["peak_wave_insts_per_cycle_per_simd"])
                 lane_ops = float(tj["mask_stage_valu_wave_insts_per_launch"]) * 64.0
                 peak = info.cu_count * 4 * peak_rate * 64.0 * 2.4e9       # CUs x SIMDs x wave-insts/clk x 64 lanes x 2.4 GHz
@@ -461,14 +462,24 @@ def main():
                     per_kernel[st] = {"ms": round(ms, 4),
                                       "valu_issue_frac": round(insts / (ms * 1e-3 * 2.4e9 * info.cu_count * 4 * peak_rate), 3),
                                       "hbm_side_GBs": round(byts / (ms * 1e-3) / 1e9, 1)}
+                rocprof = None
+                try:
+                    ks = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_kernel_stats_summary.json")))
+                    rocprof = {"stage_ms": ks["mask_stage_ms"], "this_run_over_rocprof": round(mask_ms / ks["mask_stage_ms"], 3),
+                               "note": "sum of the rocprofv3 --kernel-trace average durations of the same kernels in the committed "
+                                       "profile run (kernels under the tracer run slower than between hipEvents)"}
+                except Exception:
+                    pass
                 from_profile = {
-                    "from_profile": PROFILE_TAG, "source": tj.get("source"), "per_kernel": per_kernel,
+                    "from_profile": PROFILE_TAG, "commit": tj.get("commit"), "rocprof_kernel_trace": rocprof,
+                    "source": tj.get("source"), "per_kernel": per_kernel,
                     "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": round(traffic / float(alg), 2),
                     "fetch_write_calibration": tj.get("calibration"),
+                    "traffic_over_compulsory": round(traffic / float(tj["mask_stage_compulsory_bytes_per_launch"]), 2) if tj.get("mask_stage_compulsory_bytes_per_launch") else None,
                     "valu_issue": {"achieved": round(lane_ops / (mask_ms * 1e-3) / 1e12, 3), "peak": round(peak / 1e12, 3),
                                    "unit": "T lane-ops/s", "frac": round(lane_ops / (mask_ms * 1e-3) / peak, 4),
                                    "peak_from": "profiles/%s_valu_issue.json: %s wave64 instructions per cycle per SIMD measured for "
-                                                "the packed-16 / integer instructions of these kernels" % (PROFILE_TAG, peak_rate)}}
+                                                "the packed-16 / integer instructions of these kernels" % (CALIB_TAG, peak_rate)}}
         except Exception:
             pass
         workload = ("BASELINE config 4: %d-frame synthetic stream sharded over %d GPU(s) (%d frames on rank 0), HBM-resident"
