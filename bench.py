@@ -146,7 +146,22 @@ def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    cores = max(1, avail)                               # threads actually used: one frame per thread on every visible CPU
+    # CPU time this process may actually use: the cgroup quota (the GPU box shows 256 CPUs and grants 16 CPUs' worth of
+    # time; 256 threads on that are throttled to less than 16 run)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    cores = max(1, min(avail, int(quota + 0.999)) if quota else avail)   # threads actually used: one frame per thread
     try:
         # The port allocates its planes per frame; with glibc's defaults every megabyte-sized block is an mmap / munmap pair
         # and 256 threads serialise on the process's mmap lock.  Keep freed blocks in the per-thread arenas instead
@@ -214,11 +229,11 @@ def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
     except OSError:
         pass
     out = {"value": round(n_all / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port", "cpu_model": model,
-           "nproc": os.cpu_count(), "stage_ms_one_thread": stages,
+           "nproc": os.cpu_count(), "cpus_in_affinity_mask": avail, "cgroup_cpu_quota": quota, "stage_ms_one_thread": stages,
            "note": "naive O(k)-per-pixel oracle written for fidelity, not a tuned CPU path; never quote the GPU/CPU ratio",
            "sample": "%d passes over frames of the same synthetic batch through oracle/lt_oracle.c (mask + sliding window + fit), one frame "
-                     "per thread on %d threads (%d CPUs visible); single-thread %.1f ms/frame = %.1f frames/s, so the "
-                     "threaded run is %.1fx one thread" % (n_all, cores, avail, one * 1e3, 1.0 / one, (n_all / dt) * one)}
+                     "per thread on %d threads (%d CPUs visible, cgroup quota %s); single-thread %.1f ms/frame = %.1f frames/s, so the "
+                     "threaded run is %.1fx one thread" % (n_all, cores, avail, quota, one * 1e3, 1.0 / one, (n_all / dt) * one)}
     try:   # the reference's own NumPy stages (a5-a8), timed in the build container where the reference can be imported
         out["reference_numpy_container"] = json.load(open(os.path.join(ROOT, "profiles", "reference_numpy_timings.json")))
     except Exception:
