@@ -1538,6 +1538,8 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
         if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
         c->h_rec_stage = nullptr;
         c->h_rec_stage_cap = 0;
+        for (auto& t : c->chains) c->chain_event_pool.push_back(t.done);   // tickets of the old staging block: nothing to collect any more
+        c->chains.clear();
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_rec_stage), (size_t)c->capacity * sizeof(lt_lane_record), hipHostMallocDefault));
         c->h_rec_stage_cap = c->capacity;
     }
