@@ -109,6 +109,7 @@ class LaneTracker:
         self._overlay_ready = False
         self._have_font = False
         self._resident = None       # (frame array, slot) of the camera frame last uploaded to the main context
+        self._in_stream = False     # a process_stream() generator is active: its windows own the context's slots
 
     # ------------------------------------------------------------------------------------------
     def get_success_ratio(self):
@@ -540,10 +541,15 @@ class LaneTracker:
         norm2 = np.abs(slope(LF, y3) - slope(RF, y3))
         return ~dist_bad & ~((norm1 >= lim['thresh']) | (norm2 >= lim['thresh']))
 
-    def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred):
-        """process_batch's frame loop with the searches chained on the device.  State after every frame, and every
-        attribute at the end, equal those of `_step` frame by frame (tests/test_gpu_tracker.py)."""
+    def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred, base=0, prefed=0, ahead=None):
+        """The frame loop of a window with the searches chained on the device.  State after every frame, and every
+        attribute at the end, equal those of `_step` frame by frame (tests/test_gpu_chain.py, tests/fuzz_chain.py).
+        The window's frames live in slots base .. base+n-1; the first `prefed` of them already have their upload and
+        first-try mask enqueued (by the previous window); `ahead` = (frames of the next window, its first slot): its first
+        frames are fed as this window drains, and their number is returned."""
         ctx, n = self._ctx, frames.shape[0]
+        nxt, nxt_base = ahead if ahead is not None else (None, 0)
+        total = n + (len(nxt) if nxt is not None else 0)
         partial = first_try[-1]
         sws_kw = dict(window_width=first_try[9], window_height=first_try[10], search_range=first_try[11], mu=first_try[12],
                       no_success_limit=first_try[13], start_slice=first_try[14], ignore_sides=first_try[15],
@@ -551,43 +557,51 @@ class LaneTracker:
         sp_sws = _native.search_params(**sws_kw)
         sp_band = _native.search_params(bandwidth=first_try[17], ignore_bottom=first_try[16], partial=partial)
         chunk = max(2, int(self.chain_chunk)) & ~1
-        masked = 0                       # frames [0, masked) have their upload + first-try mask enqueued
+        masked = prefed                  # stream positions [0, masked) have their upload + first-try mask enqueued;
+                                         # positions >= n are frames of the next window
+        head = prefed == 0 and base == 0 and ahead is None or self.counter == 0
 
-        def span(at):                    # frames per launch at stream position `at`: short at the head of a window (the
-            return min(chunk, max(16, at & ~1))   # first records come back early), then `chunk`
+        def span(at):                    # frames per launch at position `at`: short at the head of a stand-alone window (the
+            return min(chunk, max(16, at & ~1)) if head else chunk   # first records come back early), then `chunk`
 
         def feed(upto):                  # keep the device supplied with masks ahead of the searches
             nonlocal masked
-            while masked < min(n, upto):
-                m = min(span(masked), n - masked)
-                ctx.upload_frame_rows_async(frames[masked:masked + m], first=masked)
-                ctx.mask_run(m, fp, first=masked)
+            while masked < min(total, upto):
+                if masked < n:
+                    m = min(span(masked), n - masked)
+                    ctx.upload_frame_rows_async(frames[masked:masked + m], first=base + masked)
+                    ctx.mask_run(m, fp, first=base + masked)
+                else:
+                    q = masked - n
+                    m = min(chunk, len(nxt) - q)
+                    ctx.upload_frame_rows_async(nxt[q:q + m], first=nxt_base + q)
+                    ctx.mask_run(m, fp, first=nxt_base + q)
                 masked += m
         feed(2 * chunk)
         if annotate:
-            self._upload_keepalive = ctx.upload_frame_rest(frames)     # beside the mask chain, for the overlay
+            self._upload_keepalive = ctx.upload_frame_rest(frames, first=base)     # beside the mask chain, for the overlay
         depth = max(1, int(self.chain_depth))
 
         def launch(at):
             """Enqueue a chain at frame `at` from the tracker's state (host seed, or a sliding-window search of `at` and a
             chain behind it).  Returns (first, length, search mode of the first frame) or None (frame by frame)."""
             feed(at + (depth + 1) * chunk)
-            L = min(span(at), masked - at)
+            L = min(span(at), min(masked, n) - at)
             mode = 'sws' if self.last_detection > self.n_reset else 'bs'          # :851
-            if self._pending is not None and self._pending[0] is ctx and at <= self._pending[1]:
+            if self._pending is not None and self._pending[0] is ctx and base + at <= self._pending[1] < base + n:
                 self._materialise_pixels()        # (cannot happen inside a window: committed frames lie before `at`)
-            if mode == 'sws' and self._pending_cent is not None and self._pending_cent[0] is ctx and self._pending_cent[1] == at:
+            if mode == 'sws' and self._pending_cent is not None and self._pending_cent[0] is ctx and self._pending_cent[1] == base + at:
                 self._materialise_centroids()
             try:
                 if mode == 'sws':
                     if L < 2:
                         return None
-                    ctx.sws_fit_run(1, sp_sws, first=at)
-                    ctx.band_fit_chain_run(L - 1, None, sp_band, first=at + 1)
+                    ctx.sws_fit_run(1, sp_sws, first=base + at)
+                    ctx.band_fit_chain_run(L - 1, None, sp_band, first=base + at + 1)
                 else:
                     seed = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
                                            np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
-                    ctx.band_fit_chain_run(L, seed, sp_band, first=at)
+                    ctx.band_fit_chain_run(L, seed, sp_band, first=base + at)
             except _native.NativeError:  # geometry outside the chain kernel's limits
                 return None
             return at, L, mode
@@ -596,11 +610,12 @@ class LaneTracker:
             """Speculate further: the chain continues on the device from the last record of `prev` (not yet checked)."""
             at = prev[0] + prev[1]
             if at >= n:
+                feed(at + (depth + 1) * chunk)   # nothing left to chain in this window: keep feeding the next one
                 return None
             feed(at + (depth + 1) * chunk)
-            L = min(span(at), masked - at)
+            L = min(span(at), min(masked, n) - at)
             try:
-                ctx.band_fit_chain_run(L, None, sp_band, first=at)
+                ctx.band_fit_chain_run(L, None, sp_band, first=base + at)
             except _native.NativeError:
                 return None
             return at, L, 'bs'
@@ -612,7 +627,7 @@ class LaneTracker:
             if not flight:
                 first_chain = launch(i)
                 if first_chain is None:
-                    self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
+                    self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate,
                                defer=deferred)
                     i += 1
                     continue
@@ -623,7 +638,7 @@ class LaneTracker:
                     break
                 flight.append(more)
             first, L, mode = flight.pop(0)
-            rec = ctx.band_fit_chain_collect(L, first=first)
+            rec = ctx.band_fit_chain_collect(L, first=base + first)
             good = (rec["mode"] != 255) & (rec["detected"] != 0) & (rec["fit_flags"] == 0)
             LF, RF = rec["left_coeffs"], rec["right_coeffs"]
             g = L if good.all() else int(np.argmin(good))              # frames [0, g) were found, with regular fits
@@ -635,7 +650,7 @@ class LaneTracker:
             # trace in the state (histories are that long; every other attribute is overwritten by each success).
             skip = 0 if annotate else max(0, g - max(int(self.n_average), 1))
             if g and mode == 'sws':
-                self._pending_cent = (ctx, first)    # the sliding-window search of the chain's first frame found pixels (:439-440)
+                self._pending_cent = (ctx, base + first)    # the sliding-window search of the chain's first frame found pixels (:439-440)
             if skip:
                 self.counter += skip
                 self.success += skip
@@ -644,9 +659,9 @@ class LaneTracker:
                 self.detected_pixels = True
                 self.valid_lane_lines = True
                 lf, rf = np.array(LF[j], np.float64), np.array(RF[j], np.float64)
-                self._pending = (ctx, first + j)
+                self._pending = (ctx, base + first + j)
                 self._fit = ("pending", None, lf, rf)
-                self._resident = (frames[first + j], first + j)
+                self._resident = (frames[first + j], base + first + j)
                 self._record_success(lf, rf, partial)
                 if annotate:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
@@ -658,9 +673,10 @@ class LaneTracker:
                 if flight:
                     ctx.band_fit_chain_cancel()
                 flight = []
-                self._step(frames[i], first_try, n_tries, False, slot=i, have_mask=True, lazy=True, annotate=annotate,
+                self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate,
                            defer=deferred)
                 i += 1
+        return max(0, masked - n)
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,
@@ -681,19 +697,54 @@ class LaneTracker:
         # The lane-pixel lists stay on the device until somebody reads lt.left_x & co.  Frames alternate between
         # two slots, so that the lists of the previous search are still there when this frame's searches find
         # nothing (upstream keeps the old lists in that case).
+        if self._in_stream:
+            raise RuntimeError("process() inside an active process_stream() would overwrite its frames")
         self._slot ^= 1
         return self._step(img, first_try, n_tries, diagnostics, slot=self._slot, have_mask=False, lazy=True, annotate=True,
                           visualize_search=visualize_search, split_view=split_view)
+
+    def _batch_arguments(self, kwargs):
+        """process()'s keywords with its defaults -> (keyword dict, first-try parameter tuple, filter parameters)."""
+        import inspect
+        sig = inspect.signature(LaneTracker.process)
+        k = {name: v.default for name, v in sig.parameters.items() if name not in ("self", "img")}
+        unknown = set(kwargs) - set(k)
+        if unknown:
+            raise TypeError("unexpected keyword(s): " + ", ".join(sorted(unknown)))
+        k.update(kwargs)
+        if k["visualize_search"] or k["split_view"]:
+            raise NotImplementedError("search visualisation / split view are not available in the stream pipeline")
+        first_try = (k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"], k["filter_type"], k["mask_noise"], k["noise_thresh"],
+                     k["ksize_noise"], k["C_noise"], k["window_width"], k["window_height"], k["search_range"], k["mu"],
+                     k["no_success_limit"], k["start_slice"], k["ignore_sides"], k["ignore_bottom"], k["bandwidth"],
+                     k["partial"])
+        fp = _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],
+                                   k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"])
+        return k, first_try, fp
+
+    @staticmethod
+    def _as_window(frames):
+        frames = np.ascontiguousarray(frames, np.uint8)
+        if frames.ndim != 4:
+            raise ValueError("expected frames of shape (n, H, W, 3)")
+        return frames
+
+    def _render_window(self, deferred, base):
+        """One overlay launch and one download for a whole window; a failed frame has no polygon (plain copy)."""
+        self._configure_overlay()
+        empty = np.zeros(0, np.int64)
+        return list(self._annotate([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in deferred],
+                                   [d[2] for d in deferred], first=base))
 
     def process_batch(self, frames, annotate=True, **kwargs):
         """The same result as calling `process()` on each frame of `frames` in order (one stateful
         stream), arranged for throughput:
 
-          * all frames are uploaded once and the first-try masks (undistort + warp + filter) of the
-            whole window are computed ahead in one batched launch -- that stage is stateless;
+          * the frames are uploaded (only the camera rows the path reads) and their first-try masks (undistort + warp
+            + filter) computed a few dozen at a time, ahead of the searches -- that stage is stateless;
           * the searches of consecutive frames are chained on the device (`lt_band_fit_chain_run`): frame
             k+1's band is drawn around frame k's fit without a host round trip, speculating that frame k
-            will be found valid; the host downloads the records of a whole run once, replays
+            will be found valid; the host collects the records of a whole run once, replays
             check_validity / the history exactly as `process()` does, and at the first frame that was
             not detected, not valid (or whose fit was rank deficient) drops the speculative tail, runs that
             frame the ordinary way (second try included) and starts the next chain behind it;
@@ -702,30 +753,16 @@ class LaneTracker:
           * lane-pixel lists stay on the device unless somebody reads them.
 
         `kwargs` are `process()`'s keywords.  Returns the list of annotated frames, or None for every
-        frame when `annotate=False` (state and attributes are updated identically)."""
-        import inspect
-        sig = inspect.signature(LaneTracker.process)
-        defaults = {k: v.default for k, v in sig.parameters.items() if k not in ("self", "img")}
-        unknown = set(kwargs) - set(defaults)
-        if unknown:
-            raise TypeError("unexpected keyword(s): " + ", ".join(sorted(unknown)))
-        defaults.update(kwargs)
-        k = defaults
-        if k["visualize_search"] or k["split_view"]:
-            raise NotImplementedError("search visualisation / split view are not available in the stream pipeline")
-        frames = np.ascontiguousarray(frames, np.uint8)
-        if frames.ndim != 4:
-            raise ValueError("process_batch expects frames of shape (n, H, W, 3)")
+        frame when `annotate=False` (state and attributes are updated identically).  For consecutive windows of one
+        video prefer `process_stream`, which keeps the device busy across window boundaries."""
+        if self._in_stream:
+            raise RuntimeError("process_batch() inside an active process_stream() would overwrite its frames")
+        k, first_try, fp = self._batch_arguments(kwargs)
+        frames = self._as_window(frames)
         n = frames.shape[0]
-        first_try = (k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"], k["filter_type"], k["mask_noise"], k["noise_thresh"],
-                     k["ksize_noise"], k["C_noise"], k["window_width"], k["window_height"], k["search_range"], k["mu"],
-                     k["no_success_limit"], k["start_slice"], k["ignore_sides"], k["ignore_bottom"], k["bandwidth"],
-                     k["partial"])
         ctx = self._ctx
         self._materialise_pending()      # growing the context below drops what is still on the device
         ctx.reserve(max(n, 1))
-        fp = _native.filter_params(k["filter_type"], k["ksize_r"], k["C_r"], k["ksize_b"], k["C_b"],
-                                   k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"])
         deferred = []
         if self.chain_searches and not k["diagnostics"]:
             self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred)
@@ -738,14 +775,55 @@ class LaneTracker:
                 self._step(frames[i], first_try, k["n_tries"], k["diagnostics"], slot=i, have_mask=True, lazy=True,
                            annotate=annotate, defer=deferred)
         self._materialise_pending()      # the attributes describe the last frame, as after process()
-        if not annotate:
-            return [None] * n
-        # one overlay launch and one download for the whole window; a failed frame has no polygon (plain copy)
-        self._configure_overlay()
-        empty = np.zeros(0, np.int64)
-        annotated = self._annotate([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in deferred],
-                                   [d[2] for d in deferred])
-        return list(annotated)
+        return self._render_window(deferred, 0) if annotate else [None] * n
+
+    def process_stream(self, windows, annotate=True, **kwargs):
+        """Generator over consecutive windows of ONE video: `windows` yields arrays (n, H, W, 3); for each, what
+        `process_batch` would return is yielded, and the tracker's state after it is what `process()` frame by frame
+        leaves.  The context holds two windows side by side: while the searches of one window drain, the uploads and masks
+        of the next one are already running, so the device does not idle at window boundaries (a window's head and tail
+        cost about a quarter of a 256-frame `process_batch` call).  Do not call `process()` / `process_batch()` on this
+        tracker until the generator is exhausted or closed."""
+        k, first_try, fp = self._batch_arguments(kwargs)
+        if not (self.chain_searches and not k["diagnostics"]):
+            for w in windows:            # the frame-by-frame route has nothing to overlap
+                yield self.process_batch(w, annotate=annotate, **kwargs)
+            return
+        it = iter(windows)
+        cur = next(it, None)
+        if cur is None:
+            return
+        if self._in_stream:
+            raise RuntimeError("this tracker already runs a process_stream()")
+        cur = self._as_window(cur)
+        ctx = self._ctx
+        half, base, prefed = 0, 0, 0
+        self._in_stream = True
+        try:
+            while cur is not None:
+                nxt = next(it, None)
+                nxt = None if nxt is None else self._as_window(nxt)
+                n = cur.shape[0]
+                if n > half:             # first window, or a longer one than the halves hold (then nothing was fed ahead)
+                    self._materialise_pending()      # growing the context drops what is still on the device
+                    half = (n + 1) & ~1
+                    ctx.reserve(2 * half)
+                    base, prefed = 0, 0
+                other = half - base if base else half
+                ahead = (nxt, other) if nxt is not None and 0 < nxt.shape[0] <= half else None
+                deferred = []
+                fed = self._run_window_chained(cur, first_try, fp, k["n_tries"], annotate, deferred, base=base, prefed=prefed,
+                                               ahead=ahead) if n else 0
+                out = self._render_window(deferred, base) if (annotate and n) else [None] * n
+                if ahead is not None:
+                    base, prefed = other, fed
+                else:
+                    prefed = 0           # the next window starts from scratch (possibly after a resize)
+                cur = nxt
+                yield out
+            self._materialise_pending()  # the attributes describe the last frame, as after process()
+        finally:
+            self._in_stream = False
 
     def _step(self, img, first_try, n_tries, diagnostics, slot, have_mask, lazy, annotate, visualize_search=False,
               split_view=False, defer=None):

@@ -9,7 +9,7 @@ frames out.  Supported on both sides:
   * a `.npy` array of shape (n, H, W, 3) (memory-mapped, so a long clip never has to fit in RAM),
   * a headerless raw RGB24 file (`.rgb` / `.raw`; what `ffmpeg -pix_fmt rgb24 -f rawvideo` writes and reads).
 
-`process_frames()` feeds the tracker in windows through `LaneTracker.process_batch` (the stream pipeline:
+`process_frames()` feeds the tracker in windows through `LaneTracker.process_stream` (the stream pipeline:
 masks of the whole window batched ahead on the GPU, state machine trailing), which gives exactly the
 frames `process()` would return one by one.  `VideoFileClip` is the small part of moviepy's interface that
 `process_video.py` uses, on top of the same sources and sinks.
@@ -182,9 +182,9 @@ def process_frames(tracker, source, sink=None, window=64, **process_kwargs):
     annotated frames to `sink` if there is one.  Returns (frames, seconds)."""
     t0 = time.perf_counter()
     n = len(source)
-    for start in range(0, n, window):
-        frames = source.read(start, start + window)
-        out = tracker.process_batch(frames, annotate=sink is not None, **process_kwargs)
+    windows = (source.read(start, start + window) for start in range(0, n, window))
+    # process_stream: the uploads and masks of window k+1 run while the searches of window k drain
+    for out in tracker.process_stream(windows, annotate=sink is not None, **process_kwargs):
         if sink is not None:
             sink.write(np.stack(out, 0))
     return n, time.perf_counter() - t0
@@ -193,7 +193,7 @@ def process_frames(tracker, source, sink=None, window=64, **process_kwargs):
 class VideoFileClip:
     """The slice of `moviepy.editor.VideoFileClip` that process_video.py touches (`:41-44`), over frame
     sequences: `clip.fl_image(fn)` returns a lazy clip, `write_videofile(path)` evaluates it.  When `fn`
-    is the bound `process` of a `lane_tracker_amd` LaneTracker, evaluation goes through `process_batch`
+    is the bound `process` of a `lane_tracker_amd` LaneTracker, evaluation goes through `process_stream`
     windows instead of one call per frame (same frames, higher throughput)."""
 
     def __init__(self, filename, size=None, fps=25.0, _fn=None, _source=None):

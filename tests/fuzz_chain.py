@@ -65,26 +65,33 @@ def main(iters=20, seed=1, cal=None, verbose=True):
         seq, bat = LaneTracker(**cal, **ctor), LaneTracker(**cal, **ctor)
         bat.chain_chunk, bat.chain_depth = int(rng.choice([2, 8, 16, 32, 64])), int(rng.choice([1, 2, 3]))
         try:
-            lo = 0
+            wins, lo = [], 0
             while lo < n:
                 wlen = int(rng.integers(1, 40))
-                win = frames[lo:lo + wlen]
+                wins.append(frames[lo:lo + wlen])
+                lo += wlen
+            stream = bool(rng.random() < 0.5)              # process_stream (windows overlap on the device) or one process_batch per window
+            results = bat.process_stream(wins, annotate=annotate, **kw) if stream else (bat.process_batch(w, annotate=annotate, **kw) for w in wins)
+            lo = 0
+            for win, outs in zip(wins, results):
+                wlen = len(win)
                 outs_seq = [seq.process(f, **kw) for f in win]
-                outs = bat.process_batch(win, annotate=annotate, **kw)
                 s1, s2 = state(seq), state(bat)
                 if s1 != s2:
                     keys = [k for k in s1 if s1[k] != s2[k]]
-                    print("STATE MISMATCH it", it, "seed", seed, "window", lo, wlen, "keys", keys, ctor, kw, bat.chain_chunk, bat.chain_depth)
+                    print("STATE MISMATCH it", it, "seed", seed, "window", lo, wlen, "keys", keys, ctor, kw, bat.chain_chunk, bat.chain_depth, "stream" if stream else "batch")
                     bad += 1
                     break
                 if annotate and any(not np.array_equal(g, s) for g, s in zip(outs, outs_seq)):
-                    print("FRAME MISMATCH it", it, "seed", seed, "window", lo, wlen, ctor, kw)
+                    print("FRAME MISMATCH it", it, "seed", seed, "window", lo, wlen, ctor, kw, "stream" if stream else "batch")
                     bad += 1
                     break
                 lo += wlen
+            if stream:
+                results.close()
             if verbose:
-                print("it %d: %d frames, %d/%d valid, chunk %d depth %d%s" % (it, n, bat.success, bat.counter, bat.chain_chunk, bat.chain_depth,
-                                                                             ", annotated" if annotate else ""))
+                print("it %d: %d frames, %d/%d valid, chunk %d depth %d%s%s" % (it, n, bat.success, bat.counter, bat.chain_chunk, bat.chain_depth,
+                                                                               ", annotated" if annotate else "", ", stream" if stream else ""))
         finally:
             seq.close()
             bat.close()

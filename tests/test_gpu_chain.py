@@ -216,3 +216,40 @@ def test_chain_fuzz_short():
     window splits): process_batch == process() after every window."""
     import fuzz_chain
     assert fuzz_chain.main(iters=6, seed=11, verbose=False) == 0
+
+
+@pytest.mark.parametrize("annotate", [False, True])
+def test_process_stream_equals_process_frame_by_frame(annotate):
+    """Windows of one video through process_stream (the next window's uploads and masks run while the current one's searches
+    drain; two windows resident side by side) -- state after every window and the annotated frames equal process();
+    a longer window in the middle forces the context to grow; process() inside an active stream is refused."""
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    sizes = (24, 24, 10, 40, 24, 1, 24)
+    frames = _stream_with_failures(sum(sizes), 9, seed=37)
+    wins, lo = [], 0
+    for w in sizes:
+        wins.append(frames[lo:lo + w])
+        lo += w
+    seq, bat = LaneTracker(**cal), LaneTracker(**cal)
+    try:
+        gen = bat.process_stream(wins, annotate=annotate)
+        for k, (win, outs) in enumerate(zip(wins, gen)):
+            outs_seq = [seq.process(f) for f in win]
+            assert _state(bat) == _state(seq), k
+            assert np.array_equal(bat.left_x, seq.left_x) and np.array_equal(bat.right_y, seq.right_y)
+            assert bat.left_window_centroids == seq.left_window_centroids
+            if annotate:
+                assert all(np.array_equal(g, s) for g, s in zip(outs, outs_seq)), k
+            else:
+                assert outs == [None] * len(win)
+            if k == 1:
+                with pytest.raises(RuntimeError):
+                    bat.process(win[0])
+        assert next(gen, None) is None and not bat._in_stream
+        assert 0 < bat.success < bat.counter == sum(sizes)
+        bat.process(frames[0])                                 # usable again once the generator is exhausted
+    finally:
+        seq.close()
+        bat.close()

@@ -41,6 +41,7 @@ for name, cal in (("1280x720", calib.reference_calibration()), ("1920x1080", cal
         lt.process_batch(frames, annotate=False)
         r["process_batch_pageable_fps"] = n / t(lambda: lt.process_batch(frames, annotate=False), 3)
         r["process_batch_pinned_fps"] = n / t(lambda: lt.process_batch(pin, annotate=False), 3)
+        r["process_stream_pageable_fps"] = 6 * n / t(lambda: list(lt.process_stream([frames] * 6, annotate=False)), 2)
         r["success_ratio"] = lt.get_success_ratio()[0]
         bad = frames.copy()
         bad[9::10] = 0                                      # every tenth frame fails both tries
