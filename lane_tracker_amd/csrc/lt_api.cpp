@@ -129,8 +129,9 @@ struct lt_ctx {
     // what the slots' streams have written since the last full synchronisation, by slot range (masks, records): a chain
     // waits for the entries that touch its slots instead of for the tails of those streams
     struct Written { int lo, hi; hipEvent_t ev; };
-    Written written[32] = {};
-    unsigned written_count = 0;               // entries since the last full synchronisation (> 32: the ring has wrapped)
+    Written written[32] = {};                 // ring: entries [written_head, written_head + written_count) mod 32 are live
+    unsigned written_head = 0, written_count = 0;
+    bool written_overflow = false;            // 32 launches in flight at once: until the next full synchronisation a chain waits for stream tails
     hipStream_t search = nullptr;
     struct ChainTicket { int first, n; hipEvent_t done; };
     std::vector<ChainTicket> chains;          // not yet collected, oldest first
@@ -173,13 +174,24 @@ int sync_all(lt_ctx* c) {
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
     for (bool& b : c->frames_read_set) b = false;       // every reader enqueued so far is done
     c->chain_lo = c->chain_hi = 0;                      // and every chain
-    c->written_count = 0;
+    c->written_head = c->written_count = 0;
+    c->written_overflow = false;
     return LT_OK;
 }
 
 // kernels writing the masks / records of slots [lo, hi) have just been enqueued on `st`
 int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) {
-    lt_ctx::Written& w = c->written[c->written_count % 32];
+    // a long stream never synchronises the whole context: entries whose kernels have finished need no waiting for any more
+    while (c->written_count > 0 && hipEventQuery(c->written[c->written_head].ev) == hipSuccess) {
+        c->written_head = (c->written_head + 1) % 32;
+        --c->written_count;
+    }
+    if (c->written_count == 32) {             // 32 launches still in flight: give up the precise bookkeeping until the next sync
+        c->written_overflow = true;
+        c->written_head = (c->written_head + 1) % 32;
+        --c->written_count;
+    }
+    lt_ctx::Written& w = c->written[(c->written_head + c->written_count) % 32];
     if (!w.ev && hipEventCreateWithFlags(&w.ev, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(w.ev, st));
     w.lo = lo;
@@ -1518,11 +1530,13 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cancel), c->h_cancel, 0));
     }
     const int lo = seed ? first : first - 1, cnt = seed ? n : n + 1;     // with a device seed the seed record is collected too
-    if (c->written_count <= 32) {
-        // everything the slots' streams wrote into these slots since the last full synchronisation (their masks; the search
-        // that left the seed record); a seed record left by an earlier chain is ordered by the search stream itself
-        for (unsigned i = 0; i < c->written_count; ++i)
-            if (c->written[i].lo < lo + cnt && c->written[i].hi > lo) HIP_TRY(hipStreamWaitEvent(c->search, c->written[i].ev, 0));
+    if (!c->written_overflow) {
+        // everything the slots' streams wrote into these slots and may not have finished (their masks; the search that left
+        // the seed record); a seed record left by an earlier chain is ordered by the search stream itself
+        for (unsigned i = 0; i < c->written_count; ++i) {
+            const lt_ctx::Written& w = c->written[(c->written_head + i) % 32];
+            if (w.lo < lo + cnt && w.hi > lo) HIP_TRY(hipStreamWaitEvent(c->search, w.ev, 0));
+        }
     } else {
         rc = for_each_slice(c, lo, cnt, [&](hipStream_t st, int, int) {      // the ring has wrapped: wait for the streams' tails
             hipEvent_t e = next_order_event(c);
