@@ -511,7 +511,9 @@ class LaneTracker:
 
     # ---- the chained stream pipeline (reference :851-872, :1064-1128, :1178-1199) ------------
     chain_searches = True            # False: process_batch searches frame by frame (one record round trip per frame)
-    chain_chunk = 32                 # frames per upload + mask launch, and per chain, inside a window
+    chain_chunk = None               # frames per upload + mask launch, and per chain, inside a window; None: by window size --
+                                     # 32 for a stand-alone window (its head and tail count), half a window up to 128 in a
+                                     # stream of windows (the walking threshold kernels take launches of >= 80 frames)
     chain_depth = 3                  # chains kept in flight behind the one the host is checking
 
     def _valid_many(self, LF, RF):
@@ -556,7 +558,12 @@ class LaneTracker:
                       ignore_bottom=first_try[16], partial=partial)
         sp_sws = _native.search_params(**sws_kw)
         sp_band = _native.search_params(bandwidth=first_try[17], ignore_bottom=first_try[16], partial=partial)
-        chunk = max(2, int(self.chain_chunk)) & ~1
+        if self.chain_chunk is not None:
+            chunk = max(2, int(self.chain_chunk)) & ~1
+        elif self._in_stream:
+            chunk = max(32, min(128, (n // 2) & ~1))
+        else:
+            chunk = 32 if n < 512 else 64
         masked = prefed                  # stream positions [0, masked) have their upload + first-try mask enqueued;
                                          # positions >= n are frames of the next window
         head = prefed == 0 and base == 0 and ahead is None or self.counter == 0

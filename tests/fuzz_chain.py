@@ -63,7 +63,7 @@ def main(iters=20, seed=1, cal=None, verbose=True):
                   window_height=int(rng.choice([40, 40, 118])), no_success_limit=int(rng.choice([8, 3, 50])))
         annotate = bool(rng.random() < 0.3)
         seq, bat = LaneTracker(**cal, **ctor), LaneTracker(**cal, **ctor)
-        bat.chain_chunk, bat.chain_depth = int(rng.choice([2, 8, 16, 32, 64])), int(rng.choice([1, 2, 3]))
+        bat.chain_chunk, bat.chain_depth = (int(rng.choice([2, 8, 16, 32, 64, 0])) or None), int(rng.choice([1, 2, 3]))
         try:
             wins, lo = [], 0
             while lo < n:
@@ -90,7 +90,7 @@ def main(iters=20, seed=1, cal=None, verbose=True):
             if stream:
                 results.close()
             if verbose:
-                print("it %d: %d frames, %d/%d valid, chunk %d depth %d%s%s" % (it, n, bat.success, bat.counter, bat.chain_chunk, bat.chain_depth,
+                print("it %d: %d frames, %d/%d valid, chunk %s depth %d%s%s" % (it, n, bat.success, bat.counter, bat.chain_chunk, bat.chain_depth,
                                                                                ", annotated" if annotate else "", ", stream" if stream else ""))
         finally:
             seq.close()
