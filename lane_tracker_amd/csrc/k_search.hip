@@ -1131,6 +1131,10 @@ __global__ __launch_bounds__(NT) void k_band_chain2(const uint8_t* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double carry[8];
     __shared__ int s_stop;
+    // One workgroup, serial in the frames, usually sharing its CU with waves of the mask chain of later frames: whatever it
+    // loses in issue arbitration lengthens every frame of the stream, so its four waves ask for the highest wave priority.
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x == 0) s_stop = 0;
     if (threadIdx.x < 6)
         carry[threadIdx.x] = seed.by_value ? seed.c[threadIdx.x]
                                            : (threadIdx.x < 3 ? seed_rec->left_coeffs[threadIdx.x] : seed_rec->right_coeffs[threadIdx.x - 3]);
@@ -1141,11 +1145,14 @@ __global__ __launch_bounds__(NT) void k_band_chain2(const uint8_t* __restrict__ 
         // the coefficients the frame reads must not change under it: copy them out of the carry slot first
         __shared__ double pc[6];
         if (threadIdx.x < 6) pc[threadIdx.x] = carry[threadIdx.x];
-        // the host gave up on this speculation (lt_band_fit_chain_cancel: page-locked host word, read once per frame)
-        if (threadIdx.x == 6) s_stop = __atomic_load_n(cancel_epoch, __ATOMIC_RELAXED) > my_epoch ? 1 : 0;
         __syncthreads();
         if (s_stop) break;
+        // "the host gave up on this speculation" (lt_band_fit_chain_cancel) is a page-locked host word: the read crosses the
+        // bus (~2 us), so it is issued here and looked at after the frame -- a cancelled chain runs one frame further
+        int epoch_now = 0;
+        if (threadIdx.x == 6) epoch_now = __atomic_load_n(cancel_epoch, __ATOMIC_RELAXED);
         band_fit2_frame<BITS>(smem, f, masks, mask_stride, mb, g, pc, pix_all, recs, nq, carry);
+        if (threadIdx.x == 6) s_stop = epoch_now > my_epoch ? 1 : 0;
         __syncthreads();
     }
     for (int i = f + (int)threadIdx.x; i < n; i += NT) {

@@ -117,21 +117,26 @@ struct lt_ctx {
     // ordering events of lt_upload_frame_rows_async (a ring: an event is reused long after its waits were enqueued)
     std::vector<hipEvent_t> order_events;
     size_t order_next = 0;
-    // The kernels that READ the camera frames (d_frames): the undistortion of every slice's stream ([0..7]) and the overlay
-    // ([8]).  A stream-ordered upload into slots of a slice waits for these -- not for the tail of the stream, so the rows of
-    // the next frames cross the bus while the rest of the mask chain of the previous ones still runs.
-    hipEvent_t frames_read[9] = {};
-    bool frames_read_set[9] = {};
+    // Slot-range bookkeeping of work in flight on the slots' streams, so that other streams wait for exactly what they
+    // depend on instead of for the tails of those streams:
+    //   readers -- kernels that READ the camera frames (undistortion, overlay): a stream-ordered upload into slots waits for
+    //              the readers of those slots only, so the rows of later frames cross the bus while earlier ones are processed;
+    //   writers -- kernels that wrote masks / records: a chained search waits for the writers of its own slots only.
+    // A ring of 32 entries each; finished entries are dropped as new ones arrive (a long stream never synchronises the whole
+    // context); with 32 launches in flight at once the ring gives up (`overflow`) and waiters fall back to stream tails
+    // until the next full synchronisation.
+    struct RangeEvents {
+        struct Entry { int lo, hi; hipEvent_t ev; };
+        Entry e[32] = {};
+        unsigned head = 0, count = 0;
+        bool overflow = false;
+        void reset() { head = count = 0; overflow = false; }
+    };
+    RangeEvents readers, writers;
     // The chained band search of a stream (lt_band_fit_chain_run) is one workgroup walking many frames: it runs on a stream
     // of its own, beside the mask chains of later frames on the slots' streams.  A chain leaves its records in page-locked
     // host memory behind an event (lt_band_fit_chain_collect waits for that event only, not for the device).  Work on the
     // slots' streams that touches slots of a chain still in flight waits for it (for_each_slice).
-    // what the slots' streams have written since the last full synchronisation, by slot range (masks, records): a chain
-    // waits for the entries that touch its slots instead of for the tails of those streams
-    struct Written { int lo, hi; hipEvent_t ev; };
-    Written written[32] = {};                 // ring: entries [written_head, written_head + written_count) mod 32 are live
-    unsigned written_head = 0, written_count = 0;
-    bool written_overflow = false;            // 32 launches in flight at once: until the next full synchronisation a chain waits for stream tails
     hipStream_t search = nullptr;
     struct ChainTicket { int first, n; hipEvent_t done; };
     std::vector<ChainTicket> chains;          // not yet collected, oldest first
@@ -172,48 +177,45 @@ int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
-    for (bool& b : c->frames_read_set) b = false;       // every reader enqueued so far is done
+    c->readers.reset();                                 // every reader / writer enqueued so far is done
+    c->writers.reset();
     c->chain_lo = c->chain_hi = 0;                      // and every chain
-    c->written_head = c->written_count = 0;
-    c->written_overflow = false;
     return LT_OK;
 }
 
-// kernels writing the masks / records of slots [lo, hi) have just been enqueued on `st`
-int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) {
-    // a long stream never synchronises the whole context: entries whose kernels have finished need no waiting for any more
-    while (c->written_count > 0 && hipEventQuery(c->written[c->written_head].ev) == hipSuccess) {
-        c->written_head = (c->written_head + 1) % 32;
-        --c->written_count;
+// work touching slots [lo, hi) has just been enqueued on `st`
+int note_range(lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi) {
+    while (r.count > 0 && hipEventQuery(r.e[r.head].ev) == hipSuccess) {   // finished: nobody has to wait for it any more
+        r.head = (r.head + 1) % 32;
+        --r.count;
     }
-    if (c->written_count == 32) {             // 32 launches still in flight: give up the precise bookkeeping until the next sync
-        c->written_overflow = true;
-        c->written_head = (c->written_head + 1) % 32;
-        --c->written_count;
+    if (r.count == 32) {
+        r.overflow = true;
+        r.head = (r.head + 1) % 32;
+        --r.count;
     }
-    lt_ctx::Written& w = c->written[(c->written_head + c->written_count) % 32];
+    lt_ctx::RangeEvents::Entry& w = r.e[(r.head + r.count) % 32];
     if (!w.ev && hipEventCreateWithFlags(&w.ev, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(w.ev, st));
     w.lo = lo;
     w.hi = hi;
-    ++c->written_count;
+    ++r.count;
     return LT_OK;
 }
-
-// a kernel reading d_frames has just been enqueued on `st` (idx 8: the overlay, whatever its stream)
-int mark_frames_read(lt_ctx* c, hipStream_t st, bool overlay = false) {
-    int idx = 8;
-    if (!overlay) {
-        idx = 0;
-        for (int i = 0; i < (int)c->streams.size() && i < 8; ++i)
-            if (c->streams[i] == st) idx = i;
+// `waiter` waits for the entries that touch slots [lo, hi); *precise = false if the ring has overflowed (the caller then waits
+// for stream tails)
+int wait_range(const lt_ctx::RangeEvents& r, hipStream_t waiter, int lo, int hi, bool* precise) {
+    *precise = !r.overflow;
+    if (r.overflow) return LT_OK;
+    for (unsigned i = 0; i < r.count; ++i) {
+        const lt_ctx::RangeEvents::Entry& w = r.e[(r.head + i) % 32];
+        if (w.lo < hi && w.hi > lo) HIP_TRY(hipStreamWaitEvent(waiter, w.ev, 0));
     }
-    if (!c->frames_read[idx] && hipEventCreateWithFlags(&c->frames_read[idx], hipEventDisableTiming) != hipSuccess)
-        return fail(LT_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(c->frames_read[idx], st));
-    c->frames_read_set[idx] = true;
     return LT_OK;
 }
+int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) { return note_range(c->writers, st, lo, hi); }
+
+
 
 // Slot -> stream mapping is fixed (contiguous slices of the capacity), so consecutive stages of one
 // slot stay ordered on one stream while different slices overlap: the latency-bound search of one
@@ -701,8 +703,8 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_xpos);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
-    for (auto e : c->frames_read) if (e) (void)hipEventDestroy(e);
-    for (auto& w : c->written) if (w.ev) (void)hipEventDestroy(w.ev);
+    for (auto& w : c->readers.e) if (w.ev) (void)hipEventDestroy(w.ev);
+    for (auto& w : c->writers.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
@@ -837,15 +839,20 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     if (!frames) return fail(LT_ERR_INVALID, "null frames");
     if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
     if ((rc = set_device(c))) return rc;
-    // the copy waits for the kernels that still read these slots' camera rows -- the undistortion launches of the slices'
-    // streams and the overlay (mark_frames_read) -- not for the rest of their mask chains
-    rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
-        for (int i = 0; i < (int)c->streams.size() && i < 8; ++i)
-            if (c->streams[i] == st && c->frames_read_set[i]) HIP_TRY(hipStreamWaitEvent(c->copy, c->frames_read[i], 0));
-        return (int)LT_OK;
-    });
-    if (rc) return rc;
-    if (c->frames_read_set[8]) HIP_TRY(hipStreamWaitEvent(c->copy, c->frames_read[8], 0));
+    // the copy waits for the kernels that still read these slots' camera rows (the undistortion launches over these slots, the
+    // overlay) -- not for the rest of their mask chains, and not for launches over other slots
+    bool precise = true;
+    if ((rc = wait_range(c->readers, c->copy, first, first + n, &precise))) return rc;
+    if (!precise) {
+        rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
+            hipEvent_t e = next_order_event(c);
+            if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e, st));
+            HIP_TRY(hipStreamWaitEvent(c->copy, e, 0));
+            return (int)LT_OK;
+        });
+        if (rc) return rc;
+    }
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                              (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->copy));
@@ -1128,7 +1135,7 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
     HIP_TRY(hipGetLastError());
-    return mark_frames_read(c, c->stream, true);
+    return note_range(c->readers, c->stream, first, first + n);
 }
 
 int lt_overlay_set_font(lt_ctx* c, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
@@ -1394,7 +1401,7 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
         { StageScope t(c, ST_UNDISTORT, st);
           launch_undistort_rows(st, c->d_frames + (size_t)f0 * c->frame_bytes, c->frame_bytes, c->d_uxy, c->d_ufrac,
                                 c->fe, c->d_und, c->und_px, f0, m); }
-        { int mrc = mark_frames_read(c, st); if (mrc) return mrc; }
+        { int mrc = note_range(c->readers, st, f0, f0 + m); if (mrc) return mrc; }
         { StageScope t(c, ST_WARP_SPLIT, st);
           launch_warp_split(st, c->d_und, c->und_px, f0, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
                             c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
@@ -1530,15 +1537,12 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cancel), c->h_cancel, 0));
     }
     const int lo = seed ? first : first - 1, cnt = seed ? n : n + 1;     // with a device seed the seed record is collected too
-    if (!c->written_overflow) {
-        // everything the slots' streams wrote into these slots and may not have finished (their masks; the search that left
-        // the seed record); a seed record left by an earlier chain is ordered by the search stream itself
-        for (unsigned i = 0; i < c->written_count; ++i) {
-            const lt_ctx::Written& w = c->written[(c->written_head + i) % 32];
-            if (w.lo < lo + cnt && w.hi > lo) HIP_TRY(hipStreamWaitEvent(c->search, w.ev, 0));
-        }
-    } else {
-        rc = for_each_slice(c, lo, cnt, [&](hipStream_t st, int, int) {      // the ring has wrapped: wait for the streams' tails
+    bool precise = true;
+    // everything the slots' streams wrote into these slots and may not have finished (their masks; the search that left the
+    // seed record); a seed record left by an earlier chain is ordered by the search stream itself
+    if ((rc = wait_range(c->writers, c->search, lo, lo + cnt, &precise))) return rc;
+    if (!precise) {
+        rc = for_each_slice(c, lo, cnt, [&](hipStream_t st, int, int) {      // the ring has overflowed: wait for the streams' tails
             hipEvent_t e = next_order_event(c);
             if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
             HIP_TRY(hipEventRecord(e, st));
