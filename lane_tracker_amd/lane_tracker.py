@@ -326,7 +326,8 @@ class LaneTracker:
         """Curve radius in metres, the reference's integers (:530-549).  The reference refits the pixels in metric
         units with two more np.polyfit calls.  A least-squares parabola is equivariant under axis scaling, so the
         metric coefficients follow from the pixel fit (a_m = a*mpph/mppv^2, b_m = b*mpph/mppv) up to floating-point
-        rounding (~1e-12 relative); only when that value lies so close to an integer that `int()` could truncate
+        rounding (<= 1.6e-10 relative over 3000 random lanes, nearly straight ones included); only when that value lies within
+        1e-8 relative of an integer, so that `int()` could truncate
         differently are the lane pixels fetched and refitted exactly as upstream does."""
         lf, rf = self.fit_poly()
         y_eval = self.warped_size[1]
@@ -336,7 +337,7 @@ class LaneTracker:
         radii = []
         for side, c in enumerate((lf, rf)):
             val = radius_of((c[0] * self.mpph / (self.mppv ** 2), c[1] * self.mpph / self.mppv))
-            if np.isfinite(val) and abs(val - np.rint(val)) <= 1e-7 * max(1.0, abs(val)):
+            if np.isfinite(val) and abs(val - np.rint(val)) <= 1e-8 * max(1.0, abs(val)):
                 ys, xs = (self.left_y, self.left_x) if side == 0 else (self.right_y, self.right_x)
                 val = radius_of(np.polyfit(np.asarray(ys) * self.mppv, np.asarray(xs) * self.mpph, 2))
             radii.append(int(val))
