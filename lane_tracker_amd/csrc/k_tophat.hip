@@ -415,6 +415,11 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
             for_each_const([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (fused_stage_of_update<SE>(j) == decltype(stage)::value) {
+#ifdef LT_PROBE_SKIP_CENTRE   // timing probe (WRONG results): the ten centre-row updates of 55x55 (half-width 27 on both rows) become moves --
+                    // an upper bound for what pre-reducing those rows with a sliding minimum could save (lead ii)
+                    if constexpr (j >= 22 && j <= 31) An[j] = A[j + 2];
+                    else
+#endif
                     An[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
                     asm volatile("" : "+v"(An[j]));   // pins the update into its stage: the optimiser would sink it below every read
                 }
