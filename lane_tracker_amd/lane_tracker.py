@@ -567,7 +567,7 @@ class LaneTracker:
             chunk = 32 if n < 512 else 64
         masked = prefed                  # stream positions [0, masked) have their upload + first-try mask enqueued;
                                          # positions >= n are frames of the next window
-        head = prefed == 0 and base == 0 and ahead is None or self.counter == 0
+        head = not self._in_stream       # a stand-alone window: nothing is in flight when it starts
 
         def span(at):                    # frames per launch at position `at`: short at the head of a stand-alone window (the
             return min(chunk, max(16, at & ~1)) if head else chunk   # first records come back early), then `chunk`
@@ -817,7 +817,7 @@ class LaneTracker:
                     half = (n + 1) & ~1
                     ctx.reserve(2 * half)
                     base, prefed = 0, 0
-                other = half - base if base else half
+                other = 0 if base else half      # the half of the context the next window will live in
                 ahead = (nxt, other) if nxt is not None and 0 < nxt.shape[0] <= half else None
                 deferred = []
                 fed = self._run_window_chained(cur, first_try, fp, k["n_tries"], annotate, deferred, base=base, prefed=prefed,
