@@ -236,6 +236,11 @@ int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const
                            int16_t* spans);
 /* annotated frames, RGB interleaved, n * img_h * img_w * 3 bytes */
 int  lt_download_overlay(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+/* The same copy enqueued behind the slots' overlay work without waiting: `out` (page-locked memory from lt_host_alloc, or
+ * the copy is not asynchronous) holds the frames after the next lt_sync / lt_download_*.  lt_overlay_run and lt_overlay_text
+ * themselves only enqueue (their staging is per slot), so a window can be rendered and downloaded in pieces while later
+ * frames are still searched; a call over slots whose previous overlay is still in flight waits for that one. */
+int  lt_download_overlay_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
 /* Page-locked host memory for buffers passed to the upload / download entry points (copies from or to pageable
  * memory run at a fraction of the PCIe rate).  Needs a GPU; lt_host_free(NULL) is a no-op.  The reference has no
  * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */

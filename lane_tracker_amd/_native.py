@@ -91,6 +91,7 @@ _SIGNATURES = {
     "lt_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "lt_download_overlay": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "lt_download_overlay_async": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_bev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "lt_host_free": (C.c_int, [_P]),
@@ -426,6 +427,13 @@ class Context:
         out = pinned_empty((n, self.img_h, self.img_w, 3))
         _check(self.lib.lt_download_overlay(self._h, first, n, out.ctypes.data))
         return out
+
+    def download_overlay_async(self, out, first=0):
+        """Enqueue the copy of the annotated frames of slots first .. first+len(out)-1 into `out` (a C-contiguous u8 array
+        (n, H, W, 3), from pinned_empty()); valid after the next sync()."""
+        if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.shape[1:] != (self.img_h, self.img_w, 3):
+            raise ValueError("download_overlay_async needs a C-contiguous uint8 array (n, H, W, 3)")
+        _check(self.lib.lt_download_overlay_async(self._h, first, out.shape[0], out.ctypes.data))
 
     def download_bev(self, n, first=0):
         out = pinned_empty((n, self.warp_h, self.warp_w, 3))

@@ -106,14 +106,25 @@ struct lt_ctx {
     bool have_overlay = false;
     int16_t* d_spans = nullptr;       // [slot][warp_h] (lo, hi)
     uint8_t* d_annot = nullptr;
-    std::vector<int16_t> h_spans;
+    // Page-locked staging with one region PER SLOT (row intervals, text lines, glyph positions), so that an overlay call only
+    // enqueues copies and kernels: calls over disjoint slots never wait for each other (the stream pipeline renders a window
+    // in pieces while later frames are still searched).  A call over slots whose previous overlay may still be in flight
+    // waits for that one first (overlay_lo / overlay_hi / overlay_done).
+    int16_t* h_spans = nullptr;       // [capacity][warp_h * 2]
+    int h_spans_cap = 0;
+    int overlay_lo = 0, overlay_hi = 0;
+    hipEvent_t overlay_done = nullptr;
+    hipEvent_t rest_done = nullptr;   // end of the most recent lt_upload_frame_rest on the copy stream
+    bool rest_pending = false;
     // text: glyph atlas (set once) and the per-slot lines of the current call
     uint8_t *d_atlas = nullptr, *d_advance = nullptr, *d_lines = nullptr;
     int16_t* d_xpos = nullptr;
     std::vector<uint8_t> h_advance;
-    std::vector<int16_t> h_xpos;
+    uint8_t* h_lines = nullptr;       // page-locked, [text_slots][text_per_slot]
+    int16_t* h_xpos = nullptr;
     int font_first = 0, font_glyphs = 0, font_gw = 0, font_gh = 0;
-    size_t text_cap = 0;
+    size_t text_per_slot = 0;         // characters per slot the text buffers hold (n_lines * line_len of the largest call)
+    int text_slots = 0;
     // ordering events of lt_upload_frame_rows_async (a ring: an event is reused long after its waits were enqueued)
     std::vector<hipEvent_t> order_events;
     size_t order_next = 0;
@@ -177,6 +188,8 @@ int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
+    c->overlay_lo = c->overlay_hi = 0;                  // every overlay, every copy of the rest rows
+    c->rest_pending = false;
     c->readers.reset();                                 // every reader / writer enqueued so far is done
     c->writers.reset();
     c->chain_lo = c->chain_hi = 0;                      // and every chain
@@ -703,6 +716,11 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_xpos);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
+    if (c->overlay_done) (void)hipEventDestroy(c->overlay_done);
+    if (c->rest_done) (void)hipEventDestroy(c->rest_done);
+    if (c->h_spans) (void)hipHostFree(c->h_spans);
+    if (c->h_lines) (void)hipHostFree(c->h_lines);
+    if (c->h_xpos) (void)hipHostFree(c->h_xpos);
     for (auto& w : c->readers.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& w : c->writers.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
@@ -865,6 +883,13 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     });
 }
 
+static int rest_mark(lt_ctx* c) {      // the overlay (on the context's first stream) waits for this before it reads the frames
+    if (!c->rest_done && hipEventCreateWithFlags(&c->rest_done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(c->rest_done, c->copy));
+    c->rest_pending = true;
+    return LT_OK;
+}
+
 int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -878,14 +903,14 @@ int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
     uint8_t* dst = c->d_frames + (size_t)first * c->frame_bytes;
     if (c->cam_r1 <= c->cam_r0) {
         HIP_TRY(hipMemcpyAsync(dst, frames, (size_t)n * c->frame_bytes, hipMemcpyHostToDevice, c->copy));
-        return LT_OK;
+        return rest_mark(c);
     }
     if (head)
         HIP_TRY(hipMemcpy2DAsync(dst, c->frame_bytes, frames, c->frame_bytes, head, (size_t)n, hipMemcpyHostToDevice, c->copy));
     if (tail0 < c->frame_bytes)
         HIP_TRY(hipMemcpy2DAsync(dst + tail0, c->frame_bytes, frames + tail0, c->frame_bytes, c->frame_bytes - tail0, (size_t)n,
                                  hipMemcpyHostToDevice, c->copy));
-    return LT_OK;
+    return rest_mark(c);
 }
 
 int lt_upload_masks(lt_ctx* c, const uint8_t* masks, int first, int n) {
@@ -1102,6 +1127,24 @@ int lt_overlay_configure(lt_ctx* c, const double* Minv) {
     return LT_OK;
 }
 
+// An overlay call is about to write the staging regions and annotated frames of slots [first, first + n): wait for the
+// previous overlay work if it touches the same slots (it may still be reading those regions), and widen the busy range.
+static int overlay_claim(lt_ctx* c, int first, int n) {
+    if (c->overlay_hi > c->overlay_lo && first < c->overlay_hi && first + n > c->overlay_lo && c->overlay_done) {
+        HIP_TRY(hipEventSynchronize(c->overlay_done));
+        c->overlay_lo = c->overlay_hi = 0;
+    }
+    if (c->overlay_hi <= c->overlay_lo) { c->overlay_lo = first; c->overlay_hi = first + n; }
+    else { c->overlay_lo = std::min(c->overlay_lo, first); c->overlay_hi = std::max(c->overlay_hi, first + n); }
+    return LT_OK;
+}
+static int overlay_mark(lt_ctx* c) {
+    if (!c->overlay_done && hipEventCreateWithFlags(&c->overlay_done, hipEventDisableTiming) != hipSuccess)
+        return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(c->overlay_done, c->stream));
+    return LT_OK;
+}
+
 int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                    const int32_t* right_yx, double alpha) {
     int rc = check_slots(c, first, n);
@@ -1120,21 +1163,31 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     const int bh = c->calib.warp_h;
     if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
     if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
-    if ((rc = sync_all(c))) return rc;     // the previous call's staging buffer is free again
-    c->h_spans.resize((size_t)n * bh * 2);
+    if ((rc = overlay_claim(c, first, n))) return rc;
+    if (c->h_spans_cap < c->capacity) {
+        if ((rc = sync_all(c))) return rc;
+        if (c->h_spans) (void)hipHostFree(c->h_spans);
+        c->h_spans = nullptr;
+        c->h_spans_cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
+        c->h_spans_cap = c->capacity;
+    }
+    int16_t* hs = c->h_spans + (size_t)first * bh * 2;
     size_t ol = 0, orr = 0;
     for (int i = 0; i < n; ++i) {
-        lane_polygon_spans(c->h_spans.data() + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
+        lane_polygon_spans(hs + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
                            right_yx ? right_yx + 2 * orr : nullptr, right_n[i]);
         ol += (size_t)left_n[i];
         orr += (size_t)right_n[i];
     }
-    HIP_TRY(hipMemcpyAsync(c->d_spans + (size_t)first * bh * 2, c->h_spans.data(), c->h_spans.size() * sizeof(int16_t),
-                           hipMemcpyHostToDevice, c->stream));
+    // the rows of the frame the path does not read came on the copy stream (lt_upload_frame_rest): the overlay is their reader
+    if (c->rest_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->rest_done, 0));
+    HIP_TRY(hipMemcpyAsync(c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     launch_overlay_lane(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
     HIP_TRY(hipGetLastError());
+    if ((rc = overlay_mark(c))) return rc;
     return note_range(c->readers, c->stream, first, first + n);
 }
 
@@ -1170,36 +1223,50 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
     if (n == 0 || n_lines <= 0 || line_len <= 0) return LT_OK;
     if (!lines) return fail(LT_ERR_INVALID, "null text");
     if ((rc = set_device(c))) return rc;
-    const size_t count = (size_t)n * n_lines * line_len;
-    if ((rc = sync_all(c))) return rc;     // the previous call's staging buffers are free again
-    if (count > c->text_cap) {
+    const size_t per = (size_t)n_lines * line_len;
+    if (per > c->text_per_slot || c->text_slots < c->capacity) {      // (re)size the per-slot text buffers: rare, synchronises
+        if ((rc = sync_all(c))) return rc;
+        const size_t per_new = std::max(per, c->text_per_slot), total = per_new * (size_t)c->capacity;
         dev_free(c->d_lines);
         dev_free(c->d_xpos);
-        c->text_cap = 0;
-        if ((rc = dev_alloc(&c->d_lines, count))) return rc;
-        if ((rc = dev_alloc(&c->d_xpos, count))) return rc;
-        c->text_cap = count;
+        if (c->h_lines) (void)hipHostFree(c->h_lines);
+        if (c->h_xpos) (void)hipHostFree(c->h_xpos);
+        c->h_lines = nullptr;
+        c->h_xpos = nullptr;
+        c->text_per_slot = 0;
+        c->text_slots = 0;
+        if ((rc = dev_alloc(&c->d_lines, total))) return rc;
+        if ((rc = dev_alloc(&c->d_xpos, total))) return rc;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_lines), total, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_xpos), total * sizeof(int16_t), hipHostMallocDefault));
+        c->text_per_slot = per_new;
+        c->text_slots = c->capacity;
     }
-    c->h_xpos.resize(count);
+    if ((rc = overlay_claim(c, first, n))) return rc;
+    // this call's lines are packed (n_lines * line_len per slot) at the slots' own positions in the per-slot buffers
+    uint8_t* hl = c->h_lines + (size_t)first * per;
+    int16_t* hx = c->h_xpos + (size_t)first * per;
+    std::memcpy(hl, lines, (size_t)n * per);
     for (size_t l = 0; l < (size_t)n * n_lines; ++l) {     // left edge of every character: running sum of advances
         int x = x0;
         bool ended = false;
         for (int k = 0; k < line_len; ++k) {
             const unsigned char ch = (unsigned char)lines[l * line_len + k];
             ended = ended || ch == 0;
-            c->h_xpos[l * line_len + k] = (int16_t)std::min(x, 32767);
+            hx[l * line_len + k] = (int16_t)std::min(x, 32767);
             const int g = (int)ch - c->font_first;
             if (!ended && g >= 0 && g < c->font_glyphs) x += c->h_advance[(size_t)g];
         }
     }
-    HIP_TRY(hipMemcpyAsync(c->d_lines, lines, count, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->d_xpos, c->h_xpos.data(), count * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));              // `lines` is caller memory
+    uint8_t* dl = c->d_lines + (size_t)first * per;
+    int16_t* dx = c->d_xpos + (size_t)first * per;
+    HIP_TRY(hipMemcpyAsync(dl, hl, (size_t)n * per, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dx, hx, (size_t)n * per * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     launch_overlay_text(c->stream, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
-                        c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, c->d_lines, c->d_xpos,
+                        c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, dl, dx,
                         n_lines, line_len, y0, step, n);
     HIP_TRY(hipGetLastError());
-    return LT_OK;
+    return overlay_mark(c);
 }
 
 // Page-locked host memory for the buffers a caller hands to the upload / download entry points: a copy from or to
@@ -1230,6 +1297,17 @@ int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
     if (rc) return rc;
     if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay before lt_overlay_run");
     return download(c, c->d_annot + (size_t)first * c->frame_bytes, out, (size_t)n * c->frame_bytes);
+}
+
+int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay_async before lt_overlay_run");
+    if (n == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->stream));
+    return overlay_mark(c);
 }
 
 int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {

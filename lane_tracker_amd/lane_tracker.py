@@ -544,7 +544,7 @@ class LaneTracker:
         norm2 = np.abs(slope(LF, y3) - slope(RF, y3))
         return ~dist_bad & ~((norm1 >= lim['thresh']) | (norm2 >= lim['thresh']))
 
-    def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred, base=0, prefed=0, ahead=None):
+    def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred, base=0, prefed=0, ahead=None, flush=None):
         """The frame loop of a window with the searches chained on the device.  State after every frame, and every
         attribute at the end, equal those of `_step` frame by frame (tests/test_gpu_chain.py, tests/fuzz_chain.py).
         The window's frames live in slots base .. base+n-1; the first `prefed` of them already have their upload and
@@ -675,6 +675,8 @@ class LaneTracker:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
                                      self._lane_text()))
             i = first + g
+            if flush is not None:
+                flush(False)             # render and download what has been committed so far, under the searches still running
             if g < L:
                 # frame i: first try failed (or needs the host's exact fit): the ordinary route, second try included;
                 # whatever was chained behind it is dropped (and told to stop)
@@ -684,6 +686,8 @@ class LaneTracker:
                 self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate,
                            defer=deferred)
                 i += 1
+        if flush is not None:
+            flush(True)
         return max(0, masked - n)
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
@@ -737,6 +741,28 @@ class LaneTracker:
             raise ValueError("expected frames of shape (n, H, W, 3)")
         return frames
 
+    def _window_renderer(self, deferred, base, n, piece=32):
+        """(flush, out) for a window of n frames in slots base..: `flush(force)` renders the frames committed to `deferred`
+        since the last call -- overlay and text kernels, then the copy into the page-locked `out`, all only enqueued -- once
+        at least `piece` of them have gathered (or `force`); `out` is complete after the next sync."""
+        self._configure_overlay()
+        ctx = self._ctx
+        out = _native.pinned_empty((n, ctx.img_h, ctx.img_w, 3))
+        empty = np.zeros(0, np.int64)
+        done = [0]
+
+        def flush(force):
+            lo, hi = done[0], len(deferred)
+            if hi <= lo or (hi - lo < piece and not force):
+                return
+            part = deferred[lo:hi]
+            ctx.overlay_run([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in part], first=base + lo)
+            if self._have_font:
+                ctx.overlay_text([d[2] for d in part], first=base + lo)
+            ctx.download_overlay_async(out[lo:hi], first=base + lo)
+            done[0] = hi
+        return flush, out
+
     def _render_window(self, deferred, base):
         """One overlay launch and one download for a whole window; a failed frame has no polygon (plain copy)."""
         self._configure_overlay()
@@ -773,7 +799,13 @@ class LaneTracker:
         ctx.reserve(max(n, 1))
         deferred = []
         if self.chain_searches and not k["diagnostics"]:
-            self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred)
+            flush, out = self._window_renderer(deferred, 0, n) if (annotate and n) else (None, None)
+            self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred, flush=flush)
+            self._materialise_pending()  # the attributes describe the last frame, as after process() (also waits for `out`)
+            if out is not None:
+                ctx.sync()
+                return list(out)
+            return [None] * n
         else:
             ctx.upload_frame_rows(frames)        # the camera rows the path reads; the rest only if frames are annotated
             ctx.mask_run(n, fp)
@@ -820,9 +852,14 @@ class LaneTracker:
                 other = 0 if base else half      # the half of the context the next window will live in
                 ahead = (nxt, other) if nxt is not None and 0 < nxt.shape[0] <= half else None
                 deferred = []
+                flush, frames_out = self._window_renderer(deferred, base, n) if (annotate and n) else (None, None)
                 fed = self._run_window_chained(cur, first_try, fp, k["n_tries"], annotate, deferred, base=base, prefed=prefed,
-                                               ahead=ahead) if n else 0
-                out = self._render_window(deferred, base) if (annotate and n) else [None] * n
+                                               ahead=ahead, flush=flush) if n else 0
+                if frames_out is not None:
+                    ctx.sync()           # the last pieces of this window's frames are on their way (the next window's head runs too)
+                    out = list(frames_out)
+                else:
+                    out = [None] * n
                 if ahead is not None:
                     base, prefed = other, fed
                 else:
