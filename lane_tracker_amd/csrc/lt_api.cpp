@@ -112,8 +112,8 @@ struct lt_ctx {
     // waits for that one first (overlay_lo / overlay_hi / overlay_done).
     int16_t* h_spans = nullptr;       // [capacity][warp_h * 2]
     int h_spans_cap = 0;
-    int overlay_lo = 0, overlay_hi = 0;
-    hipEvent_t overlay_done = nullptr;
+    struct StagingBusy { int lo = 0, hi = 0; hipEvent_t done = nullptr; };   // slots whose staging region a copy may still read
+    StagingBusy spans_busy, text_busy;
     hipEvent_t rest_done = nullptr;   // end of the most recent lt_upload_frame_rest on the copy stream
     bool rest_pending = false;
     // text: glyph atlas (set once) and the per-slot lines of the current call
@@ -188,7 +188,8 @@ int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
-    c->overlay_lo = c->overlay_hi = 0;                  // every overlay, every copy of the rest rows
+    c->spans_busy.lo = c->spans_busy.hi = 0;            // every overlay, every copy of the rest rows
+    c->text_busy.lo = c->text_busy.hi = 0;
     c->rest_pending = false;
     c->readers.reset();                                 // every reader / writer enqueued so far is done
     c->writers.reset();
@@ -716,7 +717,8 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_xpos);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
-    if (c->overlay_done) (void)hipEventDestroy(c->overlay_done);
+    if (c->spans_busy.done) (void)hipEventDestroy(c->spans_busy.done);
+    if (c->text_busy.done) (void)hipEventDestroy(c->text_busy.done);
     if (c->rest_done) (void)hipEventDestroy(c->rest_done);
     if (c->h_spans) (void)hipHostFree(c->h_spans);
     if (c->h_lines) (void)hipHostFree(c->h_lines);
@@ -1127,21 +1129,20 @@ int lt_overlay_configure(lt_ctx* c, const double* Minv) {
     return LT_OK;
 }
 
-// An overlay call is about to write the staging regions and annotated frames of slots [first, first + n): wait for the
-// previous overlay work if it touches the same slots (it may still be reading those regions), and widen the busy range.
-static int overlay_claim(lt_ctx* c, int first, int n) {
-    if (c->overlay_hi > c->overlay_lo && first < c->overlay_hi && first + n > c->overlay_lo && c->overlay_done) {
-        HIP_TRY(hipEventSynchronize(c->overlay_done));
-        c->overlay_lo = c->overlay_hi = 0;
+// A call is about to overwrite the page-locked staging regions of slots [first, first + n): if a copy out of those regions
+// may still be in flight (an earlier call of the same kind over the same slots), wait for it; then widen the busy range.
+static int staging_claim(lt_ctx::StagingBusy& b, int first, int n) {
+    if (b.hi > b.lo && first < b.hi && first + n > b.lo && b.done) {
+        HIP_TRY(hipEventSynchronize(b.done));
+        b.lo = b.hi = 0;
     }
-    if (c->overlay_hi <= c->overlay_lo) { c->overlay_lo = first; c->overlay_hi = first + n; }
-    else { c->overlay_lo = std::min(c->overlay_lo, first); c->overlay_hi = std::max(c->overlay_hi, first + n); }
+    if (b.hi <= b.lo) { b.lo = first; b.hi = first + n; }
+    else { b.lo = std::min(b.lo, first); b.hi = std::max(b.hi, first + n); }
     return LT_OK;
 }
-static int overlay_mark(lt_ctx* c) {
-    if (!c->overlay_done && hipEventCreateWithFlags(&c->overlay_done, hipEventDisableTiming) != hipSuccess)
-        return fail(LT_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(c->overlay_done, c->stream));
+static int staging_mark(lt_ctx::StagingBusy& b, hipStream_t st) {
+    if (!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(b.done, st));
     return LT_OK;
 }
 
@@ -1163,7 +1164,7 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     const int bh = c->calib.warp_h;
     if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
     if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
-    if ((rc = overlay_claim(c, first, n))) return rc;
+    if ((rc = staging_claim(c->spans_busy, first, n))) return rc;
     if (c->h_spans_cap < c->capacity) {
         if ((rc = sync_all(c))) return rc;
         if (c->h_spans) (void)hipHostFree(c->h_spans);
@@ -1187,7 +1188,7 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
     HIP_TRY(hipGetLastError());
-    if ((rc = overlay_mark(c))) return rc;
+    if ((rc = staging_mark(c->spans_busy, c->stream))) return rc;
     return note_range(c->readers, c->stream, first, first + n);
 }
 
@@ -1242,7 +1243,7 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
         c->text_per_slot = per_new;
         c->text_slots = c->capacity;
     }
-    if ((rc = overlay_claim(c, first, n))) return rc;
+    if ((rc = staging_claim(c->text_busy, first, n))) return rc;
     // this call's lines are packed (n_lines * line_len per slot) at the slots' own positions in the per-slot buffers
     uint8_t* hl = c->h_lines + (size_t)first * per;
     int16_t* hx = c->h_xpos + (size_t)first * per;
@@ -1266,7 +1267,7 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
                         c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, dl, dx,
                         n_lines, line_len, y0, step, n);
     HIP_TRY(hipGetLastError());
-    return overlay_mark(c);
+    return staging_mark(c->text_busy, c->stream);
 }
 
 // Page-locked host memory for the buffers a caller hands to the upload / download entry points: a copy from or to
@@ -1307,7 +1308,7 @@ int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
     if (n == 0) return LT_OK;
     if ((rc = set_device(c))) return rc;
     HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->stream));
-    return overlay_mark(c);
+    return LT_OK;
 }
 
 int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
