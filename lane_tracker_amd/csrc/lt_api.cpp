@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -1174,6 +1175,8 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
         c->h_spans_cap = c->capacity;
     }
     int16_t* hs = c->h_spans + (size_t)first * bh * 2;
+    static const bool timing = std::getenv("LT_OVERLAY_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     size_t ol = 0, orr = 0;
     for (int i = 0; i < n; ++i) {
         lane_polygon_spans(hs + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
@@ -1182,14 +1185,22 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
         orr += (size_t)right_n[i];
     }
     // the rows of the frame the path does not read came on the copy stream (lt_upload_frame_rest): the overlay is their reader
+    const auto t1 = std::chrono::steady_clock::now();
     if (c->rest_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->rest_done, 0));
     HIP_TRY(hipMemcpyAsync(c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    const auto t2 = std::chrono::steady_clock::now();
     launch_overlay_lane(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
     HIP_TRY(hipGetLastError());
     if ((rc = staging_mark(c->spans_busy, c->stream))) return rc;
-    return note_range(c->readers, c->stream, first, first + n);
+    rc = note_range(c->readers, c->stream, first, first + n);
+    if (timing) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        std::fprintf(stderr, "overlay_run n=%d: spans %ld us, wait+memcpy %ld us, launch+events %ld us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
+    }
+    return rc;
 }
 
 int lt_overlay_set_font(lt_ctx* c, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
