@@ -115,6 +115,8 @@ struct lt_ctx {
     int h_spans_cap = 0;
     struct StagingBusy { int lo = 0, hi = 0; hipEvent_t done = nullptr; };   // slots whose staging region a copy may still read
     StagingBusy spans_busy, text_busy;
+    hipStream_t dl = nullptr;         // lt_download_overlay_async: device-to-host copies beside the compute and upload streams
+    StagingBusy annot_busy;           // annotated frames a copy on `dl` may still read
     hipEvent_t rest_done = nullptr;   // end of the most recent lt_upload_frame_rest on the copy stream
     bool rest_pending = false;
     // text: glyph atlas (set once) and the per-slot lines of the current call
@@ -189,8 +191,10 @@ int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
+    if (c->dl) HIP_TRY(hipStreamSynchronize(c->dl));
     c->spans_busy.lo = c->spans_busy.hi = 0;            // every overlay, every copy of the rest rows
     c->text_busy.lo = c->text_busy.hi = 0;
+    c->annot_busy.lo = c->annot_busy.hi = 0;
     c->rest_pending = false;
     c->readers.reset();                                 // every reader / writer enqueued so far is done
     c->writers.reset();
@@ -720,6 +724,8 @@ void lt_destroy(lt_ctx* c) {
     for (auto e : c->order_events) (void)hipEventDestroy(e);
     if (c->spans_busy.done) (void)hipEventDestroy(c->spans_busy.done);
     if (c->text_busy.done) (void)hipEventDestroy(c->text_busy.done);
+    if (c->annot_busy.done) (void)hipEventDestroy(c->annot_busy.done);
+    if (c->dl) (void)hipStreamDestroy(c->dl);
     if (c->rest_done) (void)hipEventDestroy(c->rest_done);
     if (c->h_spans) (void)hipHostFree(c->h_spans);
     if (c->h_lines) (void)hipHostFree(c->h_lines);
@@ -1187,6 +1193,9 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     // the rows of the frame the path does not read came on the copy stream (lt_upload_frame_rest): the overlay is their reader
     const auto t1 = std::chrono::steady_clock::now();
     if (c->rest_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->rest_done, 0));
+    // an asynchronous download may still be reading the annotated frames this call overwrites
+    if (c->annot_busy.hi > c->annot_busy.lo && first < c->annot_busy.hi && first + n > c->annot_busy.lo && c->annot_busy.done)
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->annot_busy.done, 0));
     HIP_TRY(hipMemcpyAsync(c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
     const auto t2 = std::chrono::steady_clock::now();
     launch_overlay_lane(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
@@ -1318,8 +1327,17 @@ int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
     if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay_async before lt_overlay_run");
     if (n == 0) return LT_OK;
     if ((rc = set_device(c))) return rc;
-    HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->stream));
-    return LT_OK;
+    // on a stream of its own, behind the overlay work enqueued so far: the copy neither holds up the kernels queued behind
+    // it on the context's stream nor shares a queue with the uploads
+    if (!c->dl) HIP_TRY(hipStreamCreateWithFlags(&c->dl, hipStreamNonBlocking));
+    hipEvent_t e = next_order_event(c);
+    if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(e, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
+    HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->dl));
+    if (c->annot_busy.hi <= c->annot_busy.lo) { c->annot_busy.lo = first; c->annot_busy.hi = first + n; }
+    else { c->annot_busy.lo = std::min(c->annot_busy.lo, first); c->annot_busy.hi = std::max(c->annot_busy.hi, first + n); }
+    return staging_mark(c->annot_busy, c->dl);
 }
 
 int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
