@@ -142,6 +142,29 @@ __global__ __launch_bounds__(256) void k_overlay_text(uint8_t* __restrict__ out,
 
 }  // namespace
 
+// Small host -> device copies of the overlay stage as a KERNEL reading page-locked (device-visible) host memory: a
+// hipMemcpyAsync of a few hundred KB was seen to block its caller for as long as a large upload on another stream was in
+// progress (8 ms per window); a launch never waits.
+namespace {
+__global__ __launch_bounds__(256) void k_copy_words(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+}  // namespace
+
+void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, size_t bytes) {
+    if (!bytes) return;
+    void* src_dev = nullptr;
+    if (((bytes | (size_t)(uintptr_t)dst | (size_t)(uintptr_t)src_pinned) & 3) ||
+        hipHostGetDevicePointer(&src_dev, const_cast<void*>(src_pinned), 0) != hipSuccess || !src_dev) {
+        (void)hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, s);
+        return;
+    }
+    const size_t n = bytes >> 2;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<uint32_t*>(dst),
+                       static_cast<const uint32_t*>(src_dev), n);
+}
+
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
                          const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
                          const int16_t* xpos, int nl, int len, int y0, int step, int n) {

@@ -1196,7 +1196,7 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     // an asynchronous download may still be reading the annotated frames this call overwrites
     if (c->annot_busy.hi > c->annot_busy.lo && first < c->annot_busy.hi && first + n > c->annot_busy.lo && c->annot_busy.done)
         HIP_TRY(hipStreamWaitEvent(c->stream, c->annot_busy.done, 0));
-    HIP_TRY(hipMemcpyAsync(c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    launch_copy_from_pinned(c->stream, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
     const auto t2 = std::chrono::steady_clock::now();
     launch_overlay_lane(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
@@ -1281,8 +1281,8 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
     }
     uint8_t* dl = c->d_lines + (size_t)first * per;
     int16_t* dx = c->d_xpos + (size_t)first * per;
-    HIP_TRY(hipMemcpyAsync(dl, hl, (size_t)n * per, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dx, hx, (size_t)n * per * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    launch_copy_from_pinned(c->stream, dl, hl, (size_t)n * per);
+    launch_copy_from_pinned(c->stream, dx, hx, (size_t)n * per * sizeof(int16_t));
     launch_overlay_text(c->stream, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
                         c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, dl, dx,
                         n_lines, line_len, y0, step, n);

@@ -58,6 +58,8 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
                          const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
                          const int16_t* xpos, int nl, int len, int y0, int step, int n);
+// host -> device copy of a few hundred KB out of page-locked memory as a kernel launch (never blocks the caller)
+void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, size_t bytes);
 void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy, const uint16_t* wfrac,
                      FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n);
 

@@ -10,6 +10,9 @@ n = 256
 base = synth.stream_lanes(32, seed=5, cal=cal)
 frames = np.concatenate([base, base[::-1]] * (n // 64 + 1), 0)[:n].copy()
 lt = LaneTracker(**cal)
+if os.environ.get("PINNED"):
+    from lane_tracker_amd._native import pinned_empty
+    pf = pinned_empty(frames.shape); pf[...] = frames; frames = pf
 lt.process_batch(frames)
 acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
 def wrap(obj, name):
