@@ -95,8 +95,11 @@ def test_cancelled_chain_stops_and_later_chains_run():
         c.mask_run(n)
         c.sws_fit_run(1, sp, first=0)
         c.sync()
-        c.band_fit_chain_run(n - 1, None, sp, first=1)         # ~2.5 ms of device work ...
-        c.band_fit_chain_cancel()                              # ... told to stop right away
+        c.mask_run(n, first=0)                                 # the chain waits for the masks of its slots: ~4 ms of mask
+        c.mask_run(n, first=0)                                 # work are queued in front of it (same masks again) ...
+        c.sws_fit_run(1, sp, first=0)
+        c.band_fit_chain_run(n - 1, None, sp, first=1)         # ... then ~2.5 ms of chain ...
+        c.band_fit_chain_cancel()                              # ... told to stop right away: long before it can finish
         rec = c.band_fit_chain_collect(n, first=0)
         stopped = int(np.argmax(rec["mode"] == 255))
         assert rec["mode"][-1] == 255 and 1 <= stopped < n and (rec["mode"][stopped:] == 255).all()
