@@ -24,14 +24,14 @@ __global__ __launch_bounds__(256) void k(unsigned long long* out, int iters) {
                          "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6), "=&v"(a7) : "v"(base) : "memory");
-            acc += a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+            acc += a0;   // one consumer only: the loop must be bound by the LDS pipe, not by VALU work on the results
         } else {
             typedef unsigned u4 __attribute__((ext_vector_type(4)));
             u4 b0, b1, b2, b3;
             asm volatile("ds_read_b128 %0, %4 offset:0\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:32\n\tds_read_b128 %3, %4 offset:48\n\t"
                          "s_waitcnt lgkmcnt(0)"
                          : "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3) : "v"(base) : "memory");
-            acc += (unsigned long long)(b0.x ^ b1.y ^ b2.z ^ b3.w) + b0.w + b1.x + b2.y + b3.z;
+            acc += b0.x;
         }
     }
     out[blockIdx.x * 256 + threadIdx.x] = acc;
