@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Host wall time per context call inside LaneTracker.process() (one frame per call, annotated frame back)."""
+import collections, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lane_tracker_amd import calib, synth
+from lane_tracker_amd.lane_tracker import LaneTracker
+cal = calib.reference_calibration() if len(sys.argv) < 2 else calib.scaled_calibration(1.5)
+frames = synth.stream_lanes(24, seed=5, cal=cal)
+frames = np.concatenate([frames, frames[::-1]] * 4, 0)
+lt = LaneTracker(**cal)
+for f in frames[:8]:
+    lt.process(f)
+acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
+def wrap(obj, name):
+    fn = getattr(obj, name)
+    def w(*a, **k):
+        t0 = time.perf_counter(); r = fn(*a, **k); acc[name] += time.perf_counter() - t0; cnt[name] += 1; return r
+    setattr(obj, name, w)
+for name in ("upload_frame_rows", "upload_frame_rest", "mask_run", "sws_fit_run", "band_fit_run", "download_records", "overlay_run", "overlay_text", "download_overlay", "download_pixels"):
+    wrap(lt._ctx, name)
+for name in ("_record_success", "check_validity", "get_poly_points", "get_curve_radius", "_lane_text"):
+    wrap(lt, name)
+n = len(frames) - 8
+t0 = time.perf_counter()
+for f in frames[8:]:
+    out = lt.process(f)
+total = time.perf_counter() - t0
+print(json.dumps({"us_per_frame": round(total / n * 1e6, 1), "fps": round(n / total, 1),
+                  "us_per_frame_by_call": {k: round(v / n * 1e6, 1) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])}}))
