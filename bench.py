@@ -37,6 +37,30 @@ PROFILE_TAG = "r03"            # profiles/<tag>_traffic.json, <tag>_kernel_stats
 CALIB_TAG = "r02"              # profiles/<tag>_valu_issue.json, <tag>_fetch_calib.json: the issue-rate / counter calibrations (hardware facts)
 
 
+def cpu_quota():
+    """CPUs' worth of time the cgroup grants this process (None: unlimited).  The GPU boxes show 256 CPUs and grant 16."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else None
+    except Exception:
+        return None
+
+
+def usable_cpus():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    q = cpu_quota()
+    return max(1, min(avail, int(q + 0.999))) if q else avail
+
+
 def _render_one(i):
     from lane_tracker_amd import synth
     global _RENDERER
@@ -51,10 +75,7 @@ def render_frames(indices):
     """Fresh synthetic scene per frame index (lane_tracker_amd/synth.py), rendered on the host cores BEFORE this
     process touches the GPU (worker processes are forked)."""
     indices = list(indices)
-    try:
-        cpus = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cpus = os.cpu_count() or 1
+    cpus = usable_cpus()                 # not the 256 the box shows: worker processes beyond the quota only add set-up cost
     world = int(os.environ.get("WORLD_SIZE", "1"))
     workers = max(1, min(32, cpus // max(world, 1), len(indices)))
     if workers == 1:
@@ -83,11 +104,7 @@ def render_streams(n_base=32):
     from concurrent.futures import ProcessPoolExecutor
     from lane_tracker_amd import synth
     jobs = [(scale,) + prm for scale in (1.0, 1.5) for prm in synth.stream_lane_params(n_base, seed=5)]
-    try:
-        cpus = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cpus = os.cpu_count() or 1
-    with ProcessPoolExecutor(max(1, min(32, cpus, len(jobs)))) as ex:
+    with ProcessPoolExecutor(max(1, min(32, usable_cpus(), len(jobs)))) as ex:
         got = list(ex.map(_render_stream_one, jobs, chunksize=2))
     return {"1280x720": np.stack(got[:n_base], 0), "1920x1080": np.stack(got[n_base:], 0)}
 
@@ -154,21 +171,7 @@ def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
-    # CPU time this process may actually use: the cgroup quota (the GPU box shows 256 CPUs and grants 16 CPUs' worth of
-    # time; 256 threads on that are throttled to less than 16 run)
-    quota = None
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if q != "max":
-            quota = float(q) / float(per)
-    except Exception:
-        try:
-            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                quota = q / per
-        except Exception:
-            pass
+    quota = cpu_quota()
     cores = max(1, min(avail, int(quota + 0.999)) if quota else avail)   # threads actually used: one frame per thread
     try:
         # The port allocates its planes per frame; with glibc's defaults every megabyte-sized block is an mmap / munmap pair

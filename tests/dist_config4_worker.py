@@ -37,6 +37,12 @@ def main():
         cpus = len(os.sched_getaffinity(0))
     except AttributeError:
         cpus = os.cpu_count() or 1
+    try:                                             # the box shows 256 CPUs and grants a cgroup quota of 16: more workers only add set-up cost
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            cpus = max(1, min(cpus, int(float(q) / float(per) + 0.999)))
+    except Exception:
+        pass
     workers = max(1, min(48, cpus // world))
     pool = ProcessPoolExecutor(workers)
     list(pool.map(_render, range(workers)))          # forks every worker now, before any HIP call below
