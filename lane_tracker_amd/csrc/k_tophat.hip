@@ -780,8 +780,15 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
 #ifndef LT_MORPH_WPB
 #define LT_MORPH_WPB 4
 #endif
+// -DLT_MORPH_MAX_WAVES=n: cap the kernel at n waves per SIMD (co-residency experiments: the registers of the waves it does
+// not take stay free for another stream's kernels)
+#ifdef LT_MORPH_MAX_WAVES
+#define LT_MORPH_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(1, LT_MORPH_MAX_WAVES)))
+#else
+#define LT_MORPH_WAVES_ATTR
+#endif
 template <class SE, bool DIL, bool WIDE, bool TH>
-__global__ __launch_bounds__(64 * LT_MORPH_WPB) void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(64 * LT_MORPH_WPB) LT_MORPH_WAVES_ATTR void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     const uint8_t* __restrict__ minuend, RunsGeom g) {
     __shared__ uint2 s_chain[LT_MORPH_WPB][4 * PLANE];   // S0, S1, S4, S13
     __shared__ __attribute__((aligned(8))) uint8_t s_out[WIDE ? LT_MORPH_WPB : 1][WIDE ? 256 : 8];   // [2*col + row] of a row pair
