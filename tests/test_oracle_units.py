@@ -7,6 +7,16 @@ from scipy import ndimage as ndi
 
 def test_ellipse_structuring_elements(oracle):
     assert oracle.ellipse_kernel(5).tolist() == [[0, 0, 1, 0, 0], [1] * 5, [1] * 5, [1] * 5, [0, 0, 1, 0, 0]]
+    # 5x5 above is printed in OpenCV's own morphology tutorial; 3x3, 7x7 and 9x9 are the printouts of
+    # cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (k, k)) as commonly quoted (written down from memory: there is no network
+    # here to fetch them) -- the pointed single-pixel top and bottom rows and the flat sides are what distinguishes OpenCV's
+    # ellipse from a rasterised disc
+    assert oracle.ellipse_kernel(3).tolist() == [[0, 1, 0], [1, 1, 1], [0, 1, 0]]
+    assert oracle.ellipse_kernel(7).tolist() == [[0, 0, 0, 1, 0, 0, 0], [0, 1, 1, 1, 1, 1, 0], [1] * 7, [1] * 7, [1] * 7,
+                                                 [0, 1, 1, 1, 1, 1, 0], [0, 0, 0, 1, 0, 0, 0]]
+    assert oracle.ellipse_kernel(9).tolist() == [[0, 0, 0, 0, 1, 0, 0, 0, 0], [0, 1, 1, 1, 1, 1, 1, 1, 0], [0, 1, 1, 1, 1, 1, 1, 1, 0],
+                                                 [1] * 9, [1] * 9, [1] * 9, [0, 1, 1, 1, 1, 1, 1, 1, 0], [0, 1, 1, 1, 1, 1, 1, 1, 0],
+                                                 [0, 0, 0, 0, 1, 0, 0, 0, 0]]
     dx29, taps29 = oracle.ellipse_halfwidths(29)
     dx55, taps55 = oracle.ellipse_halfwidths(55)
     assert taps29 == 641 and taps55 == 2337          # lane_tracker.py:203-204 footprints
