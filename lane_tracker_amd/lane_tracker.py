@@ -516,6 +516,8 @@ class LaneTracker:
                                      # 32 for a stand-alone window (its head and tail count), half a window up to 128 in a
                                      # stream of windows (the walking threshold kernels take launches of >= 80 frames)
     chain_depth = 3                  # chains kept in flight behind the one the host is checking
+    stream_lookahead = 2             # process_stream: windows fed (uploads + masks) ahead of the one being searched; with 1 the
+                                     # uploads pause between windows (the next-but-one window would reuse the slots still searched)
 
     def _valid_many(self, LF, RF):
         """check_validity (:561-627) for m fits at once: the same f64 operations in the same order, element by element,
@@ -548,11 +550,11 @@ class LaneTracker:
         """The frame loop of a window with the searches chained on the device.  State after every frame, and every
         attribute at the end, equal those of `_step` frame by frame (tests/test_gpu_chain.py, tests/fuzz_chain.py).
         The window's frames live in slots base .. base+n-1; the first `prefed` of them already have their upload and
-        first-try mask enqueued (by the previous window); `ahead` = (frames of the next window, its first slot): its first
-        frames are fed as this window drains, and their number is returned."""
+        first-try mask enqueued (by an earlier window); `ahead` = the windows that follow, in order, as mutable lists
+        [frames, first slot, frames fed so far]: they are fed, in order, as this window drains (the third entry is updated)."""
         ctx, n = self._ctx, frames.shape[0]
-        nxt, nxt_base = ahead if ahead is not None else (None, 0)
-        total = n + (len(nxt) if nxt is not None else 0)
+        ahead = ahead or []
+        total = n + sum(len(a[0]) for a in ahead)
         partial = first_try[-1]
         sws_kw = dict(window_width=first_try[9], window_height=first_try[10], search_range=first_try[11], mu=first_try[12],
                       no_success_limit=first_try[13], start_slice=first_try[14], ignore_sides=first_try[15],
@@ -565,8 +567,9 @@ class LaneTracker:
             chunk = max(32, min(128, (n // 2) & ~1))
         else:
             chunk = 32 if n < 512 else 64
-        masked = prefed                  # stream positions [0, masked) have their upload + first-try mask enqueued;
-                                         # positions >= n are frames of the next window
+        masked = prefed + (sum(a[2] for a in ahead) if prefed >= n else 0)
+        # stream positions [0, masked) have their upload + first-try mask enqueued; positions >= n are frames of the windows
+        # ahead (fed strictly in order, so a later window has frames fed only if the ones before it are fed completely)
         head = not self._in_stream       # a stand-alone window: nothing is in flight when it starts
 
         def span(at):                    # frames per launch at position `at`: short at the head of a stand-alone window (the
@@ -581,9 +584,14 @@ class LaneTracker:
                     ctx.mask_run(m, fp, first=base + masked)
                 else:
                     q = masked - n
-                    m = min(chunk, len(nxt) - q)
-                    ctx.upload_frame_rows_async(nxt[q:q + m], first=nxt_base + q)
-                    ctx.mask_run(m, fp, first=nxt_base + q)
+                    for a in ahead:                       # the window position `masked` falls into
+                        if q < len(a[0]):
+                            break
+                        q -= len(a[0])
+                    m = min(chunk, len(a[0]) - q)
+                    ctx.upload_frame_rows_async(a[0][q:q + m], first=a[1] + q)
+                    ctx.mask_run(m, fp, first=a[1] + q)
+                    a[2] = q + m
                 masked += m
         feed(2 * chunk)
         if annotate:
@@ -688,7 +696,6 @@ class LaneTracker:
                 i += 1
         if flush is not None:
             flush(True)
-        return max(0, masked - n)
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,
@@ -820,9 +827,9 @@ class LaneTracker:
     def process_stream(self, windows, annotate=True, **kwargs):
         """Generator over consecutive windows of ONE video: `windows` yields arrays (n, H, W, 3); for each, what
         `process_batch` would return is yielded, and the tracker's state after it is what `process()` frame by frame
-        leaves.  The context holds two windows side by side: while the searches of one window drain, the uploads and masks
-        of the next one are already running, so the device does not idle at window boundaries (a window's head and tail
-        cost about a quarter of a 256-frame `process_batch` call).  Do not call `process()` / `process_batch()` on this
+        leaves.  The context holds `stream_lookahead + 1` windows side by side: while the searches of one window drain, the
+        uploads and masks of the next ones are already running, so neither the bus nor the device idles at window boundaries
+        (a window's head and tail cost about a quarter of a 256-frame `process_batch` call).  Do not call `process()` / `process_batch()` on this
         tracker until the generator is exhausted or closed."""
         k, first_try, fp = self._batch_arguments(kwargs)
         if not (self.chain_searches and not k["diagnostics"]):
@@ -837,34 +844,49 @@ class LaneTracker:
             raise RuntimeError("this tracker already runs a process_stream()")
         cur = self._as_window(cur)
         ctx = self._ctx
-        half, base, prefed = 0, 0, 0
+        look = max(1, int(self.stream_lookahead))
+        regions = look + 1               # windows resident side by side: the one being searched and `look` being fed
+        size = 0                         # slots per region
+        free = []                        # first slots of the regions nobody lives in
+        queue = []                       # windows ahead of `cur`, in order: [frames, first slot, frames fed]; [.., None, 0]: not placed
+        cur = [cur, None, 0]
         self._in_stream = True
         try:
             while cur is not None:
-                nxt = next(it, None)
-                nxt = None if nxt is None else self._as_window(nxt)
-                n = cur.shape[0]
-                if n > half:             # first window, or a longer one than the halves hold (then nothing was fed ahead)
-                    self._materialise_pending()      # growing the context drops what is still on the device
-                    half = (n + 1) & ~1
-                    ctx.reserve(2 * half)
-                    base, prefed = 0, 0
-                other = 0 if base else half      # the half of the context the next window will live in
-                ahead = (nxt, other) if nxt is not None and 0 < nxt.shape[0] <= half else None
+                while len(queue) < look:             # know the next windows
+                    w = next(it, None)
+                    if w is None:
+                        break
+                    queue.append([self._as_window(w), None, 0])
+                n = cur[0].shape[0]
+                if cur[1] is None:                   # first window, or one that did not fit the regions: (re)size the context
+                    if n > size:
+                        self._materialise_pending()  # growing the context drops what is still on the device
+                        size = (n + 1) & ~1
+                        ctx.reserve(regions * size)
+                    free = [r * size for r in range(regions)]
+                    for q in queue:                  # nothing can have been fed ahead of an unplaced window
+                        q[1], q[2] = None, 0
+                    cur[1] = free.pop(0)
+                ahead = []
+                for q in queue:                      # place the windows ahead while they fit and regions are free, in order
+                    if q[1] is None:
+                        if not (0 < q[0].shape[0] <= size) or not free:
+                            break
+                        q[1] = free.pop(0)
+                    ahead.append(q)
                 deferred = []
-                flush, frames_out = self._window_renderer(deferred, base, n) if (annotate and n) else (None, None)
-                fed = self._run_window_chained(cur, first_try, fp, k["n_tries"], annotate, deferred, base=base, prefed=prefed,
-                                               ahead=ahead, flush=flush) if n else 0
+                flush, frames_out = self._window_renderer(deferred, cur[1], n) if (annotate and n) else (None, None)
+                if n:
+                    self._run_window_chained(cur[0], first_try, fp, k["n_tries"], annotate, deferred, base=cur[1], prefed=cur[2],
+                                             ahead=ahead, flush=flush)
                 if frames_out is not None:
-                    ctx.sync()           # the last pieces of this window's frames are on their way (the next window's head runs too)
+                    ctx.sync()           # the last pieces of this window's frames are on their way (the next windows' heads run too)
                     out = list(frames_out)
                 else:
                     out = [None] * n
-                if ahead is not None:
-                    base, prefed = other, fed
-                else:
-                    prefed = 0           # the next window starts from scratch (possibly after a resize)
-                cur = nxt
+                free.append(cur[1])      # its frames, masks and records are not needed any more
+                cur = queue.pop(0) if queue else None
                 yield out
             self._materialise_pending()  # the attributes describe the last frame, as after process()
         finally:
