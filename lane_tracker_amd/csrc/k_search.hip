@@ -1165,6 +1165,154 @@ __global__ __launch_bounds__(NT) void k_band_chain2(const uint8_t* __restrict__ 
     }
 }
 
+// k_band_chain3: the same walk as k_band_chain2 (bit-plane masks only), reorganised around what a frame costs when ONE
+// workgroup does it alone -- latency, barriers and the serial solve -- because in a stream this kernel, not the mask chain,
+// sets the pace (17.6 us per frame beside the mask kernels of later frames against 16.3 us for the bus):
+//   * one pass per row with no LDS staging: band interval, the two bit-plane words (every load of a thread issued before
+//     the first is used), funnel shift, closed-form moments, and the row's `a` / mask straight to the pixel block;
+//   * CT = 512 threads (five rows each at 1100 x 1080) instead of 256;
+//   * the 18 partial sums of a thread (8 moments per side as int64, pixel and row counts packed) go to LDS value-major and
+//     each wave folds a few of the 18 values (8 reads per lane + ONE wave sum per value) -- 16 wave sums of 64-bit values per
+//     wave were the largest single piece of k_band_fit2's reduction;
+//   * the two Cholesky solves (a dozen dependent f64 divisions and square roots each) run side by side on two waves.
+// Records, pixel blocks and the stop / cancel behaviour are identical to k_band_chain2 (tests/test_gpu_chain.py holds both
+// against the frame-by-frame band search).
+constexpr int CT = 512;           // threads of k_band_chain3
+constexpr int C3_VALUES = 18;     // per side: 8 moments + (rows << 32 | pixels)
+__global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, const lt_lane_record* __restrict__ seed_rec, BandPrev seed,
+                                                   uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int n,
+                                                   const int* cancel_epoch, int my_epoch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    long long* part = reinterpret_cast<long long*>(smem);                  // [C3_VALUES][CT]
+    __shared__ long long s_tot[C3_VALUES];
+    __shared__ double carry[8], pc[6], s_fit[6];
+    __shared__ int s_stop, s_ok[2];
+    const int lane = lane_id(), wv = threadIdx.x >> 6;
+    const int W = g.w, top = g.band_top, nrows = max(g.band_bottom - top, 0), rows_total = 2 * nrows;
+    const int y0c = g.h / 2, x0c = g.w / 2;
+    const double bw = g.bandwidth;
+    __builtin_amdgcn_s_setprio(3);
+    if (threadIdx.x < 6)
+        carry[threadIdx.x] = seed.by_value ? seed.c[threadIdx.x]
+                                           : (threadIdx.x < 3 ? seed_rec->left_coeffs[threadIdx.x] : seed_rec->right_coeffs[threadIdx.x - 3]);
+    if (threadIdx.x == 6) carry[6] = seed.by_value || (seed_rec->detected && seed_rec->fit_flags == 0) ? 1.0 : 0.0;
+    if (threadIdx.x == 0) s_stop = 0;
+    __syncthreads();
+    int f = 0;
+    for (; f < n && carry[6] != 0.0; ++f) {
+        if (threadIdx.x < 6) pc[threadIdx.x] = carry[threadIdx.x];
+        __syncthreads();
+        if (s_stop) break;
+        int epoch_now = 0;
+        if (threadIdx.x == 6) epoch_now = __atomic_load_n(cancel_epoch, __ATOMIC_RELAXED);   // crosses the bus: looked at after the frame
+        uint32_t* hdr = pix_all + (size_t)f * 2 * g.maxpix;
+        int32_t* g_a = reinterpret_cast<int32_t*>(hdr + 4);
+        unsigned long long* gmask = reinterpret_cast<unsigned long long*>(hdr + band2_mask_offset(nrows));
+        const unsigned long long* fb = mb.bits + (size_t)f * mb.bits_stride;
+        if (threadIdx.x == 0) { hdr[0] = (uint32_t)nrows; hdr[1] = (uint32_t)top; hdr[2] = 0u; hdr[3] = 0u; }
+        Moments mom[2];
+        mom[0].clear();
+        mom[1].clear();
+        unsigned n_rows[2] = {0, 0}, n_pix[2] = {0, 0};
+        constexpr int U = 5;          // rows per thread and batch: 2140 rows / 512 threads
+        for (int r0 = (int)threadIdx.x; r0 < rows_total; r0 += CT * U) {
+            int ra[U], rw[U];
+            unsigned long long w0[U], w1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {                                  // intervals and loads of the whole batch first
+                const int r = min(r0 + u * CT, rows_total - 1);
+                const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
+                const double y2 = (double)((long long)y * y), yd = (double)y;
+                const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];   // ((a y^2 + b y) + c), no FMA (:474-489)
+                int a, b;
+                band_columns(t - bw, t + bw, W, a, b);
+                ra[u] = a;
+                rw[u] = max(b - a, 0);
+                const int j0 = min(a >> 6, mb.wpr - 1);
+                w0[u] = fb[(size_t)y * mb.wpr + j0];
+                w1[u] = j0 + 1 < mb.wpr ? fb[(size_t)y * mb.wpr + j0 + 1] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * CT;
+                if (r >= rows_total) break;
+                const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
+                const int a = ra[u], bwid = rw[u], sh = a & 63;
+                unsigned long long m = sh ? (w0[u] >> sh) | (w1[u] << (64 - sh)) : w0[u];
+                m &= bwid <= 0 ? 0ull : bwid < 64 ? (1ull << bwid) - 1ull : ~0ull;
+                g_a[r] = a;
+                gmask[r] = m;
+                const int cnt = __popcll(m);
+                const int sj = __popcll(m & 0xaaaaaaaaaaaaaaaaull) + 2 * __popcll(m & 0xccccccccccccccccull) +
+                               4 * __popcll(m & 0xf0f0f0f0f0f0f0f0ull) + 8 * __popcll(m & 0xff00ff00ff00ff00ull) +
+                               16 * __popcll(m & 0xffff0000ffff0000ull) + 32 * __popcll(m & 0xffffffff00000000ull);
+                const int dy = y - y0c, dy2 = dy * dy, sdx = sj + cnt * (a - x0c), cdy2 = cnt * dy2;   // 32-bit safe: h <= 8192
+                Moments& mm = s == 0 ? mom[0] : mom[1];
+                mm.m[0] += cnt; mm.m[1] += cnt * dy; mm.m[2] += cdy2; mm.m[3] += (long long)cdy2 * dy; mm.m[4] += (long long)cdy2 * dy2;
+                mm.m[5] += sdx; mm.m[6] += (long long)sdx * dy; mm.m[7] += (long long)sdx * dy2;
+                n_pix[s] += (unsigned)cnt;
+                n_rows[s] += cnt != 0 ? 1u : 0u;
+            }
+        }
+        // stage 1: every thread's 18 partial sums, value-major
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) part[(s * 9 + k) * CT + threadIdx.x] = mom[s].m[k];
+            part[(s * 9 + 8) * CT + threadIdx.x] = (long long)(((unsigned long long)n_rows[s] << 32) | n_pix[s]);
+        }
+        __syncthreads();
+        // stage 2: wave w folds values w, w + 8, w + 16
+        for (int v = wv; v < C3_VALUES; v += CT / 64) {
+            long long acc = 0;
+#pragma unroll
+            for (int i = 0; i < CT / 64; ++i) acc += part[v * CT + i * 64 + lane];
+            const long long tot = wave_sum_i64(acc);
+            if (lane == 0) s_tot[v] = tot;
+        }
+        __syncthreads();
+        // the two fits side by side: wave 0 lane 0 left, wave 1 lane 0 right
+        const int nl = (int)(unsigned)(s_tot[8] & 0xffffffffll), nr = (int)(unsigned)(s_tot[17] & 0xffffffffll);
+        const bool detected = nl != 0 && nr != 0;                            // :491
+        if (lane == 0 && wv < 2) {
+            const double y0 = (double)(g.h / 2), x0 = (double)(g.w / 2), sy = (double)(g.h > 1 ? g.h : 2) * 0.5;
+            double c[3] = {0.0, 0.0, 0.0};
+            bool ok = true;
+            if (detected) ok = solve_poly2(s_tot + wv * 9, (int)(s_tot[wv * 9 + 8] >> 32), y0, x0, sy, c);
+            s_fit[wv * 3] = c[0]; s_fit[wv * 3 + 1] = c[1]; s_fit[wv * 3 + 2] = c[2];
+            s_ok[wv] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            lt_lane_record r;
+            const unsigned flags = detected ? ((s_ok[0] ? 0u : 1u) | (s_ok[1] ? 0u : 2u)) : 0u;
+            for (int k = 0; k < 3; ++k) { r.left_coeffs[k] = detected ? s_fit[k] : 0.0; r.right_coeffs[k] = detected ? s_fit[3 + k] : 0.0; }
+            if (detected && (flags & 1u)) for (int k = 0; k < 3; ++k) r.left_coeffs[k] = 0.0;
+            if (detected && (flags & 2u)) for (int k = 0; k < 3; ++k) r.right_coeffs[k] = 0.0;
+            r.n_left = nl;
+            r.n_right = nr;
+            r.detected = detected ? 1 : 0;
+            r.fit_flags = (uint8_t)flags;
+            r.mode = 1;
+            r._pad = 2;               // per-row column masks (k_band_fit2's format)
+            r.frame = recs[f].frame;  // keep the caller's tag
+            recs[f] = r;
+            for (int k = 0; k < 3; ++k) { carry[k] = r.left_coeffs[k]; carry[3 + k] = r.right_coeffs[k]; }
+            carry[6] = detected && flags == 0 ? 1.0 : 0.0;
+        }
+        if (threadIdx.x == 6) s_stop = epoch_now > my_epoch ? 1 : 0;
+        __syncthreads();
+    }
+    for (int i = f + (int)threadIdx.x; i < n; i += CT) {
+        lt_lane_record r;
+        for (int k = 0; k < 3; ++k) r.left_coeffs[k] = r.right_coeffs[k] = 0.0;
+        r.n_left = r.n_right = 0;
+        r.detected = 0; r.fit_flags = 0; r.mode = 255; r._pad = 0;
+        r.frame = recs[i].frame;
+        recs[i] = r;
+    }
+}
+
 // fit_poly() on an explicit pixel list: moments by all threads, one Cholesky solve
 __global__ __launch_bounds__(NT) void k_fit_list(const uint32_t* __restrict__ pix, int n, int h, int w,
                                                 double* __restrict__ out4) {
@@ -1323,6 +1471,13 @@ void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, 
     const int nrows = std::max(g.band_bottom - g.band_top, 0);
     const size_t lds2 = band2_mom_offset(nrows) + 16 * sizeof(long long);
     const int nq = (int)((2LL * (long long)g.bandwidth + 2 + 3 + 15) / 16);
+    static const bool v2 = env_flag("LT_CHAIN_V2");      // A/B: the first chained kernel (the body of k_band_fit2 in a loop)
+    const size_t lds3 = (size_t)C3_VALUES * CT * sizeof(long long);
+    static const bool big3 = allow_big_lds(k_band_chain3);
+    if (mb.bits && !v2 && big3 && g.h <= 8192) {
+        hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, seed_rec, seed, pix, rec, n, cancel_epoch, my_epoch);
+        return;
+    }
     if (mb.bits) hipLaunchKernelGGL(k_band_chain2<true>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);
     else hipLaunchKernelGGL(k_band_chain2<false>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);
 }

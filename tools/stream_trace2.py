@@ -13,5 +13,5 @@ lt = LaneTracker(**cal)
 list(lt.process_stream([frames] * 2, annotate=False))
 time.sleep(0.05)
 t0 = time.perf_counter()
-list(lt.process_stream([frames] * 4, annotate=False))
-print("fps", 4 * n / (time.perf_counter() - t0))
+list(lt.process_stream([frames] * 8, annotate=False))
+print("fps", 8 * n / (time.perf_counter() - t0))
