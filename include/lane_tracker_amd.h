@@ -179,6 +179,13 @@ int  lt_band_fit_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params*
  * also waits for all chains. */
 int  lt_band_fit_chain_run(lt_ctx* ctx, int first_slot, int n, const lt_search_params* p, const double* seed_coeffs);
 int  lt_band_fit_chain_collect(lt_ctx* ctx, int first_slot, int n, lt_lane_record* out);
+/* Give the chained search n CUs of its own (0 = none, the default): the context's compute streams are recreated with a CU
+ * mask that keeps them off CUs 0 .. n-1, and the search stream is restricted to those.  Why: the kernels of the mask chain
+ * spread their workgroups over the chip once, statically; a workgroup of the chain kernel sharing ONE CU with them slows that
+ * CU's share of every mask kernel, and each kernel then ends with that CU -- measured: the mask chain of 128-frame launches
+ * takes 18.6 us per frame beside a running chain, 15.1 with one CU set aside (12.8 alone).  Call it on an idle context (it
+ * synchronises); a context that only processes independent batches has no use for it. */
+int  lt_set_search_cus(lt_ctx* ctx, int n);
 /* The caller has rejected a frame: every chain enqueued so far stops at its next frame (the slots it has not searched
  * get mode 255) instead of finishing its speculation.  Chains enqueued afterwards are not affected. */
 int  lt_band_fit_chain_cancel(lt_ctx* ctx);

@@ -103,6 +103,7 @@ _SIGNATURES = {
     "lt_band_fit_chain_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams), _P]),
     "lt_band_fit_chain_collect": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_band_fit_chain_cancel": (C.c_int, [_P]),
+    "lt_set_search_cus": (C.c_int, [_P, C.c_int]),
     "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "lt_mask_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(FilterParams), _P]),
     "lt_sws_fit_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(SearchParams), _P]),
@@ -496,6 +497,10 @@ class Context:
         sp = sp or search_params()
         seed = None if seed_coeffs is None else np.ascontiguousarray(seed_coeffs, np.float64).reshape(6)
         _check(self.lib.lt_band_fit_chain_run(self._h, first, n, C.byref(sp), None if seed is None else seed.ctypes.data))
+
+    def set_search_cus(self, n):
+        """Reserve n CUs for the chained search (the compute streams are recreated without them); 0 undoes it."""
+        _check(self.lib.lt_set_search_cus(self._h, int(n)))
 
     def band_fit_chain_cancel(self):
         """Chains enqueued so far stop at their next frame (their speculation has been rejected)."""

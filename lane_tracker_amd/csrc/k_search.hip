@@ -1181,7 +1181,17 @@ constexpr int CT = 512;           // threads of k_band_chain3
 constexpr int C3_VALUES = 18;     // per side: 8 moments + (rows << 32 | pixels)
 __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, const lt_lane_record* __restrict__ seed_rec, BandPrev seed,
                                                    uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int n,
-                                                   const int* cancel_epoch, int my_epoch) {
+                                                   const int* cancel_epoch, int my_epoch, int prio, int ablate_arg) {
+    // Timing probes of tools/stream_interference.py, in a build with -DLT_CHAIN_PROBES only (WRONG results): ablate bit 1 no
+    // pixel-block stores, 2 no bit-plane loads, 4 no f64 band evaluation, 8 no solve, 16 no reduction; prio = wave priority.
+    // The product build compiles them out (ablate is the constant 0, the priority the constant 3).
+#ifdef LT_CHAIN_PROBES
+    const int ablate = ablate_arg;
+#else
+    constexpr int ablate = 0;
+    prio = 3;
+    (void)ablate_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     long long* part = reinterpret_cast<long long*>(smem);                  // [C3_VALUES][CT]
     __shared__ long long s_tot[C3_VALUES];
@@ -1191,7 +1201,9 @@ __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, c
     const int W = g.w, top = g.band_top, nrows = max(g.band_bottom - top, 0), rows_total = 2 * nrows;
     const int y0c = g.h / 2, x0c = g.w / 2;
     const double bw = g.bandwidth;
-    __builtin_amdgcn_s_setprio(3);
+    if (prio >= 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     if (threadIdx.x < 6)
         carry[threadIdx.x] = seed.by_value ? seed.c[threadIdx.x]
                                            : (threadIdx.x < 3 ? seed_rec->left_coeffs[threadIdx.x] : seed_rec->right_coeffs[threadIdx.x - 3]);
@@ -1222,15 +1234,21 @@ __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, c
             for (int u = 0; u < U; ++u) {                                  // intervals and loads of the whole batch first
                 const int r = min(r0 + u * CT, rows_total - 1);
                 const int s = r >= nrows ? 1 : 0, y = top + r - s * nrows;
-                const double y2 = (double)((long long)y * y), yd = (double)y;
-                const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];   // ((a y^2 + b y) + c), no FMA (:474-489)
                 int a, b;
-                band_columns(t - bw, t + bw, W, a, b);
+                if (ablate & 4) { a = 400 + 200 * s + (y & 7); b = a + 50; }
+                else {
+                    const double y2 = (double)((long long)y * y), yd = (double)y;
+                    const double t = pc[s * 3] * y2 + pc[s * 3 + 1] * yd + pc[s * 3 + 2];   // ((a y^2 + b y) + c), no FMA (:474-489)
+                    band_columns(t - bw, t + bw, W, a, b);
+                }
                 ra[u] = a;
                 rw[u] = max(b - a, 0);
                 const int j0 = min(a >> 6, mb.wpr - 1);
-                w0[u] = fb[(size_t)y * mb.wpr + j0];
-                w1[u] = j0 + 1 < mb.wpr ? fb[(size_t)y * mb.wpr + j0 + 1] : 0ull;
+                if (ablate & 2) { w0[u] = 0x0000ffff00000000ull >> (y & 15); w1[u] = 0; }
+                else {
+                    w0[u] = fb[(size_t)y * mb.wpr + j0];
+                    w1[u] = j0 + 1 < mb.wpr ? fb[(size_t)y * mb.wpr + j0 + 1] : 0ull;
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1240,8 +1258,7 @@ __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, c
                 const int a = ra[u], bwid = rw[u], sh = a & 63;
                 unsigned long long m = sh ? (w0[u] >> sh) | (w1[u] << (64 - sh)) : w0[u];
                 m &= bwid <= 0 ? 0ull : bwid < 64 ? (1ull << bwid) - 1ull : ~0ull;
-                g_a[r] = a;
-                gmask[r] = m;
+                if (!(ablate & 1)) { g_a[r] = a; gmask[r] = m; }
                 const int cnt = __popcll(m);
                 const int sj = __popcll(m & 0xaaaaaaaaaaaaaaaaull) + 2 * __popcll(m & 0xccccccccccccccccull) +
                                4 * __popcll(m & 0xf0f0f0f0f0f0f0f0ull) + 8 * __popcll(m & 0xff00ff00ff00ff00ull) +
@@ -1263,7 +1280,7 @@ __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, c
         }
         __syncthreads();
         // stage 2: wave w folds values w, w + 8, w + 16
-        for (int v = wv; v < C3_VALUES; v += CT / 64) {
+        for (int v = wv; v < C3_VALUES && !(ablate & 16); v += CT / 64) {
             long long acc = 0;
 #pragma unroll
             for (int i = 0; i < CT / 64; ++i) acc += part[v * CT + i * 64 + lane];
@@ -1278,7 +1295,8 @@ __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, c
             const double y0 = (double)(g.h / 2), x0 = (double)(g.w / 2), sy = (double)(g.h > 1 ? g.h : 2) * 0.5;
             double c[3] = {0.0, 0.0, 0.0};
             bool ok = true;
-            if (detected) ok = solve_poly2(s_tot + wv * 9, (int)(s_tot[wv * 9 + 8] >> 32), y0, x0, sy, c);
+            if (detected && !(ablate & 8)) ok = solve_poly2(s_tot + wv * 9, (int)(s_tot[wv * 9 + 8] >> 32), y0, x0, sy, c);
+            if (ablate & 8) { c[0] = pc[wv * 3]; c[1] = pc[wv * 3 + 1]; c[2] = pc[wv * 3 + 2]; }
             s_fit[wv * 3] = c[0]; s_fit[wv * 3 + 1] = c[1]; s_fit[wv * 3 + 2] = c[2];
             s_ok[wv] = ok ? 1 : 0;
         }
@@ -1475,7 +1493,13 @@ void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, 
     const size_t lds3 = (size_t)C3_VALUES * CT * sizeof(long long);
     static const bool big3 = allow_big_lds(k_band_chain3);
     if (mb.bits && !v2 && big3 && g.h <= 8192) {
-        hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, seed_rec, seed, pix, rec, n, cancel_epoch, my_epoch);
+#ifdef LT_CHAIN_PROBES
+        static const int prio = [] { const char* e = std::getenv("LT_CHAIN_PRIO"); return e ? std::atoi(e) : 3; }();
+        static const int ablate = [] { const char* e = std::getenv("LT_CHAIN_ABLATE"); return e ? std::atoi(e) : 0; }();
+#else
+        constexpr int prio = 3, ablate = 0;
+#endif
+        hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, seed_rec, seed, pix, rec, n, cancel_epoch, my_epoch, prio, ablate);
         return;
     }
     if (mb.bits) hipLaunchKernelGGL(k_band_chain2<true>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);

@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "lt_internal.h"
 
 using namespace lt;
@@ -152,6 +154,7 @@ struct lt_ctx {
     // host memory behind an event (lt_band_fit_chain_collect waits for that event only, not for the device).  Work on the
     // slots' streams that touches slots of a chain still in flight waits for it (for_each_slice).
     hipStream_t search = nullptr;
+    int search_cus = 0;                       // lt_set_search_cus: CUs the search stream has to itself (0: none reserved)
     struct ChainTicket { int first, n; hipEvent_t done; };
     std::vector<ChainTicket> chains;          // not yet collected, oldest first
     std::vector<hipEvent_t> chain_event_pool;
@@ -598,7 +601,15 @@ const char* lt_stage_name(int stage) { return stage >= 0 && stage < LT_NUM_STAGE
 // holds other streams (torch's, RCCL's) two slices can land on one queue and stop overlapping (measured: 9 % of the
 // batch rate under torch.distributed).  The slices therefore take the highest priority level, whose pool nothing
 // else in the process uses; LT_STREAM_PRIORITY=normal restores plain streams.
-static hipError_t create_compute_stream(hipStream_t* st) {
+// reserved > 0 (lt_set_search_cus): the stream is kept off CUs 0 .. reserved-1 (bits of the CU mask), which the search stream
+// has to itself -- see lt_set_search_cus.
+static hipError_t create_compute_stream(hipStream_t* st, int reserved = 0) {
+    if (reserved > 0) {
+        uint32_t mask[8];
+        for (auto& w : mask) w = 0xffffffffu;
+        for (int i = 0; i < reserved && i < 256; ++i) mask[i >> 5] &= ~(1u << (i & 31));
+        return hipExtStreamCreateWithCUMask(st, 8, mask);
+    }
     const char* e = getenv("LT_STREAM_PRIORITY");
     int least = 0, greatest = 0;
     if ((e && strcmp(e, "normal") == 0) || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
@@ -816,7 +827,7 @@ int lt_set_streams(lt_ctx* c, int nstreams) {
     if ((rc = flush_stage_events(c))) return rc;
     while ((int)c->streams.size() < nstreams) {
         hipStream_t st = nullptr;
-        HIP_TRY(create_compute_stream(&st));
+        HIP_TRY(create_compute_stream(&st, c->search_cus));
         c->streams.push_back(st);
     }
     c->nstreams = nstreams;
@@ -1638,7 +1649,13 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     // The chain runs on the context's search stream, behind whatever the slots' streams hold so far (the masks of these
     // slots, the search that wrote the seed record); those streams do not wait for it -- the mask chains of later frames run
     // beside it -- unless they touch its slots (for_each_slice).
-    if (!c->search) HIP_TRY(create_compute_stream(&c->search));
+    if (!c->search) {
+        if (c->search_cus > 0) {                  // the CUs the slots' streams were kept off (lt_set_search_cus)
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < c->search_cus && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->search, 8, mask));
+        } else HIP_TRY(create_compute_stream(&c->search));
+    }
     if (!c->h_cancel) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_cancel), 64, hipHostMallocMapped));
         *c->h_cancel = 0;
@@ -1690,6 +1707,33 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     c->chain_tail = done;
     if (c->chain_hi <= c->chain_lo) { c->chain_lo = lo; c->chain_hi = lo + cnt; }
     else { c->chain_lo = std::min(c->chain_lo, lo); c->chain_hi = std::max(c->chain_hi, lo + cnt); }
+    return LT_OK;
+}
+
+int lt_set_search_cus(lt_ctx* c, int n) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (n < 0 || n > 64) return fail(LT_ERR_INVALID, "the search stream can have 0 .. 64 CUs to itself");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (n == c->search_cus) return LT_OK;
+    if ((rc = sync_all(c))) return rc;
+    if ((rc = flush_stage_events(c))) return rc;
+    // every stream that carries slot kernels is recreated with (or without) the reservation; the search stream follows on its
+    // next use
+    std::vector<hipStream_t> fresh;
+    for (size_t i = 0; i < c->streams.size(); ++i) {
+        hipStream_t st = nullptr;
+        if (create_compute_stream(&st, n) != hipSuccess) {
+            for (auto f : fresh) (void)hipStreamDestroy(f);
+            return fail(LT_ERR_HIP, "stream with a CU mask could not be created");
+        }
+        fresh.push_back(st);
+    }
+    for (auto st : c->streams) if (st) (void)hipStreamDestroy(st);
+    c->streams = fresh;
+    c->stream = c->streams.empty() ? c->stream : c->streams[0];
+    if (c->search) { (void)hipStreamDestroy(c->search); c->search = nullptr; }
+    c->search_cus = n;
     return LT_OK;
 }
 

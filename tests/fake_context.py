@@ -46,6 +46,9 @@ class FakeContext:
     def sync(self):
         pass
 
+    def set_search_cus(self, n):
+        pass
+
     def close(self):
         pass
 
