@@ -241,6 +241,13 @@ int  lt_overlay_text(lt_ctx* ctx, int first_slot, int n, const char* lines, int 
  * paints for that polygon; empty rows are (32767, -32768).  spans: warp_h * 2 int16. */
 int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,
                            int16_t* spans);
+/* Host-only helper (no GPU needed): get_poly_points (lane_tracker.py:511-528) for n pairs of parabolas, in the packed form
+ * lt_overlay_run takes.  coeffs: n * 6 doubles (left a, b, c, right a, b, c); ploty / ploty2: the n_rows plot rows and their
+ * squares, as the caller's NumPy computed them.  fitx = a * ploty2 + b * ploty + c in exactly these IEEE operations; points
+ * with 0 <= fitx <= warp_w - 1 are kept, x truncated, y = warp_h - count .. warp_h - 1 (upstream's rule).  left_n / right_n:
+ * n counts; left_yx / right_yx: room for n * n_rows (y, x) pairs each, written back to back. */
+int  lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const double* ploty, const double* ploty2, int n_rows,
+                    int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx);
 /* annotated frames, RGB interleaved, n * img_h * img_w * 3 bytes */
 int  lt_download_overlay(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
 /* The same copy enqueued behind the slots' overlay work without waiting: `out` (page-locked memory from lt_host_alloc, or
@@ -248,6 +255,9 @@ int  lt_download_overlay(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
  * themselves only enqueue (their staging is per slot), so a window can be rendered and downloaded in pieces while later
  * frames are still searched; a call over slots whose previous overlay is still in flight waits for that one. */
 int  lt_download_overlay_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+/* Wait until every copy enqueued by lt_download_overlay_async has landed -- and for nothing else: uploads and masks of
+ * later frames keep running (lt_sync would drain them too). */
+int  lt_download_overlay_wait(lt_ctx* ctx);
 /* Page-locked host memory for buffers passed to the upload / download entry points (copies from or to pageable
  * memory run at a fraction of the PCIe rate).  Needs a GPU; lt_host_free(NULL) is a no-op.  The reference has no
  * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */

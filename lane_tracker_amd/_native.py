@@ -104,6 +104,8 @@ _SIGNATURES = {
     "lt_band_fit_chain_collect": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_band_fit_chain_cancel": (C.c_int, [_P]),
     "lt_set_search_cus": (C.c_int, [_P, C.c_int]),
+    "lt_poly_points": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "lt_download_overlay_wait": (C.c_int, [_P]),
     "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "lt_mask_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(FilterParams), _P]),
     "lt_sws_fit_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(SearchParams), _P]),
@@ -183,7 +185,7 @@ class _PinnedPool:
     holds enough of that size).  Beyond `limit` bytes outstanding, or when the allocation fails, callers get a
     plain NumPy array -- slower copies, same results."""
 
-    def __init__(self, limit=4 << 30, keep_per_size=4):
+    def __init__(self, limit=8 << 30, keep_per_size=4):
         self.limit, self.keep = limit, keep_per_size
         self.free, self.outstanding = {}, 0
 
@@ -274,6 +276,37 @@ def calib_tables(cal):
         ell[k] = (dx, taps.value)
     return dict(source_rows=(r0.value, r1.value), warp_xy=wxy, warp_frac=wfr, und_xy=uxy, und_frac=ufr, gamma=gamma,
                 cbrt=cbrt, lab_coeffs=coef, ellipse=ell)
+
+
+def pack_polygons(polygons):
+    """[(left_y, left_x, right_y, right_x), ...] -> (left counts, right counts, left (y, x) pairs, right (y, x) pairs), the
+    form lt_overlay_run takes."""
+    ln = np.array([len(p[0]) for p in polygons], np.int32)
+    rn = np.array([len(p[2]) for p in polygons], np.int32)
+
+    def pairs(ys, xs, counts):
+        out = np.empty((int(counts.sum()), 2), np.int32)
+        at = 0
+        for y, x, m in zip(ys, xs, counts):
+            out[at:at + m, 0] = y
+            out[at:at + m, 1] = x
+            at += m
+        return out
+    return ln, rn, pairs([p[0] for p in polygons], [p[1] for p in polygons], ln), pairs([p[2] for p in polygons], [p[3] for p in polygons], rn)
+
+
+def poly_points(warped_size, coeffs, ploty, ploty2):
+    """get_poly_points (reference :511-528) for many pairs of parabolas at once, packed for overlay_run_packed: coeffs (n, 6)
+    = left a, b, c, right a, b, c; ploty / ploty2 as LaneTracker._plot_rows gives them.  Host-only (lt_poly_points)."""
+    lib = load()
+    coeffs = np.ascontiguousarray(coeffs, np.float64).reshape(-1, 6)
+    ploty, ploty2 = np.ascontiguousarray(ploty, np.float64), np.ascontiguousarray(ploty2, np.float64)
+    n, rows = coeffs.shape[0], ploty.shape[0]
+    ln, rn = np.empty(n, np.int32), np.empty(n, np.int32)
+    lyx, ryx = np.empty((n * rows, 2), np.int32), np.empty((n * rows, 2), np.int32)
+    _check(lib.lt_poly_points(int(warped_size[0]), int(warped_size[1]), coeffs.ctypes.data, n, ploty.ctypes.data, ploty2.ctypes.data,
+                              rows, ln.ctypes.data, rn.ctypes.data, lyx.ctypes.data, ryx.ctypes.data))
+    return ln, rn, lyx[:int(ln.sum())], ryx[:int(rn.sum())]
 
 
 class Context:
@@ -385,21 +418,16 @@ class Context:
 
     def overlay_run(self, polygons, first=0, alpha=0.3):
         """polygons: one (left_y, left_x, right_y, right_x) tuple per slot (empty arrays: plain copy)."""
-        n = len(polygons)
-        ln = np.array([len(p[0]) for p in polygons], np.int32)
-        rn = np.array([len(p[2]) for p in polygons], np.int32)
+        self.overlay_run_packed(*pack_polygons(polygons), first=first, alpha=alpha)
 
-        def pairs(ys, xs, counts):
-            out = np.empty((int(counts.sum()), 2), np.int32)
-            at = 0
-            for y, x, m in zip(ys, xs, counts):
-                out[at:at + m, 0] = y
-                out[at:at + m, 1] = x
-                at += m
-            return out
-        lyx = pairs([p[0] for p in polygons], [p[1] for p in polygons], ln)
-        ryx = pairs([p[2] for p in polygons], [p[3] for p in polygons], rn)
-        _check(self.lib.lt_overlay_run(self._h, first, n, ln.ctypes.data, rn.ctypes.data,
+    def overlay_run_packed(self, ln, rn, lyx, ryx, first=0, alpha=0.3):
+        """The same with the polygons already packed (pack_polygons / poly_points): int32 counts per slot and the (y, x) pairs
+        of all slots back to back."""
+        ln, rn = np.ascontiguousarray(ln, np.int32), np.ascontiguousarray(rn, np.int32)
+        lyx, ryx = np.ascontiguousarray(lyx, np.int32), np.ascontiguousarray(ryx, np.int32)
+        if len(rn) != len(ln) or lyx.size != 2 * int(ln.sum()) or ryx.size != 2 * int(rn.sum()):
+            raise ValueError("point lists do not match their counts")
+        _check(self.lib.lt_overlay_run(self._h, first, len(ln), ln.ctypes.data, rn.ctypes.data,
                                        lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None,
                                        float(alpha)))
 
@@ -435,6 +463,10 @@ class Context:
         if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.shape[1:] != (self.img_h, self.img_w, 3):
             raise ValueError("download_overlay_async needs a C-contiguous uint8 array (n, H, W, 3)")
         _check(self.lib.lt_download_overlay_async(self._h, first, out.shape[0], out.ctypes.data))
+
+    def download_overlay_wait(self):
+        """Block until the frames of every download_overlay_async have landed (later uploads / masks keep running)."""
+        _check(self.lib.lt_download_overlay_wait(self._h))
 
     def download_bev(self, n, first=0):
         out = pinned_empty((n, self.warp_h, self.warp_w, 3))

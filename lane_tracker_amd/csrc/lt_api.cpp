@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -118,6 +119,11 @@ struct lt_ctx {
     struct StagingBusy { int lo = 0, hi = 0; hipEvent_t done = nullptr; };   // slots whose staging region a copy may still read
     StagingBusy spans_busy, text_busy;
     hipStream_t dl = nullptr;         // lt_download_overlay_async: device-to-host copies beside the compute and upload streams
+    // The presentation kernels (spans copy, lane overlay, text) run on a stream of their own: on a slot's compute stream they would
+    // queue behind the mask launches of LATER frames, which wait for uploads the bus has not delivered yet (measured: the first
+    // overlay of a stream of windows ran 30 ms after its frames were ready).  It waits, per slot range, for the kernels that
+    // wrote the slots' masks (hence for their camera rows) and for the copies of the remaining rows.
+    hipStream_t present = nullptr;
     StagingBusy annot_busy;           // annotated frames a copy on `dl` may still read
     hipEvent_t rest_done = nullptr;   // end of the most recent lt_upload_frame_rest on the copy stream
     bool rest_pending = false;
@@ -149,6 +155,7 @@ struct lt_ctx {
         void reset() { head = count = 0; overflow = false; }
     };
     RangeEvents readers, writers;
+    RangeEvents rests;                        // lt_upload_frame_rest copies (copy stream): the overlay of a slot waits for ITS rows only
     // The chained band search of a stream (lt_band_fit_chain_run) is one workgroup walking many frames: it runs on a stream
     // of its own, beside the mask chains of later frames on the slots' streams.  A chain leaves its records in page-locked
     // host memory behind an event (lt_band_fit_chain_collect waits for that event only, not for the device).  Work on the
@@ -194,6 +201,7 @@ int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
+    if (c->present) HIP_TRY(hipStreamSynchronize(c->present));
     if (c->dl) HIP_TRY(hipStreamSynchronize(c->dl));
     c->spans_busy.lo = c->spans_busy.hi = 0;            // every overlay, every copy of the rest rows
     c->text_busy.lo = c->text_busy.hi = 0;
@@ -201,6 +209,7 @@ int sync_all(lt_ctx* c) {
     c->rest_pending = false;
     c->readers.reset();                                 // every reader / writer enqueued so far is done
     c->writers.reset();
+    c->rests.reset();
     c->chain_lo = c->chain_hi = 0;                      // and every chain
     return LT_OK;
 }
@@ -737,6 +746,7 @@ void lt_destroy(lt_ctx* c) {
     if (c->text_busy.done) (void)hipEventDestroy(c->text_busy.done);
     if (c->annot_busy.done) (void)hipEventDestroy(c->annot_busy.done);
     if (c->dl) (void)hipStreamDestroy(c->dl);
+    if (c->present) (void)hipStreamDestroy(c->present);
     if (c->rest_done) (void)hipEventDestroy(c->rest_done);
     if (c->h_spans) (void)hipHostFree(c->h_spans);
     if (c->h_lines) (void)hipHostFree(c->h_lines);
@@ -903,11 +913,13 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     });
 }
 
-static int rest_mark(lt_ctx* c) {      // the overlay (on the context's first stream) waits for this before it reads the frames
+// the overlay (on the context's first stream) waits for the copies into its own slots before it reads the frames (or, when the
+// ring of slot ranges has overflowed, for the most recent copy)
+static int rest_mark(lt_ctx* c, int first, int n) {
     if (!c->rest_done && hipEventCreateWithFlags(&c->rest_done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(c->rest_done, c->copy));
     c->rest_pending = true;
-    return LT_OK;
+    return note_range(c->rests, c->copy, first, first + n);
 }
 
 int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
@@ -916,21 +928,31 @@ int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
     if (!frames) return fail(LT_ERR_INVALID, "null frames");
     if (n == 0) return LT_OK;
     if ((rc = set_device(c))) return rc;
-    // no synchronisation with the compute streams: these rows are read by nobody but the overlay, which waits
-    // for this stream (lt_sync / every download does)
+    // these rows are read by nobody but the overlay: the copy waits for the overlays still reading the frames it replaces
+    // (slot-range events; a stream of windows re-uses its slots), and the overlay of these slots waits for it
+    {
+        bool precise = true;
+        if ((rc = wait_range(c->readers, c->copy, first, first + n, &precise))) return rc;
+        if (!precise) {                      // the overlays run on the context's first stream
+            hipEvent_t e = next_order_event(c);
+            if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+            HIP_TRY(hipEventRecord(e, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->copy, e, 0));
+        }
+    }
     const size_t row_bytes = (size_t)c->calib.img_w * 3;
     const size_t head = (size_t)c->cam_r0 * row_bytes, tail0 = (size_t)c->cam_r1 * row_bytes;
     uint8_t* dst = c->d_frames + (size_t)first * c->frame_bytes;
     if (c->cam_r1 <= c->cam_r0) {
         HIP_TRY(hipMemcpyAsync(dst, frames, (size_t)n * c->frame_bytes, hipMemcpyHostToDevice, c->copy));
-        return rest_mark(c);
+        return rest_mark(c, first, n);
     }
     if (head)
         HIP_TRY(hipMemcpy2DAsync(dst, c->frame_bytes, frames, c->frame_bytes, head, (size_t)n, hipMemcpyHostToDevice, c->copy));
     if (tail0 < c->frame_bytes)
         HIP_TRY(hipMemcpy2DAsync(dst + tail0, c->frame_bytes, frames + tail0, c->frame_bytes, c->frame_bytes - tail0, (size_t)n,
                                  hipMemcpyHostToDevice, c->copy));
-    return rest_mark(c);
+    return rest_mark(c, first, n);
 }
 
 int lt_upload_masks(lt_ctx* c, const uint8_t* masks, int first, int n) {
@@ -1164,6 +1186,39 @@ static int staging_mark(lt_ctx::StagingBusy& b, hipStream_t st) {
     return LT_OK;
 }
 
+static int present_stream(lt_ctx* c) {
+    if (!c->present && create_compute_stream(&c->present, c->search_cus) != hipSuccess) return fail(LT_ERR_HIP, "hipStreamCreate failed");
+    return LT_OK;
+}
+
+int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const double* ploty, const double* ploty2, int n_rows,
+                   int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx) {
+    if (warp_w < 1 || warp_h < 1 || n < 0 || n_rows < 0 || !coeffs || !left_n || !right_n || !left_yx || !right_yx ||
+        (n_rows && (!ploty || !ploty2)))
+        return fail(LT_ERR_INVALID, "bad arguments");
+    // get_poly_points (lane_tracker.py:511-528) for n pairs of parabolas: fitx = a * ploty**2 + b * ploty + c evaluated as NumPy
+    // does (two products, two sums, no contraction: this file is built with -ffp-contract=off), the points with
+    // 0 <= fitx <= W - 1 kept, x truncated (astype(int)), and -- as upstream -- y = H - count .. H - 1 whatever rows they were
+    const double xmax = (double)(warp_w - 1);
+    size_t ol = 0, orr = 0;
+    for (int i = 0; i < n; ++i) {
+        for (int side = 0; side < 2; ++side) {
+            const double a = coeffs[6 * i + 3 * side], b = coeffs[6 * i + 3 * side + 1], cc = coeffs[6 * i + 3 * side + 2];
+            int32_t* out = side ? right_yx + 2 * orr : left_yx + 2 * ol;
+            int cnt = 0;
+            for (int r = 0; r < n_rows; ++r) {
+                const double t1 = a * ploty2[r], t2 = b * ploty[r];
+                const double x = (t1 + t2) + cc;
+                if (x <= xmax && x >= 0.0) out[2 * cnt++ + 1] = (int32_t)(long long)x;
+            }
+            for (int k = 0; k < cnt; ++k) out[2 * k] = warp_h - cnt + k;
+            if (side) { right_n[i] = cnt; orr += (size_t)cnt; }
+            else { left_n[i] = cnt; ol += (size_t)cnt; }
+        }
+    }
+    return LT_OK;
+}
+
 int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                    const int32_t* right_yx, double alpha) {
     int rc = check_slots(c, first, n);
@@ -1194,27 +1249,60 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     int16_t* hs = c->h_spans + (size_t)first * bh * 2;
     static const bool timing = std::getenv("LT_OVERLAY_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    size_t ol = 0, orr = 0;
-    for (int i = 0; i < n; ++i) {
-        lane_polygon_spans(hs + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
-                           right_yx ? right_yx + 2 * orr : nullptr, right_n[i]);
-        ol += (size_t)left_n[i];
-        orr += (size_t)right_n[i];
+    // ~18 us of edge walking per polygon: a window's piece of 32 .. 128 polygons is shared among a few threads (the caller is
+    // the one thread that feeds the device)
+    const int workers = std::max(1, std::min({n / 8, 8, (int)std::thread::hardware_concurrency()}));
+    auto some = [&](int w) {
+        size_t ol = 0, orr = 0;
+        for (int i = 0; i < n; ++i) {
+            if (i * (long long)workers / n == w)
+                lane_polygon_spans(hs + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
+                                   right_yx ? right_yx + 2 * orr : nullptr, right_n[i]);
+            ol += (size_t)left_n[i];
+            orr += (size_t)right_n[i];
+        }
+    };
+    if (workers == 1) some(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; ++w) pool.emplace_back(some, w);
+        some(0);
+        for (auto& t : pool) t.join();
     }
     // the rows of the frame the path does not read came on the copy stream (lt_upload_frame_rest): the overlay is their reader
     const auto t1 = std::chrono::steady_clock::now();
-    if (c->rest_pending) HIP_TRY(hipStreamWaitEvent(c->stream, c->rest_done, 0));
+    if ((rc = present_stream(c))) return rc;
+    hipStream_t ps = c->present;
+    if (c->rest_pending) {
+        bool precise = true;
+        if ((rc = wait_range(c->rests, ps, first, first + n, &precise))) return rc;
+        if (!precise) HIP_TRY(hipStreamWaitEvent(ps, c->rest_done, 0));
+    }
+    {   // the camera rows of these slots: behind the launches that wrote their masks (which waited for the rows' upload)
+        bool precise = true;
+        if ((rc = wait_range(c->writers, ps, first, first + n, &precise))) return rc;
+        if (!precise) {
+            rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
+                hipEvent_t e = next_order_event(c);
+                if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+                HIP_TRY(hipEventRecord(e, st));
+                HIP_TRY(hipStreamWaitEvent(ps, e, 0));
+                return (int)LT_OK;
+            });
+            if (rc) return rc;
+        }
+    }
     // an asynchronous download may still be reading the annotated frames this call overwrites
     if (c->annot_busy.hi > c->annot_busy.lo && first < c->annot_busy.hi && first + n > c->annot_busy.lo && c->annot_busy.done)
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->annot_busy.done, 0));
-    launch_copy_from_pinned(c->stream, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
+        HIP_TRY(hipStreamWaitEvent(ps, c->annot_busy.done, 0));
+    launch_copy_from_pinned(ps, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
     const auto t2 = std::chrono::steady_clock::now();
-    launch_overlay_lane(c->stream, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
+    launch_overlay_lane(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
     HIP_TRY(hipGetLastError());
-    if ((rc = staging_mark(c->spans_busy, c->stream))) return rc;
-    rc = note_range(c->readers, c->stream, first, first + n);
+    if ((rc = staging_mark(c->spans_busy, ps))) return rc;
+    rc = note_range(c->readers, ps, first, first + n);
     if (timing) {
         const auto t3 = std::chrono::steady_clock::now();
         auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
@@ -1292,13 +1380,14 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
     }
     uint8_t* dl = c->d_lines + (size_t)first * per;
     int16_t* dx = c->d_xpos + (size_t)first * per;
-    launch_copy_from_pinned(c->stream, dl, hl, (size_t)n * per);
-    launch_copy_from_pinned(c->stream, dx, hx, (size_t)n * per * sizeof(int16_t));
-    launch_overlay_text(c->stream, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
+    if ((rc = present_stream(c))) return rc;
+    launch_copy_from_pinned(c->present, dl, hl, (size_t)n * per);
+    launch_copy_from_pinned(c->present, dx, hx, (size_t)n * per * sizeof(int16_t));
+    launch_overlay_text(c->present, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
                         c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, dl, dx,
                         n_lines, line_len, y0, step, n);
     HIP_TRY(hipGetLastError());
-    return staging_mark(c->text_busy, c->stream);
+    return staging_mark(c->text_busy, c->present);
 }
 
 // Page-locked host memory for the buffers a caller hands to the upload / download entry points: a copy from or to
@@ -1343,12 +1432,22 @@ int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
     if (!c->dl) HIP_TRY(hipStreamCreateWithFlags(&c->dl, hipStreamNonBlocking));
     hipEvent_t e = next_order_event(c);
     if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(e, c->stream));
+    HIP_TRY(hipEventRecord(e, c->present ? c->present : c->stream));
     HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
     HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->dl));
     if (c->annot_busy.hi <= c->annot_busy.lo) { c->annot_busy.lo = first; c->annot_busy.hi = first + n; }
     else { c->annot_busy.lo = std::min(c->annot_busy.lo, first); c->annot_busy.hi = std::max(c->annot_busy.hi, first + n); }
     return staging_mark(c->annot_busy, c->dl);
+}
+
+int lt_download_overlay_wait(lt_ctx* c) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->dl) return LT_OK;
+    HIP_TRY(hipStreamSynchronize(c->dl));   // every copy of lt_download_overlay_async is behind its slots' overlay kernels
+    c->annot_busy.lo = c->annot_busy.hi = 0;
+    return LT_OK;
 }
 
 int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
@@ -1733,6 +1832,7 @@ int lt_set_search_cus(lt_ctx* c, int n) {
     c->streams = fresh;
     c->stream = c->streams.empty() ? c->stream : c->streams[0];
     if (c->search) { (void)hipStreamDestroy(c->search); c->search = nullptr; }
+    if (c->present) { (void)hipStreamDestroy(c->present); c->present = nullptr; }
     c->search_cus = n;
     return LT_OK;
 }

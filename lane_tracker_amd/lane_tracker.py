@@ -512,6 +512,63 @@ class LaneTracker:
         self.get_curve_radius()
         self.get_eccentricity()
 
+    def _record_successes(self, LF, RF, lo, hi, partial, deferred):
+        """`_record_success` + the deferred picture for the frames lo .. hi-1 of a run of valid first tries (raw fits LF, RF,
+        frames 0 .. lo-1 of the run already recorded; lo >= n_average - 1, so every average stays inside the run), all at
+        once: the same IEEE operations element-wise (averages: the sequential sum np.average forms, then the division;
+        radii: `get_curve_radius`; eccentricity) and `lt_poly_points` for `get_poly_points`.  Leaves the histories as they
+        are before frame `hi`.  Returns False -- nothing touched -- whenever a frame needs the scalar route's care: a radius
+        within 2e-8 of an integer (the exact refit decides those), not finite or huge, no positive radius in an averaging
+        window, or a parabola without a point inside the image."""
+        k = int(self.n_average)
+        LF, RF = np.asarray(LF, np.float64), np.asarray(RF, np.float64)
+        y_eval = self.warped_size[1]
+
+        def radii(Cf):                   # get_curve_radius for every frame of the run (their own raw fits)
+            a_m, b_m = Cf[:, 0] * self.mpph / (self.mppv ** 2), Cf[:, 1] * self.mpph / self.mppv
+            with np.errstate(all="ignore"):
+                return ((1 + (2 * a_m * y_eval * self.mppv + b_m) ** 2) ** 1.5) / np.absolute(2 * a_m)
+        vl, vr = radii(LF[:hi]), radii(RF[:hi])
+        for v in (vl, vr):
+            if not np.all(np.isfinite(v)) or np.any(v >= 2.0 ** 50) or np.any(np.abs(v - np.rint(v)) <= 2e-8 * np.maximum(1.0, np.abs(v))):
+                return False
+        r = np.trunc(0.5 * (np.trunc(vl).astype(np.int64) + np.trunc(vr).astype(np.int64))).astype(np.int64)   # per frame, :545
+        m = hi - lo
+        idx = np.arange(lo, hi)
+        total, count = np.zeros(m), np.zeros(m, np.int64)
+        suml, sumr = LF[idx - k + 1].copy(), RF[idx - k + 1].copy()
+        for t in range(k):               # window entry t of every frame: frame j - k + 1 + t
+            w = r[idx - k + 1 + t]
+            total += np.where(w > 0, w, 0)
+            count += w > 0
+            if t:
+                suml += LF[idx - k + 1 + t]
+                sumr += RF[idx - k + 1 + t]
+        if not np.all(count > 0):
+            return False
+        avg_radius = np.trunc(total / count).astype(np.int64)
+        avg = np.concatenate([suml / k, sumr / k], axis=1)
+        ploty, ploty2 = self._plot_rows(partial)
+        ln, rn, lyx, ryx = _native.poly_points(self.warped_size, avg, ploty, ploty2)
+        if not (np.all(ln > 0) and np.all(rn > 0)):
+            return False
+        le, re = np.cumsum(ln), np.cumsum(rn)
+        mid = int(self.warped_size[0] / 2)
+        ecc = (((mid - lyx[le - 1, 1].astype(np.int64)) - (ryx[re - 1, 1].astype(np.int64) - mid)) / 2) * self.mpph
+        lyx64, ryx64 = lyx.astype(np.int64), ryx.astype(np.int64)
+        for q in range(m):
+            self.counter += 1
+            lines = ["Curve Radius: {} m".format(int(avg_radius[q])), "Eccentricity: {:.2f} m".format(float(ecc[q]))]
+            if self.print_frame_count:
+                lines.append("Frame: {}".format(self.counter - 1))
+            a, b = lyx64[le[q] - ln[q]:le[q]], ryx64[re[q] - rn[q]:re[q]]
+            deferred.append(('lane', (a[:, 0], a[:, 1], b[:, 0], b[:, 1]), lines))
+        self.success += m
+        self.left_fit_coeffs = [np.array(c) for c in LF[hi - k:hi]]
+        self.right_fit_coeffs = [np.array(c) for c in RF[hi - k:hi]]
+        self.average_curve_radii = [int(v) for v in r[hi - k:hi]]
+        return True
+
     # ---- the chained stream pipeline (SURVEY.md 8(f) N2; reference :851-872, :1064-1128, :1178-1199) ------------
     search_cus = 1                   # CUs the chained search has to itself (the mask chain is kept off them); 0: shared
     chain_searches = True            # False: process_batch searches frame by frame (one record round trip per frame)
@@ -554,7 +611,9 @@ class LaneTracker:
         attribute at the end, equal those of `_step` frame by frame (tests/test_gpu_chain.py, tests/fuzz_chain.py).
         The window's frames live in slots base .. base+n-1; the first `prefed` of them already have their upload and
         first-try mask enqueued (by an earlier window); `ahead` = the windows that follow, in order, as mutable lists
-        [frames, first slot, frames fed so far]: they are fed, in order, as this window drains (the third entry is updated)."""
+        [frames, first slot, frames fed so far]: they are fed, in order, as this window drains (the third entry is updated).
+        A generator: it yields exactly once, when the window's first searches are in flight (`process_stream` uses that moment to
+        wait for the previous window's annotated frames); run it to exhaustion."""
         ctx, n = self._ctx, frames.shape[0]
         ahead = ahead or []
         total = n + sum(len(a[0]) for a in ahead)
@@ -585,6 +644,8 @@ class LaneTracker:
                     m = min(span(masked), n - masked)
                     ctx.upload_frame_rows_async(frames[masked:masked + m], first=base + masked)
                     ctx.mask_run(m, fp, first=base + masked)
+                    if annotate:         # the rest of these frames, for the overlay: behind their rows on the copy stream
+                        ctx.upload_frame_rest(frames[masked:masked + m], first=base + masked)
                 else:
                     q = masked - n
                     for a in ahead:                       # the window position `masked` falls into
@@ -594,11 +655,11 @@ class LaneTracker:
                     m = min(chunk, len(a[0]) - q)
                     ctx.upload_frame_rows_async(a[0][q:q + m], first=a[1] + q)
                     ctx.mask_run(m, fp, first=a[1] + q)
+                    if annotate:
+                        ctx.upload_frame_rest(a[0][q:q + m], first=a[1] + q)
                     a[2] = q + m
                 masked += m
         feed(2 * chunk)
-        if annotate:
-            self._upload_keepalive = ctx.upload_frame_rest(frames, first=base)     # beside the mask chain, for the overlay
         depth = max(1, int(self.chain_depth))
 
         def launch(at):
@@ -641,11 +702,14 @@ class LaneTracker:
 
         # chains in flight, oldest first: each but the first is seeded on the device by the last record of the one before it,
         # so each waits for the masks of its own frames only and the host checks one while the next ones run
-        i, flight = 0, []
+        i, flight, started = 0, [], False
         while i < n:
             if not flight:
                 first_chain = launch(i)
                 if first_chain is None:
+                    if not started:
+                        started = True
+                        yield
                     self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate,
                                defer=deferred)
                     i += 1
@@ -656,6 +720,9 @@ class LaneTracker:
                 if more is None:
                     break
                 flight.append(more)
+            if not started:
+                started = True
+                yield
             first, L, mode = flight.pop(0)
             rec = ctx.band_fit_chain_collect(L, first=base + first)
             good = (rec["mode"] != 255) & (rec["detected"] != 0) & (rec["fit_flags"] == 0)
@@ -673,7 +740,7 @@ class LaneTracker:
             if skip:
                 self.counter += skip
                 self.success += skip
-            for j in range(skip, g):
+            def commit(j):
                 self.counter += 1
                 self.detected_pixels = True
                 self.valid_lane_lines = True
@@ -685,6 +752,15 @@ class LaneTracker:
                 if annotate:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
                                      self._lane_text()))
+            j, k_avg = skip, int(self.n_average)
+            if annotate and k_avg >= 1 and g >= 2 * k_avg + 4:
+                # with annotation every frame leaves a picture: the first n_average - 1 frames (their averages reach back
+                # before the run) and the last one (it leaves the state) go the ordinary way, the ones between all at once
+                for j in range(k_avg - 1):
+                    commit(j)
+                j = g - 1 if self._record_successes(LF[:g], RF[:g], k_avg - 1, g - 1, partial, deferred) else k_avg - 1
+            for j in range(j, g):
+                commit(j)
             i = first + g
             if flush is not None:
                 flush(False)             # render and download what has been committed so far, under the searches still running
@@ -699,6 +775,8 @@ class LaneTracker:
                 i += 1
         if flush is not None:
             flush(True)
+        if not started:                  # (an empty window)
+            yield
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,
@@ -810,7 +888,8 @@ class LaneTracker:
         deferred = []
         if self.chain_searches and not k["diagnostics"]:
             flush, out = self._window_renderer(deferred, 0, n) if (annotate and n) else (None, None)
-            self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred, flush=flush)
+            for _ in self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred, flush=flush):
+                pass
             self._materialise_pending()  # the attributes describe the last frame, as after process() (also waits for `out`)
             if out is not None:
                 ctx.sync()
@@ -848,11 +927,22 @@ class LaneTracker:
         cur = self._as_window(cur)
         ctx = self._ctx
         look = max(1, int(self.stream_lookahead))
-        regions = look + 1               # windows resident side by side: the one being searched and `look` being fed
+        # windows resident side by side: the one being searched and `look` being fed -- and, with annotation, the one before,
+        # whose frames are still on their way back while the next one's first searches start
+        regions = look + (2 if annotate else 1)
         size = 0                         # slots per region
         free = []                        # first slots of the regions nobody lives in
         queue = []                       # windows ahead of `cur`, in order: [frames, first slot, frames fed]; [.., None, 0]: not placed
         cur = [cur, None, 0]
+        landing = None                   # (page-locked frames, first slot) of the window before `cur`, annotated frames being copied back
+
+        def landed():
+            nonlocal landing
+            arrays, region = landing
+            landing = None
+            ctx.download_overlay_wait()  # these frames have landed; the uploads, masks and searches of the next windows run on
+            free.append(region)
+            return list(arrays)
         self._in_stream = True
         try:
             while cur is not None:
@@ -863,6 +953,8 @@ class LaneTracker:
                     queue.append([self._as_window(w), None, 0])
                 n = cur[0].shape[0]
                 if cur[1] is None:                   # first window, or one that did not fit the regions: (re)size the context
+                    if landing is not None:
+                        yield landed()
                     if n > size:
                         self._materialise_pending()  # growing the context drops what is still on the device
                         size = (n + 1) & ~1
@@ -881,16 +973,21 @@ class LaneTracker:
                 deferred = []
                 flush, frames_out = self._window_renderer(deferred, cur[1], n) if (annotate and n) else (None, None)
                 if n:
-                    self._run_window_chained(cur[0], first_try, fp, k["n_tries"], annotate, deferred, base=cur[1], prefed=cur[2],
-                                             ahead=ahead, flush=flush)
+                    for _ in self._run_window_chained(cur[0], first_try, fp, k["n_tries"], annotate, deferred, base=cur[1],
+                                                      prefed=cur[2], ahead=ahead, flush=flush):
+                        if landing is not None:      # this window's first searches are in flight: now wait for the frames of the one before
+                            yield landed()
+                if landing is not None:
+                    yield landed()
                 if frames_out is not None:
-                    ctx.sync()           # the last pieces of this window's frames are on their way (the next windows' heads run too)
-                    out = list(frames_out)
+                    landing = (frames_out, cur[1])   # handed out when the next window is under way (or the stream ends)
+                    cur = queue.pop(0) if queue else None
                 else:
-                    out = [None] * n
-                free.append(cur[1])      # its frames, masks and records are not needed any more
-                cur = queue.pop(0) if queue else None
-                yield out
+                    free.append(cur[1])  # its frames, masks and records are not needed any more
+                    cur = queue.pop(0) if queue else None
+                    yield [None] * n
+            if landing is not None:
+                yield landed()
             self._materialise_pending()  # the attributes describe the last frame, as after process()
         finally:
             self._in_stream = False

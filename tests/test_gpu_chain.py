@@ -221,21 +221,23 @@ def test_chain_fuzz_short():
     assert fuzz_chain.main(iters=6, seed=11, verbose=False) == 0
 
 
-@pytest.mark.parametrize("annotate", [False, True])
-def test_process_stream_equals_process_frame_by_frame(annotate):
+@pytest.mark.parametrize("annotate,sizes,every,n_average", [(False, (24, 24, 10, 40, 24, 1, 24), 9, 2), (True, (24, 24, 10, 40, 24, 1, 24), 9, 2),
+                                                            (True, (70, 0, 50, 31), 40, 3), (True, (64, 64), 1000, 1)])
+def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_average):
     """Windows of one video through process_stream (the next window's uploads and masks run while the current one's searches
-    drain; two windows resident side by side) -- state after every window and the annotated frames equal process();
-    a longer window in the middle forces the context to grow; process() inside an active stream is refused."""
+    drain; windows resident side by side) -- state after every window and the annotated frames equal process();
+    a longer window in the middle forces the context to grow; process() inside an active stream is refused.  The long
+    runs of valid frames of the last two cases go through the all-at-once bookkeeping (`_record_successes`), with an empty
+    window in between; an annotated window is handed out while the next one's first searches are already in flight."""
     from lane_tracker_amd import calib
     from lane_tracker_amd.lane_tracker import LaneTracker
     cal = calib.reference_calibration()
-    sizes = (24, 24, 10, 40, 24, 1, 24)
-    frames = _stream_with_failures(sum(sizes), 9, seed=37)
+    frames = _stream_with_failures(sum(sizes), every, seed=37)
     wins, lo = [], 0
     for w in sizes:
         wins.append(frames[lo:lo + w])
         lo += w
-    seq, bat = LaneTracker(**cal), LaneTracker(**cal)
+    seq, bat = LaneTracker(n_average=n_average, **cal), LaneTracker(n_average=n_average, **cal)
     try:
         gen = bat.process_stream(wins, annotate=annotate)
         for k, (win, outs) in enumerate(zip(wins, gen)):
@@ -249,9 +251,9 @@ def test_process_stream_equals_process_frame_by_frame(annotate):
                 assert outs == [None] * len(win)
             if k == 1:
                 with pytest.raises(RuntimeError):
-                    bat.process(win[0])
+                    bat.process(frames[0])
         assert next(gen, None) is None and not bat._in_stream
-        assert 0 < bat.success < bat.counter == sum(sizes)
+        assert 0 < bat.success <= bat.counter == sum(sizes) and (bat.success < bat.counter or every > sum(sizes))
         bat.process(frames[0])                                 # usable again once the generator is exhausted
     finally:
         seq.close()

@@ -97,3 +97,109 @@ def test_rendezvous_path_is_new_for_every_elastic_attempt(monkeypatch):
     assert distributed.shares_devices() is False
     monkeypatch.setenv("LT_DEVICE_MODULO", "1")
     assert distributed.shares_devices() is True
+
+
+def _history_tracker(n_average, print_frame_count=False):
+    t = HostOnlyTracker()
+    t.n_average, t.print_frame_count = n_average, print_frame_count
+    t.mppv, t.mpph = 0.02002, 0.01851            # metres per pixel of the reference calibration's order
+    t.left_fit_coeffs, t.right_fit_coeffs, t.average_curve_radii = [], [], []
+    t.counter = t.success = 0
+    t.last_detection = 3
+    return t
+
+
+def _scalar_commit(t, lf, rf, partial, deferred):
+    t.counter += 1
+    t._fit = ("pending", None, lf, rf)
+    t._record_success(lf, rf, partial)
+    deferred.append(('lane', (t.left_avg_y, t.left_avg_x, t.right_avg_y, t.right_avg_x), t._lane_text()))
+
+
+@pytest.mark.parametrize("n_average,partial,frame_count", [(1, 1.0, False), (2, 1.0, True), (3, 0.5, False), (5, 1.0, True), (8, 0.3, False)])
+def test_run_of_successes_recorded_at_once_equals_frame_by_frame(n_average, partial, frame_count):
+    """`_record_successes` (the annotated stream pipeline commits a whole run of valid frames in one go) against
+    `_record_success` frame by frame: every picture (polygon points, text lines) and the state left behind, bit for bit --
+    with a history that holds a failure and older fits when the run starts."""
+    rng = np.random.default_rng(10 + n_average)
+    g = 70
+    LF = np.stack([[rng.uniform(-3e-4, 3e-4), rng.uniform(-0.5, 0.3), rng.uniform(350, 520)] for _ in range(g)])
+    RF = LF + np.stack([[rng.uniform(-2e-5, 2e-5), rng.uniform(-0.05, 0.05), rng.uniform(150, 230)] for _ in range(g)])
+    LF[20] = [2e-4, -1.4, 1400.0]                # leaves the image at the bottom: fewer points than rows
+    a, b = _history_tracker(n_average, frame_count), _history_tracker(n_average, frame_count)
+    for t in (a, b):                             # what happened before the run
+        d0 = []
+        _scalar_commit(t, LF[0] * 1.01, RF[0] * 1.01, partial, d0)
+        t.counter += 1
+        t._record_failure()
+    want, got = [], []
+    for j in range(g):
+        _scalar_commit(a, np.array(LF[j]), np.array(RF[j]), partial, want)
+    for j in range(n_average - 1):
+        _scalar_commit(b, np.array(LF[j]), np.array(RF[j]), partial, got)
+    assert b._record_successes(LF, RF, n_average - 1, g - 1, partial, got)
+    _scalar_commit(b, np.array(LF[g - 1]), np.array(RF[g - 1]), partial, got)
+    assert len(got) == len(want) == g
+    for j, (x, y) in enumerate(zip(got, want)):
+        assert x[0] == y[0] and x[2] == y[2], (j, x[2], y[2])
+        for p, q in zip(x[1], y[1]):
+            assert p.dtype == q.dtype and np.array_equal(p, q), j
+    for name in ("counter", "success", "last_detection", "average_curve_radii", "average_curve_radius", "eccentricity",
+                 "left_curve_radius", "right_curve_radius"):
+        assert getattr(a, name) == getattr(b, name), name
+    for name in ("left_fit_coeffs", "right_fit_coeffs"):
+        assert len(getattr(a, name)) == len(getattr(b, name)) and all(np.array_equal(p, q) for p, q in zip(getattr(a, name), getattr(b, name)))
+    for name in ("left_avg_coeffs", "right_avg_coeffs", "left_avg_x", "left_avg_y", "right_avg_x", "right_avg_y", "last_left_coeffs"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_run_of_successes_hands_the_delicate_frames_back():
+    """A radius on an integer (the exact refit decides), a straight lane (infinite radius) or a parabola outside the image:
+    nothing is recorded and the caller goes frame by frame."""
+    t = _history_tracker(2)
+    rng = np.random.default_rng(4)
+    LF = np.stack([[rng.uniform(1e-4, 3e-4), rng.uniform(-0.3, 0.1), 420.0] for _ in range(12)])
+    RF = LF + [0.0, 0.0, 190.0]
+    for case in ("straight", "outside", "integer"):
+        L2 = LF.copy()
+        if case == "straight":
+            L2[5, 0] = 0.0
+        elif case == "outside":
+            L2[5] = [0.0001, 0.0, 5000.0]
+            L2[6] = [0.0001, 0.0, 5000.0]
+        else:
+            # choose `a` so that the radius is an integer to ~1e-12: solve by bisection on the closed form
+            f = lambda a: ((1 + (2 * (a * t.mpph / t.mppv ** 2) * 1100 * t.mppv + L2[5, 1] * t.mpph / t.mppv) ** 2) ** 1.5) / abs(2 * a * t.mpph / t.mppv ** 2)
+            target = float(np.floor(f(2e-4)))
+            lo, hi = 2e-4, 2.2e-4
+            assert (f(lo) - target) * (f(hi) - target) < 0
+            for _ in range(200):
+                mid = 0.5 * (lo + hi)
+                lo, hi = (mid, hi) if (f(mid) - target) * (f(hi) - target) < 0 else (lo, mid)
+            L2[5, 0] = lo
+            assert abs(f(lo) - target) < 1e-6
+        before = (t.counter, t.success, list(t.left_fit_coeffs))
+        d = []
+        assert t._record_successes(L2, RF, 1, 11, 1.0, d) is False
+        assert d == [] and (t.counter, t.success, list(t.left_fit_coeffs)) == before, case
+
+
+def test_packed_poly_points_equal_get_poly_points():
+    """lt_poly_points (C, host-only) = get_poly_points for each pair of parabolas, including ones that leave the image, for
+    integer and fractional `partial` (the plot rows come from the tracker's own NumPy linspace)."""
+    from lane_tracker_amd import _native
+    t = HostOnlyTracker()
+    rng = np.random.default_rng(8)
+    C = np.stack([[rng.uniform(-6e-4, 6e-4), rng.uniform(-1.2, 1.2), rng.uniform(-200, 1300),
+                   rng.uniform(-6e-4, 6e-4), rng.uniform(-1.2, 1.2), rng.uniform(-200, 1300)] for _ in range(300)])
+    C[7] = [0, 0, 1079.0, 0, 0, 0.0]             # exactly on both borders
+    C[8] = [0, 0, 1079.0000001, 0, 0, -1e-9]     # just outside
+    for partial in (1, 1.0, 0.5, 0.3):
+        ploty, ploty2 = t._plot_rows(partial)
+        ln, rn, lyx, ryx = _native.poly_points(t.warped_size, C, ploty, ploty2)
+        le, re = np.cumsum(ln), np.cumsum(rn)
+        for i in range(len(C)):
+            ly, lx, ry, rx = t.get_poly_points(C[i, :3], C[i, 3:], partial)
+            a, b = lyx[le[i] - ln[i]:le[i]], ryx[re[i] - rn[i]:re[i]]
+            assert np.array_equal(a[:, 0], ly) and np.array_equal(a[:, 1], lx) and np.array_equal(b[:, 0], ry) and np.array_equal(b[:, 1], rx), (i, partial)
+    assert ln[7] == 1100 * 0 + len(t._plot_rows(0.3)[0]) and rn[7] == ln[7] and ln[8] == 0 and rn[8] == 0
