@@ -612,8 +612,9 @@ class LaneTracker:
         The window's frames live in slots base .. base+n-1; the first `prefed` of them already have their upload and
         first-try mask enqueued (by an earlier window); `ahead` = the windows that follow, in order, as mutable lists
         [frames, first slot, frames fed so far]: they are fed, in order, as this window drains (the third entry is updated).
-        A generator: it yields exactly once, when the window's first searches are in flight (`process_stream` uses that moment to
-        wait for the previous window's annotated frames); run it to exhaustion."""
+        A generator: it yields exactly once, when the window's first searches are in flight and the first of them is checked, but
+        before anything of the window is committed to the tracker's state (`process_stream` uses that moment to wait for the
+        previous window's annotated frames); run it to exhaustion."""
         ctx, n = self._ctx, frames.shape[0]
         ahead = ahead or []
         total = n + sum(len(a[0]) for a in ahead)
@@ -636,6 +637,12 @@ class LaneTracker:
 
         def span(at):                    # frames per launch at position `at`: short at the head of a stand-alone window (the
             return min(chunk, max(16, at & ~1)) if head else chunk   # first records come back early), then `chunk`
+
+        def chain_span(at):              # frames per chain: in an annotated stream a window starts with short chains (32, 32, 64,
+            if annotate and self._in_stream and self.chain_chunk is None:    # ...), so that its first frames are on their way
+                return min(chunk, max(32, at & ~1))    # back soon after the frames of the window before have landed (the host waits
+            return span(at)              # for those before it commits anything of this window) and each piece's bookkeeping hides
+                                         # under the copy of the piece before
 
         def feed(upto):                  # keep the device supplied with masks ahead of the searches
             nonlocal masked
@@ -666,7 +673,7 @@ class LaneTracker:
             """Enqueue a chain at frame `at` from the tracker's state (host seed, or a sliding-window search of `at` and a
             chain behind it).  Returns (first, length, search mode of the first frame) or None (frame by frame)."""
             feed(at + (depth + 1) * chunk)
-            L = min(span(at), min(masked, n) - at)
+            L = min(chain_span(at), min(masked, n) - at)
             mode = 'sws' if self.last_detection > self.n_reset else 'bs'          # :851
             if self._pending is not None and self._pending[0] is ctx and base + at <= self._pending[1] < base + n:
                 self._materialise_pixels()        # (cannot happen inside a window: committed frames lie before `at`)
@@ -693,7 +700,7 @@ class LaneTracker:
                 feed(at + (depth + 1) * chunk)   # nothing left to chain in this window: keep feeding the next one
                 return None
             feed(at + (depth + 1) * chunk)
-            L = min(span(at), min(masked, n) - at)
+            L = min(chain_span(at), min(masked, n) - at)
             try:
                 ctx.band_fit_chain_run(L, None, sp_band, first=base + at)
             except _native.NativeError:
@@ -720,9 +727,6 @@ class LaneTracker:
                 if more is None:
                     break
                 flight.append(more)
-            if not started:
-                started = True
-                yield
             first, L, mode = flight.pop(0)
             rec = ctx.band_fit_chain_collect(L, first=base + first)
             good = (rec["mode"] != 255) & (rec["detected"] != 0) & (rec["fit_flags"] == 0)
@@ -732,6 +736,9 @@ class LaneTracker:
                 ok = self._valid_many(LF[:g], RF[:g])
                 if not ok.all():
                     g = int(np.argmin(ok))
+            if not started:              # nothing of this window has touched the tracker's state yet
+                started = True
+                yield
             # frames first .. first+g-1: first try valid.  Without annotation only the last n_average of them leave a
             # trace in the state (histories are that long; every other attribute is overwritten by each success).
             skip = 0 if annotate else max(0, g - max(int(self.n_average), 1))

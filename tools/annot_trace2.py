@@ -10,10 +10,10 @@ n = 256
 base = synth.stream_lanes(32, seed=5, cal=cal)
 frames = np.concatenate([base, base[::-1]] * (n // 64 + 1), 0)[:n].copy()
 lt = LaneTracker(**cal)
-for o in lt.process_stream([frames] * 2):
+for o in lt.process_stream([frames] * 4):
     pass
 time.sleep(0.05)
 t0 = time.perf_counter()
-for o in lt.process_stream([frames] * 3):
+for o in lt.process_stream([frames] * 5):
     pass
-print("fps", 3 * n / (time.perf_counter() - t0))
+print("fps", 5 * n / (time.perf_counter() - t0))
