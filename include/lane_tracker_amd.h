@@ -186,6 +186,12 @@ int  lt_band_fit_chain_collect(lt_ctx* ctx, int first_slot, int n, lt_lane_recor
  * takes 18.6 us per frame beside a running chain, 15.1 with one CU set aside (12.8 alone).  Call it on an idle context (it
  * synchronises); a context that only processes independent batches has no use for it. */
 int  lt_set_search_cus(lt_ctx* ctx, int n);
+/* Urgent mode, for the frame of a stateful stream whose first try failed (lane_tracker.py:1071-1128: second parameter set,
+ * second search) while masks of later frames are already queued: between lt_set_urgent(ctx, 1) and lt_set_urgent(ctx, 0),
+ * lt_mask_run / lt_filter_run / lt_sws_fit_run / lt_band_fit_run run on a stream of their own, behind the work enqueued for
+ * THEIR slots only, and the lt_download_* calls wait for that stream only (they must ask for results produced in urgent mode,
+ * or already complete).  Work enqueued for those slots afterwards is ordered behind it.  Leaving the mode waits for it. */
+int  lt_set_urgent(lt_ctx* ctx, int on);
 /* The caller has rejected a frame: every chain enqueued so far stops at its next frame (the slots it has not searched
  * get mode 255) instead of finishing its speculation.  Chains enqueued afterwards are not affected. */
 int  lt_band_fit_chain_cancel(lt_ctx* ctx);

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "lt_band_fit_chain_collect": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_band_fit_chain_cancel": (C.c_int, [_P]),
     "lt_set_search_cus": (C.c_int, [_P, C.c_int]),
+    "lt_set_urgent": (C.c_int, [_P, C.c_int]),
     "lt_poly_points": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
     "lt_download_overlay_wait": (C.c_int, [_P]),
     "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
@@ -533,6 +534,20 @@ class Context:
     def set_search_cus(self, n):
         """Reserve n CUs for the chained search (the compute streams are recreated without them); 0 undoes it."""
         _check(self.lib.lt_set_search_cus(self._h, int(n)))
+
+    def urgent(self):
+        """Context manager: the stage calls inside run on the context's urgent stream (lt_set_urgent) -- behind the work of their
+        own slots only, not behind masks of later frames already queued -- and downloads wait for that stream only."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            _check(self.lib.lt_set_urgent(self._h, 1))
+            try:
+                yield self
+            finally:
+                _check(self.lib.lt_set_urgent(self._h, 0))
+        return scope()
 
     def band_fit_chain_cancel(self):
         """Chains enqueued so far stop at their next frame (their speculation has been rejected)."""

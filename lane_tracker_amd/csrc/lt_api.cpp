@@ -124,6 +124,11 @@ struct lt_ctx {
     // overlay of a stream of windows ran 30 ms after its frames were ready).  It waits, per slot range, for the kernels that
     // wrote the slots' masks (hence for their camera rows) and for the copies of the remaining rows.
     hipStream_t present = nullptr;
+    // lt_set_urgent: while on, the stage calls run on this stream instead of the slots' streams -- behind what was enqueued
+    // for THEIR slots only (slot-range events), not behind the masks of later frames queued on the slots' streams, which
+    // wait for uploads still on the bus.  The stateful stream handles a frame whose first try failed this way.
+    hipStream_t urgent = nullptr;
+    bool urgent_on = false;
     StagingBusy annot_busy;           // annotated frames a copy on `dl` may still read
     hipEvent_t rest_done = nullptr;   // end of the most recent lt_upload_frame_rest on the copy stream
     bool rest_pending = false;
@@ -202,6 +207,7 @@ int sync_all(lt_ctx* c) {
     if (c->copy) HIP_TRY(hipStreamSynchronize(c->copy));
     if (c->search) HIP_TRY(hipStreamSynchronize(c->search));
     if (c->present) HIP_TRY(hipStreamSynchronize(c->present));
+    if (c->urgent) HIP_TRY(hipStreamSynchronize(c->urgent));
     if (c->dl) HIP_TRY(hipStreamSynchronize(c->dl));
     c->spans_busy.lo = c->spans_busy.hi = 0;            // every overlay, every copy of the rest rows
     c->text_busy.lo = c->text_busy.hi = 0;
@@ -251,9 +257,46 @@ int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) { return note_range(
 // Slot -> stream mapping is fixed (contiguous slices of the capacity), so consecutive stages of one
 // slot stay ordered on one stream while different slices overlap: the latency-bound search of one
 // slice runs under the mask chain of another.  Calls fn(stream, first, n) for every non-empty piece.
+hipEvent_t next_order_event(lt_ctx* c);
 template <class F>
 int for_each_slice(lt_ctx* c, int first, int n, F fn) {
     const int k = std::max(1, std::min(c->nstreams, c->capacity));
+    if (c->urgent_on && c->urgent) {
+        // one piece on the urgent stream: behind the kernels that wrote these slots (or, with the ring overflowed, the tails of
+        // their streams) and a chain still touching them; the slots' own streams then wait for it, so that whatever is
+        // enqueued for these slots later stays ordered behind it
+        hipStream_t us = c->urgent;
+        bool precise = true;
+        int rc = wait_range(c->writers, us, first, first + n, &precise);
+        if (rc) return rc;
+        auto slices = [&](auto g) {
+            for (int si = 0; si < k; ++si) {
+                const int lo = (int)((long long)c->capacity * si / k) & ~1, hi = si + 1 == k ? c->capacity : (int)((long long)c->capacity * (si + 1) / k) & ~1;
+                if (std::min(first + n, hi) > std::max(first, lo)) { int r = g(c->streams[si]); if (r) return r; }
+            }
+            return (int)LT_OK;
+        };
+        if (!precise) {
+            rc = slices([&](hipStream_t st) {
+                hipEvent_t e = next_order_event(c);
+                if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+                HIP_TRY(hipEventRecord(e, st));
+                HIP_TRY(hipStreamWaitEvent(us, e, 0));
+                return (int)LT_OK;
+            });
+            if (rc) return rc;
+        }
+        if (c->chain_hi > c->chain_lo && first < c->chain_hi && first + n > c->chain_lo && c->chain_tail)
+            HIP_TRY(hipStreamWaitEvent(us, c->chain_tail, 0));
+        if ((rc = fn(us, first, n))) return rc;
+        hipEvent_t done = next_order_event(c);
+        if (!done) return fail(LT_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(done, us));
+        return slices([&](hipStream_t st) {
+            HIP_TRY(hipStreamWaitEvent(st, done, 0));
+            return (int)LT_OK;
+        });
+    }
     for (int si = 0; si < k; ++si) {
         // even boundaries: the undistorted rows of slots 2p and 2p+1 are interleaved, and the warp serves a pair with one load
         const int lo = (int)((long long)c->capacity * si / k) & ~1, hi = si + 1 == k ? c->capacity : (int)((long long)c->capacity * (si + 1) / k) & ~1;
@@ -747,6 +790,7 @@ void lt_destroy(lt_ctx* c) {
     if (c->annot_busy.done) (void)hipEventDestroy(c->annot_busy.done);
     if (c->dl) (void)hipStreamDestroy(c->dl);
     if (c->present) (void)hipStreamDestroy(c->present);
+    if (c->urgent) (void)hipStreamDestroy(c->urgent);
     if (c->rest_done) (void)hipEventDestroy(c->rest_done);
     if (c->h_spans) (void)hipHostFree(c->h_spans);
     if (c->h_lines) (void)hipHostFree(c->h_lines);
@@ -986,6 +1030,11 @@ static int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
     if (!dst) return fail(LT_ERR_INVALID, "null output buffer");
     int rc = set_device(c);
     if (rc) return rc;
+    if (c->urgent_on && c->urgent) {        // lt_set_urgent: what is asked for was produced on the urgent stream (or is complete)
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->urgent));
+        HIP_TRY(hipStreamSynchronize(c->urgent));
+        return LT_OK;
+    }
     if ((rc = sync_all(c))) return rc;      // results may come from any of the context's streams
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1701,7 +1750,9 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
     if (n == 0) return LT_OK;
     BandPrev bp;
     std::memset(&bp, 0, sizeof bp);
-    if (n == 1) {   // the stateful stream: one frame at a time, coefficients by value
+    bool one_seed = true;     // every frame around the same curves (a group of frames behind a failure: the last valid fits)
+    for (int i = 1; i < n && one_seed; ++i) one_seed = std::memcmp(prev, prev + (size_t)i * 6, 6 * sizeof(double)) == 0;
+    if (one_seed) {   // the stateful stream: coefficients by value, no copy to wait for
         std::memcpy(bp.c, prev, sizeof bp.c);
         bp.by_value = 1;
     } else {
@@ -1809,6 +1860,16 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     return LT_OK;
 }
 
+int lt_set_urgent(lt_ctx* c, int on) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (on && !c->urgent && create_compute_stream(&c->urgent, c->search_cus) != hipSuccess) return fail(LT_ERR_HIP, "hipStreamCreate failed");
+    if (!on && c->urgent_on && c->urgent) HIP_TRY(hipStreamSynchronize(c->urgent));   // leaving: nothing of it is left in flight unseen
+    c->urgent_on = on != 0;
+    return LT_OK;
+}
+
 int lt_set_search_cus(lt_ctx* c, int n) {
     if (!c) return fail(LT_ERR_INVALID, "null context");
     if (n < 0 || n > 64) return fail(LT_ERR_INVALID, "the search stream can have 0 .. 64 CUs to itself");
@@ -1833,6 +1894,7 @@ int lt_set_search_cus(lt_ctx* c, int n) {
     c->stream = c->streams.empty() ? c->stream : c->streams[0];
     if (c->search) { (void)hipStreamDestroy(c->search); c->search = nullptr; }
     if (c->present) { (void)hipStreamDestroy(c->present); c->present = nullptr; }
+    if (c->urgent) { (void)hipStreamDestroy(c->urgent); c->urgent = nullptr; c->urgent_on = false; }
     c->search_cus = n;
     return LT_OK;
 }

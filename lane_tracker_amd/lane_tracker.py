@@ -576,6 +576,8 @@ class LaneTracker:
                                      # 32 for a stand-alone window (its head and tail count), half a window up to 128 in a
                                      # stream of windows (the walking threshold kernels take launches of >= 80 frames)
     chain_depth = 3                  # chains kept in flight behind the one the host is checking
+    outage_groups = True             # False: a frame whose first try failed is handled alone (`_step`), not in speculative groups
+    _outage_group = 4                # frames in the next such group: 4, doubling up to 32 while every frame of a group fails
     stream_lookahead = 2             # process_stream: windows fed (uploads + masks) ahead of the one being searched; with 1 the
                                      # uploads pause between windows (the next-but-one window would reuse the slots still searched)
 
@@ -605,6 +607,138 @@ class LaneTracker:
         norm1 = np.abs(slope(LF, y1) - slope(RF, y1))
         norm2 = np.abs(slope(LF, y3) - slope(RF, y3))
         return ~dist_bad & ~((norm1 >= lim['thresh']) | (norm2 >= lim['thresh']))
+
+    _SECOND_TRY = (15, 5, 35, 5, 'neighborhood', False, 140, 65, 10, 30, 40, 20, 0.1, 50, 0.25, 360, 30, 30, 1.0)   # :1081-1099
+
+    def _fail_group(self, frames, base, i, k, first_try, fp, n_tries, annotate, deferred):
+        """Frames i .. i+k-1 of a window (slots base+i ..; first-try masks computed), the first of which is known or
+        expected to fail its first try: all of them at once, speculating that every one fails both tries.  While frames
+        fail, nothing a frame needs depends on the frame before it except the count of misses: its search mode (sliding
+        windows once `last_detection > n_reset`, :851) and the band seed (the last valid fits, unchanged) are known in
+        advance.  So: the first-try searches of the whole group in one launch, one record download; the second-try masks
+        and searches of the frames in front of the first first-try success likewise; then the frames are committed in order up
+        to and including the first success (whatever was computed behind it under the wrong hypothesis is dropped, and the
+        first-try masks the second try overwrote are computed again).  Returns (frames committed >= 1, ended with a success).
+        State after every frame = `_step` frame by frame (tests/test_stream_driver_cpu.py, tests/fuzz_chain.py)."""
+        ctx = self._ctx
+        tries = [first_try] + ([self._SECOND_TRY] if (n_tries >= 2 or n_tries == -1) else [])
+        d0 = int(self.last_detection)
+        n_bs = max(0, min(k, int(self.n_reset) - d0 + 1))          # frames j with d0 + j <= n_reset search a band, the rest windows
+        if n_bs and (self.last_left_coeffs is None or self.last_right_coeffs is None or np.size(self.last_left_coeffs) != 3):
+            k = 0
+        seed = None if not n_bs or not k else np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
+                                                              np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
+        for handle, fetch in ((self._pending, self._materialise_pixels), (self._pending_cent, self._materialise_centroids)):
+            if handle is not None and handle[0] is ctx and base + i <= handle[1] < base + i + k:
+                fetch()                  # (lists not fetched yet that these searches would overwrite)
+
+        def search(t, lo, hi):           # try t of frames lo .. hi-1 -> their records
+            q = tries[t]
+            try:
+                if lo < min(n_bs, hi):
+                    m = min(n_bs, hi) - lo
+                    ctx.band_fit_run(m, np.tile(seed, (m, 1)), _native.search_params(bandwidth=q[17], ignore_bottom=q[16], partial=q[18]),
+                                     first=base + i + lo)
+                if max(n_bs, lo) < hi:
+                    a = max(n_bs, lo)
+                    ctx.sws_fit_run(hi - a, _native.search_params(window_width=q[9], window_height=q[10], search_range=q[11], mu=q[12],
+                                                                  no_success_limit=q[13], start_slice=q[14], ignore_sides=q[15],
+                                                                  ignore_bottom=q[16], partial=q[18]), first=base + i + a)
+            except _native.NativeError:  # geometry outside the kernels' limits
+                return None
+            return ctx.download_records(hi - lo, first=base + i + lo)
+
+        def verdicts(rec):               # per record: 1 valid, 0 failed, -1 needs the frame-by-frame route (rank-deficient fit)
+            det = rec["detected"] != 0
+            v = np.zeros(len(rec), np.int64)
+            v[det & (rec["fit_flags"] != 0)] = -1
+            idx = np.flatnonzero(det & (rec["fit_flags"] == 0))
+            if len(idx):
+                v[idx] = self._valid_many(rec["left_coeffs"][idx], rec["right_coeffs"][idx])
+            return v
+
+        def first_where(cond, default):
+            hits = np.flatnonzero(cond)
+            return int(hits[0]) if len(hits) else default
+
+        rec1 = search(0, 0, k) if k else None
+        if rec1 is None:
+            self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
+            return 1, bool(self.valid_lane_lines)
+        v1 = verdicts(rec1)
+        end = first_where(v1 != 0, k)                              # frames [0, end) failed their first try for certain
+        rec2, v2, e2 = None, None, 0
+        if len(tries) == 2 and end:
+            e2 = end
+            ctx.mask_run(e2, _native.filter_params(*[self._SECOND_TRY[x] for x in (4, 0, 1, 2, 3, 5, 6, 7, 8)]), first=base + i)
+            rec2 = search(1, 0, e2)
+            if rec2 is None:
+                ctx.mask_run(e2, fp, first=base + i)
+                self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
+                return 1, bool(self.valid_lane_lines)
+            v2 = verdicts(rec2)
+            end = min(end, first_where(v2 != 0, e2))
+        # frames [0, end) failed every try; frame `end` (if inside the group) is a success or needs care
+        win = None                       # (try, record) of the success that ends the group
+        if end < k:
+            if rec2 is not None and end < e2 and v2[end] == 1:
+                win = (1, rec2[end])
+            elif (rec2 is None or end >= e2) and v1[end] == 1:
+                win = (0, rec1[end])
+        committed = end + (1 if win else 0)
+        empty = np.zeros(0, np.int64)
+        last = None                      # the most recent search of the committed frames that found pixels: (frame, try, record)
+        for j in range(end):
+            final = rec2[j] if rec2 is not None else rec1[j]
+            self.counter += 1
+            self.detected_pixels = bool(final["detected"])
+            self.valid_lane_lines = False
+            self._record_failure()
+            if annotate:
+                redraw = (self.left_avg_y.size != 0) and (self.last_detection <= self.n_fail)
+                deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x), self._lane_text())
+                                if redraw else ('fail', None, self._failure_text()))
+            if rec1[j]["detected"]:
+                last = (j, 0, rec1[j])
+            if rec2 is not None and rec2[j]["detected"]:
+                last = (j, 1, rec2[j])
+        if win:
+            t, r = win
+            if t == 1 and rec1[end]["detected"]:
+                last = (end, 0, rec1[end])
+            last = (end, t, r)
+        if committed:
+            jl = committed - 1
+            self._resident = (frames[i + jl], base + i + jl)
+        if last is not None:
+            j, t, r = last
+            if t == 0 and rec2 is not None and j < e2:
+                # the second try of that frame ran on its slot afterwards and found nothing: the lists this search left are
+                # the tracker's, so it is run again (same mask, same search: same lists)
+                ctx.mask_run(1, fp, first=base + i + j)
+                search(0, j, j + 1)
+            self._pending = (ctx, base + i + j)
+            if j >= n_bs:
+                self._pending_cent = (ctx, base + i + j)
+            final_search_found = (j == committed - 1) and (win is not None or t == len(tries) - 1 or rec2 is None)
+            self._fit = ("pending", None, np.array(r["left_coeffs"], np.float64), np.array(r["right_coeffs"], np.float64)) \
+                if final_search_found else None
+        elif committed:
+            self._fit = None
+        if win:
+            t, r = win
+            self.counter += 1
+            self.detected_pixels = True
+            self.valid_lane_lines = True
+            self._record_success(np.array(r["left_coeffs"], np.float64), np.array(r["right_coeffs"], np.float64), tries[t][18])
+            if annotate:
+                deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x), self._lane_text()))
+        if e2 > committed:               # frames behind the last committed one still carry second-try masks
+            ctx.mask_run(e2 - committed, fp, first=base + i + committed)
+        if not committed:                # frame i itself needs the frame-by-frame route (a rank-deficient fit)
+            self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
+            return 1, bool(self.valid_lane_lines)
+        return committed, win is not None
 
     def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred, base=0, prefed=0, ahead=None, flush=None):
         """The frame loop of a window with the searches chained on the device.  State after every frame, and every
@@ -777,9 +911,20 @@ class LaneTracker:
                 if flight:
                     ctx.band_fit_chain_cancel()
                 flight = []
-                self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate,
-                           defer=deferred)
-                i += 1
+                while i < n:             # groups of frames, speculating that the outage lasts (`_fail_group`), until one succeeds
+                    k = min(max(1, int(self._outage_group)), n - i) if self.outage_groups else 1
+                    feed(i + k)
+                    k = min(k, min(masked, n) - i)
+                    with ctx.urgent():   # not behind the masks of later frames queued on the slots' streams
+                        done, recovered = self._fail_group(frames, base, i, k, first_try, fp, n_tries, annotate, deferred)
+                    i += done
+                    if flush is not None:
+                        flush(False)
+                    if recovered or not self.outage_groups:
+                        self._outage_group = 4
+                        break
+                    if done == k:        # every frame of the group failed: a longer group next
+                        self._outage_group = min(32, 2 * max(1, int(self._outage_group)))
         if flush is not None:
             flush(True)
         if not started:                  # (an empty window)
@@ -1023,8 +1168,7 @@ class LaneTracker:
             if diagnostics:
                 print("No success at first attempt, now trying second.")
             partial = 1.0                                               # the second parameter set (:1081-1099)
-            second_try = (15, 5, 35, 5, 'neighborhood', False, 140, 65, 10, 30, 40, 20, 0.1, 50, 0.25, 360, 30, 30,
-                          partial)
+            second_try = self._SECOND_TRY
             used = second_try
             search_mode = self._find_lane_points_device(img, *second_try, diagnostics, reuse_frame=True, slot=slot,
                                                         lazy=lazy)

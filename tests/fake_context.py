@@ -49,6 +49,10 @@ class FakeContext:
     def set_search_cus(self, n):
         pass
 
+    def urgent(self):
+        import contextlib
+        return contextlib.nullcontext(self)
+
     def close(self):
         pass
 

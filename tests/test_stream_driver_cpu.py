@@ -97,3 +97,38 @@ def test_wide_band_falls_back_to_frame_by_frame(fake, pool):
     seq.process_batch(frames, annotate=False, bandwidth=40)
     bat.process_batch(frames, annotate=False, bandwidth=40)
     assert _state(bat) == _state(seq) and bat._ctx.tickets == []
+
+
+@pytest.mark.parametrize("seed,n_reset,n_fail,n_tries,groups", [(1, 4, 8, 2, True), (2, 1, 2, 2, True), (3, 4, 8, 1, True), (4, 0, 8, 2, True),
+                                                                   (5, 6, 3, 2, True), (6, 4, 8, 2, False)])
+def test_outages_handled_in_groups_equal_frame_by_frame(fake, pool, seed, n_reset, n_fail, n_tries, groups):
+    """Runs of failing frames go through `_fail_group` (all first tries of a group at once, then the second tries of the frames in
+    front of the first success, speculating that the outage lasts): the state after every window -- pixel lists and window
+    centroids included -- must be the frame-by-frame state machine's, for random streams of lanes, jumps and outages of
+    random length (shorter and longer than n_reset and than the group sizes), with one try or two, and windows that end
+    inside an outage."""
+    rng = np.random.default_rng(seed)
+    plan = []
+    while len(plan) < 90:
+        kind = rng.integers(0, 4)
+        if kind == 0:
+            plan += [int(rng.integers(0, 3)) for _ in range(rng.integers(1, 7))]          # lane a
+        elif kind == 1:
+            plan += [int(rng.integers(3, 6)) for _ in range(rng.integers(1, 5))]          # lane b (a jump)
+        else:
+            plan += [int(rng.integers(6, 8)) for _ in range(rng.integers(1, 14))]         # an outage
+    plan = plan[:90]
+    frames = _stream(pool, plan)
+    cal = calib.reference_calibration()
+    seq = LaneTracker(n_reset=n_reset, n_fail=n_fail, **cal)
+    bat = LaneTracker(n_reset=n_reset, n_fail=n_fail, **cal)
+    seq.chain_searches = False
+    bat.chain_chunk, bat.outage_groups = 6, groups
+    lo = 0
+    for w in (17, 30, 1, 42):
+        for f in frames[lo:lo + w]:
+            seq.process_batch(f[None], annotate=False, n_tries=n_tries)
+        bat.process_batch(frames[lo:lo + w], annotate=False, n_tries=n_tries)
+        assert _state(bat) == _state(seq), (lo, w)
+        lo += w
+    assert 0 < bat.success < bat.counter == 90
