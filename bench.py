@@ -142,6 +142,15 @@ def stream_leg(streams, window=256, seconds=1.0):
                 list(lt.process_stream([frames] * 6, annotate=False))
                 k += 6
             res["process_stream_fps"] = round(k * window / (time.perf_counter() - t0), 1)
+            # ... and with every annotated frame rendered and copied back (what process_video.py consumes)
+            for _ in lt.process_stream([frames] * 4, annotate=True):
+                pass
+            t0, k = time.perf_counter(), 0
+            while time.perf_counter() - t0 < seconds * 0.3 or k == 0:
+                for _ in lt.process_stream([frames] * 6, annotate=True):
+                    pass
+                k += 6
+            res["process_stream_annotated_fps"] = round(k * window / (time.perf_counter() - t0), 1)
             res["success_ratio"] = round(lt.get_success_ratio()[0], 4)
             out[name] = res
         finally:
@@ -150,7 +159,8 @@ def stream_leg(streams, window=256, seconds=1.0):
     out["note"] = ("one stateful stream, host-fed (pageable NumPy frames in, PCIe included): process() = one frame per call, "
                    "annotated frame returned; process_batch() = windows of %d frames, searches chained on the device "
                    "(lt_band_fit_chain_run), check_validity / history on the host; process_stream() = the same over consecutive "
-                   "windows, the next window's uploads and masks under the current one's searches; 1920x1080 is BASELINE config 5" % window)
+                   "windows, the next windows' uploads and masks under the current one's searches (the *_annotated figures return every "
+                   "annotated frame: 2 x the frame bytes over the bus); 1920x1080 is BASELINE config 5" % window)
     return out
 
 

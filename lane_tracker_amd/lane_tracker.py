@@ -1143,6 +1143,12 @@ class LaneTracker:
             self._materialise_pending()  # the attributes describe the last frame, as after process()
         finally:
             self._in_stream = False
+            if annotate:                 # a generator closed early: no copy may still be writing into page-locked arrays
+                try:                     # that go back to the pool with their last reference
+                    ctx.band_fit_chain_cancel()
+                    ctx.sync()
+                except Exception:
+                    pass
 
     def _step(self, img, first_try, n_tries, diagnostics, slot, have_mask, lazy, annotate, visualize_search=False,
               split_view=False, defer=None):

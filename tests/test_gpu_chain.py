@@ -258,3 +258,26 @@ def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_
     finally:
         seq.close()
         bat.close()
+
+
+def test_annotated_stream_closed_early_leaves_a_usable_tracker():
+    """A consumer that stops after the first window: the generator's clean-up cancels the searches in flight and waits for
+    the copies still writing into the page-locked frame arrays; the tracker takes frames again and its first window came
+    out right."""
+    from lane_tracker_amd import calib, synth
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    frames = synth.stream_lanes(96, seed=21)
+    seq, bat = LaneTracker(**cal), LaneTracker(**cal)
+    try:
+        gen = bat.process_stream([frames[:32], frames[32:64], frames[64:]], annotate=True)
+        first = next(gen)
+        want = [seq.process(f) for f in frames[:32]]
+        assert all(np.array_equal(a, b) for a, b in zip(first, want))
+        gen.close()
+        assert not bat._in_stream
+        out = bat.process_batch(frames[:8])
+        assert len(out) == 8 and all(o.shape == frames[0].shape for o in out)
+    finally:
+        seq.close()
+        bat.close()
