@@ -364,8 +364,6 @@ def main():
     two_copies = NL <= 1024 and not a.single_copy
     ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
                           cal["warp_matrices"][0], device=device, capacity=2 * NL if two_copies else NL)
-    if os.environ.get("LT_BENCH_SEARCH_CUS"):                # measurement: CUs set aside for the searches (with LT_SEARCH_ON_RESERVED=1)
-        ctx.set_search_cus(int(os.environ["LT_BENCH_SEARCH_CUS"]))
     info = ctx.info()
     t0 = time.perf_counter()
     for c0 in range(0, NL, 256):

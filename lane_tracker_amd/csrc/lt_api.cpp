@@ -1713,27 +1713,6 @@ static int ensure_search_stream(lt_ctx* c) {
     return LT_OK;
 }
 
-// LT_SEARCH_ON_RESERVED=1 (measurement): with CUs reserved (lt_set_search_cus), the plain searches of lt_sws_fit_run /
-// lt_band_fit_run run on the search stream too -- on the reserved CUs, ordered like an urgent call -- instead of on the slots'
-// streams, where their single-wave workgroups share CUs with the other slices' mask kernels.
-struct SearchRoute {
-    lt_ctx* c;
-    hipStream_t saved_stream;
-    bool saved_on, active = false;
-    explicit SearchRoute(lt_ctx* c_) : c(c_), saved_stream(c_->urgent), saved_on(c_->urgent_on) {
-        static const bool want = std::getenv("LT_SEARCH_ON_RESERVED") != nullptr;
-        if (!want || c->search_cus <= 0 || c->urgent_on || ensure_search_stream(c) != LT_OK) return;
-        c->urgent = c->search;
-        c->urgent_on = true;
-        active = true;
-    }
-    ~SearchRoute() {
-        if (!active) return;
-        c->urgent = saved_stream;
-        c->urgent_on = saved_on;
-    }
-};
-
 int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -1755,7 +1734,6 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     const bool use_bits = masks_have_bits(c, first, n) && sws_fit_takes_bits(g, c->plane_bytes);
     if (!use_bits && (rc = ensure_u8_masks(c, first, n))) return rc;
     const int wpr = (c->calib.warp_w + 63) / 64;
-    SearchRoute route(c);
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         StageScope t(c, ST_SWS_FIT, st);
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
@@ -1795,7 +1773,6 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
     const bool use_bits = masks_have_bits(c, first, n) && band_fit_takes_bits(g, c->plane_bytes);
     if (!use_bits && (rc = ensure_u8_masks(c, first, n))) return rc;
     const int wpr = (c->calib.warp_w + 63) / 64;
-    SearchRoute route(c);
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         StageScope t(c, ST_BAND_FIT, st);
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
