@@ -797,6 +797,7 @@ void lt_destroy(lt_ctx* c) {
     if (c->h_xpos) (void)hipHostFree(c->h_xpos);
     for (auto& w : c->readers.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& w : c->writers.e) if (w.ev) (void)hipEventDestroy(w.ev);
+    for (auto& w : c->rests.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
