@@ -203,3 +203,15 @@ def test_packed_poly_points_equal_get_poly_points():
             a, b = lyx[le[i] - ln[i]:le[i]], ryx[re[i] - rn[i]:re[i]]
             assert np.array_equal(a[:, 0], ly) and np.array_equal(a[:, 1], lx) and np.array_equal(b[:, 0], ry) and np.array_equal(b[:, 1], rx), (i, partial)
     assert ln[7] == 1100 * 0 + len(t._plot_rows(0.3)[0]) and rn[7] == ln[7] and ln[8] == 0 and rn[8] == 0
+
+
+def test_mean_of_rows_is_numpy_average():
+    """The averaged lane coefficients (reference :1191-1192, np.average over the history) through the cheaper helper: bit for
+    bit, for every history length and magnitudes over ten decades."""
+    from lane_tracker_amd.lane_tracker import _mean_of_rows
+    rng = np.random.default_rng(0)
+    for k in range(1, 12):
+        for _ in range(500):
+            rows = [rng.uniform(-1, 1, 3) * 10.0 ** rng.integers(-6, 4) for _ in range(k)]
+            a, b = np.average(rows, axis=0), _mean_of_rows(rows)
+            assert a.tobytes() == b.tobytes() and b is not rows[0]
