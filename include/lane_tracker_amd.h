@@ -183,8 +183,9 @@ int  lt_band_fit_chain_collect(lt_ctx* ctx, int first_slot, int n, lt_lane_recor
  * mask that keeps them off CUs 0 .. n-1, and the search stream is restricted to those.  Why: the kernels of the mask chain
  * spread their workgroups over the chip once, statically; a workgroup of the chain kernel sharing ONE CU with them slows that
  * CU's share of every mask kernel, and each kernel then ends with that CU -- measured: the mask chain of 128-frame launches
- * takes 18.6 us per frame beside a running chain, 15.1 with one CU set aside (12.8 alone).  Call it on an idle context (it
- * synchronises); a context that only processes independent batches has no use for it. */
+ * takes 18.6 us per frame beside a running chain, 15.1 with one CU set aside (12.8 alone).  With n >= 2 the search has CU 0
+ * and the others belong to the download stream (used when LT_DL_KERNEL=1 copies annotated frames back with a kernel).  Call it
+ * on an idle context (it synchronises); a context that only processes independent batches has no use for it. */
 int  lt_set_search_cus(lt_ctx* ctx, int n);
 /* Urgent mode, for the frame of a stateful stream whose first try failed (lane_tracker.py:1071-1128: second parameter set,
  * second search) while masks of later frames are already queued: between lt_set_urgent(ctx, 1) and lt_set_urgent(ctx, 0),

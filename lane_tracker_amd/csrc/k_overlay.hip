@@ -10,6 +10,7 @@
 // 8-connected edge lines, lt_api.cpp).  The inverse warp is OpenCV's fixed-point bilinear remap of that
 // 0/255 image: each camera pixel tests its four taps against the row intervals.  Only the green byte
 // changes; 0.3*lane is added in f32 and rounded half-to-even like cv::addWeighted's saturate_cast.
+#include <algorithm>
 #include "lt_internal.h"
 
 namespace lt {
@@ -163,6 +164,32 @@ void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, s
     const size_t n = bytes >> 2;
     hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<uint32_t*>(dst),
                        static_cast<const uint32_t*>(src_dev), n);
+}
+
+// Device -> page-locked host memory by a kernel (16 bytes per lane, grid-stride over a grid that a few CUs hold), the
+// alternative to the copy engine for lt_download_overlay_async (LT_DL_KERNEL=1; trade-off and numbers there and in
+// tools/microbench/d2h_kernel.hip): stores from a kernel cross the bus beside the engine's uploads whatever engine the runtime
+// gave the download stream.
+namespace {
+typedef unsigned int vec4u __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_copy_vec16(vec4u* __restrict__ dst, const vec4u* __restrict__ src, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+}  // namespace
+
+bool launch_copy_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes) {
+    if (!bytes) return true;
+    void* dst_dev = nullptr;
+    if (((bytes | (size_t)(uintptr_t)dst_pinned | (size_t)(uintptr_t)src) & 15) ||
+        hipHostGetDevicePointer(&dst_dev, dst_pinned, 0) != hipSuccess || !dst_dev) {
+        (void)hipGetLastError();
+        return false;                    // not page-locked (or not aligned): the caller copies with hipMemcpyAsync
+    }
+    const size_t n = bytes >> 4;
+    const unsigned blocks = (unsigned)std::min<size_t>((n + 255) / 256, 64);   // 64 blocks already saturate the bus (tools/microbench/d2h_kernel.hip)
+    hipLaunchKernelGGL(k_copy_vec16, dim3(blocks), dim3(256), 0, s, static_cast<vec4u*>(dst_dev), static_cast<const vec4u*>(src), n);
+    return true;
 }
 
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,

@@ -1479,12 +1479,30 @@ int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
     if ((rc = set_device(c))) return rc;
     // on a stream of its own, behind the overlay work enqueued so far: the copy neither holds up the kernels queued behind
     // it on the context's stream nor shares a queue with the uploads
-    if (!c->dl) HIP_TRY(hipStreamCreateWithFlags(&c->dl, hipStreamNonBlocking));
+    if (!c->dl) {
+        if (c->search_cus >= 2) {                  // the reserved CUs but the first are the copy kernel's (lt_set_search_cus)
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 1; b < c->search_cus && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->dl, 8, mask));
+        } else {                                   // highest priority: the copy kernel's few workgroups go ahead of the mask kernels'
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
+        }
+    }
     hipEvent_t e = next_order_event(c);
     if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(e, c->present ? c->present : c->stream));
     HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
-    HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->dl));
+    // The copy engine by default.  Its downloads were seen in two states (tools/annot_bisect.py): beside the uploads of the copy
+    // stream (annotated 1280x720 stream 15.3 k frames/s) or taking turns with them (9.4 k) -- which one depends on what the
+    // process did with its streams before, not on anything this library controls.  LT_DL_KERNEL=1 copies with a kernel instead
+    // (k_copy_vec16, on the CUs lt_set_search_cus(>= 2) sets aside for it): always beside the uploads, but at the 38-40 GB/s a
+    // kernel's stores reach while the runtime stages pageable uploads (13.7 k always; 1920x1080: 5.8 k against 7.0-7.2 k).
+    static const bool by_kernel = std::getenv("LT_DL_KERNEL") != nullptr;
+    if (!by_kernel || !launch_copy_to_pinned(c->dl, out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes))
+        HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->dl));
+    HIP_TRY(hipGetLastError());
     if (c->annot_busy.hi <= c->annot_busy.lo) { c->annot_busy.lo = first; c->annot_busy.hi = first + n; }
     else { c->annot_busy.lo = std::min(c->annot_busy.lo, first); c->annot_busy.hi = std::max(c->annot_busy.hi, first + n); }
     return staging_mark(c->annot_busy, c->dl);
@@ -1708,7 +1726,8 @@ static int ensure_search_stream(lt_ctx* c) {
     if (c->search) return LT_OK;
     if (c->search_cus > 0) {                  // the CUs the slots' streams were kept off (lt_set_search_cus)
         uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < c->search_cus && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+        const int mine = c->search_cus >= 2 ? 1 : c->search_cus;   // with two or more, the others are the download stream's
+        for (int i = 0; i < mine && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
         HIP_TRY(hipExtStreamCreateWithCUMask(&c->search, 8, mask));
     } else HIP_TRY(create_compute_stream(&c->search));
     return LT_OK;
@@ -1900,6 +1919,7 @@ int lt_set_search_cus(lt_ctx* c, int n) {
     if (c->search) { (void)hipStreamDestroy(c->search); c->search = nullptr; }
     if (c->present) { (void)hipStreamDestroy(c->present); c->present = nullptr; }
     if (c->urgent) { (void)hipStreamDestroy(c->urgent); c->urgent = nullptr; c->urgent_on = false; }
+    if (c->dl) { (void)hipStreamDestroy(c->dl); c->dl = nullptr; }
     c->search_cus = n;
     return LT_OK;
 }

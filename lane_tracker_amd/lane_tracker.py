@@ -101,7 +101,7 @@ class LaneTracker:
         self.device = device
         self._ctx = _native.Context(img_size, warped_size, cam_matrix, dist_coeffs, self.M, device=device, capacity=2)
         if self.search_cus:
-            self._ctx.set_search_cus(self.search_cus)   # one CU for the chained searches of the stream pipeline (lt_set_search_cus)
+            self._ctx.set_search_cus(self.search_cus)   # CUs of their own for the stream pipeline's long-running kernels (lt_set_search_cus)
         self._slot = 0              # process() alternates between two slots (see process())
         self._aux_ctx = {}          # contexts for images that are not the calibration's BEV size
         self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search
@@ -573,7 +573,8 @@ class LaneTracker:
         return True
 
     # ---- the chained stream pipeline (reference :851-872, :1064-1128, :1178-1199) ------------
-    search_cus = 1                   # CUs the chained search has to itself (the mask chain is kept off them); 0: shared
+    search_cus = 1                   # CUs kept free of the mask chain for the chained search (lt_set_search_cus); 0: shared; >= 2: the
+                                     # others belong to the kernel that copies annotated frames back when LT_DL_KERNEL=1 asks for it
     chain_searches = True            # False: process_batch searches frame by frame (one record round trip per frame)
     chain_chunk = None               # frames per upload + mask launch, and per chain, inside a window; None: by window size --
                                      # 32 for a stand-alone window (its head and tail count), half a window up to 128 in a

@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.environ.get("LT_TEST_SEARCH_CUS"):     # a sub-run of the suite with more CUs set aside (tests/test_gpu_streams.py)
+        from lane_tracker_amd.lane_tracker import LaneTracker
+        LaneTracker.search_cus = int(os.environ["LT_TEST_SEARCH_CUS"])
 
 
 def has_gpu():

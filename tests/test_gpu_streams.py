@@ -130,6 +130,9 @@ def test_overlay_pieces_with_targeted_wait_equal_one_blocking_download(nat, cal,
     texts = [["Curve Radius: %d m" % (100 + i), "Eccentricity: 0.%02d m" % i] for i in range(n)]
     c = _ctx(nat, cal, 2 * n)
     try:
+        import os
+        if os.environ.get("LT_TEST_SEARCH_CUS"):
+            c.set_search_cus(int(os.environ["LT_TEST_SEARCH_CUS"]))
         c.overlay_configure(cal["warp_matrices"][1])
         from lane_tracker_amd import overlay as ov
         font = ov.font_atlas()
@@ -156,3 +159,18 @@ def test_overlay_pieces_with_targeted_wait_equal_one_blocking_download(nat, cal,
         assert np.array_equal(out, want)
     finally:
         c.close()
+
+
+def test_kernel_download_path_gives_the_same_frames():
+    """LT_DL_KERNEL=1 (annotated frames copied back by a kernel on the CUs set aside for it, instead of the copy engine): the
+    pieces test above and an annotated stream against process(), in a process of their own (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LT_DL_KERNEL="1", LT_TEST_SEARCH_CUS="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                        "tests/test_gpu_streams.py::test_overlay_pieces_with_targeted_wait_equal_one_blocking_download",
+                        "tests/test_gpu_chain.py::test_process_stream_equals_process_frame_by_frame"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

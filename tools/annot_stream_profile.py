@@ -9,6 +9,10 @@ cal = calib.reference_calibration() if len(sys.argv) < 2 or sys.argv[1] != "1080
 n, W = 256, 6
 base = synth.stream_lanes(32, seed=5, cal=cal)
 frames = np.concatenate([base, base[::-1]] * (n // 64 + 1), 0)[:n].copy()
+if os.environ.get("CUS"):
+    LaneTracker.search_cus = int(os.environ["CUS"])
+if os.environ.get("SECOND"):                 # not the first tracker of the process (the copy engines are handed out differently then)
+    t0 = LaneTracker(**cal); t0.process(frames[0]); t0.close()
 lt = LaneTracker(**cal)
 for out in lt.process_stream([frames] * 4):      # (three page-locked output windows are alive at a time: let the pool get them)
     pass
