@@ -167,15 +167,13 @@ struct lt_ctx {
     // slots' streams that touches slots of a chain still in flight waits for it (for_each_slice).
     hipStream_t search = nullptr;
     int search_cus = 0;                       // lt_set_search_cus: CUs the search stream has to itself (0: none reserved)
-    struct ChainTicket { int first, n; hipEvent_t done; };
+    struct ChainTicket { int first, n; hipEvent_t done; int own; };   // own: first slot the chain searched itself (first + 1 when slot `first` is only its seed record)
     std::vector<ChainTicket> chains;          // not yet collected, oldest first
     std::vector<hipEvent_t> chain_event_pool;
     int* h_cancel = nullptr;                  // page-locked, device-visible: chains launched with an older epoch stop at their next frame
     int* d_cancel = nullptr;                  // its device address
     lt_lane_record* h_rec_stage = nullptr;    // capacity records
     int h_rec_stage_cap = 0;
-    int chain_lo = 0, chain_hi = 0;           // slots touched by chains enqueued since the last full synchronisation
-    hipEvent_t chain_tail = nullptr;          // end of the most recent chain
     // timing
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool stage_timing = false;
@@ -216,7 +214,6 @@ int sync_all(lt_ctx* c) {
     c->readers.reset();                                 // every reader / writer enqueued so far is done
     c->writers.reset();
     c->rests.reset();
-    c->chain_lo = c->chain_hi = 0;                      // and every chain
     return LT_OK;
 }
 
@@ -258,6 +255,14 @@ int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) { return note_range(
 // slot stay ordered on one stream while different slices overlap: the latency-bound search of one
 // slice runs under the mask chain of another.  Calls fn(stream, first, n) for every non-empty piece.
 hipEvent_t next_order_event(lt_ctx* c);
+// `st` waits for the chains still outstanding (not collected) that read or write slots [lo, hi): ticket by ticket, so that work on
+// a frame in front of a running chain -- the second try of a failed frame while the frames behind it are already chained -- does
+// not wait for that chain
+static int wait_chains(lt_ctx* c, hipStream_t st, int lo, int hi) {
+    for (const auto& t : c->chains)
+        if (t.first < hi && t.first + t.n > lo) HIP_TRY(hipStreamWaitEvent(st, t.done, 0));
+    return LT_OK;
+}
 template <class F>
 int for_each_slice(lt_ctx* c, int first, int n, F fn) {
     const int k = std::max(1, std::min(c->nstreams, c->capacity));
@@ -286,8 +291,7 @@ int for_each_slice(lt_ctx* c, int first, int n, F fn) {
             });
             if (rc) return rc;
         }
-        if (c->chain_hi > c->chain_lo && first < c->chain_hi && first + n > c->chain_lo && c->chain_tail)
-            HIP_TRY(hipStreamWaitEvent(us, c->chain_tail, 0));
+        if ((rc = wait_chains(c, us, first, first + n))) return rc;
         if ((rc = fn(us, first, n))) return rc;
         hipEvent_t done = next_order_event(c);
         if (!done) return fail(LT_ERR_HIP, "hipEventCreate failed");
@@ -302,9 +306,9 @@ int for_each_slice(lt_ctx* c, int first, int n, F fn) {
         const int lo = (int)((long long)c->capacity * si / k) & ~1, hi = si + 1 == k ? c->capacity : (int)((long long)c->capacity * (si + 1) / k) & ~1;
         const int a = std::max(first, lo), b = std::min(first + n, hi);
         if (b <= a) continue;
-        if (c->chain_hi > c->chain_lo && a < c->chain_hi && b > c->chain_lo && c->chain_tail)
-            HIP_TRY(hipStreamWaitEvent(c->streams[si], c->chain_tail, 0));   // a chain in flight reads / writes these slots
-        int rc = fn(c->streams[si], a, b - a);
+        int rc = wait_chains(c, c->streams[si], a, b);                     // a chain in flight reads / writes these slots
+        if (rc) return rc;
+        rc = fn(c->streams[si], a, b - a);
         if (rc) return rc;
     }
     return LT_OK;
@@ -1877,10 +1881,7 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
         c->chain_event_pool.push_back(c->chains.front().done);
         c->chains.erase(c->chains.begin());
     }
-    c->chains.push_back({lo, cnt, done});
-    c->chain_tail = done;
-    if (c->chain_hi <= c->chain_lo) { c->chain_lo = lo; c->chain_hi = lo + cnt; }
-    else { c->chain_lo = std::min(c->chain_lo, lo); c->chain_hi = std::max(c->chain_hi, lo + cnt); }
+    c->chains.push_back({lo, cnt, done, first});
     return LT_OK;
 }
 
@@ -1936,10 +1937,15 @@ int lt_band_fit_chain_collect(lt_ctx* c, int first, int n, lt_lane_record* out) 
     if (!out) return fail(LT_ERR_INVALID, "null output buffer");
     if (n == 0) return LT_OK;
     if ((rc = set_device(c))) return rc;
-    // the most recent chain that covers the range decides (an older, superseded chain over the same slots is dropped)
+    // the most recent chain that covers the range decides (an older, superseded chain over the same slots is dropped) -- a chain
+    // that searched the range's first slot itself before one that only holds it as its seed record (a one-frame chain with
+    // another chain behind it: collecting the first must not use up the ticket of the second)
     int hit = -1;
-    for (int i = (int)c->chains.size() - 1; i >= 0; --i)
-        if (c->chains[(size_t)i].first <= first && first + n <= c->chains[(size_t)i].first + c->chains[(size_t)i].n) { hit = i; break; }
+    for (int pass = 0; pass < 2 && hit < 0; ++pass)
+        for (int i = (int)c->chains.size() - 1; i >= 0; --i) {
+            const lt_ctx::ChainTicket& t = c->chains[(size_t)i];
+            if ((pass ? t.first : t.own) <= first && first + n <= t.first + t.n) { hit = i; break; }
+        }
     if (hit < 0) return fail(LT_ERR_STATE, "no chained search covers slots [%d, %d)", first, first + n);
     HIP_TRY(hipEventSynchronize(c->chains[(size_t)hit].done));
     std::memcpy(out, c->h_rec_stage + first, (size_t)n * sizeof(lt_lane_record));

@@ -614,7 +614,7 @@ class LaneTracker:
 
     _SECOND_TRY = (15, 5, 35, 5, 'neighborhood', False, 140, 65, 10, 30, 40, 20, 0.1, 50, 0.25, 360, 30, 30, 1.0)   # :1081-1099
 
-    def _fail_group(self, frames, base, i, k, first_try, fp, n_tries, annotate, deferred):
+    def _fail_group(self, frames, base, i, k, first_try, fp, n_tries, annotate, deferred, speculate=None):
         """Frames i .. i+k-1 of a window (slots base+i ..; first-try masks computed), the first of which is known or
         expected to fail its first try: all of them at once, speculating that every one fails both tries.  While frames
         fail, nothing a frame needs depends on the frame before it except the count of misses: its search mode (sliding
@@ -622,7 +622,10 @@ class LaneTracker:
         advance.  So: the first-try searches of the whole group in one launch, one record download; the second-try masks
         and searches of the frames in front of the first first-try success likewise; then the frames are committed in order up
         to and including the first success (whatever was computed behind it under the wrong hypothesis is dropped, and the
-        first-try masks the second try overwrote are computed again).  Returns (frames committed >= 1, ended with a success).
+        first-try masks the second try overwrote are computed again).  When a first try succeeds behind failing frames, the
+        frames behind it are chained from its record at once (`speculate(position)`, the caller's launcher), beside the second
+        tries still to run in front of it: those usually fail too, and the chain has then done its work under them.
+        Returns (frames committed >= 1, ended with a success, that chain or None).
         State after every frame = `_step` frame by frame (tests/test_stream_driver_cpu.py, tests/fuzz_chain.py)."""
         ctx = self._ctx
         tries = [first_try] + ([self._SECOND_TRY] if (n_tries >= 2 or n_tries == -1) else [])
@@ -668,18 +671,23 @@ class LaneTracker:
         rec1 = search(0, 0, k) if k else None
         if rec1 is None:
             self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
-            return 1, bool(self.valid_lane_lines)
+            return 1, bool(self.valid_lane_lines), None
         v1 = verdicts(rec1)
         end = first_where(v1 != 0, k)                              # frames [0, end) failed their first try for certain
         rec2, v2, e2 = None, None, 0
+        spec = None
         if len(tries) == 2 and end:
             e2 = end
+            if speculate is not None and end < k and v1[end] == 1:
+                spec = speculate(i + end + 1)                      # seeded on the device by the record the first try of frame `end` left
             ctx.mask_run(e2, _native.filter_params(*[self._SECOND_TRY[x] for x in (4, 0, 1, 2, 3, 5, 6, 7, 8)]), first=base + i)
             rec2 = search(1, 0, e2)
             if rec2 is None:
+                if spec is not None:
+                    ctx.band_fit_chain_cancel()
                 ctx.mask_run(e2, fp, first=base + i)
                 self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
-                return 1, bool(self.valid_lane_lines)
+                return 1, bool(self.valid_lane_lines), None
             v2 = verdicts(rec2)
             end = min(end, first_where(v2 != 0, e2))
         # frames [0, end) failed every try; frame `end` (if inside the group) is a success or needs care
@@ -690,7 +698,9 @@ class LaneTracker:
             elif (rec2 is None or end >= e2) and v1[end] == 1:
                 win = (0, rec1[end])
         committed = end + (1 if win else 0)
-        empty = np.zeros(0, np.int64)
+        if spec is not None and not (win is not None and win[0] == 0 and i + committed == spec[0]):
+            ctx.band_fit_chain_cancel()  # a second try succeeded in front of it (or a frame needs care): its seed is not the stream's state
+            spec = None
         last = None                      # the most recent search of the committed frames that found pixels: (frame, try, record)
         for j in range(end):
             final = rec2[j] if rec2 is not None else rec1[j]
@@ -741,8 +751,8 @@ class LaneTracker:
             ctx.mask_run(e2 - committed, fp, first=base + i + committed)
         if not committed:                # frame i itself needs the frame-by-frame route (a rank-deficient fit)
             self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
-            return 1, bool(self.valid_lane_lines)
-        return committed, win is not None
+            return 1, bool(self.valid_lane_lines), None
+        return committed, win is not None, spec
 
     def _run_window_chained(self, frames, first_try, fp, n_tries, annotate, deferred, base=0, prefed=0, ahead=None, flush=None):
         """The frame loop of a window with the searches chained on the device.  State after every frame, and every
@@ -919,13 +929,25 @@ class LaneTracker:
                     k = min(max(1, int(self._outage_group)), n - i) if self.outage_groups else 1
                     feed(i + k)
                     k = min(k, min(masked, n) - i)
+                    def speculate(at):  # a chain behind a first try that succeeded inside the group, from the masks already there
+                        L = min(chain_span(at), min(masked, n) - at) if at < n else 0
+                        if L < 1:
+                            return None
+                        try:
+                            ctx.band_fit_chain_run(L, None, sp_band, first=base + at)
+                        except _native.NativeError:
+                            return None
+                        return at, L, 'bs'
                     with ctx.urgent():   # not behind the masks of later frames queued on the slots' streams
-                        done, recovered = self._fail_group(frames, base, i, k, first_try, fp, n_tries, annotate, deferred)
+                        done, recovered, spec = self._fail_group(frames, base, i, k, first_try, fp, n_tries, annotate, deferred,
+                                                                 speculate if self.outage_groups else None)
                     i += done
                     if flush is not None:
                         flush(False)
                     if recovered or not self.outage_groups:
                         self._outage_group = 4
+                        if spec is not None:
+                            flight = [spec]   # already running: the frames behind the recovered one
                         break
                     if done == k:        # every frame of the group failed: a longer group next
                         self._outage_group = min(32, 2 * max(1, int(self._outage_group)))

@@ -152,10 +152,12 @@ class FakeContext:
                 continue
             rec = self._store(first + k, O.band_search(self._slot(first + k)["mask"], carry[:3], carry[3:], _osp(sp)), 1)
             carry = np.concatenate([rec["left_coeffs"], rec["right_coeffs"]]) if (rec["detected"] and not rec["fit_flags"]) else None
-        self.tickets.append((lo, first + n - lo))
+        self.tickets.append((lo, first + n - lo, first))
 
     def band_fit_chain_collect(self, n, first=0):
-        hit = [i for i, (lo, cnt) in enumerate(self.tickets) if lo <= first and first + n <= lo + cnt]
+        hit = [i for i, (lo, cnt, own) in enumerate(self.tickets) if own <= first and first + n <= lo + cnt]
+        if not hit:              # (a chain that searched the first slot itself goes before one that only holds it as its seed)
+            hit = [i for i, (lo, cnt, own) in enumerate(self.tickets) if lo <= first and first + n <= lo + cnt]
         if not hit:
             raise _native.NativeError("no chained search covers slots [%d, %d)" % (first, first + n))
         del self.tickets[:hit[-1] + 1]

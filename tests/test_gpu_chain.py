@@ -281,3 +281,31 @@ def test_annotated_stream_closed_early_leaves_a_usable_tracker():
     finally:
         seq.close()
         bat.close()
+
+
+def test_one_frame_chain_with_a_chain_behind_it_keeps_both_tickets():
+    """A chain of ONE frame followed by a chain seeded by its record: collecting the first must take the first chain's
+    ticket (the second one also holds that slot -- as its seed record), so that the second can still be collected."""
+    from lane_tracker_amd import _native, calib, synth
+    cal = calib.reference_calibration()
+    frames = synth.stream_lanes(12, seed=3)
+    c = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0,
+                        capacity=12)
+    try:
+        sp = _native.search_params()
+        c.upload_frames(frames)
+        c.mask_run(12)
+        c.sws_fit_run(1, sp, first=0)
+        seed = c.download_records(1)[0]
+        c.band_fit_chain_run(1, np.concatenate([seed["left_coeffs"], seed["right_coeffs"]]), sp, first=1)   # one frame, seed by value
+        c.band_fit_chain_run(1, None, sp, first=2)             # one frame, seeded by slot 1 ...
+        c.band_fit_chain_run(5, None, sp, first=3)             # ... and a longer one behind it
+        a = c.band_fit_chain_collect(1, first=1)
+        b = c.band_fit_chain_collect(1, first=2)
+        d = c.band_fit_chain_collect(5, first=3)
+        assert a["detected"].all() and b["detected"].all() and d["detected"].all() and (d["mode"] == 1).all()
+        c.sws_fit_run(1, sp, first=0)                          # the seed slot itself is collectable when nothing searched it in a chain
+        c.band_fit_chain_run(3, None, sp, first=1)
+        assert c.band_fit_chain_collect(4, first=0)["detected"].all()
+    finally:
+        c.close()

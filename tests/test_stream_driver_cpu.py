@@ -100,7 +100,8 @@ def test_wide_band_falls_back_to_frame_by_frame(fake, pool):
 
 
 @pytest.mark.parametrize("seed,n_reset,n_fail,n_tries,groups", [(1, 4, 8, 2, True), (2, 1, 2, 2, True), (3, 4, 8, 1, True), (4, 0, 8, 2, True),
-                                                                   (5, 6, 3, 2, True), (6, 4, 8, 2, False)])
+                                                                   (5, 6, 3, 2, True), (6, 4, 8, 2, False), (7, 4, 8, 2, True), (8, 2, 8, 2, True),
+                                                                   (10, 4, 8, 2, True), (11, 3, 8, 2, True), (13, 4, 8, 2, True)])
 def test_outages_handled_in_groups_equal_frame_by_frame(fake, pool, seed, n_reset, n_fail, n_tries, groups):
     """Runs of failing frames go through `_fail_group` (all first tries of a group at once, then the second tries of the frames in
     front of the first success, speculating that the outage lasts): the state after every window -- pixel lists and window
@@ -123,7 +124,7 @@ def test_outages_handled_in_groups_equal_frame_by_frame(fake, pool, seed, n_rese
     seq = LaneTracker(n_reset=n_reset, n_fail=n_fail, **cal)
     bat = LaneTracker(n_reset=n_reset, n_fail=n_fail, **cal)
     seq.chain_searches = False
-    bat.chain_chunk, bat.outage_groups = 6, groups
+    bat.chain_chunk, bat.chain_depth, bat.outage_groups = (6, 2, 8)[seed % 3], 1 + seed % 3, groups
     lo = 0
     for w in (17, 30, 1, 42):
         for f in frames[lo:lo + w]:
