@@ -350,6 +350,22 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
     // and the kernel is LDS-pipe bound (SQ_WAIT_INST_LDS ~28 % with read2).  One s_waitcnt covers each
     // batch; the results are threaded through the wait statement so nothing is consumed before it.
 #define LT_RD64(dst, base, off) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(base), "n"(off) : "memory")
+// Issue priority (LT_MORPH_PRIO bit 1, the default): a wave raises its priority (s_setprio 3) while it puts a stage's window
+// reads into the LDS queue and drops it for the min / max work that follows -- the LDS pipe is the busier of the two co-bound
+// units, so whoever can feed it goes first.  Measured per 256 frames (tools/ab_prio.sh, variant builds): 55x55 erode
+// 0.490 -> 0.470 ms, top-hat 0.494 -> 0.474 ms; priority 2: 0.473 / 0.477; the other way round (-DLT_MORPH_PRIO=2, min / max
+// first) 0.502 / 0.505; also around the chain steps, stage 1 and the 29x29 windows (bit 4): no gain, 29x29 unchanged.
+#ifndef LT_MORPH_PRIO
+#define LT_MORPH_PRIO 1
+#endif
+#ifndef LT_MORPH_PRIO_LEVEL
+#define LT_MORPH_PRIO_LEVEL 3
+#endif
+#define LT_PRIO_READS() do { if (LT_MORPH_PRIO & 1) __builtin_amdgcn_s_setprio(LT_MORPH_PRIO_LEVEL); else if (LT_MORPH_PRIO == 2) __builtin_amdgcn_s_setprio(0); } while (0)
+#define LT_PRIO_MATH()  do { if (LT_MORPH_PRIO & 1) __builtin_amdgcn_s_setprio(0); else if (LT_MORPH_PRIO == 2) __builtin_amdgcn_s_setprio(2); } while (0)
+// bit 4: also around the reads of the chain steps, of stage 1 and of the 29x29 windows
+#define LT_PRIO_READS2() do { if (LT_MORPH_PRIO & 4) __builtin_amdgcn_s_setprio(LT_MORPH_PRIO_LEVEL); } while (0)
+#define LT_PRIO_MATH2()  do { if (LT_MORPH_PRIO & 4) __builtin_amdgcn_s_setprio(0); } while (0)
     const uint32_t cb = (uint32_t)(uintptr_t)(s + lane);   // low 32 bits of a flat LDS address = LDS offset
     auto pair = [](unsigned long long v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); };
     // One chain step with three taps: DST[p] = op(SRC[p - D], SRC[p], SRC[p + D]) for p = pa, pb; entry p of
@@ -357,12 +373,14 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
 #define LT_STEP3(SRC, DST, D)                                                                                        \
     {                                                                                                                \
         unsigned long long a0, a1, a2, b0, b1, b2;                                                                   \
+        LT_PRIO_READS2();                                                                                            \
         LT_RD64(a0, cb, ((SRC) * PLANE + MARGIN - (D)) * 8);                                                         \
         LT_RD64(a1, cb, ((SRC) * PLANE + MARGIN) * 8);                                                               \
         LT_RD64(a2, cb, ((SRC) * PLANE + MARGIN + (D)) * 8);                                                         \
         LT_RD64(b0, cb, ((SRC) * PLANE + MARGIN + 64 - (D)) * 8);                                                    \
         LT_RD64(b1, cb, ((SRC) * PLANE + MARGIN + 64) * 8);                                                          \
         LT_RD64(b2, cb, ((SRC) * PLANE + MARGIN + 64 + (D)) * 8);                                                    \
+        LT_PRIO_MATH2();                                                                                             \
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2)::"memory"); \
         (S0 + (DST) * PLANE)[pa] = op3v<DIL>(pair(a0), pair(a1), pair(a2));                                          \
         (S0 + (DST) * PLANE)[pb] = op3v<DIL>(pair(b0), pair(b1), pair(b2));                                          \
@@ -433,15 +451,19 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         // "at most n outstanding" with n = the reads issued after a stage means that stage has arrived).
         // stage 1: half-widths 0, 7, 10, 12 -- planes S0 and S4, read under the last chain step
         unsigned long long r0, f0, f1, f2, f3, f4, f5, f6;
+        LT_PRIO_READS2();
         LT_RD64(r0, s0_rd, 0);
         LT_RD64(f0, cb, O4 + 0); LT_RD64(f1, cb, O4 + 16); LT_RD64(f2, cb, O4 + 40); LT_RD64(f3, cb, O4 + 64);   // p-8, p-6, p-3, p
         LT_RD64(f4, cb, O4 + 88); LT_RD64(f5, cb, O4 + 112); LT_RD64(f6, cb, O4 + 128);                          // p+3, p+6, p+8
+        LT_PRIO_MATH2();
         LT_STEP3(2, 3, 9)                                                                                        // waits for everything
         LT_WAIT8(0, r0, f0, f1, f2, f3, f4, f5, f6);
         // stage 2: 14, 16, 17, 18   (half-width 13 + q from S13[p - q], S13[p + q])
+        LT_PRIO_READS();
         unsigned long long a2, b2, c2, d2, e2, f2_, g2, h2;
         LT_RD64(a2, cb, LT_G(13)); LT_RD64(b2, cb, LT_G(15)); LT_RD64(c2, cb, LT_G(11)); LT_RD64(d2, cb, LT_G(17));
         LT_RD64(e2, cb, LT_G(10)); LT_RD64(f2_, cb, LT_G(18)); LT_RD64(g2, cb, LT_G(9)); LT_RD64(h2, cb, LT_G(19));
+        LT_PRIO_MATH();
         {
             Ha[0] = lo(r0); Hb[0] = hi(r0);
             LT_PAIR(1, f2, f4)
@@ -454,26 +476,32 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
             updates(std::integral_constant<int, 1>{});
         }
         // stage 3: 19, 20, 21, 22
+        LT_PRIO_READS();
         unsigned long long a3, b3, c3, d3, e3, f3_, g3, h3;
         LT_RD64(a3, cb, LT_G(8)); LT_RD64(b3, cb, LT_G(20)); LT_RD64(c3, cb, LT_G(7)); LT_RD64(d3, cb, LT_G(21));
         LT_RD64(e3, cb, LT_G(6)); LT_RD64(f3_, cb, LT_G(22)); LT_RD64(g3, cb, LT_G(5)); LT_RD64(h3, cb, LT_G(23));
+        LT_PRIO_MATH();
         LT_WAIT8(8, a2, b2, c2, d2, e2, f2_, g2, h2);
         {
             LT_PAIR(4, a2, b2) LT_PAIR(5, c2, d2) LT_PAIR(6, e2, f2_) LT_PAIR(7, g2, h2)
             updates(std::integral_constant<int, 2>{});
         }
         // stage 4: 23, 24, 25
+        LT_PRIO_READS();
         unsigned long long a4, b4, c4, d4, e4, f4_;
         LT_RD64(a4, cb, LT_G(4)); LT_RD64(b4, cb, LT_G(24)); LT_RD64(c4, cb, LT_G(3)); LT_RD64(d4, cb, LT_G(25));
         LT_RD64(e4, cb, LT_G(2)); LT_RD64(f4_, cb, LT_G(26));
+        LT_PRIO_MATH();
         LT_WAIT8(6, a3, b3, c3, d3, e3, f3_, g3, h3);
         {
             LT_PAIR(8, a3, b3) LT_PAIR(9, c3, d3) LT_PAIR(10, e3, f3_) LT_PAIR(11, g3, h3)
             updates(std::integral_constant<int, 3>{});
         }
         // stage 5: 26, 27 (= 13 + 14 as S13[p - 14], S13[p], S13[p + 14])
+        LT_PRIO_READS();
         unsigned long long a5, b5, c5, d5, e5;
         LT_RD64(a5, cb, LT_G(1)); LT_RD64(b5, cb, LT_G(27)); LT_RD64(c5, cb, LT_G(0)); LT_RD64(d5, cb, LT_G(14)); LT_RD64(e5, cb, LT_G(28));
+        LT_PRIO_MATH();
         asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a4), "+v"(b4), "+v"(c4), "+v"(d4), "+v"(e4), "+v"(f4_) :: "memory");
         {
             LT_PAIR(12, a4, b4) LT_PAIR(13, c4, d4) LT_PAIR(14, e4, f4_)
@@ -534,11 +562,13 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         // 128-entry LDS store per row pair: the LDS pipe, where a 16-byte store takes 13 cycles, is this kernel's bound.
         const uint32_t a4 = lds_addr(S4 + p - 10);
         unsigned long long r0, g[21];
+        LT_PRIO_READS2();
         LT_RD64(r0, s0_rd, 0);
 #define LT_G(i) LT_RD64(g[i], a4, (i) * 8)
         LT_G(9); LT_G(11); LT_G(7); LT_G(13); LT_G(10); LT_G(5); LT_G(15); LT_G(4); LT_G(16); LT_G(3); LT_G(17); LT_G(2); LT_G(18);
         LT_G(1); LT_G(19); LT_G(0); LT_G(20);
 #undef LT_G
+        LT_PRIO_MATH2();
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(r0), "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(g[4]), "+v"(g[5]), "+v"(g[7]), "+v"(g[9]),
                        "+v"(g[10]), "+v"(g[11]), "+v"(g[13]), "+v"(g[15]), "+v"(g[16]), "+v"(g[17]), "+v"(g[18]), "+v"(g[19]), "+v"(g[20])
