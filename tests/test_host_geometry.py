@@ -215,3 +215,20 @@ def test_mean_of_rows_is_numpy_average():
             rows = [rng.uniform(-1, 1, 3) * 10.0 ** rng.integers(-6, 4) for _ in range(k)]
             a, b = np.average(rows, axis=0), _mean_of_rows(rows)
             assert a.tobytes() == b.tobytes() and b is not rows[0]
+
+
+@pytest.mark.parametrize("path", golden_files("sws_")[:12])
+def test_packed_poly_points_against_the_reference_fixture(path):
+    """lt_poly_points against what the reference's own get_poly_points returned for these fits (tests/gen_golden.py)."""
+    from lane_tracker_amd import _native
+    d = np.load(path)
+    if not bool(d["detected"]):
+        pytest.skip("nothing detected in this case")
+    h, w = [int(v) for v in d["mask_shape"]]
+    t = HostOnlyTracker((w, h))
+    partial = d["param_partial"].item()
+    ploty, ploty2 = t._plot_rows(partial)
+    ln, rn, lyx, ryx = _native.poly_points((w, h), np.concatenate([d["left_coeffs"], d["right_coeffs"]])[None], ploty, ploty2)
+    assert np.array_equal(lyx[:, 1], d["poly_left_x"]) and np.array_equal(ryx[:, 1], d["poly_right_x"])
+    assert np.array_equal(lyx[:, 0], d["poly_left_y"]) and np.array_equal(ryx[:, 0], d["poly_right_y"])
+    assert ln[0] == len(d["poly_left_x"]) and rn[0] == len(d["poly_right_x"])
