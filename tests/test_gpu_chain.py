@@ -309,3 +309,34 @@ def test_one_frame_chain_with_a_chain_behind_it_keeps_both_tickets():
         assert c.band_fit_chain_collect(4, first=0)["detected"].all()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("annotate,n_tries,n_reset", [(False, 2, 4), (True, 2, 4), (False, 1, 2), (True, -1, 0)])
+def test_long_outages_in_groups_equal_process_frame_by_frame(annotate, n_tries, n_reset):
+    """Outages of 3, 11 and 37 frames (noise / grey / black; shorter and longer than n_reset and than the largest group of
+    `_fail_group`), an isolated failure and a lane jump: the windows of process_batch leave the state, the pixel lists, the
+    centroids and (annotated) the frames of process() frame by frame -- with one try, two, or 'as many as it takes' (-1)."""
+    from lane_tracker_amd import calib, synth
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    a, b = synth.stream_lanes(60, seed=41), synth.stream_lanes(30, seed=42)
+    frames = np.concatenate([a[:20], b[:12], a[20:]], 0).copy()          # a jump to another lane and back
+    for start, length, kind in ((8, 3, 0), (25, 1, 1), (40, 11, 2), (55, 37, 0)):
+        for i in range(start, min(len(frames), start + length)):
+            frames[i] = synth.frame_uniform(500 + i) if (kind + i) % 3 == 0 else (128 if (kind + i) % 3 == 1 else 0)
+    seq, bat = LaneTracker(n_reset=n_reset, **cal), LaneTracker(n_reset=n_reset, **cal)
+    try:
+        lo = 0
+        for w in (30, 45, len(frames) - 75):
+            outs = bat.process_batch(frames[lo:lo + w], annotate=annotate, n_tries=n_tries)
+            outs_seq = [seq.process(f, n_tries=n_tries) for f in frames[lo:lo + w]]
+            assert _state(bat) == _state(seq), lo
+            assert np.array_equal(bat.left_x, seq.left_x) and np.array_equal(bat.right_y, seq.right_y)
+            assert bat.left_window_centroids == seq.left_window_centroids and bat.right_window_centroids == seq.right_window_centroids
+            if annotate:
+                assert all(np.array_equal(g, s) for g, s in zip(outs, outs_seq)), lo
+            lo += w
+        assert 0 < bat.success < bat.counter == len(frames)
+    finally:
+        seq.close()
+        bat.close()
