@@ -152,6 +152,18 @@ def stream_leg(streams, window=256, seconds=1.0):
                 k += 12
             res["process_stream_annotated_fps"] = round(k * window / (time.perf_counter() - t0), 1)
             res["success_ratio"] = round(lt.get_success_ratio()[0], 4)
+            # ... and with outages: every 64th frame starts 16 frames of noise / flat grey / black (tools/outage_profile.py)
+            broken = frames.copy()
+            for j, s0 in enumerate(range(40, window, 64)):
+                for i in range(s0, min(window, s0 + 16)):
+                    broken[i] = (np.random.default_rng(4000 + i).integers(0, 256, broken[i].shape, dtype=np.uint8) if j % 3 == 0
+                                 else (128 if j % 3 == 1 else 0))
+            list(lt.process_stream([broken] * 2, annotate=False))
+            t0, k = time.perf_counter(), 0
+            while time.perf_counter() - t0 < seconds * 0.3 or k == 0:
+                list(lt.process_stream([broken] * 4, annotate=False))
+                k += 4
+            res["process_stream_outages_fps"] = round(k * window / (time.perf_counter() - t0), 1)
             out[name] = res
         finally:
             lt.close()
@@ -160,7 +172,8 @@ def stream_leg(streams, window=256, seconds=1.0):
                    "annotated frame returned; process_batch() = windows of %d frames, searches chained on the device "
                    "(lt_band_fit_chain_run), check_validity / history on the host; process_stream() = the same over consecutive "
                    "windows, the next windows' uploads and masks under the current one's searches (the *_annotated figures return every "
-                   "annotated frame: 2 x the frame bytes over the bus); 1920x1080 is BASELINE config 5" % window)
+                   "annotated frame: 2 x the frame bytes over the bus; *_outages: four outages of 16 frames per window, handled in speculative "
+                   "groups); success_ratio is that of the clean streams; 1920x1080 is BASELINE config 5" % window)
     return out
 
 
