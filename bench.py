@@ -177,6 +177,63 @@ def stream_leg(streams, window=256, seconds=1.0):
     return out
 
 
+FILTER_KEYS = ("filter_type", "ksize_r", "C_r", "ksize_b", "C_b", "mask_noise", "noise_thresh", "ksize_noise", "C_noise")
+SEARCH_KEYS = ("window_width", "window_height", "search_range", "mu", "no_success_limit", "start_slice", "ignore_sides",
+               "ignore_bottom", "bandwidth", "partial")
+
+
+def parameter_sets():
+    """The parameter sets the reference itself documents: process()'s defaults (lane_tracker.py:876-900), the author's three
+    demo configurations (tracker_settings.md:1-111) and the hard-coded second try (lane_tracker.py:1081-1099)."""
+    from lane_tracker_amd import settings
+    try2 = dict(ksize_r=15, C_r=5, ksize_b=35, C_b=5, filter_type="neighborhood", mask_noise=False, noise_thresh=140,
+                ksize_noise=65, C_noise=10, window_width=30, window_height=40, search_range=20, mu=0.1, no_success_limit=50,
+                start_slice=0.25, ignore_sides=360, ignore_bottom=30, bandwidth=30, partial=1.0)
+    return [("process_defaults", {}), ("demo1", settings.DEMO_1["process"]), ("demo2", settings.DEMO_2["process"]),
+            ("demo3", settings.DEMO_3["process"]), ("second_try", try2)]
+
+
+def settings_leg(ctx, NL, streams, steps=5):
+    """Batch frames/s and the mask-stage time per launch for every documented parameter set, on the frames already
+    resident in `ctx` (slots [0, NL)): the same step as `value` -- mask chain + sliding-window search + fit -- on one
+    copy of the batch."""
+    from lane_tracker_amd import _native
+    out = {}
+    for name, kw in parameter_sets():
+        fp = _native.filter_params(**{k: v for k, v in kw.items() if k in FILTER_KEYS})
+        sp = _native.search_params(**{k: v for k, v in kw.items() if k in SEARCH_KEYS})
+        ctx.set_streams(streams)
+        for _ in range(2):
+            ctx.mask_run(NL, fp)
+            ctx.sws_fit_run(NL, sp)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.mask_run(NL, fp)
+            ctx.sws_fit_run(NL, sp)
+        ctx.sync()
+        fps = NL * steps / (time.perf_counter() - t0)
+        path = ctx.last_threshold_path() if kw.get("filter_type", "bilateral") == "bilateral" else None
+        rec = ctx.download_records(NL)
+        ctx.set_streams(1)
+        ctx.set_stage_timing(True)
+        ctx.stage_reset()
+        for _ in range(3):
+            ctx.mask_run(NL, fp)
+        ctx.sync()
+        st = ctx.stage_ms()
+        ctx.set_stage_timing(False)
+        out[name] = {"frames_per_s": round(fps, 1), "mask_stage_ms": round(sum(st[k][0] for k in MASK_STAGES) / 3, 4),
+                     "threshold_ms": round((st["threshold"][0] + st["merge"][0]) / 3, 4),
+                     "walking_threshold_kernels": None if path is None else bool(path == 1),
+                     "detected_fraction": round(float(np.mean(rec["detected"])), 4),
+                     "kernels_ms": {k: round(st[k][0] / 3, 4) for k in MASK_STAGES if st[k][1]}}
+    out["note"] = ("per parameter set: frames_per_s = mask chain + sliding-window search + fit over the %d resident frames, every step on the "
+                   "same slots, %d HIP streams; mask_stage_ms = the stage's kernels on one stream between hipEvents; second_try = the "
+                   "'neighborhood' filter of lane_tracker.py:1081-1099 (no top-hats)" % (NL, streams))
+    return out
+
+
 def coeff_close(got, want, h=1100, tol=1e-4):
     """north_star tolerance: 1e-4 relative per coefficient with the absolute floor of SURVEY 8(a)."""
     lim = tol * max(1.0, abs(float(want[2])))
@@ -335,6 +392,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
     ap.add_argument("--no-stream", action="store_true", help="skip the stateful-stream leg (process / process_batch frames/s)")
+    ap.add_argument("--no-settings", action="store_true", help="skip the parameter-set leg (defaults, demo 1-3, second try)")
+    ap.add_argument("--only-settings", action="store_true", help="development probe: print the parameter-set leg alone")
     a = ap.parse_args()
     if a.gpus < 1 or a.steps < 1 or a.warmup < 0:
         ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
@@ -363,7 +422,7 @@ def main():
         indices = range(rank * a.batch, (rank + 1) * a.batch)
     NL = len(indices)                                   # frames this rank processes per step
     frames = render_frames(indices)                     # before anything initialises the GPU (forked workers)
-    streams = render_streams() if (world == 1 and not strong and not a.no_stream) else None
+    streams = render_streams() if (world == 1 and not strong and not a.no_stream and not a.only_settings) else None
 
     try:
         device = distributed.local_device(local_rank)   # LOCAL_RANK (LT_DEVICE_MODULO: test runs that share a GPU, labelled below)
@@ -392,6 +451,10 @@ def main():
             ctx.upload_frames(frames[c0:c0 + 256], first=NL + c0)
         ctx.set_frame_base(NL, indices[0], first=NL)
     fp, sp = _native.filter_params(), _native.search_params()
+    if a.only_settings:
+        print(json.dumps(settings_leg(ctx, NL, a.streams), indent=1))
+        ctx.close()
+        return
 
     # ranks: every step's records are staged, stream-ordered and without a host wait, into the gather's send buffer;
     # the timed region ends with ONE RCCL all-gather of all of them (the path has no other exchange step)
@@ -585,6 +648,11 @@ def main():
                     masks_cache[i] = ctx.download_masks(1, first=i)[0]
                 return masks_cache.pop(i)
             out["cpu_baseline"], out["parity"] = cpu_baseline(frames, cal, rec_all, gpu_mask_of)
+        if single and not a.no_settings:
+            try:
+                out["settings"] = settings_leg(ctx, NL, a.streams)
+            except Exception as e:
+                out["settings"] = {"error": repr(e)}
         ctx.close()
         ctx = None
         if single and not a.no_host_fed:

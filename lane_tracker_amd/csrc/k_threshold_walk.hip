@@ -50,6 +50,7 @@ struct WalkArgs {
     int h, w, wpr;
     int pitch;                   // bytes per row of the plane (a multiple of 64 >= w)
     int C;
+    uint32_t rbias;              // RANGE walks: (0x8000 - noise_thresh) in both halves (see walk_h_task)
     int groups;                  // 128-row groups (horizontal) / 128-column groups (vertical) per frame
     int segs, seg_len;           // segments per walk, nominal length (horizontal: a multiple of 128)
     int ntasks;
@@ -261,7 +262,11 @@ __device__ __forceinline__ void walk_v_task(const WalkArgs& a, int blk) {
 // piece lane&7: 8 rows x one whole 128-byte line per instruction); the eighth of the lanes that holds the next 16 columns
 // writes them into the ring every 16 steps with 128-bit stores, and the streams read 128 bits per row and 16 steps.
 // (64 VGPRs for the block: the ring limits a CU to 11 waves at k = 35 anyway, so up to 168 VGPRs cost no occupancy.)
-template <int K, bool PLACED = false>
+// RANGE: the greenery mask of filter_lane_points (lane_tracker.py:223-225),  noise = !inRange(b, T, 255) | bilateral(b),
+// folded into this pass: a pixel below T passes whatever its sums say.  With rbias = 0x8000 - T in both halves (T clamped
+// to [0, 256]) bit 15 of  q + rbias  is set exactly when q >= T, so  fails &= q + rbias  (one add, one and per step; the
+// horizontal walks have the issue slots to spare, the vertical ones do not).
+template <int K, bool PLACED = false, bool RANGE = false>
 __device__ __forceinline__ void walk_h_task(const WalkArgs& a, int task_blk) {
     using Cfg = WalkCfgH<K>;
     constexpr int WIN = Cfg::WIN, NPRE = Cfg::NPRE, NCH = Cfg::NCH, WSTEP = Cfg::WSTEP, PITCH = Cfg::PITCH, E = Cfg::E,
@@ -405,7 +410,8 @@ __device__ __forceinline__ void walk_h_task(const WalkArgs& a, int task_blk) {
                     const uint32_t qi = pick(si, std::integral_constant<int, PI>{});
                     // verdict of pixel ys + s: both rows at once, "fails" in bits 15 and 31
                     const uint32_t kp = __umul24(qc, (uint32_t)K);
-                    const uint32_t v = (sl - kp) | (sr - kp);
+                    uint32_t v = (sl - kp) | (sr - kp);
+                    if (RANGE) v &= qc + a.rbias;
                     acc = (v & 0x80008000u) | ((acc >> 1) & 0x7fff7fffu);
                     if constexpr ((u - E + 16 * 64) % 16 == 15) if (sb + u >= E + 15) {   // 16 pixels of the segment are complete
                         wa = (wa >> 16) | ((unsigned long long)(acc & 0xffffu) << 48);
@@ -453,32 +459,37 @@ __global__ __launch_bounds__(64, 3) void k_bilateral_walk_h(WalkArgs a) { walk_h
 // passes of a frame's plane run on one XCD close together and its L2 fetches the plane from HBM once.  (Alternating by the
 // parity of b itself put every horizontal task on the even XCDs and every vertical task on the odd ones: each plane
 // crossed the fabric once per pass.)  xcd = 0: the parity order, for A/B.
-template <int K>
-__global__ __launch_bounds__(64, 3) void k_bilateral_walk_hv(WalkArgs ah, WalkArgs av, int xcd) {
+// (window 65: the rings leave room for 7 waves per CU, so the registers of two waves per SIMD are free to use)
+template <int K, bool RANGE = false>
+__global__ __launch_bounds__(64, K > 35 ? 2 : 3) void k_bilateral_walk_hv(WalkArgs ah, WalkArgs av, int xcd) {
     const int pairs = min(ah.ntasks, av.ntasks);
     if (xcd) {
         const int b = xcd_contiguous(blockIdx.x, gridDim.x);
         if (b < 2 * pairs) {
             if (b & 1) walk_v_task<K, true>(av, b >> 1);
-            else walk_h_task<K, true>(ah, b >> 1);
-        } else if (ah.ntasks > pairs) walk_h_task<K, true>(ah, b - pairs);
+            else walk_h_task<K, true, RANGE>(ah, b >> 1);
+        } else if (ah.ntasks > pairs) walk_h_task<K, true, RANGE>(ah, b - pairs);
         else walk_v_task<K, true>(av, b - pairs);
         return;
     }
     const int b = blockIdx.x;
     if (b < 2 * pairs) {
         if (b & 1) walk_v_task<K>(av, b >> 1);
-        else walk_h_task<K>(ah, b >> 1);
-    } else if (ah.ntasks > pairs) walk_h_task<K>(ah, b - pairs);
+        else walk_h_task<K, false, RANGE>(ah, b >> 1);
+    } else if (ah.ntasks > pairs) walk_h_task<K, false, RANGE>(ah, b - pairs);
     else walk_v_task<K>(av, b - pairs);
 }
 
 // partial planes -> merged plane (out may alias p0)
 __global__ __launch_bounds__(256) void k_or4_bits(const unsigned long long* __restrict__ p0, const unsigned long long* __restrict__ p1,
                                                  const unsigned long long* __restrict__ p2, const unsigned long long* __restrict__ p3,
+                                                 const unsigned long long* __restrict__ n0, const unsigned long long* __restrict__ n1,
                                                  unsigned long long* out, size_t n) {
     const size_t i = blockIdx.x * 256ull + threadIdx.x;
-    if (i < n) out[i] = p0[i] | p1[i] | p2[i] | p3[i];
+    if (i >= n) return;
+    unsigned long long v = p0[i] | p1[i] | p2[i] | p3[i];
+    if (n0) v &= n0[i] | n1[i];      // the greenery mask (lane_tracker.py:229)
+    out[i] = v;
 }
 
 template <bool VERT>
@@ -489,6 +500,7 @@ WalkArgs walk_args(const uint8_t* src, int C, unsigned long long* out, int h, in
     a.h = h; a.w = w; a.wpr = (w + 63) / 64;
     a.pitch = pitch;
     a.C = C;
+    a.rbias = 0;
     a.groups = ((VERT ? w : h) + 127) / 128;
     const int len = VERT ? h : w;
     a.segs = len > 640 ? 2 : 1;
@@ -528,6 +540,19 @@ void launch_walk_both(hipStream_t s, const uint8_t* src, int C, unsigned long lo
     else (void)hipMemsetAsync(out_v, 0, bytes, s);
 }
 
+// The greenery-mask walks: window 65 over the raw Lab-b plane, the inRange term folded into the horizontal pass.
+// out_h = !inRange | (left & right), out_v = up & down; their OR is the noise mask.
+constexpr int K_NOISE = 65;
+void launch_walk_noise(hipStream_t s, const uint8_t* src, int C, int noise_thresh, unsigned long long* out_h, unsigned long long* out_v,
+                       int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n) {
+    WalkArgs ah = walk_args<false>(src, C, out_h, h, w, pitch, plane_stride, bits_stride, n);
+    const WalkArgs av = walk_args<true>(src, C, out_v, h, w, pitch, plane_stride, bits_stride, n);
+    ah.rbias = (uint32_t)(0x8000 - std::min(std::max(noise_thresh, 0), 256)) * 0x10001u;
+    const int lds = std::max(WalkCfgH<K_NOISE>::LDS, WalkCfg<K_NOISE>::V_LDS);
+    static const int xcd = [] { const char* e = std::getenv("LT_WALK_XCD"); return e && e[0] == '0' ? 0 : 1; }();   // A/B
+    hipLaunchKernelGGL((k_bilateral_walk_hv<K_NOISE, true>), dim3(ah.ntasks + av.ntasks), dim3(64), lds, s, ah, av, xcd);
+}
+
 bool walk_supports(int k) { return k == 15 || k == 20 || k == 35; }
 
 void dispatch_walk(int k, hipStream_t s, const uint8_t* src, int C, unsigned long long* out_h, unsigned long long* out_v, int h, int w,
@@ -562,11 +587,28 @@ int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
     return 0;
 }
 
+bool noise_walk_supported(int k_n, int C_n, int h, int w, int pitch) {
+    static const bool off = [] { const char* e = std::getenv("LT_BILATERAL_TILES"); return e && e[0] == '1'; }();
+    if (off || k_n != K_NOISE || C_n < 0 || (long long)k_n * (255 + C_n) >= 32768) return false;
+    return !((w & 3) || (pitch & 63) || pitch < w || w < 8 || h < 1);
+}
+
+// noise_h | noise_v = the greenery mask  !inRange(b, noise_thresh, 255) | bilateral(b, 65, C_n)  of lane_tracker.py:223-225;
+// `braw` is the RAW Lab-b plane with the padded pitch.  0 = ran, -1 = outside its limits.
+int launch_noise_walk(hipStream_t s, const uint8_t* braw, int k_n, int C_n, int noise_thresh, unsigned long long* noise_h,
+                      unsigned long long* noise_v, int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n) {
+    if (n <= 0 || !noise_walk_supported(k_n, C_n, h, w, pitch) || (plane_stride & 63)) return -1;
+    launch_walk_noise(s, braw, C_n, noise_thresh, noise_h, noise_v, h, w, pitch, plane_stride, bits_stride, n);
+    return 0;
+}
+
 void launch_or4_bits(hipStream_t s, unsigned long long* merged, const unsigned long long* s1, const unsigned long long* s2,
-                     const unsigned long long* s3, int h, int w, size_t bits_stride, int n) {
+                     const unsigned long long* s3, int h, int w, size_t bits_stride, int n, const unsigned long long* n0,
+                     const unsigned long long* n1) {
     if (n <= 0) return;
     const size_t words = (size_t)(n - 1) * bits_stride + (size_t)h * ((w + 63) / 64);
-    hipLaunchKernelGGL(k_or4_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, merged, s1, s2, s3, merged, words);
+    if (!n0 || !n1) n0 = n1 = nullptr;
+    hipLaunchKernelGGL(k_or4_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, merged, s1, s2, s3, n0, n1, merged, words);
 }
 
 }  // namespace lt

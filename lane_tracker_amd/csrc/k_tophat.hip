@@ -156,6 +156,7 @@ struct RunsGeom {
     int nstrips_normal;          // strips handled one frame per wave; nstrips - 1 when the last strip is a PAIR strip (below)
     int n_normal;                // tasks of those strips: nframes * nstrips_normal * nbands; the tasks behind them are pair tasks
     int xcd;                     // 1: workgroups are renumbered so that each XCD (= each L2) owns one contiguous range of tasks
+    uint8_t* copy_dst;           // COPYM kernels: the minuend is also stored here, with the destination's pitch and stride
 };
 
 // Per-lane column bookkeeping, loop invariant: clamped byte offsets of the (up to) four pixels a
@@ -617,10 +618,15 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
 // (x0 - R + e) of the two frames).  Input: four dwords per row instead of three (columns a, b of both frames); output:
 // lanes 0..15 of each half-wave store frame f, lanes 16..31 frame f + 1 (explicit row predicate instead of the band
 // descriptor, which cannot clip two frames).  An odd last frame is processed against itself and not stored twice.
-template <class SE, bool DIL, bool WIDE, bool TH, bool PAIR>
+// COPYM (top-hat, WIDE): the minuend dword every lane holds for its store is stored a second time into g.copy_dst, a plane
+// with the destination's pitch -- the raw Lab-b plane in the layout the threshold walks read (the greenery mask of
+// filter_lane_points, lane_tracker.py:224, is a bilateral threshold of the RAW plane).  One more store per row pair in a
+// kernel whose memory pipe idles.
+template <class SE, bool DIL, bool WIDE, bool TH, bool PAIR, bool COPYM = false>
 __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint8_t* __restrict__ minuend,
                                            const RunsGeom& g, uint2* chain, uint8_t* s_out_w, int lane, int strip, int band, int frame) {
     static_assert(WIDE || !PAIR, "pair strips exist for the WIDE kernels only");
+    static_assert(!COPYM || (WIDE && TH), "the minuend copy rides on the dword store of the WIDE top-hat");
     constexpr int K = SE::K, R = SE::R, NH = SE::NH;
     constexpr uint32_t NEUTRAL = (DIL ? 0u : 0x00ff00ffu) | BIAS2;
     const uint8_t* s = src + (size_t)frame * g.plane_stride;
@@ -653,6 +659,8 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
     // (PAIR: the band of frame f through the band of frame f + 1; rows are tested explicitly there)
     const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(d + (size_t)yb0 * g.dpitch, 0, (yb1 - yb0) * g.dpitch + (has_b ? (int)g.dst_stride : 0), RSRC_RAW);
     const __amdgpu_buffer_rsrc_t min_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(TH ? m : s), 0, plane_bytes + b_src, RSRC_RAW);
+    const __amdgpu_buffer_rsrc_t cp_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (COPYM ? g.copy_dst + (size_t)frame * g.dst_stride : d) + (size_t)yb0 * g.dpitch, 0, (yb1 - yb0) * g.dpitch + (has_b ? (int)g.dst_stride : 0), RSRC_RAW);
     auto row_ptr = [&](int y) { return __mul24(min(max(y, 0), g.h - 1), g.w); };   // byte offset of the (clamped) row: wave-uniform
     // Software prefetch: the three pixels (a, b, c) of each row of the NEXT pair are requested at the top of a pair, and
     // combined into its two entries (a | b << 16, b | c << 16) by the LAST statements of the pair.  The combine is a
@@ -719,9 +727,14 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
         if (TH) v = mp - v;   // TOPHAT: src - open(src) >= 0 in every byte
         if (PAIR) {           // two frames behind one descriptor: the band is tested per lane
             const int row = yp + (lane >> 5);
-            if (row >= yb0 && row < yb1) __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, (int)st_off, 0, 0);
-        } else
+            if (row >= yb0 && row < yb1) {
+                __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, (int)st_off, 0, 0);
+                if (COPYM) __builtin_amdgcn_raw_buffer_store_b32(mp, cp_rs, (int)st_off, 0, 0);
+            }
+        } else {
             __builtin_amdgcn_raw_buffer_store_b32(v, dst_rs, (int)st_off, 0, 0);
+            if (COPYM) __builtin_amdgcn_raw_buffer_store_b32(mp, cp_rs, (int)st_off, 0, 0);
+        }
     };
     auto row_pair = [&](int yy) __attribute__((always_inline)) {
         const uint2 e_pa = make_uint2(ea0, eb0);
@@ -821,7 +834,7 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
 #else
 #define LT_MORPH_WAVES_ATTR
 #endif
-template <class SE, bool DIL, bool WIDE, bool TH>
+template <class SE, bool DIL, bool WIDE, bool TH, bool COPYM = false>
 __global__ __launch_bounds__(64 * LT_MORPH_WPB) LT_MORPH_WAVES_ATTR void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     const uint8_t* __restrict__ minuend, RunsGeom g) {
     __shared__ uint2 s_chain[LT_MORPH_WPB][4 * PLANE];   // S0, S1, S4, S13
@@ -848,9 +861,9 @@ __global__ __launch_bounds__(64 * LT_MORPH_WPB) LT_MORPH_WAVES_ATTR void k_morph
         const int strip = t % g.nstrips_normal;
         const int band = (t / g.nstrips_normal) % g.nbands;
         const int frame = t / (g.nstrips_normal * g.nbands);
-        morph_task<SE, DIL, WIDE, TH, false>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, strip, band, frame);
+        morph_task<SE, DIL, WIDE, TH, false, COPYM>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, strip, band, frame);
     } else if constexpr (WIDE) {
-        morph_task<SE, DIL, WIDE, TH, true>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, g.nstrips_normal, task % g.nbands, 2 * (task / g.nbands));
+        morph_task<SE, DIL, WIDE, TH, true, COPYM>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, g.nstrips_normal, task % g.nbands, 2 * (task / g.nbands));
     }
 }
 
@@ -863,9 +876,10 @@ bool table_matches(const EllipseSE& se) {
 }
 
 template <class SE>
-void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, bool dilate,
-                 size_t plane_stride, int n, int dpitch, size_t dst_stride) {
+bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, bool dilate,
+                 size_t plane_stride, int n, int dpitch, size_t dst_stride, uint8_t* copy_dst) {
     RunsGeom g;
+    g.copy_dst = copy_dst;
     g.h = h;
     g.w = w;
     g.plane_stride = plane_stride;
@@ -938,12 +952,21 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.xcd = want_xcd ? 1 : 0;
     dim3 grid((g.ntasks + 3) / 4);
     const dim3 grid2((g.ntasks + LT_MORPH_WPB - 1) / LT_MORPH_WPB), block2(64 * LT_MORPH_WPB);
+    if (copy_dst && one_row) return false;
     if (one_row) {   // previous formulation (one row per iteration, u16 min/max), kept for A/B measurements
         if (dilate) hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
         else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
     } else {
         static const int extra_lds = [] { const char* e = std::getenv("LT_MORPH_EXTRA_LDS"); return e ? std::atoi(e) : 0; }();   // occupancy experiments
         const bool th = dilate && minuend != nullptr;
+        if (copy_dst) {   // the minuend copy exists for the 55x55 WIDE top-hat only (the Lab-b plane)
+            if constexpr (SE::K == 55) {
+                if (!wide || !th || ((uintptr_t)copy_dst & 3)) return false;
+                hipLaunchKernelGGL((k_morph_runs2<SE, true, true, true, true>), grid2, block2, extra_lds, s, src, dst, minuend, g);
+                return true;
+            } else
+                return false;
+        }
 #define LT_LAUNCH(DIL_, WIDE_, TH_) hipLaunchKernelGGL((k_morph_runs2<SE, DIL_, WIDE_, TH_>), grid2, block2, extra_lds, s, src, dst, minuend, g)
         if (wide) {
             if (th) LT_LAUNCH(true, true, true);
@@ -956,6 +979,7 @@ void launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         }
 #undef LT_LAUNCH
     }
+    return copy_dst == nullptr;
 }
 
 }  // namespace
@@ -965,13 +989,12 @@ bool tophat_tables_match(const EllipseSE& se29, const EllipseSE& se55) {
     return table_matches<SE29>(se29) && table_matches<SE55>(se55);
 }
 
-void launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
-                       bool dilate, size_t plane_stride, int n, int dpitch, size_t dst_stride) {
-    if (n <= 0 || h <= 0 || w <= 0) return;
+bool launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
+                       bool dilate, size_t plane_stride, int n, int dpitch, size_t dst_stride, uint8_t* copy_dst) {
+    if (n <= 0 || h <= 0 || w <= 0) return true;
     if (k == 55)
-        launch_runs<SE55>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride);
-    else
-        launch_runs<SE29>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride);
+        return launch_runs<SE55>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride, copy_dst);
+    return launch_runs<SE29>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride, copy_dst);
 }
 
 }  // namespace lt

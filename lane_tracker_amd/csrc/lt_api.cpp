@@ -85,6 +85,10 @@ struct lt_ctx {
     size_t th_pad_bytes = 0;
     int th_pitch = 0;
     std::vector<uint8_t> th_padded;
+    // mask_noise through the walking kernels (allocated by the first such call, ensure_noise_buffers): the raw Lab-b plane
+    // in the padded layout (the 55x55 top-hat launch stores its minuend there) and the two greenery-mask bit planes
+    uint8_t* d_b_pad = nullptr;
+    unsigned long long *d_bits_n1 = nullptr, *d_bits_n2 = nullptr;
     int last_threshold_path = -1;                 // lt_last_threshold_path
     // The walking threshold kernels are long serial walks (a wave covers half an image row or column): they win once a
     // call brings enough frames to fill the chip -- measured crossover 70-80 frames of 1100 x 1080 per call
@@ -393,6 +397,9 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_bits_tmp2);
     dev_free(c->d_th_pad[0]);
     dev_free(c->d_th_pad[1]);
+    dev_free(c->d_b_pad);
+    dev_free(c->d_bits_n1);
+    dev_free(c->d_bits_n2);
     c->th_padded.clear();
     c->mask_bits_ok.clear();
     c->mask_u8_ok.clear();
@@ -481,6 +488,16 @@ int ensure_u8_masks(lt_ctx* c, int first, int n) {
     return LT_OK;
 }
 
+int ensure_noise_buffers(lt_ctx* c) {
+    if (c->d_b_pad && c->d_bits_n1 && c->d_bits_n2) return LT_OK;
+    const size_t n = (size_t)c->capacity;
+    int rc;
+    if (!c->d_b_pad && (rc = dev_alloc(&c->d_b_pad, n * c->th_pad_bytes))) return rc;
+    if (!c->d_bits_n1 && (rc = dev_alloc(&c->d_bits_n1, n * c->bits_stride))) return rc;
+    if (!c->d_bits_n2 && (rc = dev_alloc(&c->d_bits_n2, n * c->bits_stride))) return rc;
+    return LT_OK;
+}
+
 int validate_filter(const lt_filter_params* p) {
     if (!p) return fail(LT_ERR_INVALID, "null filter params");
     if (p->filter_type != 0 && p->filter_type != 1)
@@ -509,13 +526,31 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     uint8_t* merged = c->d_plane[P_MERGED] + off;
     uint8_t* mask = c->d_plane[P_MASK] + off;
     // the walking threshold kernels read the top-hat planes with a padded row pitch: the dilate launches write them so
-    const bool walk = p->filter_type == 0 && !p->mask_noise && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp && c->d_bits_tmp2 &&
+    // (the greenery mask, mask_noise, rides along: a third walk with window 65 over the raw Lab-b plane)
+    const bool walk = p->filter_type == 0 && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp && c->d_bits_tmp2 &&
                       first + n <= (int)c->th_padded.size() && (long long)call_frames * h * w >= c->walk_min_pixels &&
-                      bilateral_walk_supported(p->ksize_r, p->C_r, p->ksize_b, p->C_b, h, w, c->th_pitch);
+                      bilateral_walk_supported(p->ksize_r, p->C_r, p->ksize_b, p->C_b, h, w, c->th_pitch) &&
+                      (!p->mask_noise || noise_walk_supported(p->ksize_noise, p->C_noise, h, w, c->th_pitch));
+    const bool walk_noise = walk && p->mask_noise;
+    if (walk_noise) {
+        const int rc = ensure_noise_buffers(c);
+        if (rc) return rc;
+    }
+    uint8_t* bpad = walk_noise ? c->d_b_pad + (size_t)first * c->th_pad_bytes : nullptr;
     if (p->filter_type == 0) c->last_threshold_path = walk ? 1 : 0;
     const int dpitch = walk ? c->th_pitch : 0;
     uint8_t* thRd = walk ? c->d_th_pad[0] + (size_t)first * c->th_pad_bytes : thR;
     uint8_t* thBd = walk ? c->d_th_pad[1] + (size_t)first * c->th_pad_bytes : thB;
+    // the 55x55 top-hat of the Lab-b plane; with the greenery mask it also leaves the raw plane in the padded layout
+    auto tophat_b = [&](hipStream_t st) -> int {
+        if (bpad && launch_morph_runs(st, t0, thBd, B, h, w, 55, true, ps, n, dpitch, c->th_pad_bytes, bpad)) return LT_OK;
+        launch_morph_runs(st, t0, thBd, B, h, w, 55, true, ps, n, dpitch, c->th_pad_bytes);
+        if (bpad)   // that kernel form does not exist for this geometry / A-B switch: plain strided copies
+            for (int i = 0; i < n; ++i)
+                HIP_TRY(hipMemcpy2DAsync(bpad + (size_t)i * c->th_pad_bytes, (size_t)c->th_pitch, B + (size_t)i * ps, (size_t)w, (size_t)w,
+                                         (size_t)h, hipMemcpyDeviceToDevice, st));
+        return LT_OK;
+    };
     if (p->filter_type == 0 && first + n <= (int)c->th_padded.size())
         for (int i = first; i < first + n; ++i) c->th_padded[(size_t)i] = walk ? 1 : 0;
     if (p->filter_type == 0) {
@@ -534,13 +569,13 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             launch_morph_runs(c->side, t3, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes);
             HIP_TRY(hipEventRecord(c->ev_join, c->side));
             launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
-            launch_morph_runs(s, t0, thBd, B, h, w, 55, true, ps, n, dpitch, c->th_pad_bytes);
+            { const int rc = tophat_b(s); if (rc) return rc; }
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
         } else {
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n); }
             { StageScope t(c, ST_TOPHAT_R, s); launch_morph_runs(s, t0, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes); }
             { StageScope t(c, ST_ERODE_B, s);  launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n); }
-            { StageScope t(c, ST_TOPHAT_B, s); launch_morph_runs(s, t0, thBd, B, h, w, 55, true, ps, n, dpitch, c->th_pad_bytes); }
+            { StageScope t(c, ST_TOPHAT_B, s); const int rc = tophat_b(s); if (rc) return rc; }
         }
     }
     unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
@@ -548,6 +583,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     bool merged_done = false, partials = false;   // partials: mbits, ebits, tmp, tmp2 still wait for their OR
     unsigned long long* tbits = c->d_bits_tmp + (size_t)first * c->bits_stride;
     unsigned long long* ubits = c->d_bits_tmp2 + (size_t)first * c->bits_stride;
+    unsigned long long *nbits1 = nullptr, *nbits2 = nullptr;   // the greenery mask of the walking kernels: n1 | n2
     if (p->filter_type == 0) {
         StageScope t(c, ST_THRESHOLD, s);   // both bilateral thresholds, the greenery mask and the OR-merge
         // long-walk kernels for the supported window sizes; their four partial planes are merged on the way into the open
@@ -555,6 +591,13 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             merged_done = launch_bilateral_walk(s, thRd, p->ksize_r, p->C_r, thBd, p->ksize_b, p->C_b, mbits, ebits, tbits, ubits,
                                                 h, w, c->th_pitch, c->th_pad_bytes, c->bits_stride, n, false) == 0;
             partials = merged_done;
+            if (merged_done && walk_noise) {
+                nbits1 = c->d_bits_n1 + (size_t)first * c->bits_stride;
+                nbits2 = c->d_bits_n2 + (size_t)first * c->bits_stride;
+                if (launch_noise_walk(s, bpad, p->ksize_noise, p->C_noise, p->noise_thresh, nbits1, nbits2, h, w, c->th_pitch,
+                                      c->th_pad_bytes, c->bits_stride, n))
+                    return fail(LT_ERR_STATE, "the greenery-mask walk refused parameters its own predicate accepted");
+            }
         }
         if (!merged_done)
           merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
@@ -581,9 +624,10 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
       unsigned long long* obits = c->d_bits_open + (size_t)first * c->bits_stride;
       bool opened = false;
       // one pass over the words; a handful of frames is latency-bound and better off with the wide, shallow kernels
-      if (!u8_mask && (partials || n >= 16)) opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, tbits, ubits, obits, h, w, c->bits_stride, n);
+      if (!u8_mask && (partials || n >= 16))
+          opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, tbits, ubits, obits, h, w, c->bits_stride, n, nbits1, nbits2);
       if (!opened) {
-          if (partials) launch_or4_bits(s, mbits, ebits, tbits, ubits, h, w, c->bits_stride, n);
+          if (partials) launch_or4_bits(s, mbits, ebits, tbits, ubits, h, w, c->bits_stride, n, nbits1, nbits2);
           if (u8_mask) launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n);
           else launch_open5_to_bits(s, mbits, ebits, obits, h, w, c->bits_stride, n);
       } }

@@ -69,8 +69,10 @@ void launch_morph_ellipse(hipStream_t s, const uint8_t* src, uint8_t* dst, const
                           const EllipseSE& se, bool dilate, size_t plane_stride, int n);
 // decomposed 29x29 / 55x55 ellipses (k_tophat.hip); same contract as launch_morph_ellipse
 // dpitch > 0: the destination has its own row pitch and per-frame stride (the padded top-hat planes the threshold walks read)
-void launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
-                       bool dilate, size_t plane_stride, int n, int dpitch = 0, size_t dst_stride = 0);
+// copy_dst (55x55 top-hat with dpitch > 0 only): the minuend is stored there as well, in the destination's layout; false
+// when that form is not available for the geometry (nothing was launched)
+bool launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
+                       bool dilate, size_t plane_stride, int n, int dpitch = 0, size_t dst_stride = 0, uint8_t* copy_dst = nullptr);
 bool tophat_tables_match(const EllipseSE& se29, const EllipseSE& se55);
 void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int ksize, int C, int mode,
                       int tv, int fv, size_t plane_stride, int n);
@@ -96,10 +98,18 @@ int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
                           unsigned long long* merged, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
                           int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n, bool merge);
 void launch_or4_bits(hipStream_t s, unsigned long long* merged, const unsigned long long* s1, const unsigned long long* s2,
-                     const unsigned long long* s3, int h, int w, size_t bits_stride, int n);
+                     const unsigned long long* s3, int h, int w, size_t bits_stride, int n, const unsigned long long* n0 = nullptr,
+                     const unsigned long long* n1 = nullptr);
+// the greenery mask (lane_tracker.py:223-225) through the walking kernels: noise_h | noise_v = !inRange(b, thresh, 255) |
+// bilateral(b, 65, C_n); `braw` = the raw Lab-b plane with the padded pitch.  0 = ran, -1 = outside its limits.
+bool noise_walk_supported(int k_n, int C_n, int h, int w, int pitch);
+int launch_noise_walk(hipStream_t s, const uint8_t* braw, int k_n, int C_n, int noise_thresh, unsigned long long* noise_h,
+                      unsigned long long* noise_v, int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n);
 // erode + dilate with the 5x5 ellipse, bit plane in, bit plane out
+// n0 / n1 (both or neither; with p1..p3 only): the merged plane is (p0 | p1 | p2 | p3) & (n0 | n1) -- the greenery mask
 bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
-                        const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n);
+                        const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n,
+                        const unsigned long long* n0 = nullptr, const unsigned long long* n1 = nullptr);
 void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded,
                           unsigned long long* opened, int h, int w, size_t bits_stride, int n);
 void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* out, int h, int w, size_t plane_stride,

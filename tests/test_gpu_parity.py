@@ -82,6 +82,9 @@ def test_mask_chain_bit_exact(ctx, nat, oracle, ref_calib, frames, kw):
     n = frames.shape[0]
     ctx.upload_frames(frames)
     ctx.mask_run(n, nat.filter_params(**kw))
+    if os.environ.get("LT_WALK_MIN_FRAMES") == "0" and os.environ.get("LT_BILATERAL_TILES") != "1" and \
+            kw.get("filter_type", "bilateral") == "bilateral" and kw.get("ksize_r", 15) in (15, 20, 35):
+        assert ctx.last_threshold_path() == 1      # the greenery mask included (test_alternative_kernel_paths_keep_parity)
     masks = ctx.download_masks(n)
     thr, thb = ctx.download_plane(2, n), ctx.download_plane(3, n)
     merged = ctx.download_plane(4, n)
@@ -530,7 +533,8 @@ def test_randomised_differential_run():
 @pytest.mark.parametrize("switch", ["LT_MORPH_WIDE=0", "LT_XCD_REMAP=0", "LT_STREAM_PRIORITY=normal", "LT_MORPH_ONE_ROW=1",
                                     "LT_SEARCH_U8=1", "LT_SWS_V1=1", "LT_BAND_V1=1", "LT_WALK_MIN_FRAMES=0", "LT_BILATERAL_TILES=1",
                                     "LT_MORPH_PAIR=0", "LT_UNDISTORT_UNALIGNED=1", "LT_WALK_MIN_FRAMES=0,LT_WALK_SPLIT=1",
-                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN5_SEPARATE=1"])
+                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN5_SEPARATE=1", "LT_WALK_MIN_FRAMES=0,LT_MORPH_WIDE=0",
+                                    "LT_WALK_MIN_FRAMES=0,LT_MORPH_ONE_ROW=1"])
 def test_alternative_kernel_paths_keep_parity(switch):
     """Every measurement switch of DESIGN.md selects a path that stays bit-exact: the mask-chain, top-hat operator and
     search parity tests again in a process started with the switch set (the library reads them once)."""

@@ -74,8 +74,56 @@ def test_walk_kernels_match_the_oracle_on_many_sizes(size, monkeypatch):
         ctx.close()
 
 
+NOISE = [dict(), dict(noise_thresh=120, C_noise=0), dict(noise_thresh=0), dict(noise_thresh=256), dict(noise_thresh=300, C_noise=40),
+         dict(noise_thresh=-5, C_noise=3), dict(noise_thresh=255, C_noise=249)]
+
+
+@pytest.mark.parametrize("size", [(1080, 1100), (1084, 300), (256, 128), (132, 70), (8, 5), (64, 64), (644, 130), (72, 300)])
+def test_greenery_mask_through_the_walking_kernels(size, monkeypatch):
+    """mask_noise (lane_tracker.py:221-231; the author's Demo 1 / Demo 3 settings): the third walk with window 65 over the raw
+    Lab-b plane -- which the 55x55 top-hat launch leaves in the padded layout -- with the inRange term folded in, AND-ed
+    into the merged plane on the way into the 5x5 open."""
+    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")
+    from lane_tracker_amd import _native, calib
+    from oracle import oracle as O
+    w, h = size
+    cal = calib.reference_calibration()
+    ctx = _native.Context(cal["img_size"], (w, h), cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=3)
+    rng = np.random.default_rng(w * 31 + h)
+    try:
+        for pi, nz in enumerate(NOISE):
+            if (w * h > 500000) and pi > 1:
+                continue
+            kw = dict(ksize_r=15, C_r=8, ksize_b=35, C_b=5, mask_noise=True, **nz)
+            bev = np.stack([_bev(rng, h, w, k) for k in range(3)], 0)
+            if pi % 2:   # Lab-b values around the threshold: shades of grey with a yellow / blue tint
+                tint = rng.integers(-40, 41, (3, h, w))
+                grey = rng.integers(60, 200, (3, h, w))
+                bev = np.clip(np.stack([grey + tint, grey + tint, grey - tint], -1), 0, 255).astype(np.uint8)
+            ctx.upload_bev(bev)
+            ctx.filter_run(3, _native.filter_params(**kw))
+            assert ctx.last_threshold_path() == 1, "the walking kernels did not take the greenery mask"
+            got = ctx.download_masks(3)
+            merged = ctx.download_plane(_native.PLANE_MERGED, 3)
+            for i in range(3):
+                want, planes = O.filter_lane_points(bev[i], O.filter_params(**kw), want_planes=True)
+                b = planes[1]
+                noise = ~(b >= kw.get("noise_thresh", 140)) | _bilateral_np(b, 65, kw.get("C_noise", 10))
+                expect = (_bilateral_np(planes[2], 15, 8) | _bilateral_np(planes[3], 35, 5)) & noise
+                tag = (size, nz, i)
+                assert np.array_equal(merged[i] > 0, expect), (tag, int(((merged[i] > 0) != expect).sum()))
+                assert np.array_equal(got[i], want), tag
+            # the same slots again without the mask: nothing of it may linger
+            fp = _native.filter_params(ksize_r=15, C_r=8, ksize_b=35, C_b=5)
+            ctx.filter_run(3, fp)
+            assert np.array_equal(ctx.download_masks(3)[1], O.filter_lane_points(bev[1], O.filter_params(ksize_r=15, C_r=8, ksize_b=35, C_b=5)))
+    finally:
+        ctx.close()
+
+
 def test_other_parameters_take_the_tile_kernel_and_agree(monkeypatch):
-    """Window sizes outside {15, 20, 35}, the greenery mask and LT-internal limits fall back to k_bilateral_tile2."""
+    """Window sizes outside {15, 20, 35}, a greenery mask with another window than 65 and LT-internal limits fall back to
+    k_bilateral_tile2."""
     monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")
     from lane_tracker_amd import _native, calib
     from oracle import oracle as O
@@ -85,7 +133,8 @@ def test_other_parameters_take_the_tile_kernel_and_agree(monkeypatch):
     rng = np.random.default_rng(5)
     try:
         bev = _bev(rng, h, w, 1)[None]
-        for kw in (dict(ksize_r=17, C_r=8, ksize_b=35, C_b=5), dict(ksize_r=15, C_r=8, ksize_b=35, C_b=5, mask_noise=True)):
+        for kw in (dict(ksize_r=17, C_r=8, ksize_b=35, C_b=5), dict(ksize_r=15, C_r=8, ksize_b=35, C_b=5, mask_noise=True, ksize_noise=45),
+                   dict(ksize_r=15, C_r=8, ksize_b=35, C_b=5, mask_noise=True, C_noise=250)):
             ctx.upload_bev(bev)
             ctx.filter_run(1, _native.filter_params(**kw))
             assert ctx.last_threshold_path() == 0
