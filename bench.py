@@ -213,7 +213,7 @@ def settings_leg(ctx, NL, streams, steps=5):
             ctx.sws_fit_run(NL, sp)
         ctx.sync()
         fps = NL * steps / (time.perf_counter() - t0)
-        path = ctx.last_threshold_path() if kw.get("filter_type", "bilateral") == "bilateral" else None
+        path = ctx.last_threshold_path() if kw.get("filter_type", "bilateral") == "bilateral" else ctx.last_adaptive_path()
         rec = ctx.download_records(NL)
         ctx.set_streams(1)
         ctx.set_stage_timing(True)
@@ -225,7 +225,7 @@ def settings_leg(ctx, NL, streams, steps=5):
         ctx.set_stage_timing(False)
         out[name] = {"frames_per_s": round(fps, 1), "mask_stage_ms": round(sum(st[k][0] for k in MASK_STAGES) / 3, 4),
                      "threshold_ms": round((st["threshold"][0] + st["merge"][0]) / 3, 4),
-                     "walking_threshold_kernels": None if path is None else bool(path == 1),
+                     "walking_threshold_kernels": bool(path == 1),
                      "detected_fraction": round(float(np.mean(rec["detected"])), 4),
                      "kernels_ms": {k: round(st[k][0] / 3, 4) for k in MASK_STAGES if st[k][1]}}
     out["note"] = ("per parameter set: frames_per_s = mask chain + sliding-window search + fit over the %d resident frames, every step on the "

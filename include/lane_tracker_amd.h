@@ -324,11 +324,15 @@ int  lt_stage_reset(lt_ctx* ctx);
 int  lt_stage_ms(lt_ctx* ctx, float* ms, int32_t* launches, int n);
 const char* lt_stage_name(int stage);
 /* Which kernels evaluated the bilateral thresholds in the context's last 'bilateral' lt_mask_run / lt_filter_run:
- * 1 = the long-walk kernels (window sizes 15 / 20 / 35, no greenery mask, width a multiple of 4), 0 = the tile kernel,
- * -1 = none yet; LT_NO_CONTEXT for a null context (distinct from every status and from "none yet").  Both give
- * identical masks; tests use this to know which one they have exercised. */
+ * 1 = the long-walk kernels (window sizes 15 / 20 / 35, width a multiple of 4; with the greenery mask -- mask_noise,
+ * lane_tracker.py:221-231 -- when its window is 65), 0 = the tile kernel, -1 = none yet; LT_NO_CONTEXT for a null
+ * context (distinct from every status and from "none yet").  Both give identical masks; tests use this to know which
+ * one they have exercised. */
 #define LT_NO_CONTEXT (-2147483647 - 1)
 int  lt_last_threshold_path(lt_ctx* ctx);
+/* The same for the last 'neighborhood' call (cv2.adaptiveThreshold, lane_tracker.py:217-218): 1 = running box sums
+ * (odd windows up to 63, width a multiple of 4, no greenery mask), 0 = the per-pixel window kernel, -1 = none yet. */
+int  lt_last_adaptive_path(lt_ctx* ctx);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -136,6 +136,7 @@ _SIGNATURES = {
     "lt_stage_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]),
     "lt_stage_name": (C.c_char_p, [C.c_int]),
     "lt_last_threshold_path": (C.c_int, [_P]),
+    "lt_last_adaptive_path": (C.c_int, [_P]),
 }
 
 _lib = None
@@ -619,6 +620,10 @@ class Context:
     def last_threshold_path(self):
         """1 = long-walk threshold kernels, 0 = tile kernel, -1 = no bilateral chain has run yet."""
         return int(self.lib.lt_last_threshold_path(self._h))
+
+    def last_adaptive_path(self):
+        """'neighborhood' calls: 1 = running box sums, 0 = per-pixel windows, -1 = none yet."""
+        return int(self.lib.lt_last_adaptive_path(self._h))
 
     def stage_reset(self):
         _check(self.lib.lt_stage_reset(self._h))

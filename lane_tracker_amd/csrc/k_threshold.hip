@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256) void k_erode5_bits(const unsigned long long* _
 // (the 17-tap ellipse: one pixel in the outer rows, five in the three inner ones).  Erode ignores taps outside the image
 // (= set), dilate too (= clear).  NP = 4 also writes the merged plane over p0 (lt_download_plane(LT_PLANE_MERGED)); a
 // neighbouring band that still reads that row gets the same OR either way.
+// NP = 2: the two thresholded planes of the 'neighborhood' filter (k_adaptive_walk.hip).
 // NP = 6: the four partial planes AND-ed with the OR of the two greenery-mask planes n0 / n1 (mask_noise, lane_tracker.py:229).
 template <int NP>
 __global__ __launch_bounds__(64) void k_merge_open5(unsigned long long* p0, const unsigned long long* __restrict__ p1,
@@ -616,7 +617,8 @@ __global__ __launch_bounds__(64) void k_merge_open5(unsigned long long* p0, cons
     auto load_row = [&](int y, u64 (&q)[6]) {
         const size_t o = base + (size_t)min(max(y, 0), h - 1) * wpr;
         q[0] = p0[o];
-        if (NP >= 4) { q[1] = p1[o]; q[2] = p2[o]; q[3] = p3[o]; }
+        if (NP >= 2) q[1] = p1[o];
+        if (NP >= 4) { q[2] = p2[o]; q[3] = p3[o]; }
         if (NP == 6) { q[4] = n0[o]; q[5] = n1[o]; }
     };
     u64 m0 = ~0ull, m1 = ~0ull, m2 = ~0ull, m3 = ~0ull;     // m[t-4 .. t-1]
@@ -627,9 +629,9 @@ __global__ __launch_bounds__(64) void k_merge_open5(unsigned long long* p0, cons
     load_row(yb0 - 4, q);
     for (int t = yb0 - 4; t <= yb1 + 3; ++t) {
         load_row(t + 1, qn);                                  // next row in flight while this one goes through the pipeline
-        const u64 raw = NP == 6 ? ((q[0] | q[1] | q[2] | q[3]) & (q[4] | q[5])) : NP == 4 ? (q[0] | q[1] | q[2] | q[3]) : q[0];
+        const u64 raw = NP == 6 ? ((q[0] | q[1] | q[2] | q[3]) & (q[4] | q[5])) : NP == 4 ? (q[0] | q[1] | q[2] | q[3]) : NP == 2 ? (q[0] | q[1]) : q[0];
         const bool in_img = t >= 0 && t < h;
-        if (NP >= 4 && active && t >= yb0 && t < yb1) p0[base + (size_t)t * wpr] = raw;
+        if (NP >= 2 && active && t >= yb0 && t < yb1) p0[base + (size_t)t * wpr] = raw;
         const u64 m = in_img ? (raw | ~vb) : ~0ull;           // pixels right of / rows outside the image count as set
         u64 l, r;
         shift_in(m, ~0ull, l, r);
@@ -826,7 +828,8 @@ bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned lo
                         const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n,
                         const unsigned long long* n0, const unsigned long long* n1) {
     const int wpr = (w + 63) / 64;
-    if ((n0 || n1) && !(n0 && n1 && p1)) return false;
+    if ((n0 || n1) && !(n0 && n1 && p1 && p2 && p3)) return false;
+    if ((p2 != nullptr) != (p3 != nullptr) || (p2 && !p1)) return false;
     static const bool off = [] { const char* e = std::getenv("LT_OPEN5_SEPARATE"); return e && e[0] == '1'; }();   // A/B
     if (off || n <= 0 || h <= 0 || wpr > 64 || opened == p0) return false;
     const int G = 64 / wpr;
@@ -838,6 +841,7 @@ bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned lo
     nbands = (h + band_rows - 1) / band_rows;
     dim3 grid(groups, nbands);
     if (n0) hipLaunchKernelGGL(k_merge_open5<6>, grid, dim3(64), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride, band_rows, G, n);
+    else if (p1 && !p2) hipLaunchKernelGGL(k_merge_open5<2>, grid, dim3(64), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride, band_rows, G, n);
     else if (p1) hipLaunchKernelGGL(k_merge_open5<4>, grid, dim3(64), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride, band_rows, G, n);
     else hipLaunchKernelGGL(k_merge_open5<1>, grid, dim3(64), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride, band_rows, G, n);
     return true;

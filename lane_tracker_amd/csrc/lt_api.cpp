@@ -90,6 +90,7 @@ struct lt_ctx {
     uint8_t* d_b_pad = nullptr;
     unsigned long long *d_bits_n1 = nullptr, *d_bits_n2 = nullptr;
     int last_threshold_path = -1;                 // lt_last_threshold_path
+    int last_adaptive_path = -1;                  // 'neighborhood' calls: 1 = running box sums (k_adaptive_walk.hip), 0 = per-pixel windows
     // The walking threshold kernels are long serial walks (a wave covers half an image row or column): they win once a
     // call brings enough frames to fill the chip -- measured crossover 70-80 frames of 1100 x 1080 per call
     // (tools/threshold_crossover.py: 64 frames 232 vs 210 us, 96 frames 255 vs 304 us) -- and lose badly on a single
@@ -581,6 +582,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
     unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
     bool merged_done = false, partials = false;   // partials: mbits, ebits, tmp, tmp2 still wait for their OR
+    bool two_partials = false;                    // ... only mbits and ebits (the 'neighborhood' walk)
     unsigned long long* tbits = c->d_bits_tmp + (size_t)first * c->bits_stride;
     unsigned long long* ubits = c->d_bits_tmp2 + (size_t)first * c->bits_stride;
     unsigned long long *nbits1 = nullptr, *nbits2 = nullptr;   // the greenery mask of the walking kernels: n1 | n2
@@ -609,8 +611,17 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
         }
     } else {
         StageScope t(c, ST_THRESHOLD, s);
-        launch_adaptive_mean(s, R, t1, h, w, p->ksize_r, p->C_r, ps, n);
-        launch_adaptive_mean(s, B, t2, h, w, p->ksize_b, p->C_b, ps, n);
+        // running box sums, both planes in one launch, bit planes out (merged on the way into the open); the per-pixel
+        // window kernel for what that does not take (window > 63, a width that is not a multiple of 4, the greenery mask)
+        if (!p->mask_noise && launch_adaptive_walk(s, R, p->ksize_r, p->C_r, mbits, B, p->ksize_b, p->C_b, ebits, h, w, ps, c->bits_stride, n)) {
+            merged_done = true;
+            partials = true;
+            two_partials = true;
+        } else {
+            launch_adaptive_mean(s, R, t1, h, w, p->ksize_r, p->C_r, ps, n);
+            launch_adaptive_mean(s, B, t2, h, w, p->ksize_b, p->C_b, ps, n);
+        }
+        c->last_adaptive_path = two_partials ? 1 : 0;
     }
     if (!merged_done) {
         if (p->mask_noise) {
@@ -625,9 +636,10 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
       bool opened = false;
       // one pass over the words; a handful of frames is latency-bound and better off with the wide, shallow kernels
       if (!u8_mask && (partials || n >= 16))
-          opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, tbits, ubits, obits, h, w, c->bits_stride, n, nbits1, nbits2);
+          opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, two_partials ? nullptr : tbits, two_partials ? nullptr : ubits, obits,
+                                      h, w, c->bits_stride, n, nbits1, nbits2);
       if (!opened) {
-          if (partials) launch_or4_bits(s, mbits, ebits, tbits, ubits, h, w, c->bits_stride, n, nbits1, nbits2);
+          if (partials) launch_or4_bits(s, mbits, ebits, two_partials ? ebits : tbits, two_partials ? ebits : ubits, h, w, c->bits_stride, n, nbits1, nbits2);
           if (u8_mask) launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n);
           else launch_open5_to_bits(s, mbits, ebits, obits, h, w, c->bits_stride, n);
       } }
@@ -2177,6 +2189,11 @@ int lt_timer_stop(lt_ctx* c, float* ms) {
 int lt_last_threshold_path(lt_ctx* c) {
     if (!c) { (void)fail(LT_ERR_INVALID, "null context"); return LT_NO_CONTEXT; }
     return c->last_threshold_path;
+}
+
+int lt_last_adaptive_path(lt_ctx* c) {
+    if (!c) { (void)fail(LT_ERR_INVALID, "null context"); return LT_NO_CONTEXT; }
+    return c->last_adaptive_path;
 }
 
 int lt_set_stage_timing(lt_ctx* c, int enabled) {

@@ -78,6 +78,11 @@ void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, in
                       int tv, int fv, size_t plane_stride, int n);
 void launch_adaptive_mean(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int bs, int C,
                           size_t plane_stride, int n);
+// the 'neighborhood' filter (lane_tracker.py:217-218) of both planes as running box sums (k_adaptive_walk.hip): out_r / out_b
+// are the two thresholded bit planes.  false = outside its limits (nothing launched).
+bool adaptive_walk_supported(int bs_r, int bs_b, int h, int w, size_t plane_stride);
+bool launch_adaptive_walk(hipStream_t s, const uint8_t* R, int bs_r, int C_r, unsigned long long* out_r, const uint8_t* B, int bs_b,
+                          int C_b, unsigned long long* out_b, int h, int w, size_t plane_stride, size_t bits_stride, int n);
 // merged = ((tr | tb) & (use_noise ? (!(labb >= thresh) | noise_bil) : 1)) ? 255 : 0
 void launch_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uint8_t* labb, const uint8_t* noise_bil,
                   int noise_thresh, int use_noise, uint8_t* merged, size_t npix, size_t plane_stride, int n);
@@ -106,7 +111,7 @@ bool noise_walk_supported(int k_n, int C_n, int h, int w, int pitch);
 int launch_noise_walk(hipStream_t s, const uint8_t* braw, int k_n, int C_n, int noise_thresh, unsigned long long* noise_h,
                       unsigned long long* noise_v, int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n);
 // erode + dilate with the 5x5 ellipse, bit plane in, bit plane out
-// n0 / n1 (both or neither; with p1..p3 only): the merged plane is (p0 | p1 | p2 | p3) & (n0 | n1) -- the greenery mask
+// p1 alone: two partial planes.  n0 / n1 (both or neither; with p1..p3 only): the merged plane is (p0 | p1 | p2 | p3) & (n0 | n1)
 bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
                         const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n,
                         const unsigned long long* n0 = nullptr, const unsigned long long* n1 = nullptr);
