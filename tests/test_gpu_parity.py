@@ -278,11 +278,25 @@ def test_filter_lane_points_any_size(ctx, nat, oracle, shape):
         assert_same(got, oracle.filter_lane_points(bev, oracle.filter_params(**kw)), f"{shape} {kw}")
 
 
-def test_full_batch_256_unique_frames_bit_exact(nat, cal, oracle, ref_calib):
+BATCH_SETS = {
+    "process_defaults": (dict(), dict()),
+    # the author's Demo 1 / Demo 3 filter (tracker_settings.md:10-13, 86-89: the greenery mask) with Demo 3's half look-ahead
+    "demo1_demo3": (dict(mask_noise=True, noise_thresh=140, ksize_noise=65, C_noise=10), dict(no_success_limit=50, bandwidth=30, partial=0.5)),
+    # process()'s hard-coded second try (lane_tracker.py:1081-1099)
+    "second_try": (dict(filter_type="neighborhood", ksize_r=15, C_r=5, ksize_b=35, C_b=5), dict(no_success_limit=50, bandwidth=30)),
+}
+
+
+@pytest.mark.parametrize("which", list(BATCH_SETS))
+def test_full_batch_256_unique_frames_bit_exact(nat, cal, oracle, ref_calib, which):
     """BASELINE configs 2 / 3: a batch of 256 DIFFERENT synthetic frames resident in HBM, every mask compared bit for bit
-    with the oracle and every record with its search + fit (the oracle runs one frame per host thread)."""
+    with the oracle and every record with its search + fit (the oracle runs one frame per host thread) -- for process()'s
+    defaults, the greenery-mask filter of the author's demos and the second try, each through its batch-size kernels."""
     from concurrent.futures import ThreadPoolExecutor
     from lane_tracker_amd import synth
+    fkw, skw = BATCH_SETS[which]
+    fp, sp = nat.filter_params(**fkw), nat.search_params(**skw)
+    ofp, osp = oracle.filter_params(**fkw), oracle.search_params(**skw)
     r = synth.SceneRenderer()
     n = 256
     batch = np.stack([r.render(500 + i)[0] if i % 16 else synth.frame_uniform(500 + i) for i in range(n)], 0)
@@ -291,15 +305,19 @@ def test_full_batch_256_unique_frames_bit_exact(nat, cal, oracle, ref_calib):
     try:
         c.upload_frames(batch)
         c.set_frame_base(n, 1000)
-        c.mask_run(n)
-        c.sws_fit_run(n)
+        c.mask_run(n, fp)
+        if fkw.get("filter_type") == "neighborhood":
+            assert c.last_adaptive_path() == 1           # the running box sums, not the per-pixel windows
+        else:
+            assert c.last_threshold_path() == 1          # the walking kernels, the greenery mask included
+        c.sws_fit_run(n, sp)
         rec = c.download_records(n)
         masks = c.download_masks(n)
         assert rec["frame"].tolist() == list(range(1000, 1000 + n))
         threads = min(64, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else 8
         oracle.frame_sws_fit(ref_calib, batch[0])        # builds the oracle's per-calibration tables before the threads start
         with ThreadPoolExecutor(threads) as ex:          # ctypes releases the GIL
-            want = list(ex.map(lambda i: oracle.frame_sws_fit(ref_calib, batch[i], want_mask=True), range(n)))
+            want = list(ex.map(lambda i: oracle.frame_sws_fit(ref_calib, batch[i], ofp, osp, want_mask=True), range(n)))
         bad_masks = [i for i in range(n) if not np.array_equal(masks[i], want[i]["mask"])]
         assert not bad_masks, f"{len(bad_masks)} of {n} masks differ from the oracle, first: frame {bad_masks[0]}"
         for i, o in enumerate(want):
