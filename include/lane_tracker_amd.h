@@ -193,8 +193,9 @@ int  lt_set_search_cus(lt_ctx* ctx, int n);
  * THEIR slots only, and the lt_download_* calls wait for that stream only (they must ask for results produced in urgent mode,
  * or already complete).  Work enqueued for those slots afterwards is ordered behind it.  Leaving the mode waits for it. */
 int  lt_set_urgent(lt_ctx* ctx, int on);
-/* The caller has rejected a frame: every chain enqueued so far stops at its next frame (the slots it has not searched
- * get mode 255) instead of finishing its speculation.  Chains enqueued afterwards are not affected. */
+/* The caller has rejected a frame: every chain enqueued so far ON THIS CONTEXT -- whatever its slot range -- stops at its
+ * next frame (the slots it has not searched get mode 255) instead of finishing its speculation.  Chains enqueued
+ * afterwards are not affected.  One context serves one stream; independent streams take separate contexts. */
 int  lt_band_fit_chain_cancel(lt_ctx* ctx);
 /* tag records with global frame indices first_frame, first_frame+1, ... */
 int  lt_set_frame_base(lt_ctx* ctx, int first_slot, int n, int first_frame);

@@ -121,12 +121,12 @@ __global__ __launch_bounds__(256) void k_overlay_text(uint8_t* __restrict__ out,
                                                      const uint8_t* __restrict__ atlas, const uint8_t* __restrict__ advance,
                                                      int first_char, int n_glyphs, int gw, int gh,
                                                      const uint8_t* __restrict__ lines, const int16_t* __restrict__ xpos,
-                                                     int nl, int len, int y0, int step) {
+                                                     int nl, int len, int slot_chars, int y0, int step) {
     const int cell = gw * gh, t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= len * cell) return;
     const int k = t / cell, rem = t - k * cell, gy = rem / gw, gx = rem - gy * gw;
     const int line = blockIdx.y, slot = blockIdx.z;
-    const size_t li = ((size_t)slot * nl + line) * len + k;
+    const size_t li = (size_t)slot * slot_chars + (size_t)line * len + k;     // a slot's lines sit at the buffers' fixed stride
     const int ch = (int)lines[li] - first_char;
     if (ch < 0 || ch >= n_glyphs || gx >= advance[ch]) return;
     const int alpha = atlas[((size_t)ch * gh + gy) * gw + gx];
@@ -194,11 +194,11 @@ bool launch_copy_to_pinned(hipStream_t s, void* dst_pinned, const void* src, siz
 
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
                          const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
-                         const int16_t* xpos, int nl, int len, int y0, int step, int n) {
+                         const int16_t* xpos, int nl, int len, int slot_chars, int y0, int step, int n) {
     if (n <= 0 || nl <= 0 || len <= 0) return;
     dim3 grid((unsigned)((len * gw * gh + 255) / 256), (unsigned)nl, (unsigned)n);
     hipLaunchKernelGGL(k_overlay_text, grid, dim3(256), 0, s, out, frame_stride, img_h, img_w, atlas, advance, first_char,
-                       n_glyphs, gw, gh, lines, xpos, nl, len, y0, step);
+                       n_glyphs, gw, gh, lines, xpos, nl, len, slot_chars, y0, step);
 }
 
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,

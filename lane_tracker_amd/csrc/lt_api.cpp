@@ -154,12 +154,13 @@ struct lt_ctx {
     //   readers -- kernels that READ the camera frames (undistortion, overlay): a stream-ordered upload into slots waits for
     //              the readers of those slots only, so the rows of later frames cross the bus while earlier ones are processed;
     //   writers -- kernels that wrote masks / records: a chained search waits for the writers of its own slots only.
-    // A ring of 32 entries each; finished entries are dropped as new ones arrive (a long stream never synchronises the whole
-    // context); with 32 launches in flight at once the ring gives up (`overflow`) and waiters fall back to stream tails
-    // until the next full synchronisation.
+    // A ring each; finished entries are dropped as new ones arrive (a long stream never synchronises the whole context).
+    // The ring grows with the launches in flight (an outage group adds two or three entries per piece while the head
+    // still waits for the bus); beyond 4096 entries it gives up (`overflow`) and waiters fall back to the tails of every
+    // stream that can touch the slots, until the next full synchronisation.
     struct RangeEvents {
         struct Entry { int lo, hi; hipEvent_t ev; };
-        Entry e[32] = {};
+        std::vector<Entry> e = std::vector<Entry>(32, Entry{0, 0, nullptr});
         unsigned head = 0, count = 0;
         bool overflow = false;
         void reset() { head = count = 0; overflow = false; }
@@ -224,16 +225,24 @@ int sync_all(lt_ctx* c) {
 
 // work touching slots [lo, hi) has just been enqueued on `st`
 int note_range(lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi) {
+    unsigned cap = (unsigned)r.e.size();
     while (r.count > 0 && hipEventQuery(r.e[r.head].ev) == hipSuccess) {   // finished: nobody has to wait for it any more
-        r.head = (r.head + 1) % 32;
+        r.head = (r.head + 1) % cap;
         --r.count;
     }
-    if (r.count == 32) {
+    if (r.count == cap && cap < 4096) {        // everything in flight: a longer ring (the live entries first, in order)
+        std::vector<lt_ctx::RangeEvents::Entry> bigger(2 * (size_t)cap, lt_ctx::RangeEvents::Entry{0, 0, nullptr});
+        for (unsigned i = 0; i < r.count; ++i) bigger[i] = r.e[(r.head + i) % cap];
+        r.e.swap(bigger);
+        r.head = 0;
+        cap *= 2;
+    }
+    if (r.count == cap) {
         r.overflow = true;
-        r.head = (r.head + 1) % 32;
+        r.head = (r.head + 1) % cap;
         --r.count;
     }
-    lt_ctx::RangeEvents::Entry& w = r.e[(r.head + r.count) % 32];
+    lt_ctx::RangeEvents::Entry& w = r.e[(r.head + r.count) % cap];
     if (!w.ev && hipEventCreateWithFlags(&w.ev, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(w.ev, st));
     w.lo = lo;
@@ -247,7 +256,7 @@ int wait_range(const lt_ctx::RangeEvents& r, hipStream_t waiter, int lo, int hi,
     *precise = !r.overflow;
     if (r.overflow) return LT_OK;
     for (unsigned i = 0; i < r.count; ++i) {
-        const lt_ctx::RangeEvents::Entry& w = r.e[(r.head + i) % 32];
+        const lt_ctx::RangeEvents::Entry& w = r.e[(r.head + i) % (unsigned)r.e.size()];
         if (w.lo < hi && w.hi > lo) HIP_TRY(hipStreamWaitEvent(waiter, w.ev, 0));
     }
     return LT_OK;
@@ -714,7 +723,10 @@ const char* lt_stage_name(int stage) { return stage >= 0 && stage < LT_NUM_STAGE
 // batch rate under torch.distributed).  The slices therefore take the highest priority level, whose pool nothing
 // else in the process uses; LT_STREAM_PRIORITY=normal restores plain streams.
 // reserved > 0 (lt_set_search_cus): the stream is kept off CUs 0 .. reserved-1 (bits of the CU mask), which the search stream
-// has to itself -- see lt_set_search_cus.
+// has to itself -- see lt_set_search_cus.  hipExtStreamCreateWithCUMask takes no priority, so a CU-masked stream has the
+// runtime's default priority and LT_STREAM_PRIORITY has no effect on it: the priority only serves to put the slices of an
+// independent-batch context on separate hardware queues (contexts that never call lt_set_search_cus), while a stream
+// context runs its slices back to back behind the bus anyway.
 static hipError_t create_compute_stream(hipStream_t* st, int reserved = 0) {
     if (reserved > 0) {
         uint32_t mask[8];
@@ -983,6 +995,24 @@ int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
     return LT_OK;
 }
 
+// Fallback of the stream-ordered uploads when the ring of readers has overflowed: `waiter` waits for the tail of every stream
+// a kernel that reads camera frames can be on -- the slots' compute streams (undistortion), the presentation stream (overlays)
+// and the urgent stream.
+static int wait_reader_tails(lt_ctx* c, hipStream_t waiter) {
+    auto tail = [&](hipStream_t st) {
+        if (!st || st == waiter) return (int)LT_OK;
+        hipEvent_t e = next_order_event(c);
+        if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+        HIP_TRY(hipEventRecord(e, st));
+        HIP_TRY(hipStreamWaitEvent(waiter, e, 0));
+        return (int)LT_OK;
+    };
+    for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) { const int rc = tail(c->streams[i]); if (rc) return rc; }
+    int rc = tail(c->present);
+    if (!rc) rc = tail(c->urgent);
+    return rc;
+}
+
 // The same rows, stream-ordered instead of synchronous: the copy runs on the copy stream after the work already
 // enqueued on the streams that own these slots (their previous occupants), and those streams wait for it before
 // anything enqueued later -- so the upload of one slot range overlaps the chain of every other slot range.
@@ -996,16 +1026,7 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     // overlay) -- not for the rest of their mask chains, and not for launches over other slots
     bool precise = true;
     if ((rc = wait_range(c->readers, c->copy, first, first + n, &precise))) return rc;
-    if (!precise) {
-        rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
-            hipEvent_t e = next_order_event(c);
-            if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-            HIP_TRY(hipEventRecord(e, st));
-            HIP_TRY(hipStreamWaitEvent(c->copy, e, 0));
-            return (int)LT_OK;
-        });
-        if (rc) return rc;
-    }
+    if (!precise && (rc = wait_reader_tails(c, c->copy))) return rc;
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                              (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->copy));
@@ -1018,7 +1039,7 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     });
 }
 
-// the overlay (on the context's first stream) waits for the copies into its own slots before it reads the frames (or, when the
+// the overlay (on the presentation stream) waits for the copies into its own slots before it reads the frames (or, when the
 // ring of slot ranges has overflowed, for the most recent copy)
 static int rest_mark(lt_ctx* c, int first, int n) {
     if (!c->rest_done && hipEventCreateWithFlags(&c->rest_done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
@@ -1038,12 +1059,7 @@ int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
     {
         bool precise = true;
         if ((rc = wait_range(c->readers, c->copy, first, first + n, &precise))) return rc;
-        if (!precise) {                      // the overlays run on the context's first stream
-            hipEvent_t e = next_order_event(c);
-            if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-            HIP_TRY(hipEventRecord(e, c->stream));
-            HIP_TRY(hipStreamWaitEvent(c->copy, e, 0));
-        }
+        if (!precise && (rc = wait_reader_tails(c, c->copy))) return rc;
     }
     const size_t row_bytes = (size_t)c->calib.img_w * 3;
     const size_t head = (size_t)c->cam_r0 * row_bytes, tail0 = (size_t)c->cam_r1 * row_bytes;
@@ -1456,7 +1472,7 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
     const size_t per = (size_t)n_lines * line_len;
     if (per > c->text_per_slot || c->text_slots < c->capacity) {      // (re)size the per-slot text buffers: rare, synchronises
         if ((rc = sync_all(c))) return rc;
-        const size_t per_new = std::max(per, c->text_per_slot), total = per_new * (size_t)c->capacity;
+        const size_t per_new = (std::max(per, c->text_per_slot) + 3) & ~(size_t)3, total = per_new * (size_t)c->capacity;
         dev_free(c->d_lines);
         dev_free(c->d_xpos);
         if (c->h_lines) (void)hipHostFree(c->h_lines);
@@ -1473,29 +1489,36 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
         c->text_slots = c->capacity;
     }
     if ((rc = staging_claim(c->text_busy, first, n))) return rc;
-    // this call's lines are packed (n_lines * line_len per slot) at the slots' own positions in the per-slot buffers
-    uint8_t* hl = c->h_lines + (size_t)first * per;
-    int16_t* hx = c->h_xpos + (size_t)first * per;
-    std::memcpy(hl, lines, (size_t)n * per);
-    for (size_t l = 0; l < (size_t)n * n_lines; ++l) {     // left edge of every character: running sum of advances
-        int x = x0;
-        bool ended = false;
-        for (int k = 0; k < line_len; ++k) {
-            const unsigned char ch = (unsigned char)lines[l * line_len + k];
-            ended = ended || ch == 0;
-            hx[l * line_len + k] = (int16_t)std::min(x, 32767);
-            const int g = (int)ch - c->font_first;
-            if (!ended && g >= 0 && g < c->font_glyphs) x += c->h_advance[(size_t)g];
+    // A slot's lines sit at the slot's own position in the per-slot buffers, at their FIXED stride text_per_slot -- not at
+    // this call's n_lines * line_len: staging_claim orders calls by slot range, and two calls in flight over disjoint
+    // slots with different line counts (a 'fail' piece has one line, a lane piece two) must not meet in bytes.
+    const size_t stride = c->text_per_slot;
+    uint8_t* hl = c->h_lines + (size_t)first * stride;
+    int16_t* hx = c->h_xpos + (size_t)first * stride;
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(hl + (size_t)i * stride, lines + (size_t)i * per, per);
+        for (int l = 0; l < n_lines; ++l) {                // left edge of every character: running sum of advances
+            const char* src = lines + (size_t)i * per + (size_t)l * line_len;
+            int16_t* dst = hx + (size_t)i * stride + (size_t)l * line_len;
+            int x = x0;
+            bool ended = false;
+            for (int k = 0; k < line_len; ++k) {
+                const unsigned char ch = (unsigned char)src[k];
+                ended = ended || ch == 0;
+                dst[k] = (int16_t)std::min(x, 32767);
+                const int g = (int)ch - c->font_first;
+                if (!ended && g >= 0 && g < c->font_glyphs) x += c->h_advance[(size_t)g];
+            }
         }
     }
-    uint8_t* dl = c->d_lines + (size_t)first * per;
-    int16_t* dx = c->d_xpos + (size_t)first * per;
+    uint8_t* dl = c->d_lines + (size_t)first * stride;
+    int16_t* dx = c->d_xpos + (size_t)first * stride;
     if ((rc = present_stream(c))) return rc;
-    launch_copy_from_pinned(c->present, dl, hl, (size_t)n * per);
-    launch_copy_from_pinned(c->present, dx, hx, (size_t)n * per * sizeof(int16_t));
+    launch_copy_from_pinned(c->present, dl, hl, (size_t)n * stride);
+    launch_copy_from_pinned(c->present, dx, hx, (size_t)n * stride * sizeof(int16_t));
     launch_overlay_text(c->present, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
                         c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, dl, dx,
-                        n_lines, line_len, y0, step, n);
+                        n_lines, line_len, (int)stride, y0, step, n);
     HIP_TRY(hipGetLastError());
     return staging_mark(c->text_busy, c->present);
 }
@@ -1933,7 +1956,10 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     if (!c->chain_event_pool.empty()) { done = c->chain_event_pool.back(); c->chain_event_pool.pop_back(); }
     else if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(done, c->search));
-    while (c->chains.size() >= 32) {            // tickets nobody collected: the oldest goes (its event is long done or superseded)
+    while (c->chains.size() >= 32) {            // tickets nobody collected: the oldest goes -- once its chain has really ended
+        // (a cancelled chain runs one more frame, and later work on its slots is ordered behind tickets only: dropping the
+        // ticket of a chain still running would let mask / search launches race with it)
+        HIP_TRY(hipEventSynchronize(c->chains.front().done));
         c->chain_event_pool.push_back(c->chains.front().done);
         c->chains.erase(c->chains.begin());
     }

@@ -245,9 +245,10 @@ int lt_gather_records(lt_gather* g, int n_records, lt_lane_record* out_host) {
     if (!g || !out_host) return set_error(LT_ERR_INVALID, "null argument");
     if (n_records < 0 || n_records > g->cap) return set_error(LT_ERR_CAPACITY, "%d records exceed the gather's capacity %d", n_records, g->cap);
     // Every rank must pass the same count and hold the same capacity: a mismatch would hang or misplace records inside
-    // the collective, so it is checked with one small all-gather whenever the count changes (also for 0, which is a
-    // collective no-op only if it is 0 everywhere).
-    if (n_records != g->agreed_records) {
+    // the collective, so it is checked with one small all-gather on EVERY call (also for 0, which is a collective no-op
+    // only if it is 0 everywhere).  Unconditional: a check that ran only when this rank's count changed would itself be a
+    // mismatched collective when one rank's count changes and another's does not.  8 bytes per rank, latency only.
+    {
         const int32_t mine[2] = {n_records, g->cap};
         std::vector<int32_t> all(2 * (size_t)g->world);
         int rc = lt_gather_host(g, mine, sizeof mine, all.data());

@@ -57,7 +57,7 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
                          int bh, int bw, float alpha, int n);
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
                          const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
-                         const int16_t* xpos, int nl, int len, int y0, int step, int n);
+                         const int16_t* xpos, int nl, int len, int slot_chars, int y0, int step, int n);   // slot_chars: characters between two slots' lines
 // host -> device copy of a few hundred KB out of page-locked memory as a kernel launch (never blocks the caller)
 void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, size_t bytes);
 bool launch_copy_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes);   // false: not page-locked / aligned

@@ -261,6 +261,51 @@ def test_overlay_text_matches_the_atlas_blend(nat, cal):
 
 
 @pytest.mark.gpu
+def test_overlay_text_pieces_with_different_line_counts_do_not_share_staging(nat, cal):
+    """Several lt_overlay_text calls in flight over disjoint slot ranges with alternating line counts (a run of failed frames
+    has one line per slot, a lane piece two or three): each slot's lines sit at the buffers' fixed per-slot stride, so a
+    later call's host copy cannot land in the bytes an earlier call's queued copy kernel still reads."""
+    from lane_tracker_amd import overlay
+    font = overlay.font_atlas()
+    if font is None:
+        pytest.skip("Pillow is not installed: no glyph atlas")
+    atlas, adv, first_char = font
+    n = 64
+    frames = np.zeros((n, 720, 1280, 3), np.uint8)
+    e = np.zeros(0, np.int64)
+    c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                    device=0, capacity=n)
+
+    def lines_of(i):
+        return ["Curve Radius: %d m" % (100 + i), "Eccentricity: %.2f m" % (i / 64.0), "Frame: %d" % i][:1 + (i // 8) % 3]
+
+    try:
+        c.overlay_configure(cal["warp_matrices"][1])
+        c.upload_frames(frames)
+        c.overlay_set_font(atlas, adv, first_char)
+        c.overlay_run([(e, e, e, e)] * n)
+        c.overlay_text([lines_of(i) for i in range(16, 24)], first=16)        # sizes the buffers for three lines first
+        for rep in range(6):                                                  # pieces of 8 slots, 1 / 2 / 3 lines, back to back
+            for p0 in range(0, n, 8):
+                c.overlay_text([lines_of(i) for i in range(p0, p0 + 8)], first=p0)
+        out = c.download_overlay(n)
+        for i in (0, 7, 8, 9, 23, 24, 40, 63):
+            want = np.zeros((720, 1280), np.int32)
+            for j, line in enumerate(lines_of(i)):
+                x = 20
+                for ch in line:
+                    g = ord(ch) - first_char
+                    cell = atlas[g][:, :adv[g]].astype(np.int32)
+                    y = 8 + 35 * j
+                    reg = want[y:y + cell.shape[0], x:x + cell.shape[1]]
+                    for _ in range(6 + (1 if 16 <= i < 24 else 0)):            # blended once per call
+                        reg += ((255 - reg) * cell + 127) // 255
+                    x += int(adv[g])
+            assert_same(out[i][:, :, 0], want.astype(np.uint8), f"text of slot {i}")
+    finally:
+        c.close()
+
+
 def test_pinned_pool_hands_out_writable_arrays_and_reuses_blocks():
     """lt_host_alloc behind NumPy arrays: writable, correctly shaped, the block returns to the pool when the
     array and its views are gone, and download_overlay results live in such arrays."""
