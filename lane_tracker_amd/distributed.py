@@ -131,9 +131,33 @@ def process_shard(ctx, frames, first_frame, fp=None, sp=None, batch=256, gather=
 
 
 # ---- launch plumbing ---------------------------------------------------------------------------------------
+IPC_ENV = ("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def ensure_ipc_env(env=None):
+    """RCCL's intra-node transport hands device buffers from one rank process to another through HIP IPC handles
+    (hipIpcGetMemHandle / hipIpcOpenMemHandle).  The hosts this runs on export such handles as dmabuf file descriptors only;
+    the ROCm runtime's older ("legacy") IPC mode fails there with `hipIpcGetMemHandle: invalid argument` at
+    `ncclCommInitRank`.  HSA_ENABLE_IPC_MODE_LEGACY=0 selects the dmabuf mode.  The runtime reads the variable when it
+    initialises, so it has to be in the process environment BEFORE the first HIP call of a rank: every way a rank is
+    started -- `spawn_ranks`, `python -m torch.distributed.run ... bench.py`, a user's own launcher calling `env_rank()`
+    / `init_gather()` -- goes through here.  A value the caller has set is left alone."""
+    env = os.environ if env is None else env
+    env.setdefault(*IPC_ENV)
+    return env
+
+
 def env_rank():
-    """(rank, local_rank, world) from the launcher's environment; (0, 0, 1) when not launched as a rank."""
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    """(rank, local_rank, world) from the launcher's environment; (0, 0, 1) when not launched as a rank.  Call it before
+    anything touches the GPU: with more than one rank it also puts the IPC mode RCCL needs into the environment."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        ensure_ipc_env()
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world
+
+
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1:      # a rank process: at import, i.e. before _native creates a context
+    ensure_ipc_env()
 
 
 def rendezvous_path():
@@ -172,7 +196,7 @@ def local_device(local_rank=None):
 
 def init_gather(ctx, timeout_s=120):
     """The rank's `_native.Gather`, from the launcher's environment.  Collective over all ranks."""
-    rank, _, world = env_rank()
+    rank, _, world = env_rank()        # (also: the IPC mode, if this is the rank's first call into this module)
     path = rendezvous_path()
     g = _native.Gather(ctx, rank, world, path, timeout_s)
     g.barrier()                       # every rank has read the id
@@ -212,8 +236,8 @@ def spawn_ranks(world, argv, timeout=None):
         pass
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), LT_GATHER_ID=id_path, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env = ensure_ipc_env(dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                                  MASTER_PORT=str(port), LT_GATHER_ID=id_path))
         procs.append(subprocess.Popen(list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
     import time
     worst, t0 = 0, time.monotonic()

@@ -438,10 +438,81 @@ void lto_adaptive_mean_threshold(const uint8_t* src, int h, int w, int bs, int C
     free(rows);
 }
 
+/* The same two thresholds with running sums, O(1) per pixel instead of O(k): NOT the parity checker (that stays on
+ * the loops above, which read like the reference's kernels) -- these exist so that bench.py's cpu_baseline is a fair
+ * statement of a CPU path; tests/test_oracle_units.py checks them equal to the loops. */
+int lto_bilateral_adaptive_threshold_fast(const uint8_t* img, int h, int w, int ksize, int C, int mode,
+                                          int true_value, int false_value, uint8_t* out) {
+    if (mode != 0 && mode != 1) return -1;
+    const int k = ksize, delta = mode == 0 ? C * k : -C * k;
+    int32_t* su = calloc((size_t)w, sizeof(int32_t)); /* sum of the k pixels above, per column */
+    int32_t* sd = calloc((size_t)w, sizeof(int32_t)); /* ... below */
+    int32_t* pre = malloc(sizeof(int32_t) * ((size_t)w + 1));
+    for (int i = 1; i <= k && i < h; ++i)
+        for (int x = 0; x < w; ++x) sd[x] += img[(size_t)i * w + x];
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = img + (size_t)y * w;
+        pre[0] = 0;
+        for (int x = 0; x < w; ++x) pre[x + 1] = pre[x] + row[x];
+        for (int x = 0; x < w; ++x) {
+            const int p = row[x], kp = k * p;
+            const int xl = x - k < 0 ? 0 : x - k, xr = x + 1 + k > w ? w : x + 1 + k;
+            const int l = pre[x] - pre[xl] - kp + delta, r = pre[xr] - pre[x + 1] - kp + delta;
+            const int u = su[x] - kp + delta, d = sd[x] - kp + delta;
+            const int pass = mode == 0 ? ((0 > l && 0 > r) || (0 > u && 0 > d)) : ((0 < l && 0 < r) || (0 < u && 0 < d));
+            out[(size_t)y * w + x] = (uint8_t)(pass ? true_value : false_value);
+        }
+        if (y + 1 < h) { /* slide both column windows to row y + 1 */
+            const uint8_t* next = img + (size_t)(y + 1) * w;
+            const uint8_t* leave = y - k >= 0 ? img + (size_t)(y - k) * w : NULL;
+            const uint8_t* enter = y + 1 + k < h ? img + (size_t)(y + 1 + k) * w : NULL;
+            for (int x = 0; x < w; ++x) {
+                su[x] += row[x] - (leave ? leave[x] : 0);
+                sd[x] += (enter ? enter[x] : 0) - next[x];
+            }
+        }
+    }
+    free(su); free(sd); free(pre);
+    return 0;
+}
+
+void lto_adaptive_mean_threshold_fast(const uint8_t* src, int h, int w, int bs, int C, uint8_t* out) {
+    const int r = bs / 2, area = bs * bs;
+    int32_t* hs = malloc(sizeof(int32_t) * (size_t)h * w); /* horizontal window sums, replicated border */
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* row = src + (size_t)y * w;
+        int s = 0;
+        for (int j = -r; j <= r; ++j) s += row[j < 0 ? 0 : (j >= w ? w - 1 : j)];
+        for (int x = 0; x < w; ++x) {
+            hs[(size_t)y * w + x] = s;
+            const int in = x + r + 1, outx = x - r;
+            s += row[in >= w ? w - 1 : in] - row[outx < 0 ? 0 : outx];
+        }
+    }
+    int32_t* vs = calloc((size_t)w, sizeof(int32_t));
+    for (int i = -r; i <= r; ++i) {
+        const int32_t* q = hs + (size_t)(i < 0 ? 0 : (i >= h ? h - 1 : i)) * w;
+        for (int x = 0; x < w; ++x) vs[x] += q[x];
+    }
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w; ++x) {
+            const int mean = (2 * vs[x] + area) / (2 * area);
+            out[(size_t)y * w + x] = (uint8_t)((int)src[(size_t)y * w + x] - mean > C ? 255 : 0);
+        }
+        const int in = y + r + 1, outy = y - r;
+        const int32_t* qi = hs + (size_t)(in >= h ? h - 1 : in) * w;
+        const int32_t* qo = hs + (size_t)(outy < 0 ? 0 : outy) * w;
+        for (int x = 0; x < w; ++x) vs[x] += qi[x] - qo[x];
+    }
+    free(hs); free(vs);
+}
+
 /* ------------------------------------------------------------------------------------------- */
-/* LaneTracker.filter_lane_points (lane_tracker.py:183-240) */
-int lto_filter_lane_points(const uint8_t* bev, int h, int w, const lto_filter_params* p,
-                           uint8_t* mask, uint8_t* planes) {
+/* LaneTracker.filter_lane_points (lane_tracker.py:183-240); fast != 0: the running-sum thresholds (cpu_baseline only) */
+static int filter_impl(const uint8_t* bev, int h, int w, const lto_filter_params* p, uint8_t* mask, uint8_t* planes, int fast) {
+    int (*bil)(const uint8_t*, int, int, int, int, int, int, int, uint8_t*) =
+        fast ? lto_bilateral_adaptive_threshold_fast : lto_bilateral_adaptive_threshold;
+    void (*ada)(const uint8_t*, int, int, int, int, uint8_t*) = fast ? lto_adaptive_mean_threshold_fast : lto_adaptive_mean_threshold;
     if (p->filter_type != 0 && p->filter_type != 1) return -1; /* :220 ValueError */
     const size_t n = (size_t)h * w;
     uint8_t* buf = malloc(n * 8);
@@ -452,14 +523,14 @@ int lto_filter_lane_points(const uint8_t* bev, int h, int w, const lto_filter_pa
     if (p->filter_type == 0) {
         lto_tophat(R, h, w, 29, thR);                   /* :210 (computed on both branches upstream; unused by 'neighborhood') */
         lto_tophat(B, h, w, 55, thB);                   /* :211 */
-        lto_bilateral_adaptive_threshold(thR, h, w, p->ksize_r, p->C_r, 0, 255, 0, tr); /* :214 */
-        lto_bilateral_adaptive_threshold(thB, h, w, p->ksize_b, p->C_b, 0, 255, 0, tb); /* :215 */
+        bil(thR, h, w, p->ksize_r, p->C_r, 0, 255, 0, tr); /* :214 */
+        bil(thB, h, w, p->ksize_b, p->C_b, 0, 255, 0, tb); /* :215 */
     } else {
-        lto_adaptive_mean_threshold(R, h, w, p->ksize_r, p->C_r, tr); /* :217 */
-        lto_adaptive_mean_threshold(B, h, w, p->ksize_b, p->C_b, tb); /* :218 */
+        ada(R, h, w, p->ksize_r, p->C_r, tr); /* :217 */
+        ada(B, h, w, p->ksize_b, p->C_b, tb); /* :218 */
     }
     if (p->mask_noise) {                                /* :221-231 */
-        lto_bilateral_adaptive_threshold(B, h, w, p->ksize_noise, p->C_noise, 0, 255, 0, tmp); /* :224 */
+        bil(B, h, w, p->ksize_noise, p->C_noise, 0, 255, 0, tmp); /* :224 */
         for (size_t i = 0; i < n; ++i) {
             int part1 = B[i] >= p->noise_thresh;        /* inRange(b, thresh, 255) :223 */
             int noise = (!part1) || tmp[i];             /* :225 */
@@ -478,13 +549,22 @@ int lto_filter_lane_points(const uint8_t* bev, int h, int w, const lto_filter_pa
     return 0;
 }
 
-int lto_mask_from_frame(const lto_calib* c, const uint8_t* frame, const lto_filter_params* p,
-                        uint8_t* mask) {
+int lto_filter_lane_points(const uint8_t* bev, int h, int w, const lto_filter_params* p, uint8_t* mask, uint8_t* planes) {
+    return filter_impl(bev, h, w, p, mask, planes, 0);
+}
+int lto_filter_lane_points_fast(const uint8_t* bev, int h, int w, const lto_filter_params* p, uint8_t* mask, uint8_t* planes) {
+    return filter_impl(bev, h, w, p, mask, planes, 1);
+}
+
+static int mask_impl(const lto_calib* c, const uint8_t* frame, const lto_filter_params* p, uint8_t* mask, int fast) {
     uint8_t* bev = malloc((size_t)c->warp_w * c->warp_h * 3);
     lto_front_end(c, frame, bev);                       /* :832, :834 */
-    int rc = lto_filter_lane_points(bev, c->warp_h, c->warp_w, p, mask, NULL); /* :837 */
+    int rc = filter_impl(bev, c->warp_h, c->warp_w, p, mask, NULL, fast); /* :837 */
     free(bev);
     return rc;
+}
+int lto_mask_from_frame(const lto_calib* c, const uint8_t* frame, const lto_filter_params* p, uint8_t* mask) {
+    return mask_impl(c, frame, p, mask, 0);
 }
 
 /* ------------------------------------------------------------------------------------------- */
@@ -790,12 +870,24 @@ static void jacobi_svd3(double A[3][3], double U[3][3], double S[3], double V[3]
 
 /* ------------------------------------------------------------------------------------------- */
 /* One independent frame with a fresh tracker: find_lane_points (sliding window) + fit_poly.      */
+static int frame_impl(const lto_calib* c, const uint8_t* frame, const lto_filter_params* fp, const lto_search_params* sp,
+                      uint8_t* mask_out, double coef[6], int32_t counts[3], int fast);
 int lto_frame_sws_fit(const lto_calib* c, const uint8_t* frame, const lto_filter_params* fp,
                       const lto_search_params* sp, uint8_t* mask_out, double coef[6],
                       int32_t counts[3]) {
+    return frame_impl(c, frame, fp, sp, mask_out, coef, counts, 0);
+}
+/* the same with the running-sum thresholds: bench.py's cpu_baseline (results equal, tests/test_oracle_units.py) */
+int lto_frame_sws_fit_fast(const lto_calib* c, const uint8_t* frame, const lto_filter_params* fp,
+                           const lto_search_params* sp, uint8_t* mask_out, double coef[6],
+                           int32_t counts[3]) {
+    return frame_impl(c, frame, fp, sp, mask_out, coef, counts, 1);
+}
+static int frame_impl(const lto_calib* c, const uint8_t* frame, const lto_filter_params* fp, const lto_search_params* sp,
+                      uint8_t* mask_out, double coef[6], int32_t counts[3], int fast) {
     const int h = c->warp_h, w = c->warp_w;
     uint8_t* mask = mask_out ? mask_out : malloc((size_t)h * w);
-    int rc = lto_mask_from_frame(c, frame, fp, mask);
+    int rc = mask_impl(c, frame, fp, mask, fast);
     if (rc) { if (!mask_out) free(mask); return rc; }
     int nlev = (int)((sp->partial * (h - sp->ignore_bottom)) / sp->window_height);
     if (nlev < 1) nlev = 1;

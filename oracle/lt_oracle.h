@@ -87,6 +87,11 @@ int  lto_bilateral_adaptive_threshold(const uint8_t* img, int h, int w, int ksiz
                                       int true_value, int false_value, uint8_t* out);
 /* cv2.adaptiveThreshold(src,255,MEAN_C,THRESH_BINARY,bs,-C): 255 iff src - boxmean > C */
 void lto_adaptive_mean_threshold(const uint8_t* src, int h, int w, int bs, int C, uint8_t* out);
+/* The same two with running sums (O(1) per pixel).  Not the parity checker: they exist so that the CPU baseline of
+ * bench.py is a fair CPU path; tests/test_oracle_units.py checks them equal to the functions above. */
+int  lto_bilateral_adaptive_threshold_fast(const uint8_t* img, int h, int w, int ksize, int C, int mode,
+                                           int true_value, int false_value, uint8_t* out);
+void lto_adaptive_mean_threshold_fast(const uint8_t* src, int h, int w, int bs, int C, uint8_t* out);
 
 /* ---- filter_lane_points and the whole mask stage ------------------------------------------ */
 /* returns 0, or -1 for a bad filter_type.  planes (optional, may be NULL): 4 planes h*w each:
@@ -95,6 +100,8 @@ int  lto_filter_lane_points(const uint8_t* bev_rgb, int h, int w, const lto_filt
                             uint8_t* mask, uint8_t* planes);
 int  lto_mask_from_frame(const lto_calib* c, const uint8_t* frame, const lto_filter_params* p,
                          uint8_t* mask);
+int  lto_filter_lane_points_fast(const uint8_t* bev_rgb, int h, int w, const lto_filter_params* p,
+                                 uint8_t* mask, uint8_t* planes);   /* running-sum thresholds; equal results */
 
 /* ---- search + fit ------------------------------------------------------------------------- */
 /* Pixel lists are (y, x) int32 pairs, reference order.  Capacity per side must be >= h*w for
@@ -117,6 +124,9 @@ int  lto_polyfit2(const int32_t* y, const int32_t* x, int n, double coef[3]);
 int  lto_frame_sws_fit(const lto_calib* c, const uint8_t* frame, const lto_filter_params* fp,
                        const lto_search_params* sp, uint8_t* mask_out, double coef[6],
                        int32_t counts[3]);
+int  lto_frame_sws_fit_fast(const lto_calib* c, const uint8_t* frame, const lto_filter_params* fp,
+                            const lto_search_params* sp, uint8_t* mask_out, double coef[6],
+                            int32_t counts[3]);   /* running-sum thresholds (cpu_baseline); equal results */
 
 /* ---- presentation (cv2 calls, parity unpinned) ------------------------------ */
 /* cv2.fillPoly(img, [pts], color) for ONE polygon on an interleaved u8 image with `ch` channels,

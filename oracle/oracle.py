@@ -181,24 +181,25 @@ def morph_open(img, k=5):
     return _plane_op("lto_open", img, k)
 
 
-def bilateral_adaptive_threshold(img, ksize=30, C_=0, mode="floor", true_value=255, false_value=0):
+def bilateral_adaptive_threshold(img, ksize=30, C_=0, mode="floor", true_value=255, false_value=0, fast=False):
     if mode not in ("floor", "ceil"):
         raise ValueError("Unexpected mode value. Expected value is 'floor' or 'ceil'.")
-    return _plane_op("lto_bilateral_adaptive_threshold", img, int(ksize), int(C_),
+    return _plane_op("lto_bilateral_adaptive_threshold" + ("_fast" if fast else ""), img, int(ksize), int(C_),
                      0 if mode == "floor" else 1, int(true_value), int(false_value))
 
 
-def adaptive_mean_threshold(img, block_size, C_):
-    return _plane_op("lto_adaptive_mean_threshold", img, int(block_size), int(C_))
+def adaptive_mean_threshold(img, block_size, C_, fast=False):
+    return _plane_op("lto_adaptive_mean_threshold" + ("_fast" if fast else ""), img, int(block_size), int(C_))
 
 
-def filter_lane_points(bev_rgb, fp=None, want_planes=False):
+def filter_lane_points(bev_rgb, fp=None, want_planes=False, fast=False):
+    """fast=True: the running-sum thresholds (the CPU baseline's form; equal results, tests/test_oracle_units.py)."""
     fp = fp or filter_params()
     f, fptr = _u8(bev_rgb)
     h, w = f.shape[:2]
     mask = np.empty((h, w), np.uint8)
     planes = np.zeros((4, h, w), np.uint8) if want_planes else None
-    rc = lib().lto_filter_lane_points(fptr, h, w, C.byref(fp), mask.ctypes.data_as(C.c_void_p),
+    rc = (lib().lto_filter_lane_points_fast if fast else lib().lto_filter_lane_points)(fptr, h, w, C.byref(fp), mask.ctypes.data_as(C.c_void_p),
                                       planes.ctypes.data_as(C.c_void_p) if want_planes else None)
     if rc:
         raise ValueError("Unexpected filter mode. Expected modes are 'bilateral' or 'neighborhood'.")
@@ -261,14 +262,14 @@ def polyfit2(y, x):
     return np.array(out[:], np.float64)
 
 
-def frame_sws_fit(calib, frame, fp=None, sp=None, want_mask=False):
+def frame_sws_fit(calib, frame, fp=None, sp=None, want_mask=False, fast=False):
     fp = fp or filter_params()
     sp = sp or search_params()
     f, fptr = _u8(frame)
     mask = np.empty((calib.warp_h, calib.warp_w), np.uint8) if want_mask else None
     coef = (C.c_double * 6)()
     counts = (C.c_int32 * 3)()
-    rc = lib().lto_frame_sws_fit(C.byref(calib), fptr, C.byref(fp), C.byref(sp),
+    rc = (lib().lto_frame_sws_fit_fast if fast else lib().lto_frame_sws_fit)(C.byref(calib), fptr, C.byref(fp), C.byref(sp),
                                  mask.ctypes.data_as(C.c_void_p) if want_mask else None, coef, counts)
     if rc:
         raise ValueError("bad filter_type")

@@ -114,3 +114,34 @@ def test_bench_refuses_a_rank_count_it_cannot_deliver():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+
+
+def test_every_launch_form_puts_the_ipc_mode_into_a_rank_before_the_library_loads():
+    """RCCL's intra-node transport needs HSA_ENABLE_IPC_MODE_LEGACY=0 on these hosts (distributed.ensure_ipc_env says why),
+    and the runtime reads it once, at its initialisation.  A rank started the torch.distributed.run way -- RANK /
+    LOCAL_RANK / WORLD_SIZE in the environment, nothing else -- has it after importing `lane_tracker_amd.distributed`, i.e.
+    before `_native.load()` or any context exists; `spawn_ranks` hands it to its children; a caller's own value survives;
+    a single-process run is left alone."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "before = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')\n"
+            "from lane_tracker_amd import distributed\n"
+            "at_import = os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')\n"
+            "from lane_tracker_amd import _native\n"
+            "loaded = _native._LIB is not None if hasattr(_native, '_LIB') else None\n"
+            "print(before, at_import, distributed.env_rank(), os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))\n" % root)
+    base = {k: v for k, v in os.environ.items() if k not in ("HSA_ENABLE_IPC_MODE_LEGACY", "RANK", "LOCAL_RANK", "WORLD_SIZE")}
+
+    def run(extra):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(base, **extra), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        return r.stdout.strip().splitlines()[-1]
+
+    assert run(dict(RANK="1", LOCAL_RANK="1", WORLD_SIZE="4")) == "None 0 (1, 1, 4) 0"          # the driver's launch line
+    assert run(dict(RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="1")) == "1 1 (0, 0, 2) 1"
+    assert run({}) == "None None (0, 0, 1) None"                                                # one process: untouched
+    from lane_tracker_amd import distributed
+    env = distributed.ensure_ipc_env({})
+    assert env == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}

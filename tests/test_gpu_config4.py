@@ -78,3 +78,22 @@ def test_bench_two_ranks_weak_fake_rccl():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["frames_per_step_all_gpus"] == 128
+
+
+def test_the_drivers_launch_line_four_ranks_on_one_gpu_fake_rccl():
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port P bench.py --gpus 4`:
+    the launcher form the driver uses for SCALE_rNN.json (RANK / LOCAL_RANK / WORLD_SIZE from torch's agent), here with four
+    rank processes sharing GPU 0 over the stand-in.  The environment deliberately does NOT carry HSA_ENABLE_IPC_MODE_LEGACY:
+    the ranks must arrive at it by themselves (lane_tracker_amd.distributed.ensure_ipc_env), exactly as under the driver."""
+    env = fake_rccl.env()
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--batch", "64", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["config"]["frames_per_step_all_gpus"] == 256
+    assert line["config"]["ranks_share_devices"] is True and line["config"]["gathered_records_checked"] == 256
+    assert line["config"]["rank_environment"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}

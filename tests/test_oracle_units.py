@@ -149,3 +149,37 @@ def test_filter_lane_points_composition(oracle):
     assert np.array_equal(oracle.filter_lane_points(bev, fp3), oracle.morph_open(np.where((merged > 0) & noise, 255, 0).astype(np.uint8), 5))
     with pytest.raises(ValueError):
         oracle.filter_lane_points(bev, oracle.filter_params(filter_type="median"))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 200), (97, 131), (64, 64), (300, 17), (40, 41)])
+def test_running_sum_thresholds_equal_the_loops(oracle, shape):
+    O = oracle
+    """The O(1)-per-pixel variants bench.py's cpu_baseline times (lto_*_fast) against the loops that are the parity checker:
+    every window size class, both modes, zero / negative / large C, images smaller than a window."""
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    for kind in range(3):
+        if kind == 0:
+            img = rng.integers(0, 256, shape, dtype=np.uint8)
+        elif kind == 1:
+            img = np.clip(rng.integers(100, 140, shape) + (rng.random(shape) < 0.05) * 90, 0, 255).astype(np.uint8)
+        else:
+            img = np.full(shape, 255, np.uint8)
+        for k, c in ((1, 0), (15, 8), (35, 5), (65, 10), (20, 0), (128, 3), (7, -4)):
+            for mode in ("floor", "ceil"):
+                assert np.array_equal(O.bilateral_adaptive_threshold(img, k, c, mode, 200, 3, fast=True),
+                                      O.bilateral_adaptive_threshold(img, k, c, mode, 200, 3)), (shape, kind, k, c, mode)
+        for bs, c in ((1, 0), (3, 0), (15, 5), (35, 5), (63, -2), (101, 7)):
+            assert np.array_equal(O.adaptive_mean_threshold(img, bs, c, fast=True), O.adaptive_mean_threshold(img, bs, c)), (shape, kind, bs, c)
+
+
+def test_fast_filter_chain_equals_the_checker_on_a_rendered_frame(oracle):
+    O = oracle
+    from lane_tracker_amd import calib, synth
+    cal = calib.reference_calibration()
+    oc = O.make_calib(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0])
+    frame = synth.SceneRenderer(cal).render(77)[0]
+    bev = O.front_end(oc, frame)
+    for kw in (dict(), dict(mask_noise=True), dict(filter_type="neighborhood", C_r=5)):
+        assert np.array_equal(O.filter_lane_points(bev, O.filter_params(**kw), fast=True), O.filter_lane_points(bev, O.filter_params(**kw))), kw
+    a, b = O.frame_sws_fit(oc, frame, fast=True), O.frame_sws_fit(oc, frame)
+    assert (a["n_left"], a["n_right"], a["detected"]) == (b["n_left"], b["n_right"], b["detected"]) and np.array_equal(a["coeffs"], b["coeffs"])
