@@ -266,6 +266,13 @@ int  lt_download_overlay_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out)
 /* Wait until every copy enqueued by lt_download_overlay_async has landed -- and for nothing else: uploads and masks of
  * later frames keep running (lt_sync would drain them too). */
 int  lt_download_overlay_wait(lt_ctx* ctx);
+/* How lt_download_overlay_async moves the frames: 0 = the copy engine, 1 = a kernel storing into the (page-locked, 16-byte
+ * aligned) destination, -1 (default) = chosen by measurement: every copy is timed, the engine is used while its copies
+ * reach ~42 GB/s, otherwise whichever of the two measures faster (the engine's rate depends on how the process's memory
+ * happens to be laid out: 28-56 GB/s; the kernel reaches 38-40 GB/s regardless).  lt_download_stats reports the running
+ * rates (GB/s), the number of timed copies per method and the method the next copy would use; any pointer may be NULL. */
+int  lt_set_download_method(lt_ctx* ctx, int method);
+int  lt_download_stats(lt_ctx* ctx, double* engine_gbs, int* engine_copies, double* kernel_gbs, int* kernel_copies, int* method);
 /* Page-locked host memory for buffers passed to the upload / download entry points (copies from or to pageable
  * memory run at a fraction of the PCIe rate).  Needs a GPU; lt_host_free(NULL) is a no-op.  The reference has no
  * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */

@@ -135,6 +135,8 @@ _SIGNATURES = {
     "lt_stage_reset": (C.c_int, [_P]),
     "lt_stage_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]),
     "lt_stage_name": (C.c_char_p, [C.c_int]),
+    "lt_set_download_method": (C.c_int, [_P, C.c_int]),
+    "lt_download_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "lt_last_threshold_path": (C.c_int, [_P]),
     "lt_last_adaptive_path": (C.c_int, [_P]),
 }
@@ -465,6 +467,17 @@ class Context:
         if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.shape[1:] != (self.img_h, self.img_w, 3):
             raise ValueError("download_overlay_async needs a C-contiguous uint8 array (n, H, W, 3)")
         _check(self.lib.lt_download_overlay_async(self._h, first, out.shape[0], out.ctypes.data))
+
+    def set_download_method(self, method):
+        """-1: engine or kernel by measurement (default); 0: copy engine; 1: kernel."""
+        _check(self.lib.lt_set_download_method(self._h, int(method)))
+
+    def download_stats(self):
+        eg, kg = C.c_double(), C.c_double()
+        ec, kc, m = C.c_int(), C.c_int(), C.c_int()
+        _check(self.lib.lt_download_stats(self._h, C.byref(eg), C.byref(ec), C.byref(kg), C.byref(kc), C.byref(m)))
+        return {"engine_GBs": round(eg.value, 1), "engine_copies": ec.value, "kernel_GBs": round(kg.value, 1), "kernel_copies": kc.value,
+                "method": "kernel" if m.value == 1 else "engine"}
 
     def download_overlay_wait(self):
         """Block until the frames of every download_overlay_async have landed (later uploads / masks keep running)."""

@@ -135,6 +135,16 @@ struct lt_ctx {
     hipStream_t urgent = nullptr;
     bool urgent_on = false;
     StagingBusy annot_busy;           // annotated frames a copy on `dl` may still read
+    // How the annotated frames go back (lt_download_overlay_async): by the copy engine or by a kernel that stores into the
+    // page-locked destination.  Both are timed, copy by copy, with an event pair on the download stream; see choose_download().
+    struct DlTimed { hipEvent_t a, b; double bytes; int method; };
+    std::vector<DlTimed> dl_inflight;
+    std::vector<hipEvent_t> dl_event_pool;
+    double dl_rate[2] = {0.0, 0.0};   // GB/s, running mean of the last copies: [0] engine, [1] kernel
+    int dl_samples[2] = {0, 0};
+    int dl_method = 0;                // what the next copy uses
+    int dl_since_probe = 0;           // copies since the other method was last tried
+    int dl_forced = -1;               // LT_DL_KERNEL=0 / 1, lt_set_download_method: -1 = choose by measurement
     hipEvent_t rest_done = nullptr;   // end of the most recent lt_upload_frame_rest on the copy stream
     bool rest_pending = false;
     // text: glyph atlas (set once) and the per-slot lines of the current call
@@ -861,6 +871,8 @@ void lt_destroy(lt_ctx* c) {
     if (c->text_busy.done) (void)hipEventDestroy(c->text_busy.done);
     if (c->annot_busy.done) (void)hipEventDestroy(c->annot_busy.done);
     if (c->dl) (void)hipStreamDestroy(c->dl);
+    for (auto& d : c->dl_inflight) { (void)hipEventDestroy(d.a); (void)hipEventDestroy(d.b); }
+    for (auto e : c->dl_event_pool) (void)hipEventDestroy(e);
     if (c->present) (void)hipStreamDestroy(c->present);
     if (c->urgent) (void)hipStreamDestroy(c->urgent);
     if (c->rest_done) (void)hipEventDestroy(c->rest_done);
@@ -1553,6 +1565,8 @@ int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
     return download(c, c->d_annot + (size_t)first * c->frame_bytes, out, (size_t)n * c->frame_bytes);
 }
 
+static void harvest_downloads(lt_ctx* c);
+static int choose_download(lt_ctx* c);
 int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -1577,18 +1591,98 @@ int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
     if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(e, c->present ? c->present : c->stream));
     HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
-    // The copy engine by default.  Its downloads were seen in two states (tools/annot_bisect.py): beside the uploads of the copy
-    // stream (annotated 1280x720 stream 15.3 k frames/s) or taking turns with them (9.4 k) -- which one depends on what the
-    // process did with its streams before, not on anything this library controls.  LT_DL_KERNEL=1 copies with a kernel instead
-    // (k_copy_vec16, on the CUs lt_set_search_cus(>= 2) sets aside for it): always beside the uploads, but at the 38-40 GB/s a
-    // kernel's stores reach while the runtime stages pageable uploads (13.7 k always; 1920x1080: 5.8 k against 7.0-7.2 k).
-    static const bool by_kernel = std::getenv("LT_DL_KERNEL") != nullptr;
-    if (!by_kernel || !launch_copy_to_pinned(c->dl, out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes))
-        HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, (size_t)n * c->frame_bytes, hipMemcpyDeviceToHost, c->dl));
+    // engine or kernel: by measurement (choose_download); LT_DL_KERNEL=1 / 0 and lt_set_download_method pin one of them
+    static const int env_method = [] { const char* e = std::getenv("LT_DL_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    if (env_method >= 0 && c->dl_forced < 0) c->dl_forced = env_method;
+    harvest_downloads(c);
+    int method = choose_download(c);
+    auto timing_event = [&]() -> hipEvent_t {
+        hipEvent_t ev = nullptr;
+        if (!c->dl_event_pool.empty()) { ev = c->dl_event_pool.back(); c->dl_event_pool.pop_back(); }
+        else if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+        return ev;
+    };
+    hipEvent_t ta = timing_event(), tb = timing_event();
+    if (ta && tb) HIP_TRY(hipEventRecord(ta, c->dl));
+    const size_t bytes = (size_t)n * c->frame_bytes;
+    if (method == 1 && !launch_copy_to_pinned(c->dl, out, c->d_annot + (size_t)first * c->frame_bytes, bytes)) method = 0;   // not page-locked / aligned
+    if (method == 0) HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, bytes, hipMemcpyDeviceToHost, c->dl));
     HIP_TRY(hipGetLastError());
+    if (ta && tb) {
+        HIP_TRY(hipEventRecord(tb, c->dl));
+        c->dl_inflight.push_back({ta, tb, (double)bytes, method});
+    } else {
+        if (ta) c->dl_event_pool.push_back(ta);
+        if (tb) c->dl_event_pool.push_back(tb);
+    }
     if (c->annot_busy.hi <= c->annot_busy.lo) { c->annot_busy.lo = first; c->annot_busy.hi = first + n; }
     else { c->annot_busy.lo = std::min(c->annot_busy.lo, first); c->annot_busy.hi = std::max(c->annot_busy.hi, first + n); }
     return staging_mark(c->annot_busy, c->dl);
+}
+
+// Engine or kernel?  The copy engine moves the frames at 48-56 GB/s when the page-locked destination and the device buffer are
+// laid out kindly, and at 28-30 GB/s when they are not -- a property of the memory the process happened to get (allocation
+// history, the box), not of anything this library orders: tools/copy_engine_probe.py RAW=1 shows one lone download at 29 GB/s
+// on the same engine, same code path, beside nothing.  (Rounds 2-3 read the resulting 9.3 k instead of 15 k frames/s of
+// the annotated 1280x720 stream as uploads and downloads "taking turns"; they do overlap.)  A kernel storing 16 bytes per lane
+// into the same destination is not affected (an annotated 1280x720 stream does 13.3 k frames/s that way in either regime: less
+// than the engine at its best, 15 k, because the copy kernel shares the chip with the mask chain, far more than the engine at
+// its worst).  So: every copy is timed with an event pair; the engine is the default; when its running rate drops below
+// DL_SLOW GB/s the kernel takes over, and one copy in DL_REPROBE goes by the engine again so that a recovery is noticed.
+static constexpr double DL_SLOW = 36.0;
+static constexpr int DL_REPROBE = 48;
+static void harvest_downloads(lt_ctx* c) {
+    size_t keep = 0;
+    for (size_t i = 0; i < c->dl_inflight.size(); ++i) {
+        lt_ctx::DlTimed& d = c->dl_inflight[i];
+        float ms = 0.f;
+        if (hipEventQuery(d.b) == hipSuccess && hipEventElapsedTime(&ms, d.a, d.b) == hipSuccess) {
+            if (ms > 0.f && d.bytes >= 8e6) {              // small copies time the launch, not the bus
+                const double r = d.bytes / (ms * 1e-3) / 1e9;
+                c->dl_rate[d.method] = c->dl_samples[d.method] ? 0.5 * c->dl_rate[d.method] + 0.5 * r : r;
+                ++c->dl_samples[d.method];
+            }
+            c->dl_event_pool.push_back(d.a);
+            c->dl_event_pool.push_back(d.b);
+        } else {
+            (void)hipGetLastError();
+            c->dl_inflight[keep++] = d;
+        }
+    }
+    c->dl_inflight.resize(keep);
+}
+static int choose_download(lt_ctx* c) {
+    if (c->dl_forced >= 0) return c->dl_forced;
+    const int cur = c->dl_method, other = 1 - cur;
+    ++c->dl_since_probe;
+    if (c->dl_samples[cur] >= 4) {       // (the first copies of a stream are short and wait for their overlays: not a verdict)
+        const bool never = c->dl_samples[other] == 0;
+        if (cur == 0 && c->dl_rate[0] < DL_SLOW && (never || c->dl_rate[1] > c->dl_rate[0])) { c->dl_method = 1; c->dl_since_probe = 0; }
+        else if (cur == 1 && c->dl_rate[0] >= DL_SLOW) { c->dl_method = 0; c->dl_since_probe = 0; }   // the engine has recovered
+        else if (c->dl_since_probe >= DL_REPROBE && (cur == 1 || c->dl_rate[0] < DL_SLOW)) {   // one copy the other way
+            c->dl_since_probe = 0;
+            return other;
+        }
+    }
+    return c->dl_method;
+}
+
+int lt_set_download_method(lt_ctx* c, int method) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (method < -1 || method > 1) return fail(LT_ERR_INVALID, "download method: -1 = measured choice, 0 = copy engine, 1 = kernel");
+    c->dl_forced = method;
+    return LT_OK;
+}
+
+int lt_download_stats(lt_ctx* c, double* engine_gbs, int* engine_copies, double* kernel_gbs, int* kernel_copies, int* method) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    harvest_downloads(c);
+    if (engine_gbs) *engine_gbs = c->dl_rate[0];
+    if (engine_copies) *engine_copies = c->dl_samples[0];
+    if (kernel_gbs) *kernel_gbs = c->dl_rate[1];
+    if (kernel_copies) *kernel_copies = c->dl_samples[1];
+    if (method) *method = c->dl_forced >= 0 ? c->dl_forced : c->dl_method;
+    return LT_OK;
 }
 
 int lt_download_overlay_wait(lt_ctx* c) {

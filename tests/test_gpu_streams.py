@@ -174,3 +174,41 @@ def test_kernel_download_path_gives_the_same_frames():
                         "tests/test_gpu_chain.py::test_process_stream_equals_process_frame_by_frame"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_download_method_is_chosen_by_measurement_and_every_choice_gives_the_same_frames(nat, cal):
+    """lt_download_overlay_async times every copy and moves the frames by the copy engine or by a kernel, whichever the
+    measurements favour (lt_set_download_method / lt_download_stats).  The same annotated frames come back whichever way:
+    forced engine, forced kernel, and the measured choice over enough copies for it to have samples of its own."""
+    from lane_tracker_amd import synth
+    n = 24
+    frames = synth.stream_lanes(n, seed=21, cal=cal)
+    e = np.zeros(0, np.int64)
+    c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
+                    device=0, capacity=n)
+    try:
+        c.overlay_configure(cal["warp_matrices"][1])
+        c.upload_frames(frames)
+        ys = np.arange(300, 1100, dtype=np.int64)
+        poly = (ys, np.full_like(ys, 430), ys, np.full_like(ys, 640))
+        c.overlay_run([poly if i % 3 else (e, e, e, e) for i in range(n)])
+        want = c.download_overlay(n)                       # the blocking download
+        assert c.download_stats()["engine_copies"] == 0 and c.download_stats()["kernel_copies"] == 0
+        outs = {}
+        for method in (0, 1, -1):
+            c.set_download_method(method)
+            out = nat.pinned_empty(want.shape)
+            out[...] = 0
+            for rep in range(8 if method < 0 else 1):      # 8 x 3 copies of 22 MB: enough samples for the rule to look at
+                for a, b in ((0, 8), (8, 16), (16, n)):
+                    c.download_overlay_async(out[a:b], first=a)
+            c.download_overlay_wait()
+            outs[method] = out
+            assert np.array_equal(out, want), method
+        st = c.download_stats()
+        assert st["engine_copies"] >= 3 and st["kernel_copies"] >= 3, st      # both were really used and timed
+        assert st["method"] in ("engine", "kernel") and st["engine_GBs"] > 1.0 and st["kernel_GBs"] > 1.0, st
+        with pytest.raises(nat.NativeError):
+            c.set_download_method(2)
+    finally:
+        c.close()
