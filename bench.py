@@ -98,9 +98,10 @@ def _render_stream_one(args):
     return cache[scale].render(sd, lc, rc, dashed_phase=ph)[0]
 
 
-def render_streams(n_base=32):
+def render_streams(n_base=96):
     """One drifting-lane stream per camera size (1280x720, and 1920x1080 = BASELINE config 5), rendered before the GPU is
-    touched: n_base frames each; the stream leg plays them forwards and backwards (smooth at the turning points)."""
+    touched: n_base DISTINCT frames each; the stream leg plays them forwards and backwards (smooth at the turning points)
+    into separately allocated windows."""
     from concurrent.futures import ProcessPoolExecutor
     from lane_tracker_amd import synth
     jobs = [(scale,) + prm for scale in (1.0, 1.5) for prm in synth.stream_lane_params(n_base, seed=5)]
@@ -109,71 +110,99 @@ def render_streams(n_base=32):
     return {"1280x720": np.stack(got[:n_base], 0), "1920x1080": np.stack(got[n_base:], 0)}
 
 
-def stream_leg(streams, window=256, seconds=1.0):
-    """The stateful stream (BASELINE config 5) through the drop-in API: frames/s of process() frame by frame
-    (annotated frame back, as process_video.py uses it) and of process_batch() (device-chained searches), per camera size."""
-    from lane_tracker_amd import calib
+def stream_windows(base, window, count):
+    """`count` consecutive windows of the endless forwards / backwards playback of `base`, each one a separately allocated
+    pageable array whose pages this call touches for the first time (what a decoder hands over: memory the runtime has
+    never pinned or staged)."""
+    from concurrent.futures import ThreadPoolExecutor
+    period = np.concatenate([np.arange(len(base)), np.arange(len(base))[::-1]])
+
+    def one(w):
+        idx = period[(np.arange(window) + w * window) % len(period)]
+        return np.take(base, idx, axis=0)                 # a fresh array; NumPy releases the GIL while it copies
+    with ThreadPoolExecutor(min(count, max(1, usable_cpus() // 2))) as ex:
+        return list(ex.map(one, range(count)))
+
+
+def stream_leg(streams, window=256, seconds=1.0, nwin=8):
+    """The stateful stream (BASELINE config 5) through the drop-in API, host-fed: frames/s of process() frame
+    by frame (annotated frame back, as process_video.py uses it), of process_batch() (device-chained searches) and of
+    process_stream() over `nwin` DISTINCT windows -- the first pass over them (pages the runtime has never seen) and a second
+    pass, separately."""
+    from lane_tracker_amd import calib, settings
     from lane_tracker_amd.lane_tracker import LaneTracker
     out = {}
-    for name, base in streams.items():
+    order = list(streams.items())
+    if os.environ.get("LT_BENCH_STREAM_ORDER") == "reverse":      # experiment: the larger camera first
+        order = order[::-1]
+    for name, base in order:
         cal = calib.reference_calibration() if name == "1280x720" else calib.scaled_calibration(1.5)
-        frames = np.concatenate([base, base[::-1]] * (window // (2 * len(base)) + 1), 0)[:window].copy()
+        wins = stream_windows(base, window, nwin)
+        frames = wins[0]
         lt = LaneTracker(**cal)
         try:
             for f in frames[:4]:
                 lt.process(f)
             t0, k = time.perf_counter(), 0
-            while time.perf_counter() - t0 < seconds * 0.4:
+            while time.perf_counter() - t0 < seconds * 0.3:
                 lt.process(frames[4 + k % (window - 4)])
                 k += 1
-            fps_process = k / (time.perf_counter() - t0)
-            res = {"process_fps": round(fps_process, 1)}
+            res = {"process_fps": round(k / (time.perf_counter() - t0), 1)}
             for key, ann in (("process_batch_fps", False), ("process_batch_annotated_fps", True)):
                 lt.process_batch(frames, annotate=ann)
                 t0, k = time.perf_counter(), 0
-                while time.perf_counter() - t0 < seconds * 0.3 or k == 0:
-                    lt.process_batch(frames, annotate=ann)
+                while time.perf_counter() - t0 < seconds * 0.2 or k == 0:
+                    lt.process_batch(wins[1 + k % (nwin - 1)], annotate=ann)
                     k += 1
                 res[key] = round(k * window / (time.perf_counter() - t0), 1)
-            # consecutive windows of one video: process_stream keeps the device busy across window boundaries
-            list(lt.process_stream([frames, frames], annotate=False))
-            t0, k = time.perf_counter(), 0
-            while time.perf_counter() - t0 < seconds * 0.3 or k == 0:
-                list(lt.process_stream([frames] * 16, annotate=False))      # 4096 frames per stream: its head and tail are ~3 %
-                k += 16
-            res["process_stream_fps"] = round(k * window / (time.perf_counter() - t0), 1)
-            # ... and with every annotated frame rendered and copied back (what process_video.py consumes)
-            for _ in lt.process_stream([frames] * 4, annotate=True):
-                pass
-            t0, k = time.perf_counter(), 0
-            while time.perf_counter() - t0 < seconds * 0.3 or k == 0:
-                for _ in lt.process_stream([frames] * 12, annotate=True):
+
+            def stream_rate(ws, ann, tracker=lt, **kw):
+                t0 = time.perf_counter()
+                for _ in tracker.process_stream(ws, annotate=ann, **kw):
                     pass
-                k += 12
-            res["process_stream_annotated_fps"] = round(k * window / (time.perf_counter() - t0), 1)
+                return round(len(ws) * window / (time.perf_counter() - t0), 1)
+            # consecutive windows of one video: process_stream keeps the device busy across window boundaries.  Fresh copies for
+            # the first pass of each variant (the batch calls above have touched wins[...] already).
+            cold = stream_windows(base, window, nwin)
+            res["process_stream_first_pass_fps"] = stream_rate(cold, False)
+            res["process_stream_fps"] = max(stream_rate(cold + cold, False) for _ in range(2))      # 4096 frames per stream
+            cold = stream_windows(base, window, nwin)
+            # ... and with every annotated frame rendered and copied back (what process_video.py consumes)
+            res["process_stream_annotated_first_pass_fps"] = stream_rate(cold, True)
+            res["process_stream_annotated_fps"] = max(stream_rate(cold, True) for _ in range(2))
+            res["annotated_frames_came_back_by"] = lt._ctx.download_stats()
             res["success_ratio"] = round(lt.get_success_ratio()[0], 4)
             # ... and with outages: every 64th frame starts 16 frames of noise / flat grey / black (tools/outage_profile.py)
-            broken = frames.copy()
+            broken = cold[0].copy()
             for j, s0 in enumerate(range(40, window, 64)):
                 for i in range(s0, min(window, s0 + 16)):
                     broken[i] = (np.random.default_rng(4000 + i).integers(0, 256, broken[i].shape, dtype=np.uint8) if j % 3 == 0
                                  else (128 if j % 3 == 1 else 0))
             list(lt.process_stream([broken] * 2, annotate=False))
-            t0, k = time.perf_counter(), 0
-            while time.perf_counter() - t0 < seconds * 0.3 or k == 0:
-                list(lt.process_stream([broken] * 4, annotate=False))
-                k += 4
-            res["process_stream_outages_fps"] = round(k * window / (time.perf_counter() - t0), 1)
+            res["process_stream_outages_fps"] = stream_rate([broken] * 4, False)
+            if name == "1280x720":       # the author's Demo 1 settings (tracker_settings.md:1-33: the greenery mask) on the same stream
+                lt1 = LaneTracker(**cal)
+                try:
+                    kw = settings.apply(lt1, settings.DEMO_1)
+                    stream_rate(cold[:2], False, lt1, **kw)
+                    res["process_stream_demo1_fps"] = stream_rate(cold, False, lt1, **kw)
+                    res["demo1_success_ratio"] = round(lt1.get_success_ratio()[0], 4)
+                finally:
+                    lt1.close()
             out[name] = res
         finally:
             lt.close()
+        del wins, cold
     out["window"] = window
-    out["note"] = ("one stateful stream, host-fed (pageable NumPy frames in, PCIe included): process() = one frame per call, "
-                   "annotated frame returned; process_batch() = windows of %d frames, searches chained on the device "
-                   "(lt_band_fit_chain_run), check_validity / history on the host; process_stream() = the same over consecutive "
-                   "windows, the next windows' uploads and masks under the current one's searches (the *_annotated figures return every "
-                   "annotated frame: 2 x the frame bytes over the bus; *_outages: four outages of 16 frames per window, handled in speculative "
-                   "groups); success_ratio is that of the clean streams; 1920x1080 is BASELINE config 5" % window)
+    out["distinct_windows"] = nwin
+    out["note"] = ("one stateful stream, host-fed (pageable NumPy frames in, PCIe included), %d distinct rendered frames per size played "
+                   "forwards and backwards into %d separately allocated windows of %d frames: process() = one frame per call, annotated frame "
+                   "returned; process_batch() = one window per call, searches chained on the device (lt_band_fit_chain_run), check_validity / "
+                   "history on the host; process_stream() = the same over consecutive windows, the next windows' uploads and masks under the "
+                   "current one's searches; *_first_pass = the first time the runtime sees those pages, the figure beside it a later pass "
+                   "(the *_annotated figures return every annotated frame: 2 x the frame bytes over the bus; *_outages: four outages of 16 "
+                   "frames per window, handled in speculative groups; *_demo1: settings.DEMO_1, mask_noise = True); success_ratio is that of "
+                   "the clean streams; 1920x1080 is BASELINE config 5" % (len(next(iter(streams.values()))), nwin, window))
     return out
 
 
@@ -403,7 +432,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="frames per GPU per step (weak scaling, BASELINE config 3)")
     ap.add_argument("--frames", type=int, default=0,
                     help="total frames of one stream, sharded over the GPUs (strong scaling; 4096 = BASELINE config 4)")
-    ap.add_argument("--single-copy", action="store_true", help="one resident copy of the batch: consecutive steps do not overlap")
+    ap.add_argument("--single-copy", action="store_true", help="do not keep a second resident copy of the batch (no overlapped_batches figure)")
     ap.add_argument("--streams", type=int, default=4, help="HIP streams per context (slot slices overlap each other's stages)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
@@ -414,6 +443,13 @@ def main():
     if a.gpus < 1 or a.steps < 1 or a.warmup < 0:
         ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
 
+    if os.environ.get("LT_BIND_NODE") is not None:        # experiment: run (and first-touch every host buffer) on one NUMA node's CPUs
+        txt = open("/sys/devices/system/node/node%s/cpulist" % os.environ["LT_BIND_NODE"]).read().strip()
+        cpus = []
+        for part in txt.split(","):
+            lo, _, hi = part.partition("-")
+            cpus += list(range(int(lo), int(hi or lo) + 1))
+        os.sched_setaffinity(0, cpus)
     in_rank = "RANK" in os.environ
     if not in_rank and a.gpus > 1:
         sys.exit(launcher(a))
@@ -445,10 +481,10 @@ def main():
     except RuntimeError as e:
         print("bench.py: rank %d: %s" % (rank, e), file=sys.stderr)
         sys.exit(2)
-    # Two resident copies of the batch (slots [0, NL) and [NL, 2 NL)) for batches that are not a whole stream anyway: the
-    # steps alternate between them, so the tail of step k and the head of step k+1 overlap the way consecutive batches of
-    # a stream do.  Every step still runs the whole path over NL resident frames; the rate with a single copy (each step
-    # waits in order behind the previous one on the same slots) is reported beside it as single_copy_frames_per_s.
+    # `value`: every step over the SAME NL resident frames (slots [0, NL)); each step waits in order behind the previous one on
+    # its slots.  A second resident copy of the batch (slots [NL, 2 NL)) serves one extra figure outside the timed region,
+    # overlapped_batches_frames_per_s: steps alternating between the copies, so that the tail of step k and the head of step
+    # k+1 overlap the way consecutive batches of a stream do (rounds 1-3 reported that one as `value`).
     two_copies = NL <= 1024 and not a.single_copy
     ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"],
                           cal["warp_matrices"][0], device=device, capacity=2 * NL if two_copies else NL)
@@ -480,11 +516,11 @@ def main():
         gather = distributed.init_gather(ctx)
         gather.reserve(nsteps * NL)
 
-    def step(k=0, alternate=True):
+    def step(k=0, alternate=False, stage=True):
         first = NL * (k & 1) if two_copies and alternate else 0
         ctx.mask_run(NL, fp, first=first)
         ctx.sws_fit_run(NL, sp, first=first)
-        if gather is not None and alternate:
+        if gather is not None and stage:
             gather.stage(NL, at=k * NL, first=first)
 
     marks = {}
@@ -514,15 +550,16 @@ def main():
             (marks["drained"] - t0) * 1e3, (marks.get("gathered", marks["drained"]) - marks["drained"]) * 1e3,
             (marks["fenced"] - marks.get("gathered", marks["drained"])) * 1e3), file=sys.stderr)
 
-    single_copy_fps = None
-    if two_copies and not in_rank:     # the same steps on one copy of the batch (not part of the timed region)
-        step(0, False)
+    overlapped_fps = None
+    if two_copies and not in_rank:     # not part of the timed region: the same steps alternating between two resident copies of
+        for k in range(2):             # the batch, so that consecutive steps overlap the way consecutive batches of a stream do
+            step(k, True, False)
         ctx.sync()
         t1 = time.perf_counter()
         for k in range(a.steps):
-            step(k, False)
+            step(k, True, False)
         ctx.sync()
-        single_copy_fps = NL * a.steps / (time.perf_counter() - t1)
+        overlapped_fps = NL * a.steps / (time.perf_counter() - t1)
 
     # Per-kernel durations for the roofline: the same steps again on ONE stream with a hipEvent pair
     # around every kernel (with several streams the kernels of different slices overlap, so their
@@ -626,7 +663,7 @@ def main():
                        "gathered_records_checked": int(len(rec_all)) if gather is not None else 0,
                        "ranks_share_devices": bool(distributed.shares_devices()) if world > 1 else False,
                        "rank_environment": {distributed.IPC_ENV[0]: os.environ.get(distributed.IPC_ENV[0])} if world > 1 else None,
-                       "streams_per_gpu": a.streams, "resident_copies_of_the_batch": 2 if two_copies else 1,
+                       "streams_per_gpu": a.streams, "resident_copies_of_the_batch_in_the_timed_region": 1,
                        "detected_fraction": round(float(np.mean(rec_all["detected"])), 4)},
             "roofline": {"bound": "hbm", "kernel": "warp+threshold stage (%d kernels: %s)" % (len(MASK_STAGES), ",".join(MASK_STAGES)),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -640,14 +677,13 @@ def main():
                                  "rocprofv3 run named in profile.from_profile (null when the launch shape differs). The stage is "
                                  "integer-VALU / LDS bound, not HBM bound; see DESIGN.md"},
             "kernels_ms_per_step": {k: round(v[0] / KS, 4) for k, v in stages.items() if v[1]},
-            "timing_note": "value / ms_per_step: %d steps on %d HIP streams per GPU (slot slices overlap: the latency-bound "
-                           "search of one slice hides under the mask chain of another)%s. kernels_ms_per_step, roofline and "
+            "timing_note": "value / ms_per_step: %d steps over the same resident frames on %d HIP streams per GPU (slot slices overlap: the "
+                           "latency-bound search of one slice hides under the mask chain of another)%s. kernels_ms_per_step, roofline and "
                            "search_fit: %d further steps on one stream with hipEvents around every kernel; their sum (%.3f ms) "
                            "is the un-overlapped step" % (a.steps, a.streams,
-                                                          ", alternating between two resident copies of the batch (consecutive steps overlap "
-                                                          "like consecutive batches of a stream; single_copy_frames_per_s: every step on the same slots)"
-                                                          if two_copies else "", KS, mask_ms + search_ms),
-            "single_copy_frames_per_s": round(single_copy_fps, 2) if single_copy_fps else None,
+                                                          "; overlapped_batches_frames_per_s: the same steps alternating between two resident copies "
+                                                          "of the batch (what rounds 1-3 reported as value)" if overlapped_fps else "", KS, mask_ms + search_ms),
+            "overlapped_batches_frames_per_s": round(overlapped_fps, 2) if overlapped_fps else None,
             "search_fit": {"ms_per_step": round(search_ms, 4),
                            "achieved_GBs": round(info.alg_bytes_search * NL / (search_ms * 1e-3) / 1e9, 3) if search_ms > 0 else None},
             "host_fed": {"h2d_seconds_whole_frames": round(h2d_s, 4),

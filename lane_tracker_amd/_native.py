@@ -555,12 +555,17 @@ class Context:
         import contextlib
 
         @contextlib.contextmanager
-        def scope():
-            _check(self.lib.lt_set_urgent(self._h, 1))
+        def scope():                     # re-entrant: the mode ends with the outermost scope
+            depth = getattr(self, "_urgent_depth", 0)
+            if depth == 0:
+                _check(self.lib.lt_set_urgent(self._h, 1))
+            self._urgent_depth = depth + 1
             try:
                 yield self
             finally:
-                _check(self.lib.lt_set_urgent(self._h, 0))
+                self._urgent_depth -= 1
+                if self._urgent_depth == 0:
+                    _check(self.lib.lt_set_urgent(self._h, 0))
         return scope()
 
     def band_fit_chain_cancel(self):

@@ -11,6 +11,8 @@ What runs where
 There is no CPU implementation of the hot path in this package: without the shared library and a
 GPU, constructing a LaneTracker raises.
 """
+import contextlib
+
 import numpy as np
 
 from . import _native
@@ -182,8 +184,14 @@ class LaneTracker:
         if self._pending is not None:
             ctx, slot = self._pending
             self._pending = None
-            self._lp['left_y'], self._lp['left_x'] = ctx.download_pixels(slot, 0)
-            self._lp['right_y'], self._lp['right_x'] = ctx.download_pixels(slot, 1)
+            # The search that wrote these lists is complete (the host has seen its record), so the copy need not wait for
+            # anything: in urgent mode a download waits for its own stream only -- outside it, for every stream of the context,
+            # i.e. for all the uploads and masks queued ahead in a stream (7 ms per call there; get_curve_radius asks for the
+            # lists when a radius lies within 1e-8 of an integer, which near-straight lanes do for frames on end).
+            scope = ctx.urgent() if hasattr(ctx, "urgent") else contextlib.nullcontext()
+            with scope:
+                self._lp['left_y'], self._lp['left_x'] = ctx.download_pixels(slot, 0)
+                self._lp['right_y'], self._lp['right_x'] = ctx.download_pixels(slot, 1)
             if self._fit is not None and isinstance(self._fit[0], str):
                 self._fit = (self._lp['left_y'], self._lp['right_y'], self._fit[2], self._fit[3])
 

@@ -58,15 +58,44 @@ def child(mode):
     if "A" in pre:          # a short annotated stream, then a pause
         for _ in lt.process_stream([frames[:64]] * 2, annotate=True):
             pass
-    for _ in lt.process_stream([frames] * 4, annotate=True):
+    wins = [frames] * 8
+    if os.environ.get("LIKE_BENCH"):              # bench.py's stream windows: N distinct rendered frames, separately allocated windows
+        import bench
+        nb = int(os.environ["LIKE_BENCH"])
+        prm = synth.stream_lane_params(nb, seed=5)
+        r = synth.SceneRenderer(cal)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(16) as ex:
+            base2 = np.stack(list(ex.map(lambda q: r.render(q[0], q[1], q[2], dashed_phase=q[3])[0], prm)), 0)
+        wins = bench.stream_windows(base2, n, 8)
+    if os.environ.get("DISTINCT") == "1":         # eight separately allocated windows (same content): nothing the runtime has pinned before
+        wins = [frames.copy() for _ in range(8)]
+    if os.environ.get("REGISTER") == "1":         # ... page-locked once by the caller instead of chunk by chunk inside every copy
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        t0 = time.perf_counter()
+        for w in wins:
+            assert hip.hipHostRegister(ctypes.c_void_p(w.ctypes.data), ctypes.c_size_t(w.nbytes), 0) == 0
+        print("registered %d windows in %.1f ms" % (len(wins), (time.perf_counter() - t0) * 1e3), flush=True)
+    for _ in lt.process_stream(wins[:4], annotate=True):
         pass
     if os.environ.get("RAW") != "1":
         print("MARK measured-part", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
-    for _ in lt.process_stream([frames] * 8, annotate=True):
+    for _ in lt.process_stream(wins, annotate=True):
         pass
     dt = time.perf_counter() - t0
     print("MARK end", file=sys.stderr, flush=True)
+    if os.environ.get("HOSTPROF") == "1":
+        import cProfile, io, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in lt.process_stream(wins, annotate=True):
+            pass
+        pr.disable()
+        st = io.StringIO()
+        pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(14)
+        print(st.getvalue()[:3500], flush=True)
     print("RESULT %s: %.0f frames/s annotated stream  %s" % (mode, 8 * n / dt, lt._ctx.download_stats()), flush=True)
     if os.environ.get("RAW") == "1":              # the two copies by themselves and side by side, on the tracker's own buffers
         from lane_tracker_amd import _native
