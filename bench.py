@@ -132,10 +132,7 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
     from lane_tracker_amd import calib, settings
     from lane_tracker_amd.lane_tracker import LaneTracker
     out = {}
-    order = list(streams.items())
-    if os.environ.get("LT_BENCH_STREAM_ORDER") == "reverse":      # experiment: the larger camera first
-        order = order[::-1]
-    for name, base in order:
+    for name, base in streams.items():
         cal = calib.reference_calibration() if name == "1280x720" else calib.scaled_calibration(1.5)
         wins = stream_windows(base, window, nwin)
         frames = wins[0]
@@ -443,13 +440,6 @@ def main():
     if a.gpus < 1 or a.steps < 1 or a.warmup < 0:
         ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
 
-    if os.environ.get("LT_BIND_NODE") is not None:        # experiment: run (and first-touch every host buffer) on one NUMA node's CPUs
-        txt = open("/sys/devices/system/node/node%s/cpulist" % os.environ["LT_BIND_NODE"]).read().strip()
-        cpus = []
-        for part in txt.split(","):
-            lo, _, hi = part.partition("-")
-            cpus += list(range(int(lo), int(hi or lo) + 1))
-        os.sched_setaffinity(0, cpus)
     in_rank = "RANK" in os.environ
     if not in_rank and a.gpus > 1:
         sys.exit(launcher(a))
