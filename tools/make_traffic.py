@@ -6,7 +6,7 @@ root, out = sys.argv[1], sys.argv[2]
 frames = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
 MASK = ("k_undistort_rows", "k_warp_split", "k_morph_runs", "k_bilateral_tile", "k_bilateral_walk", "k_or4_bits", "k_pack_merge",
-        "k_erode5_bits", "k_dilate5_mask", "k_dilate5_bits", "k_adaptive_mean", "k_morph_ellipse", "k_merge")
+        "k_erode5_bits", "k_dilate5_mask", "k_dilate5_bits", "k_adaptive_mean", "k_adaptive_box_walk", "k_morph_ellipse", "k_merge")
 # FETCH_SIZE reads 1/2 of the bytes of every coalesced, aligned load width (1, 2, 4, 8, 16 bytes per lane); WRITE_SIZE is exact
 # (profiles/r02_fetch_calib.json, measured with tools/microbench/fetch_calib.hip on 1 GiB buffers).  Every kernel of the chain
 # loads aligned pieces since round 2 (the remap kernels' unaligned 8-byte taps, factor 1.714, are gone), so the factor is 2.0
@@ -23,7 +23,8 @@ PLANE, PITCHED, BITS, UND, CAM = 1100 * 1080, 1100 * 1088, 149600, 238 * 1280 * 
 COMPULSORY = {"k_undistort_rows": (CAM, UND), "k_warp_split4": (UND, 2 * PLANE),
               "k_morph_runs2<SE29, false": (PLANE, PLANE), "k_morph_runs2<SE29, true": (2 * PLANE, PITCHED),
               "k_morph_runs2<SE55, false": (PLANE, PLANE), "k_morph_runs2<SE55, true": (2 * PLANE, PITCHED),
-              "k_bilateral_walk_hv": (PITCHED, 2 * BITS), "k_merge_open5": (4 * BITS, 2 * BITS)}
+              "k_bilateral_walk_hv": (PITCHED, 2 * BITS), "k_adaptive_box_walk": (2 * PLANE, 2 * BITS),
+              "k_merge_open5<6": (6 * BITS, 2 * BITS), "k_merge_open5<2": (2 * BITS, 2 * BITS), "k_merge_open5": (4 * BITS, 2 * BITS)}
 def compulsory(kernel):
     for k, v in COMPULSORY.items():
         if kernel.startswith(k):
