@@ -21,3 +21,12 @@ x0, x1 = 462, 849
 for tag, (y0, y1) in (("original", (27, 245)), ("rgb_r", (285, 503)), ("lab_b", (1318, 1535))):
     Image.fromarray(a[y0:y1, x0:x1]).save(os.path.join(OUT, "color_channels10_test4_%s_panel.png" % tag), optimize=True)
 print(sorted(os.listdir(OUT)))
+
+# the demo-3 pair (README.md:142-148): search_lane_result01.png = the annotated camera frame of the first frame of the third
+# demo video, drawn at 0.70x (image area 894 x 503 at (33, 11)); search_lane_vis01.png = its bird's-eye mask with the search
+# drawn over it (image area 855 x 871 at (40, 10)).  Stored as cut: the pixels inside the axes.
+a = np.asarray(Image.open(os.path.join(REF, "search_lane_result01.png")).convert("RGB"))[11:514, 33:927]
+Image.fromarray(a).save(os.path.join(OUT, "search_lane_result01_axes.png"), optimize=True)
+a = np.asarray(Image.open(os.path.join(REF, "search_lane_vis01.png")).convert("RGB"))[10:881, 40:895]
+Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=16).save(os.path.join(OUT, "search_lane_vis01_axes.png"), optimize=True)
+print(sorted(os.listdir(OUT)))

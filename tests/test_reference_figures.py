@@ -150,3 +150,63 @@ def test_lab_b_plane_correlates_with_the_authors_lab_b_panel():
     got = {"lab_b": corr(O.lab_b(src)), "r": corr(src[:, :, 0]), "g": corr(src[:, :, 1]), "b": corr(src[:, :, 2])}
     print("\ncorrelation with the author's LAB B-Channel panel:", {k: round(v, 3) for k, v in got.items()})
     assert got["lab_b"] > 0.95 and max(got["r"], got["g"], got["b"]) < 0.0
+
+
+def test_demo3_mask_bounds_the_greenery_mask_the_open_and_the_filter_type(oc):
+    """The one published figure pair that went through the WHOLE `filter_lane_points` with real OpenCV -- top-hats, bilateral
+    thresholds, greenery mask (Demo 3 settings, tracker_settings.md:74-111), open: `search_lane_result01.png` (the annotated
+    camera frame, drawn at 0.70x) and `search_lane_vis01.png` (its bird's-eye mask under the search visualisation).  The
+    camera frame is recovered from the figure -- resampled back to 1280 x 720, the lane polygon's addWeighted(.., 0.3) taken
+    out of the green channel -- and sent through the oracle; the mask is compared with the figure's white / red / blue
+    pixels at figure resolution.
+
+    What this bounds (IoU, figure resolution): the greenery mask (0.53 with, 0.29 without), the 5x5 open (0.43 without),
+    the filter type (second-try set 0.23).  What it does NOT resolve: the top-hats.  With them 0.528, without 0.504, and the
+    structuring-element sizes 25..33 / 51..59 all give 0.526-0.529 -- a frame that has been through a 0.70x resampling and back
+    has lost the contrast detail the top-hats act on.  So a3.2 stays without an OpenCV pixel; this is a bound on a3.5-a3.7,
+    not a pin of anything."""
+    from scipy import ndimage as ndi
+    from lane_tracker_amd import settings
+    crop = _rgb(os.path.join(FIG, "search_lane_result01_axes.png"))
+    frame = np.asarray(PIL.fromarray(crop).resize((1280, 720), PIL.BICUBIC)).astype(np.int32)
+    R, G = frame[..., 0], frame[..., 1]
+    poly = G - R > 38                                    # grey asphalt, yellow and white paint all have G - R near 0 outside the polygon
+    poly[:430] = False
+    poly = ndi.binary_fill_holes(ndi.binary_closing(ndi.binary_opening(poly, iterations=2), iterations=6))
+    lab, nl = ndi.label(poly)
+    poly = lab == (1 + int(np.argmax(ndi.sum(poly, lab, range(1, nl + 1)))))
+    assert 90000 < poly.sum() < 130000                   # the lane polygon of the figure
+    frame[..., 1] = np.where(poly, np.clip(G - 76, 0, 255), G)
+    bev = O.front_end(oc, frame.astype(np.uint8))
+    ax = _rgb(os.path.join(FIG, "search_lane_vis01_axes.png")).astype(np.int32)
+    near = lambda c: np.abs(ax - np.array(c)).sum(-1) < 90
+    want = near((255, 255, 255)) | near((255, 0, 0)) | near((0, 0, 255))        # mask pixels: plain, found left, found right
+    visible = ~near((255, 255, 0))                                              # (the fitted curves are drawn over the mask)
+
+    def iou(mask):
+        got = np.asarray(PIL.fromarray(mask).resize((ax.shape[1], ax.shape[0]), PIL.BOX)) > 127
+        return float((got & want & visible).sum()) / float(((got | want) & visible).sum())
+    P = settings.DEMO_3["process"]
+    kw = dict(ksize_r=P["ksize_r"], C_r=P["C_r"], ksize_b=P["ksize_b"], C_b=P["C_b"], mask_noise=True, noise_thresh=P["noise_thresh"],
+              ksize_noise=P["ksize_noise"], C_noise=P["C_noise"])
+    Rp, bp = np.ascontiguousarray(bev[..., 0]), O.lab_b(bev)
+
+    def chain(kR, kB, open5=True):                        # filter_lane_points with other (or no) top-hats
+        thR, thB = (O.tophat(Rp, kR) if kR else Rp), (O.tophat(bp, kB) if kB else bp)
+        m = (O.bilateral_adaptive_threshold(thR, 15, 8) > 0) | (O.bilateral_adaptive_threshold(thB, 35, 5) > 0)
+        m &= (~(bp >= 140)) | (O.bilateral_adaptive_threshold(bp, 65, 10) > 0)
+        m = (m * 255).astype(np.uint8)
+        return O.morph_open(m, 5) if open5 else m
+    full = O.filter_lane_points(bev, O.filter_params(**kw))
+    assert np.array_equal(chain(29, 55), full)
+    s_full = iou(full)
+    s_no_noise = iou(O.filter_lane_points(bev, O.filter_params(**dict(kw, mask_noise=False))))
+    s_try2 = iou(O.filter_lane_points(bev, O.filter_params(filter_type="neighborhood", ksize_r=15, C_r=5, ksize_b=35, C_b=5)))
+    s_no_open = iou(chain(29, 55, open5=False))
+    s_no_tophat = iou(chain(0, 0))
+    sweep = {k: round(iou(chain(*k)), 3) for k in ((27, 55), (31, 55), (29, 53), (29, 57))}
+    print("\ndemo-3 mask vs the author's figure: IoU %.3f; without the greenery mask %.3f, without the open %.3f, second-try filter %.3f; "
+          "without the top-hats %.3f, SE sizes +-2: %s -- the top-hats are not resolved by this figure" % (s_full, s_no_noise, s_no_open, s_try2, s_no_tophat, sweep))
+    assert s_full > 0.45
+    assert s_no_noise < s_full - 0.15 and s_try2 < s_full - 0.2 and s_no_open < s_full - 0.05
+    assert abs(s_no_tophat - s_full) < 0.06               # documented: this comparison cannot tell (keep the claim honest)
