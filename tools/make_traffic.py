@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh.
+"""profiles/<tag>_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of tools/prof_round.sh.
 usage: tools/make_traffic.py gpurun_out/<pmc dir> profiles/r03_traffic.json [frames_per_launch] [commit]"""
 import collections, csv, glob, json, re, sys
 root, out = sys.argv[1], sys.argv[2]
@@ -54,7 +54,7 @@ for k, v in acc.items():
 fetch = sum(v["fetch_bytes"] for k, v in per.items() if k.startswith(MASK))
 write = sum(v["write_bytes"] for k, v in per.items() if k.startswith(MASK))
 valu = sum(v["valu_wave_insts"] for k, v in per.items() if k.startswith(MASK))
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_pmc.sh); bench.py --steps 1 --warmup 1 "
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_round.sh); bench.py --steps 1 --warmup 1 "
                      "--streams 1 (mean per dispatch), %d frames per launch" % frames,
            "commit": commit,
            "calibration": "FETCH_SIZE x 2.0, WRITE_SIZE x 1.0: factors measured per access pattern on 1 GiB buffers, "

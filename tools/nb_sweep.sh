@@ -1,9 +1,11 @@
 #!/bin/bash
-# sweep the band count of each top-hat kernel (single stream, 256 frames); prints kernel ms per setting
-for k in 29E 29D 55E 55D; do
-  for nb in 2 3 4 5 6 7 8 10; do
-    r=$(env LT_MORPH_NB_$k=$nb timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 | python -c "
-import sys,json; d=json.loads(sys.stdin.read())['kernels_ms_per_step']; print(d['erode_r29'], d['tophat_r29'], d['erode_b55'], d['tophat_b55'])")
-    echo "$k nb=$nb : $r"
-  done
+# Band-count sweep of the top-hat launches on the bench shape (GPU box, repo root): kernel ms per band count.
+# usage: tools/nb_sweep.sh [kernels: 29E 29D 55E 55D ...]   (default: all four together)
+ks=${*:-"29E 29D 55E 55D"}
+for nb in 2 3 4 5 6 8 10; do
+  env=""
+  for k in $ks; do env="$env LT_MORPH_NB_$k=$nb"; done
+  r=$(env $env timeout 120 python3 bench.py --only-settings --streams 1 | python3 -c "
+import sys, json; d = json.load(sys.stdin)['process_defaults']['kernels_ms']; print(d['erode_r29'], d['tophat_r29'], d['erode_b55'], d['tophat_b55'])")
+  echo "bands=$nb ($ks): $r"
 done

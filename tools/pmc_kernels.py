@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel means of every counter found under a tools/prof_pmc.sh output directory.
+"""Per-kernel means of every counter found under a tools/prof_round.sh output directory.
 usage: tools/pmc_kernels.py gpurun_out/<dir> [substring ...]   (kernels whose name contains any substring; default all)"""
 import collections, csv, glob, re, sys
 root, subs = sys.argv[1], sys.argv[2:]
