@@ -40,6 +40,15 @@ def random_filter():
               ksize_b=odd(3, 70) if ft == "neighborhood" else int(rng.integers(1, 80)), C_b=int(rng.integers(0, 25)),
               mask_noise=bool(rng.random() < 0.4), noise_thresh=int(rng.integers(100, 180)), ksize_noise=int(rng.integers(1, 120)),
               C_noise=int(rng.integers(0, 25)))
+    if rng.random() < 0.5:       # the parameter classes the batch-size kernels take (with LT_WALK_MIN_FRAMES=0 also for these two frames)
+        if ft == "bilateral":
+            kw.update(ksize_r=int(rng.choice([15, 20, 35])), ksize_b=int(rng.choice([15, 20, 35])))
+            if kw["mask_noise"]:
+                kw.update(ksize_noise=65, noise_thresh=int(rng.choice([0, 100, 128, 140, 200, 255, 256, 300])),
+                          C_noise=int(rng.choice([0, 10, 40, 249])))
+        else:
+            kw.update(mask_noise=False, C_r=int(rng.integers(-30, 60)), C_b=int(rng.integers(-30, 60)),
+                      ksize_r=odd(1, 64), ksize_b=odd(1, 64))
     return kw
 
 
