@@ -1,3 +1,4 @@
-for st in 1 2 3 4 5; do for rep in 1 2; do
-v=$(timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --streams $st | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"); echo "streams=$st : $v"; done; done
-for f in 4 8 16 32; do v=$(LT_FRONTEND_FPB=$f timeout 120 python bench.py --steps 10 --warmup 3 --no-cpu-baseline | python -c "import sys,json; print(json.loads(sys.stdin.read())['value'])"); echo "fpb_cap=$f : $v"; done
+for S in 3 4 5 6 8; do python bench.py --streams $S --steps 20 --no-cpu-baseline --no-host-fed --no-stream --no-settings 2>/dev/null | python -c "
+import json,sys
+d=json.load(sys.stdin); print('streams', d['config']['streams_per_gpu'], d['value'], d['overlapped_batches_frames_per_s'], d['ms_per_step'])
+"; done
