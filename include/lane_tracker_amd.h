@@ -278,6 +278,12 @@ int  lt_download_stats(lt_ctx* ctx, double* engine_gbs, int* engine_copies, doub
  * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */
 int  lt_host_alloc(size_t bytes, void** out);
 int  lt_host_free(void* p);
+/* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact
+ * size, and reused by later allocations; it returns to the driver when more than LT_DEVICE_CACHE_GB (default: an eighth of the
+ * device memory, at most 32 GB) would be kept, and here: everything beyond keep_bytes now.  Why: memory handed back to the
+ * driver is wiped in the background on an SDMA engine, and for that time the process's device-to-host copies run at half
+ * speed (csrc/lt_api.cpp, DevCache). */
+int  lt_device_cache_trim(size_t keep_bytes);
 /* the bird's-eye RGB image of the slots' frames (lane_tracker.py:834, :1035): n * warp_h * warp_w * 3;
  * needs lt_mask_run on those slots first (it reuses their undistorted rows) */
 int  lt_download_bev(lt_ctx* ctx, int first_slot, int n, uint8_t* out);

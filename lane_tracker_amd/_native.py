@@ -135,6 +135,7 @@ _SIGNATURES = {
     "lt_stage_reset": (C.c_int, [_P]),
     "lt_stage_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]),
     "lt_stage_name": (C.c_char_p, [C.c_int]),
+    "lt_device_cache_trim": (C.c_int, [C.c_size_t]),
     "lt_set_download_method": (C.c_int, [_P, C.c_int]),
     "lt_download_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "lt_last_threshold_path": (C.c_int, [_P]),
@@ -222,6 +223,11 @@ class _PinnedPool:
 
 
 _pinned = _PinnedPool()
+
+
+def device_cache_trim(keep_bytes=0):
+    """Hand the device memory closed contexts left in the library's cache back to the driver (all of it beyond keep_bytes)."""
+    _check(load().lt_device_cache_trim(int(keep_bytes)))
 
 
 def pinned_empty(shape, dtype=np.uint8):

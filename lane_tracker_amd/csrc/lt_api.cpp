@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -203,16 +205,88 @@ struct lt_ctx {
 
 namespace {
 
+// Device memory goes through a small cache instead of straight back to the driver.  Memory handed back with hipFree is wiped by
+// the kernel driver in the background, on an SDMA engine -- and while that runs, the copy engine's device-to-host copies of
+// THIS process drop from 50-56 to 28-30 GB/s (tools/copy_engine_probe.py: one lone 350 MB download takes 12.7 ms instead of
+// 6.3 for the first third of a second after a 5 GB context is destroyed; a context growing twice -- freeing its 256- and
+// 768-slot buffers -- does the same to the annotated stream that follows: 9.3 k instead of 15 k frames/s; uploads are not
+// affected).  That is what rounds 2-3 described as "two states of the copy engine".  So freed blocks are kept, per device
+// and exact size, and handed out again (a tracker closed and another of the same shape opened, a context growing back to a
+// size it had); they go back to the driver only when more than LT_DEVICE_CACHE_GB (default: an eighth of the device's memory,
+// at most 32 GB) would be kept, largest first, or at lt_device_cache_trim / process exit.
+struct DevCache {
+    std::mutex m;
+    std::multimap<std::pair<int, size_t>, void*> blocks;       // (device, bytes) -> free block
+    std::map<void*, std::pair<int, size_t>> live;              // blocks handed out: their device and size
+    size_t kept = 0;
+    long long cap = -1;                                        // bytes; -1: not decided yet
+};
+static DevCache& dev_cache() { static DevCache* c = new DevCache; return *c; }   // (never destroyed: no order problems at exit)
+
+static void* cached_alloc(size_t bytes) {
+    DevCache& dc = dev_cache();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> g(dc.m);
+        auto it = dc.blocks.find({dev, bytes});
+        if (it != dc.blocks.end()) {
+            void* p = it->second;
+            dc.blocks.erase(it);
+            dc.kept -= bytes;
+            dc.live[p] = {dev, bytes};
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {                  // make room: everything kept goes back, then once more
+        (void)hipGetLastError();
+        (void)lt_device_cache_trim(0);
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    std::lock_guard<std::mutex> g(dc.m);
+    dc.live[p] = {dev, bytes};
+    return p;
+}
+static void cached_free(void* p) {
+    DevCache& dc = dev_cache();
+    std::unique_lock<std::mutex> g(dc.m);
+    auto it = dc.live.find(p);
+    if (it == dc.live.end()) { g.unlock(); (void)hipFree(p); return; }
+    const std::pair<int, size_t> key = it->second;
+    dc.live.erase(it);
+    if (dc.cap < 0) {
+        size_t free_b = 0, total_b = 0;
+        const char* e = std::getenv("LT_DEVICE_CACHE_GB");
+        if (e) dc.cap = (long long)(std::atof(e) * 1e9);
+        else dc.cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? (long long)std::min<size_t>(total_b / 8, (size_t)32 << 30) : 0;
+    }
+    if ((long long)key.second > dc.cap) { g.unlock(); (void)hipFree(p); return; }
+    dc.blocks.insert({key, p});
+    dc.kept += key.second;
+    std::vector<void*> out;
+    while ((long long)dc.kept > dc.cap && !dc.blocks.empty()) {       // over the cap: the largest blocks go back to the driver
+        auto big = dc.blocks.begin();
+        for (auto j = dc.blocks.begin(); j != dc.blocks.end(); ++j)
+            if (j->first.second > big->first.second) big = j;
+        dc.kept -= big->first.second;
+        out.push_back(big->second);
+        dc.blocks.erase(big);
+    }
+    g.unlock();
+    for (void* q : out) (void)hipFree(q);
+}
+
 template <class T>
 int dev_alloc(T** p, size_t count) {
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
-    if (e != hipSuccess) return fail(LT_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    *p = static_cast<T*>(cached_alloc(count * sizeof(T)));
+    if (!*p) return fail(LT_ERR_NOMEM, "hipMalloc(%zu bytes) failed", count * sizeof(T));
     return LT_OK;
 }
 template <class T>
 void dev_free(T*& p) {
-    if (p) (void)hipFree(p);
+    if (p) cached_free(p);
     p = nullptr;
 }
 
@@ -1546,6 +1620,22 @@ int lt_host_alloc(size_t bytes, void** out) {
         *out = nullptr;
         return fail(LT_ERR_HIP, "hipHostMalloc(%zu) failed", bytes);
     }
+    return LT_OK;
+}
+
+int lt_device_cache_trim(size_t keep_bytes) {
+    DevCache& dc = dev_cache();
+    std::vector<void*> out;
+    {
+        std::lock_guard<std::mutex> g(dc.m);
+        while (dc.kept > keep_bytes && !dc.blocks.empty()) {
+            auto it = dc.blocks.begin();
+            dc.kept -= it->first.second;
+            out.push_back(it->second);
+            dc.blocks.erase(it);
+        }
+    }
+    for (void* q : out) (void)hipFree(q);
     return LT_OK;
 }
 

@@ -110,6 +110,14 @@ def child(mode):
                 fn()
             ctx.sync(); ctx.download_overlay_wait()
             return (time.perf_counter() - t0) / reps * 1e3
+        if os.environ.get("PREHEAT"):                 # do many small copies into a new destination make it a fast one?
+            k = int(os.environ["PREHEAT"])
+            first = up.nbytes / 1e6 / t(lambda: ctx.download_overlay_async(out, first=512), reps=1)
+            for i in range(k):
+                ctx.download_overlay_async(out[i % 128:i % 128 + 1], first=512 + i % 128)
+            ctx.download_overlay_wait()
+            after = up.nbytes / 1e6 / t(lambda: ctx.download_overlay_async(out, first=512), reps=2)
+            print("PREHEAT %s: first big copies %.1f GB/s, after %d one-frame copies %.1f GB/s" % (mode, first, k, after), flush=True)
         h2d = t(lambda: (ctx.upload_frame_rows_async(up, first=0), ctx.upload_frame_rest(up, first=0)))
         print("MARK measured-part", file=sys.stderr, flush=True)
         d2h = t(lambda: ctx.download_overlay_async(out, first=512))
@@ -140,6 +148,10 @@ def child(mode):
             grid.append(name + ": " + " ".join("%d:%.1f" % (sl, up.nbytes / 1e6 / t(lambda: ctx.download_overlay_async(hb, first=sl), reps=3))
                                                for sl in range(0, min(ctx.capacity, 1024) - 127, 128)))
         print("RAW3 %s: GB/s by first slot -- %s" % (mode, " | ".join(grid)), flush=True)
+        if os.environ.get("SCAN") == "1":             # rate against the source slot and the destination offset, 64 frames per copy
+            rs = ["%d:%.0f" % (sl, 64 * up[0].nbytes / 1e6 / t(lambda: ctx.download_overlay_async(out[:64], first=sl), reps=2)) for sl in range(0, 960, 37)]
+            rd = ["%d:%.0f" % (k, 64 * up[0].nbytes / 1e6 / t(lambda: ctx.download_overlay_async(out[k:k + 64], first=300), reps=2)) for k in range(0, 64, 5)]
+            print("SCAN %s: by source slot %s | by destination frame offset %s" % (mode, " ".join(rs), " ".join(rd)), flush=True)
         # user pages (a NumPy allocation: anonymous mmap, transparent huge pages where the kernel grants them), registered with the
         # runtime, against hipHostMalloc'ed blocks allocated at the same moment
         import ctypes
