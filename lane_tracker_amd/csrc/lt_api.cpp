@@ -249,6 +249,10 @@ static void* cached_alloc(size_t bytes) {
     return p;
 }
 static void cached_free(void* p) {
+    // hipFree waits for the device before it releases anything, and callers have always relied on that (a block freed while
+    // another of the context's streams still works on it); a cached block can be handed out again at once, so the same wait
+    // happens here.
+    (void)hipDeviceSynchronize();
     DevCache& dc = dev_cache();
     std::unique_lock<std::mutex> g(dc.m);
     auto it = dc.live.find(p);
@@ -924,7 +928,11 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
 void lt_destroy(lt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    // Everything this context has in flight ends here, on EVERY stream it owns: its device memory goes back to the cache below
+    // (dev_free), not through hipFree -- which used to wait for the whole device -- and the next context may be handed the very
+    // same blocks at once (a cancelled chain still runs one more frame; copies may be queued on the download stream).
     for (auto st : c->streams) if (st) (void)hipStreamSynchronize(st);
+    for (hipStream_t st : {c->copy, c->side, c->search, c->present, c->urgent, c->dl}) if (st) (void)hipStreamSynchronize(st);
     free_slots(c);
     dev_free(c->d_uxy);
     dev_free(c->d_wxy);
