@@ -523,6 +523,49 @@ class LaneTracker:
         self.get_curve_radius()
         self.get_eccentricity()
 
+    def _commit_valid_run(self, LF, RF, g, skip, annotate, partial, deferred, commit):
+        """Frames skip .. g-1 of a run of valid first tries (raw fits LF, RF; `commit(j)` = what `_step` does for frame j on
+        success).  With annotation every frame leaves a picture: the first n_average - 1 frames (their averages reach back before
+        the run) and the last one (it leaves the state) go the ordinary way, the ones between all at once (`_record_successes`)
+        -- except around a frame whose radius needs the scalar route's care (a near-straight lane, `_delicate_radii`): that
+        frame and the n_average - 1 behind it (their averaging windows contain it) go the ordinary way, the stretches between
+        such frames all at once."""
+        j, k_avg = skip, int(self.n_average)
+        if annotate and k_avg >= 1 and g >= 2 * k_avg + 4:
+            for j in range(k_avg - 1):
+                commit(j)
+            plain = ~self._delicate_radii(LF[:g], RF[:g])
+            clean = plain.copy()                       # clean[f]: no delicate frame in f's averaging window [f - k + 1, f]
+            for t in range(1, k_avg):
+                clean[t:] &= plain[:-t]
+            j = k_avg - 1
+            while j < g - 1:
+                if clean[j]:
+                    e = j
+                    while e < g - 1 and clean[e]:
+                        e += 1
+                    if e - j >= 4 and self._record_successes(LF[:g], RF[:g], j, e, partial, deferred):
+                        j = e
+                        continue
+                commit(j)
+                j += 1
+        for j in range(j, g):
+            commit(j)
+
+    def _delicate_radii(self, LF, RF):
+        """Per frame: does `get_curve_radius` need the scalar route for this pair of raw fits -- a radius that is not finite,
+        huge, or within 2e-8 (relative) of an integer, where only the exact refit on the lane pixels decides what `int()`
+        gives upstream?  (Every radius above 2.5e7 m qualifies: near-straight lanes.)"""
+        LF, RF = np.asarray(LF, np.float64).reshape(-1, 3), np.asarray(RF, np.float64).reshape(-1, 3)
+        y_eval = self.warped_size[1]
+        bad = np.zeros(len(LF), bool)
+        for Cf in (LF, RF):
+            a_m, b_m = Cf[:, 0] * self.mpph / (self.mppv ** 2), Cf[:, 1] * self.mpph / self.mppv
+            with np.errstate(all="ignore"):
+                v = ((1 + (2 * a_m * y_eval * self.mppv + b_m) ** 2) ** 1.5) / np.absolute(2 * a_m)
+                bad |= ~np.isfinite(v) | (v >= 2.0 ** 50) | (np.abs(v - np.rint(v)) <= 2e-8 * np.maximum(1.0, np.abs(v)))
+        return bad
+
     def _record_successes(self, LF, RF, lo, hi, partial, deferred):
         """`_record_success` + the deferred picture for the frames lo .. hi-1 of a run of valid first tries (raw fits LF, RF,
         frames 0 .. lo-1 of the run already recorded; lo >= n_average - 1, so every average stays inside the run), all at
@@ -540,10 +583,12 @@ class LaneTracker:
             with np.errstate(all="ignore"):
                 return ((1 + (2 * a_m * y_eval * self.mppv + b_m) ** 2) ** 1.5) / np.absolute(2 * a_m)
         vl, vr = radii(LF[:hi]), radii(RF[:hi])
-        for v in (vl, vr):
-            if not np.all(np.isfinite(v)) or np.any(v >= 2.0 ** 50) or np.any(np.abs(v - np.rint(v)) <= 2e-8 * np.maximum(1.0, np.abs(v))):
-                return False
-        r = np.trunc(0.5 * (np.trunc(vl).astype(np.int64) + np.trunc(vr).astype(np.int64))).astype(np.int64)   # per frame, :545
+        w0 = max(0, lo - k + 1)              # the frames whose radii enter an averaging window of lo .. hi-1
+        if self._delicate_radii(LF[w0:hi], RF[w0:hi]).any():
+            return False
+        with np.errstate(all="ignore"):      # (frames in front of w0 may be delicate: their entries of r are never read)
+            r = np.trunc(0.5 * (np.trunc(vl) + np.trunc(vr)))
+        r = np.where(np.isfinite(r) & (np.abs(r) < 2.0 ** 62), r, 0).astype(np.int64)                          # per frame, :545
         m = hi - lo
         idx = np.arange(lo, hi)
         total, count = np.zeros(m), np.zeros(m, np.int64)
@@ -915,15 +960,7 @@ class LaneTracker:
                 if annotate:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
                                      self._lane_text()))
-            j, k_avg = skip, int(self.n_average)
-            if annotate and k_avg >= 1 and g >= 2 * k_avg + 4:
-                # with annotation every frame leaves a picture: the first n_average - 1 frames (their averages reach back
-                # before the run) and the last one (it leaves the state) go the ordinary way, the ones between all at once
-                for j in range(k_avg - 1):
-                    commit(j)
-                j = g - 1 if self._record_successes(LF[:g], RF[:g], k_avg - 1, g - 1, partial, deferred) else k_avg - 1
-            for j in range(j, g):
-                commit(j)
+            self._commit_valid_run(LF, RF, g, skip, annotate, partial, deferred, commit)
             i = first + g
             if flush is not None:
                 flush(False)             # render and download what has been committed so far, under the searches still running

@@ -232,3 +232,64 @@ def test_packed_poly_points_against_the_reference_fixture(path):
     assert np.array_equal(lyx[:, 1], d["poly_left_x"]) and np.array_equal(ryx[:, 1], d["poly_right_x"])
     assert np.array_equal(lyx[:, 0], d["poly_left_y"]) and np.array_equal(ryx[:, 0], d["poly_right_y"])
     assert ln[0] == len(d["poly_left_x"]) and rn[0] == len(d["poly_right_x"])
+
+
+def test_runs_of_valid_frames_are_recorded_at_once_around_near_straight_frames():
+    """`_commit_valid_run`: a run of valid first tries recorded all at once (`_record_successes`) except around frames whose
+    curve radius needs the scalar route (`_delicate_radii`: near-straight lanes, a radius above 2.5e7 m or next to an integer)
+    -- state, radii, eccentricity and the deferred pictures equal those of the frame-by-frame route, frame by frame."""
+    import fake_context
+    from lane_tracker_amd import _native, calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    real = _native.Context
+    _native.Context = fake_context.FakeContext
+    try:
+        rng = np.random.default_rng(77)
+        for n_average, g in ((2, 40), (3, 64), (1, 23), (2, 9)):
+            ys = np.arange(100, 1070, 7, dtype=np.int64)
+
+            def fits(n):
+                a = rng.uniform(-8e-5, 8e-5, n)
+                a[rng.random(n) < 0.2] *= 1e-6                             # near-straight: radius beyond 2.5e7 m (a dead-straight
+                                                                           # fit, radius inf, fails in int() upstream too)
+                b = rng.uniform(-0.12, 0.04, n)
+                cl = rng.uniform(420, 450, n)
+                LF = np.stack([a, b, cl], 1)
+                RF = np.stack([a * rng.uniform(0.9, 1.1, n), b + rng.uniform(-0.01, 0.01, n), cl + rng.uniform(175, 195, n)], 1)
+                return LF, RF
+            LF, RF = fits(g)
+            results = []
+            for at_once in (False, True):
+                lt = LaneTracker(n_average=n_average, **cal)
+                deferred = []
+
+                def commit(j, lt=lt, deferred=deferred):
+                    lt.counter += 1
+                    lf, rf = np.array(LF[j]), np.array(RF[j])
+                    # the pixel lists the exact refit of get_curve_radius reads: points on the two parabolas
+                    lt._lp['left_y'], lt._lp['right_y'] = ys, ys
+                    lt._lp['left_x'] = np.rint(lf[0] * ys ** 2 + lf[1] * ys + lf[2]).astype(np.int64)
+                    lt._lp['right_x'] = np.rint(rf[0] * ys ** 2 + rf[1] * ys + rf[2]).astype(np.int64)
+                    lt._pending = None
+                    lt._fit = (lt._lp['left_y'], lt._lp['right_y'], lf, rf)
+                    lt._record_success(lf, rf, 1.0)
+                    deferred.append(('lane', (lt.left_avg_y, lt.left_avg_x, lt.right_avg_y, lt.right_avg_x), lt._lane_text()))
+                if at_once:
+                    lt._commit_valid_run(LF, RF, g, 0, True, 1.0, deferred, commit)
+                else:
+                    for j in range(g):
+                        commit(j)
+                results.append((lt, deferred))
+            (a, da), (b, db) = results
+            assert len(da) == len(db) == g
+            for j, (x, y) in enumerate(zip(da, db)):
+                assert x[2] == y[2], (n_average, j, x[2], y[2])                                    # the text: radius, eccentricity
+                assert all(np.array_equal(p, q) for p, q in zip(x[1], y[1])), (n_average, j)       # the polygon
+            assert (a.counter, a.success, list(a.average_curve_radii), a.average_curve_radius, a.eccentricity) == \
+                   (b.counter, b.success, list(b.average_curve_radii), b.average_curve_radius, b.eccentricity)
+            assert all(np.array_equal(p, q) for p, q in zip(a.left_fit_coeffs + a.right_fit_coeffs, b.left_fit_coeffs + b.right_fit_coeffs))
+            if g >= 2 * n_average + 4:
+                assert b._delicate_radii(LF, RF).any() and not b._delicate_radii(LF, RF).all()       # both kinds of stretch occurred
+    finally:
+        _native.Context = real
