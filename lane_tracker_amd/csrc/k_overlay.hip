@@ -166,6 +166,23 @@ void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, s
                        static_cast<const uint32_t*>(src_dev), n);
 }
 
+// A few words or kilobytes device -> page-locked host memory as a kernel launch (records, lane-pixel blocks): a hipMemcpyAsync
+// of 64 bytes takes 23 us by itself and, beside a stream of annotated frames, queues behind them on the copy engine (4 ms per
+// lt_download_pixels in an annotated 1920x1080 stream); a launch does neither.  false: not word-aligned / not page-locked.
+bool launch_copy_words_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes) {
+    if (!bytes) return true;
+    void* dst_dev = nullptr;
+    if (((bytes | (size_t)(uintptr_t)dst_pinned | (size_t)(uintptr_t)src) & 3) ||
+        hipHostGetDevicePointer(&dst_dev, dst_pinned, 0) != hipSuccess || !dst_dev) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const size_t n = bytes >> 2;
+    hipLaunchKernelGGL(k_copy_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<uint32_t*>(dst_dev),
+                       static_cast<const uint32_t*>(src), n);
+    return true;
+}
+
 // Device -> page-locked host memory by a kernel (16 bytes per lane, grid-stride over a grid that a few CUs hold), the
 // alternative to the copy engine for lt_download_overlay_async (LT_DL_KERNEL=1; trade-off and numbers there and in
 // tools/microbench/d2h_kernel.hip): stores from a kernel cross the bus beside the engine's uploads whatever engine the runtime

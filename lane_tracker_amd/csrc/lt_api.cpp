@@ -190,6 +190,7 @@ struct lt_ctx {
     std::vector<hipEvent_t> chain_event_pool;
     int* h_cancel = nullptr;                  // page-locked, device-visible: chains launched with an older epoch stop at their next frame
     int* d_cancel = nullptr;                  // its device address
+    uint8_t* h_small = nullptr;               // page-locked scratch of the small downloads (download())
     lt_lane_record* h_rec_stage = nullptr;    // capacity records
     int h_rec_stage_cap = 0;
     // timing
@@ -966,6 +967,7 @@ void lt_destroy(lt_ctx* c) {
     for (auto& w : c->rests.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
+    if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
     if (c->h_cancel) (void)hipHostFree(c->h_cancel);
     if (c->search) (void)hipStreamDestroy(c->search);
@@ -1201,14 +1203,26 @@ static int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
     if (!dst) return fail(LT_ERR_INVALID, "null output buffer");
     int rc = set_device(c);
     if (rc) return rc;
-    if (c->urgent_on && c->urgent) {        // lt_set_urgent: what is asked for was produced on the urgent stream (or is complete)
-        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->urgent));
-        HIP_TRY(hipStreamSynchronize(c->urgent));
-        return LT_OK;
+    hipStream_t st = c->stream;
+    if (c->urgent_on && c->urgent) st = c->urgent;      // lt_set_urgent: what is asked for was produced on the urgent stream (or is complete)
+    else if ((rc = sync_all(c))) return rc;             // results may come from any of the context's streams
+    // Records, headers, lane-pixel blocks: through a page-locked scratch buffer by a kernel launch, not the copy engine (23 us
+    // for 64 bytes; behind the annotated frames of a stream, milliseconds).
+    constexpr size_t SMALL = 256 << 10;
+    if (bytes <= SMALL) {
+        if (!c->h_small && hipHostMalloc(reinterpret_cast<void**>(&c->h_small), SMALL, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_small = nullptr;
+        }
+        if (c->h_small && launch_copy_words_to_pinned(st, c->h_small, src, bytes)) {
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+            std::memcpy(dst, c->h_small, bytes);
+            return LT_OK;
+        }
     }
-    if ((rc = sync_all(c))) return rc;      // results may come from any of the context's streams
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return LT_OK;
 }
 

@@ -61,6 +61,7 @@ void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int i
 // host -> device copy of a few hundred KB out of page-locked memory as a kernel launch (never blocks the caller)
 void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, size_t bytes);
 bool launch_copy_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes);   // false: not page-locked / aligned
+bool launch_copy_words_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes);          // small, 4-byte granular
 void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy, const uint16_t* wfrac,
                      FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n);
 
