@@ -215,27 +215,18 @@ bool adaptive_walk_supported(int bs_r, int bs_b, int h, int w, size_t plane_stri
     return ok(bs_r) && ok(bs_b) && (w & 3) == 0 && w >= 4 && h >= 1 && (plane_stride & 3) == 0;
 }
 
-// both planes of the 'neighborhood' filter in one launch: out_r / out_b are the two thresholded bit planes
-bool launch_adaptive_walk(hipStream_t s, const uint8_t* R, int bs_r, int C_r, unsigned long long* out_r, const uint8_t* B, int bs_b,
-                          int C_b, unsigned long long* out_b, int h, int w, size_t plane_stride, size_t bits_stride, int n) {
-    if (n <= 0) return true;
-    if (!adaptive_walk_supported(bs_r, bs_b, h, w, plane_stride)) return false;
+// one launch over `np` planes (1 or 2)
+static bool launch_box(hipStream_t s, const BoxPlane* planes, int np, int h, int w, size_t plane_stride, size_t bits_stride, int n) {
     BoxArgs a;
-    auto fill = [](BoxPlane& p, const uint8_t* src, unsigned long long* out, int bs, int C) {
-        p.src = src; p.out = out; p.r = bs / 2; p.area = bs * bs;
-        const long long t = (long long)p.area * (2LL * C + 1) + 1;
-        p.c0 = (int)(t / 2);       // exact: area and 2 C + 1 are odd
-    };
-    if (std::llabs((long long)bs_r * bs_r * (2LL * C_r + 1)) > (1ll << 30) || std::llabs((long long)bs_b * bs_b * (2LL * C_b + 1)) > (1ll << 30)) return false;
-    fill(a.pl[0], R, out_r, bs_r, C_r);
-    fill(a.pl[1], B, out_b, bs_b, C_b);
-    a.nplanes = 2;
+    int rmax = 0;
+    for (int i = 0; i < np; ++i) { a.pl[i] = planes[i]; rmax = std::max(rmax, planes[i].r); }
+    if (np == 1) a.pl[1] = planes[0];
+    a.nplanes = np;
     a.h = h; a.w = w; a.wpr = (w + 63) / 64;
     a.nstrips = (w + STRIP_OUT - 1) / STRIP_OUT;
     a.nframes = n;
     a.plane_stride = plane_stride;
     a.bits_stride = bits_stride;
-    const int rmax = std::max(bs_r, bs_b) / 2;
     const size_t lds = (size_t)P_BYTES + (size_t)(2 * rmax + 2) * STRIP_IN;
     // bands: every task pays a prologue of bs rows (about a third of a walked row each); enough tasks to fill the chip
     // a few times over, none shorter than 4 r rows
@@ -249,12 +240,15 @@ bool launch_adaptive_walk(hipStream_t s, const uint8_t* R, int bs_r, int C_r, un
         const int rows = (h + nb - 1) / nb;
         const int real_nb = (h + rows - 1) / rows;
         if (real_nb != nb) continue;
-        const long long tasks = 2LL * n * a.nstrips * nb;
+        const long long tasks = (long long)np * n * a.nstrips * nb;
         if (nb > 1 && rows < std::max(8, (tasks <= slots ? 1 : 4) * rmax)) break;
         const double per_task = rows + (2 * rmax + 1) * 0.35;
         const double cost = tasks < slots ? per_task : (double)((tasks + slots - 1) / slots) * per_task;
         if (cost < best_cost - 1e-9) { best_cost = cost; best_nb = nb; }
     }
+    // measured on launches that fill the chip several times over (256 frames, a sweep of 3 .. 32 bands, each twice): 10 bands of
+    // 110 rows are fastest, 0.336 ms for both planes against 0.36 for the model's choice and 0.37-0.46 for 16 .. 32 bands
+    if ((long long)np * n * a.nstrips * 10 >= 2 * slots && h / 10 >= 2 * std::max(rmax, 4)) best_nb = 10;
     if (g_bands_override > 0) best_nb = std::min(g_bands_override, h);
     a.band_rows = (h + best_nb - 1) / best_nb;
     a.nbands = (h + a.band_rows - 1) / a.band_rows;
@@ -264,6 +258,28 @@ bool launch_adaptive_walk(hipStream_t s, const uint8_t* R, int bs_r, int C_r, un
         return false;
     hipLaunchKernelGGL(k_adaptive_box_walk, dim3(a.ntasks), dim3(64), lds, s, a);
     return true;
+}
+
+// both planes of the 'neighborhood' filter: out_r / out_b are the two thresholded bit planes
+bool launch_adaptive_walk(hipStream_t s, const uint8_t* R, int bs_r, int C_r, unsigned long long* out_r, const uint8_t* B, int bs_b,
+                          int C_b, unsigned long long* out_b, int h, int w, size_t plane_stride, size_t bits_stride, int n) {
+    if (n <= 0) return true;
+    if (!adaptive_walk_supported(bs_r, bs_b, h, w, plane_stride)) return false;
+    auto fill = [](BoxPlane& p, const uint8_t* src, unsigned long long* out, int bs, int C) {
+        p.src = src; p.out = out; p.r = bs / 2; p.area = bs * bs;
+        const long long t = (long long)p.area * (2LL * C + 1) + 1;
+        p.c0 = (int)(t / 2);       // exact: area and 2 C + 1 are odd
+    };
+    if (std::llabs((long long)bs_r * bs_r * (2LL * C_r + 1)) > (1ll << 30) || std::llabs((long long)bs_b * bs_b * (2LL * C_b + 1)) > (1ll << 30)) return false;
+    BoxPlane pl[2];
+    fill(pl[0], R, out_r, bs_r, C_r);
+    fill(pl[1], B, out_b, bs_b, C_b);
+    // One launch per plane, each with the ring its own window needs (a 15-pixel window: 5 KB per wave instead of the 10 KB a
+    // 35-pixel window beside it imposes): 0.336 against 0.352 ms per 256 frames for one launch over both (LT_BOX_SPLIT=0).  A
+    // few dozen frames cannot fill the chip either way and take the single launch (one tail instead of two: 59 against 66 us at 32).
+    static const bool split = [] { const char* e = std::getenv("LT_BOX_SPLIT"); return !(e && e[0] == '0'); }();
+    if (split && n >= 64) return launch_box(s, pl, 1, h, w, plane_stride, bits_stride, n) && launch_box(s, pl + 1, 1, h, w, plane_stride, bits_stride, n);
+    return launch_box(s, pl, 2, h, w, plane_stride, bits_stride, n);
 }
 
 }  // namespace lt
