@@ -182,7 +182,7 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                 try:
                     kw = settings.apply(lt1, settings.DEMO_1)
                     stream_rate(cold[:2], False, lt1, **kw)
-                    res["process_stream_demo1_fps"] = stream_rate(cold, False, lt1, **kw)
+                    res["process_stream_demo1_fps"] = stream_rate(cold + cold, False, lt1, **kw)      # 4096 frames, as process_stream_fps
                     res["demo1_success_ratio"] = round(lt1.get_success_ratio()[0], 4)
                 finally:
                     lt1.close()
