@@ -245,6 +245,19 @@ int  lt_overlay_set_font(lt_ctx* ctx, const uint8_t* atlas, const uint8_t* advan
  * lines: n * n_lines * line_len bytes, zero-padded; line i of a slot starts at (x0, y0 + i * step). */
 int  lt_overlay_text(lt_ctx* ctx, int first_slot, int n, const char* lines, int n_lines, int line_len, int x0, int y0,
                      int step);
+/* The camera rows [*row0, *row1) in which draw_lane()'s inverse warp (lane_tracker.py:648) can place a lane pixel at all, from
+ * the table lt_overlay_configure built: every pixel of an annotated frame outside these rows and outside the text lines equals
+ * the camera pixel, whatever the polygon. */
+int  lt_overlay_rows(lt_ctx* ctx, int* row0, int* row1);
+/* draw_lane() / print_failure() (lane_tracker.py:629-673) for ONE resident frame in one call: lt_overlay_run with one polygon
+ * (left_n / right_n: one count each), lt_overlay_text when lines != NULL, and the annotated frame into `out` (img_h * img_w * 3
+ * bytes, page-locked memory preferred); returns when it is there.  rows4 = NULL: the whole frame.  rows4 = {a0, a1, b0, b1},
+ * two ordered runs of camera rows: only these rows are drawn and written, at their places in `out` -- the caller fills the
+ * others from the camera frame it holds (LaneTracker.process() does so while the device is busy, and half the frame crosses the
+ * bus).  The runs must cover the text lines and, for a non-empty polygon, lt_overlay_rows; LT_ERR_INVALID otherwise. */
+int  lt_present_frame(lt_ctx* ctx, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                      const int32_t* right_yx, double alpha, const char* lines, int n_lines, int line_len, int x0, int y0,
+                      int step, uint8_t* out, const int32_t* rows4);
 /* Host-only helper (no GPU needed): the (lo, hi) column interval per bird's-eye row that cv2.fillPoly
  * paints for that polygon; empty rows are (32767, -32768).  spans: warp_h * 2 int16. */
 int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,

@@ -4,8 +4,10 @@ The library is HIP-only.  There is deliberately no fallback: if the shared objec
 GPU is visible, constructing a `Context` raises -- nothing in this package computes on the CPU.
 """
 import ctypes as C
+import math
 import os
 import subprocess
+import weakref
 
 import numpy as np
 
@@ -89,6 +91,8 @@ _SIGNATURES = {
     "lt_overlay_run": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double]),
     "lt_overlay_set_font": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lt_overlay_rows": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "lt_present_frame": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "lt_download_overlay": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_overlay_async": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -192,11 +196,10 @@ class _PinnedPool:
 
     def __init__(self, limit=8 << 30, keep_per_size=4):
         self.limit, self.keep = limit, keep_per_size
-        self.free, self.outstanding = {}, 0
+        self.free, self.outstanding, self.kinds = {}, 0, {}
 
     def empty(self, shape, dtype=np.uint8):
-        import weakref
-        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        nbytes = math.prod(shape) * np.dtype(dtype).itemsize
         if nbytes == 0 or self.outstanding + nbytes > self.limit:
             return np.empty(shape, dtype)
         blocks = self.free.get(nbytes)
@@ -207,7 +210,10 @@ class _PinnedPool:
             if load().lt_host_alloc(nbytes, C.byref(out)) != 0 or not out.value:
                 return np.empty(shape, dtype)
             ptr = out.value
-        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        kind = self.kinds.get(nbytes)
+        if kind is None:
+            kind = self.kinds[nbytes] = C.c_uint8 * nbytes
+        buf = kind.from_address(ptr)
         self.outstanding += nbytes
         fin = weakref.finalize(buf, self._release, nbytes, ptr)
         fin.atexit = False                       # at interpreter exit the driver reclaims everything
@@ -497,6 +503,36 @@ class Context:
     def download_records(self, n, first=0):
         out = np.zeros(n, RECORD_DTYPE)
         _check(self.lib.lt_download_records(self._h, first, n, out.ctypes.data))
+        return out
+
+    def download_record(self, slot):
+        """The record of one slot -> (left coeffs, right coeffs, detected, fit_flags): download_records(1, slot) without
+        the per-call array and field lookups (LaneTracker.process() asks once per frame, with the device idle behind it)."""
+        v = self.__dict__.get("_rec1")
+        if v is None:
+            r = np.zeros(1, RECORD_DTYPE)
+            v = self._rec1 = (r, r.ctypes.data, r["left_coeffs"][0], r["right_coeffs"][0], r["detected"], r["fit_flags"])
+        rc = self.lib.lt_download_records(self._h, slot, 1, v[1])
+        if rc:
+            _check(rc)
+        return v[2].copy(), v[3].copy(), bool(v[4][0]), int(v[5][0])
+
+    def overlay_rows(self):
+        """(row0, row1): the camera rows in which the lane overlay can change a pixel (lt_overlay_rows)."""
+        a, b = C.c_int(0), C.c_int(0)
+        _check(self.lib.lt_overlay_rows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def present_frame(self, slot, left_n, right_n, left_yx, right_yx, text, n_lines, line_len, out, rows=None, origin=(20, 8),
+                      step=35, alpha=0.3):
+        """draw_lane() / print_failure() of ONE slot in one library call (lt_present_frame), for a caller that keeps the packed
+        polygon in buffers of its own: left_n / right_n / left_yx / right_yx are ADDRESSES (int32 count; int32 (y, x) pairs, or
+        None when the count is 0), text is None or n_lines * line_len bytes (lines padded with NUL), out the (1, H, W, 3) array
+        the frame lands in, rows None or the ADDRESS of four int32 {a0, a1, b0, b1}: only these two runs of rows are written."""
+        rc = self.lib.lt_present_frame(self._h, slot, left_n, right_n, left_yx, right_yx, alpha, text, n_lines, line_len, origin[0],
+                                       origin[1], step, out.ctypes.data, rows)
+        if rc:
+            _check(rc)
         return out
 
     def download_pixels(self, slot, side):

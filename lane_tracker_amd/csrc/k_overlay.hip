@@ -11,6 +11,7 @@
 // 0/255 image: each camera pixel tests its four taps against the row intervals.  Only the green byte
 // changes; 0.3*lane is added in f32 and rounded half-to-even like cv::addWeighted's saturate_cast.
 #include <algorithm>
+#include <cstring>
 #include "lt_internal.h"
 
 namespace lt {
@@ -74,6 +75,40 @@ __global__ __launch_bounds__(256) void k_overlay_lane4(const uint32_t* __restric
     for (int i = 0; i < 4; ++i)
         v[i] = lane_value(sp, bh, bw, (int16_t)(xyv[i] & 0xffffu), (int16_t)(xyv[i] >> 16), (int)frv[i]);
     // byte layout of the three dwords: R0 G0 B0 R1 | G1 B1 R2 G2 | B2 R3 G3 B3
+    if (v[0]) d0 = (d0 & 0xffff00ffu) | (blend_green((d0 >> 8) & 255u, v[0], alpha) << 8);
+    if (v[1]) d1 = (d1 & 0xffffff00u) | blend_green(d1 & 255u, v[1], alpha);
+    if (v[2]) d1 = (d1 & 0x00ffffffu) | (blend_green(d1 >> 24, v[2], alpha) << 24);
+    if (v[3]) d2 = (d2 & 0xff00ffffu) | (blend_green((d2 >> 16) & 255u, v[3], alpha) << 16);
+    dst[0] = d0;
+    dst[1] = d1;
+    dst[2] = d2;
+}
+
+// k_overlay_lane4 for ONE frame with the row intervals as a kernel ARGUMENT (up to LT_SPAN_ARG_ROWS bird's-eye rows; should the
+// runtime refuse that many argument bytes, launch_overlay_lane_one says so and the staged path takes over): process() annotates one frame per call with the host waiting for it, and intervals staged in
+// page-locked memory cost a copy launch plus the events that guard the staging buffer before the overlay can start.
+constexpr int SPAN_ARG_ROWS = LT_SPAN_ARG_ROWS;
+struct SpanArg { short2 s[SPAN_ARG_ROWS]; };
+__global__ __launch_bounds__(256) void k_overlay_lane4_arg(const uint32_t* __restrict__ frames, uint32_t* __restrict__ out,
+                                                          const int16_t* __restrict__ oxy, const uint16_t* __restrict__ ofrac,
+                                                          int qa, int na, int qb, int nb, int bh, int bw, float alpha,
+                                                          const SpanArg spans) {
+    // two runs of pixel quads: [qa, qa + na) and [qb, qb + nb) (whole rows of the frame: the text rows and the rows the lane
+    // can reach, or the whole frame and nothing)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= na + nb) return;
+    const int q = t < na ? qa + t : qb + (t - na);
+    const uint32_t* src = frames + (size_t)q * 3;
+    uint32_t* dst = out + (size_t)q * 3;
+    uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+    const uint4 xy = reinterpret_cast<const uint4*>(oxy)[q];
+    const uint2 fr = reinterpret_cast<const uint2*>(ofrac)[q];
+    const uint32_t xyv[4] = {xy.x, xy.y, xy.z, xy.w};
+    const uint32_t frv[4] = {fr.x & 0xffffu, fr.x >> 16, fr.y & 0xffffu, fr.y >> 16};
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        v[i] = lane_value(spans.s, bh, bw, (int16_t)(xyv[i] & 0xffffu), (int16_t)(xyv[i] >> 16), (int)frv[i]);
     if (v[0]) d0 = (d0 & 0xffff00ffu) | (blend_green((d0 >> 8) & 255u, v[0], alpha) << 8);
     if (v[1]) d1 = (d1 & 0xffffff00u) | blend_green(d1 & 255u, v[1], alpha);
     if (v[2]) d1 = (d1 & 0x00ffffffu) | (blend_green(d1 >> 24, v[2], alpha) << 24);
@@ -233,6 +268,23 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
         hipLaunchKernelGGL(k_overlay_lane, dim3((npix + 255) / 256, 1, n), dim3(256), 0, s, frames, out, frame_stride, oxy,
                            ofrac, sp, span_stride_rows, npix, bh, bw, alpha);
     }
+}
+
+bool launch_overlay_lane_one(hipStream_t s, const uint8_t* frame, uint8_t* out, const int16_t* oxy, const uint16_t* ofrac,
+                             const int16_t* spans_host, int img_h, int img_w, int bh, int bw, float alpha, const int* rows4) {
+    static bool refused = false;         // the runtime did not take a launch with this many argument bytes: never again
+    if (refused || bh > SPAN_ARG_ROWS || (img_w & 3) || (((size_t)(uintptr_t)frame | (size_t)(uintptr_t)out) & 3)) return false;
+    SpanArg arg;
+    std::memcpy(arg.s, spans_host, (size_t)bh * sizeof(short2));
+    const int qrow = img_w >> 2;
+    int qa = 0, na = img_h * qrow, qb = 0, nb = 0;
+    if (rows4) { qa = rows4[0] * qrow; na = (rows4[1] - rows4[0]) * qrow; qb = rows4[2] * qrow; nb = (rows4[3] - rows4[2]) * qrow; }
+    if (na + nb <= 0) return true;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_overlay_lane4_arg, dim3((na + nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(frame),
+                       reinterpret_cast<uint32_t*>(out), oxy, ofrac, qa, na, qb, nb, bh, bw, alpha, arg);
+    if (hipGetLastError() != hipSuccess) { refused = true; return false; }
+    return true;
 }
 
 void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy, const uint16_t* wfrac,

@@ -1483,6 +1483,20 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Ma
 
 bool band_chain_supported(const SearchGeom& g, size_t mask_stride) { return band2_eligible(g, mask_stride); }
 
+// The band search of ONE frame around coefficients given by value, by the chain kernel with a chain of one: k_band_chain3 is
+// built around the latency of a single workgroup (8 us per frame against k_band_fit2's 22 for one frame; record and pixel
+// block are the same, tests/test_gpu_chain.py), which is what process() -- one frame per call, the host waiting -- pays for.
+// `zero` = any readable device word (the chain's cancel flag; a chain of one never looks at it again).  false: not launched.
+bool launch_band_fit_one(hipStream_t s, MaskBits mb, SearchGeom g, const BandPrev& bp, uint32_t* pix, lt_lane_record* rec,
+                         size_t mask_stride, const int* zero) {
+    static const bool big3 = allow_big_lds(k_band_chain3);
+    if (!mb.bits || !bp.by_value || !big3 || g.h > 8192 || !band2_eligible(g, mask_stride)) return false;
+    const size_t lds3 = (size_t)C3_VALUES * CT * sizeof(long long);
+    hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, (const lt_lane_record*)nullptr, bp, pix, rec, 1, zero, 0x7fffffff,
+                       3, 0);
+    return true;
+}
+
 void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const lt_lane_record* seed_rec,
                        const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n, const int* cancel_epoch, int my_epoch) {
     if (n <= 0) return;

@@ -191,6 +191,10 @@ struct lt_ctx {
     int* h_cancel = nullptr;                  // page-locked, device-visible: chains launched with an older epoch stop at their next frame
     int* d_cancel = nullptr;                  // its device address
     uint8_t* h_small = nullptr;               // page-locked scratch of the small downloads (download())
+    int ov_r0 = 0, ov_r1 = 0;                 // camera rows the lane overlay can change (lt_overlay_configure)
+    lt_lane_record* h_rec = nullptr;          // page-locked mirror of the record of the last ONE-frame search (mirror_record)
+    int rec_mirror_slot = -1;                 // the slot whose record the mirror holds once rec_mirror_stream is idle; -1: none
+    hipStream_t rec_mirror_stream = nullptr;
     lt_lane_record* h_rec_stage = nullptr;    // capacity records
     int h_rec_stage_cap = 0;
     // timing
@@ -652,6 +656,9 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     };
     if (p->filter_type == 0 && first + n <= (int)c->th_padded.size())
         for (int i = first; i < first + n; ++i) c->th_padded[(size_t)i] = walk ? 1 : 0;
+    unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
+    unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
+    bool r_verdicts_done = false;                 // the R plane's threshold ran beside the Lab-b top-hats, into ebits
     if (p->filter_type == 0) {
         if (c->brute_tophat) {   // debugging aid (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
@@ -666,6 +673,13 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             launch_morph_runs(c->side, R, t3, nullptr, h, w, 29, false, ps, n);
             launch_morph_runs(c->side, t3, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes);
+            // ... and so does the R plane's threshold: its 29x29 top-hat is done while the 55x55 pair still has half its way
+            // to go, and the threshold kernel takes its planes one after the other anyway -- here one per launch, the R
+            // verdicts as a partial bit plane the open ORs in (12 us less on the one-frame chain)
+            static const bool split_ok = [] { const char* e = std::getenv("LT_THRESHOLD_SPLIT"); return !(e && e[0] == '0'); }();
+            if (split_ok && !walk && !p->mask_noise)
+                r_verdicts_done = launch_bilateral_bits(c->side, thR, p->ksize_r, p->C_r, nullptr, 1, 0, B, p->ksize_noise, p->C_noise,
+                                                        p->noise_thresh, 0, ebits, h, w, ps, c->bits_stride, n) == 0;
             HIP_TRY(hipEventRecord(c->ev_join, c->side));
             launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
             { const int rc = tophat_b(s); if (rc) return rc; }
@@ -677,8 +691,6 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             { StageScope t(c, ST_TOPHAT_B, s); const int rc = tophat_b(s); if (rc) return rc; }
         }
     }
-    unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
-    unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
     bool merged_done = false, partials = false;   // partials: mbits, ebits, tmp, tmp2 still wait for their OR
     bool two_partials = false;                    // ... only mbits and ebits (the 'neighborhood' walk)
     unsigned long long* tbits = c->d_bits_tmp + (size_t)first * c->bits_stride;
@@ -698,6 +710,11 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
                                       c->th_pad_bytes, c->bits_stride, n))
                     return fail(LT_ERR_STATE, "the greenery-mask walk refused parameters its own predicate accepted");
             }
+        }
+        if (!merged_done && r_verdicts_done) {   // the Lab-b plane alone; should that launch be refused, both planes below
+            merged_done = launch_bilateral_bits(s, nullptr, 1, 0, thB, p->ksize_b, p->C_b, B, p->ksize_noise, p->C_noise,
+                                                p->noise_thresh, 0, mbits, h, w, ps, c->bits_stride, n) == 0;
+            partials = two_partials = merged_done;
         }
         if (!merged_done)
           merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
@@ -968,6 +985,7 @@ void lt_destroy(lt_ctx* c) {
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
     if (c->h_cancel) (void)hipHostFree(c->h_cancel);
     if (c->search) (void)hipStreamDestroy(c->search);
@@ -990,6 +1008,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     if (capacity <= c->capacity) return LT_OK;
     if ((rc = sync_all(c))) return rc;
     free_slots(c);
+    c->rec_mirror_slot = -1;
     c->capacity = capacity;
     const size_t n = (size_t)capacity;
     if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes + 16))) { free_slots(c); return rc; }   // +16: k_undistort_rows reads 8-byte windows
@@ -1085,8 +1104,9 @@ int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
     if ((rc = set_device(c))) return rc;
     if ((rc = sync_all(c))) return rc;
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
+    const size_t bytes = (size_t)(c->cam_r1 - c->cam_r0) * row_bytes;
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
-                             (size_t)(c->cam_r1 - c->cam_r0) * row_bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
+                             bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
 }
@@ -1292,7 +1312,21 @@ namespace {
 // union of the 8-connected edge lines and the even-odd interior is, per row, the hull of the edge
 // pixels on that row.  The walk is OpenCV's LineIterator (left end point first, error term
 // dx - 2 dy, one major-axis step per pixel).
+static inline void span_point(int16_t* spans, int bh, int x, int y) {
+    if (y >= 0 && y < bh) {
+        const int16_t xc = (int16_t)std::min(std::max(x, -32768), 32767);
+        if (xc < spans[2 * y]) spans[2 * y] = xc;
+        if (xc > spans[2 * y + 1]) spans[2 * y + 1] = xc;
+    }
+}
+
 static void span_line(int16_t* spans, int bh, int xa, int ya, int xb, int yb) {
+    if (std::abs(xb - xa) <= 1 && std::abs(yb - ya) <= 1) {
+        // neighbouring pixels (nearly every edge of a lane polygon: one plot point per row): the line is its two end points
+        span_point(spans, bh, xa, ya);
+        span_point(spans, bh, xb, yb);
+        return;
+    }
     if (xb < xa) { std::swap(xa, xb); std::swap(ya, yb); }
     const int adx = xb - xa, ady = std::abs(yb - ya), ystep = yb < ya ? -1 : 1;
     const bool tall = ady > adx;
@@ -1317,11 +1351,17 @@ static void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int n
     const int np = nl + nr;
     if (np <= 0) return;
     // vertex k of the closed polygon: the left points in order, then the right points reversed (np.flipud)
-    auto vx = [&](int k) { return k < nl ? lyx[2 * k + 1] : ryx[2 * (nr - 1 - (k - nl)) + 1]; };
-    auto vy = [&](int k) { return k < nl ? lyx[2 * k] : ryx[2 * (nr - 1 - (k - nl))]; };
-    for (int k = 0; k < np; ++k) {
-        const int j = (k + np - 1) % np;
-        span_line(spans, bh, vx(j), vy(j), vx(k), vy(k));
+    const int32_t* last = nr ? ryx : lyx + 2 * (nl - 1);          // vertex np - 1: the first right point, or the last left one
+    int px = last[1], py = last[0];
+    for (int k = 0; k < nl; ++k) {
+        span_line(spans, bh, px, py, lyx[2 * k + 1], lyx[2 * k]);
+        px = lyx[2 * k + 1];
+        py = lyx[2 * k];
+    }
+    for (int k = nr - 1; k >= 0; --k) {
+        span_line(spans, bh, px, py, ryx[2 * k + 1], ryx[2 * k]);
+        px = ryx[2 * k + 1];
+        py = ryx[2 * k];
     }
 }
 
@@ -1399,6 +1439,21 @@ int lt_overlay_configure(lt_ctx* c, const double* Minv) {
     if ((rc = dev_alloc(&c->d_ofrac, t.frac.size()))) return rc;
     HIP_TRY(hipMemcpy(c->d_oxy, t.xy.data(), t.xy.size() * 2, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_ofrac, t.frac.data(), t.frac.size() * 2, hipMemcpyHostToDevice));
+    // Camera rows the lane can reach at all: a pixel's four taps are (sx, sy) .. (sx + 1, sy + 1), so only pixels with
+    // -1 <= sx <= bw - 1 and -1 <= sy <= bh - 1 can see the bird's-eye image; every other pixel of the annotated frame is the
+    // camera pixel whatever the polygon (lt_overlay_rows, lt_present_frame).
+    c->ov_r0 = c->ov_r1 = 0;
+    for (int y = 0; y < t.rows; ++y) {
+        bool any = false;
+        for (int x = 0; x < t.cols && !any; ++x) {
+            const int sx = t.xy[2 * ((size_t)y * t.cols + x)], sy = t.xy[2 * ((size_t)y * t.cols + x) + 1];
+            any = sx >= -1 && sx <= c->calib.warp_w - 1 && sy >= -1 && sy <= c->calib.warp_h - 1;
+        }
+        if (any) {
+            if (c->ov_r1 == 0) c->ov_r0 = y;
+            c->ov_r1 = y + 1;
+        }
+    }
     c->have_overlay = true;
     return LT_OK;
 }
@@ -1453,8 +1508,10 @@ int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const do
     return LT_OK;
 }
 
-int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
-                   const int32_t* right_yx, double alpha) {
+// lt_overlay_run; rows4 (one frame only): two runs of camera rows {a0, a1, b0, b1} outside which the annotated frame is not
+// needed (lt_present_frame), nullptr = all of it
+static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                            const int32_t* right_yx, double alpha, const int* rows4) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_run before lt_overlay_configure");
@@ -1471,16 +1528,25 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     const int bh = c->calib.warp_h;
     if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
     if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
-    if ((rc = staging_claim(c->spans_busy, first, n))) return rc;
-    if (c->h_spans_cap < c->capacity) {
-        if ((rc = sync_all(c))) return rc;
-        if (c->h_spans) (void)hipHostFree(c->h_spans);
-        c->h_spans = nullptr;
-        c->h_spans_cap = 0;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
-        c->h_spans_cap = c->capacity;
-    }
-    int16_t* hs = c->h_spans + (size_t)first * bh * 2;
+    // One frame (process()): the intervals travel as a kernel argument -- no staging buffer, no copy launch, no events
+    static const bool arg_ok = [] { const char* e = std::getenv("LT_SPANS_ARG"); return !(e && e[0] == '0'); }();
+    bool one = arg_ok && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
+    int16_t one_spans[2 * LT_SPAN_ARG_ROWS];
+    auto claim_staging = [&]() -> int {
+        int r = staging_claim(c->spans_busy, first, n);
+        if (r) return r;
+        if (c->h_spans_cap < c->capacity) {
+            if ((r = sync_all(c))) return r;
+            if (c->h_spans) (void)hipHostFree(c->h_spans);
+            c->h_spans = nullptr;
+            c->h_spans_cap = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
+            c->h_spans_cap = c->capacity;
+        }
+        return (int)LT_OK;
+    };
+    if (!one && (rc = claim_staging())) return rc;
+    int16_t* hs = one ? one_spans : c->h_spans + (size_t)first * bh * 2;
     static const bool timing = std::getenv("LT_OVERLAY_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     // ~18 us of edge walking per polygon: a window's piece of 32 .. 128 polygons is shared among a few threads (the caller is
@@ -1529,6 +1595,18 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
     // an asynchronous download may still be reading the annotated frames this call overwrites
     if (c->annot_busy.hi > c->annot_busy.lo && first < c->annot_busy.hi && first + n > c->annot_busy.lo && c->annot_busy.done)
         HIP_TRY(hipStreamWaitEvent(ps, c->annot_busy.done, 0));
+    if (one) {
+        if (launch_overlay_lane_one(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
+                                    c->d_oxy, c->d_ofrac, hs, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, rows4)) {
+            HIP_TRY(hipGetLastError());
+            return note_range(c->readers, ps, first, first + n);
+        }
+        // not launched (the runtime refused the argument block): the staged way after all, with the intervals already built
+        one = false;
+        if ((rc = claim_staging())) return rc;
+        std::memcpy(c->h_spans + (size_t)first * bh * 2, one_spans, (size_t)bh * 2 * sizeof(int16_t));
+        hs = c->h_spans + (size_t)first * bh * 2;
+    }
     launch_copy_from_pinned(ps, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
     const auto t2 = std::chrono::steady_clock::now();
     launch_overlay_lane(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
@@ -1543,6 +1621,19 @@ int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int
         std::fprintf(stderr, "overlay_run n=%d: spans %ld us, wait+memcpy %ld us, launch+events %ld us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
     }
     return rc;
+}
+
+int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                   const int32_t* right_yx, double alpha) {
+    return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr);
+}
+
+int lt_overlay_rows(lt_ctx* c, int* row0, int* row1) {
+    if (!c || !row0 || !row1) return fail(LT_ERR_INVALID, "null argument");
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_rows before lt_overlay_configure");
+    *row0 = c->ov_r0;
+    *row1 = c->ov_r1;
+    return LT_OK;
 }
 
 int lt_overlay_set_font(lt_ctx* c, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
@@ -1622,10 +1713,23 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
     uint8_t* dl = c->d_lines + (size_t)first * stride;
     int16_t* dx = c->d_xpos + (size_t)first * stride;
     if ((rc = present_stream(c))) return rc;
-    launch_copy_from_pinned(c->present, dl, hl, (size_t)n * stride);
-    launch_copy_from_pinned(c->present, dx, hx, (size_t)n * stride * sizeof(int16_t));
+    // A frame or two (process(), one frame per call): the kernel reads the few hundred bytes from the page-locked buffers
+    // themselves -- two launches fewer between the record and the annotated frame.  A window's worth goes to the device first.
+    const uint8_t* kl = dl;
+    const int16_t* kx = dx;
+    void *pl = nullptr, *px = nullptr;
+    static const bool direct_ok = [] { const char* e = std::getenv("LT_TEXT_DIRECT"); return !(e && e[0] == '0'); }();
+    if (direct_ok && n <= 2 && hipHostGetDevicePointer(&pl, hl, 0) == hipSuccess && hipHostGetDevicePointer(&px, hx, 0) == hipSuccess &&
+        pl && px) {
+        kl = static_cast<const uint8_t*>(pl);
+        kx = static_cast<const int16_t*>(px);
+    } else {
+        (void)hipGetLastError();
+        launch_copy_from_pinned(c->present, dl, hl, (size_t)n * stride);
+        launch_copy_from_pinned(c->present, dx, hx, (size_t)n * stride * sizeof(int16_t));
+    }
     launch_overlay_text(c->present, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
-                        c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, dl, dx,
+                        c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, kl, kx,
                         n_lines, line_len, (int)stride, y0, step, n);
     HIP_TRY(hipGetLastError());
     return staging_mark(c->text_busy, c->present);
@@ -1674,7 +1778,65 @@ int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay before lt_overlay_run");
-    return download(c, c->d_annot + (size_t)first * c->frame_bytes, out, (size_t)n * c->frame_bytes);
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    const uint8_t* src = c->d_annot + (size_t)first * c->frame_bytes;
+    const size_t bytes = (size_t)n * c->frame_bytes;
+    if (!c->present || n == 0) return download(c, src, out, bytes);
+    // The annotated frames are written on the presentation stream and nowhere else (lt_overlay_run, lt_overlay_text), behind
+    // everything they depend on: the copy is enqueued there, behind them, and the host waits once -- not once for the overlay
+    // and once more for a copy it issues only then (10 us of process()'s 0.4 ms per frame).
+    if ((rc = set_device(c))) return rc;
+    // a frame or two: by a copy kernel (no engine start-up: 11 us less per frame of process()); LT_DL1_KERNEL=0: the engine
+    static const bool by_kernel = [] { const char* e = std::getenv("LT_DL1_KERNEL"); return !(e && e[0] == '0'); }();
+    if (!(by_kernel && n <= 2 && launch_copy_to_pinned(c->present, out, src, bytes)))
+        HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->present));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->present));
+    return LT_OK;
+}
+
+// process()'s tail for ONE frame in one call: lt_overlay_run + lt_overlay_text + the way back, the host waiting once.  With
+// rows4 = {a0, a1, b0, b1} only those two runs of camera rows are drawn and written to `out` (the rows at their places in the
+// frame): a pixel outside the rows the lane can reach (lt_overlay_rows) and outside the text lines is the camera pixel, which
+// the caller has -- process() copies those rows from its input while the device is busy, and only half the frame crosses the
+// bus behind the overlay.  The runs must cover the text lines and, for a non-empty polygon, lt_overlay_rows.
+int lt_present_frame(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx, const int32_t* right_yx,
+                     double alpha, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
+                     const int32_t* rows4) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_frame before lt_overlay_configure");
+    const int H = c->calib.img_h;
+    const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
+    int r[4] = {0, H, H, H};
+    if (rows4) {
+        for (int k = 0; k < 4; ++k) r[k] = rows4[k];
+        if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= H))
+            return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
+        auto covered = [&](int lo, int hi) {
+            lo = std::max(lo, 0);
+            hi = std::min(hi, H);
+            return lo >= hi || (r[0] <= lo && hi <= r[1]) || (r[2] <= lo && hi <= r[3]) || (r[1] == r[2] && r[0] <= lo && hi <= r[3]);
+        };
+        if (text && !covered(y0, y0 + (n_lines - 1) * step + c->font_gh)) return fail(LT_ERR_INVALID, "the row runs do not cover the text lines");
+        if ((left_n[0] > 0 || right_n[0] > 0) && !covered(c->ov_r0, c->ov_r1))
+            return fail(LT_ERR_INVALID, "the row runs do not cover the rows the lane can reach (lt_overlay_rows)");
+    }
+    if ((rc = overlay_run_impl(c, slot, 1, left_n, right_n, left_yx, right_yx, alpha, rows4 ? r : nullptr))) return rc;
+    if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
+    const size_t row_bytes = (size_t)c->calib.img_w * 3;
+    const uint8_t* src = c->d_annot + (size_t)slot * c->frame_bytes;
+    for (int k = 0; k < 4; k += 2) {
+        if (r[k + 1] <= r[k]) continue;
+        const size_t off = (size_t)r[k] * row_bytes, bytes = (size_t)(r[k + 1] - r[k]) * row_bytes;
+        if (!launch_copy_to_pinned(c->present, out + off, src + off, bytes))
+            HIP_TRY(hipMemcpyAsync(out + off, src + off, bytes, hipMemcpyDeviceToHost, c->present));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->present));
+    return LT_OK;
 }
 
 static void harvest_downloads(lt_ctx* c);
@@ -1824,9 +1986,30 @@ int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
     return download(c, dst, out, (size_t)n * c->bev_bytes);
 }
 
+// A search over ONE slot (process(): one frame per call, the host waiting for its record) sends the record to page-locked
+// memory by a launch queued right behind the search kernel, while the device is still busy with the frame: lt_download_records
+// then waits for that stream and reads 64 bytes, instead of launching the copy once the search is over (8 us of 0.4 ms).
+static void mirror_record(lt_ctx* c, hipStream_t st, int slot) {
+    c->rec_mirror_slot = -1;
+    if (!c->h_rec && hipHostMalloc(reinterpret_cast<void**>(&c->h_rec), 256, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->h_rec = nullptr;
+    }
+    if (c->h_rec && launch_copy_words_to_pinned(st, c->h_rec, c->d_rec + slot, sizeof(lt_lane_record))) {
+        c->rec_mirror_slot = slot;
+        c->rec_mirror_stream = st;
+    }
+}
+
 int lt_download_records(lt_ctx* c, int first, int n, lt_lane_record* out) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
+    if (n == 1 && out && c->rec_mirror_slot == first && c->h_rec) {
+        if ((rc = set_device(c))) return rc;
+        HIP_TRY(hipStreamSynchronize(c->rec_mirror_stream));
+        std::memcpy(out, c->h_rec, sizeof(lt_lane_record));
+        return LT_OK;
+    }
     return download(c, c->d_rec + first, out, (size_t)n * sizeof(lt_lane_record));
 }
 
@@ -1954,6 +2137,7 @@ int lt_enqueue_records_to_device(lt_ctx* c, int first, int n, void* dst) {
 int lt_set_frame_base(lt_ctx* c, int first, int n, int first_frame) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
+    c->rec_mirror_slot = -1;                  // the records change: the page-locked mirror of a one-frame search is stale
     if ((rc = set_device(c))) return rc;
     std::vector<lt_lane_record> tmp((size_t)n);
     if (n == 0) return LT_OK;
@@ -2025,6 +2209,7 @@ static int ensure_search_stream(lt_ctx* c) {
 int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
+    c->rec_mirror_slot = -1;                  // the records change: the page-locked mirror of a one-frame search is stale
     if ((rc = set_device(c))) return rc;
     if (!c->have_mask) return fail(LT_ERR_STATE, "no mask in the slots: run lt_mask_run or lt_upload_masks first");
     SearchGeom g;
@@ -2049,6 +2234,7 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
         launch_sws_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g,
                        c->d_band_sums + (size_t)f0 * g.nbands * c->calib.warp_w, c->d_pix + (size_t)f0 * 2 * c->maxpix,
                        c->d_cent + (size_t)f0 * 2 * (c->maxlev + 2), c->d_rec + f0, m);
+        if (n == 1) mirror_record(c, st, f0);
         return note_written(c, st, f0, f0 + m);
     });
     if (rc) return rc;
@@ -2059,6 +2245,7 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
 int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, const double* prev) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
+    c->rec_mirror_slot = -1;                  // the records change: the page-locked mirror of a one-frame search is stale
     if (!prev) return fail(LT_ERR_INVALID, "band search needs the previous coefficients (last_left_coeffs/last_right_coeffs)");
     if ((rc = set_device(c))) return rc;
     if (!c->have_mask) return fail(LT_ERR_STATE, "no mask in the slots: run lt_mask_run or lt_upload_masks first");
@@ -2085,8 +2272,14 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         StageScope t(c, ST_BAND_FIT, st);
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
-        launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g, c->d_prev + (size_t)f0 * 6, bp,
-                        c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
+        // one frame (process()): the chain kernel with a chain of one, a third of the latency (LT_BAND_ONE=0: k_band_fit2)
+        const char* one_env = n == 1 ? std::getenv("LT_BAND_ONE") : nullptr;
+        if (!(n == 1 && !(one_env && one_env[0] == '0') &&
+              launch_band_fit_one(st, mb, g, bp, c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, c->plane_bytes,
+                                  reinterpret_cast<const int*>(c->d_prev))))
+            launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g, c->d_prev + (size_t)f0 * 6, bp,
+                            c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
+        if (n == 1) mirror_record(c, st, f0);
         return note_written(c, st, f0, f0 + m);
     });
     if (rc) return rc;
@@ -2097,6 +2290,7 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
 int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p, const double* seed) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
+    c->rec_mirror_slot = -1;                  // the records change: the page-locked mirror of a one-frame search is stale
     if (!seed && first < 1) return fail(LT_ERR_INVALID, "a chain without seed coefficients continues from the record of slot first - 1");
     if ((rc = set_device(c))) return rc;
     if (!c->have_mask) return fail(LT_ERR_STATE, "no mask in the slots: run lt_mask_run or lt_upload_masks first");

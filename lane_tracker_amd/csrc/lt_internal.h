@@ -55,6 +55,12 @@ void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_px
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
                          const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
                          int bh, int bw, float alpha, int n);
+// one frame, the row intervals (host memory, bh pairs) passed as a kernel argument; rows4 = nullptr: the whole frame, else two
+// runs of camera rows {a0, a1, b0, b1} (the others are not written); false: not launched (bh above LT_SPAN_ARG_ROWS, a row
+// length that is no multiple of 4, or the runtime refused the argument block)
+constexpr int LT_SPAN_ARG_ROWS = 1104;
+bool launch_overlay_lane_one(hipStream_t s, const uint8_t* frame, uint8_t* out, const int16_t* oxy, const uint16_t* ofrac,
+                             const int16_t* spans_host, int img_h, int img_w, int bh, int bw, float alpha, const int* rows4);
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,
                          const uint8_t* advance, int first_char, int n_glyphs, int gw, int gh, const uint8_t* lines,
                          const int16_t* xpos, int nl, int len, int slot_chars, int y0, int step, int n);   // slot_chars: characters between two slots' lines
@@ -167,6 +173,8 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Ma
 // the chained band search of one stream (k_band_chain2): slots [first, first + n) in order, frame k+1 around frame k's fit;
 // the first frame around `seed` (by value) or, with seed.by_value == 0, around the fit in *seed_rec (device memory)
 bool band_chain_supported(const SearchGeom& g, size_t mask_stride);
+bool launch_band_fit_one(hipStream_t s, MaskBits mb, SearchGeom g, const BandPrev& bp, uint32_t* pix, lt_lane_record* rec,
+                         size_t mask_stride, const int* zero);
 void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const lt_lane_record* seed_rec,
                        const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n, const int* cancel_epoch, int my_epoch);
 

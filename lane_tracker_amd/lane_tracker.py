@@ -12,6 +12,8 @@ There is no CPU implementation of the hot path in this package: without the shar
 GPU, constructing a LaneTracker raises.
 """
 import contextlib
+import math
+import os
 
 import numpy as np
 
@@ -158,14 +160,10 @@ class LaneTracker:
         """Pull the lane record of `slot`.  The pixel lists (self.left_y/left_x/right_y/right_x) and
         window centroids are fetched right away, or -- in the stream pipeline, `lazy=True` -- only if
         somebody reads them before the slot is reused (the state machine itself needs the record only)."""
-        rec = ctx.download_records(1, first=slot)[0]
-        self.detected_pixels = bool(rec["detected"])
+        lf, rf, self.detected_pixels, flags = ctx.download_record(slot)
         if not self.detected_pixels:
             self._fit = None        # like the reference, a failed search leaves the previous pixel lists in place
             return
-        lf = np.array(rec["left_coeffs"], np.float64)
-        rf = np.array(rec["right_coeffs"], np.float64)
-        flags = int(rec["fit_flags"])
         self._pending = (ctx, slot)
         if want_centroids:
             self._pending_cent = (ctx, slot)
@@ -253,6 +251,8 @@ class LaneTracker:
             prev = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
                                    np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
             ctx.band_fit_run(1, prev, _native.search_params(**kw), first=slot)
+        if self._want_out and self._out is None:
+            self._prepare_out()
         self._collect_search(ctx, want_centroids=(mode == 'sws'), slot=slot, lazy=lazy)
         if diagnostics:
             print("Lane pixels found." if self.detected_pixels else "No lane pixels found.")
@@ -285,6 +285,33 @@ class LaneTracker:
         fitx = coeffs[0] * ploty2 + coeffs[1] * ploty + coeffs[2]
         return fitx, (fitx <= self.warped_size[0] - 1) & (fitx >= 0)
 
+    _want_out = False      # process() is under way and will hand back an annotated frame ...
+    _out = None            # ... which lands in this page-locked array, fetched while the device works
+    _out_rows = None       # address of the row runs still to come from the device when the other rows of _out are filled already
+    _avg_packed = None     # (buffers, left_avg_x, right_avg_x) while the 'avg' buffers hold the polygon of left_avg_* / right_avg_*
+
+    def _points_packed(self, left_fit_coeffs, right_fit_coeffs, partial, purpose):
+        """get_poly_points through lt_poly_points (host C, the same f64 operations in the same order; pinned to the reference's
+        fixtures by tests/test_host_geometry.py) into buffers this tracker keeps per (partial, purpose) -> the buffers:
+        [0] the six coefficients, [1] int32 counts (left, right), [2] / [3] the left / right (y, x) pairs, [4] addresses."""
+        packed = self.__dict__.setdefault("_packed", {})
+        b = packed.get((partial, purpose))
+        if b is None:
+            ploty, ploty2 = self._plot_rows(partial)
+            rows = len(ploty)
+            co, cnt = np.empty(6, np.float64), np.zeros(2, np.int32)
+            lyx, ryx = np.empty((max(rows, 1), 2), np.int32), np.empty((max(rows, 1), 2), np.int32)
+            args = (int(self.warped_size[0]), int(self.warped_size[1]), co.ctypes.data, 1, ploty.ctypes.data, ploty2.ctypes.data,
+                    rows, cnt.ctypes.data, cnt.ctypes.data + 4, lyx.ctypes.data, ryx.ctypes.data)
+            b = packed[(partial, purpose)] = (co, cnt, lyx, ryx, args, _native.load().lt_poly_points, (ploty, ploty2))
+        co = b[0]
+        co[:3] = left_fit_coeffs
+        co[3:] = right_fit_coeffs
+        rc = b[5](*b[4])
+        if rc:
+            _native._check(rc)
+        return b
+
     def get_poly_points(self, left_fit_coeffs, right_fit_coeffs, partial=1):
         img_height = self.warped_size[1]
         left_fitx, lin = self._poly_inside(left_fit_coeffs, partial)
@@ -302,17 +329,19 @@ class LaneTracker:
     def check_validity(self, left_fit_coeffs, right_fit_coeffs, diagnostics=False):
         lim = self.validity_limits
         # only the number of plot points inside the image matters here (:565-569)
-        n = min(int(np.count_nonzero(self._poly_inside(left_fit_coeffs, 1)[1])),
-                int(np.count_nonzero(self._poly_inside(right_fit_coeffs, 1)[1])))
+        cnt = self._points_packed(left_fit_coeffs, right_fit_coeffs, 1, 'validity')[1]
+        n = min(int(cnt[0]), int(cnt[1]))
         # NB: the reference takes the image WIDTH as the bottom y (:571-573); reproduced as is
         y1 = self.warped_size[0] - 1
         y2 = self.warped_size[0] - int(n * 0.35)
         y3 = self.warped_size[0] - int(n * 0.75)
-        lf, rf = left_fit_coeffs, right_fit_coeffs
+        # Python floats from here on: the same IEEE doubles and the same operations in the same order as NumPy's f64 scalars,
+        # at a fifth of their cost per operation
+        lf, rf = np.asarray(left_fit_coeffs, np.float64).tolist(), np.asarray(right_fit_coeffs, np.float64).tolist()
         at = lambda c, y: c[0] * (y ** 2) + c[1] * y + c[2]
         x1_diff, x2_diff, x3_diff = abs(at(lf, y1) - at(rf, y1)), abs(at(lf, y2) - at(rf, y2)), abs(at(lf, y3) - at(rf, y3))
-        if ((x1_diff < lim['min_dist_y1']) | (x1_diff > lim['max_dist_y1']) | (x2_diff < lim['min_dist_y2'])
-                | (x2_diff > lim['max_dist_y2']) | (x3_diff < lim['min_dist_y3']) | (x3_diff > lim['max_dist_y3'])):
+        if ((x1_diff < lim['min_dist_y1']) or (x1_diff > lim['max_dist_y1']) or (x2_diff < lim['min_dist_y2'])
+                or (x2_diff > lim['max_dist_y2']) or (x3_diff < lim['min_dist_y3']) or (x3_diff > lim['max_dist_y3'])):
             self.valid_lane_lines = False
             if diagnostics:
                 print("No valid lane lines found, violated distance criterion: "
@@ -321,7 +350,7 @@ class LaneTracker:
         slope = lambda c, y: 2 * c[0] * y + c[1]
         norm1 = abs(slope(lf, y1) - slope(rf, y1))
         norm2 = abs(slope(lf, y3) - slope(rf, y3))
-        if (norm1 >= lim['thresh']) | (norm2 >= lim['thresh']):
+        if (norm1 >= lim['thresh']) or (norm2 >= lim['thresh']):
             self.valid_lane_lines = False
             if diagnostics:
                 print("No valid lane lines found, violated tangent criterion: norm1 == {:.3f}, norm2 == {:.3f}".format(norm1, norm2))
@@ -344,10 +373,25 @@ class LaneTracker:
 
         def radius_of(fit_m):
             return ((1 + (2 * fit_m[0] * y_eval * self.mppv + fit_m[1]) ** 2) ** 1.5) / np.absolute(2 * fit_m[0])
+
+        def quick(c):
+            # radius_of on Python floats: the same doubles, the same operations (NumPy's f64 scalars call the same pow);
+            # anything NumPy answers with inf / nan and a warning where Python raises goes the NumPy way
+            mppv, mpph = self.mppv, self.mpph
+            if type(mppv) is not float or type(mpph) is not float:
+                return None
+            a, b = float(c[0]) * mpph / (mppv ** 2), float(c[1]) * mpph / mppv
+            try:
+                val = ((1 + (2 * a * y_eval * mppv + b) ** 2) ** 1.5) / abs(2 * a)
+            except (ZeroDivisionError, OverflowError):
+                return None
+            return val if math.isfinite(val) else None
         radii = []
         for side, c in enumerate((lf, rf)):
-            val = radius_of((c[0] * self.mpph / (self.mppv ** 2), c[1] * self.mpph / self.mppv))
-            if np.isfinite(val) and abs(val - np.rint(val)) <= 1e-8 * max(1.0, abs(val)):
+            val = quick(c)
+            if val is None:
+                val = radius_of((c[0] * self.mpph / (self.mppv ** 2), c[1] * self.mpph / self.mppv))
+            if math.isfinite(val) and abs(val - round(val)) <= 1e-8 * max(1.0, abs(val)):
                 ys, xs = (self.left_y, self.left_x) if side == 0 else (self.right_y, self.right_x)
                 val = radius_of(np.polyfit(np.asarray(ys) * self.mppv, np.asarray(xs) * self.mpph, 2))
             radii.append(int(val))
@@ -413,14 +457,77 @@ class LaneTracker:
         fill, its inverse warp with `Minv`, the 0.3 blend and the text run on the GPU (lt_overlay_run / lt_overlay_text); unlike
         upstream the caller's array is not written to."""
         slot = self._overlay_slot(img)
+        ap = self._avg_packed
+        if ap is not None and ap[1] is self.left_avg_x and ap[2] is self.right_avg_x:
+            # the polygon of the averages is still packed where _record_success left it
+            b = ap[0]
+            a = b[4]
+            return self._present(slot, a[7], a[8], a[9] if b[1][0] else None, a[10] if b[1][1] else None, self._lane_text())
         return self._annotate([(self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x)], [self._lane_text()],
                               first=slot)[0]
+
+    def _present_rows(self):
+        """The two runs of camera rows an annotated frame can differ from its camera frame in -- the text lines and the rows the
+        lane can reach (lt_overlay_rows) -- as four int32 {a0, a1, b0, b1}, or None when they cover (nearly) the whole frame."""
+        if "_rows4" not in self.__dict__:
+            self._configure_overlay()
+            H = self.img_size[1]
+            runs = [self._ctx.overlay_rows()]
+            if self._have_font:
+                gh = _overlay.font_atlas()[0].shape[1]
+                runs.append((max(self._TEXT_ORIGIN[1], 0), min(self._TEXT_ORIGIN[1] + 2 * self._TEXT_STEP + gh, H)))   # up to three lines
+            runs = sorted(r for r in runs if r[1] > r[0])
+            if len(runs) == 2 and runs[1][0] <= runs[0][1]:
+                runs = [(runs[0][0], max(runs[0][1], runs[1][1]))]
+            runs += [(H, H)] * (2 - len(runs))
+            rows = np.array([runs[0][0], runs[0][1], runs[1][0], runs[1][1]], np.int32)
+            covered = (rows[1] - rows[0]) + (rows[3] - rows[2])
+            self._rows4 = (rows, rows.ctypes.data, [int(v) for v in rows]) if covered <= 0.8 * H else None
+        return self._rows4
+
+    _TEXT_ORIGIN, _TEXT_STEP = (20, 8), 35          # Context.present_frame / overlay_text defaults
+
+    def _prepare_out(self):
+        """While the device is busy with the frame (another 0.1 ms until its record is there): fetch the page-locked array the
+        annotated frame will land in and copy the rows no overlay can touch from the camera frame the caller handed in -- they
+        are the same bytes, and what the host copies now does not cross the bus later."""
+        H, W = self.img_size[1], self.img_size[0]
+        out = self._out = _native.pinned_empty((1, H, W, 3))
+        self._out_rows = None
+        img = self._resident[0] if self._resident is not None else None
+        rows = self._present_rows() if self.host_copies_rows else None
+        if rows is None or not (isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.shape == (H, W, 3)
+                                and img.flags["C_CONTIGUOUS"]):
+            return
+        a0, a1, b0, b1 = rows[2]
+        frame = out[0]
+        if a0 > 0:
+            frame[:a0] = img[:a0]
+        if b0 > a1:
+            frame[a1:b0] = img[a1:b0]
+        if b1 < H:
+            frame[b1:] = img[b1:]
+        self._out_rows = rows[1]
+
+    host_copies_rows = os.environ.get("LT_HOST_ROWS", "1") != "0"   # False: the whole annotated frame comes back from the device (A/B, tests)
+
+    def _present(self, slot, left_n, right_n, left_yx, right_yx, lines, line_len=40):
+        """Polygon (packed, by address) and text lines onto the frame in `slot` -> the annotated frame."""
+        out, rows, self._out, self._out_rows = self._out, self._out_rows, None, None
+        if out is None:
+            out, rows = _native.pinned_empty((1, self.img_size[1], self.img_size[0], 3)), None
+        if len(lines) > 3:
+            raise ValueError("at most three text lines")
+        text = b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) \
+            if self._have_font and lines else None
+        return self._ctx.present_frame(slot, left_n, right_n, left_yx, right_yx, text, len(lines), line_len, out, rows,
+                                       origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
 
     def print_failure(self, img):
         """The failure message on a copy of the frame (upstream writes into the caller's array, :664-673)."""
         slot = self._overlay_slot(img)
-        empty = np.zeros(0, np.int64)
-        return self._annotate([(empty, empty, empty, empty)], [self._failure_text()], first=slot)[0]
+        zero = self.__dict__.setdefault("_zero_counts", np.zeros(2, np.int32))
+        return self._present(slot, zero.ctypes.data, zero.ctypes.data + 4, None, None, self._failure_text())
 
     def window_mask(self, img, window_width, window_height, center, level, ignore_bottom):
         return _overlay.window_mask(img, window_width, window_height, center, level, ignore_bottom)
@@ -518,8 +625,11 @@ class LaneTracker:
         self.success += 1
         self.left_avg_coeffs = _mean_of_rows([c for c in self.left_fit_coeffs if c.size != 0])
         self.right_avg_coeffs = _mean_of_rows([c for c in self.right_fit_coeffs if c.size != 0])
-        self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x = self.get_poly_points(
-            self.left_avg_coeffs, self.right_avg_coeffs, partial)
+        b = self._points_packed(self.left_avg_coeffs, self.right_avg_coeffs, partial, 'avg')     # = get_poly_points
+        nl, nr, H = int(b[1][0]), int(b[1][1]), self.warped_size[1]
+        self.left_avg_y, self.left_avg_x = np.arange(H - nl, H, dtype=np.int64), b[2][:nl, 1].astype(np.int64)
+        self.right_avg_y, self.right_avg_x = np.arange(H - nr, H, dtype=np.int64), b[3][:nr, 1].astype(np.int64)
+        self._avg_packed = (b, self.left_avg_x, self.right_avg_x)
         self.get_curve_radius()
         self.get_eccentricity()
 
@@ -1023,8 +1133,11 @@ class LaneTracker:
         if self._in_stream:
             raise RuntimeError("process() inside an active process_stream() would overwrite its frames")
         self._slot ^= 1
-        return self._step(img, first_try, n_tries, diagnostics, slot=self._slot, have_mask=False, lazy=True, annotate=True,
-                          visualize_search=visualize_search, split_view=split_view)
+        try:
+            return self._step(img, first_try, n_tries, diagnostics, slot=self._slot, have_mask=False, lazy=True, annotate=True,
+                              visualize_search=visualize_search, split_view=split_view)
+        finally:
+            self._want_out, self._out, self._out_rows = False, None, None
 
     def _batch_arguments(self, kwargs):
         """process()'s keywords with its defaults -> (keyword dict, first-try parameter tuple, filter parameters)."""
@@ -1232,6 +1345,7 @@ class LaneTracker:
         self.valid_lane_lines = False
         left_fit_coeffs = right_fit_coeffs = None
         used = first_try                      # the parameter set of the most recent attempt
+        self._want_out = annotate and defer is None
 
         search_mode = self._find_lane_points_device(img, *first_try, diagnostics, reuse_frame=have_mask, slot=slot,
                                                     have_mask=have_mask, lazy=lazy)

@@ -79,6 +79,11 @@ class FakeContext:
             out[k] = self._slot(first + k)["rec"]
         return out
 
+    def download_record(self, slot):
+        r = self.download_records(1, first=slot)[0]
+        return (np.array(r["left_coeffs"], np.float64), np.array(r["right_coeffs"], np.float64), bool(r["detected"]),
+                int(r["fit_flags"]))
+
     def download_pixels(self, slot, side):
         p = self._slot(slot)["pix"]
         return (p[0], p[1]) if side == 0 else (p[2], p[3])

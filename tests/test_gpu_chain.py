@@ -18,9 +18,12 @@ def _coeffs(rec):
     return np.concatenate([rec["left_coeffs"], rec["right_coeffs"]])
 
 
-@pytest.mark.parametrize("streams", [1, 3])
-def test_chain_records_and_pixels_equal_frame_by_frame_band_search(streams):
+@pytest.mark.parametrize("streams,band_one", [(1, "0"), (3, "0"), (1, "1")])
+def test_chain_records_and_pixels_equal_frame_by_frame_band_search(streams, band_one, monkeypatch):
+    """band_one "0": the frame-by-frame side runs k_band_fit2 (the batch kernel, which a one-frame band search used up to round
+    3); "1" (the default): a one-frame band search is itself a chain of one (launch_band_fit_one)."""
     from lane_tracker_amd import _native, calib, synth
+    monkeypatch.setenv("LT_BAND_ONE", band_one)
     cal = calib.reference_calibration()
     n = 24
     frames = synth.stream_lanes(n, seed=21)
@@ -221,9 +224,11 @@ def test_chain_fuzz_short():
     assert fuzz_chain.main(iters=6, seed=11, verbose=False) == 0
 
 
-@pytest.mark.parametrize("annotate,sizes,every,n_average", [(False, (24, 24, 10, 40, 24, 1, 24), 9, 2), (True, (24, 24, 10, 40, 24, 1, 24), 9, 2),
-                                                            (True, (70, 0, 50, 31), 40, 3), (True, (64, 64), 1000, 1)])
-def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_average):
+@pytest.mark.parametrize("annotate,sizes,every,n_average,band_one",
+                         [(False, (24, 24, 10, 40, 24, 1, 24), 9, 2, "1"), (True, (24, 24, 10, 40, 24, 1, 24), 9, 2, "1"),
+                          (True, (70, 0, 50, 31), 40, 3, "1"), (True, (64, 64), 1000, 1, "1"),
+                          (False, (24, 24, 10, 40, 24, 1, 24), 9, 2, "0")])     # "0": process() searches with k_band_fit2
+def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_average, band_one, monkeypatch):
     """Windows of one video through process_stream (the next window's uploads and masks run while the current one's searches
     drain; windows resident side by side) -- state after every window and the annotated frames equal process();
     a longer window in the middle forces the context to grow; process() inside an active stream is refused.  The long
@@ -231,6 +236,7 @@ def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_
     window in between; an annotated window is handed out while the next one's first searches are already in flight."""
     from lane_tracker_amd import calib
     from lane_tracker_amd.lane_tracker import LaneTracker
+    monkeypatch.setenv("LT_BAND_ONE", band_one)
     cal = calib.reference_calibration()
     frames = _stream_with_failures(sum(sizes), every, seed=37)
     wins, lo = [], 0

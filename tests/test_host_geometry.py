@@ -293,3 +293,59 @@ def test_runs_of_valid_frames_are_recorded_at_once_around_near_straight_frames()
                 assert b._delicate_radii(LF, RF).any() and not b._delicate_radii(LF, RF).all()       # both kinds of stretch occurred
     finally:
         _native.Context = real
+
+
+def _bare_tracker(size=(1280, 720)):
+    t = HostOnlyTracker(size)
+    t.mppv, t.mpph = 30 / 720, 3.7 / 700
+    t.n_average, t.left_fit_coeffs, t.right_fit_coeffs, t.average_curve_radii = 2, [], [], []
+    t.success, t.counter, t.print_frame_count = 0, 0, False
+    return t
+
+
+def test_curve_radius_on_python_floats_is_the_numpy_scalar_value():
+    """get_curve_radius computes on Python floats; upstream (:541-546) on NumPy f64 scalars.  Same doubles, same operations:
+    the integers must agree for every lane, nearly straight ones (huge radii) included."""
+    t = _bare_tracker()
+    rng = np.random.default_rng(11)
+    y_eval, mppv, mpph = t.warped_size[1], t.mppv, t.mpph
+    done = 0
+    for i in range(4000):
+        scale = 10.0 ** rng.uniform(-7.5, -3)
+        lf = np.array([rng.choice([-1, 1]) * scale, rng.uniform(-1.2, 1.2), rng.uniform(0, 1280)])
+        rf = lf + np.array([rng.uniform(-1, 1) * scale * 0.1, rng.uniform(-0.05, 0.05), rng.uniform(100, 300)])
+        want = []
+        for c in (lf, rf):
+            fit_m = (c[0] * mpph / (mppv ** 2), c[1] * mpph / mppv)
+            want.append(int(((1 + (2 * fit_m[0] * y_eval * mppv + fit_m[1]) ** 2) ** 1.5) / np.absolute(2 * fit_m[0])))
+        t._fit = ("pending", None, lf, rf)
+        try:
+            t.get_curve_radius()
+        except AttributeError:      # within 1e-8 of an integer: the lane pixels are refitted (needs a device), not this test's case
+            continue
+        done += 1
+        assert [t.left_curve_radius, t.right_curve_radius] == want, (i, lf, rf)
+    assert done > 3000
+
+
+def test_record_success_keeps_the_points_of_get_poly_points():
+    """_record_success takes the plot points of the averaged parabolas from lt_poly_points (packed, ready for the overlay);
+    the public attributes must be what get_poly_points returns for them."""
+    t = _bare_tracker((1280, 720))
+    rng = np.random.default_rng(12)
+    for i in range(300):
+        lf = np.array([rng.uniform(-6e-4, 6e-4), rng.uniform(-1.2, 1.2), rng.uniform(-200, 1300)])
+        rf = lf + np.array([rng.uniform(-1e-4, 1e-4), rng.uniform(-0.2, 0.2), rng.uniform(-60, 400)])
+        partial = (1, 1.0, 0.5, 0.3)[i % 4]
+        t._fit = ("pending", None, lf, rf)
+        try:
+            t._record_success(lf, rf, partial)
+        except IndexError:          # no plot point inside the image: get_eccentricity fails upstream as well (:553)
+            pass
+        want = t.get_poly_points(t.left_avg_coeffs, t.right_avg_coeffs, partial)
+        got = (t.left_avg_y, t.left_avg_x, t.right_avg_y, t.right_avg_x)
+        assert all(np.array_equal(g, w) and g.dtype == w.dtype for g, w in zip(got, want)), (i, partial)
+        b = t._avg_packed[0]
+        assert (int(b[1][0]), int(b[1][1])) == (len(want[0]), len(want[2]))
+        assert np.array_equal(b[2][:len(want[0])], np.stack([want[0], want[1]], 1))
+        assert np.array_equal(b[3][:len(want[2])], np.stack([want[2], want[3]], 1))

@@ -17,9 +17,21 @@ def wrap(obj, name):
     def w(*a, **k):
         t0 = time.perf_counter(); r = fn(*a, **k); acc[name] += time.perf_counter() - t0; cnt[name] += 1; return r
     setattr(obj, name, w)
-for name in ("upload_frame_rows", "upload_frame_rest", "mask_run", "sws_fit_run", "band_fit_run", "download_records", "overlay_run", "overlay_text", "download_overlay", "download_pixels"):
+for name in ("upload_frame_rows", "upload_frame_rest", "mask_run", "sws_fit_run", "band_fit_run", "download_record", "present_frame",
+             "download_pixels"):
     wrap(lt._ctx, name)
-for name in ("_record_success", "check_validity", "get_poly_points", "get_curve_radius", "_lane_text"):
+class Lib:                                   # the library calls themselves, without their Python wrappers
+    def __init__(self, lib):
+        self._lib = lib
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in ("lt_present_frame", "lt_download_records"):
+            return fn
+        def w(*a):
+            t0 = time.perf_counter(); r = fn(*a); acc[" " + name] += time.perf_counter() - t0; cnt[" " + name] += 1; return r
+        return w
+lt._ctx.lib = Lib(lt._ctx.lib)
+for name in ("_record_success", "check_validity", "_points_packed", "get_curve_radius", "_lane_text", "_present", "_prepare_out"):
     wrap(lt, name)
 n = len(frames) - 8
 t0 = time.perf_counter()
