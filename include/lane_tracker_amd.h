@@ -134,6 +134,10 @@ int  lt_upload_frame_rows_async(lt_ctx* ctx, const uint8_t* frames_rgb, int firs
  * the mask chain (call it after lt_mask_run).  The host buffer must stay valid until the next lt_sync or download;
  * lt_overlay_run waits for it. */
 int  lt_upload_frame_rest(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
+/* Of that complement, only the rows inside the two runs rows4 = {a0, a1, b0, b1} (NULL: all of it, as above): what
+ * lt_present_frame with the same runs reads.  The other rows of the slots keep whatever they held -- an overlay over the whole
+ * frame needs lt_upload_frame_rest first. */
+int  lt_upload_frame_rest_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n, const int32_t* rows4);
 /* masks: n * warp_h * warp_w bytes; lets the search stages run on caller-supplied binary images */
 int  lt_upload_masks(lt_ctx* ctx, const uint8_t* masks, int first_slot, int n);
 int  lt_download_masks(lt_ctx* ctx, int first_slot, int n, uint8_t* masks);
@@ -258,6 +262,16 @@ int  lt_overlay_rows(lt_ctx* ctx, int* row0, int* row1);
 int  lt_present_frame(lt_ctx* ctx, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                       const int32_t* right_yx, double alpha, const char* lines, int n_lines, int line_len, int x0, int y0,
                       int step, uint8_t* out, const int32_t* rows4);
+/* lt_present_frame in two halves, for a caller that knows the polygon before it knows the text (radius, eccentricity and the
+ * verdict on the frame take LaneTracker.process() another 25 us of host work behind the record).  lt_present_lane_async draws
+ * both row runs (rows4 is required: the text lines in the first run, lt_overlay_rows in the second, the two apart) and sends the
+ * second run on its way without waiting; lt_present_finish blends the text into the first run, sends it and waits for both.  A
+ * first half that turns out to be for nothing (the frame was invalid) is followed by a whole lt_present_frame on the same slot
+ * and `out`, which draws and sends everything again. */
+int  lt_present_lane_async(lt_ctx* ctx, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                           const int32_t* right_yx, double alpha, uint8_t* out, const int32_t* rows4);
+int  lt_present_finish(lt_ctx* ctx, int slot, const char* lines, int n_lines, int line_len, int x0, int y0, int step,
+                       uint8_t* out, const int32_t* rows4);
 /* Host-only helper (no GPU needed): the (lo, hi) column interval per bird's-eye row that cv2.fillPoly
  * paints for that polygon; empty rows are (32767, -32768).  spans: warp_h * 2 int16. */
 int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,

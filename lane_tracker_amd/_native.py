@@ -78,6 +78,7 @@ _SIGNATURES = {
     "lt_upload_frame_rows": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_frame_rows_async": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_frame_rest": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_upload_frame_rest_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "lt_upload_masks": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_download_masks": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_plane": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
@@ -93,6 +94,8 @@ _SIGNATURES = {
     "lt_overlay_text": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_overlay_rows": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lt_present_frame": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "lt_present_lane_async": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P]),
+    "lt_present_finish": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "lt_download_overlay": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_overlay_async": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -389,11 +392,15 @@ class Context:
         _check(self.lib.lt_upload_frame_rows_async(self._h, f.ctypes.data, first, f.shape[0]))
         return f
 
-    def upload_frame_rest(self, frames, first=0):
-        """The rows upload_frame_rows left out, on a copy stream beside the compute streams (for the overlay).
-        Returns the array actually handed to the library: keep it alive until the next sync() / download."""
+    def upload_frame_rest(self, frames, first=0, rows=None):
+        """The rows upload_frame_rows left out, on a copy stream beside the compute streams (for the overlay); with `rows` (the
+        ADDRESS of four int32 {a0, a1, b0, b1}) only those of them inside the two runs -- what present_frame with the same runs
+        reads.  Returns the array actually handed to the library: keep it alive until the next sync() / download."""
         f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
-        _check(self.lib.lt_upload_frame_rest(self._h, f.ctypes.data, first, f.shape[0]))
+        if rows is None:
+            _check(self.lib.lt_upload_frame_rest(self._h, f.ctypes.data, first, f.shape[0]))
+        else:
+            _check(self.lib.lt_upload_frame_rest_rows(self._h, f.ctypes.data, first, f.shape[0], rows))
         return f
 
     def upload_frames(self, frames, first=0):
@@ -531,6 +538,20 @@ class Context:
         the frame lands in, rows None or the ADDRESS of four int32 {a0, a1, b0, b1}: only these two runs of rows are written."""
         rc = self.lib.lt_present_frame(self._h, slot, left_n, right_n, left_yx, right_yx, alpha, text, n_lines, line_len, origin[0],
                                        origin[1], step, out.ctypes.data, rows)
+        if rc:
+            _check(rc)
+        return out
+
+    def present_lane_async(self, slot, left_n, right_n, left_yx, right_yx, out, rows, alpha=0.3):
+        """First half of present_frame (lt_present_lane_async): the polygon drawn, the rows the lane can reach on their way into
+        `out`; no wait.  `rows` (address of four int32) is required."""
+        rc = self.lib.lt_present_lane_async(self._h, slot, left_n, right_n, left_yx, right_yx, alpha, out.ctypes.data, rows)
+        if rc:
+            _check(rc)
+
+    def present_finish(self, slot, text, n_lines, line_len, out, rows, origin=(20, 8), step=35):
+        """Second half (lt_present_finish): the text lines, their rows into `out`, and the wait for both halves."""
+        rc = self.lib.lt_present_finish(self._h, slot, text, n_lines, line_len, origin[0], origin[1], step, out.ctypes.data, rows)
         if rc:
             _check(rc)
         return out

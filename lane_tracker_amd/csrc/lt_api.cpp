@@ -1164,6 +1164,36 @@ static int rest_mark(lt_ctx* c, int first, int n) {
     return note_range(c->rests, c->copy, first, first + n);
 }
 
+int lt_upload_frame_rest_rows(lt_ctx* c, const uint8_t* frames, int first, int n, const int32_t* rows4) {
+    if (!rows4) return lt_upload_frame_rest(c, frames, first, n);
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!frames) return fail(LT_ERR_INVALID, "null frames");
+    const int H = c->calib.img_h;
+    if (!(0 <= rows4[0] && rows4[0] <= rows4[1] && rows4[1] <= rows4[2] && rows4[2] <= rows4[3] && rows4[3] <= H))
+        return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
+    if (n == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    {
+        bool precise = true;
+        if ((rc = wait_range(c->readers, c->copy, first, first + n, &precise))) return rc;
+        if (!precise && (rc = wait_reader_tails(c, c->copy))) return rc;
+    }
+    // of the two runs, the rows lt_upload_frame_rows has not brought: below the window of rows the path reads, and above it
+    const size_t row_bytes = (size_t)c->calib.img_w * 3;
+    const int lo = c->cam_r1 > c->cam_r0 ? c->cam_r0 : 0, hi = c->cam_r1 > c->cam_r0 ? c->cam_r1 : 0;
+    uint8_t* dst = c->d_frames + (size_t)first * c->frame_bytes;
+    for (int k = 0; k < 4; k += 2) {
+        const int piece[2][2] = {{rows4[k], std::min(rows4[k + 1], lo)}, {std::max(rows4[k], hi), rows4[k + 1]}};
+        for (const auto& pc : piece) {
+            if (pc[1] <= pc[0]) continue;
+            const size_t off = (size_t)pc[0] * row_bytes, bytes = (size_t)(pc[1] - pc[0]) * row_bytes;
+            HIP_TRY(hipMemcpy2DAsync(dst + off, c->frame_bytes, frames + off, c->frame_bytes, bytes, (size_t)n, hipMemcpyHostToDevice, c->copy));
+        }
+    }
+    return rest_mark(c, first, n);
+}
+
 int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -1800,6 +1830,37 @@ int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
 // frame): a pixel outside the rows the lane can reach (lt_overlay_rows) and outside the text lines is the camera pixel, which
 // the caller has -- process() copies those rows from its input while the device is busy, and only half the frame crosses the
 // bus behind the overlay.  The runs must cover the text lines and, for a non-empty polygon, lt_overlay_rows.
+static int present_copy_rows(lt_ctx* c, int slot, uint8_t* out, int row0, int row1) {
+    if (row1 <= row0) return LT_OK;
+    const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)row0 * row_bytes, bytes = (size_t)(row1 - row0) * row_bytes;
+    const uint8_t* src = c->d_annot + (size_t)slot * c->frame_bytes;
+    if (!launch_copy_to_pinned(c->present, out + off, src + off, bytes))
+        HIP_TRY(hipMemcpyAsync(out + off, src + off, bytes, hipMemcpyDeviceToHost, c->present));
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+// rows4 -> r[4] (nullptr: the whole frame as the first run); `split`: the text lines must lie in the first run and the rows the
+// lane can reach in the second, the two apart -- the condition for drawing and sending the second run before the text exists
+static int present_rows(lt_ctx* c, const int32_t* rows4, bool text, int n_lines, int y0, int step, bool lane, bool split, int r[4]) {
+    const int H = c->calib.img_h;
+    r[0] = 0; r[1] = H; r[2] = H; r[3] = H;
+    if (!rows4) return split ? fail(LT_ERR_INVALID, "two row runs are needed") : (int)LT_OK;
+    for (int k = 0; k < 4; ++k) r[k] = rows4[k];
+    if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= H))
+        return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
+    auto within = [&](int lo, int hi, int a, int b) { lo = std::max(lo, 0); hi = std::min(hi, H); return lo >= hi || (a <= lo && hi <= b); };
+    const int t0 = y0, t1 = y0 + (n_lines - 1) * step + c->font_gh;
+    if (split) {
+        if (text && !within(t0, t1, r[0], r[1])) return fail(LT_ERR_INVALID, "the first row run does not cover the text lines");
+        if (!within(c->ov_r0, c->ov_r1, r[2], r[3])) return fail(LT_ERR_INVALID, "the second row run does not cover the rows the lane can reach (lt_overlay_rows)");
+        return LT_OK;
+    }
+    auto covered = [&](int lo, int hi) { return within(lo, hi, r[0], r[1]) || within(lo, hi, r[2], r[3]) || (r[1] == r[2] && within(lo, hi, r[0], r[3])); };
+    if (text && !covered(t0, t1)) return fail(LT_ERR_INVALID, "the row runs do not cover the text lines");
+    if (lane && !covered(c->ov_r0, c->ov_r1)) return fail(LT_ERR_INVALID, "the row runs do not cover the rows the lane can reach (lt_overlay_rows)");
+    return LT_OK;
+}
+
 int lt_present_frame(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx, const int32_t* right_yx,
                      double alpha, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
                      const int32_t* rows4) {
@@ -1808,33 +1869,47 @@ int lt_present_frame(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* 
     if (!out) return fail(LT_ERR_INVALID, "null output buffer");
     if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
     if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_frame before lt_overlay_configure");
-    const int H = c->calib.img_h;
     const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
-    int r[4] = {0, H, H, H};
-    if (rows4) {
-        for (int k = 0; k < 4; ++k) r[k] = rows4[k];
-        if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= H))
-            return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
-        auto covered = [&](int lo, int hi) {
-            lo = std::max(lo, 0);
-            hi = std::min(hi, H);
-            return lo >= hi || (r[0] <= lo && hi <= r[1]) || (r[2] <= lo && hi <= r[3]) || (r[1] == r[2] && r[0] <= lo && hi <= r[3]);
-        };
-        if (text && !covered(y0, y0 + (n_lines - 1) * step + c->font_gh)) return fail(LT_ERR_INVALID, "the row runs do not cover the text lines");
-        if ((left_n[0] > 0 || right_n[0] > 0) && !covered(c->ov_r0, c->ov_r1))
-            return fail(LT_ERR_INVALID, "the row runs do not cover the rows the lane can reach (lt_overlay_rows)");
-    }
+    int r[4];
+    if ((rc = present_rows(c, rows4, text, n_lines, y0, step, left_n[0] > 0 || right_n[0] > 0, false, r))) return rc;
     if ((rc = overlay_run_impl(c, slot, 1, left_n, right_n, left_yx, right_yx, alpha, rows4 ? r : nullptr))) return rc;
     if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
-    const size_t row_bytes = (size_t)c->calib.img_w * 3;
-    const uint8_t* src = c->d_annot + (size_t)slot * c->frame_bytes;
-    for (int k = 0; k < 4; k += 2) {
-        if (r[k + 1] <= r[k]) continue;
-        const size_t off = (size_t)r[k] * row_bytes, bytes = (size_t)(r[k + 1] - r[k]) * row_bytes;
-        if (!launch_copy_to_pinned(c->present, out + off, src + off, bytes))
-            HIP_TRY(hipMemcpyAsync(out + off, src + off, bytes, hipMemcpyDeviceToHost, c->present));
-    }
-    HIP_TRY(hipGetLastError());
+    if ((rc = present_copy_rows(c, slot, out, r[0], r[1]))) return rc;
+    if ((rc = present_copy_rows(c, slot, out, r[2], r[3]))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->present));
+    return LT_OK;
+}
+
+// lt_present_frame in two halves, for a caller that knows the polygon before it knows the text (LaneTracker.process(): the
+// averaged curves follow from the record at once, radius, eccentricity and the verdict on the frame take the host another
+// 25 us): the first half draws both row runs and sends the second one -- the rows the lane can reach -- on its way without
+// waiting; the second half blends the text into the first run, sends that and waits for both.  A first half whose frame turns
+// out invalid is simply followed by a whole lt_present_frame (same slot, same `out`): it draws and sends everything again.
+int lt_present_lane_async(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                          const int32_t* right_yx, double alpha, uint8_t* out, const int32_t* rows4) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_lane_async before lt_overlay_configure");
+    int r[4];
+    if ((rc = present_rows(c, rows4, false, 0, 0, 0, true, true, r))) return rc;
+    if ((rc = overlay_run_impl(c, slot, 1, left_n, right_n, left_yx, right_yx, alpha, r))) return rc;
+    return present_copy_rows(c, slot, out, r[2], r[3]);
+}
+
+int lt_present_finish(lt_ctx* c, int slot, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
+                      const int32_t* rows4) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!c->d_annot || !c->present) return fail(LT_ERR_STATE, "lt_present_finish before lt_present_lane_async");
+    const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
+    int r[4];
+    if ((rc = present_rows(c, rows4, text, n_lines, y0, step, false, true, r))) return rc;
+    if ((rc = set_device(c))) return rc;
+    if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
+    if ((rc = present_copy_rows(c, slot, out, r[0], r[1]))) return rc;
     HIP_TRY(hipStreamSynchronize(c->present));
     return LT_OK;
 }

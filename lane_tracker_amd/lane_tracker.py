@@ -449,7 +449,7 @@ class LaneTracker:
         if self._resident is not None and self._resident[0] is img:
             return self._resident[1]
         self._ctx.upload_frames(img, first=0)
-        self._resident = (img, 0)
+        self._resident, self._resident_partial = (img, 0), False
         return 0
 
     def draw_lane(self, img):
@@ -462,7 +462,8 @@ class LaneTracker:
             # the polygon of the averages is still packed where _record_success left it
             b = ap[0]
             a = b[4]
-            return self._present(slot, a[7], a[8], a[9] if b[1][0] else None, a[10] if b[1][1] else None, self._lane_text())
+            return self._present(slot, a[7], a[8], a[9] if b[1][0] else None, a[10] if b[1][1] else None, self._lane_text(),
+                                 drawn=self._lane_in_flight is b)
         return self._annotate([(self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x)], [self._lane_text()],
                               first=slot)[0]
 
@@ -495,9 +496,8 @@ class LaneTracker:
         out = self._out = _native.pinned_empty((1, H, W, 3))
         self._out_rows = None
         img = self._resident[0] if self._resident is not None else None
-        rows = self._present_rows() if self.host_copies_rows else None
-        if rows is None or not (isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.shape == (H, W, 3)
-                                and img.flags["C_CONTIGUOUS"]):
+        rows = self._rows_for(img)
+        if rows is None:
             return
         a0, a1, b0, b1 = rows[2]
         frame = out[0]
@@ -509,17 +509,34 @@ class LaneTracker:
             frame[b1:] = img[b1:]
         self._out_rows = rows[1]
 
+    def _rows_for(self, img):
+        """_present_rows() when `img` is a frame whose rows the host can copy as they are, else None."""
+        if not self.host_copies_rows or not (isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.flags["C_CONTIGUOUS"]
+                                             and img.shape == (self.img_size[1], self.img_size[0], 3)):
+            return None
+        return self._present_rows()
+
+    _resident_partial = False   # of the resident frame only the rows process() reads and presents are on the device
+
     host_copies_rows = os.environ.get("LT_HOST_ROWS", "1") != "0"   # False: the whole annotated frame comes back from the device (A/B, tests)
 
-    def _present(self, slot, left_n, right_n, left_yx, right_yx, lines, line_len=40):
-        """Polygon (packed, by address) and text lines onto the frame in `slot` -> the annotated frame."""
-        out, rows, self._out, self._out_rows = self._out, self._out_rows, None, None
+    def _present(self, slot, left_n, right_n, left_yx, right_yx, lines, line_len=40, drawn=False):
+        """Polygon (packed, by address) and text lines onto the frame in `slot` -> the annotated frame.  drawn: _lane_ahead has
+        drawn this polygon and sent its rows already; the text lines are what is left."""
+        out, rows, self._out, self._out_rows, self._lane_in_flight = self._out, self._out_rows, None, None, None
         if out is None:
             out, rows = _native.pinned_empty((1, self.img_size[1], self.img_size[0], 3)), None
         if len(lines) > 3:
             raise ValueError("at most three text lines")
+        if rows is None and self._resident_partial and self._resident is not None:
+            # the whole frame is wanted after all (draw_lane() by hand on the frame process() has just seen): bring the rest
+            self._upload_keepalive = self._ctx.upload_frame_rest(self._resident[0], first=slot)
+            self._resident_partial = False
         text = b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) \
             if self._have_font and lines else None
+        if drawn and out is not None and rows is not None:
+            return self._ctx.present_finish(slot, text, len(lines), line_len, out, rows, origin=self._TEXT_ORIGIN,
+                                            step=self._TEXT_STEP)[0]
         return self._ctx.present_frame(slot, left_n, right_n, left_yx, right_yx, text, len(lines), line_len, out, rows,
                                        origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
 
@@ -585,7 +602,10 @@ class LaneTracker:
             ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
                                                   ksize_noise, C_noise), first=slot)
         if not reuse_frame:
-            self._upload_keepalive = ctx.upload_frame_rest(img, first=slot)
+            # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
+            rows = self._rows_for(img) if self._want_out else None
+            self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
+            self._resident_partial = rows is not None
         if self.last_detection > self.n_reset:                       # :851
             if diagnostics:
                 print("Using sliding window search.")
@@ -613,7 +633,35 @@ class LaneTracker:
             self.average_curve_radii.pop(0)
         self.last_detection += 1
 
-    def _record_success(self, left_fit_coeffs, right_fit_coeffs, partial):
+    def _averages_with(self, left_fit_coeffs, right_fit_coeffs):
+        """left_avg_coeffs / right_avg_coeffs as _record_success would leave them for this fit (nothing is changed)."""
+        L, R = self.left_fit_coeffs + [left_fit_coeffs], self.right_fit_coeffs + [right_fit_coeffs]
+        if len(L) > self.n_average:
+            L, R = L[1:], R[1:]
+        return _mean_of_rows([c for c in L if c.size != 0]), _mean_of_rows([c for c in R if c.size != 0])
+
+    speculates_lane = os.environ.get("LT_LANE_AHEAD", "1") != "0"   # False: the lane is drawn once the frame is known to be valid (A/B, tests)
+    _lane_in_flight = None      # the packed-point buffers whose polygon lt_present_lane_async is drawing / has drawn for this frame
+
+    def _lane_ahead(self, left_fit_coeffs, right_fit_coeffs, partial, slot):
+        """The averaged curves this frame will have IF it is valid follow from its fit alone; whether it is valid, its radius and
+        eccentricity take the host another 25 us.  So the polygon is drawn and the rows it can reach sent on their way now
+        (lt_present_lane_async); a valid frame -- nearly all of a video -- only adds the text lines (lt_present_finish), an invalid
+        one has everything drawn again by whatever is presented in the end.  -> (left average, right average, point buffers)."""
+        la, ra = self._averages_with(left_fit_coeffs, right_fit_coeffs)
+        # two buffer sets: the polygon of the last valid frame (redrawn on failures) must survive a speculation that fails
+        keep = self._avg_packed[0] if self._avg_packed is not None else None
+        purpose = 'avg1' if keep is not None and keep is self.__dict__.get("_packed", {}).get((partial, 'avg0')) else 'avg0'
+        b = self._points_packed(la, ra, partial, purpose)
+        if b is keep:
+            return None
+        self._configure_overlay()
+        a = b[4]
+        self._ctx.present_lane_async(slot, a[7], a[8], a[9] if b[1][0] else None, a[10] if b[1][1] else None, self._out, self._out_rows)
+        self._lane_in_flight = b
+        return la, ra, b
+
+    def _record_success(self, left_fit_coeffs, right_fit_coeffs, partial, ahead=None):
         self.left_fit_coeffs.append(left_fit_coeffs)
         self.right_fit_coeffs.append(right_fit_coeffs)
         self.last_left_coeffs = left_fit_coeffs
@@ -623,9 +671,14 @@ class LaneTracker:
             self.right_fit_coeffs.pop(0)
         self.last_detection = 0
         self.success += 1
-        self.left_avg_coeffs = _mean_of_rows([c for c in self.left_fit_coeffs if c.size != 0])
-        self.right_avg_coeffs = _mean_of_rows([c for c in self.right_fit_coeffs if c.size != 0])
-        b = self._points_packed(self.left_avg_coeffs, self.right_avg_coeffs, partial, 'avg')     # = get_poly_points
+        if ahead is not None:       # _lane_ahead has formed the averages and their plot points already
+            self.left_avg_coeffs, self.right_avg_coeffs, b = ahead
+        else:
+            self.left_avg_coeffs = _mean_of_rows([c for c in self.left_fit_coeffs if c.size != 0])
+            self.right_avg_coeffs = _mean_of_rows([c for c in self.right_fit_coeffs if c.size != 0])
+            keep = self._avg_packed[0] if self._avg_packed is not None else None
+            purpose = 'avg1' if keep is not None and keep is self.__dict__.get("_packed", {}).get((partial, 'avg0')) else 'avg0'
+            b = self._points_packed(self.left_avg_coeffs, self.right_avg_coeffs, partial, purpose)     # = get_poly_points
         nl, nr, H = int(b[1][0]), int(b[1][1]), self.warped_size[1]
         self.left_avg_y, self.left_avg_x = np.arange(H - nl, H, dtype=np.int64), b[2][:nl, 1].astype(np.int64)
         self.right_avg_y, self.right_avg_x = np.arange(H - nr, H, dtype=np.int64), b[3][:nr, 1].astype(np.int64)
@@ -886,7 +939,7 @@ class LaneTracker:
             last = (end, t, r)
         if committed:
             jl = committed - 1
-            self._resident = (frames[i + jl], base + i + jl)
+            self._resident, self._resident_partial = (frames[i + jl], base + i + jl), False
         if last is not None:
             j, t, r = last
             if t == 0 and rec2 is not None and j < e2:
@@ -1065,7 +1118,7 @@ class LaneTracker:
                 lf, rf = np.array(LF[j], np.float64), np.array(RF[j], np.float64)
                 self._pending = (ctx, base + first + j)
                 self._fit = ("pending", None, lf, rf)
-                self._resident = (frames[first + j], base + first + j)
+                self._resident, self._resident_partial = (frames[first + j], base + first + j), False
                 self._record_success(lf, rf, partial)
                 if annotate:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
@@ -1137,6 +1190,9 @@ class LaneTracker:
             return self._step(img, first_try, n_tries, diagnostics, slot=self._slot, have_mask=False, lazy=True, annotate=True,
                               visualize_search=visualize_search, split_view=split_view)
         finally:
+            if self._lane_in_flight is not None:     # an exception between the two halves: the copy into _out may still be running
+                self._lane_in_flight = None
+                self._ctx.sync()
             self._want_out, self._out, self._out_rows = False, None, None
 
     def _batch_arguments(self, kwargs):
@@ -1349,11 +1405,16 @@ class LaneTracker:
 
         search_mode = self._find_lane_points_device(img, *first_try, diagnostics, reuse_frame=have_mask, slot=slot,
                                                     have_mask=have_mask, lazy=lazy)
+        spec = None
         if self.detected_pixels:
             left_fit_coeffs, right_fit_coeffs = self.fit_poly()
+            if self._out_rows is not None and self.speculates_lane:
+                spec = self._lane_ahead(left_fit_coeffs, right_fit_coeffs, partial, slot)
             self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
             if diagnostics and self.valid_lane_lines:
                 print("Success at first attempt!")
+            if not self.valid_lane_lines:
+                spec = self._lane_in_flight = None      # drawn for nothing: whatever is presented later draws everything again
 
         if ((not self.detected_pixels) or (not self.valid_lane_lines)) and ((n_tries >= 2) or (n_tries == -1)):
             if diagnostics:
@@ -1407,7 +1468,7 @@ class LaneTracker:
             return present(self.draw_lane(img) if redraw else self.print_failure(img))
 
         # success (:1178-1209)
-        self._record_success(left_fit_coeffs, right_fit_coeffs, partial)
+        self._record_success(left_fit_coeffs, right_fit_coeffs, partial, spec)
         if not annotate:
             return None
         if defer is not None:

@@ -67,7 +67,7 @@ class FakeContext:
         self.upload_frame_rows(frames, first)
         return frames
 
-    def upload_frame_rest(self, frames, first=0):
+    def upload_frame_rest(self, frames, first=0, rows=None):
         return frames
 
     def download_masks(self, n, first=0):
