@@ -31,7 +31,10 @@ extern "C" {
 
 /* 2: + lt_gather_*, lt_band_fit_chain_run, lt_calib_*, lt_upload_frame_rows_async & co.; lt_debug_cycles removed;
  *    lt_last_threshold_path(NULL) returns LT_NO_CONTEXT instead of -1. */
-#define LT_ABI_VERSION 2
+/* 3: + lt_present_frame, lt_present_lane_async, lt_present_finish, lt_overlay_rows, lt_upload_frame_rest_rows (one frame per
+ *    call, the host waiting: LaneTracker.process()), lt_set_download_method, lt_download_stats, lt_device_cache_trim,
+ *    lt_last_adaptive_path.  Nothing removed or changed. */
+#define LT_ABI_VERSION 3
 
 typedef enum lt_status {
     LT_OK = 0,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LANE_TRACKER_AMD_LIB: load another build of the same library (tools/toolchain_cases.sh compares variant builds)
 LIB_PATH = os.environ.get("LANE_TRACKER_AMD_LIB") or os.path.join(_HERE, "liblane_tracker_amd.so")
 NUM_STAGES = 12
-ABI_VERSION = 2          # LT_ABI_VERSION of include/lane_tracker_amd.h this table was written against
+ABI_VERSION = 3          # LT_ABI_VERSION of include/lane_tracker_amd.h this table was written against
 
 PLANE_R, PLANE_LAB_B, PLANE_TOPHAT_R, PLANE_TOPHAT_B, PLANE_MERGED, PLANE_MASK = range(6)
 
