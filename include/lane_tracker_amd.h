@@ -33,7 +33,7 @@ extern "C" {
  *    lt_last_threshold_path(NULL) returns LT_NO_CONTEXT instead of -1. */
 /* 3: + lt_present_frame, lt_present_lane_async, lt_present_finish, lt_overlay_rows, lt_upload_frame_rest_rows (one frame per
  *    call, the host waiting: LaneTracker.process()), lt_set_download_method, lt_download_stats, lt_device_cache_trim,
- *    lt_last_adaptive_path.  Nothing removed or changed. */
+ *    lt_last_adaptive_path, lt_host_copy_async, lt_host_copy_wait.  Nothing removed or changed. */
 #define LT_ABI_VERSION 3
 
 typedef enum lt_status {
@@ -307,6 +307,12 @@ int  lt_download_stats(lt_ctx* ctx, double* engine_gbs, int* engine_copies, doub
  * memory run at a fraction of the PCIe rate).  Needs a GPU; lt_host_free(NULL) is a no-op.  The reference has no
  * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */
 int  lt_host_alloc(size_t bytes, void** out);
+/* Plain host-to-host copies on a second host thread of the library (one per process), for a caller that has launches to issue
+ * meanwhile: LaneTracker.process() fills the rows of its output that no overlay can touch from the camera frame this way.
+ * lt_host_copy_async returns at once; both buffers must stay valid until lt_host_copy_wait() has returned, which is when every
+ * copy requested so far (by any thread) is complete. */
+int  lt_host_copy_async(void* dst, const void* src, size_t bytes);
+int  lt_host_copy_wait(void);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact
  * size, and reused by later allocations; it returns to the driver when more than LT_DEVICE_CACHE_GB (default: an eighth of the

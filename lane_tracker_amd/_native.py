@@ -102,6 +102,8 @@ _SIGNATURES = {
     "lt_download_bev": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "lt_host_free": (C.c_int, [_P]),
+    "lt_host_copy_async": (C.c_int, [_P, _P, C.c_size_t]),
+    "lt_host_copy_wait": (C.c_int, []),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),

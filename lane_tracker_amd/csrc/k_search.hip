@@ -1181,7 +1181,10 @@ constexpr int CT = 512;           // threads of k_band_chain3
 constexpr int C3_VALUES = 18;     // per side: 8 moments + (rows << 32 | pixels)
 __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, const lt_lane_record* __restrict__ seed_rec, BandPrev seed,
                                                    uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int n,
-                                                   const int* cancel_epoch, int my_epoch, int prio, int ablate_arg) {
+                                                   const int* cancel_epoch, int my_epoch, int prio, int ablate_arg,
+                                                   lt_lane_record* __restrict__ mirror) {
+    // mirror (a chain of one, launch_band_fit_one): page-locked host memory that gets a copy of the record, so that the host
+    // reads it as soon as this kernel has ended
     // Timing probes of tools/stream_interference.py, in a build with -DLT_CHAIN_PROBES only (WRONG results): ablate bit 1 no
     // pixel-block stores, 2 no bit-plane loads, 4 no f64 band evaluation, 8 no solve, 16 no reduction; prio = wave priority.
     // The product build compiles them out (ablate is the constant 0, the priority the constant 3).
@@ -1315,6 +1318,7 @@ __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, c
             r._pad = 2;               // per-row column masks (k_band_fit2's format)
             r.frame = recs[f].frame;  // keep the caller's tag
             recs[f] = r;
+            if (mirror) mirror[f] = r;
             for (int k = 0; k < 3; ++k) { carry[k] = r.left_coeffs[k]; carry[3 + k] = r.right_coeffs[k]; }
             carry[6] = detected && flags == 0 ? 1.0 : 0.0;
         }
@@ -1486,14 +1490,15 @@ bool band_chain_supported(const SearchGeom& g, size_t mask_stride) { return band
 // The band search of ONE frame around coefficients given by value, by the chain kernel with a chain of one: k_band_chain3 is
 // built around the latency of a single workgroup (8 us per frame against k_band_fit2's 22 for one frame; record and pixel
 // block are the same, tests/test_gpu_chain.py), which is what process() -- one frame per call, the host waiting -- pays for.
-// `zero` = any readable device word (the chain's cancel flag; a chain of one never looks at it again).  false: not launched.
+// `zero` = any readable device word (the chain's cancel flag; a chain of one never looks at it again); `mirror` = nullptr or
+// device-visible page-locked memory for a copy of the record.  false: not launched.
 bool launch_band_fit_one(hipStream_t s, MaskBits mb, SearchGeom g, const BandPrev& bp, uint32_t* pix, lt_lane_record* rec,
-                         size_t mask_stride, const int* zero) {
+                         size_t mask_stride, const int* zero, lt_lane_record* mirror) {
     static const bool big3 = allow_big_lds(k_band_chain3);
     if (!mb.bits || !bp.by_value || !big3 || g.h > 8192 || !band2_eligible(g, mask_stride)) return false;
     const size_t lds3 = (size_t)C3_VALUES * CT * sizeof(long long);
     hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, (const lt_lane_record*)nullptr, bp, pix, rec, 1, zero, 0x7fffffff,
-                       3, 0);
+                       3, 0, mirror);
     return true;
 }
 
@@ -1513,7 +1518,8 @@ void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, 
 #else
         constexpr int prio = 3, ablate = 0;
 #endif
-        hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, seed_rec, seed, pix, rec, n, cancel_epoch, my_epoch, prio, ablate);
+        hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, seed_rec, seed, pix, rec, n, cancel_epoch, my_epoch, prio, ablate,
+                           (lt_lane_record*)nullptr);
         return;
     }
     if (mb.bits) hipLaunchKernelGGL(k_band_chain2<true>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);

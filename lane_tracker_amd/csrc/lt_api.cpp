@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -1804,6 +1806,64 @@ int lt_host_free(void* p) {
     return LT_OK;
 }
 
+// ---- a second host thread for plain copies -------------------------------------------------------------------------------
+// LaneTracker.process() fills the rows of its output array that no overlay can touch from the caller's frame (1.4 MB at
+// 1280x720, 3.2 MB at 1920x1080: 60 / 130 us of memcpy).  The thread that feeds the device has launches to issue meanwhile;
+// this one has nothing else to do.  One worker per process, started at the first request, joined when the library is unloaded.
+extern "C++" {
+namespace {
+struct HostCopier {
+    struct Job { void* dst; const void* src; size_t bytes; };
+    std::mutex m;
+    std::condition_variable work, done;
+    std::deque<Job> q;
+    size_t pending = 0;          // requests taken and not finished yet
+    bool stop = false;
+    std::thread th;
+    void run() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            work.wait(lk, [&] { return stop || !q.empty(); });
+            if (q.empty()) return;               // stop
+            const Job j = q.front();
+            q.pop_front();
+            lk.unlock();
+            std::memcpy(j.dst, j.src, j.bytes);
+            lk.lock();
+            if (--pending == 0) done.notify_all();
+        }
+    }
+    ~HostCopier() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; q.clear(); }
+        work.notify_all();
+        if (th.joinable()) th.join();
+    }
+};
+HostCopier& host_copier() { static HostCopier h; return h; }
+}  // namespace
+}  // extern "C++"
+
+int lt_host_copy_async(void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return LT_OK;
+    if (!dst || !src) return fail(LT_ERR_INVALID, "lt_host_copy_async: null pointer");
+    HostCopier& h = host_copier();
+    {
+        std::lock_guard<std::mutex> lk(h.m);
+        if (!h.th.joinable()) h.th = std::thread([&h] { h.run(); });
+        h.q.push_back({dst, src, bytes});
+        ++h.pending;
+    }
+    h.work.notify_one();
+    return LT_OK;
+}
+
+int lt_host_copy_wait(void) {
+    HostCopier& h = host_copier();
+    std::unique_lock<std::mutex> lk(h.m);
+    h.done.wait(lk, [&] { return h.pending == 0; });
+    return LT_OK;
+}
+
 int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -2064,13 +2124,21 @@ int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
 // A search over ONE slot (process(): one frame per call, the host waiting for its record) sends the record to page-locked
 // memory by a launch queued right behind the search kernel, while the device is still busy with the frame: lt_download_records
 // then waits for that stream and reads 64 bytes, instead of launching the copy once the search is over (8 us of 0.4 ms).
-static void mirror_record(lt_ctx* c, hipStream_t st, int slot) {
-    c->rec_mirror_slot = -1;
+static lt_lane_record* rec_mirror_device(lt_ctx* c) {      // the mirror as kernels address it (nullptr: there is none)
     if (!c->h_rec && hipHostMalloc(reinterpret_cast<void**>(&c->h_rec), 256, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         c->h_rec = nullptr;
     }
-    if (c->h_rec && launch_copy_words_to_pinned(st, c->h_rec, c->d_rec + slot, sizeof(lt_lane_record))) {
+    void* dev = nullptr;
+    if (!c->h_rec || hipHostGetDevicePointer(&dev, c->h_rec, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return static_cast<lt_lane_record*>(dev);
+}
+static void mirror_record(lt_ctx* c, hipStream_t st, int slot) {
+    c->rec_mirror_slot = -1;
+    if (rec_mirror_device(c) && launch_copy_words_to_pinned(st, c->h_rec, c->d_rec + slot, sizeof(lt_lane_record))) {
         c->rec_mirror_slot = slot;
         c->rec_mirror_stream = st;
     }
@@ -2349,12 +2417,19 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
         // one frame (process()): the chain kernel with a chain of one, a third of the latency (LT_BAND_ONE=0: k_band_fit2)
         const char* one_env = n == 1 ? std::getenv("LT_BAND_ONE") : nullptr;
-        if (!(n == 1 && !(one_env && one_env[0] == '0') &&
-              launch_band_fit_one(st, mb, g, bp, c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, c->plane_bytes,
-                                  reinterpret_cast<const int*>(c->d_prev))))
+        lt_lane_record* mirror = n == 1 ? rec_mirror_device(c) : nullptr;
+        if (n == 1 && !(one_env && one_env[0] == '0') &&
+            launch_band_fit_one(st, mb, g, bp, c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, c->plane_bytes,
+                                reinterpret_cast<const int*>(c->d_prev), mirror)) {
+            if (mirror) {                    // the kernel itself leaves a copy of the record in page-locked memory
+                c->rec_mirror_slot = f0;
+                c->rec_mirror_stream = st;
+            }
+        } else {
             launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g, c->d_prev + (size_t)f0 * 6, bp,
                             c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
-        if (n == 1) mirror_record(c, st, f0);
+            if (n == 1) mirror_record(c, st, f0);
+        }
         return note_written(c, st, f0, f0 + m);
     });
     if (rc) return rc;

@@ -251,8 +251,6 @@ class LaneTracker:
             prev = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
                                    np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
             ctx.band_fit_run(1, prev, _native.search_params(**kw), first=slot)
-        if self._want_out and self._out is None:
-            self._prepare_out()
         self._collect_search(ctx, want_centroids=(mode == 'sws'), slot=slot, lazy=lazy)
         if diagnostics:
             print("Lane pixels found." if self.detected_pixels else "No lane pixels found.")
@@ -500,13 +498,11 @@ class LaneTracker:
         if rows is None:
             return
         a0, a1, b0, b1 = rows[2]
-        frame = out[0]
-        if a0 > 0:
-            frame[:a0] = img[:a0]
-        if b0 > a1:
-            frame[a1:b0] = img[a1:b0]
-        if b1 < H:
-            frame[b1:] = img[b1:]
+        lib, dst, src, rb = self._ctx.lib, out.ctypes.data, img.ctypes.data, W * 3
+        for lo, hi in ((0, a0), (a1, b0), (b1, H)):
+            if hi > lo and lib.lt_host_copy_async(dst + lo * rb, src + lo * rb, (hi - lo) * rb):
+                raise _native.NativeError("lt_host_copy_async failed")
+        self._copying = True             # until lt_host_copy_wait: `out` and `img` must stay as they are
         self._out_rows = rows[1]
 
     def _rows_for(self, img):
@@ -515,6 +511,13 @@ class LaneTracker:
                                              and img.shape == (self.img_size[1], self.img_size[0], 3)):
             return None
         return self._present_rows()
+
+    _copying = False            # the library's copy thread may still be filling rows of _out (or of the frame just handed out)
+
+    def _copies_done(self):
+        if self._copying:
+            self._copying = False
+            self._ctx.lib.lt_host_copy_wait()
 
     _resident_partial = False   # of the resident frame only the rows process() reads and presents are on the device
 
@@ -534,11 +537,14 @@ class LaneTracker:
             self._resident_partial = False
         text = b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) \
             if self._have_font and lines else None
-        if drawn and out is not None and rows is not None:
-            return self._ctx.present_finish(slot, text, len(lines), line_len, out, rows, origin=self._TEXT_ORIGIN,
-                                            step=self._TEXT_STEP)[0]
-        return self._ctx.present_frame(slot, left_n, right_n, left_yx, right_yx, text, len(lines), line_len, out, rows,
-                                       origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
+        try:
+            if drawn and out is not None and rows is not None:
+                return self._ctx.present_finish(slot, text, len(lines), line_len, out, rows, origin=self._TEXT_ORIGIN,
+                                                step=self._TEXT_STEP)[0]
+            return self._ctx.present_frame(slot, left_n, right_n, left_yx, right_yx, text, len(lines), line_len, out, rows,
+                                           origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
+        finally:
+            self._copies_done()          # the rows the host fills itself
 
     def print_failure(self, img):
         """The failure message on a copy of the frame (upstream writes into the caller's array, :664-673)."""
@@ -601,6 +607,8 @@ class LaneTracker:
         if not have_mask:
             ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
                                                   ksize_noise, C_noise), first=slot)
+        if self._want_out and self._out is None:
+            self._prepare_out()          # the output array; its untouched rows start to fill on the library's copy thread
         if not reuse_frame:
             # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
             rows = self._rows_for(img) if self._want_out else None
@@ -1193,6 +1201,7 @@ class LaneTracker:
             if self._lane_in_flight is not None:     # an exception between the two halves: the copy into _out may still be running
                 self._lane_in_flight = None
                 self._ctx.sync()
+            self._copies_done()
             self._want_out, self._out, self._out_rows = False, None, None
 
     def _batch_arguments(self, kwargs):

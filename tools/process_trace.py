@@ -31,7 +31,7 @@ class Lib:                                   # the library calls themselves, wit
             t0 = time.perf_counter(); r = fn(*a); acc[" " + name] += time.perf_counter() - t0; cnt[" " + name] += 1; return r
         return w
 lt._ctx.lib = Lib(lt._ctx.lib)
-for name in ("_record_success", "check_validity", "_points_packed", "get_curve_radius", "_lane_text", "_present", "_prepare_out"):
+for name in ("_record_success", "check_validity", "_points_packed", "get_curve_radius", "_lane_text", "_present", "_prepare_out", "_copies_done", "_lane_ahead"):
     wrap(lt, name)
 n = len(frames) - 8
 t0 = time.perf_counter()
