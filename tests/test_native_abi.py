@@ -176,3 +176,29 @@ def test_pinned_empty_falls_back_to_pageable_memory_without_gpu():
     assert _native.load().lt_host_alloc(64, C.byref(out)) != 0 and not out.value
     assert _native.load().lt_host_alloc(0, C.byref(out)) != 0
     assert _native.load().lt_host_free(None) == 0
+
+
+def test_host_copy_thread_copies_and_waits():
+    """lt_host_copy_async / lt_host_copy_wait need no GPU: pieces requested from two Python threads all arrive, the wait
+    returns only when they have, and a wait with nothing pending returns at once."""
+    import threading
+    from lane_tracker_amd import _native
+    lib = _native.load()
+    assert lib.lt_host_copy_wait() == 0
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 256, (64, 1 << 16), dtype=np.uint8)
+    dst = np.zeros_like(src)
+
+    def feed(rows):
+        for r in rows:
+            assert lib.lt_host_copy_async(dst[r].ctypes.data, src[r].ctypes.data, src.shape[1]) == 0
+    ts = [threading.Thread(target=feed, args=(range(k, 64, 2),)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert lib.lt_host_copy_wait() == 0
+    assert np.array_equal(dst, src)
+    assert lib.lt_host_copy_async(None, src.ctypes.data, 8) != 0          # a null pointer is refused, nothing is queued
+    assert lib.lt_host_copy_async(dst.ctypes.data, src.ctypes.data, 0) == 0
+    assert lib.lt_host_copy_wait() == 0
