@@ -285,6 +285,7 @@ class LaneTracker:
 
     _want_out = False      # process() is under way and will hand back an annotated frame ...
     _out = None            # ... which lands in this page-locked array, fetched while the device works
+    _out_ahead = False     # ... and those runs are text rows, then lane rows: the lane can be drawn ahead of the text
     _out_rows = None       # address of the row runs still to come from the device when the other rows of _out are filled already
     _avg_packed = None     # (buffers, left_avg_x, right_avg_x) while the 'avg' buffers hold the polygon of left_avg_* / right_avg_*
 
@@ -471,17 +472,20 @@ class LaneTracker:
         if "_rows4" not in self.__dict__:
             self._configure_overlay()
             H = self.img_size[1]
-            runs = [self._ctx.overlay_rows()]
+            lane = self._ctx.overlay_rows()
+            text = (0, 0)
             if self._have_font:
                 gh = _overlay.font_atlas()[0].shape[1]
-                runs.append((max(self._TEXT_ORIGIN[1], 0), min(self._TEXT_ORIGIN[1] + 2 * self._TEXT_STEP + gh, H)))   # up to three lines
-            runs = sorted(r for r in runs if r[1] > r[0])
-            if len(runs) == 2 and runs[1][0] <= runs[0][1]:
-                runs = [(runs[0][0], max(runs[0][1], runs[1][1]))]
-            runs += [(H, H)] * (2 - len(runs))
+                text = (max(self._TEXT_ORIGIN[1], 0), min(self._TEXT_ORIGIN[1] + 2 * self._TEXT_STEP + gh, H))   # up to three lines
+            if text[1] <= lane[0]:                          # the text above the lane rows (or no text): two runs, in this order --
+                runs, ahead = [text, lane], True            # what drawing the lane ahead of the text needs (lt_present_lane_async)
+            elif lane[1] <= text[0]:
+                runs, ahead = [lane, text], False
+            else:
+                runs, ahead = [(min(text[0], lane[0]), max(text[1], lane[1])), (H, H)], False
             rows = np.array([runs[0][0], runs[0][1], runs[1][0], runs[1][1]], np.int32)
             covered = (rows[1] - rows[0]) + (rows[3] - rows[2])
-            self._rows4 = (rows, rows.ctypes.data, [int(v) for v in rows]) if covered <= 0.8 * H else None
+            self._rows4 = (rows, rows.ctypes.data, [int(v) for v in rows], ahead) if covered <= 0.8 * H else None
         return self._rows4
 
     _TEXT_ORIGIN, _TEXT_STEP = (20, 8), 35          # Context.present_frame / overlay_text defaults
@@ -503,7 +507,7 @@ class LaneTracker:
             if hi > lo and lib.lt_host_copy_async(dst + lo * rb, src + lo * rb, (hi - lo) * rb):
                 raise _native.NativeError("lt_host_copy_async failed")
         self._copying = True             # until lt_host_copy_wait: `out` and `img` must stay as they are
-        self._out_rows = rows[1]
+        self._out_rows, self._out_ahead = rows[1], rows[3]
 
     def _rows_for(self, img):
         """_present_rows() when `img` is a frame whose rows the host can copy as they are, else None."""
@@ -1417,7 +1421,7 @@ class LaneTracker:
         spec = None
         if self.detected_pixels:
             left_fit_coeffs, right_fit_coeffs = self.fit_poly()
-            if self._out_rows is not None and self.speculates_lane:
+            if self._out_rows is not None and self._out_ahead and self.speculates_lane:
                 spec = self._lane_ahead(left_fit_coeffs, right_fit_coeffs, partial, slot)
             self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
             if diagnostics and self.valid_lane_lines:
