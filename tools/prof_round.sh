@@ -47,6 +47,9 @@ cp $(find $out/strace -name "*kernel_stats.csv" | head -1) $out/${tag}_settings_
 python3 tools/pmc_kernels.py $out/settings "walk_hv<65" k_adaptive_box_walk "k_merge_open5<6" "k_merge_open5<2" "true, true, true, true" > $out/${tag}_settings_pmc_kernels.txt
 python3 bench.py --only-settings > $out/${tag}_settings.json 2>/dev/null
 python3 tools/stream_profile.py > $out/${tag}_stream_profile.json 2>&1
+# process() one frame at a time: host time per call, device time per stage
+{ timeout 120 python3 tools/process_trace.py 2>/dev/null | tail -1; timeout 120 python3 tools/process_trace.py x 2>/dev/null | tail -1;
+  timeout 120 python3 tools/process_kernels.py 2>/dev/null | tail -1; } > $out/${tag}_process.jsonl
 rm -rf $out/strace $out/settings
 rm -rf $out/trace $out/fetch $out/write $out/sq1 $out/sq2
 ls -la $out
