@@ -908,19 +908,21 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, 0) == hipSuccess && nb > 0) blocks_per_cu = nb * threads / 256;
         if (blocks_per_cu < 1) blocks_per_cu = 1;
     }
-    const long long slots = (long long)cus * blocks_per_cu * 4;
+    const long long slots = (long long)cus * blocks_per_cu * 4, simds = (long long)cus * 4;
     int best_nb = 1;
     double best_cost = 1e300;
-    for (int nb = 1; nb <= 64; ++nb) {
+    for (int nb = 1; nb <= 256; ++nb) {
         const int rows = (h + nb - 1) / nb;
         const int real_nb = (h + rows - 1) / rows;
         const long long tasks = (long long)n * g.nstrips * real_nb;
         // full grids: bands no shorter than 2R keep the halo overhead sane; a grid that cannot fill the chip
-        // anyway (a single frame) is latency-bound, so it may trade redundant halo rows for shorter walks
-        if (nb > 1 && rows < (tasks <= slots ? (SE::R + 1) / 2 : 2 * SE::R)) break;
+        // anyway (a single frame) is latency-bound, so it may trade redundant halo rows for shorter walks -- down to a few
+        // rows per task while every wave still has a SIMD to itself (one 1100-row frame: 15 -> 10 rows, 29.6 -> 27.2 us per
+        // 55x55 launch; a second wave per SIMD costs more than the shorter walk gains: 31.5 us at 6 rows)
+        if (nb > 1 && rows < (tasks <= simds ? 4 : tasks <= slots ? (SE::R + 1) / 2 : 2 * SE::R)) break;
         const double rounds = (double)((tasks + slots - 1) / slots);
         // small grids cannot fill the chip: prefer more, shorter tasks there
-        const double cost = (tasks < slots ? (double)(rows + 2 * SE::R) : rounds * (rows + 2 * SE::R));
+        const double cost = tasks <= simds ? (double)(rows + 2 * SE::R) : tasks < slots ? 1.15 * (rows + 2 * SE::R) : rounds * (rows + 2 * SE::R);
         if (cost < best_cost - 1e-9) { best_cost = cost; best_nb = nb; }
     }
     // Measured on the full 256-frame grid (tools/nb_sweep.sh, tools/nb55_sweep.sh): all four kernels are fastest with
