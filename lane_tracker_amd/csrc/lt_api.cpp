@@ -752,7 +752,10 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
       unsigned long long* obits = c->d_bits_open + (size_t)first * c->bits_stride;
       bool opened = false;
       // one pass over the words; a handful of frames is latency-bound and better off with the wide, shallow kernels
-      if (!u8_mask && (partials || n >= 16))
+      // (also with partial planes to OR first: one frame's chain, wall time from the first launch to the record, 134.4 us through
+      // k_merge_open5 against 129.9 through k_or4_bits + the two shallow kernels; LT_OPEN_SHALLOW=0 restores the former)
+      static const bool deep_small = [] { const char* e = std::getenv("LT_OPEN_SHALLOW"); return e && e[0] == '0'; }();
+      if (!u8_mask && (n >= 16 || (partials && deep_small)))
           opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, two_partials ? nullptr : tbits, two_partials ? nullptr : ubits, obits,
                                       h, w, c->bits_stride, n, nbits1, nbits2);
       if (!opened) {

@@ -552,7 +552,8 @@ def test_randomised_differential_run():
                                     "LT_SEARCH_U8=1", "LT_SWS_V1=1", "LT_BAND_V1=1", "LT_WALK_MIN_FRAMES=0", "LT_BILATERAL_TILES=1",
                                     "LT_MORPH_PAIR=0", "LT_UNDISTORT_UNALIGNED=1", "LT_WALK_MIN_FRAMES=0,LT_WALK_SPLIT=1",
                                     "LT_WALK_MIN_FRAMES=0,LT_OPEN5_SEPARATE=1", "LT_WALK_MIN_FRAMES=0,LT_MORPH_WIDE=0",
-                                    "LT_WALK_MIN_FRAMES=0,LT_MORPH_ONE_ROW=1"])
+                                    "LT_WALK_MIN_FRAMES=0,LT_MORPH_ONE_ROW=1", "LT_THRESHOLD_SPLIT=0", "LT_OPEN_SHALLOW=0",
+                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN_SHALLOW=0"])
 def test_alternative_kernel_paths_keep_parity(switch):
     """Every measurement switch of DESIGN.md selects a path that stays bit-exact: the mask-chain, top-hat operator and
     search parity tests again in a process started with the switch set (the library reads them once)."""
