@@ -33,7 +33,8 @@ extern "C" {
  *    lt_last_threshold_path(NULL) returns LT_NO_CONTEXT instead of -1. */
 /* 3: + lt_present_frame, lt_present_lane_async, lt_present_finish, lt_overlay_rows, lt_upload_frame_rest_rows (one frame per
  *    call, the host waiting: LaneTracker.process()), lt_set_download_method, lt_download_stats, lt_device_cache_trim,
- *    lt_last_adaptive_path, lt_host_copy_async, lt_host_copy_wait.  Nothing removed or changed. */
+ *    lt_last_adaptive_path, lt_host_copy_async, lt_host_copy2d_async, lt_host_copy_wait, lt_overlay_run_rows,
+ *    lt_download_overlay_rows_async.  Nothing removed or changed. */
 #define LT_ABI_VERSION 3
 
 typedef enum lt_status {
@@ -243,6 +244,10 @@ int  lt_overlay_configure(lt_ctx* ctx, const double* Minv /* 9 */);
  * int32 pairs of all slots, concatenated.  A slot with no points yields a copy of its frame. */
 int  lt_overlay_run(lt_ctx* ctx, int first_slot, int n, const int32_t* left_n, const int32_t* right_n,
                     const int32_t* left_yx, const int32_t* right_yx, double alpha);
+/* The same, drawing only two runs of camera rows rows4 = {a0, a1, b0, b1} of every frame (NULL: whole frames): for annotated
+ * frames that travel back as row runs (lt_download_overlay_rows_async; lt_overlay_rows says which rows the lane can reach). */
+int  lt_overlay_run_rows(lt_ctx* ctx, int first_slot, int n, const int32_t* left_n, const int32_t* right_n,
+                         const int32_t* left_yx, const int32_t* right_yx, double alpha, const int32_t* rows4);
 /* Text on the annotated frames (putText in draw_lane / print_failure, :653-672).  OpenCV's Hershey glyphs are
  * not reproduced: the caller supplies its own glyph atlas once -- n_glyphs alpha cells of glyph_w x glyph_h bytes
  * for the characters first_char, first_char + 1, ..., and each character's advance width (<= glyph_w). */
@@ -293,6 +298,10 @@ int  lt_download_overlay(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
  * themselves only enqueue (their staging is per slot), so a window can be rendered and downloaded in pieces while later
  * frames are still searched; a call over slots whose previous overlay is still in flight waits for that one. */
 int  lt_download_overlay_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
+/* The same for two runs of rows of every frame (rows4 = {a0, a1, b0, b1}; NULL: whole frames), at their places in `out`: the
+ * other rows of an annotated frame equal the camera frame (lt_overlay_rows) and need not cross the bus -- the caller copies them
+ * from the frames it holds (lt_host_copy2d_async). */
+int  lt_download_overlay_rows_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out, const int32_t* rows4);
 /* Wait until every copy enqueued by lt_download_overlay_async has landed -- and for nothing else: uploads and masks of
  * later frames keep running (lt_sync would drain them too). */
 int  lt_download_overlay_wait(lt_ctx* ctx);
@@ -312,6 +321,9 @@ int  lt_host_alloc(size_t bytes, void** out);
  * lt_host_copy_async returns at once; both buffers must stay valid until lt_host_copy_wait() has returned, which is when every
  * copy requested so far (by any thread) is complete. */
 int  lt_host_copy_async(void* dst, const void* src, size_t bytes);
+/* height pieces of width bytes, dst_pitch / src_pitch bytes apart (a run of rows of every frame of a window), shared among
+ * the library's copy threads (LT_COPY_THREADS, default 4) */
+int  lt_host_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t height);
 int  lt_host_copy_wait(void);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact

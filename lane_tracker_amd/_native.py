@@ -103,6 +103,9 @@ _SIGNATURES = {
     "lt_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "lt_host_free": (C.c_int, [_P]),
     "lt_host_copy_async": (C.c_int, [_P, _P, C.c_size_t]),
+    "lt_host_copy2d_async": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "lt_overlay_run_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double, _P]),
+    "lt_download_overlay_rows_async": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "lt_host_copy_wait": (C.c_int, []),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
@@ -441,20 +444,21 @@ class Context:
         m = np.ascontiguousarray(Minv, np.float64).reshape(9)
         _check(self.lib.lt_overlay_configure(self._h, m.ctypes.data))
 
-    def overlay_run(self, polygons, first=0, alpha=0.3):
-        """polygons: one (left_y, left_x, right_y, right_x) tuple per slot (empty arrays: plain copy)."""
-        self.overlay_run_packed(*pack_polygons(polygons), first=first, alpha=alpha)
+    def overlay_run(self, polygons, first=0, alpha=0.3, rows=None):
+        """polygons: one (left_y, left_x, right_y, right_x) tuple per slot (empty arrays: plain copy); rows: None or the
+        ADDRESS of four int32 {a0, a1, b0, b1} -- only these two runs of rows of every frame are drawn."""
+        self.overlay_run_packed(*pack_polygons(polygons), first=first, alpha=alpha, rows=rows)
 
-    def overlay_run_packed(self, ln, rn, lyx, ryx, first=0, alpha=0.3):
+    def overlay_run_packed(self, ln, rn, lyx, ryx, first=0, alpha=0.3, rows=None):
         """The same with the polygons already packed (pack_polygons / poly_points): int32 counts per slot and the (y, x) pairs
         of all slots back to back."""
         ln, rn = np.ascontiguousarray(ln, np.int32), np.ascontiguousarray(rn, np.int32)
         lyx, ryx = np.ascontiguousarray(lyx, np.int32), np.ascontiguousarray(ryx, np.int32)
         if len(rn) != len(ln) or lyx.size != 2 * int(ln.sum()) or ryx.size != 2 * int(rn.sum()):
             raise ValueError("point lists do not match their counts")
-        _check(self.lib.lt_overlay_run(self._h, first, len(ln), ln.ctypes.data, rn.ctypes.data,
-                                       lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None,
-                                       float(alpha)))
+        _check(self.lib.lt_overlay_run_rows(self._h, first, len(ln), ln.ctypes.data, rn.ctypes.data,
+                                            lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None,
+                                            float(alpha), rows))
 
     def overlay_set_font(self, atlas, advance, first_char=32):
         """atlas: (n_glyphs, glyph_h, glyph_w) u8 alpha cells; advance: (n_glyphs,) u8."""
@@ -482,12 +486,13 @@ class Context:
         _check(self.lib.lt_download_overlay(self._h, first, n, out.ctypes.data))
         return out
 
-    def download_overlay_async(self, out, first=0):
+    def download_overlay_async(self, out, first=0, rows=None):
         """Enqueue the copy of the annotated frames of slots first .. first+len(out)-1 into `out` (a C-contiguous u8 array
-        (n, H, W, 3), from pinned_empty()); valid after the next sync()."""
+        (n, H, W, 3), from pinned_empty()); valid after the next sync().  rows: None or the ADDRESS of four int32 -- only these two
+        runs of rows of every frame (the caller fills the others)."""
         if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.shape[1:] != (self.img_h, self.img_w, 3):
             raise ValueError("download_overlay_async needs a C-contiguous uint8 array (n, H, W, 3)")
-        _check(self.lib.lt_download_overlay_async(self._h, first, out.shape[0], out.ctypes.data))
+        _check(self.lib.lt_download_overlay_rows_async(self._h, first, out.shape[0], out.ctypes.data, rows))
 
     def set_download_method(self, method):
         """-1: engine or kernel by measurement (default); 0: copy engine; 1: kernel."""

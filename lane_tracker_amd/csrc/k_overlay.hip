@@ -58,10 +58,13 @@ __global__ __launch_bounds__(256) void k_overlay_lane(const uint8_t* __restrict_
 __global__ __launch_bounds__(256) void k_overlay_lane4(const uint32_t* __restrict__ frames, uint32_t* __restrict__ out,
                                                       size_t frame_stride_dw, const int16_t* __restrict__ oxy,
                                                       const uint16_t* __restrict__ ofrac,
-                                                      const short2* __restrict__ spans, size_t span_stride, int nquads,
-                                                      int bh, int bw, float alpha) {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nquads) return;
+                                                      const short2* __restrict__ spans, size_t span_stride, int qa, int na,
+                                                      int qb, int nb, int bh, int bw, float alpha) {
+    // two runs of pixel quads per frame, [qa, qa + na) and [qb, qb + nb): the whole frame and nothing, or the text rows and
+    // the rows the lane can reach (the other rows of the annotated frame are then nobody's business)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= na + nb) return;
+    const int q = t < na ? qa + t : qb + (t - na);
     const uint32_t* src = frames + (size_t)blockIdx.z * frame_stride_dw + (size_t)q * 3;
     uint32_t* dst = out + (size_t)blockIdx.z * frame_stride_dw + (size_t)q * 3;
     uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
@@ -230,6 +233,34 @@ __global__ __launch_bounds__(256) void k_copy_vec16(vec4u* __restrict__ dst, con
 }
 }  // namespace
 
+// The same for one run of rows of n frames: bytes [off, off + bytes) of every frame, the frames `pitch` bytes apart in both
+// buffers (lt_download_overlay_rows_async).
+namespace {
+__global__ __launch_bounds__(256) void k_copy_rows16(vec4u* __restrict__ dst, const vec4u* __restrict__ src, unsigned pitch16,
+                                                    unsigned off16, unsigned w16, unsigned total) {
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned f = i / w16, u = i - f * w16;
+        const size_t a = (size_t)f * pitch16 + off16 + u;
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + a), dst + a);
+    }
+}
+}  // namespace
+
+bool launch_copy_rows_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t pitch, size_t off, size_t bytes, int n) {
+    if (!bytes || n <= 0) return true;
+    void* dst_dev = nullptr;
+    const size_t total = (size_t)n * (bytes >> 4);
+    if (((bytes | pitch | off | (size_t)(uintptr_t)dst_pinned | (size_t)(uintptr_t)src) & 15) || total >= 0xffffffffull ||
+        (pitch >> 4) >= 0xffffffffull || hipHostGetDevicePointer(&dst_dev, dst_pinned, 0) != hipSuccess || !dst_dev) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const unsigned blocks = (unsigned)std::min<size_t>((total + 255) / 256, 64);
+    hipLaunchKernelGGL(k_copy_rows16, dim3(blocks), dim3(256), 0, s, static_cast<vec4u*>(dst_dev), static_cast<const vec4u*>(src),
+                       (unsigned)(pitch >> 4), (unsigned)(off >> 4), (unsigned)(bytes >> 4), (unsigned)total);
+    return true;
+}
+
 bool launch_copy_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes) {
     if (!bytes) return true;
     void* dst_dev = nullptr;
@@ -255,16 +286,19 @@ void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int i
 
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
                          const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
-                         int bh, int bw, float alpha, int n) {
+                         int bh, int bw, float alpha, int n, const int* rows4) {
     if (n <= 0) return;
     const int npix = img_h * img_w;
     const short2* sp = reinterpret_cast<const short2*>(spans);
     if ((img_w & 3) == 0 && (frame_stride & 3) == 0) {
-        const int nq = npix >> 2;
-        hipLaunchKernelGGL(k_overlay_lane4, dim3((nq + 255) / 256, 1, n), dim3(256), 0, s,
+        const int qrow = img_w >> 2;
+        int qa = 0, na = npix >> 2, qb = 0, nb = 0;
+        if (rows4) { qa = rows4[0] * qrow; na = (rows4[1] - rows4[0]) * qrow; qb = rows4[2] * qrow; nb = (rows4[3] - rows4[2]) * qrow; }
+        if (na + nb <= 0) return;
+        hipLaunchKernelGGL(k_overlay_lane4, dim3((na + nb + 255) / 256, 1, n), dim3(256), 0, s,
                            reinterpret_cast<const uint32_t*>(frames), reinterpret_cast<uint32_t*>(out), frame_stride >> 2,
-                           oxy, ofrac, sp, span_stride_rows, nq, bh, bw, alpha);
-    } else {
+                           oxy, ofrac, sp, span_stride_rows, qa, na, qb, nb, bh, bw, alpha);
+    } else {      // (a row length that is no multiple of 4: the whole frame whatever the runs -- a superset)
         hipLaunchKernelGGL(k_overlay_lane, dim3((npix + 255) / 256, 1, n), dim3(256), 0, s, frames, out, frame_stride, oxy,
                            ofrac, sp, span_stride_rows, npix, bh, bw, alpha);
     }

@@ -1543,8 +1543,8 @@ int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const do
     return LT_OK;
 }
 
-// lt_overlay_run; rows4 (one frame only): two runs of camera rows {a0, a1, b0, b1} outside which the annotated frame is not
-// needed (lt_present_frame), nullptr = all of it
+// lt_overlay_run; rows4: two runs of camera rows {a0, a1, b0, b1} outside which the annotated frames are not needed
+// (lt_present_frame, lt_overlay_run_rows), nullptr = all of them
 static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                             const int32_t* right_yx, double alpha, const int* rows4) {
     int rc = check_slots(c, first, n);
@@ -1646,7 +1646,7 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
     const auto t2 = std::chrono::steady_clock::now();
     launch_overlay_lane(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
-                        c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n);
+                        c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n, rows4);
     HIP_TRY(hipGetLastError());
     if ((rc = staging_mark(c->spans_busy, ps))) return rc;
     rc = note_range(c->readers, ps, first, first + n);
@@ -1661,6 +1661,23 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
 int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                    const int32_t* right_yx, double alpha) {
     return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr);
+}
+
+static int ordered_rows(lt_ctx* c, const int32_t* rows4, int r[4]) {
+    for (int k = 0; k < 4; ++k) r[k] = rows4[k];
+    if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= c->calib.img_h))
+        return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
+    return LT_OK;
+}
+
+int lt_overlay_run_rows(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                        const int32_t* right_yx, double alpha, const int32_t* rows4) {
+    if (!rows4) return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr);
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int r[4];
+    const int rc = ordered_rows(c, rows4, r);
+    if (rc) return rc;
+    return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, r);
 }
 
 int lt_overlay_rows(lt_ctx* c, int* row0, int* row1) {
@@ -1812,17 +1829,18 @@ int lt_host_free(void* p) {
 // ---- a second host thread for plain copies -------------------------------------------------------------------------------
 // LaneTracker.process() fills the rows of its output array that no overlay can touch from the caller's frame (1.4 MB at
 // 1280x720, 3.2 MB at 1920x1080: 60 / 130 us of memcpy).  The thread that feeds the device has launches to issue meanwhile;
-// this one has nothing else to do.  One worker per process, started at the first request, joined when the library is unloaded.
+// these have nothing else to do.  A few workers per process (LT_COPY_THREADS), started at the first request that can use them,
+// joined when the library is unloaded.
 extern "C++" {
 namespace {
 struct HostCopier {
-    struct Job { void* dst; const void* src; size_t bytes; };
+    struct Job { uint8_t* dst; const uint8_t* src; size_t dpitch, spitch, width, height; };
     std::mutex m;
     std::condition_variable work, done;
     std::deque<Job> q;
-    size_t pending = 0;          // requests taken and not finished yet
+    size_t pending = 0;          // pieces taken and not finished yet
     bool stop = false;
-    std::thread th;
+    std::vector<std::thread> th;
     void run() {
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
@@ -1831,15 +1849,34 @@ struct HostCopier {
             const Job j = q.front();
             q.pop_front();
             lk.unlock();
-            std::memcpy(j.dst, j.src, j.bytes);
+            if (j.dpitch == j.width && j.spitch == j.width) std::memcpy(j.dst, j.src, j.width * j.height);
+            else
+                for (size_t r = 0; r < j.height; ++r) std::memcpy(j.dst + r * j.dpitch, j.src + r * j.spitch, j.width);
             lk.lock();
             if (--pending == 0) done.notify_all();
         }
     }
+    int threads() {              // LT_COPY_THREADS (1 .. 16), default 4: a window of annotated frames is 0.36 GB of untouched rows
+        static const int n = [] { const char* e = std::getenv("LT_COPY_THREADS"); const int v = e ? std::atoi(e) : 4; return std::min(std::max(v, 1), 16); }();
+        return n;
+    }
+    void submit(const Job& whole) {
+        // pieces of whole rows ("rows" of the 2-D copy: frames), a few per worker so that they finish together
+        const size_t parts = whole.height <= 1 ? 1 : std::min<size_t>(whole.height, (size_t)threads() * 2);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            while ((int)th.size() < (whole.height <= 1 ? 1 : threads())) th.emplace_back([this] { run(); });
+            for (size_t k = 0; k < parts; ++k) {
+                const size_t r0 = whole.height * k / parts, r1 = whole.height * (k + 1) / parts;
+                if (r1 > r0) { q.push_back({whole.dst + r0 * whole.dpitch, whole.src + r0 * whole.spitch, whole.dpitch, whole.spitch, whole.width, r1 - r0}); ++pending; }
+            }
+        }
+        work.notify_all();
+    }
     ~HostCopier() {
         { std::lock_guard<std::mutex> lk(m); stop = true; q.clear(); }
         work.notify_all();
-        if (th.joinable()) th.join();
+        for (auto& t : th) if (t.joinable()) t.join();
     }
 };
 HostCopier& host_copier() { static HostCopier h; return h; }
@@ -1849,14 +1886,15 @@ HostCopier& host_copier() { static HostCopier h; return h; }
 int lt_host_copy_async(void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return LT_OK;
     if (!dst || !src) return fail(LT_ERR_INVALID, "lt_host_copy_async: null pointer");
-    HostCopier& h = host_copier();
-    {
-        std::lock_guard<std::mutex> lk(h.m);
-        if (!h.th.joinable()) h.th = std::thread([&h] { h.run(); });
-        h.q.push_back({dst, src, bytes});
-        ++h.pending;
-    }
-    h.work.notify_one();
+    host_copier().submit({static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), bytes, bytes, bytes, 1});
+    return LT_OK;
+}
+
+int lt_host_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t height) {
+    if (width == 0 || height == 0) return LT_OK;
+    if (!dst || !src) return fail(LT_ERR_INVALID, "lt_host_copy2d_async: null pointer");
+    if (dst_pitch < width || src_pitch < width) return fail(LT_ERR_INVALID, "lt_host_copy2d_async: a pitch below the width");
+    host_copier().submit({static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), dst_pitch, src_pitch, width, height});
     return LT_OK;
 }
 
@@ -1979,7 +2017,18 @@ int lt_present_finish(lt_ctx* c, int slot, const char* lines, int n_lines, int l
 
 static void harvest_downloads(lt_ctx* c);
 static int choose_download(lt_ctx* c);
-int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
+static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out, const int* rows4);
+int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) { return download_overlay_async_impl(c, first, n, out, nullptr); }
+int lt_download_overlay_rows_async(lt_ctx* c, int first, int n, uint8_t* out, const int32_t* rows4) {
+    if (!rows4) return download_overlay_async_impl(c, first, n, out, nullptr);
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int r[4];
+    const int rc = ordered_rows(c, rows4, r);
+    if (rc) return rc;
+    return download_overlay_async_impl(c, first, n, out, r);
+}
+// rows4: only these two runs of rows of every frame (at their places in `out`), nullptr: whole frames
+static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out, const int* rows4) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if (!out) return fail(LT_ERR_INVALID, "null output buffer");
@@ -2016,9 +2065,30 @@ int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) {
     };
     hipEvent_t ta = timing_event(), tb = timing_event();
     if (ta && tb) HIP_TRY(hipEventRecord(ta, c->dl));
-    const size_t bytes = (size_t)n * c->frame_bytes;
-    if (method == 1 && !launch_copy_to_pinned(c->dl, out, c->d_annot + (size_t)first * c->frame_bytes, bytes)) method = 0;   // not page-locked / aligned
-    if (method == 0) HIP_TRY(hipMemcpyAsync(out, c->d_annot + (size_t)first * c->frame_bytes, bytes, hipMemcpyDeviceToHost, c->dl));
+    size_t bytes = (size_t)n * c->frame_bytes;
+    const uint8_t* src = c->d_annot + (size_t)first * c->frame_bytes;
+    if (!rows4) {
+        if (method == 1 && !launch_copy_to_pinned(c->dl, out, src, bytes)) method = 0;   // not page-locked / aligned
+        if (method == 0) HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->dl));
+    } else {
+        const size_t row_bytes = (size_t)c->calib.img_w * 3;
+        bytes = 0;
+        // row runs go by the copy kernel whatever the measured choice for whole frames says: the engine takes a pitched copy
+        // row by row (120-160 ms for a window of 256 frames against 12); only an explicit lt_set_download_method(0) gets it
+        bool by_kernel = c->dl_forced != 0;
+        for (int k = 0; k < 4 && by_kernel; k += 2)       // both runs the same way, so that the timing below means one thing
+            by_kernel = rows4[k + 1] <= rows4[k] ||
+                        ((((size_t)rows4[k] * row_bytes) | ((size_t)(rows4[k + 1] - rows4[k]) * row_bytes) | c->frame_bytes | (size_t)(uintptr_t)out) & 15) == 0;
+        for (int k = 0; k < 4; k += 2) {
+            if (rows4[k + 1] <= rows4[k]) continue;
+            const size_t off = (size_t)rows4[k] * row_bytes, run = (size_t)(rows4[k + 1] - rows4[k]) * row_bytes;
+            if (by_kernel && !launch_copy_rows_to_pinned(c->dl, out, src, c->frame_bytes, off, run, n)) by_kernel = false;
+            if (!by_kernel)
+                HIP_TRY(hipMemcpy2DAsync(out + off, c->frame_bytes, src + off, c->frame_bytes, run, (size_t)n, hipMemcpyDeviceToHost, c->dl));
+            bytes += run * (size_t)n;
+        }
+        method = by_kernel ? 1 : 0;
+    }
     HIP_TRY(hipGetLastError());
     if (ta && tb) {
         HIP_TRY(hipEventRecord(tb, c->dl));

@@ -54,7 +54,7 @@ void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_px
 // presentation stage (k_overlay.hip)
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
                          const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
-                         int bh, int bw, float alpha, int n);
+                         int bh, int bw, float alpha, int n, const int* rows4 = nullptr);
 // one frame, the row intervals (host memory, bh pairs) passed as a kernel argument; rows4 = nullptr: the whole frame, else two
 // runs of camera rows {a0, a1, b0, b1} (the others are not written); false: not launched (bh above LT_SPAN_ARG_ROWS, a row
 // length that is no multiple of 4, or the runtime refused the argument block)
@@ -67,6 +67,7 @@ void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int i
 // host -> device copy of a few hundred KB out of page-locked memory as a kernel launch (never blocks the caller)
 void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, size_t bytes);
 bool launch_copy_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes);   // false: not page-locked / aligned
+bool launch_copy_rows_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t pitch, size_t off, size_t bytes, int n);
 bool launch_copy_words_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes);          // small, 4-byte granular
 void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy, const uint16_t* wfrac,
                      FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n);

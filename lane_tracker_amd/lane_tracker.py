@@ -518,10 +518,20 @@ class LaneTracker:
 
     _copying = False            # the library's copy thread may still be filling rows of _out (or of the frame just handed out)
 
+    _copy_keepalive = None      # the arrays the copy threads read and write, until they are done
+
     def _copies_done(self):
         if self._copying:
             self._copying = False
             self._ctx.lib.lt_host_copy_wait()
+        self._copy_keepalive = None
+
+    def _rows_for_window(self, frames):
+        """_present_rows() when the annotated frames of this window can travel as row runs, else None."""
+        if not self.host_copies_rows or frames.dtype != np.uint8 or not frames.flags["C_CONTIGUOUS"] or \
+                frames.shape[1:] != (self.img_size[1], self.img_size[0], 3):
+            return None
+        return self._present_rows()
 
     _resident_partial = False   # of the resident frame only the rows process() reads and presents are on the device
 
@@ -951,7 +961,7 @@ class LaneTracker:
             last = (end, t, r)
         if committed:
             jl = committed - 1
-            self._resident, self._resident_partial = (frames[i + jl], base + i + jl), False
+            self._resident, self._resident_partial = (frames[i + jl], base + i + jl), self._window_rows is not None and annotate
         if last is not None:
             j, t, r = last
             if t == 0 and rec2 is not None and j < e2:
@@ -1020,6 +1030,8 @@ class LaneTracker:
             return span(at)              # for those before it commits anything of this window) and each piece's bookkeeping hides
                                          # under the copy of the piece before
 
+        rest_rows = self._window_rows[1] if self._window_rows is not None else None   # annotated frames travel as row runs
+
         def feed(upto):                  # keep the device supplied with masks ahead of the searches
             nonlocal masked
             while masked < min(total, upto):
@@ -1028,7 +1040,7 @@ class LaneTracker:
                     ctx.upload_frame_rows_async(frames[masked:masked + m], first=base + masked)
                     ctx.mask_run(m, fp, first=base + masked)
                     if annotate:         # the rest of these frames, for the overlay: behind their rows on the copy stream
-                        ctx.upload_frame_rest(frames[masked:masked + m], first=base + masked)
+                        ctx.upload_frame_rest(frames[masked:masked + m], first=base + masked, rows=rest_rows)
                 else:
                     q = masked - n
                     for a in ahead:                       # the window position `masked` falls into
@@ -1039,7 +1051,7 @@ class LaneTracker:
                     ctx.upload_frame_rows_async(a[0][q:q + m], first=a[1] + q)
                     ctx.mask_run(m, fp, first=a[1] + q)
                     if annotate:
-                        ctx.upload_frame_rest(a[0][q:q + m], first=a[1] + q)
+                        ctx.upload_frame_rest(a[0][q:q + m], first=a[1] + q, rows=rest_rows)
                     a[2] = q + m
                 masked += m
         feed(2 * chunk)
@@ -1130,7 +1142,7 @@ class LaneTracker:
                 lf, rf = np.array(LF[j], np.float64), np.array(RF[j], np.float64)
                 self._pending = (ctx, base + first + j)
                 self._fit = ("pending", None, lf, rf)
-                self._resident, self._resident_partial = (frames[first + j], base + first + j), False
+                self._resident, self._resident_partial = (frames[first + j], base + first + j), self._window_rows is not None and annotate
                 self._record_success(lf, rf, partial)
                 if annotate:
                     deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x),
@@ -1234,25 +1246,46 @@ class LaneTracker:
             raise ValueError("expected frames of shape (n, H, W, 3)")
         return frames
 
-    def _window_renderer(self, deferred, base, n, piece=32):
+    _window_rows = None         # _present_rows() while an annotated window / stream sends its frames back as row runs
+
+    def _window_renderer(self, deferred, base, n, piece=32, frames=None):
         """(flush, out) for a window of n frames in slots base..: `flush(force)` renders the frames committed to `deferred`
         since the last call -- overlay and text kernels, then the copy into the page-locked `out`, all only enqueued -- once
-        at least `piece` of them have gathered (or `force`); `out` is complete after the next sync."""
+        at least `piece` of them have gathered (or `force`); `out` is complete after the next sync (and, with row runs,
+        _copies_done()).  With row runs (`_window_rows`) the rows of `out` that no overlay can touch are copied from `frames`,
+        the window as the caller handed it in, by the library's copy threads, starting now."""
         self._configure_overlay()
         ctx = self._ctx
         out = _native.pinned_empty((n, ctx.img_h, ctx.img_w, 3))
         empty = np.zeros(0, np.int64)
         done = [0]
+        rows = self._window_rows[1] if (self._window_rows is not None and frames is not None and n) else None
+        copies = [rows is not None]
+
+        def start_copies():
+            # at the window's first flush, not before: in a stream the window before is handed out once this one's first
+            # searches are in flight, after waiting for ITS host copies -- which lt_host_copy_wait cannot tell from these
+            copies[0] = False
+            a0, a1, b0, b1 = self._window_rows[2]
+            H, rb, fb = ctx.img_h, ctx.img_w * 3, ctx.img_h * ctx.img_w * 3
+            lib, dst, src = ctx.lib, out.ctypes.data, frames.ctypes.data
+            self._copying = True
+            self._copy_keepalive = (out, frames)
+            for lo, hi in ((0, a0), (a1, b0), (b1, H)):
+                if hi > lo and lib.lt_host_copy2d_async(dst + lo * rb, fb, src + lo * rb, fb, (hi - lo) * rb, n):
+                    raise _native.NativeError("lt_host_copy2d_async failed")
 
         def flush(force):
+            if copies[0]:
+                start_copies()
             lo, hi = done[0], len(deferred)
             if hi <= lo or (hi - lo < piece and not force):
                 return
             part = deferred[lo:hi]
-            ctx.overlay_run([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in part], first=base + lo)
+            ctx.overlay_run([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in part], first=base + lo, rows=rows)
             if self._have_font:
                 ctx.overlay_text([d[2] for d in part], first=base + lo)
-            ctx.download_overlay_async(out[lo:hi], first=base + lo)
+            ctx.download_overlay_async(out[lo:hi], first=base + lo, rows=rows)
             done[0] = hi
         return flush, out
 
@@ -1292,14 +1325,20 @@ class LaneTracker:
         ctx.reserve(max(n, 1))
         deferred = []
         if self.chain_searches and not k["diagnostics"]:
-            flush, out = self._window_renderer(deferred, 0, n) if (annotate and n) else (None, None)
-            for _ in self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred, flush=flush):
-                pass
-            self._materialise_pending()  # the attributes describe the last frame, as after process() (also waits for `out`)
-            if out is not None:
-                ctx.sync()
-                return list(out)
-            return [None] * n
+            self._window_rows = self._rows_for_window(frames) if annotate else None
+            try:
+                flush, out = self._window_renderer(deferred, 0, n, frames=frames) if (annotate and n) else (None, None)
+                for _ in self._run_window_chained(frames, first_try, fp, k["n_tries"], annotate, deferred, flush=flush):
+                    pass
+                self._materialise_pending()  # the attributes describe the last frame, as after process() (also waits for `out`)
+                if out is not None:
+                    ctx.sync()
+                    self._copies_done()
+                    return list(out)
+                return [None] * n
+            finally:
+                self._copies_done()
+                self._window_rows = None
         else:
             ctx.upload_frame_rows(frames)        # the camera rows the path reads; the rest only if frames are annotated
             ctx.mask_run(n, fp)
@@ -1346,9 +1385,11 @@ class LaneTracker:
             arrays, region = landing
             landing = None
             ctx.download_overlay_wait()  # these frames have landed; the uploads, masks and searches of the next windows run on
+            self._copies_done()          # ... and so have the rows the host copies itself
             free.append(region)
             return list(arrays)
         self._in_stream = True
+        self._window_rows = self._rows_for_window(cur[0]) if annotate else None
         try:
             while cur is not None:
                 while len(queue) < look:             # know the next windows
@@ -1376,7 +1417,7 @@ class LaneTracker:
                         q[1] = free.pop(0)
                     ahead.append(q)
                 deferred = []
-                flush, frames_out = self._window_renderer(deferred, cur[1], n) if (annotate and n) else (None, None)
+                flush, frames_out = self._window_renderer(deferred, cur[1], n, frames=cur[0]) if (annotate and n) else (None, None)
                 if n:
                     for _ in self._run_window_chained(cur[0], first_try, fp, k["n_tries"], annotate, deferred, base=cur[1],
                                                       prefed=cur[2], ahead=ahead, flush=flush):
@@ -1396,10 +1437,12 @@ class LaneTracker:
             self._materialise_pending()  # the attributes describe the last frame, as after process()
         finally:
             self._in_stream = False
+            self._window_rows = None
             if annotate:                 # a generator closed early: no copy may still be writing into page-locked arrays
                 try:                     # that go back to the pool with their last reference
                     ctx.band_fit_chain_cancel()
                     ctx.sync()
+                    self._copies_done()
                 except Exception:
                     pass
 

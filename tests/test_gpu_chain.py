@@ -154,8 +154,9 @@ def test_process_batch_chained_equals_process_frame_by_frame(every, windows, ann
     n = sum(windows)
     frames = _stream_with_failures(n, every, seed=31)
     seq, bat = LaneTracker(**cal), LaneTracker(**cal)
+    seq.host_copies_rows = False         # whole frames from the device on the frame-by-frame side, row runs in the batch
     try:
-        assert bat.chain_searches
+        assert bat.chain_searches and bat.host_copies_rows
         lo = 0
         for w in windows:
             outs_seq = [seq.process(f) for f in frames[lo:lo + w]]
@@ -244,7 +245,9 @@ def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_
         wins.append(frames[lo:lo + w])
         lo += w
     seq, bat = LaneTracker(n_average=n_average, **cal), LaneTracker(n_average=n_average, **cal)
+    seq.host_copies_rows = False         # the frame-by-frame side takes whole frames from the device, the stream row runs
     try:
+        assert bat.host_copies_rows
         gen = bat.process_stream(wins, annotate=annotate)
         for k, (win, outs) in enumerate(zip(wins, gen)):
             outs_seq = [seq.process(f) for f in win]
