@@ -473,13 +473,10 @@ class Context:
         nl = max((len(l) for l in lines_per_slot), default=0)
         if n == 0 or nl == 0:
             return
-        buf = np.zeros((n, nl, line_len), np.uint8)
-        for i, lines in enumerate(lines_per_slot):
-            for j, text in enumerate(lines):
-                b = text.encode("ascii", "replace")[:line_len]
-                buf[i, j, :len(b)] = np.frombuffer(b, np.uint8)
-        _check(self.lib.lt_overlay_text(self._h, first, n, buf.ctypes.data, nl, line_len, int(origin[0]), int(origin[1]),
-                                        int(step)))
+        blank = b"\0" * line_len
+        buf = b"".join(b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) + blank * (nl - len(lines))
+                       for lines in lines_per_slot)
+        _check(self.lib.lt_overlay_text(self._h, first, n, buf, nl, line_len, int(origin[0]), int(origin[1]), int(step)))
 
     def download_overlay(self, n, first=0):
         out = pinned_empty((n, self.img_h, self.img_w, 3))

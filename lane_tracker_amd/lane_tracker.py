@@ -796,14 +796,12 @@ class LaneTracker:
         le, re = np.cumsum(ln), np.cumsum(rn)
         mid = int(self.warped_size[0] / 2)
         ecc = (((mid - lyx[le - 1, 1].astype(np.int64)) - (ryx[re - 1, 1].astype(np.int64) - mid)) / 2) * self.mpph
-        lyx64, ryx64 = lyx.astype(np.int64), ryx.astype(np.int64)
         for q in range(m):
             self.counter += 1
             lines = ["Curve Radius: {} m".format(int(avg_radius[q])), "Eccentricity: {:.2f} m".format(float(ecc[q]))]
             if self.print_frame_count:
                 lines.append("Frame: {}".format(self.counter - 1))
-            a, b = lyx64[le[q] - ln[q]:le[q]], ryx64[re[q] - rn[q]:re[q]]
-            deferred.append(('lane', (a[:, 0], a[:, 1], b[:, 0], b[:, 1]), lines))
+            deferred.append(('lane', _PackedPoly(lyx[le[q] - ln[q]:le[q]], ryx[re[q] - rn[q]:re[q]]), lines))
         self.success += m
         self.left_fit_coeffs = [np.array(c) for c in LF[hi - k:hi]]
         self.right_fit_coeffs = [np.array(c) for c in RF[hi - k:hi]]
@@ -830,10 +828,11 @@ class LaneTracker:
         ploty, ploty2 = self._plot_rows(1)
         W = self.warped_size[0]
 
-        def inside_count(Cf):
-            fitx = Cf[:, 0:1] * ploty2[None, :] + Cf[:, 1:2] * ploty[None, :] + Cf[:, 2:3]
-            return np.count_nonzero((fitx <= W - 1) & (fitx >= 0), axis=1)
-        n = np.minimum(inside_count(LF), inside_count(RF))
+        # plot points inside the image, per side (:565-569): lt_poly_points counts them (the same f64 operations in the same
+        # order as fitx = a * ploty**2 + b * ploty + c; tests/test_host_geometry.py)
+        ln, rn, _, _ = _native.poly_points(self.warped_size, np.concatenate([np.asarray(LF, np.float64).reshape(-1, 3),
+                                                                             np.asarray(RF, np.float64).reshape(-1, 3)], axis=1), ploty, ploty2)
+        n = np.minimum(ln, rn).astype(np.int64)
         y1 = np.full(len(LF), W - 1, np.int64)
         y2 = W - (n * 0.35).astype(np.int64)
         y3 = W - (n * 0.75).astype(np.int64)
@@ -1282,7 +1281,7 @@ class LaneTracker:
             if hi <= lo or (hi - lo < piece and not force):
                 return
             part = deferred[lo:hi]
-            ctx.overlay_run([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in part], first=base + lo, rows=rows)
+            ctx.overlay_run_packed(*_pack_deferred(part), first=base + lo, rows=rows)
             if self._have_font:
                 ctx.overlay_text([d[2] for d in part], first=base + lo)
             ctx.download_overlay_async(out[lo:hi], first=base + lo, rows=rows)
@@ -1292,9 +1291,11 @@ class LaneTracker:
     def _render_window(self, deferred, base):
         """One overlay launch and one download for a whole window; a failed frame has no polygon (plain copy)."""
         self._configure_overlay()
-        empty = np.zeros(0, np.int64)
-        return list(self._annotate([d[1] if d[0] == 'lane' else (empty, empty, empty, empty) for d in deferred],
-                                   [d[2] for d in deferred], first=base))
+        ctx = self._ctx
+        ctx.overlay_run_packed(*_pack_deferred(deferred), first=base)
+        if self._have_font:
+            ctx.overlay_text([d[2] for d in deferred], first=base)
+        return list(ctx.download_overlay(len(deferred), first=base))
 
     def process_batch(self, frames, annotate=True, **kwargs):
         """The same result as calling `process()` on each frame of `frames` in order (one stateful
@@ -1532,6 +1533,41 @@ class LaneTracker:
                           self._lane_text()))
             return None
         return present(self.draw_lane(img))
+
+
+class _PackedPoly:
+    """A lane polygon as lt_poly_points leaves it -- int32 (y, x) pairs of the left and of the right curve -- in the entries
+    `_record_successes` defers for the overlay (the other entries carry upstream's four int64 arrays)."""
+    __slots__ = ("lyx", "ryx")
+
+    def __init__(self, lyx, ryx):
+        self.lyx, self.ryx = lyx, ryx
+
+    def as_tuple(self):
+        a, b = self.lyx.astype(np.int64), self.ryx.astype(np.int64)
+        return a[:, 0], a[:, 1], b[:, 0], b[:, 1]
+
+
+_NO_POINTS = np.zeros((0, 2), np.int32)
+
+
+def _pack_deferred(part):
+    """Deferred pictures ('lane', polygon, text) / ('fail', None, text) -> (left counts, right counts, left (y, x) pairs,
+    right (y, x) pairs) as Context.overlay_run_packed takes them; a failed frame has no polygon (plain copy)."""
+    L, R = [], []
+    for d in part:
+        p = d[1] if d[0] == 'lane' else None
+        if p is None:
+            L.append(_NO_POINTS)
+            R.append(_NO_POINTS)
+        elif isinstance(p, _PackedPoly):
+            L.append(p.lyx)
+            R.append(p.ryx)
+        else:
+            L.append(np.stack([p[0], p[1]], 1).astype(np.int32))
+            R.append(np.stack([p[2], p[3]], 1).astype(np.int32))
+    ln, rn = np.array([len(a) for a in L], np.int32), np.array([len(a) for a in R], np.int32)
+    return ln, rn, (np.concatenate(L) if L else _NO_POINTS), (np.concatenate(R) if R else _NO_POINTS)
 
 
 def _mean_of_rows(rows):

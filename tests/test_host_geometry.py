@@ -109,6 +109,11 @@ def _history_tracker(n_average, print_frame_count=False):
     return t
 
 
+def _four(polygon):
+    """A deferred polygon as upstream's four int64 arrays (the run recorder defers lt_poly_points' packed int32 pairs)."""
+    return polygon.as_tuple() if hasattr(polygon, "as_tuple") else polygon
+
+
 def _scalar_commit(t, lf, rf, partial, deferred):
     t.counter += 1
     t._fit = ("pending", None, lf, rf)
@@ -142,7 +147,7 @@ def test_run_of_successes_recorded_at_once_equals_frame_by_frame(n_average, part
     assert len(got) == len(want) == g
     for j, (x, y) in enumerate(zip(got, want)):
         assert x[0] == y[0] and x[2] == y[2], (j, x[2], y[2])
-        for p, q in zip(x[1], y[1]):
+        for p, q in zip(_four(x[1]), _four(y[1])):
             assert p.dtype == q.dtype and np.array_equal(p, q), j
     for name in ("counter", "success", "last_detection", "average_curve_radii", "average_curve_radius", "eccentricity",
                  "left_curve_radius", "right_curve_radius"):
@@ -285,7 +290,7 @@ def test_runs_of_valid_frames_are_recorded_at_once_around_near_straight_frames()
             assert len(da) == len(db) == g
             for j, (x, y) in enumerate(zip(da, db)):
                 assert x[2] == y[2], (n_average, j, x[2], y[2])                                    # the text: radius, eccentricity
-                assert all(np.array_equal(p, q) for p, q in zip(x[1], y[1])), (n_average, j)       # the polygon
+                assert all(np.array_equal(p, q) for p, q in zip(_four(x[1]), _four(y[1]))), (n_average, j)       # the polygon
             assert (a.counter, a.success, list(a.average_curve_radii), a.average_curve_radius, a.eccentricity) == \
                    (b.counter, b.success, list(b.average_curve_radii), b.average_curve_radius, b.eccentricity)
             assert all(np.array_equal(p, q) for p, q in zip(a.left_fit_coeffs + a.right_fit_coeffs, b.left_fit_coeffs + b.right_fit_coeffs))
