@@ -168,6 +168,10 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
             res["process_stream_annotated_first_pass_fps"] = stream_rate(cold, True)
             res["process_stream_annotated_fps"] = max(stream_rate(cold, True) for _ in range(2))
             res["annotated_frames_came_back_by"] = lt._ctx.download_stats()
+            rows = lt._present_rows() if lt.host_copies_rows else None
+            res["annotated_frames_travel_as"] = ("whole frames" if rows is None else
+                                                 "row runs %s of %d rows (text lines, rows the lane can reach: copy kernel); the other rows are copied "
+                                                 "from the caller's window by host threads" % (rows[2], cal["img_size"][1]))
             res["success_ratio"] = round(lt.get_success_ratio()[0], 4)
             # ... and with outages: every 64th frame starts 16 frames of noise / flat grey / black (tools/outage_profile.py)
             broken = cold[0].copy()
@@ -197,7 +201,7 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                    "returned; process_batch() = one window per call, searches chained on the device (lt_band_fit_chain_run), check_validity / "
                    "history on the host; process_stream() = the same over consecutive windows, the next windows' uploads and masks under the "
                    "current one's searches; *_first_pass = the first time the runtime sees those pages, the figure beside it a later pass "
-                   "(the *_annotated figures return every annotated frame: 2 x the frame bytes over the bus; *_outages: four outages of 16 "
+                   "(the *_annotated figures return every annotated frame; only the rows an overlay can touch cross the bus, annotated_frames_travel_as; *_outages: four outages of 16 "
                    "frames per window, handled in speculative groups; *_demo1: settings.DEMO_1, mask_noise = True); success_ratio is that of "
                    "the clean streams; 1920x1080 is BASELINE config 5" % (len(next(iter(streams.values()))), nwin, window))
     return out
