@@ -327,8 +327,8 @@ int  lt_host_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t s
 int  lt_host_copy_wait(void);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact
- * size, and reused by later allocations; it returns to the driver when more than LT_DEVICE_CACHE_GB (default: an eighth of the
- * device memory, at most 32 GB) would be kept, and here: everything beyond keep_bytes now.  Why: memory handed back to the
+ * size, and reused by later allocations; it returns to the driver when more than LT_DEVICE_CACHE_GB (default: half of the
+ * device memory, at most 128 GB) would be kept, and here: everything beyond keep_bytes now.  Why: memory handed back to the
  * driver is wiped in the background on an SDMA engine, and for that time the process's device-to-host copies run at half
  * speed (csrc/lt_api.cpp, DevCache). */
 int  lt_device_cache_trim(size_t keep_bytes);

@@ -219,8 +219,8 @@ namespace {
 // 768-slot buffers -- does the same to the annotated stream that follows: 9.3 k instead of 15 k frames/s; uploads are not
 // affected).  That is what rounds 2-3 described as "two states of the copy engine".  So freed blocks are kept, per device
 // and exact size, and handed out again (a tracker closed and another of the same shape opened, a context growing back to a
-// size it had); they go back to the driver only when more than LT_DEVICE_CACHE_GB (default: an eighth of the device's memory,
-// at most 32 GB) would be kept, largest first, or at lt_device_cache_trim / process exit.
+// size it had); they go back to the driver only when more than LT_DEVICE_CACHE_GB (default: half of the device's memory,
+// at most 128 GB) would be kept, largest first, or at lt_device_cache_trim / process exit.
 struct DevCache {
     std::mutex m;
     std::multimap<std::pair<int, size_t>, void*> blocks;       // (device, bytes) -> free block
@@ -270,7 +270,7 @@ static void cached_free(void* p) {
         size_t free_b = 0, total_b = 0;
         const char* e = std::getenv("LT_DEVICE_CACHE_GB");
         if (e) dc.cap = (long long)(std::atof(e) * 1e9);
-        else dc.cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? (long long)std::min<size_t>(total_b / 8, (size_t)32 << 30) : 0;
+        else dc.cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? (long long)std::min<size_t>(total_b / 2, (size_t)128 << 30) : 0;
     }
     if ((long long)key.second > dc.cap) { g.unlock(); (void)hipFree(p); return; }
     dc.blocks.insert({key, p});
@@ -285,7 +285,11 @@ static void cached_free(void* p) {
         dc.blocks.erase(big);
     }
     g.unlock();
-    for (void* q : out) (void)hipFree(q);
+    static const bool trace = std::getenv("LT_TRACE_DESTROY") != nullptr;
+    for (void* q : out) {
+        if (trace) { std::fprintf(stderr, "device cache over its cap: hipFree(%p)\n", q); std::fflush(stderr); }
+        (void)hipFree(q);
+    }
 }
 
 template <class T>
@@ -954,9 +958,18 @@ void lt_destroy(lt_ctx* c) {
     // Everything this context has in flight ends here, on EVERY stream it owns: its device memory goes back to the cache below
     // (dev_free), not through hipFree -- which used to wait for the whole device -- and the next context may be handed the very
     // same blocks at once (a cancelled chain still runs one more frame; copies may be queued on the download stream).
+    static const bool trace = std::getenv("LT_TRACE_DESTROY") != nullptr;     // where a close() that does not return is waiting
+    auto note = [&](const char* what) { if (trace) { std::fprintf(stderr, "lt_destroy: %s\n", what); std::fflush(stderr); } };
+    note("streams of the slots");
     for (auto st : c->streams) if (st) (void)hipStreamSynchronize(st);
-    for (hipStream_t st : {c->copy, c->side, c->search, c->present, c->urgent, c->dl}) if (st) (void)hipStreamSynchronize(st);
+    {
+        const char* names[6] = {"copy", "side", "search", "present", "urgent", "dl"};
+        hipStream_t sts[6] = {c->copy, c->side, c->search, c->present, c->urgent, c->dl};
+        for (int i = 0; i < 6; ++i) if (sts[i]) { note(names[i]); (void)hipStreamSynchronize(sts[i]); }
+    }
+    note("slots");
     free_slots(c);
+    note("tables and buffers");
     dev_free(c->d_uxy);
     dev_free(c->d_wxy);
     dev_free(c->d_ufrac);
@@ -970,6 +983,7 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_advance);
     dev_free(c->d_lines);
     dev_free(c->d_xpos);
+    note("events, streams, page-locked buffers");
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
     if (c->spans_busy.done) (void)hipEventDestroy(c->spans_busy.done);
@@ -1002,6 +1016,7 @@ void lt_destroy(lt_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto st : c->streams) if (st) (void)hipStreamDestroy(st);
     if (c->streams.empty() && c->stream) (void)hipStreamDestroy(c->stream);
+    note("done");
     delete c;
 }
 
