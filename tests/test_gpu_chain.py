@@ -218,6 +218,33 @@ def test_config5_1080p_stream_chained():
         bat.close()
 
 
+def test_config5_1080p_annotated_frames_as_row_runs():
+    """1920x1080 (BASELINE config 5): the annotated frames of a batch and of a stream of windows travel as row runs (text
+    lines + the rows the lane can reach; the rest copied from the caller's window by the library's copy threads) and equal
+    the frames `process()` brings back whole, failures included."""
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.scaled_calibration(1.5)
+    frames = _stream_with_failures(36, 9, seed=39, cal=cal)
+    seq, bat, stm = LaneTracker(**cal), LaneTracker(**cal), LaneTracker(**cal)
+    seq.host_copies_rows = False
+    try:
+        rows = bat._present_rows()
+        assert rows is not None and rows[2][1] <= rows[2][2] and rows[2][3] <= 1080
+        want = [seq.process(f) for f in frames]
+        got = bat.process_batch(frames, annotate=True)
+        assert _state(bat) == _state(seq)
+        assert all(np.array_equal(g, w) for g, w in zip(got, want))
+        outs = [o for win in stm.process_stream([frames[:20], frames[20:21], frames[21:]], annotate=True) for o in win]
+        assert _state(stm) == _state(seq)
+        assert len(outs) == len(want) and all(np.array_equal(g, w) for g, w in zip(outs, want))
+        assert 0 < seq.success < seq.counter
+    finally:
+        seq.close()
+        bat.close()
+        stm.close()
+
+
 def test_chain_fuzz_short():
     """A short run of tests/fuzz_chain.py (random streams with jumps and outages, random tracker / chain parameters, random
     window splits): process_batch == process() after every window."""
