@@ -330,7 +330,7 @@ int  lt_host_free(void* p);
  * size, and reused by later allocations; it returns to the driver when more than LT_DEVICE_CACHE_GB (default: half of the
  * device memory, at most 128 GB) would be kept, and here: everything beyond keep_bytes now.  Why: memory handed back to the
  * driver is wiped in the background on an SDMA engine, and for that time the process's device-to-host copies run at half
- * speed (csrc/lt_api.cpp, DevCache). */
+ * speed (csrc/lt_memory.cpp, DevCache). */
 int  lt_device_cache_trim(size_t keep_bytes);
 /* the bird's-eye RGB image of the slots' frames (lane_tracker.py:834, :1035): n * warp_h * warp_w * 3;
  * needs lt_mask_run on those slots first (it reuses their undistorted rows) */

@@ -18,13 +18,17 @@
 
 #include <hip/hip_ext.h>
 
-#include "lt_internal.h"
+#include "lt_ctx.h"
 
 using namespace lt;
 
 namespace {
 
 thread_local std::string g_err;
+
+}  // namespace
+
+namespace lt {
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -36,274 +40,9 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIP_TRY(expr)                                                                               \
-    do {                                                                                            \
-        hipError_t e_ = (expr);                                                                     \
-        if (e_ != hipSuccess) return fail(LT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-enum Stage {
-    ST_UNDISTORT = 0, ST_WARP_SPLIT, ST_ERODE_R, ST_TOPHAT_R, ST_ERODE_B, ST_TOPHAT_B, ST_THRESHOLD, ST_MERGE,
-    ST_OPEN, ST_SWS_FIT, ST_BAND_FIT, ST_SPLIT_BEV
-};
 const char* kStageNames[LT_NUM_STAGES] = {"undistort_rows", "warp_split", "erode_r29", "tophat_r29", "erode_b55",
                                           "tophat_b55", "threshold", "merge", "open5", "sws_fit", "band_fit",
                                           "split_bev"};
-
-enum Plane { P_R = 0, P_B, P_THR, P_THB, P_MERGED, P_MASK, P_T0, P_T1, P_T2, P_T3, P_COUNT };
-
-}  // namespace
-
-struct lt_ctx {
-    lt_calib calib{};
-    int device = 0;
-    hipStream_t stream = nullptr;             // = streams[0]
-    std::vector<hipStream_t> streams;         // slot s runs on streams[s * nstreams / capacity]
-    hipStream_t copy = nullptr;               // lt_upload_frame_rest: the rows the path does not read, off the critical path
-    hipStream_t side = nullptr;               // second branch of a one- or two-frame chain (R and b top-hats side by side)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int nstreams = 1;
-    hipDeviceProp_t prop{};
-    FrontEndGeom fe{};
-    int cam_r0 = 0, cam_r1 = 0;               // camera rows the undistortion reads (its taps for rows [fe.r0, fe.r0 + nrows))
-    EllipseSE se5{}, se29{}, se55{};
-    // device tables
-    int16_t *d_uxy = nullptr, *d_wxy = nullptr;
-    uint16_t *d_ufrac = nullptr, *d_wfrac = nullptr, *d_gamma = nullptr, *d_cbrt = nullptr;
-    int32_t* d_coef = nullptr;
-    // slots
-    int capacity = 0;
-    size_t frame_bytes = 0, und_bytes = 0, plane_bytes = 0, bev_bytes = 0;
-    uint8_t *d_frames = nullptr, *d_bev = nullptr;
-    uint32_t* d_und = nullptr;        // undistorted camera rows [r0, r0+nrows), one RGBX dword per pixel, slots 2p / 2p+1 interleaved (und_slot_base)
-    size_t und_px = 0;                // pixels per slot of d_und
-    uint8_t* d_plane[P_COUNT] = {};
-    unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
-    unsigned long long* d_bits_open = nullptr;    // the opened mask as the mask chain leaves it (what the searches read)
-    unsigned long long* d_bits_tmp = nullptr;     // third and fourth partial plane of the walking threshold kernels
-    unsigned long long* d_bits_tmp2 = nullptr;
-    // Top-hat planes with a 64-byte-multiple row pitch: what the walking threshold kernels read (every 64-byte piece of
-    // a row is one aligned sector; with the image width as pitch the horizontal pass fetched every sector twice).
-    // th_padded[slot] says which copy of the slot's top-hat planes is current (lt_download_plane).
-    uint8_t* d_th_pad[2] = {nullptr, nullptr};
-    size_t th_pad_bytes = 0;
-    int th_pitch = 0;
-    std::vector<uint8_t> th_padded;
-    // mask_noise through the walking kernels (allocated by the first such call, ensure_noise_buffers): the raw Lab-b plane
-    // in the padded layout (the 55x55 top-hat launch stores its minuend there) and the two greenery-mask bit planes
-    uint8_t* d_b_pad = nullptr;
-    unsigned long long *d_bits_n1 = nullptr, *d_bits_n2 = nullptr;
-    int last_threshold_path = -1;                 // lt_last_threshold_path
-    int last_adaptive_path = -1;                  // 'neighborhood' calls: 1 = running box sums (k_adaptive_walk.hip), 0 = per-pixel windows
-    // The walking threshold kernels are long serial walks (a wave covers half an image row or column): they win once a
-    // call brings enough frames to fill the chip -- measured crossover 70-80 frames of 1100 x 1080 per call
-    // (tools/threshold_crossover.py: 64 frames 232 vs 210 us, 96 frames 255 vs 304 us) -- and lose badly on a single
-    // frame (164 vs 25 us).  Calls below this many pixels take the tile kernel.  LT_WALK_MIN_FRAMES=<n> (read at
-    // lt_create, in frames of this context's bird's-eye size) overrides it; 0 = always walk.
-    long long walk_min_pixels = 80LL * 1100 * 1080;
-    // per slot: which forms of the mask are current.  The chain writes the bit plane only; the u8 mask
-    // (d_plane[P_MASK]) is expanded from it when somebody asks for it; lt_upload_masks provides u8 only.
-    std::vector<uint8_t> mask_bits_ok, mask_u8_ok;
-    size_t bits_stride = 0;                                                  // u64 words per slot
-    lt_lane_record* d_rec = nullptr;
-    double* d_prev = nullptr;
-    uint32_t* d_pix = nullptr;
-    int32_t* d_cent = nullptr;
-    uint32_t* d_band_sums = nullptr;  // [slot][band][warp_w] column sums of the search bands
-    int maxpix = 0, maxlev = 0, maxbands = 0;
-    bool have_mask = false;
-    bool brute_tophat = false;
-    // presentation stage (lt_overlay_*): inverse-warp table, per-slot row intervals, annotated frames
-    int16_t* d_oxy = nullptr;
-    uint16_t* d_ofrac = nullptr;
-    bool have_overlay = false;
-    int16_t* d_spans = nullptr;       // [slot][warp_h] (lo, hi)
-    uint8_t* d_annot = nullptr;
-    // Page-locked staging with one region PER SLOT (row intervals, text lines, glyph positions), so that an overlay call only
-    // enqueues copies and kernels: calls over disjoint slots never wait for each other (the stream pipeline renders a window
-    // in pieces while later frames are still searched).  A call over slots whose previous overlay may still be in flight
-    // waits for that one first (overlay_lo / overlay_hi / overlay_done).
-    int16_t* h_spans = nullptr;       // [capacity][warp_h * 2]
-    int h_spans_cap = 0;
-    struct StagingBusy { int lo = 0, hi = 0; hipEvent_t done = nullptr; };   // slots whose staging region a copy may still read
-    StagingBusy spans_busy, text_busy;
-    hipStream_t dl = nullptr;         // lt_download_overlay_async: device-to-host copies beside the compute and upload streams
-    // The presentation kernels (spans copy, lane overlay, text) run on a stream of their own: on a slot's compute stream they would
-    // queue behind the mask launches of LATER frames, which wait for uploads the bus has not delivered yet (measured: the first
-    // overlay of a stream of windows ran 30 ms after its frames were ready).  It waits, per slot range, for the kernels that
-    // wrote the slots' masks (hence for their camera rows) and for the copies of the remaining rows.
-    hipStream_t present = nullptr;
-    // lt_set_urgent: while on, the stage calls run on this stream instead of the slots' streams -- behind what was enqueued
-    // for THEIR slots only (slot-range events), not behind the masks of later frames queued on the slots' streams, which
-    // wait for uploads still on the bus.  The stateful stream handles a frame whose first try failed this way.
-    hipStream_t urgent = nullptr;
-    bool urgent_on = false;
-    StagingBusy annot_busy;           // annotated frames a copy on `dl` may still read
-    // How the annotated frames go back (lt_download_overlay_async): by the copy engine or by a kernel that stores into the
-    // page-locked destination.  Both are timed, copy by copy, with an event pair on the download stream; see choose_download().
-    struct DlTimed { hipEvent_t a, b; double bytes; int method; };
-    std::vector<DlTimed> dl_inflight;
-    std::vector<hipEvent_t> dl_event_pool;
-    double dl_rate[2] = {0.0, 0.0};   // GB/s, running mean of the last copies: [0] engine, [1] kernel
-    int dl_samples[2] = {0, 0};
-    int dl_method = 0;                // what the next copy uses
-    int dl_since_probe = 0;           // copies since the other method was last tried
-    int dl_forced = -1;               // LT_DL_KERNEL=0 / 1, lt_set_download_method: -1 = choose by measurement
-    hipEvent_t rest_done = nullptr;   // end of the most recent lt_upload_frame_rest on the copy stream
-    bool rest_pending = false;
-    // text: glyph atlas (set once) and the per-slot lines of the current call
-    uint8_t *d_atlas = nullptr, *d_advance = nullptr, *d_lines = nullptr;
-    int16_t* d_xpos = nullptr;
-    std::vector<uint8_t> h_advance;
-    uint8_t* h_lines = nullptr;       // page-locked, [text_slots][text_per_slot]
-    int16_t* h_xpos = nullptr;
-    int font_first = 0, font_glyphs = 0, font_gw = 0, font_gh = 0;
-    size_t text_per_slot = 0;         // characters per slot the text buffers hold (n_lines * line_len of the largest call)
-    int text_slots = 0;
-    // ordering events of lt_upload_frame_rows_async (a ring: an event is reused long after its waits were enqueued)
-    std::vector<hipEvent_t> order_events;
-    size_t order_next = 0;
-    // Slot-range bookkeeping of work in flight on the slots' streams, so that other streams wait for exactly what they
-    // depend on instead of for the tails of those streams:
-    //   readers -- kernels that READ the camera frames (undistortion, overlay): a stream-ordered upload into slots waits for
-    //              the readers of those slots only, so the rows of later frames cross the bus while earlier ones are processed;
-    //   writers -- kernels that wrote masks / records: a chained search waits for the writers of its own slots only.
-    // A ring each; finished entries are dropped as new ones arrive (a long stream never synchronises the whole context).
-    // The ring grows with the launches in flight (an outage group adds two or three entries per piece while the head
-    // still waits for the bus); beyond 4096 entries it gives up (`overflow`) and waiters fall back to the tails of every
-    // stream that can touch the slots, until the next full synchronisation.
-    struct RangeEvents {
-        struct Entry { int lo, hi; hipEvent_t ev; };
-        std::vector<Entry> e = std::vector<Entry>(32, Entry{0, 0, nullptr});
-        unsigned head = 0, count = 0;
-        bool overflow = false;
-        void reset() { head = count = 0; overflow = false; }
-    };
-    RangeEvents readers, writers;
-    RangeEvents rests;                        // lt_upload_frame_rest copies (copy stream): the overlay of a slot waits for ITS rows only
-    // The chained band search of a stream (lt_band_fit_chain_run) is one workgroup walking many frames: it runs on a stream
-    // of its own, beside the mask chains of later frames on the slots' streams.  A chain leaves its records in page-locked
-    // host memory behind an event (lt_band_fit_chain_collect waits for that event only, not for the device).  Work on the
-    // slots' streams that touches slots of a chain still in flight waits for it (for_each_slice).
-    hipStream_t search = nullptr;
-    int search_cus = 0;                       // lt_set_search_cus: CUs the search stream has to itself (0: none reserved)
-    struct ChainTicket { int first, n; hipEvent_t done; int own; };   // own: first slot the chain searched itself (first + 1 when slot `first` is only its seed record)
-    std::vector<ChainTicket> chains;          // not yet collected, oldest first
-    std::vector<hipEvent_t> chain_event_pool;
-    int* h_cancel = nullptr;                  // page-locked, device-visible: chains launched with an older epoch stop at their next frame
-    int* d_cancel = nullptr;                  // its device address
-    uint8_t* h_small = nullptr;               // page-locked scratch of the small downloads (download())
-    int ov_r0 = 0, ov_r1 = 0;                 // camera rows the lane overlay can change (lt_overlay_configure)
-    lt_lane_record* h_rec = nullptr;          // page-locked mirror of the record of the last ONE-frame search (mirror_record)
-    int rec_mirror_slot = -1;                 // the slot whose record the mirror holds once rec_mirror_stream is idle; -1: none
-    hipStream_t rec_mirror_stream = nullptr;
-    lt_lane_record* h_rec_stage = nullptr;    // capacity records
-    int h_rec_stage_cap = 0;
-    // timing
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool stage_timing = false;
-    std::vector<hipEvent_t> ev_pool;
-    struct Pending { int stage; hipEvent_t a, b; };
-    std::vector<Pending> pending;
-    size_t ev_used = 0;
-    float stage_ms[LT_NUM_STAGES] = {};
-    int32_t stage_launches[LT_NUM_STAGES] = {};
-};
-
-namespace {
-
-// Device memory goes through a small cache instead of straight back to the driver.  Memory handed back with hipFree is wiped by
-// the kernel driver in the background, on an SDMA engine -- and while that runs, the copy engine's device-to-host copies of
-// THIS process drop from 50-56 to 28-30 GB/s (tools/copy_engine_probe.py: one lone 350 MB download takes 12.7 ms instead of
-// 6.3 for the first third of a second after a 5 GB context is destroyed; a context growing twice -- freeing its 256- and
-// 768-slot buffers -- does the same to the annotated stream that follows: 9.3 k instead of 15 k frames/s; uploads are not
-// affected).  That is what rounds 2-3 described as "two states of the copy engine".  So freed blocks are kept, per device
-// and exact size, and handed out again (a tracker closed and another of the same shape opened, a context growing back to a
-// size it had); they go back to the driver only when more than LT_DEVICE_CACHE_GB (default: half of the device's memory,
-// at most 128 GB) would be kept, largest first, or at lt_device_cache_trim / process exit.
-struct DevCache {
-    std::mutex m;
-    std::multimap<std::pair<int, size_t>, void*> blocks;       // (device, bytes) -> free block
-    std::map<void*, std::pair<int, size_t>> live;              // blocks handed out: their device and size
-    size_t kept = 0;
-    long long cap = -1;                                        // bytes; -1: not decided yet
-};
-static DevCache& dev_cache() { static DevCache* c = new DevCache; return *c; }   // (never destroyed: no order problems at exit)
-
-static void* cached_alloc(size_t bytes) {
-    DevCache& dc = dev_cache();
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    {
-        std::lock_guard<std::mutex> g(dc.m);
-        auto it = dc.blocks.find({dev, bytes});
-        if (it != dc.blocks.end()) {
-            void* p = it->second;
-            dc.blocks.erase(it);
-            dc.kept -= bytes;
-            dc.live[p] = {dev, bytes};
-            return p;
-        }
-    }
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) {                  // make room: everything kept goes back, then once more
-        (void)hipGetLastError();
-        (void)lt_device_cache_trim(0);
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    }
-    std::lock_guard<std::mutex> g(dc.m);
-    dc.live[p] = {dev, bytes};
-    return p;
-}
-static void cached_free(void* p) {
-    // hipFree waits for the device before it releases anything, and callers have always relied on that (a block freed while
-    // another of the context's streams still works on it); a cached block can be handed out again at once, so the same wait
-    // happens here.
-    (void)hipDeviceSynchronize();
-    DevCache& dc = dev_cache();
-    std::unique_lock<std::mutex> g(dc.m);
-    auto it = dc.live.find(p);
-    if (it == dc.live.end()) { g.unlock(); (void)hipFree(p); return; }
-    const std::pair<int, size_t> key = it->second;
-    dc.live.erase(it);
-    if (dc.cap < 0) {
-        size_t free_b = 0, total_b = 0;
-        const char* e = std::getenv("LT_DEVICE_CACHE_GB");
-        if (e) dc.cap = (long long)(std::atof(e) * 1e9);
-        else dc.cap = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? (long long)std::min<size_t>(total_b / 2, (size_t)128 << 30) : 0;
-    }
-    if ((long long)key.second > dc.cap) { g.unlock(); (void)hipFree(p); return; }
-    dc.blocks.insert({key, p});
-    dc.kept += key.second;
-    std::vector<void*> out;
-    while ((long long)dc.kept > dc.cap && !dc.blocks.empty()) {       // over the cap: the largest blocks go back to the driver
-        auto big = dc.blocks.begin();
-        for (auto j = dc.blocks.begin(); j != dc.blocks.end(); ++j)
-            if (j->first.second > big->first.second) big = j;
-        dc.kept -= big->first.second;
-        out.push_back(big->second);
-        dc.blocks.erase(big);
-    }
-    g.unlock();
-    static const bool trace = std::getenv("LT_TRACE_DESTROY") != nullptr;
-    for (void* q : out) {
-        if (trace) { std::fprintf(stderr, "device cache over its cap: hipFree(%p)\n", q); std::fflush(stderr); }
-        (void)hipFree(q);
-    }
-}
-
-template <class T>
-int dev_alloc(T** p, size_t count) {
-    if (count == 0) count = 1;
-    *p = static_cast<T*>(cached_alloc(count * sizeof(T)));
-    if (!*p) return fail(LT_ERR_NOMEM, "hipMalloc(%zu bytes) failed", count * sizeof(T));
-    return LT_OK;
-}
-template <class T>
-void dev_free(T*& p) {
-    if (p) cached_free(p);
-    p = nullptr;
-}
 
 int sync_all(lt_ctx* c) {
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) HIP_TRY(hipStreamSynchronize(c->streams[i]));
@@ -362,68 +101,12 @@ int wait_range(const lt_ctx::RangeEvents& r, hipStream_t waiter, int lo, int hi,
 }
 int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) { return note_range(c->writers, st, lo, hi); }
 
-
-
-// Slot -> stream mapping is fixed (contiguous slices of the capacity), so consecutive stages of one
-// slot stay ordered on one stream while different slices overlap: the latency-bound search of one
-// slice runs under the mask chain of another.  Calls fn(stream, first, n) for every non-empty piece.
-hipEvent_t next_order_event(lt_ctx* c);
 // `st` waits for the chains still outstanding (not collected) that read or write slots [lo, hi): ticket by ticket, so that work on
 // a frame in front of a running chain -- the second try of a failed frame while the frames behind it are already chained -- does
 // not wait for that chain
-static int wait_chains(lt_ctx* c, hipStream_t st, int lo, int hi) {
+int wait_chains(lt_ctx* c, hipStream_t st, int lo, int hi) {
     for (const auto& t : c->chains)
         if (t.first < hi && t.first + t.n > lo) HIP_TRY(hipStreamWaitEvent(st, t.done, 0));
-    return LT_OK;
-}
-template <class F>
-int for_each_slice(lt_ctx* c, int first, int n, F fn) {
-    const int k = std::max(1, std::min(c->nstreams, c->capacity));
-    if (c->urgent_on && c->urgent) {
-        // one piece on the urgent stream: behind the kernels that wrote these slots (or, with the ring overflowed, the tails of
-        // their streams) and a chain still touching them; the slots' own streams then wait for it, so that whatever is
-        // enqueued for these slots later stays ordered behind it
-        hipStream_t us = c->urgent;
-        bool precise = true;
-        int rc = wait_range(c->writers, us, first, first + n, &precise);
-        if (rc) return rc;
-        auto slices = [&](auto g) {
-            for (int si = 0; si < k; ++si) {
-                const int lo = (int)((long long)c->capacity * si / k) & ~1, hi = si + 1 == k ? c->capacity : (int)((long long)c->capacity * (si + 1) / k) & ~1;
-                if (std::min(first + n, hi) > std::max(first, lo)) { int r = g(c->streams[si]); if (r) return r; }
-            }
-            return (int)LT_OK;
-        };
-        if (!precise) {
-            rc = slices([&](hipStream_t st) {
-                hipEvent_t e = next_order_event(c);
-                if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-                HIP_TRY(hipEventRecord(e, st));
-                HIP_TRY(hipStreamWaitEvent(us, e, 0));
-                return (int)LT_OK;
-            });
-            if (rc) return rc;
-        }
-        if ((rc = wait_chains(c, us, first, first + n))) return rc;
-        if ((rc = fn(us, first, n))) return rc;
-        hipEvent_t done = next_order_event(c);
-        if (!done) return fail(LT_ERR_HIP, "hipEventCreate failed");
-        HIP_TRY(hipEventRecord(done, us));
-        return slices([&](hipStream_t st) {
-            HIP_TRY(hipStreamWaitEvent(st, done, 0));
-            return (int)LT_OK;
-        });
-    }
-    for (int si = 0; si < k; ++si) {
-        // even boundaries: the undistorted rows of slots 2p and 2p+1 are interleaved, and the warp serves a pair with one load
-        const int lo = (int)((long long)c->capacity * si / k) & ~1, hi = si + 1 == k ? c->capacity : (int)((long long)c->capacity * (si + 1) / k) & ~1;
-        const int a = std::max(first, lo), b = std::min(first + n, hi);
-        if (b <= a) continue;
-        int rc = wait_chains(c, c->streams[si], a, b);                     // a chain in flight reads / writes these slots
-        if (rc) return rc;
-        rc = fn(c->streams[si], a, b - a);
-        if (rc) return rc;
-    }
     return LT_OK;
 }
 
@@ -440,34 +123,6 @@ int flush_stage_events(lt_ctx* c) {
     c->ev_used = 0;
     return LT_OK;
 }
-
-// RAII-free helper pair: bracket one kernel launch with events when stage timing is on
-struct StageScope {
-    lt_ctx* c;
-    int stage;
-    hipStream_t st;
-    hipEvent_t a = nullptr, b = nullptr;
-    StageScope(lt_ctx* c_, int stage_, hipStream_t st_ = nullptr) : c(c_), stage(stage_), st(st_ ? st_ : c_->stream) {
-        if (!c->stage_timing) return;
-        if (c->ev_used + 2 > c->ev_pool.size()) {
-            if (flush_stage_events(c) != LT_OK) return;
-            while (c->ev_pool.size() < 256) {
-                hipEvent_t e;
-                if (hipEventCreate(&e) != hipSuccess) break;
-                c->ev_pool.push_back(e);
-            }
-        }
-        if (c->ev_used + 2 > c->ev_pool.size()) return;
-        a = c->ev_pool[c->ev_used++];
-        b = c->ev_pool[c->ev_used++];
-        (void)hipEventRecord(a, st);
-    }
-    ~StageScope() {
-        if (!a) return;
-        (void)hipEventRecord(b, st);
-        c->pending.push_back({stage, a, b});
-    }
-};
 
 hipEvent_t next_order_event(lt_ctx* c) {
     constexpr size_t RING = 64;
@@ -816,7 +471,31 @@ int make_search_geom(lt_ctx* c, const lt_search_params* p, bool band, SearchGeom
     return LT_OK;
 }
 
-}  // namespace
+// The streams that carry the slot slices' kernels.  The HIP runtime multiplexes the streams of a process onto a
+// small pool of hardware queues PER PRIORITY LEVEL (4 by default), in creation order -- so in a process that already
+// holds other streams (torch's, RCCL's) two slices can land on one queue and stop overlapping (measured: 9 % of the
+// batch rate under torch.distributed).  The slices therefore take the highest priority level, whose pool nothing
+// else in the process uses; LT_STREAM_PRIORITY=normal restores plain streams.
+// reserved > 0 (lt_set_search_cus): the stream is kept off CUs 0 .. reserved-1 (bits of the CU mask), which the search stream
+// has to itself -- see lt_set_search_cus.  hipExtStreamCreateWithCUMask takes no priority, so a CU-masked stream has the
+// runtime's default priority and LT_STREAM_PRIORITY has no effect on it: the priority only serves to put the slices of an
+// independent-batch context on separate hardware queues (contexts that never call lt_set_search_cus), while a stream
+// context runs its slices back to back behind the bus anyway.
+hipError_t create_compute_stream(hipStream_t* st, int reserved) {
+    if (reserved > 0) {
+        uint32_t mask[8];
+        for (auto& w : mask) w = 0xffffffffu;
+        for (int i = 0; i < reserved && i < 256; ++i) mask[i >> 5] &= ~(1u << (i & 31));
+        return hipExtStreamCreateWithCUMask(st, 8, mask);
+    }
+    const char* e = getenv("LT_STREAM_PRIORITY");
+    int least = 0, greatest = 0;
+    if ((e && strcmp(e, "normal") == 0) || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
+}
+
+}  // namespace lt
 
 // ================================================================================================
 extern "C" {
@@ -831,30 +510,6 @@ int lt_device_count(int* count) {
 }
 
 const char* lt_stage_name(int stage) { return stage >= 0 && stage < LT_NUM_STAGES ? kStageNames[stage] : ""; }
-
-// The streams that carry the slot slices' kernels.  The HIP runtime multiplexes the streams of a process onto a
-// small pool of hardware queues PER PRIORITY LEVEL (4 by default), in creation order -- so in a process that already
-// holds other streams (torch's, RCCL's) two slices can land on one queue and stop overlapping (measured: 9 % of the
-// batch rate under torch.distributed).  The slices therefore take the highest priority level, whose pool nothing
-// else in the process uses; LT_STREAM_PRIORITY=normal restores plain streams.
-// reserved > 0 (lt_set_search_cus): the stream is kept off CUs 0 .. reserved-1 (bits of the CU mask), which the search stream
-// has to itself -- see lt_set_search_cus.  hipExtStreamCreateWithCUMask takes no priority, so a CU-masked stream has the
-// runtime's default priority and LT_STREAM_PRIORITY has no effect on it: the priority only serves to put the slices of an
-// independent-batch context on separate hardware queues (contexts that never call lt_set_search_cus), while a stream
-// context runs its slices back to back behind the bus anyway.
-static hipError_t create_compute_stream(hipStream_t* st, int reserved = 0) {
-    if (reserved > 0) {
-        uint32_t mask[8];
-        for (auto& w : mask) w = 0xffffffffu;
-        for (int i = 0; i < reserved && i < 256; ++i) mask[i >> 5] &= ~(1u << (i & 31));
-        return hipExtStreamCreateWithCUMask(st, 8, mask);
-    }
-    const char* e = getenv("LT_STREAM_PRIORITY");
-    int least = 0, greatest = 0;
-    if ((e && strcmp(e, "normal") == 0) || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-    return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
-}
 
 int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     if (!calib || !out) return fail(LT_ERR_INVALID, "null argument");
@@ -1269,7 +924,9 @@ int lt_upload_bev(lt_ctx* c, const uint8_t* bev, int first, int n) {
     return LT_OK;
 }
 
-static int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
+}  // extern "C"
+namespace lt {
+int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
     if (!dst) return fail(LT_ERR_INVALID, "null output buffer");
     int rc = set_device(c);
     if (rc) return rc;
@@ -1295,6 +952,8 @@ static int download(lt_ctx* c, const void* src, void* dst, size_t bytes) {
     HIP_TRY(hipStreamSynchronize(st));
     return LT_OK;
 }
+}  // namespace lt
+extern "C" {
 
 int lt_download_masks(lt_ctx* c, int first, int n, uint8_t* masks) {
     int rc = check_slots(c, first, n);
@@ -1355,68 +1014,6 @@ int lt_download_undistorted(lt_ctx* c, int first, int n, uint8_t* out) {
     return rc;
 }
 
-// ---- presentation stage: draw_lane() overlay and the bird's-eye image ----------------
-namespace {
-
-// Row intervals of cv2.fillPoly's result for a polygon whose two chains are functions of y: the
-// union of the 8-connected edge lines and the even-odd interior is, per row, the hull of the edge
-// pixels on that row.  The walk is OpenCV's LineIterator (left end point first, error term
-// dx - 2 dy, one major-axis step per pixel).
-static inline void span_point(int16_t* spans, int bh, int x, int y) {
-    if (y >= 0 && y < bh) {
-        const int16_t xc = (int16_t)std::min(std::max(x, -32768), 32767);
-        if (xc < spans[2 * y]) spans[2 * y] = xc;
-        if (xc > spans[2 * y + 1]) spans[2 * y + 1] = xc;
-    }
-}
-
-static void span_line(int16_t* spans, int bh, int xa, int ya, int xb, int yb) {
-    if (std::abs(xb - xa) <= 1 && std::abs(yb - ya) <= 1) {
-        // neighbouring pixels (nearly every edge of a lane polygon: one plot point per row): the line is its two end points
-        span_point(spans, bh, xa, ya);
-        span_point(spans, bh, xb, yb);
-        return;
-    }
-    if (xb < xa) { std::swap(xa, xb); std::swap(ya, yb); }
-    const int adx = xb - xa, ady = std::abs(yb - ya), ystep = yb < ya ? -1 : 1;
-    const bool tall = ady > adx;
-    const int len = tall ? ady : adx, across = tall ? adx : ady;
-    int err = len - 2 * across;
-    for (int i = 0, x = xa, y = ya; i <= len; ++i) {
-        if (y >= 0 && y < bh) {
-            const int16_t xc = (int16_t)std::min(std::max(x, -32768), 32767);
-            if (xc < spans[2 * y]) spans[2 * y] = xc;
-            if (xc > spans[2 * y + 1]) spans[2 * y + 1] = xc;
-        }
-        const bool turn = err < 0;
-        err -= 2 * across;
-        if (turn) err += 2 * len;
-        if (tall) { y += ystep; x += turn ? 1 : 0; }
-        else { x += 1; y += turn ? ystep : 0; }
-    }
-}
-
-static void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int nl, const int32_t* ryx, int nr) {
-    for (int y = 0; y < bh; ++y) { spans[2 * y] = 32767; spans[2 * y + 1] = -32768; }
-    const int np = nl + nr;
-    if (np <= 0) return;
-    // vertex k of the closed polygon: the left points in order, then the right points reversed (np.flipud)
-    const int32_t* last = nr ? ryx : lyx + 2 * (nl - 1);          // vertex np - 1: the first right point, or the last left one
-    int px = last[1], py = last[0];
-    for (int k = 0; k < nl; ++k) {
-        span_line(spans, bh, px, py, lyx[2 * k + 1], lyx[2 * k]);
-        px = lyx[2 * k + 1];
-        py = lyx[2 * k];
-    }
-    for (int k = nr - 1; k >= 0; --k) {
-        span_line(spans, bh, px, py, ryx[2 * k + 1], ryx[2 * k]);
-        px = ryx[2 * k + 1];
-        py = ryx[2 * k];
-    }
-}
-
-}  // namespace
-
 // ---- host-only views of the calibration tables lt_create builds (no GPU needed) --------------------------------
 int lt_calib_source_rows(const lt_calib* calib, int* row0, int* row1) {
     if (!calib || !row0 || !row1) return fail(LT_ERR_INVALID, "null argument");
@@ -1459,761 +1056,6 @@ int lt_calib_ellipse(int k, int32_t* halfwidths, int* taps) {
     *taps = ellipse_halfwidths(k, dx);
     for (int i = 0; i < k; ++i) halfwidths[i] = dx[i];
     return LT_OK;
-}
-
-int lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,
-                          int16_t* spans) {
-    if (warp_h < 1 || n_left < 0 || n_right < 0 || !spans || (n_left && !left_yx) || (n_right && !right_yx))
-        return fail(LT_ERR_INVALID, "bad polygon arguments");
-    lane_polygon_spans(spans, warp_h, left_yx, n_left, right_yx, n_right);
-    return LT_OK;
-}
-
-int lt_overlay_configure(lt_ctx* c, const double* Minv) {
-    if (!c || !Minv) return fail(LT_ERR_INVALID, "null argument");
-    int rc = set_device(c);
-    if (rc) return rc;
-    if ((rc = sync_all(c))) return rc;
-    // cv2.warpPerspective(lane, Minv, (img_w, img_h)): the same table builder with M := Minv and the
-    // camera frame as the destination
-    lt_calib u = c->calib;
-    std::memcpy(u.M, Minv, sizeof u.M);
-    u.warp_w = c->calib.img_w;
-    u.warp_h = c->calib.img_h;
-    RemapTable t;
-    build_warp_table(u, t);
-    dev_free(c->d_oxy);
-    dev_free(c->d_ofrac);
-    c->have_overlay = false;
-    if ((rc = dev_alloc(&c->d_oxy, t.xy.size()))) return rc;
-    if ((rc = dev_alloc(&c->d_ofrac, t.frac.size()))) return rc;
-    HIP_TRY(hipMemcpy(c->d_oxy, t.xy.data(), t.xy.size() * 2, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_ofrac, t.frac.data(), t.frac.size() * 2, hipMemcpyHostToDevice));
-    // Camera rows the lane can reach at all: a pixel's four taps are (sx, sy) .. (sx + 1, sy + 1), so only pixels with
-    // -1 <= sx <= bw - 1 and -1 <= sy <= bh - 1 can see the bird's-eye image; every other pixel of the annotated frame is the
-    // camera pixel whatever the polygon (lt_overlay_rows, lt_present_frame).
-    c->ov_r0 = c->ov_r1 = 0;
-    for (int y = 0; y < t.rows; ++y) {
-        bool any = false;
-        for (int x = 0; x < t.cols && !any; ++x) {
-            const int sx = t.xy[2 * ((size_t)y * t.cols + x)], sy = t.xy[2 * ((size_t)y * t.cols + x) + 1];
-            any = sx >= -1 && sx <= c->calib.warp_w - 1 && sy >= -1 && sy <= c->calib.warp_h - 1;
-        }
-        if (any) {
-            if (c->ov_r1 == 0) c->ov_r0 = y;
-            c->ov_r1 = y + 1;
-        }
-    }
-    c->have_overlay = true;
-    return LT_OK;
-}
-
-// A call is about to overwrite the page-locked staging regions of slots [first, first + n): if a copy out of those regions
-// may still be in flight (an earlier call of the same kind over the same slots), wait for it; then widen the busy range.
-static int staging_claim(lt_ctx::StagingBusy& b, int first, int n) {
-    if (b.hi > b.lo && first < b.hi && first + n > b.lo && b.done) {
-        HIP_TRY(hipEventSynchronize(b.done));
-        b.lo = b.hi = 0;
-    }
-    if (b.hi <= b.lo) { b.lo = first; b.hi = first + n; }
-    else { b.lo = std::min(b.lo, first); b.hi = std::max(b.hi, first + n); }
-    return LT_OK;
-}
-static int staging_mark(lt_ctx::StagingBusy& b, hipStream_t st) {
-    if (!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(b.done, st));
-    return LT_OK;
-}
-
-static int present_stream(lt_ctx* c) {
-    if (!c->present && create_compute_stream(&c->present, c->search_cus) != hipSuccess) return fail(LT_ERR_HIP, "hipStreamCreate failed");
-    return LT_OK;
-}
-
-int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const double* ploty, const double* ploty2, int n_rows,
-                   int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx) {
-    if (warp_w < 1 || warp_h < 1 || n < 0 || n_rows < 0 || !coeffs || !left_n || !right_n || !left_yx || !right_yx ||
-        (n_rows && (!ploty || !ploty2)))
-        return fail(LT_ERR_INVALID, "bad arguments");
-    // get_poly_points (lane_tracker.py:511-528) for n pairs of parabolas: fitx = a * ploty**2 + b * ploty + c evaluated as NumPy
-    // does (two products, two sums, no contraction: this file is built with -ffp-contract=off), the points with
-    // 0 <= fitx <= W - 1 kept, x truncated (astype(int)), and -- as upstream -- y = H - count .. H - 1 whatever rows they were
-    const double xmax = (double)(warp_w - 1);
-    size_t ol = 0, orr = 0;
-    for (int i = 0; i < n; ++i) {
-        for (int side = 0; side < 2; ++side) {
-            const double a = coeffs[6 * i + 3 * side], b = coeffs[6 * i + 3 * side + 1], cc = coeffs[6 * i + 3 * side + 2];
-            int32_t* out = side ? right_yx + 2 * orr : left_yx + 2 * ol;
-            int cnt = 0;
-            for (int r = 0; r < n_rows; ++r) {
-                const double t1 = a * ploty2[r], t2 = b * ploty[r];
-                const double x = (t1 + t2) + cc;
-                if (x <= xmax && x >= 0.0) out[2 * cnt++ + 1] = (int32_t)(long long)x;
-            }
-            for (int k = 0; k < cnt; ++k) out[2 * k] = warp_h - cnt + k;
-            if (side) { right_n[i] = cnt; orr += (size_t)cnt; }
-            else { left_n[i] = cnt; ol += (size_t)cnt; }
-        }
-    }
-    return LT_OK;
-}
-
-// lt_overlay_run; rows4: two runs of camera rows {a0, a1, b0, b1} outside which the annotated frames are not needed
-// (lt_present_frame, lt_overlay_run_rows), nullptr = all of them
-static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
-                            const int32_t* right_yx, double alpha, const int* rows4) {
-    int rc = check_slots(c, first, n);
-    if (rc) return rc;
-    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_run before lt_overlay_configure");
-    if (n == 0) return LT_OK;
-    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
-    long long tl = 0, tr = 0;
-    for (int i = 0; i < n; ++i) {
-        if (left_n[i] < 0 || right_n[i] < 0) return fail(LT_ERR_INVALID, "negative point count");
-        tl += left_n[i];
-        tr += right_n[i];
-    }
-    if ((tl && !left_yx) || (tr && !right_yx)) return fail(LT_ERR_INVALID, "null point list");
-    if ((rc = set_device(c))) return rc;
-    const int bh = c->calib.warp_h;
-    if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
-    if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
-    // One frame (process()): the intervals travel as a kernel argument -- no staging buffer, no copy launch, no events
-    static const bool arg_ok = [] { const char* e = std::getenv("LT_SPANS_ARG"); return !(e && e[0] == '0'); }();
-    bool one = arg_ok && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
-    int16_t one_spans[2 * LT_SPAN_ARG_ROWS];
-    auto claim_staging = [&]() -> int {
-        int r = staging_claim(c->spans_busy, first, n);
-        if (r) return r;
-        if (c->h_spans_cap < c->capacity) {
-            if ((r = sync_all(c))) return r;
-            if (c->h_spans) (void)hipHostFree(c->h_spans);
-            c->h_spans = nullptr;
-            c->h_spans_cap = 0;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
-            c->h_spans_cap = c->capacity;
-        }
-        return (int)LT_OK;
-    };
-    if (!one && (rc = claim_staging())) return rc;
-    int16_t* hs = one ? one_spans : c->h_spans + (size_t)first * bh * 2;
-    static const bool timing = std::getenv("LT_OVERLAY_TIMING") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    // ~18 us of edge walking per polygon: a window's piece of 32 .. 128 polygons is shared among a few threads (the caller is
-    // the one thread that feeds the device)
-    const int workers = std::max(1, std::min({n / 8, 8, (int)std::thread::hardware_concurrency()}));
-    auto some = [&](int w) {
-        size_t ol = 0, orr = 0;
-        for (int i = 0; i < n; ++i) {
-            if (i * (long long)workers / n == w)
-                lane_polygon_spans(hs + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
-                                   right_yx ? right_yx + 2 * orr : nullptr, right_n[i]);
-            ol += (size_t)left_n[i];
-            orr += (size_t)right_n[i];
-        }
-    };
-    if (workers == 1) some(0);
-    else {
-        std::vector<std::thread> pool;
-        for (int w = 1; w < workers; ++w) pool.emplace_back(some, w);
-        some(0);
-        for (auto& t : pool) t.join();
-    }
-    // the rows of the frame the path does not read came on the copy stream (lt_upload_frame_rest): the overlay is their reader
-    const auto t1 = std::chrono::steady_clock::now();
-    if ((rc = present_stream(c))) return rc;
-    hipStream_t ps = c->present;
-    if (c->rest_pending) {
-        bool precise = true;
-        if ((rc = wait_range(c->rests, ps, first, first + n, &precise))) return rc;
-        if (!precise) HIP_TRY(hipStreamWaitEvent(ps, c->rest_done, 0));
-    }
-    {   // the camera rows of these slots: behind the launches that wrote their masks (which waited for the rows' upload)
-        bool precise = true;
-        if ((rc = wait_range(c->writers, ps, first, first + n, &precise))) return rc;
-        if (!precise) {
-            rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
-                hipEvent_t e = next_order_event(c);
-                if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-                HIP_TRY(hipEventRecord(e, st));
-                HIP_TRY(hipStreamWaitEvent(ps, e, 0));
-                return (int)LT_OK;
-            });
-            if (rc) return rc;
-        }
-    }
-    // an asynchronous download may still be reading the annotated frames this call overwrites
-    if (c->annot_busy.hi > c->annot_busy.lo && first < c->annot_busy.hi && first + n > c->annot_busy.lo && c->annot_busy.done)
-        HIP_TRY(hipStreamWaitEvent(ps, c->annot_busy.done, 0));
-    if (one) {
-        if (launch_overlay_lane_one(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
-                                    c->d_oxy, c->d_ofrac, hs, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, rows4)) {
-            HIP_TRY(hipGetLastError());
-            return note_range(c->readers, ps, first, first + n);
-        }
-        // not launched (the runtime refused the argument block): the staged way after all, with the intervals already built
-        one = false;
-        if ((rc = claim_staging())) return rc;
-        std::memcpy(c->h_spans + (size_t)first * bh * 2, one_spans, (size_t)bh * 2 * sizeof(int16_t));
-        hs = c->h_spans + (size_t)first * bh * 2;
-    }
-    launch_copy_from_pinned(ps, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
-    const auto t2 = std::chrono::steady_clock::now();
-    launch_overlay_lane(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
-                        c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
-                        c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n, rows4);
-    HIP_TRY(hipGetLastError());
-    if ((rc = staging_mark(c->spans_busy, ps))) return rc;
-    rc = note_range(c->readers, ps, first, first + n);
-    if (timing) {
-        const auto t3 = std::chrono::steady_clock::now();
-        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
-        std::fprintf(stderr, "overlay_run n=%d: spans %ld us, wait+memcpy %ld us, launch+events %ld us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
-    }
-    return rc;
-}
-
-int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
-                   const int32_t* right_yx, double alpha) {
-    return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr);
-}
-
-static int ordered_rows(lt_ctx* c, const int32_t* rows4, int r[4]) {
-    for (int k = 0; k < 4; ++k) r[k] = rows4[k];
-    if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= c->calib.img_h))
-        return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
-    return LT_OK;
-}
-
-int lt_overlay_run_rows(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
-                        const int32_t* right_yx, double alpha, const int32_t* rows4) {
-    if (!rows4) return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr);
-    if (!c) return fail(LT_ERR_INVALID, "null context");
-    int r[4];
-    const int rc = ordered_rows(c, rows4, r);
-    if (rc) return rc;
-    return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, r);
-}
-
-int lt_overlay_rows(lt_ctx* c, int* row0, int* row1) {
-    if (!c || !row0 || !row1) return fail(LT_ERR_INVALID, "null argument");
-    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_rows before lt_overlay_configure");
-    *row0 = c->ov_r0;
-    *row1 = c->ov_r1;
-    return LT_OK;
-}
-
-int lt_overlay_set_font(lt_ctx* c, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
-                        int glyph_h) {
-    if (!c || !atlas || !advance) return fail(LT_ERR_INVALID, "null argument");
-    if (n_glyphs < 1 || n_glyphs > 256 || glyph_w < 1 || glyph_w > 255 || glyph_h < 1 || glyph_h > 255 || first_char < 0)
-        return fail(LT_ERR_INVALID, "bad font geometry");
-    int rc = set_device(c);
-    if (rc) return rc;
-    if ((rc = sync_all(c))) return rc;
-    dev_free(c->d_atlas);
-    dev_free(c->d_advance);
-    c->font_glyphs = 0;
-    const size_t bytes = (size_t)n_glyphs * glyph_w * glyph_h;
-    if ((rc = dev_alloc(&c->d_atlas, bytes))) return rc;
-    if ((rc = dev_alloc(&c->d_advance, (size_t)n_glyphs))) return rc;
-    HIP_TRY(hipMemcpy(c->d_atlas, atlas, bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->d_advance, advance, (size_t)n_glyphs, hipMemcpyHostToDevice));
-    c->h_advance.assign(advance, advance + n_glyphs);
-    c->font_first = first_char;
-    c->font_glyphs = n_glyphs;
-    c->font_gw = glyph_w;
-    c->font_gh = glyph_h;
-    return LT_OK;
-}
-
-int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines, int line_len, int x0, int y0, int step) {
-    int rc = check_slots(c, first, n);
-    if (rc) return rc;
-    if (!c->font_glyphs) return fail(LT_ERR_STATE, "lt_overlay_text before lt_overlay_set_font");
-    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_overlay_text before lt_overlay_run");
-    if (n == 0 || n_lines <= 0 || line_len <= 0) return LT_OK;
-    if (!lines) return fail(LT_ERR_INVALID, "null text");
-    if ((rc = set_device(c))) return rc;
-    const size_t per = (size_t)n_lines * line_len;
-    if (per > c->text_per_slot || c->text_slots < c->capacity) {      // (re)size the per-slot text buffers: rare, synchronises
-        if ((rc = sync_all(c))) return rc;
-        const size_t per_new = (std::max(per, c->text_per_slot) + 3) & ~(size_t)3, total = per_new * (size_t)c->capacity;
-        dev_free(c->d_lines);
-        dev_free(c->d_xpos);
-        if (c->h_lines) (void)hipHostFree(c->h_lines);
-        if (c->h_xpos) (void)hipHostFree(c->h_xpos);
-        c->h_lines = nullptr;
-        c->h_xpos = nullptr;
-        c->text_per_slot = 0;
-        c->text_slots = 0;
-        if ((rc = dev_alloc(&c->d_lines, total))) return rc;
-        if ((rc = dev_alloc(&c->d_xpos, total))) return rc;
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_lines), total, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_xpos), total * sizeof(int16_t), hipHostMallocDefault));
-        c->text_per_slot = per_new;
-        c->text_slots = c->capacity;
-    }
-    if ((rc = staging_claim(c->text_busy, first, n))) return rc;
-    // A slot's lines sit at the slot's own position in the per-slot buffers, at their FIXED stride text_per_slot -- not at
-    // this call's n_lines * line_len: staging_claim orders calls by slot range, and two calls in flight over disjoint
-    // slots with different line counts (a 'fail' piece has one line, a lane piece two) must not meet in bytes.
-    const size_t stride = c->text_per_slot;
-    uint8_t* hl = c->h_lines + (size_t)first * stride;
-    int16_t* hx = c->h_xpos + (size_t)first * stride;
-    for (int i = 0; i < n; ++i) {
-        std::memcpy(hl + (size_t)i * stride, lines + (size_t)i * per, per);
-        for (int l = 0; l < n_lines; ++l) {                // left edge of every character: running sum of advances
-            const char* src = lines + (size_t)i * per + (size_t)l * line_len;
-            int16_t* dst = hx + (size_t)i * stride + (size_t)l * line_len;
-            int x = x0;
-            bool ended = false;
-            for (int k = 0; k < line_len; ++k) {
-                const unsigned char ch = (unsigned char)src[k];
-                ended = ended || ch == 0;
-                dst[k] = (int16_t)std::min(x, 32767);
-                const int g = (int)ch - c->font_first;
-                if (!ended && g >= 0 && g < c->font_glyphs) x += c->h_advance[(size_t)g];
-            }
-        }
-    }
-    uint8_t* dl = c->d_lines + (size_t)first * stride;
-    int16_t* dx = c->d_xpos + (size_t)first * stride;
-    if ((rc = present_stream(c))) return rc;
-    // A frame or two (process(), one frame per call): the kernel reads the few hundred bytes from the page-locked buffers
-    // themselves -- two launches fewer between the record and the annotated frame.  A window's worth goes to the device first.
-    const uint8_t* kl = dl;
-    const int16_t* kx = dx;
-    void *pl = nullptr, *px = nullptr;
-    static const bool direct_ok = [] { const char* e = std::getenv("LT_TEXT_DIRECT"); return !(e && e[0] == '0'); }();
-    if (direct_ok && n <= 2 && hipHostGetDevicePointer(&pl, hl, 0) == hipSuccess && hipHostGetDevicePointer(&px, hx, 0) == hipSuccess &&
-        pl && px) {
-        kl = static_cast<const uint8_t*>(pl);
-        kx = static_cast<const int16_t*>(px);
-    } else {
-        (void)hipGetLastError();
-        launch_copy_from_pinned(c->present, dl, hl, (size_t)n * stride);
-        launch_copy_from_pinned(c->present, dx, hx, (size_t)n * stride * sizeof(int16_t));
-    }
-    launch_overlay_text(c->present, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
-                        c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, kl, kx,
-                        n_lines, line_len, (int)stride, y0, step, n);
-    HIP_TRY(hipGetLastError());
-    return staging_mark(c->text_busy, c->present);
-}
-
-// Page-locked host memory for the buffers a caller hands to the upload / download entry points: a copy from or to
-// pageable memory is staged by the runtime at a fraction of the PCIe rate (2.8 MB annotated frame: ~0.3 ms against
-// ~0.06 ms).  Plain allocation helpers: no context, usable as soon as a device exists.
-int lt_host_alloc(size_t bytes, void** out) {
-    if (!out || bytes == 0) return fail(LT_ERR_INVALID, "lt_host_alloc: null output or zero size");
-    *out = nullptr;
-    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        *out = nullptr;
-        return fail(LT_ERR_HIP, "hipHostMalloc(%zu) failed", bytes);
-    }
-    return LT_OK;
-}
-
-int lt_device_cache_trim(size_t keep_bytes) {
-    DevCache& dc = dev_cache();
-    std::vector<void*> out;
-    {
-        std::lock_guard<std::mutex> g(dc.m);
-        while (dc.kept > keep_bytes && !dc.blocks.empty()) {
-            auto it = dc.blocks.begin();
-            dc.kept -= it->first.second;
-            out.push_back(it->second);
-            dc.blocks.erase(it);
-        }
-    }
-    for (void* q : out) (void)hipFree(q);
-    return LT_OK;
-}
-
-int lt_host_free(void* p) {
-    if (!p) return LT_OK;
-    if (hipHostFree(p) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(LT_ERR_HIP, "hipHostFree failed");
-    }
-    return LT_OK;
-}
-
-// ---- a second host thread for plain copies -------------------------------------------------------------------------------
-// LaneTracker.process() fills the rows of its output array that no overlay can touch from the caller's frame (1.4 MB at
-// 1280x720, 3.2 MB at 1920x1080: 60 / 130 us of memcpy).  The thread that feeds the device has launches to issue meanwhile;
-// these have nothing else to do.  A few workers per process (LT_COPY_THREADS), started at the first request that can use them,
-// joined when the library is unloaded.
-extern "C++" {
-namespace {
-struct HostCopier {
-    struct Job { uint8_t* dst; const uint8_t* src; size_t dpitch, spitch, width, height; };
-    std::mutex m;
-    std::condition_variable work, done;
-    std::deque<Job> q;
-    size_t pending = 0;          // pieces taken and not finished yet
-    bool stop = false;
-    std::vector<std::thread> th;
-    void run() {
-        std::unique_lock<std::mutex> lk(m);
-        for (;;) {
-            work.wait(lk, [&] { return stop || !q.empty(); });
-            if (q.empty()) return;               // stop
-            const Job j = q.front();
-            q.pop_front();
-            lk.unlock();
-            if (j.dpitch == j.width && j.spitch == j.width) std::memcpy(j.dst, j.src, j.width * j.height);
-            else
-                for (size_t r = 0; r < j.height; ++r) std::memcpy(j.dst + r * j.dpitch, j.src + r * j.spitch, j.width);
-            lk.lock();
-            if (--pending == 0) done.notify_all();
-        }
-    }
-    int threads() {              // LT_COPY_THREADS (1 .. 16), default 4: a window of annotated frames is 0.36 GB of untouched rows
-        static const int n = [] { const char* e = std::getenv("LT_COPY_THREADS"); const int v = e ? std::atoi(e) : 4; return std::min(std::max(v, 1), 16); }();
-        return n;
-    }
-    void submit(const Job& whole) {
-        // pieces of whole rows ("rows" of the 2-D copy: frames), a few per worker so that they finish together
-        const size_t parts = whole.height <= 1 ? 1 : std::min<size_t>(whole.height, (size_t)threads() * 2);
-        {
-            std::lock_guard<std::mutex> lk(m);
-            while ((int)th.size() < (whole.height <= 1 ? 1 : threads())) th.emplace_back([this] { run(); });
-            for (size_t k = 0; k < parts; ++k) {
-                const size_t r0 = whole.height * k / parts, r1 = whole.height * (k + 1) / parts;
-                if (r1 > r0) { q.push_back({whole.dst + r0 * whole.dpitch, whole.src + r0 * whole.spitch, whole.dpitch, whole.spitch, whole.width, r1 - r0}); ++pending; }
-            }
-        }
-        work.notify_all();
-    }
-    ~HostCopier() {
-        { std::lock_guard<std::mutex> lk(m); stop = true; q.clear(); }
-        work.notify_all();
-        for (auto& t : th) if (t.joinable()) t.join();
-    }
-};
-HostCopier& host_copier() { static HostCopier h; return h; }
-}  // namespace
-}  // extern "C++"
-
-int lt_host_copy_async(void* dst, const void* src, size_t bytes) {
-    if (bytes == 0) return LT_OK;
-    if (!dst || !src) return fail(LT_ERR_INVALID, "lt_host_copy_async: null pointer");
-    host_copier().submit({static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), bytes, bytes, bytes, 1});
-    return LT_OK;
-}
-
-int lt_host_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t height) {
-    if (width == 0 || height == 0) return LT_OK;
-    if (!dst || !src) return fail(LT_ERR_INVALID, "lt_host_copy2d_async: null pointer");
-    if (dst_pitch < width || src_pitch < width) return fail(LT_ERR_INVALID, "lt_host_copy2d_async: a pitch below the width");
-    host_copier().submit({static_cast<uint8_t*>(dst), static_cast<const uint8_t*>(src), dst_pitch, src_pitch, width, height});
-    return LT_OK;
-}
-
-int lt_host_copy_wait(void) {
-    HostCopier& h = host_copier();
-    std::unique_lock<std::mutex> lk(h.m);
-    h.done.wait(lk, [&] { return h.pending == 0; });
-    return LT_OK;
-}
-
-int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
-    int rc = check_slots(c, first, n);
-    if (rc) return rc;
-    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay before lt_overlay_run");
-    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    const uint8_t* src = c->d_annot + (size_t)first * c->frame_bytes;
-    const size_t bytes = (size_t)n * c->frame_bytes;
-    if (!c->present || n == 0) return download(c, src, out, bytes);
-    // The annotated frames are written on the presentation stream and nowhere else (lt_overlay_run, lt_overlay_text), behind
-    // everything they depend on: the copy is enqueued there, behind them, and the host waits once -- not once for the overlay
-    // and once more for a copy it issues only then (10 us of process()'s 0.4 ms per frame).
-    if ((rc = set_device(c))) return rc;
-    // a frame or two: by a copy kernel (no engine start-up: 11 us less per frame of process()); LT_DL1_KERNEL=0: the engine
-    static const bool by_kernel = [] { const char* e = std::getenv("LT_DL1_KERNEL"); return !(e && e[0] == '0'); }();
-    if (!(by_kernel && n <= 2 && launch_copy_to_pinned(c->present, out, src, bytes)))
-        HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->present));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->present));
-    return LT_OK;
-}
-
-// process()'s tail for ONE frame in one call: lt_overlay_run + lt_overlay_text + the way back, the host waiting once.  With
-// rows4 = {a0, a1, b0, b1} only those two runs of camera rows are drawn and written to `out` (the rows at their places in the
-// frame): a pixel outside the rows the lane can reach (lt_overlay_rows) and outside the text lines is the camera pixel, which
-// the caller has -- process() copies those rows from its input while the device is busy, and only half the frame crosses the
-// bus behind the overlay.  The runs must cover the text lines and, for a non-empty polygon, lt_overlay_rows.
-static int present_copy_rows(lt_ctx* c, int slot, uint8_t* out, int row0, int row1) {
-    if (row1 <= row0) return LT_OK;
-    const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)row0 * row_bytes, bytes = (size_t)(row1 - row0) * row_bytes;
-    const uint8_t* src = c->d_annot + (size_t)slot * c->frame_bytes;
-    if (!launch_copy_to_pinned(c->present, out + off, src + off, bytes))
-        HIP_TRY(hipMemcpyAsync(out + off, src + off, bytes, hipMemcpyDeviceToHost, c->present));
-    HIP_TRY(hipGetLastError());
-    return LT_OK;
-}
-// rows4 -> r[4] (nullptr: the whole frame as the first run); `split`: the text lines must lie in the first run and the rows the
-// lane can reach in the second, the two apart -- the condition for drawing and sending the second run before the text exists
-static int present_rows(lt_ctx* c, const int32_t* rows4, bool text, int n_lines, int y0, int step, bool lane, bool split, int r[4]) {
-    const int H = c->calib.img_h;
-    r[0] = 0; r[1] = H; r[2] = H; r[3] = H;
-    if (!rows4) return split ? fail(LT_ERR_INVALID, "two row runs are needed") : (int)LT_OK;
-    for (int k = 0; k < 4; ++k) r[k] = rows4[k];
-    if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= H))
-        return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
-    auto within = [&](int lo, int hi, int a, int b) { lo = std::max(lo, 0); hi = std::min(hi, H); return lo >= hi || (a <= lo && hi <= b); };
-    const int t0 = y0, t1 = y0 + (n_lines - 1) * step + c->font_gh;
-    if (split) {
-        if (text && !within(t0, t1, r[0], r[1])) return fail(LT_ERR_INVALID, "the first row run does not cover the text lines");
-        if (!within(c->ov_r0, c->ov_r1, r[2], r[3])) return fail(LT_ERR_INVALID, "the second row run does not cover the rows the lane can reach (lt_overlay_rows)");
-        return LT_OK;
-    }
-    auto covered = [&](int lo, int hi) { return within(lo, hi, r[0], r[1]) || within(lo, hi, r[2], r[3]) || (r[1] == r[2] && within(lo, hi, r[0], r[3])); };
-    if (text && !covered(t0, t1)) return fail(LT_ERR_INVALID, "the row runs do not cover the text lines");
-    if (lane && !covered(c->ov_r0, c->ov_r1)) return fail(LT_ERR_INVALID, "the row runs do not cover the rows the lane can reach (lt_overlay_rows)");
-    return LT_OK;
-}
-
-int lt_present_frame(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx, const int32_t* right_yx,
-                     double alpha, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
-                     const int32_t* rows4) {
-    int rc = check_slots(c, slot, 1);
-    if (rc) return rc;
-    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
-    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_frame before lt_overlay_configure");
-    const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
-    int r[4];
-    if ((rc = present_rows(c, rows4, text, n_lines, y0, step, left_n[0] > 0 || right_n[0] > 0, false, r))) return rc;
-    if ((rc = overlay_run_impl(c, slot, 1, left_n, right_n, left_yx, right_yx, alpha, rows4 ? r : nullptr))) return rc;
-    if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
-    if ((rc = present_copy_rows(c, slot, out, r[0], r[1]))) return rc;
-    if ((rc = present_copy_rows(c, slot, out, r[2], r[3]))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->present));
-    return LT_OK;
-}
-
-// lt_present_frame in two halves, for a caller that knows the polygon before it knows the text (LaneTracker.process(): the
-// averaged curves follow from the record at once, radius, eccentricity and the verdict on the frame take the host another
-// 25 us): the first half draws both row runs and sends the second one -- the rows the lane can reach -- on its way without
-// waiting; the second half blends the text into the first run, sends that and waits for both.  A first half whose frame turns
-// out invalid is simply followed by a whole lt_present_frame (same slot, same `out`): it draws and sends everything again.
-int lt_present_lane_async(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
-                          const int32_t* right_yx, double alpha, uint8_t* out, const int32_t* rows4) {
-    int rc = check_slots(c, slot, 1);
-    if (rc) return rc;
-    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
-    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_lane_async before lt_overlay_configure");
-    int r[4];
-    if ((rc = present_rows(c, rows4, false, 0, 0, 0, true, true, r))) return rc;
-    if ((rc = overlay_run_impl(c, slot, 1, left_n, right_n, left_yx, right_yx, alpha, r))) return rc;
-    return present_copy_rows(c, slot, out, r[2], r[3]);
-}
-
-int lt_present_finish(lt_ctx* c, int slot, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
-                      const int32_t* rows4) {
-    int rc = check_slots(c, slot, 1);
-    if (rc) return rc;
-    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    if (!c->d_annot || !c->present) return fail(LT_ERR_STATE, "lt_present_finish before lt_present_lane_async");
-    const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
-    int r[4];
-    if ((rc = present_rows(c, rows4, text, n_lines, y0, step, false, true, r))) return rc;
-    if ((rc = set_device(c))) return rc;
-    if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
-    if ((rc = present_copy_rows(c, slot, out, r[0], r[1]))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->present));
-    return LT_OK;
-}
-
-static void harvest_downloads(lt_ctx* c);
-static int choose_download(lt_ctx* c);
-static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out, const int* rows4);
-int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) { return download_overlay_async_impl(c, first, n, out, nullptr); }
-int lt_download_overlay_rows_async(lt_ctx* c, int first, int n, uint8_t* out, const int32_t* rows4) {
-    if (!rows4) return download_overlay_async_impl(c, first, n, out, nullptr);
-    if (!c) return fail(LT_ERR_INVALID, "null context");
-    int r[4];
-    const int rc = ordered_rows(c, rows4, r);
-    if (rc) return rc;
-    return download_overlay_async_impl(c, first, n, out, r);
-}
-// rows4: only these two runs of rows of every frame (at their places in `out`), nullptr: whole frames
-static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out, const int* rows4) {
-    int rc = check_slots(c, first, n);
-    if (rc) return rc;
-    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay_async before lt_overlay_run");
-    if (n == 0) return LT_OK;
-    if ((rc = set_device(c))) return rc;
-    // on a stream of its own, behind the overlay work enqueued so far: the copy neither holds up the kernels queued behind
-    // it on the context's stream nor shares a queue with the uploads
-    if (!c->dl) {
-        if (c->search_cus >= 2) {                  // the reserved CUs but the first are the copy kernel's (lt_set_search_cus)
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = 1; b < c->search_cus && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
-            HIP_TRY(hipExtStreamCreateWithCUMask(&c->dl, 8, mask));
-        } else {                                   // highest priority: the copy kernel's few workgroups go ahead of the mask kernels'
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
-        }
-    }
-    hipEvent_t e = next_order_event(c);
-    if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(e, c->present ? c->present : c->stream));
-    HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
-    // engine or kernel: by measurement (choose_download); LT_DL_KERNEL=1 / 0 and lt_set_download_method pin one of them
-    static const int env_method = [] { const char* e = std::getenv("LT_DL_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
-    if (env_method >= 0 && c->dl_forced < 0) c->dl_forced = env_method;
-    harvest_downloads(c);
-    int method = choose_download(c);
-    auto timing_event = [&]() -> hipEvent_t {
-        hipEvent_t ev = nullptr;
-        if (!c->dl_event_pool.empty()) { ev = c->dl_event_pool.back(); c->dl_event_pool.pop_back(); }
-        else if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
-        return ev;
-    };
-    hipEvent_t ta = timing_event(), tb = timing_event();
-    if (ta && tb) HIP_TRY(hipEventRecord(ta, c->dl));
-    size_t bytes = (size_t)n * c->frame_bytes;
-    const uint8_t* src = c->d_annot + (size_t)first * c->frame_bytes;
-    if (!rows4) {
-        if (method == 1 && !launch_copy_to_pinned(c->dl, out, src, bytes)) method = 0;   // not page-locked / aligned
-        if (method == 0) HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->dl));
-    } else {
-        const size_t row_bytes = (size_t)c->calib.img_w * 3;
-        bytes = 0;
-        // The kernel takes a run of rows of all the frames in one launch; the engine takes the run of ONE frame as an ordinary
-        // copy (a pitched copy over the frames it takes row by row: 120-160 ms for a window of 256 frames), two copies per
-        // frame -- 18.4 k frames/s of an annotated 1280x720 stream against the kernel's 22.6 k.  So the kernel, unless
-        // lt_set_download_method(0) / LT_DL_KERNEL=0 ask for the engine.
-        bool by_kernel = c->dl_forced != 0;
-        for (int k = 0; k < 4 && by_kernel; k += 2)       // both runs the same way, so that the timing below means one thing
-            by_kernel = rows4[k + 1] <= rows4[k] ||
-                        ((((size_t)rows4[k] * row_bytes) | ((size_t)(rows4[k + 1] - rows4[k]) * row_bytes) | c->frame_bytes | (size_t)(uintptr_t)out) & 15) == 0;
-        for (int k = 0; k < 4; k += 2) {
-            if (rows4[k + 1] <= rows4[k]) continue;
-            const size_t off = (size_t)rows4[k] * row_bytes, run = (size_t)(rows4[k + 1] - rows4[k]) * row_bytes;
-            if (by_kernel && !launch_copy_rows_to_pinned(c->dl, out, src, c->frame_bytes, off, run, n)) by_kernel = false;
-            bytes += run * (size_t)n;
-        }
-        if (!by_kernel)
-            for (int f = 0; f < n; ++f)
-                for (int k = 0; k < 4; k += 2) {
-                    if (rows4[k + 1] <= rows4[k]) continue;
-                    const size_t off = (size_t)f * c->frame_bytes + (size_t)rows4[k] * row_bytes;
-                    HIP_TRY(hipMemcpyAsync(out + off, src + off, (size_t)(rows4[k + 1] - rows4[k]) * row_bytes, hipMemcpyDeviceToHost, c->dl));
-                }
-        method = by_kernel ? 1 : 0;
-    }
-    HIP_TRY(hipGetLastError());
-    if (ta && tb) {
-        HIP_TRY(hipEventRecord(tb, c->dl));
-        c->dl_inflight.push_back({ta, tb, (double)bytes, method});
-    } else {
-        if (ta) c->dl_event_pool.push_back(ta);
-        if (tb) c->dl_event_pool.push_back(tb);
-    }
-    if (c->annot_busy.hi <= c->annot_busy.lo) { c->annot_busy.lo = first; c->annot_busy.hi = first + n; }
-    else { c->annot_busy.lo = std::min(c->annot_busy.lo, first); c->annot_busy.hi = std::max(c->annot_busy.hi, first + n); }
-    return staging_mark(c->annot_busy, c->dl);
-}
-
-// Engine or kernel?  The copy engine moves the frames at 48-56 GB/s when the page-locked destination and the device buffer are
-// laid out kindly, and at 28-30 GB/s when they are not -- a property of the memory the process happened to get (allocation
-// history, the box), not of anything this library orders: tools/copy_engine_probe.py RAW=1 shows one lone download at 29 GB/s
-// on the same engine, same code path, beside nothing.  (Rounds 2-3 read the resulting 9.3 k instead of 15 k frames/s of
-// the annotated 1280x720 stream as uploads and downloads "taking turns"; they do overlap.)  A kernel storing 16 bytes per lane
-// into the same destination is not affected (an annotated 1280x720 stream does 13.3 k frames/s that way in either regime: less
-// than the engine at its best, 15 k, because the copy kernel shares the chip with the mask chain, far more than the engine at
-// its worst).  So: every copy is timed with an event pair; the engine is the default; when its running rate drops below
-// DL_SLOW GB/s the kernel takes over, and one copy in DL_REPROBE goes by the engine again so that a recovery is noticed.
-static constexpr double DL_SLOW = 36.0;
-static constexpr int DL_REPROBE = 48;
-static void harvest_downloads(lt_ctx* c) {
-    size_t keep = 0;
-    for (size_t i = 0; i < c->dl_inflight.size(); ++i) {
-        lt_ctx::DlTimed& d = c->dl_inflight[i];
-        float ms = 0.f;
-        if (hipEventQuery(d.b) == hipSuccess && hipEventElapsedTime(&ms, d.a, d.b) == hipSuccess) {
-            if (ms > 0.f && d.bytes >= 8e6) {              // small copies time the launch, not the bus
-                const double r = d.bytes / (ms * 1e-3) / 1e9;
-                c->dl_rate[d.method] = c->dl_samples[d.method] ? 0.5 * c->dl_rate[d.method] + 0.5 * r : r;
-                ++c->dl_samples[d.method];
-            }
-            c->dl_event_pool.push_back(d.a);
-            c->dl_event_pool.push_back(d.b);
-        } else {
-            (void)hipGetLastError();
-            c->dl_inflight[keep++] = d;
-        }
-    }
-    c->dl_inflight.resize(keep);
-}
-static int choose_download(lt_ctx* c) {
-    if (c->dl_forced >= 0) return c->dl_forced;
-    const int cur = c->dl_method, other = 1 - cur;
-    ++c->dl_since_probe;
-    if (c->dl_samples[cur] >= 4) {       // (the first copies of a stream are short and wait for their overlays: not a verdict)
-        const bool never = c->dl_samples[other] == 0;
-        if (cur == 0 && c->dl_rate[0] < DL_SLOW && (never || c->dl_rate[1] > c->dl_rate[0])) { c->dl_method = 1; c->dl_since_probe = 0; }
-        else if (cur == 1 && c->dl_rate[0] >= DL_SLOW) { c->dl_method = 0; c->dl_since_probe = 0; }   // the engine has recovered
-        else if (c->dl_since_probe >= DL_REPROBE && (cur == 1 || c->dl_rate[0] < DL_SLOW)) {   // one copy the other way
-            c->dl_since_probe = 0;
-            return other;
-        }
-    }
-    return c->dl_method;
-}
-
-int lt_set_download_method(lt_ctx* c, int method) {
-    if (!c) return fail(LT_ERR_INVALID, "null context");
-    if (method < -1 || method > 1) return fail(LT_ERR_INVALID, "download method: -1 = measured choice, 0 = copy engine, 1 = kernel");
-    c->dl_forced = method;
-    return LT_OK;
-}
-
-int lt_download_stats(lt_ctx* c, double* engine_gbs, int* engine_copies, double* kernel_gbs, int* kernel_copies, int* method) {
-    if (!c) return fail(LT_ERR_INVALID, "null context");
-    harvest_downloads(c);
-    if (engine_gbs) *engine_gbs = c->dl_rate[0];
-    if (engine_copies) *engine_copies = c->dl_samples[0];
-    if (kernel_gbs) *kernel_gbs = c->dl_rate[1];
-    if (kernel_copies) *kernel_copies = c->dl_samples[1];
-    if (method) *method = c->dl_forced >= 0 ? c->dl_forced : c->dl_method;
-    return LT_OK;
-}
-
-int lt_download_overlay_wait(lt_ctx* c) {
-    if (!c) return fail(LT_ERR_INVALID, "null context");
-    int rc = set_device(c);
-    if (rc) return rc;
-    if (!c->dl) return LT_OK;
-    HIP_TRY(hipStreamSynchronize(c->dl));   // every copy of lt_download_overlay_async is behind its slots' overlay kernels
-    c->annot_busy.lo = c->annot_busy.hi = 0;
-    return LT_OK;
-}
-
-int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
-    int rc = check_slots(c, first, n);
-    if (rc) return rc;
-    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    if (!c->have_mask) return fail(LT_ERR_STATE, "lt_download_bev before lt_mask_run");
-    if (n == 0) return LT_OK;
-    if ((rc = set_device(c))) return rc;
-    if ((rc = ensure_bev(c))) return rc;
-    if ((rc = sync_all(c))) return rc;
-    uint8_t* dst = c->d_bev + (size_t)first * c->bev_bytes;
-    if (c->fe.nrows <= 0) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * c->bev_bytes, c->stream));
-    else
-        launch_warp_rgb(c->stream, c->d_und, c->und_px, first, c->d_wxy, c->d_wfrac, c->fe, dst, c->bev_bytes, n);
-    HIP_TRY(hipGetLastError());
-    return download(c, dst, out, (size_t)n * c->bev_bytes);
 }
 
 // A search over ONE slot (process(): one frame per call, the host waiting for its record) sends the record to page-locked
@@ -2433,17 +1275,6 @@ int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     return LT_OK;
 }
 
-static int ensure_search_stream(lt_ctx* c) {
-    if (c->search) return LT_OK;
-    if (c->search_cus > 0) {                  // the CUs the slots' streams were kept off (lt_set_search_cus)
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int mine = c->search_cus >= 2 ? 1 : c->search_cus;   // with two or more, the others are the download stream's
-        for (int i = 0; i < mine && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
-        HIP_TRY(hipExtStreamCreateWithCUMask(&c->search, 8, mask));
-    } else HIP_TRY(create_compute_stream(&c->search));
-    return LT_OK;
-}
-
 int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -2532,86 +1363,6 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
     return LT_OK;
 }
 
-int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p, const double* seed) {
-    int rc = check_slots(c, first, n);
-    if (rc) return rc;
-    c->rec_mirror_slot = -1;                  // the records change: the page-locked mirror of a one-frame search is stale
-    if (!seed && first < 1) return fail(LT_ERR_INVALID, "a chain without seed coefficients continues from the record of slot first - 1");
-    if ((rc = set_device(c))) return rc;
-    if (!c->have_mask) return fail(LT_ERR_STATE, "no mask in the slots: run lt_mask_run or lt_upload_masks first");
-    SearchGeom g;
-    if ((rc = make_search_geom(c, p, true, g))) return rc;
-    if ((rc = ensure_search_buffers(c, g.maxpix, 1))) return rc;
-    g.maxpix = c->maxpix;
-    if (!band_chain_supported(g, c->plane_bytes))
-        return fail(LT_ERR_STATE, "chained band search needs a band of at most 64 columns (2 * bandwidth + 2) and a mask width that is a multiple of 4");
-    if (n == 0) return LT_OK;
-    BandPrev bp;
-    std::memset(&bp, 0, sizeof bp);
-    if (seed) {
-        std::memcpy(bp.c, seed, sizeof bp.c);
-        bp.by_value = 1;
-    }
-    const bool use_bits = masks_have_bits(c, first, n) && band_fit_takes_bits(g, c->plane_bytes);
-    if (!use_bits && (rc = ensure_u8_masks(c, first, n))) return rc;
-    // The chain runs on the context's search stream, behind whatever the slots' streams hold so far (the masks of these
-    // slots, the search that wrote the seed record); those streams do not wait for it -- the mask chains of later frames run
-    // beside it -- unless they touch its slots (for_each_slice).
-    if ((rc = ensure_search_stream(c))) return rc;
-    if (!c->h_cancel) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_cancel), 64, hipHostMallocMapped));
-        *c->h_cancel = 0;
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cancel), c->h_cancel, 0));
-    }
-    const int lo = seed ? first : first - 1, cnt = seed ? n : n + 1;     // with a device seed the seed record is collected too
-    bool precise = true;
-    // everything the slots' streams wrote into these slots and may not have finished (their masks; the search that left the
-    // seed record); a seed record left by an earlier chain is ordered by the search stream itself
-    if ((rc = wait_range(c->writers, c->search, lo, lo + cnt, &precise))) return rc;
-    if (!precise) {
-        rc = for_each_slice(c, lo, cnt, [&](hipStream_t st, int, int) {      // the ring has overflowed: wait for the streams' tails
-            hipEvent_t e = next_order_event(c);
-            if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
-            HIP_TRY(hipEventRecord(e, st));
-            HIP_TRY(hipStreamWaitEvent(c->search, e, 0));
-            return (int)LT_OK;
-        });
-        if (rc) return rc;
-    }
-    if (c->h_rec_stage_cap < c->capacity) {
-        HIP_TRY(hipStreamSynchronize(c->search));
-        if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
-        c->h_rec_stage = nullptr;
-        c->h_rec_stage_cap = 0;
-        for (auto& t : c->chains) c->chain_event_pool.push_back(t.done);   // tickets of the old staging block: nothing to collect any more
-        c->chains.clear();
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_rec_stage), (size_t)c->capacity * sizeof(lt_lane_record), hipHostMallocDefault));
-        c->h_rec_stage_cap = c->capacity;
-    }
-    const int wpr = (c->calib.warp_w + 63) / 64;
-    {
-        StageScope t(c, ST_BAND_FIT, c->search);
-        const MaskBits mb{use_bits ? c->d_bits_open + (size_t)first * c->bits_stride : nullptr, c->bits_stride, wpr};
-        launch_band_chain(c->search, c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, c->plane_bytes, mb, g, seed ? nullptr : c->d_rec + first - 1,
-                          bp, c->d_pix + (size_t)first * 2 * c->maxpix, c->d_rec + first, n, c->d_cancel, *c->h_cancel);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->h_rec_stage + lo, c->d_rec + lo, (size_t)cnt * sizeof(lt_lane_record), hipMemcpyDeviceToHost, c->search));
-    hipEvent_t done = nullptr;
-    if (!c->chain_event_pool.empty()) { done = c->chain_event_pool.back(); c->chain_event_pool.pop_back(); }
-    else if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
-    HIP_TRY(hipEventRecord(done, c->search));
-    while (c->chains.size() >= 32) {            // tickets nobody collected: the oldest goes -- once its chain has really ended
-        // (a cancelled chain runs one more frame, and later work on its slots is ordered behind tickets only: dropping the
-        // ticket of a chain still running would let mask / search launches race with it)
-        HIP_TRY(hipEventSynchronize(c->chains.front().done));
-        c->chain_event_pool.push_back(c->chains.front().done);
-        c->chains.erase(c->chains.begin());
-    }
-    c->chains.push_back({lo, cnt, done, first});
-    return LT_OK;
-}
-
 int lt_set_urgent(lt_ctx* c, int on) {
     if (!c) return fail(LT_ERR_INVALID, "null context");
     int rc = set_device(c);
@@ -2649,35 +1400,6 @@ int lt_set_search_cus(lt_ctx* c, int n) {
     if (c->urgent) { (void)hipStreamDestroy(c->urgent); c->urgent = nullptr; c->urgent_on = false; }
     if (c->dl) { (void)hipStreamDestroy(c->dl); c->dl = nullptr; }
     c->search_cus = n;
-    return LT_OK;
-}
-
-int lt_band_fit_chain_cancel(lt_ctx* c) {
-    if (!c) return fail(LT_ERR_INVALID, "null context");
-    if (c->h_cancel) __atomic_fetch_add(c->h_cancel, 1, __ATOMIC_RELEASE);   // chains enqueued so far carry an older epoch
-    return LT_OK;
-}
-
-int lt_band_fit_chain_collect(lt_ctx* c, int first, int n, lt_lane_record* out) {
-    int rc = check_slots(c, first, n);
-    if (rc) return rc;
-    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    if (n == 0) return LT_OK;
-    if ((rc = set_device(c))) return rc;
-    // the most recent chain that covers the range decides (an older, superseded chain over the same slots is dropped) -- a chain
-    // that searched the range's first slot itself before one that only holds it as its seed record (a one-frame chain with
-    // another chain behind it: collecting the first must not use up the ticket of the second)
-    int hit = -1;
-    for (int pass = 0; pass < 2 && hit < 0; ++pass)
-        for (int i = (int)c->chains.size() - 1; i >= 0; --i) {
-            const lt_ctx::ChainTicket& t = c->chains[(size_t)i];
-            if ((pass ? t.first : t.own) <= first && first + n <= t.first + t.n) { hit = i; break; }
-        }
-    if (hit < 0) return fail(LT_ERR_STATE, "no chained search covers slots [%d, %d)", first, first + n);
-    HIP_TRY(hipEventSynchronize(c->chains[(size_t)hit].done));
-    std::memcpy(out, c->h_rec_stage + first, (size_t)n * sizeof(lt_lane_record));
-    for (int i = 0; i <= hit; ++i) c->chain_event_pool.push_back(c->chains[(size_t)i].done);   // this ticket and everything older
-    c->chains.erase(c->chains.begin(), c->chains.begin() + hit + 1);
     return LT_OK;
 }
 

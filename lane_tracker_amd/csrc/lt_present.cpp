@@ -1,0 +1,725 @@
+// Presentation stage of liblane_tracker_amd.so (lane_tracker.py:629-793): lane overlay, text lines,
+// annotated frames on their way back to the host.  See lt_ctx.h.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <hip/hip_ext.h>
+
+#include "lt_ctx.h"
+
+using namespace lt;
+
+// ---- presentation stage: draw_lane() overlay and the bird's-eye image ----------------
+namespace {
+
+// Row intervals of cv2.fillPoly's result for a polygon whose two chains are functions of y: the
+// union of the 8-connected edge lines and the even-odd interior is, per row, the hull of the edge
+// pixels on that row.  The walk is OpenCV's LineIterator (left end point first, error term
+// dx - 2 dy, one major-axis step per pixel).
+static inline void span_point(int16_t* spans, int bh, int x, int y) {
+    if (y >= 0 && y < bh) {
+        const int16_t xc = (int16_t)std::min(std::max(x, -32768), 32767);
+        if (xc < spans[2 * y]) spans[2 * y] = xc;
+        if (xc > spans[2 * y + 1]) spans[2 * y + 1] = xc;
+    }
+}
+
+static void span_line(int16_t* spans, int bh, int xa, int ya, int xb, int yb) {
+    if (std::abs(xb - xa) <= 1 && std::abs(yb - ya) <= 1) {
+        // neighbouring pixels (nearly every edge of a lane polygon: one plot point per row): the line is its two end points
+        span_point(spans, bh, xa, ya);
+        span_point(spans, bh, xb, yb);
+        return;
+    }
+    if (xb < xa) { std::swap(xa, xb); std::swap(ya, yb); }
+    const int adx = xb - xa, ady = std::abs(yb - ya), ystep = yb < ya ? -1 : 1;
+    const bool tall = ady > adx;
+    const int len = tall ? ady : adx, across = tall ? adx : ady;
+    int err = len - 2 * across;
+    for (int i = 0, x = xa, y = ya; i <= len; ++i) {
+        if (y >= 0 && y < bh) {
+            const int16_t xc = (int16_t)std::min(std::max(x, -32768), 32767);
+            if (xc < spans[2 * y]) spans[2 * y] = xc;
+            if (xc > spans[2 * y + 1]) spans[2 * y + 1] = xc;
+        }
+        const bool turn = err < 0;
+        err -= 2 * across;
+        if (turn) err += 2 * len;
+        if (tall) { y += ystep; x += turn ? 1 : 0; }
+        else { x += 1; y += turn ? ystep : 0; }
+    }
+}
+
+static void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int nl, const int32_t* ryx, int nr) {
+    for (int y = 0; y < bh; ++y) { spans[2 * y] = 32767; spans[2 * y + 1] = -32768; }
+    const int np = nl + nr;
+    if (np <= 0) return;
+    // vertex k of the closed polygon: the left points in order, then the right points reversed (np.flipud)
+    const int32_t* last = nr ? ryx : lyx + 2 * (nl - 1);          // vertex np - 1: the first right point, or the last left one
+    int px = last[1], py = last[0];
+    for (int k = 0; k < nl; ++k) {
+        span_line(spans, bh, px, py, lyx[2 * k + 1], lyx[2 * k]);
+        px = lyx[2 * k + 1];
+        py = lyx[2 * k];
+    }
+    for (int k = nr - 1; k >= 0; --k) {
+        span_line(spans, bh, px, py, ryx[2 * k + 1], ryx[2 * k]);
+        px = ryx[2 * k + 1];
+        py = ryx[2 * k];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,
+                          int16_t* spans) {
+    if (warp_h < 1 || n_left < 0 || n_right < 0 || !spans || (n_left && !left_yx) || (n_right && !right_yx))
+        return fail(LT_ERR_INVALID, "bad polygon arguments");
+    lane_polygon_spans(spans, warp_h, left_yx, n_left, right_yx, n_right);
+    return LT_OK;
+}
+
+int lt_overlay_configure(lt_ctx* c, const double* Minv) {
+    if (!c || !Minv) return fail(LT_ERR_INVALID, "null argument");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
+    // cv2.warpPerspective(lane, Minv, (img_w, img_h)): the same table builder with M := Minv and the
+    // camera frame as the destination
+    lt_calib u = c->calib;
+    std::memcpy(u.M, Minv, sizeof u.M);
+    u.warp_w = c->calib.img_w;
+    u.warp_h = c->calib.img_h;
+    RemapTable t;
+    build_warp_table(u, t);
+    dev_free(c->d_oxy);
+    dev_free(c->d_ofrac);
+    c->have_overlay = false;
+    if ((rc = dev_alloc(&c->d_oxy, t.xy.size()))) return rc;
+    if ((rc = dev_alloc(&c->d_ofrac, t.frac.size()))) return rc;
+    HIP_TRY(hipMemcpy(c->d_oxy, t.xy.data(), t.xy.size() * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_ofrac, t.frac.data(), t.frac.size() * 2, hipMemcpyHostToDevice));
+    // Camera rows the lane can reach at all: a pixel's four taps are (sx, sy) .. (sx + 1, sy + 1), so only pixels with
+    // -1 <= sx <= bw - 1 and -1 <= sy <= bh - 1 can see the bird's-eye image; every other pixel of the annotated frame is the
+    // camera pixel whatever the polygon (lt_overlay_rows, lt_present_frame).
+    c->ov_r0 = c->ov_r1 = 0;
+    for (int y = 0; y < t.rows; ++y) {
+        bool any = false;
+        for (int x = 0; x < t.cols && !any; ++x) {
+            const int sx = t.xy[2 * ((size_t)y * t.cols + x)], sy = t.xy[2 * ((size_t)y * t.cols + x) + 1];
+            any = sx >= -1 && sx <= c->calib.warp_w - 1 && sy >= -1 && sy <= c->calib.warp_h - 1;
+        }
+        if (any) {
+            if (c->ov_r1 == 0) c->ov_r0 = y;
+            c->ov_r1 = y + 1;
+        }
+    }
+    c->have_overlay = true;
+    return LT_OK;
+}
+
+// A call is about to overwrite the page-locked staging regions of slots [first, first + n): if a copy out of those regions
+// may still be in flight (an earlier call of the same kind over the same slots), wait for it; then widen the busy range.
+static int staging_claim(lt_ctx::StagingBusy& b, int first, int n) {
+    if (b.hi > b.lo && first < b.hi && first + n > b.lo && b.done) {
+        HIP_TRY(hipEventSynchronize(b.done));
+        b.lo = b.hi = 0;
+    }
+    if (b.hi <= b.lo) { b.lo = first; b.hi = first + n; }
+    else { b.lo = std::min(b.lo, first); b.hi = std::max(b.hi, first + n); }
+    return LT_OK;
+}
+static int staging_mark(lt_ctx::StagingBusy& b, hipStream_t st) {
+    if (!b.done && hipEventCreateWithFlags(&b.done, hipEventDisableTiming) != hipSuccess) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(b.done, st));
+    return LT_OK;
+}
+
+static int present_stream(lt_ctx* c) {
+    if (!c->present && create_compute_stream(&c->present, c->search_cus) != hipSuccess) return fail(LT_ERR_HIP, "hipStreamCreate failed");
+    return LT_OK;
+}
+
+int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const double* ploty, const double* ploty2, int n_rows,
+                   int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx) {
+    if (warp_w < 1 || warp_h < 1 || n < 0 || n_rows < 0 || !coeffs || !left_n || !right_n || !left_yx || !right_yx ||
+        (n_rows && (!ploty || !ploty2)))
+        return fail(LT_ERR_INVALID, "bad arguments");
+    // get_poly_points (lane_tracker.py:511-528) for n pairs of parabolas: fitx = a * ploty**2 + b * ploty + c evaluated as NumPy
+    // does (two products, two sums, no contraction: this file is built with -ffp-contract=off), the points with
+    // 0 <= fitx <= W - 1 kept, x truncated (astype(int)), and -- as upstream -- y = H - count .. H - 1 whatever rows they were
+    const double xmax = (double)(warp_w - 1);
+    size_t ol = 0, orr = 0;
+    for (int i = 0; i < n; ++i) {
+        for (int side = 0; side < 2; ++side) {
+            const double a = coeffs[6 * i + 3 * side], b = coeffs[6 * i + 3 * side + 1], cc = coeffs[6 * i + 3 * side + 2];
+            int32_t* out = side ? right_yx + 2 * orr : left_yx + 2 * ol;
+            int cnt = 0;
+            for (int r = 0; r < n_rows; ++r) {
+                const double t1 = a * ploty2[r], t2 = b * ploty[r];
+                const double x = (t1 + t2) + cc;
+                if (x <= xmax && x >= 0.0) out[2 * cnt++ + 1] = (int32_t)(long long)x;
+            }
+            for (int k = 0; k < cnt; ++k) out[2 * k] = warp_h - cnt + k;
+            if (side) { right_n[i] = cnt; orr += (size_t)cnt; }
+            else { left_n[i] = cnt; ol += (size_t)cnt; }
+        }
+    }
+    return LT_OK;
+}
+
+// lt_overlay_run; rows4: two runs of camera rows {a0, a1, b0, b1} outside which the annotated frames are not needed
+// (lt_present_frame, lt_overlay_run_rows), nullptr = all of them
+static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                            const int32_t* right_yx, double alpha, const int* rows4) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_run before lt_overlay_configure");
+    if (n == 0) return LT_OK;
+    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
+    long long tl = 0, tr = 0;
+    for (int i = 0; i < n; ++i) {
+        if (left_n[i] < 0 || right_n[i] < 0) return fail(LT_ERR_INVALID, "negative point count");
+        tl += left_n[i];
+        tr += right_n[i];
+    }
+    if ((tl && !left_yx) || (tr && !right_yx)) return fail(LT_ERR_INVALID, "null point list");
+    if ((rc = set_device(c))) return rc;
+    const int bh = c->calib.warp_h;
+    if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
+    if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
+    // One frame (process()): the intervals travel as a kernel argument -- no staging buffer, no copy launch, no events
+    static const bool arg_ok = [] { const char* e = std::getenv("LT_SPANS_ARG"); return !(e && e[0] == '0'); }();
+    bool one = arg_ok && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
+    int16_t one_spans[2 * LT_SPAN_ARG_ROWS];
+    auto claim_staging = [&]() -> int {
+        int r = staging_claim(c->spans_busy, first, n);
+        if (r) return r;
+        if (c->h_spans_cap < c->capacity) {
+            if ((r = sync_all(c))) return r;
+            if (c->h_spans) (void)hipHostFree(c->h_spans);
+            c->h_spans = nullptr;
+            c->h_spans_cap = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
+            c->h_spans_cap = c->capacity;
+        }
+        return (int)LT_OK;
+    };
+    if (!one && (rc = claim_staging())) return rc;
+    int16_t* hs = one ? one_spans : c->h_spans + (size_t)first * bh * 2;
+    static const bool timing = std::getenv("LT_OVERLAY_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    // ~18 us of edge walking per polygon: a window's piece of 32 .. 128 polygons is shared among a few threads (the caller is
+    // the one thread that feeds the device)
+    const int workers = std::max(1, std::min({n / 8, 8, (int)std::thread::hardware_concurrency()}));
+    auto some = [&](int w) {
+        size_t ol = 0, orr = 0;
+        for (int i = 0; i < n; ++i) {
+            if (i * (long long)workers / n == w)
+                lane_polygon_spans(hs + (size_t)i * bh * 2, bh, left_yx ? left_yx + 2 * ol : nullptr, left_n[i],
+                                   right_yx ? right_yx + 2 * orr : nullptr, right_n[i]);
+            ol += (size_t)left_n[i];
+            orr += (size_t)right_n[i];
+        }
+    };
+    if (workers == 1) some(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int w = 1; w < workers; ++w) pool.emplace_back(some, w);
+        some(0);
+        for (auto& t : pool) t.join();
+    }
+    // the rows of the frame the path does not read came on the copy stream (lt_upload_frame_rest): the overlay is their reader
+    const auto t1 = std::chrono::steady_clock::now();
+    if ((rc = present_stream(c))) return rc;
+    hipStream_t ps = c->present;
+    if (c->rest_pending) {
+        bool precise = true;
+        if ((rc = wait_range(c->rests, ps, first, first + n, &precise))) return rc;
+        if (!precise) HIP_TRY(hipStreamWaitEvent(ps, c->rest_done, 0));
+    }
+    {   // the camera rows of these slots: behind the launches that wrote their masks (which waited for the rows' upload)
+        bool precise = true;
+        if ((rc = wait_range(c->writers, ps, first, first + n, &precise))) return rc;
+        if (!precise) {
+            rc = for_each_slice(c, first, n, [&](hipStream_t st, int, int) {
+                hipEvent_t e = next_order_event(c);
+                if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+                HIP_TRY(hipEventRecord(e, st));
+                HIP_TRY(hipStreamWaitEvent(ps, e, 0));
+                return (int)LT_OK;
+            });
+            if (rc) return rc;
+        }
+    }
+    // an asynchronous download may still be reading the annotated frames this call overwrites
+    if (c->annot_busy.hi > c->annot_busy.lo && first < c->annot_busy.hi && first + n > c->annot_busy.lo && c->annot_busy.done)
+        HIP_TRY(hipStreamWaitEvent(ps, c->annot_busy.done, 0));
+    if (one) {
+        if (launch_overlay_lane_one(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
+                                    c->d_oxy, c->d_ofrac, hs, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, rows4)) {
+            HIP_TRY(hipGetLastError());
+            return note_range(c->readers, ps, first, first + n);
+        }
+        // not launched (the runtime refused the argument block): the staged way after all, with the intervals already built
+        one = false;
+        if ((rc = claim_staging())) return rc;
+        std::memcpy(c->h_spans + (size_t)first * bh * 2, one_spans, (size_t)bh * 2 * sizeof(int16_t));
+        hs = c->h_spans + (size_t)first * bh * 2;
+    }
+    launch_copy_from_pinned(ps, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
+    const auto t2 = std::chrono::steady_clock::now();
+    launch_overlay_lane(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
+                        c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
+                        c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n, rows4);
+    HIP_TRY(hipGetLastError());
+    if ((rc = staging_mark(c->spans_busy, ps))) return rc;
+    rc = note_range(c->readers, ps, first, first + n);
+    if (timing) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (long)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        std::fprintf(stderr, "overlay_run n=%d: spans %ld us, wait+memcpy %ld us, launch+events %ld us\n", n, us(t0, t1), us(t1, t2), us(t2, t3));
+    }
+    return rc;
+}
+
+int lt_overlay_run(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                   const int32_t* right_yx, double alpha) {
+    return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr);
+}
+
+static int ordered_rows(lt_ctx* c, const int32_t* rows4, int r[4]) {
+    for (int k = 0; k < 4; ++k) r[k] = rows4[k];
+    if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= c->calib.img_h))
+        return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
+    return LT_OK;
+}
+
+int lt_overlay_run_rows(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                        const int32_t* right_yx, double alpha, const int32_t* rows4) {
+    if (!rows4) return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr);
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int r[4];
+    const int rc = ordered_rows(c, rows4, r);
+    if (rc) return rc;
+    return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, r);
+}
+
+int lt_overlay_rows(lt_ctx* c, int* row0, int* row1) {
+    if (!c || !row0 || !row1) return fail(LT_ERR_INVALID, "null argument");
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_rows before lt_overlay_configure");
+    *row0 = c->ov_r0;
+    *row1 = c->ov_r1;
+    return LT_OK;
+}
+
+int lt_overlay_set_font(lt_ctx* c, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
+                        int glyph_h) {
+    if (!c || !atlas || !advance) return fail(LT_ERR_INVALID, "null argument");
+    if (n_glyphs < 1 || n_glyphs > 256 || glyph_w < 1 || glyph_w > 255 || glyph_h < 1 || glyph_h > 255 || first_char < 0)
+        return fail(LT_ERR_INVALID, "bad font geometry");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
+    dev_free(c->d_atlas);
+    dev_free(c->d_advance);
+    c->font_glyphs = 0;
+    const size_t bytes = (size_t)n_glyphs * glyph_w * glyph_h;
+    if ((rc = dev_alloc(&c->d_atlas, bytes))) return rc;
+    if ((rc = dev_alloc(&c->d_advance, (size_t)n_glyphs))) return rc;
+    HIP_TRY(hipMemcpy(c->d_atlas, atlas, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_advance, advance, (size_t)n_glyphs, hipMemcpyHostToDevice));
+    c->h_advance.assign(advance, advance + n_glyphs);
+    c->font_first = first_char;
+    c->font_glyphs = n_glyphs;
+    c->font_gw = glyph_w;
+    c->font_gh = glyph_h;
+    return LT_OK;
+}
+
+int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines, int line_len, int x0, int y0, int step) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!c->font_glyphs) return fail(LT_ERR_STATE, "lt_overlay_text before lt_overlay_set_font");
+    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_overlay_text before lt_overlay_run");
+    if (n == 0 || n_lines <= 0 || line_len <= 0) return LT_OK;
+    if (!lines) return fail(LT_ERR_INVALID, "null text");
+    if ((rc = set_device(c))) return rc;
+    const size_t per = (size_t)n_lines * line_len;
+    if (per > c->text_per_slot || c->text_slots < c->capacity) {      // (re)size the per-slot text buffers: rare, synchronises
+        if ((rc = sync_all(c))) return rc;
+        const size_t per_new = (std::max(per, c->text_per_slot) + 3) & ~(size_t)3, total = per_new * (size_t)c->capacity;
+        dev_free(c->d_lines);
+        dev_free(c->d_xpos);
+        if (c->h_lines) (void)hipHostFree(c->h_lines);
+        if (c->h_xpos) (void)hipHostFree(c->h_xpos);
+        c->h_lines = nullptr;
+        c->h_xpos = nullptr;
+        c->text_per_slot = 0;
+        c->text_slots = 0;
+        if ((rc = dev_alloc(&c->d_lines, total))) return rc;
+        if ((rc = dev_alloc(&c->d_xpos, total))) return rc;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_lines), total, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_xpos), total * sizeof(int16_t), hipHostMallocDefault));
+        c->text_per_slot = per_new;
+        c->text_slots = c->capacity;
+    }
+    if ((rc = staging_claim(c->text_busy, first, n))) return rc;
+    // A slot's lines sit at the slot's own position in the per-slot buffers, at their FIXED stride text_per_slot -- not at
+    // this call's n_lines * line_len: staging_claim orders calls by slot range, and two calls in flight over disjoint
+    // slots with different line counts (a 'fail' piece has one line, a lane piece two) must not meet in bytes.
+    const size_t stride = c->text_per_slot;
+    uint8_t* hl = c->h_lines + (size_t)first * stride;
+    int16_t* hx = c->h_xpos + (size_t)first * stride;
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(hl + (size_t)i * stride, lines + (size_t)i * per, per);
+        for (int l = 0; l < n_lines; ++l) {                // left edge of every character: running sum of advances
+            const char* src = lines + (size_t)i * per + (size_t)l * line_len;
+            int16_t* dst = hx + (size_t)i * stride + (size_t)l * line_len;
+            int x = x0;
+            bool ended = false;
+            for (int k = 0; k < line_len; ++k) {
+                const unsigned char ch = (unsigned char)src[k];
+                ended = ended || ch == 0;
+                dst[k] = (int16_t)std::min(x, 32767);
+                const int g = (int)ch - c->font_first;
+                if (!ended && g >= 0 && g < c->font_glyphs) x += c->h_advance[(size_t)g];
+            }
+        }
+    }
+    uint8_t* dl = c->d_lines + (size_t)first * stride;
+    int16_t* dx = c->d_xpos + (size_t)first * stride;
+    if ((rc = present_stream(c))) return rc;
+    // A frame or two (process(), one frame per call): the kernel reads the few hundred bytes from the page-locked buffers
+    // themselves -- two launches fewer between the record and the annotated frame.  A window's worth goes to the device first.
+    const uint8_t* kl = dl;
+    const int16_t* kx = dx;
+    void *pl = nullptr, *px = nullptr;
+    static const bool direct_ok = [] { const char* e = std::getenv("LT_TEXT_DIRECT"); return !(e && e[0] == '0'); }();
+    if (direct_ok && n <= 2 && hipHostGetDevicePointer(&pl, hl, 0) == hipSuccess && hipHostGetDevicePointer(&px, hx, 0) == hipSuccess &&
+        pl && px) {
+        kl = static_cast<const uint8_t*>(pl);
+        kx = static_cast<const int16_t*>(px);
+    } else {
+        (void)hipGetLastError();
+        launch_copy_from_pinned(c->present, dl, hl, (size_t)n * stride);
+        launch_copy_from_pinned(c->present, dx, hx, (size_t)n * stride * sizeof(int16_t));
+    }
+    launch_overlay_text(c->present, c->d_annot + (size_t)first * c->frame_bytes, c->frame_bytes, c->calib.img_h, c->calib.img_w,
+                        c->d_atlas, c->d_advance, c->font_first, c->font_glyphs, c->font_gw, c->font_gh, kl, kx,
+                        n_lines, line_len, (int)stride, y0, step, n);
+    HIP_TRY(hipGetLastError());
+    return staging_mark(c->text_busy, c->present);
+}
+
+int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay before lt_overlay_run");
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    const uint8_t* src = c->d_annot + (size_t)first * c->frame_bytes;
+    const size_t bytes = (size_t)n * c->frame_bytes;
+    if (!c->present || n == 0) return download(c, src, out, bytes);
+    // The annotated frames are written on the presentation stream and nowhere else (lt_overlay_run, lt_overlay_text), behind
+    // everything they depend on: the copy is enqueued there, behind them, and the host waits once -- not once for the overlay
+    // and once more for a copy it issues only then (10 us of process()'s 0.4 ms per frame).
+    if ((rc = set_device(c))) return rc;
+    // a frame or two: by a copy kernel (no engine start-up: 11 us less per frame of process()); LT_DL1_KERNEL=0: the engine
+    static const bool by_kernel = [] { const char* e = std::getenv("LT_DL1_KERNEL"); return !(e && e[0] == '0'); }();
+    if (!(by_kernel && n <= 2 && launch_copy_to_pinned(c->present, out, src, bytes)))
+        HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->present));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->present));
+    return LT_OK;
+}
+
+// process()'s tail for ONE frame in one call: lt_overlay_run + lt_overlay_text + the way back, the host waiting once.  With
+// rows4 = {a0, a1, b0, b1} only those two runs of camera rows are drawn and written to `out` (the rows at their places in the
+// frame): a pixel outside the rows the lane can reach (lt_overlay_rows) and outside the text lines is the camera pixel, which
+// the caller has -- process() copies those rows from its input while the device is busy, and only half the frame crosses the
+// bus behind the overlay.  The runs must cover the text lines and, for a non-empty polygon, lt_overlay_rows.
+static int present_copy_rows(lt_ctx* c, int slot, uint8_t* out, int row0, int row1) {
+    if (row1 <= row0) return LT_OK;
+    const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)row0 * row_bytes, bytes = (size_t)(row1 - row0) * row_bytes;
+    const uint8_t* src = c->d_annot + (size_t)slot * c->frame_bytes;
+    if (!launch_copy_to_pinned(c->present, out + off, src + off, bytes))
+        HIP_TRY(hipMemcpyAsync(out + off, src + off, bytes, hipMemcpyDeviceToHost, c->present));
+    HIP_TRY(hipGetLastError());
+    return LT_OK;
+}
+// rows4 -> r[4] (nullptr: the whole frame as the first run); `split`: the text lines must lie in the first run and the rows the
+// lane can reach in the second, the two apart -- the condition for drawing and sending the second run before the text exists
+static int present_rows(lt_ctx* c, const int32_t* rows4, bool text, int n_lines, int y0, int step, bool lane, bool split, int r[4]) {
+    const int H = c->calib.img_h;
+    r[0] = 0; r[1] = H; r[2] = H; r[3] = H;
+    if (!rows4) return split ? fail(LT_ERR_INVALID, "two row runs are needed") : (int)LT_OK;
+    for (int k = 0; k < 4; ++k) r[k] = rows4[k];
+    if (!(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= H))
+        return fail(LT_ERR_INVALID, "row runs must be ordered and inside the frame");
+    auto within = [&](int lo, int hi, int a, int b) { lo = std::max(lo, 0); hi = std::min(hi, H); return lo >= hi || (a <= lo && hi <= b); };
+    const int t0 = y0, t1 = y0 + (n_lines - 1) * step + c->font_gh;
+    if (split) {
+        if (text && !within(t0, t1, r[0], r[1])) return fail(LT_ERR_INVALID, "the first row run does not cover the text lines");
+        if (!within(c->ov_r0, c->ov_r1, r[2], r[3])) return fail(LT_ERR_INVALID, "the second row run does not cover the rows the lane can reach (lt_overlay_rows)");
+        return LT_OK;
+    }
+    auto covered = [&](int lo, int hi) { return within(lo, hi, r[0], r[1]) || within(lo, hi, r[2], r[3]) || (r[1] == r[2] && within(lo, hi, r[0], r[3])); };
+    if (text && !covered(t0, t1)) return fail(LT_ERR_INVALID, "the row runs do not cover the text lines");
+    if (lane && !covered(c->ov_r0, c->ov_r1)) return fail(LT_ERR_INVALID, "the row runs do not cover the rows the lane can reach (lt_overlay_rows)");
+    return LT_OK;
+}
+
+int lt_present_frame(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx, const int32_t* right_yx,
+                     double alpha, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
+                     const int32_t* rows4) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_frame before lt_overlay_configure");
+    const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
+    int r[4];
+    if ((rc = present_rows(c, rows4, text, n_lines, y0, step, left_n[0] > 0 || right_n[0] > 0, false, r))) return rc;
+    if ((rc = overlay_run_impl(c, slot, 1, left_n, right_n, left_yx, right_yx, alpha, rows4 ? r : nullptr))) return rc;
+    if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
+    if ((rc = present_copy_rows(c, slot, out, r[0], r[1]))) return rc;
+    if ((rc = present_copy_rows(c, slot, out, r[2], r[3]))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->present));
+    return LT_OK;
+}
+
+// lt_present_frame in two halves, for a caller that knows the polygon before it knows the text (LaneTracker.process(): the
+// averaged curves follow from the record at once, radius, eccentricity and the verdict on the frame take the host another
+// 25 us): the first half draws both row runs and sends the second one -- the rows the lane can reach -- on its way without
+// waiting; the second half blends the text into the first run, sends that and waits for both.  A first half whose frame turns
+// out invalid is simply followed by a whole lt_present_frame (same slot, same `out`): it draws and sends everything again.
+int lt_present_lane_async(lt_ctx* c, int slot, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                          const int32_t* right_yx, double alpha, uint8_t* out, const int32_t* rows4) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_lane_async before lt_overlay_configure");
+    int r[4];
+    if ((rc = present_rows(c, rows4, false, 0, 0, 0, true, true, r))) return rc;
+    if ((rc = overlay_run_impl(c, slot, 1, left_n, right_n, left_yx, right_yx, alpha, r))) return rc;
+    return present_copy_rows(c, slot, out, r[2], r[3]);
+}
+
+int lt_present_finish(lt_ctx* c, int slot, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
+                      const int32_t* rows4) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!c->d_annot || !c->present) return fail(LT_ERR_STATE, "lt_present_finish before lt_present_lane_async");
+    const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
+    int r[4];
+    if ((rc = present_rows(c, rows4, text, n_lines, y0, step, false, true, r))) return rc;
+    if ((rc = set_device(c))) return rc;
+    if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
+    if ((rc = present_copy_rows(c, slot, out, r[0], r[1]))) return rc;
+    HIP_TRY(hipStreamSynchronize(c->present));
+    return LT_OK;
+}
+
+static void harvest_downloads(lt_ctx* c);
+static int choose_download(lt_ctx* c);
+static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out, const int* rows4);
+int lt_download_overlay_async(lt_ctx* c, int first, int n, uint8_t* out) { return download_overlay_async_impl(c, first, n, out, nullptr); }
+int lt_download_overlay_rows_async(lt_ctx* c, int first, int n, uint8_t* out, const int32_t* rows4) {
+    if (!rows4) return download_overlay_async_impl(c, first, n, out, nullptr);
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int r[4];
+    const int rc = ordered_rows(c, rows4, r);
+    if (rc) return rc;
+    return download_overlay_async_impl(c, first, n, out, r);
+}
+// rows4: only these two runs of rows of every frame (at their places in `out`), nullptr: whole frames
+static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out, const int* rows4) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay_async before lt_overlay_run");
+    if (n == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    // on a stream of its own, behind the overlay work enqueued so far: the copy neither holds up the kernels queued behind
+    // it on the context's stream nor shares a queue with the uploads
+    if (!c->dl) {
+        if (c->search_cus >= 2) {                  // the reserved CUs but the first are the copy kernel's (lt_set_search_cus)
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int b = 1; b < c->search_cus && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->dl, 8, mask));
+        } else {                                   // highest priority: the copy kernel's few workgroups go ahead of the mask kernels'
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
+        }
+    }
+    hipEvent_t e = next_order_event(c);
+    if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(e, c->present ? c->present : c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
+    // engine or kernel: by measurement (choose_download); LT_DL_KERNEL=1 / 0 and lt_set_download_method pin one of them
+    static const int env_method = [] { const char* e = std::getenv("LT_DL_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    if (env_method >= 0 && c->dl_forced < 0) c->dl_forced = env_method;
+    harvest_downloads(c);
+    int method = choose_download(c);
+    auto timing_event = [&]() -> hipEvent_t {
+        hipEvent_t ev = nullptr;
+        if (!c->dl_event_pool.empty()) { ev = c->dl_event_pool.back(); c->dl_event_pool.pop_back(); }
+        else if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+        return ev;
+    };
+    hipEvent_t ta = timing_event(), tb = timing_event();
+    if (ta && tb) HIP_TRY(hipEventRecord(ta, c->dl));
+    size_t bytes = (size_t)n * c->frame_bytes;
+    const uint8_t* src = c->d_annot + (size_t)first * c->frame_bytes;
+    if (!rows4) {
+        if (method == 1 && !launch_copy_to_pinned(c->dl, out, src, bytes)) method = 0;   // not page-locked / aligned
+        if (method == 0) HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->dl));
+    } else {
+        const size_t row_bytes = (size_t)c->calib.img_w * 3;
+        bytes = 0;
+        // The kernel takes a run of rows of all the frames in one launch; the engine takes the run of ONE frame as an ordinary
+        // copy (a pitched copy over the frames it takes row by row: 120-160 ms for a window of 256 frames), two copies per
+        // frame -- 18.4 k frames/s of an annotated 1280x720 stream against the kernel's 22.6 k.  So the kernel, unless
+        // lt_set_download_method(0) / LT_DL_KERNEL=0 ask for the engine.
+        bool by_kernel = c->dl_forced != 0;
+        for (int k = 0; k < 4 && by_kernel; k += 2)       // both runs the same way, so that the timing below means one thing
+            by_kernel = rows4[k + 1] <= rows4[k] ||
+                        ((((size_t)rows4[k] * row_bytes) | ((size_t)(rows4[k + 1] - rows4[k]) * row_bytes) | c->frame_bytes | (size_t)(uintptr_t)out) & 15) == 0;
+        for (int k = 0; k < 4; k += 2) {
+            if (rows4[k + 1] <= rows4[k]) continue;
+            const size_t off = (size_t)rows4[k] * row_bytes, run = (size_t)(rows4[k + 1] - rows4[k]) * row_bytes;
+            if (by_kernel && !launch_copy_rows_to_pinned(c->dl, out, src, c->frame_bytes, off, run, n)) by_kernel = false;
+            bytes += run * (size_t)n;
+        }
+        if (!by_kernel)
+            for (int f = 0; f < n; ++f)
+                for (int k = 0; k < 4; k += 2) {
+                    if (rows4[k + 1] <= rows4[k]) continue;
+                    const size_t off = (size_t)f * c->frame_bytes + (size_t)rows4[k] * row_bytes;
+                    HIP_TRY(hipMemcpyAsync(out + off, src + off, (size_t)(rows4[k + 1] - rows4[k]) * row_bytes, hipMemcpyDeviceToHost, c->dl));
+                }
+        method = by_kernel ? 1 : 0;
+    }
+    HIP_TRY(hipGetLastError());
+    if (ta && tb) {
+        HIP_TRY(hipEventRecord(tb, c->dl));
+        c->dl_inflight.push_back({ta, tb, (double)bytes, method});
+    } else {
+        if (ta) c->dl_event_pool.push_back(ta);
+        if (tb) c->dl_event_pool.push_back(tb);
+    }
+    if (c->annot_busy.hi <= c->annot_busy.lo) { c->annot_busy.lo = first; c->annot_busy.hi = first + n; }
+    else { c->annot_busy.lo = std::min(c->annot_busy.lo, first); c->annot_busy.hi = std::max(c->annot_busy.hi, first + n); }
+    return staging_mark(c->annot_busy, c->dl);
+}
+
+// Engine or kernel?  The copy engine moves the frames at 48-56 GB/s when the page-locked destination and the device buffer are
+// laid out kindly, and at 28-30 GB/s when they are not -- a property of the memory the process happened to get (allocation
+// history, the box), not of anything this library orders: tools/copy_engine_probe.py RAW=1 shows one lone download at 29 GB/s
+// on the same engine, same code path, beside nothing.  (Rounds 2-3 read the resulting 9.3 k instead of 15 k frames/s of
+// the annotated 1280x720 stream as uploads and downloads "taking turns"; they do overlap.)  A kernel storing 16 bytes per lane
+// into the same destination is not affected (an annotated 1280x720 stream does 13.3 k frames/s that way in either regime: less
+// than the engine at its best, 15 k, because the copy kernel shares the chip with the mask chain, far more than the engine at
+// its worst).  So: every copy is timed with an event pair; the engine is the default; when its running rate drops below
+// DL_SLOW GB/s the kernel takes over, and one copy in DL_REPROBE goes by the engine again so that a recovery is noticed.
+static constexpr double DL_SLOW = 36.0;
+static constexpr int DL_REPROBE = 48;
+static void harvest_downloads(lt_ctx* c) {
+    size_t keep = 0;
+    for (size_t i = 0; i < c->dl_inflight.size(); ++i) {
+        lt_ctx::DlTimed& d = c->dl_inflight[i];
+        float ms = 0.f;
+        if (hipEventQuery(d.b) == hipSuccess && hipEventElapsedTime(&ms, d.a, d.b) == hipSuccess) {
+            if (ms > 0.f && d.bytes >= 8e6) {              // small copies time the launch, not the bus
+                const double r = d.bytes / (ms * 1e-3) / 1e9;
+                c->dl_rate[d.method] = c->dl_samples[d.method] ? 0.5 * c->dl_rate[d.method] + 0.5 * r : r;
+                ++c->dl_samples[d.method];
+            }
+            c->dl_event_pool.push_back(d.a);
+            c->dl_event_pool.push_back(d.b);
+        } else {
+            (void)hipGetLastError();
+            c->dl_inflight[keep++] = d;
+        }
+    }
+    c->dl_inflight.resize(keep);
+}
+static int choose_download(lt_ctx* c) {
+    if (c->dl_forced >= 0) return c->dl_forced;
+    const int cur = c->dl_method, other = 1 - cur;
+    ++c->dl_since_probe;
+    if (c->dl_samples[cur] >= 4) {       // (the first copies of a stream are short and wait for their overlays: not a verdict)
+        const bool never = c->dl_samples[other] == 0;
+        if (cur == 0 && c->dl_rate[0] < DL_SLOW && (never || c->dl_rate[1] > c->dl_rate[0])) { c->dl_method = 1; c->dl_since_probe = 0; }
+        else if (cur == 1 && c->dl_rate[0] >= DL_SLOW) { c->dl_method = 0; c->dl_since_probe = 0; }   // the engine has recovered
+        else if (c->dl_since_probe >= DL_REPROBE && (cur == 1 || c->dl_rate[0] < DL_SLOW)) {   // one copy the other way
+            c->dl_since_probe = 0;
+            return other;
+        }
+    }
+    return c->dl_method;
+}
+
+int lt_set_download_method(lt_ctx* c, int method) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (method < -1 || method > 1) return fail(LT_ERR_INVALID, "download method: -1 = measured choice, 0 = copy engine, 1 = kernel");
+    c->dl_forced = method;
+    return LT_OK;
+}
+
+int lt_download_stats(lt_ctx* c, double* engine_gbs, int* engine_copies, double* kernel_gbs, int* kernel_copies, int* method) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    harvest_downloads(c);
+    if (engine_gbs) *engine_gbs = c->dl_rate[0];
+    if (engine_copies) *engine_copies = c->dl_samples[0];
+    if (kernel_gbs) *kernel_gbs = c->dl_rate[1];
+    if (kernel_copies) *kernel_copies = c->dl_samples[1];
+    if (method) *method = c->dl_forced >= 0 ? c->dl_forced : c->dl_method;
+    return LT_OK;
+}
+
+int lt_download_overlay_wait(lt_ctx* c) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->dl) return LT_OK;
+    HIP_TRY(hipStreamSynchronize(c->dl));   // every copy of lt_download_overlay_async is behind its slots' overlay kernels
+    c->annot_busy.lo = c->annot_busy.hi = 0;
+    return LT_OK;
+}
+
+int lt_download_bev(lt_ctx* c, int first, int n, uint8_t* out) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    if (!c->have_mask) return fail(LT_ERR_STATE, "lt_download_bev before lt_mask_run");
+    if (n == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    if ((rc = ensure_bev(c))) return rc;
+    if ((rc = sync_all(c))) return rc;
+    uint8_t* dst = c->d_bev + (size_t)first * c->bev_bytes;
+    if (c->fe.nrows <= 0) HIP_TRY(hipMemsetAsync(dst, 0, (size_t)n * c->bev_bytes, c->stream));
+    else
+        launch_warp_rgb(c->stream, c->d_und, c->und_px, first, c->d_wxy, c->d_wfrac, c->fe, dst, c->bev_bytes, n);
+    HIP_TRY(hipGetLastError());
+    return download(c, dst, out, (size_t)n * c->bev_bytes);
+}
+
+}  // extern "C"

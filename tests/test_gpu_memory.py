@@ -1,4 +1,4 @@
-"""The device memory cache (csrc/lt_api.cpp: DevCache; lt_device_cache_trim).  Blocks a context gives up are kept and reused,
+"""The device memory cache (csrc/lt_memory.cpp: DevCache; lt_device_cache_trim).  Blocks a context gives up are kept and reused,
 because memory that goes back to the driver is wiped in the background on an SDMA engine and the process's device-to-host copies
 run at half speed meanwhile.  Checked here: a closed context's memory stays with the process and serves the
 next context of the same shape; results do not depend on what a reused block held before; the trim returns it to the driver."""

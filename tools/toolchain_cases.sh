@@ -9,7 +9,7 @@ out=$root/gpurun_out/cases
 mkdir -p $out
 cd $root/lane_tracker_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950"
-OBJS="lt_api.o lt_gather.o lt_tables.o k_filter.o k_tophat.o k_threshold.o k_threshold_walk.o k_overlay.o"
+OBJS="lt_api.o lt_memory.o lt_present.o lt_chain.o lt_gather.o lt_tables.o k_filter.o k_tophat.o k_threshold.o k_threshold_walk.o k_overlay.o"
 report=$out/report.txt
 /opt/rocm/bin/hipcc --version | head -2 > $report
 build_variant() {   # name, file, define
