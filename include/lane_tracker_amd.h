@@ -35,7 +35,9 @@ extern "C" {
  *    call, the host waiting: LaneTracker.process()), lt_set_download_method, lt_download_stats, lt_device_cache_trim,
  *    lt_last_adaptive_path, lt_host_copy_async, lt_host_copy2d_async, lt_host_copy_wait, lt_overlay_run_rows,
  *    lt_download_overlay_rows_async.  Nothing removed or changed. */
-#define LT_ABI_VERSION 3
+/* 4: + lt_host_copy_group_create / _destroy, lt_host_copy_async_group, lt_host_copy2d_async_group, lt_host_copy_wait_group
+ *    (completion per group instead of per process), lt_shutdown, lt_device_cache_stats.  Nothing removed or changed. */
+#define LT_ABI_VERSION 4
 
 typedef enum lt_status {
     LT_OK = 0,
@@ -325,13 +327,34 @@ int  lt_host_copy_async(void* dst, const void* src, size_t bytes);
  * the library's copy threads (LT_COPY_THREADS, default 4) */
 int  lt_host_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t height);
 int  lt_host_copy_wait(void);
+/* The same copies with completion per GROUP: a copy belongs to the group it is submitted to, and lt_host_copy_wait_group(g)
+ * returns when the copies of g are complete -- whatever other trackers, threads or windows have queued meanwhile (with one
+ * counter per process, two trackers on two threads waited for each other's copies and a short wait could be starved by
+ * another tracker's 360 MB window).  Group 0 is the default group lt_host_copy_async / lt_host_copy2d_async submit to;
+ * lt_host_copy_wait() waits for every group.  lt_host_copy_group_create hands out a fresh id (> 0, never reused);
+ * lt_host_copy_group_destroy waits for the group and forgets it.  An unknown group is LT_ERR_INVALID.  No GPU needed.
+ * LaneTracker keeps one group per tracker for process() and one per window of a stream. */
+int  lt_host_copy_group_create(int* group);
+int  lt_host_copy_group_destroy(int group);
+int  lt_host_copy_async_group(int group, void* dst, const void* src, size_t bytes);
+int  lt_host_copy2d_async_group(int group, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t height);
+int  lt_host_copy_wait_group(int group);
+/* Finish the queued host copies and join the copy threads now (they are also joined when the library is unloaded, and start
+ * again with the next request).  For hosts that must not have library threads alive at a point of their choosing -- before a
+ * fork(), at interpreter shutdown.  (The child of a fork() gets fresh workers by itself: pthread_atfork.) */
+int  lt_shutdown(void);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact
- * size, and reused by later allocations; it returns to the driver when more than LT_DEVICE_CACHE_GB (default: half of the
- * device memory, at most 128 GB) would be kept, and here: everything beyond keep_bytes now.  Why: memory handed back to the
- * driver is wiped in the background on an SDMA engine, and for that time the process's device-to-host copies run at half
- * speed (csrc/lt_memory.cpp, DevCache). */
+ * size, and reused by later allocations.  Why: memory handed back to the driver is wiped in the background on an SDMA engine,
+ * and for that time the process's device-to-host copies run at half speed (csrc/lt_memory.cpp, DevCache).  The cache keeps at
+ * most the high-water mark of what the process's live contexts have held at once, and at most 16 GB (LT_DEVICE_CACHE_GB=<n>:
+ * another limit; 0: no cache); beyond that the blocks that have waited longest go back to the driver.  lt_device_cache_trim
+ * returns everything beyond keep_bytes NOW -- for a process that shares the GPU (several ranks on one device, another
+ * allocator in the same process): call it with 0 after closing trackers whose memory somebody else should have.  A failed
+ * hipMalloc inside the library trims by itself and tries once more.  lt_device_cache_stats: bytes the cache holds, bytes handed
+ * out to live contexts, the current limit, the number of cached blocks (any pointer may be NULL).  No context needed. */
 int  lt_device_cache_trim(size_t keep_bytes);
+int  lt_device_cache_stats(size_t* kept_bytes, size_t* live_bytes, size_t* limit_bytes, int* kept_blocks);
 /* the bird's-eye RGB image of the slots' frames (lane_tracker.py:834, :1035): n * warp_h * warp_w * 3;
  * needs lt_mask_run on those slots first (it reuses their undistorted rows) */
 int  lt_download_bev(lt_ctx* ctx, int first_slot, int n, uint8_t* out);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LANE_TRACKER_AMD_LIB: load another build of the same library (tools/toolchain_cases.sh compares variant builds)
 LIB_PATH = os.environ.get("LANE_TRACKER_AMD_LIB") or os.path.join(_HERE, "liblane_tracker_amd.so")
 NUM_STAGES = 12
-ABI_VERSION = 3          # LT_ABI_VERSION of include/lane_tracker_amd.h this table was written against
+ABI_VERSION = 4          # LT_ABI_VERSION of include/lane_tracker_amd.h this table was written against
 
 PLANE_R, PLANE_LAB_B, PLANE_TOPHAT_R, PLANE_TOPHAT_B, PLANE_MERGED, PLANE_MASK = range(6)
 
@@ -107,6 +107,12 @@ _SIGNATURES = {
     "lt_overlay_run_rows": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double, _P]),
     "lt_download_overlay_rows_async": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
     "lt_host_copy_wait": (C.c_int, []),
+    "lt_host_copy_group_create": (C.c_int, [C.POINTER(C.c_int)]),
+    "lt_host_copy_group_destroy": (C.c_int, [C.c_int]),
+    "lt_host_copy_async_group": (C.c_int, [C.c_int, _P, _P, C.c_size_t]),
+    "lt_host_copy2d_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t]),
+    "lt_host_copy_wait_group": (C.c_int, [C.c_int]),
+    "lt_shutdown": (C.c_int, []),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
@@ -148,6 +154,7 @@ _SIGNATURES = {
     "lt_stage_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int]),
     "lt_stage_name": (C.c_char_p, [C.c_int]),
     "lt_device_cache_trim": (C.c_int, [C.c_size_t]),
+    "lt_device_cache_stats": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "lt_set_download_method": (C.c_int, [_P, C.c_int]),
     "lt_download_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "lt_last_threshold_path": (C.c_int, [_P]),
@@ -242,6 +249,25 @@ _pinned = _PinnedPool()
 def device_cache_trim(keep_bytes=0):
     """Hand the device memory closed contexts left in the library's cache back to the driver (all of it beyond keep_bytes)."""
     _check(load().lt_device_cache_trim(int(keep_bytes)))
+
+
+def host_copy_group():
+    """A fresh completion group of the library's host copy threads (lt_host_copy_group_create)."""
+    g = C.c_int(0)
+    _check(load().lt_host_copy_group_create(C.byref(g)))
+    return g.value
+
+
+def host_copy_group_release(group):
+    """Wait for the group's copies and forget it (lt_host_copy_group_destroy)."""
+    _check(load().lt_host_copy_group_destroy(int(group)))
+
+
+def device_cache_stats():
+    """{'kept_bytes', 'live_bytes', 'limit_bytes', 'kept_blocks'} of the library's device-memory cache (lt_device_cache_stats)."""
+    k, l, m, n = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
+    _check(load().lt_device_cache_stats(C.byref(k), C.byref(l), C.byref(m), C.byref(n)))
+    return {"kept_bytes": k.value, "live_bytes": l.value, "limit_bytes": m.value, "kept_blocks": n.value}
 
 
 def pinned_empty(shape, dtype=np.uint8):

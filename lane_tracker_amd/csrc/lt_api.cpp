@@ -520,6 +520,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (ndev <= 0) return fail(LT_ERR_HIP, "no HIP device visible: the lane-tracker kernels need a GPU (gfx950)");
     if (device < 0 || device >= ndev) return fail(LT_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+    TraceScope ts_all("lt_create");
     lt_ctx* c = new lt_ctx();
     c->calib = *calib;
     c->device = device;
@@ -541,6 +542,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
         return bail(fail(LT_ERR_HIP, "side stream / event creation failed"));
 
     // host tables
+    const double t_tables = trace_on() ? trace_now() : 0.0;
     RemapTable warp, und;
     build_warp_table(*calib, warp);
     int r0 = 0, r1 = 0;
@@ -577,6 +579,8 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
         c->brute_tophat = e && e[0] == '1';
     }
 
+    if (trace_on()) trace_line("lt_create:host_tables", t_tables);
+    TraceScope ts_up("lt_create:table_upload");
     int rc;
     if ((rc = dev_alloc(&c->d_wxy, warp.xy.size()))) return bail(rc);
     if ((rc = dev_alloc(&c->d_wfrac, warp.frac.size()))) return bail(rc);
@@ -638,37 +642,48 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_advance);
     dev_free(c->d_lines);
     dev_free(c->d_xpos);
-    note("events, streams, page-locked buffers");
+    // (LT_TRACE_DESTROY names every class of call: a close() that did not return in round 4 was somewhere in here, NOTES C.8)
+    note("events: timing pool, order ring, staging");
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
     if (c->spans_busy.done) (void)hipEventDestroy(c->spans_busy.done);
     if (c->text_busy.done) (void)hipEventDestroy(c->text_busy.done);
     if (c->annot_busy.done) (void)hipEventDestroy(c->annot_busy.done);
+    note("hipStreamDestroy(dl)");
     if (c->dl) (void)hipStreamDestroy(c->dl);
+    note("events: download timing");
     for (auto& d : c->dl_inflight) { (void)hipEventDestroy(d.a); (void)hipEventDestroy(d.b); }
     for (auto e : c->dl_event_pool) (void)hipEventDestroy(e);
+    note("hipStreamDestroy(present, urgent)");
     if (c->present) (void)hipStreamDestroy(c->present);
     if (c->urgent) (void)hipStreamDestroy(c->urgent);
     if (c->rest_done) (void)hipEventDestroy(c->rest_done);
+    note("hipHostFree(spans, lines, xpos)");
     if (c->h_spans) (void)hipHostFree(c->h_spans);
     if (c->h_lines) (void)hipHostFree(c->h_lines);
     if (c->h_xpos) (void)hipHostFree(c->h_xpos);
+    note("events: slot-range rings, chain tickets");
     for (auto& w : c->readers.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& w : c->writers.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& w : c->rests.e) if (w.ev) (void)hipEventDestroy(w.ev);
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
+    note("hipHostFree(small, rec, rec_stage, cancel)");
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
     if (c->h_cancel) (void)hipHostFree(c->h_cancel);
+    note("hipStreamDestroy(search)");
     if (c->search) (void)hipStreamDestroy(c->search);
+    note("hipStreamDestroy(copy, side)");
     if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    note("events: fork, join, timer");
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    note("hipStreamDestroy(slot streams)");
     for (auto st : c->streams) if (st) (void)hipStreamDestroy(st);
     if (c->streams.empty() && c->stream) (void)hipStreamDestroy(c->stream);
     note("done");
@@ -681,8 +696,12 @@ int lt_reserve(lt_ctx* c, int capacity) {
     int rc = set_device(c);
     if (rc) return rc;
     if (capacity <= c->capacity) return LT_OK;
-    if ((rc = sync_all(c))) return rc;
-    free_slots(c);
+    TraceScope ts_all("lt_reserve", (size_t)capacity);
+    {
+        TraceScope ts_("lt_reserve:sync+free_slots", (size_t)c->capacity);
+        if ((rc = sync_all(c))) return rc;
+        free_slots(c);
+    }
     c->rec_mirror_slot = -1;
     c->capacity = capacity;
     const size_t n = (size_t)capacity;
@@ -706,6 +725,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_prev, n * 6))) { free_slots(c); return rc; }
     c->capacity = capacity;
+    TraceScope ts_ms("lt_reserve:memset");
     HIP_TRY(hipMemsetAsync(c->d_rec, 0, n * sizeof(lt_lane_record), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_plane[P_MASK], 0, n * c->plane_bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -191,6 +191,21 @@ struct lt_ctx {
 
 namespace lt {
 
+// ---- LT_TRACE_START=1 (lt_memory.cpp): one line per set-up phase on stderr -------------------------------
+//   lt_start <seconds on CLOCK_MONOTONIC, = Python's time.monotonic()> <what> <ms> [<bytes>]
+// What a first window of a stream or the first calls of process() spend outside the kernels: context growth (lt_reserve,
+// hipMalloc, cache hits and misses), page-locked allocations, table builds and uploads.  tools/cold_start.py reads them.
+bool trace_on();
+double trace_now();                                          // seconds, CLOCK_MONOTONIC
+void trace_line(const char* what, double t0, size_t bytes = 0);   // prints the phase that started at t0 (trace_now())
+struct TraceScope {
+    const char* what;
+    size_t bytes;
+    double t0;
+    TraceScope(const char* w, size_t b = 0) : what(w), bytes(b), t0(trace_on() ? trace_now() : 0.0) {}
+    ~TraceScope() { if (trace_on()) trace_line(what, t0, bytes); }
+};
+
 // ---- device memory (lt_memory.cpp): a cache in front of hipMalloc / hipFree ------------------------------
 void* cached_alloc(size_t bytes);
 void cached_free(void* p);

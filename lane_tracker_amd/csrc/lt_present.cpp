@@ -97,6 +97,7 @@ int lt_overlay_configure(lt_ctx* c, const double* Minv) {
     if (!c || !Minv) return fail(LT_ERR_INVALID, "null argument");
     int rc = set_device(c);
     if (rc) return rc;
+    TraceScope ts_all("lt_overlay_configure");
     if ((rc = sync_all(c))) return rc;
     // cv2.warpPerspective(lane, Minv, (img_w, img_h)): the same table builder with M := Minv and the
     // camera frame as the destination
@@ -214,6 +215,7 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
             if (c->h_spans) (void)hipHostFree(c->h_spans);
             c->h_spans = nullptr;
             c->h_spans_cap = 0;
+            TraceScope ts_("overlay:hipHostMalloc(spans)", (size_t)c->capacity * bh * 2 * sizeof(int16_t));
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
             c->h_spans_cap = c->capacity;
         }

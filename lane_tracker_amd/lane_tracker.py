@@ -141,6 +141,13 @@ class LaneTracker:
     del _lane_pixel_property
 
     def close(self):
+        try:
+            self._all_copies_done()
+            if self._group is not None:
+                _native.host_copy_group_release(self._group)
+                self._group = None
+        except Exception:
+            pass
         self._ctx.close()
         for c in self._aux_ctx.values():
             c.close()
@@ -502,11 +509,11 @@ class LaneTracker:
         if rows is None:
             return
         a0, a1, b0, b1 = rows[2]
-        lib, dst, src, rb = self._ctx.lib, out.ctypes.data, img.ctypes.data, W * 3
+        lib, dst, src, rb, grp = self._ctx.lib, out.ctypes.data, img.ctypes.data, W * 3, self._copy_group()
         for lo, hi in ((0, a0), (a1, b0), (b1, H)):
-            if hi > lo and lib.lt_host_copy_async(dst + lo * rb, src + lo * rb, (hi - lo) * rb):
-                raise _native.NativeError("lt_host_copy_async failed")
-        self._copying = True             # until lt_host_copy_wait: `out` and `img` must stay as they are
+            if hi > lo and lib.lt_host_copy_async_group(grp, dst + lo * rb, src + lo * rb, (hi - lo) * rb):
+                raise _native.NativeError("lt_host_copy_async_group failed")
+        self._copying = True             # until the group's wait: `out` and `img` must stay as they are
         self._out_rows, self._out_ahead = rows[1], rows[3]
 
     def _rows_for(self, img):
@@ -520,11 +527,31 @@ class LaneTracker:
 
     _copy_keepalive = None      # the arrays the copy threads read and write, until they are done
 
-    def _copies_done(self):
+    _group = None               # completion group of this tracker's host copies (lt_host_copy_group_create): process() and stand-alone windows
+    _window_groups = ()         # groups of the windows of a stream whose host copies may still run, oldest first: [(group, keepalive)]
+
+    def _copy_group(self):
+        """This tracker's own completion group of the library's copy threads: its waits do not depend on what other trackers
+        (or other threads) have queued."""
+        if self._group is None:
+            self._group = _native.host_copy_group()
+        return self._group
+
+    def _copies_done(self, window_group=None):
+        """Wait for the host copies of this tracker -- process()'s and a stand-alone window's (its own group), and with
+        `window_group` that window's of a stream (its group is given back)."""
         if self._copying:
             self._copying = False
-            self._ctx.lib.lt_host_copy_wait()
+            _native._check(self._ctx.lib.lt_host_copy_wait_group(self._copy_group()))
         self._copy_keepalive = None
+        if window_group is not None:
+            _native.host_copy_group_release(window_group)
+            self._window_groups = [g for g in self._window_groups if g[0] != window_group]
+
+    def _all_copies_done(self):
+        for g, _ in list(self._window_groups):
+            self._copies_done(g)
+        self._copies_done()
 
     def _rows_for_window(self, frames):
         """_present_rows() when the annotated frames of this window can travel as row runs, else None."""
@@ -1259,24 +1286,26 @@ class LaneTracker:
         empty = np.zeros(0, np.int64)
         done = [0]
         rows = self._window_rows[1] if (self._window_rows is not None and frames is not None and n) else None
-        copies = [rows is not None]
-
-        def start_copies():
-            # at the window's first flush, not before: in a stream the window before is handed out once this one's first
-            # searches are in flight, after waiting for ITS host copies -- which lt_host_copy_wait cannot tell from these
-            copies[0] = False
+        group = None
+        if rows is not None:
+            # the rows no overlay can touch: from the caller's window into `out` on the library's copy threads, from now on.  In a
+            # stream every window has a completion group of its own (the window before is handed out after waiting for ITS
+            # copies only); a stand-alone window uses the tracker's.
             a0, a1, b0, b1 = self._window_rows[2]
             H, rb, fb = ctx.img_h, ctx.img_w * 3, ctx.img_h * ctx.img_w * 3
             lib, dst, src = ctx.lib, out.ctypes.data, frames.ctypes.data
-            self._copying = True
-            self._copy_keepalive = (out, frames)
+            if self._in_stream:
+                group = _native.host_copy_group()
+                self._window_groups = list(self._window_groups) + [(group, (out, frames))]
+            else:
+                self._copying = True
+                self._copy_keepalive = (out, frames)
             for lo, hi in ((0, a0), (a1, b0), (b1, H)):
-                if hi > lo and lib.lt_host_copy2d_async(dst + lo * rb, fb, src + lo * rb, fb, (hi - lo) * rb, n):
-                    raise _native.NativeError("lt_host_copy2d_async failed")
+                if hi > lo and lib.lt_host_copy2d_async_group(group if group is not None else self._copy_group(), dst + lo * rb, fb,
+                                                              src + lo * rb, fb, (hi - lo) * rb, n):
+                    raise _native.NativeError("lt_host_copy2d_async_group failed")
 
         def flush(force):
-            if copies[0]:
-                start_copies()
             lo, hi = done[0], len(deferred)
             if hi <= lo or (hi - lo < piece and not force):
                 return
@@ -1286,6 +1315,7 @@ class LaneTracker:
                 ctx.overlay_text([d[2] for d in part], first=base + lo)
             ctx.download_overlay_async(out[lo:hi], first=base + lo, rows=rows)
             done[0] = hi
+        flush.group = group
         return flush, out
 
     def _render_window(self, deferred, base):
@@ -1383,10 +1413,10 @@ class LaneTracker:
 
         def landed():
             nonlocal landing
-            arrays, region = landing
+            arrays, region, group = landing
             landing = None
             ctx.download_overlay_wait()  # these frames have landed; the uploads, masks and searches of the next windows run on
-            self._copies_done()          # ... and so have the rows the host copies itself
+            self._copies_done(group)     # ... and so have the rows the host copies itself (this window's group only)
             free.append(region)
             return list(arrays)
         self._in_stream = True
@@ -1427,7 +1457,7 @@ class LaneTracker:
                 if landing is not None:
                     yield landed()
                 if frames_out is not None:
-                    landing = (frames_out, cur[1])   # handed out when the next window is under way (or the stream ends)
+                    landing = (frames_out, cur[1], flush.group)   # handed out when the next window is under way (or the stream ends)
                     cur = queue.pop(0) if queue else None
                 else:
                     free.append(cur[1])  # its frames, masks and records are not needed any more
@@ -1443,7 +1473,7 @@ class LaneTracker:
                 try:                     # that go back to the pool with their last reference
                     ctx.band_fit_chain_cancel()
                     ctx.sync()
-                    self._copies_done()
+                    self._all_copies_done()
                 except Exception:
                     pass
 

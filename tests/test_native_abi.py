@@ -24,8 +24,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_native.exported_symbols()) == declared
-    assert lib.lt_abi_version() == _native.ABI_VERSION == 3
-    assert int(re.search(r"#define LT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "lane_tracker_amd.h")).read()).group(1)) == 3
+    assert lib.lt_abi_version() == _native.ABI_VERSION == 4
+    assert int(re.search(r"#define LT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "lane_tracker_amd.h")).read()).group(1)) == 4
 
 
 def test_library_exports_nothing_but_the_header():
@@ -202,3 +202,83 @@ def test_host_copy_thread_copies_and_waits():
     assert lib.lt_host_copy_async(None, src.ctypes.data, 8) != 0          # a null pointer is refused, nothing is queued
     assert lib.lt_host_copy_async(dst.ctypes.data, src.ctypes.data, 0) == 0
     assert lib.lt_host_copy_wait() == 0
+
+
+def test_host_copy_groups_complete_independently():
+    """Completion per group (ABI 4): a short copy in one group is waited for while another group still has a long queue --
+    two trackers on two threads do not wait for each other's copies -- and each group's data is complete after ITS wait."""
+    import threading
+    import time
+    from lane_tracker_amd import _native
+    lib = _native.load()
+    ga, gb = _native.host_copy_group(), _native.host_copy_group()
+    assert ga > 0 and gb > 0 and ga != gb
+    rng = np.random.default_rng(5)
+    big_src = rng.integers(0, 256, (96, 4 << 20), dtype=np.uint8)          # 384 MB in 96 pieces: tenths of a second of memcpy
+    big_dst = np.zeros_like(big_src)
+    small_src = rng.integers(0, 256, (1 << 12,), dtype=np.uint8)
+    small_dst = np.zeros_like(small_src)
+    t = {}
+
+    def long_job():
+        assert lib.lt_host_copy2d_async_group(gb, big_dst.ctypes.data, big_src.shape[1], big_src.ctypes.data, big_src.shape[1],
+                                              big_src.shape[1], big_src.shape[0]) == 0
+        t0 = time.perf_counter()
+        assert lib.lt_host_copy_wait_group(gb) == 0
+        t["long"] = time.perf_counter() - t0
+
+    th = threading.Thread(target=long_job)
+    th.start()
+    time.sleep(0.01)                     # the long job is queued and under way
+    t0 = time.perf_counter()
+    assert lib.lt_host_copy_async_group(ga, small_dst.ctypes.data, small_src.ctypes.data, small_src.size) == 0
+    assert lib.lt_host_copy_wait_group(ga) == 0
+    t["short"] = time.perf_counter() - t0
+    assert np.array_equal(small_dst, small_src)
+    th.join()
+    assert np.array_equal(big_dst, big_src)
+    # the short wait did not sit out the long queue (pieces are taken in order, so it waits for at most the pieces in front of it
+    # on the workers -- not for the group as a whole); generous bound for a loaded CI box
+    assert t["short"] < max(0.5 * t["long"], 0.05), t
+    assert lib.lt_host_copy_wait() == 0                                    # every group
+    assert lib.lt_host_copy_async_group(12345678, small_dst.ctypes.data, small_src.ctypes.data, 8) != 0   # unknown group
+    assert lib.lt_host_copy_wait_group(12345678) != 0
+    _native.host_copy_group_release(ga)
+    _native.host_copy_group_release(gb)
+    assert lib.lt_host_copy_wait_group(ga) != 0                            # forgotten
+    assert lib.lt_host_copy_group_destroy(0) == 0                          # the default group stays
+
+
+def test_host_copy_threads_survive_shutdown_and_fork():
+    """lt_shutdown joins the workers and the next request starts new ones; the child of a fork() in a process that had
+    workers gets workers of its own (round 4: its first wait blocked for ever)."""
+    import os
+    from lane_tracker_amd import _native
+    lib = _native.load()
+    src = np.arange(1 << 16, dtype=np.uint8)
+    dst = np.zeros_like(src)
+    assert lib.lt_host_copy_async(dst.ctypes.data, src.ctypes.data, src.size) == 0
+    assert lib.lt_shutdown() == 0
+    assert np.array_equal(dst, src)      # shutdown finishes what was queued
+    dst[:] = 0
+    assert lib.lt_host_copy_async(dst.ctypes.data, src.ctypes.data, src.size) == 0
+    assert lib.lt_host_copy_wait() == 0
+    assert np.array_equal(dst, src)
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                         # child: the parent's workers do not exist here
+        try:
+            os.close(r)
+            d2 = np.zeros_like(src)
+            import signal
+            signal.alarm(20)             # a hang ends the child, the parent sees no "ok"
+            ok = lib.lt_host_copy_async(d2.ctypes.data, src.ctypes.data, src.size) == 0 and lib.lt_host_copy_wait() == 0 \
+                and np.array_equal(d2, src)
+            os.write(w, b"ok" if ok else b"no")
+        finally:
+            os._exit(0)
+    os.close(w)
+    got = os.read(r, 2)
+    os.close(r)
+    os.waitpid(pid, 0)
+    assert got == b"ok"
