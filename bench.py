@@ -124,6 +124,33 @@ def stream_windows(base, window, count):
         return list(ex.map(one, range(count)))
 
 
+def _call_trace(tracker):
+    """LT_BENCH_TRACE=1: wall time of the driving thread per library call of `tracker` (and of the page-locked pool) -> a
+    function returning {call: [count, ms]} sorted by time (tools/cold_start.py has the finer tool)."""
+    import collections
+    from lane_tracker_amd import _native
+    acc = collections.defaultdict(lambda: [0, 0.0])
+
+    def timed(obj, name):
+        fn = getattr(obj, name)
+
+        def w(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                acc[name][0] += 1
+                acc[name][1] += (time.perf_counter() - t0) * 1e3
+        setattr(obj, name, w)
+    ctx = tracker._ctx
+    for m in ("reserve", "sync", "upload_frame_rows_async", "upload_frame_rest", "mask_run", "sws_fit_run", "band_fit_run", "band_fit_chain_run",
+              "band_fit_chain_collect", "download_records", "overlay_configure", "overlay_run_packed", "overlay_text", "download_overlay_async",
+              "download_overlay_wait"):
+        if hasattr(ctx, m):
+            timed(ctx, m)
+    return lambda: {k: [v[0], round(v[1], 2)] for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])}
+
+
 def stream_leg(streams, window=256, seconds=1.0, nwin=8):
     """The stateful stream (BASELINE config 5) through the drop-in API, host-fed: frames/s of process() frame
     by frame (annotated frame back, as process_video.py uses it), of process_batch() (device-chained searches) and of
@@ -153,19 +180,47 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                     k += 1
                 res[key] = round(k * window / (time.perf_counter() - t0), 1)
 
-            def stream_rate(ws, ann, tracker=lt, **kw):
+            def stream_rate(ws, ann, tracker=lt, first=None, **kw):
                 t0 = time.perf_counter()
                 for _ in tracker.process_stream(ws, annotate=ann, **kw):
-                    pass
+                    if first is not None and not first:
+                        first.append((time.perf_counter() - t0) * 1e3)
                 return round(len(ws) * window / (time.perf_counter() - t0), 1)
-            # consecutive windows of one video: process_stream keeps the device busy across window boundaries.  Fresh copies for
-            # the first pass of each variant (the batch calls above have touched wins[...] already).
+
+            def first_passes(ann, trackers=3):
+                """The first pass of a stream -- what a single video pays (process_video.py:41-44) -- from `trackers` FRESH trackers,
+                each over freshly allocated windows the runtime has never seen: frames/s and the time to the first window."""
+                rates, ttfw = [], []
+                reuse = bool(os.environ.get("LT_BENCH_OLD_FIRST"))     # diagnosis: round 4's sequence (the tracker of the legs above)
+                for _ in range(1 if reuse else trackers):
+                    ws = stream_windows(base, window, nwin)
+                    fresh = lt if reuse else LaneTracker(**cal)
+                    trace = _call_trace(fresh) if os.environ.get("LT_BENCH_TRACE") else None
+                    try:
+                        first = []
+                        rates.append(stream_rate(ws, ann, fresh, first))
+                        ttfw.append(round(first[0], 2))
+                        if trace is not None:
+                            print("LT_BENCH_TRACE %s annotate=%s %.1f frames/s ttfw %.1f ms: %s" % (name, ann, rates[-1], ttfw[-1], trace()), file=sys.stderr)
+                    finally:
+                        if not reuse:
+                            fresh.close()
+                    del ws
+                return {"frames_per_s": {"min": min(rates), "median": sorted(rates)[len(rates) // 2], "max": max(rates)},
+                        "time_to_first_window_ms": {"min": min(ttfw), "median": sorted(ttfw)[len(ttfw) // 2], "max": max(ttfw)},
+                        "fresh_trackers": len(rates)}
+            # consecutive windows of one video: process_stream keeps the device busy across window boundaries.
+            fp_plain = first_passes(False)
+            res["process_stream_first_pass"] = fp_plain
+            res["process_stream_first_pass_fps"] = fp_plain["frames_per_s"]["median"]
             cold = stream_windows(base, window, nwin)
-            res["process_stream_first_pass_fps"] = stream_rate(cold, False)
+            stream_rate(cold, False)
             res["process_stream_fps"] = max(stream_rate(cold + cold, False) for _ in range(2))      # 4096 frames per stream
-            cold = stream_windows(base, window, nwin)
             # ... and with every annotated frame rendered and copied back (what process_video.py consumes)
-            res["process_stream_annotated_first_pass_fps"] = stream_rate(cold, True)
+            fp_ann = first_passes(True)
+            res["process_stream_annotated_first_pass"] = fp_ann
+            res["process_stream_annotated_first_pass_fps"] = fp_ann["frames_per_s"]["median"]
+            stream_rate(cold, True)
             res["process_stream_annotated_fps"] = max(stream_rate(cold, True) for _ in range(2))
             res["annotated_frames_came_back_by"] = lt._ctx.download_stats()
             rows = lt._present_rows() if lt.host_copies_rows else None
