@@ -36,7 +36,10 @@ extern "C" {
  *    lt_last_adaptive_path, lt_host_copy_async, lt_host_copy2d_async, lt_host_copy_wait, lt_overlay_run_rows,
  *    lt_download_overlay_rows_async.  Nothing removed or changed. */
 /* 4: + lt_host_copy_group_create / _destroy, lt_host_copy_async_group, lt_host_copy2d_async_group, lt_host_copy_wait_group
- *    (completion per group instead of per process), lt_shutdown, lt_device_cache_stats.  Nothing removed or changed. */
+ *    (completion per group instead of per process), lt_shutdown, lt_device_cache_stats, lt_warm (a stream's set-up ahead of its
+ *    first window), lt_overlay_run_strip + lt_strip_download_async (annotated frames as one packed strip of rows per frame through
+ *    page-locked staging blocks into ordinary memory), lt_text_blend_host + lt_host_text_async_group (the text lines on the host).
+ *    Nothing removed or changed. */
 #define LT_ABI_VERSION 4
 
 typedef enum lt_status {
@@ -116,6 +119,12 @@ int  lt_device_count(int* count);
 int  lt_create(const lt_calib* calib, int device, lt_ctx** out);
 void lt_destroy(lt_ctx* ctx);
 int  lt_reserve(lt_ctx* ctx, int capacity);
+/* Set-up ahead of use, for the current capacity (call lt_reserve first): the streams, page-locked staging and device buffers that
+ * the first searches / the first chained search / the first overlay would otherwise create on the way (20-35 ms of the first
+ * window of a stream).  sws / band: the search parameters to size the result buffers for (either may be NULL); annotate: 0 = no
+ * presentation stage, 1 = whole annotated frames (lt_overlay_run), 2 = strips (lt_overlay_run_strip); needs lt_overlay_configure
+ * for 1 and 2.  Optional: every entry point still sets up what it finds missing. */
+int  lt_warm(lt_ctx* ctx, const lt_search_params* sws, const lt_search_params* band, int annotate);
 int  lt_get_info(lt_ctx* ctx, lt_info* out);
 int  lt_sync(lt_ctx* ctx);
 /* Number of HIP streams (1..8, default 1) the context spreads its slots over.  Slot s always runs on
@@ -314,6 +323,32 @@ int  lt_download_overlay_wait(lt_ctx* ctx);
  * rates (GB/s), the number of timed copies per method and the method the next copy would use; any pointer may be NULL. */
 int  lt_set_download_method(lt_ctx* ctx, int method);
 int  lt_download_stats(lt_ctx* ctx, double* engine_gbs, int* engine_copies, double* kernel_gbs, int* kernel_copies, int* method);
+/* ---- annotated frames of a window as strips (round 5) ----------------------------------------------------------------------
+ * Outside the rows the lane can reach (lt_overlay_rows) an annotated frame is the camera frame plus the text lines -- both of
+ * which the host has.  So of an annotated frame only that run of rows is drawn on the device, packed ("strip", rows * img_w * 3
+ * bytes per slot), and it comes back as ONE contiguous copy per block of 32 slots into page-locked staging blocks the library
+ * pools (copy engine, full rate), from where the library's copy threads put the rows into the caller's frames -- ordinary
+ * memory: no window-sized page-locked output array (0.13 s of page-locking per 0.7 GB, the first window's largest cost).  The
+ * other rows and the text the caller adds with lt_host_copy2d_async_group / lt_host_text_async_group in the same group;
+ * lt_host_copy_wait_group(group) returns when the frames are complete.  Needs img_w % 4 == 0.
+ *   lt_overlay_run_strip     lt_overlay_run for rows [lt_overlay_rows) only, into the context's strip buffer
+ *   lt_strip_download_async  the strips of slots [first, first + n) -> rows [row0, row1) of out + i * out_frame_stride (i < n) */
+int  lt_overlay_run_strip(lt_ctx* ctx, int first_slot, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                          const int32_t* right_yx, double alpha);
+int  lt_strip_download_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out, size_t out_frame_stride, int group);
+/* The text lines of draw_lane() / print_failure() (lane_tracker.py:652-661, 664-673; glyph atlas as for lt_overlay_set_font) drawn on
+ * the HOST, with lt_overlay_text's arithmetic bit for bit (white over the frame: v + ((255 - v) * alpha + 127) / 255): `lines` holds
+ * n_lines * line_len bytes per frame (NUL-padded), frame after frame.  No GPU, no context.
+ *   lt_text_blend_host        n frames in place, on the calling thread (LaneTracker.process(): ~10 us per frame)
+ *   lt_host_text_async_group  on the library's copy threads, in `group`: per frame, first copy rows [row0, row1) of the source
+ *                             frame into the destination frame (the rows the text lies in; row0 == row1: nothing), then draw
+ *                             the lines.  `lines` is copied; the frames and the atlas must stay valid until the group's wait. */
+int  lt_text_blend_host(uint8_t* frames, size_t frame_stride, int n, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance,
+                        int first_char, int n_glyphs, int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0,
+                        int y0, int step);
+int  lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_stride, int n, int row0, int row1,
+                              int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs,
+                              int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0, int y0, int step);
 /* Page-locked host memory for buffers passed to the upload / download entry points (copies from or to pageable
  * memory run at a fraction of the PCIe rate).  Needs a GPU; lt_host_free(NULL) is a no-op.  The reference has no
  * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */

@@ -113,6 +113,13 @@ _SIGNATURES = {
     "lt_host_copy2d_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t]),
     "lt_host_copy_wait_group": (C.c_int, [C.c_int]),
     "lt_shutdown": (C.c_int, []),
+    "lt_warm": (C.c_int, [_P, C.POINTER(SearchParams), C.POINTER(SearchParams), C.c_int]),
+    "lt_overlay_run_strip": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double]),
+    "lt_strip_download_async": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
+    "lt_text_blend_host": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
+                                     C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lt_host_text_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
+                                           C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
@@ -261,6 +268,42 @@ def host_copy_group():
 def host_copy_group_release(group):
     """Wait for the group's copies and forget it (lt_host_copy_group_destroy)."""
     _check(load().lt_host_copy_group_destroy(int(group)))
+
+
+def text_bytes(lines_per_frame, line_len=40):
+    """[[str, ...], ...] -> (bytes, n_lines): every frame's lines NUL-padded to line_len, frames padded to the longest list."""
+    nl = max((len(l) for l in lines_per_frame), default=0)
+    blank = b"\0" * line_len
+    return b"".join(b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) + blank * (nl - len(lines))
+                    for lines in lines_per_frame), nl
+
+
+def text_blend(frames, font, text, n_lines, line_len=40, origin=(20, 8), step=35):
+    """The text lines of `frames` (n, H, W, 3) u8 drawn in place on the calling thread (lt_text_blend_host: lt_overlay_text's
+    arithmetic on the host).  font = (atlas (g, gh, gw) u8, advance (g,) u8, first_char); text = n * n_lines * line_len bytes."""
+    atlas, advance, first_char = font
+    n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+    rc = load().lt_text_blend_host(frames.ctypes.data, H * W * 3, n, H, W, atlas.ctypes.data, advance.ctypes.data, int(first_char),
+                                   atlas.shape[0], atlas.shape[2], atlas.shape[1], text, n_lines, line_len, int(origin[0]), int(origin[1]), int(step))
+    if rc:
+        _check(rc)
+
+
+def host_text_async(group, dst, src, rows, font, text, n_lines, line_len=40, origin=(20, 8), step=35):
+    """On the library's copy threads, in `group`: rows [rows[0], rows[1]) of every frame of `src` into `dst` (both (n, H, W, 3) u8,
+    C-contiguous), then that frame's text lines drawn over them (lt_host_text_async_group).  font None / n_lines 0: only the rows."""
+    n, H, W = dst.shape[0], dst.shape[1], dst.shape[2]
+    if font is None or not n_lines:
+        atlas = advance = None
+        first_char = g = gw = gh = 0
+        text, n_lines = None, 0
+    else:
+        atlas, advance, first_char = font
+        g, gh, gw = atlas.shape
+    _check(load().lt_host_text_async_group(int(group), dst.ctypes.data, H * W * 3, src.ctypes.data, H * W * 3, n, int(rows[0]), int(rows[1]), H, W,
+                                           None if atlas is None else atlas.ctypes.data, None if advance is None else advance.ctypes.data,
+                                           int(first_char), int(g), int(gw), int(gh), text, int(n_lines), int(line_len), int(origin[0]),
+                                           int(origin[1]), int(step)))
 
 
 def device_cache_stats():
@@ -485,6 +528,27 @@ class Context:
         _check(self.lib.lt_overlay_run_rows(self._h, first, len(ln), ln.ctypes.data, rn.ctypes.data,
                                             lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None,
                                             float(alpha), rows))
+
+    def overlay_run_strip_packed(self, ln, rn, lyx, ryx, first=0, alpha=0.3):
+        """overlay_run_packed in strip mode (lt_overlay_run_strip): only the rows the lane can reach, packed per slot."""
+        ln, rn = np.ascontiguousarray(ln, np.int32), np.ascontiguousarray(rn, np.int32)
+        lyx, ryx = np.ascontiguousarray(lyx, np.int32), np.ascontiguousarray(ryx, np.int32)
+        if len(rn) != len(ln) or lyx.size != 2 * int(ln.sum()) or ryx.size != 2 * int(rn.sum()):
+            raise ValueError("point lists do not match their counts")
+        _check(self.lib.lt_overlay_run_strip(self._h, first, len(ln), ln.ctypes.data, rn.ctypes.data,
+                                             lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None, float(alpha)))
+
+    def strip_download_async(self, out, first, group):
+        """The strips of slots first .. first+len(out)-1 into rows overlay_rows() of the frames `out` (n, H, W, 3) u8, C-contiguous,
+        ordinary memory; complete when the host-copy group `group` has been waited for (lt_strip_download_async)."""
+        if out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] or out.shape[1:] != (self.img_h, self.img_w, 3):
+            raise ValueError("strip_download_async needs a C-contiguous uint8 array (n, H, W, 3)")
+        _check(self.lib.lt_strip_download_async(self._h, first, out.shape[0], out.ctypes.data, self.img_h * self.img_w * 3, int(group)))
+
+    def warm(self, sws=None, band=None, annotate=0):
+        """Set up now what the first searches / chains / overlays would set up on the way (lt_warm); annotate: 0 none, 1 whole
+        annotated frames, 2 strips."""
+        _check(self.lib.lt_warm(self._h, None if sws is None else C.byref(sws), None if band is None else C.byref(band), int(annotate)))
 
     def overlay_set_font(self, atlas, advance, first_char=32):
         """atlas: (n_glyphs, glyph_h, glyph_w) u8 alpha cells; advance: (n_glyphs,) u8."""

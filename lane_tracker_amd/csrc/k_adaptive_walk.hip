@@ -282,4 +282,10 @@ bool launch_adaptive_walk(hipStream_t s, const uint8_t* R, int bs_r, int C_r, un
     return launch_box(s, pl, 2, h, w, plane_stride, bits_stride, n);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_adaptive_walk() {} }
+void preload_k_adaptive_walk(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_adaptive_walk, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

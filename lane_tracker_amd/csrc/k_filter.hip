@@ -202,4 +202,10 @@ void launch_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uin
                        plane_stride);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_filter() {} }
+void preload_k_filter(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_filter, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

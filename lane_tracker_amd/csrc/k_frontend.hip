@@ -521,4 +521,10 @@ void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_px
     hipLaunchKernelGGL(k_undistorted_to_rgb, grid, dim3(256), 0, s, und, und_px, first_slot, nrows, w, out);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_frontend() {} }
+void preload_k_frontend(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_frontend, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

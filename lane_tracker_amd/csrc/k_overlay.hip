@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void k_overlay_lane(const uint8_t* __restrict_
 
 // Four pixels (12 bytes = three dwords) per thread when the row length allows it.
 __global__ __launch_bounds__(256) void k_overlay_lane4(const uint32_t* __restrict__ frames, uint32_t* __restrict__ out,
-                                                      size_t frame_stride_dw, const int16_t* __restrict__ oxy,
+                                                      size_t frame_stride_dw, size_t out_stride_dw, int out_q0,
+                                                      const int16_t* __restrict__ oxy,
                                                       const uint16_t* __restrict__ ofrac,
                                                       const short2* __restrict__ spans, size_t span_stride, int qa, int na,
                                                       int qb, int nb, int bh, int bw, float alpha) {
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(256) void k_overlay_lane4(const uint32_t* __restric
     if (t >= na + nb) return;
     const int q = t < na ? qa + t : qb + (t - na);
     const uint32_t* src = frames + (size_t)blockIdx.z * frame_stride_dw + (size_t)q * 3;
-    uint32_t* dst = out + (size_t)blockIdx.z * frame_stride_dw + (size_t)q * 3;
+    // the annotated frame at the camera frame's place (out_stride_dw = frame_stride_dw, out_q0 = 0), or -- strip mode -- only the
+    // run of rows the lane can reach, packed: slot z's strip starts at z * out_stride_dw and holds the quads from out_q0 on
+    uint32_t* dst = out + (size_t)blockIdx.z * out_stride_dw + (size_t)(q - out_q0) * 3;
     uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
     const uint4 xy = reinterpret_cast<const uint4*>(oxy)[q];
     const uint2 fr = reinterpret_cast<const uint2*>(ofrac)[q];
@@ -284,6 +287,18 @@ void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int i
                        n_glyphs, gw, gh, lines, xpos, nl, len, slot_chars, y0, step);
 }
 
+bool launch_overlay_lane_strip(hipStream_t s, const uint8_t* frames, size_t frame_stride, uint8_t* strips, size_t strip_stride,
+                               const int16_t* oxy, const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_w,
+                               int row0, int row1, int bh, int bw, float alpha, int n) {
+    if (n <= 0 || row1 <= row0) return true;
+    if ((img_w & 3) || (frame_stride & 3) || (strip_stride & 3) || (((size_t)(uintptr_t)frames | (size_t)(uintptr_t)strips) & 3)) return false;
+    const int qrow = img_w >> 2, qb = row0 * qrow, nb = (row1 - row0) * qrow;
+    hipLaunchKernelGGL(k_overlay_lane4, dim3((nb + 255) / 256, 1, n), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(frames),
+                       reinterpret_cast<uint32_t*>(strips), frame_stride >> 2, strip_stride >> 2, qb, oxy, ofrac,
+                       reinterpret_cast<const short2*>(spans), span_stride_rows, 0, 0, qb, nb, bh, bw, alpha);
+    return true;
+}
+
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
                          const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
                          int bh, int bw, float alpha, int n, const int* rows4) {
@@ -296,7 +311,7 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
         if (rows4) { qa = rows4[0] * qrow; na = (rows4[1] - rows4[0]) * qrow; qb = rows4[2] * qrow; nb = (rows4[3] - rows4[2]) * qrow; }
         if (na + nb <= 0) return;
         hipLaunchKernelGGL(k_overlay_lane4, dim3((na + nb + 255) / 256, 1, n), dim3(256), 0, s,
-                           reinterpret_cast<const uint32_t*>(frames), reinterpret_cast<uint32_t*>(out), frame_stride >> 2,
+                           reinterpret_cast<const uint32_t*>(frames), reinterpret_cast<uint32_t*>(out), frame_stride >> 2, frame_stride >> 2, 0,
                            oxy, ofrac, sp, span_stride_rows, qa, na, qb, nb, bh, bw, alpha);
     } else {      // (a row length that is no multiple of 4: the whole frame whatever the runs -- a superset)
         hipLaunchKernelGGL(k_overlay_lane, dim3((npix + 255) / 256, 1, n), dim3(256), 0, s, frames, out, frame_stride, oxy,
@@ -329,4 +344,10 @@ void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int firs
                        wfrac, g, bev, bev_stride);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_overlay() {} }
+void preload_k_overlay(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_overlay, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

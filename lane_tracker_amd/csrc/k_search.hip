@@ -1526,4 +1526,10 @@ void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, 
     else hipLaunchKernelGGL(k_band_chain2<false>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_search() {} }
+void preload_k_search(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_search, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

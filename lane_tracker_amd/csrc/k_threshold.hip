@@ -860,4 +860,10 @@ void launch_bits_to_u8(hipStream_t s, const unsigned long long* bits, uint8_t* o
                        plane_stride);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_threshold() {} }
+void preload_k_threshold(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_threshold, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

@@ -617,4 +617,10 @@ void launch_or4_bits(hipStream_t s, unsigned long long* merged, const unsigned l
     hipLaunchKernelGGL(k_or4_bits, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, merged, s1, s2, s3, n0, n1, merged, words);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_threshold_walk() {} }
+void preload_k_threshold_walk(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_threshold_walk, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

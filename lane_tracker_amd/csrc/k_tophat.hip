@@ -999,4 +999,10 @@ bool launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const ui
     return launch_runs<SE29>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride, copy_dst);
 }
 
+// Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches
+// this no-op so that no stream's first window pays for it (lt_api.cpp: preload_kernels).
+namespace { __global__ void k_preload_k_tophat() {} }
+void preload_k_tophat(hipStream_t s) { hipLaunchKernelGGL(k_preload_k_tophat, dim3(1), dim3(1), 0, s); }
+
 }  // namespace lt
+

@@ -174,6 +174,7 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_band_sums);
     dev_free(c->d_spans);
     dev_free(c->d_annot);
+    dev_free(c->d_strip);
     c->maxbands = 0;
     c->capacity = 0;
     c->maxpix = 0;
@@ -213,6 +214,37 @@ int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev) {
         c->maxlev = maxlev;
     }
     return LT_OK;
+}
+
+int ensure_band_sums(lt_ctx* c, int nbands) {
+    if (nbands <= c->maxbands) return LT_OK;
+    int rc = sync_all(c);
+    if (rc) return rc;
+    dev_free(c->d_band_sums);
+    if ((rc = dev_alloc(&c->d_band_sums, (size_t)c->capacity * nbands * c->calib.warp_w))) return rc;
+    c->maxbands = nbands;
+    return LT_OK;
+}
+
+// one no-op launch per kernel translation unit, once per process and device: their code objects load now (a few ms each), not under
+// the first window of a stream or the first frame of a video
+static void preload_kernels(int device, hipStream_t s) {
+    static std::mutex m;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> g(m);
+    if (std::find(done.begin(), done.end(), device) != done.end()) return;
+    done.push_back(device);
+    TraceScope ts_("lt_create:preload_kernels");
+    preload_k_frontend(s);
+    preload_k_filter(s);
+    preload_k_tophat(s);
+    preload_k_threshold(s);
+    preload_k_threshold_walk(s);
+    preload_k_adaptive_walk(s);
+    preload_k_search(s);
+    preload_k_overlay(s);
+    (void)hipStreamSynchronize(s);
+    (void)hipGetLastError();
 }
 
 int ensure_bev(lt_ctx* c) {
@@ -602,6 +634,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     up(c->d_coef, coef, sizeof coef);
     if (e != hipSuccess) return bail(fail(LT_ERR_HIP, "table upload failed: %s", hipGetErrorString(e)));
 
+    preload_kernels(device, c->stream);
     c->frame_bytes = (size_t)calib->img_h * calib->img_w * 3;
     c->und_bytes = (size_t)c->fe.nrows * calib->img_w * 3;   // as returned by lt_download_undistorted (RGB)
     c->und_px = (size_t)c->fe.nrows * calib->img_w;
@@ -730,6 +763,41 @@ int lt_reserve(lt_ctx* c, int capacity) {
     HIP_TRY(hipMemsetAsync(c->d_plane[P_MASK], 0, n * c->plane_bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
+}
+
+// Everything a stream's first window (or a video's first frame) would otherwise set up on the way -- streams, page-locked
+// staging, search buffers sized for these parameters, the presentation stage's buffers -- now, for the current capacity
+// (lt_reserve first).  Nothing changes in what later calls compute; they find their buffers in place.
+int lt_warm(lt_ctx* c, const lt_search_params* sws, const lt_search_params* band, int annotate) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (c->capacity < 1) return fail(LT_ERR_STATE, "lt_warm before lt_reserve");
+    int rc = set_device(c);
+    if (rc) return rc;
+    TraceScope ts_all("lt_warm", (size_t)c->capacity);
+    if ((rc = ensure_chain_buffers(c))) return rc;
+    if (!c->urgent && create_compute_stream(&c->urgent, c->search_cus) != hipSuccess) return fail(LT_ERR_HIP, "hipStreamCreate failed");
+    constexpr size_t SMALL = 256 << 10;
+    if (!c->h_small && hipHostMalloc(reinterpret_cast<void**>(&c->h_small), SMALL, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->h_small = nullptr;
+    }
+    int maxpix = 0, maxlev = 0;
+    if (sws) {
+        SearchGeom g;
+        if ((rc = make_search_geom(c, sws, false, g))) return rc;
+        maxpix = std::max(maxpix, g.maxpix);
+        maxlev = std::max(maxlev, g.maxlev);
+        if ((rc = ensure_band_sums(c, g.nbands))) return rc;
+    }
+    if (band) {
+        SearchGeom g;
+        if ((rc = make_search_geom(c, band, true, g))) return rc;
+        maxpix = std::max(maxpix, g.maxpix);
+        maxlev = std::max(maxlev, 1);
+    }
+    if (maxpix && (rc = ensure_search_buffers(c, maxpix, maxlev))) return rc;
+    if (annotate && (rc = warm_presentation(c, annotate == 2))) return rc;
+    return sync_all(c);
 }
 
 int lt_get_info(lt_ctx* c, lt_info* out) {
@@ -1304,12 +1372,7 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
     SearchGeom g;
     if ((rc = make_search_geom(c, p, false, g))) return rc;
     if ((rc = ensure_search_buffers(c, g.maxpix, g.maxlev))) return rc;
-    if (g.nbands > c->maxbands) {
-        if ((rc = sync_all(c))) return rc;
-        dev_free(c->d_band_sums);
-        if ((rc = dev_alloc(&c->d_band_sums, (size_t)c->capacity * g.nbands * c->calib.warp_w))) return rc;
-        c->maxbands = g.nbands;
-    }
+    if ((rc = ensure_band_sums(c, g.nbands))) return rc;
     g.maxpix = c->maxpix;
     g.maxlev = c->maxlev;
     if (n == 0) return LT_OK;

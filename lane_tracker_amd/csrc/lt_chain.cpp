@@ -23,7 +23,9 @@ using namespace lt;
 
 extern "C" {
 
-static int ensure_search_stream(lt_ctx* c) {
+}  // extern "C"
+namespace lt {
+int ensure_search_stream(lt_ctx* c) {
     if (c->search) return LT_OK;
     if (c->search_cus > 0) {                  // the CUs the slots' streams were kept off (lt_set_search_cus)
         uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -33,6 +35,31 @@ static int ensure_search_stream(lt_ctx* c) {
     } else HIP_TRY(create_compute_stream(&c->search));
     return LT_OK;
 }
+
+// what a chain needs besides its slots: the search stream, the cancel word (page-locked, device-visible) and the page-locked
+// staging of the records, one entry per slot.  The first chain of a stream used to pay for these (9 ms: lt_warm does it ahead).
+int ensure_chain_buffers(lt_ctx* c) {
+    int rc = ensure_search_stream(c);
+    if (rc) return rc;
+    if (!c->h_cancel) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_cancel), 64, hipHostMallocMapped));
+        *c->h_cancel = 0;
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cancel), c->h_cancel, 0));
+    }
+    if (c->h_rec_stage_cap < c->capacity) {
+        HIP_TRY(hipStreamSynchronize(c->search));
+        if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
+        c->h_rec_stage = nullptr;
+        c->h_rec_stage_cap = 0;
+        for (auto& t : c->chains) c->chain_event_pool.push_back(t.done);   // tickets of the old staging block: nothing to collect any more
+        c->chains.clear();
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_rec_stage), (size_t)c->capacity * sizeof(lt_lane_record), hipHostMallocDefault));
+        c->h_rec_stage_cap = c->capacity;
+    }
+    return LT_OK;
+}
+}  // namespace lt
+extern "C" {
 
 int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p, const double* seed) {
     int rc = check_slots(c, first, n);
@@ -59,12 +86,7 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
     // The chain runs on the context's search stream, behind whatever the slots' streams hold so far (the masks of these
     // slots, the search that wrote the seed record); those streams do not wait for it -- the mask chains of later frames run
     // beside it -- unless they touch its slots (for_each_slice).
-    if ((rc = ensure_search_stream(c))) return rc;
-    if (!c->h_cancel) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_cancel), 64, hipHostMallocMapped));
-        *c->h_cancel = 0;
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_cancel), c->h_cancel, 0));
-    }
+    if ((rc = ensure_chain_buffers(c))) return rc;
     const int lo = seed ? first : first - 1, cnt = seed ? n : n + 1;     // with a device seed the seed record is collected too
     bool precise = true;
     // everything the slots' streams wrote into these slots and may not have finished (their masks; the search that left the
@@ -79,16 +101,6 @@ int lt_band_fit_chain_run(lt_ctx* c, int first, int n, const lt_search_params* p
             return (int)LT_OK;
         });
         if (rc) return rc;
-    }
-    if (c->h_rec_stage_cap < c->capacity) {
-        HIP_TRY(hipStreamSynchronize(c->search));
-        if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
-        c->h_rec_stage = nullptr;
-        c->h_rec_stage_cap = 0;
-        for (auto& t : c->chains) c->chain_event_pool.push_back(t.done);   // tickets of the old staging block: nothing to collect any more
-        c->chains.clear();
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_rec_stage), (size_t)c->capacity * sizeof(lt_lane_record), hipHostMallocDefault));
-        c->h_rec_stage_cap = c->capacity;
     }
     const int wpr = (c->calib.warp_w + 63) / 64;
     {

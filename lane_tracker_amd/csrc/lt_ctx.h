@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <functional>
+#include <memory>
 #include <vector>
 
 #include "lt_internal.h"
@@ -98,6 +100,8 @@ struct lt_ctx {
     bool have_overlay = false;
     int16_t* d_spans = nullptr;       // [slot][warp_h] (lo, hi)
     uint8_t* d_annot = nullptr;
+    uint8_t* d_strip = nullptr;       // strip mode (lt_overlay_run_strip): rows [ov_r0, ov_r1) of every slot's annotated frame, packed
+    size_t strip_bytes = 0;
     // Page-locked staging with one region PER SLOT (row intervals, text lines, glyph positions), so that an overlay call only
     // enqueues copies and kernels: calls over disjoint slots never wait for each other (the stream pipeline renders a window
     // in pieces while later frames are still searched).  A call over slots whose previous overlay may still be in flight
@@ -206,6 +210,19 @@ struct TraceScope {
     ~TraceScope() { if (trace_on()) trace_line(what, t0, bytes); }
 };
 
+// ---- host copy threads, staging blocks (lt_memory.cpp), for lt_present.cpp ----------------------------------
+int host_submit_copy2d(int group, uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, size_t height,
+                       std::shared_ptr<void> hold);          // `hold` is released when the last piece of the copy has run
+int host_submit_fn(int group, std::function<void()> fn, bool many);
+int host_reserve(int group);                                 // a piece that will be submitted later: the group waits for it
+void host_unreserve(int group);
+void host_after_event(hipEvent_t ev, int device, std::function<void()> then);   // `then` runs on the library's waiter thread once `ev` has fired
+int host_copy_threads();
+void* pinned_block_acquire(size_t bytes);                    // page-locked staging, pooled per size (nullptr: allocation failed)
+void pinned_block_release(void* p, size_t bytes);
+hipEvent_t pooled_event();                                   // process-wide events (they outlive the context that recorded them)
+void pooled_event_release(hipEvent_t e);
+
 // ---- device memory (lt_memory.cpp): a cache in front of hipMalloc / hipFree ------------------------------
 void* cached_alloc(size_t bytes);
 void cached_free(void* p);
@@ -240,6 +257,10 @@ int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev);
 bool masks_have_bits(const lt_ctx* c, int first, int n);
 int ensure_u8_masks(lt_ctx* c, int first, int n);
 int make_search_geom(lt_ctx* c, const lt_search_params* p, bool band, SearchGeom& g);
+int ensure_band_sums(lt_ctx* c, int nbands);
+int ensure_search_stream(lt_ctx* c);                          // lt_chain.cpp
+int ensure_chain_buffers(lt_ctx* c);                          // lt_chain.cpp
+int warm_presentation(lt_ctx* c, bool strips);                // lt_present.cpp
 
 
 

@@ -51,7 +51,22 @@ void launch_split_bev(hipStream_t s, const uint8_t* bev, size_t bev_stride, int 
 void launch_undistorted_to_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, int nrows, int w, uint8_t* out,
                                int n);
 
+// one no-op launch per kernel translation unit: loads its code object (lt_create)
+void preload_k_frontend(hipStream_t s);
+void preload_k_filter(hipStream_t s);
+void preload_k_tophat(hipStream_t s);
+void preload_k_threshold(hipStream_t s);
+void preload_k_threshold_walk(hipStream_t s);
+void preload_k_adaptive_walk(hipStream_t s);
+void preload_k_search(hipStream_t s);
+void preload_k_overlay(hipStream_t s);
+
 // presentation stage (k_overlay.hip)
+// strip mode: only the camera rows [row0, row1) of every slot's annotated frame, packed, strip_stride bytes per slot; false: the
+// geometry does not allow the four-pixel kernel (nothing launched)
+bool launch_overlay_lane_strip(hipStream_t s, const uint8_t* frames, size_t frame_stride, uint8_t* strips, size_t strip_stride,
+                               const int16_t* oxy, const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_w,
+                               int row0, int row1, int bh, int bw, float alpha, int n);
 void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
                          const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w,
                          int bh, int bw, float alpha, int n, const int* rows4 = nullptr);

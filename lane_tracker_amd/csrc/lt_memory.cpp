@@ -8,6 +8,8 @@
 #include <chrono>
 #include <ctime>
 #include <pthread.h>
+#include <functional>
+#include <memory>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -239,32 +241,59 @@ int lt_host_free(void* p) {
 extern "C++" {
 namespace {
 struct HostCopier {
-    struct Job { uint8_t* dst; const uint8_t* src; size_t dpitch, spitch, width, height; int group; };
+    // a piece of work for a worker: a 2-D copy, or (fn) anything else that runs on the host alone.  `hold` is released when the
+    // last piece that carries it has run (a staging block going back to its pool).
+    struct Job { uint8_t* dst; const uint8_t* src; size_t dpitch, spitch, width, height; int group; std::function<void()> fn; std::shared_ptr<void> hold; };
+    struct Wait { hipEvent_t ev; int device; std::function<void()> then; };
     std::mutex m;
-    std::condition_variable work, done;
+    std::condition_variable work, done, wwork;
     std::deque<Job> q;
-    std::map<int, size_t> pending;   // group -> pieces queued or being copied (absent: none)
+    std::deque<Wait> wq;             // continuations behind device events, in submission order (the waiter thread)
+    std::map<int, size_t> pending;   // group -> pieces queued, being copied or reserved (absent: none)
     size_t pending_all = 0;
     int next_group = 1;
     std::map<int, bool> groups;      // live groups created by lt_host_copy_group_create
     bool stop = false;
     std::vector<std::thread> th;
+    std::thread waiter;
+    void finished(int group) {       // (under m)
+        --pending_all;
+        auto it = pending.find(group);
+        if (it != pending.end() && --it->second == 0) pending.erase(it);
+        done.notify_all();
+    }
     void run() {
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             work.wait(lk, [&] { return stop || !q.empty(); });
             if (q.empty()) return;               // stop
-            const Job j = q.front();
+            Job j = std::move(q.front());
             q.pop_front();
             lk.unlock();
-            if (j.dpitch == j.width && j.spitch == j.width) std::memcpy(j.dst, j.src, j.width * j.height);
+            if (j.fn) j.fn();
+            else if (j.dpitch == j.width && j.spitch == j.width) std::memcpy(j.dst, j.src, j.width * j.height);
             else
                 for (size_t r = 0; r < j.height; ++r) std::memcpy(j.dst + r * j.dpitch, j.src + r * j.spitch, j.width);
+            j.fn = nullptr;
+            j.hold.reset();                      // (outside the lock: the release may take a pool's lock)
             lk.lock();
-            --pending_all;
-            auto it = pending.find(j.group);
-            if (it != pending.end() && --it->second == 0) pending.erase(it);
-            done.notify_all();
+            finished(j.group);
+        }
+    }
+    void run_waiter() {
+        std::unique_lock<std::mutex> lk(m);
+        int on = -1;
+        for (;;) {
+            wwork.wait(lk, [&] { return stop || !wq.empty(); });
+            if (wq.empty()) return;
+            Wait w = std::move(wq.front());
+            wq.pop_front();
+            lk.unlock();
+            if (w.device != on) { (void)hipSetDevice(w.device); on = w.device; }
+            (void)hipEventSynchronize(w.ev);
+            w.then();                            // submits the host side of the copy (and gives up its reservation)
+            w.then = nullptr;
+            lk.lock();
         }
     }
     int threads() {              // LT_COPY_THREADS (1 .. 16), default 4
@@ -272,18 +301,22 @@ struct HostCopier {
         return n;
     }
     bool known(int group) { return group == 0 || groups.count(group) != 0; }      // (under m)
+    void start_workers(std::unique_lock<std::mutex>& lk, int want) {               // (under m)
+        done.wait(lk, [&] { return !stop; });          // an lt_shutdown() under way: workers start again once it is over
+        while ((int)th.size() < want) th.emplace_back([this] { run(); });
+    }
     int submit(const Job& whole) {
         // pieces of whole rows ("rows" of the 2-D copy: frames), a few per worker so that they finish together
         const size_t parts = whole.height <= 1 ? 1 : std::min<size_t>(whole.height, (size_t)threads() * 2);
         {
             std::unique_lock<std::mutex> lk(m);
             if (!known(whole.group)) return -1;
-            done.wait(lk, [&] { return !stop; });          // an lt_shutdown() under way: workers start again once it is over
-            while ((int)th.size() < (whole.height <= 1 ? 1 : threads())) th.emplace_back([this] { run(); });
+            start_workers(lk, whole.height <= 1 ? 1 : threads());
             for (size_t k = 0; k < parts; ++k) {
                 const size_t r0 = whole.height * k / parts, r1 = whole.height * (k + 1) / parts;
                 if (r1 > r0) {
-                    q.push_back({whole.dst + r0 * whole.dpitch, whole.src + r0 * whole.spitch, whole.dpitch, whole.spitch, whole.width, r1 - r0, whole.group});
+                    q.push_back({whole.dst + r0 * whole.dpitch, whole.src + r0 * whole.spitch, whole.dpitch, whole.spitch, whole.width, r1 - r0, whole.group,
+                                 nullptr, whole.hold});
                     ++pending[whole.group];
                     ++pending_all;
                 }
@@ -291,6 +324,38 @@ struct HostCopier {
         }
         work.notify_all();
         return 0;
+    }
+    int submit_fn(int group, std::function<void()> fn, bool many) {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            if (!known(group)) return -1;
+            start_workers(lk, many ? threads() : 1);
+            q.push_back({nullptr, nullptr, 0, 0, 0, 0, group, std::move(fn), nullptr});
+            ++pending[group];
+            ++pending_all;
+        }
+        work.notify_one();
+        return 0;
+    }
+    int reserve(int group) {         // a piece that will be submitted later (behind a device copy): the group is not complete without it
+        std::lock_guard<std::mutex> lk(m);
+        if (!known(group)) return -1;
+        ++pending[group];
+        ++pending_all;
+        return 0;
+    }
+    void unreserve(int group) {
+        std::lock_guard<std::mutex> lk(m);
+        finished(group);
+    }
+    void after_event(hipEvent_t ev, int device, std::function<void()> then) {
+        {
+            std::unique_lock<std::mutex> lk(m);
+            done.wait(lk, [&] { return !stop; });
+            if (!waiter.joinable()) waiter = std::thread([this] { run_waiter(); });
+            wq.push_back({ev, device, std::move(then)});
+        }
+        wwork.notify_one();
     }
     void wait_all() {
         std::unique_lock<std::mutex> lk(m);
@@ -302,23 +367,29 @@ struct HostCopier {
         done.wait(lk, [&] { return pending.find(group) == pending.end(); });
         return 0;
     }
-    void shutdown() {            // finish what is queued, then join the workers
+    void shutdown() {            // finish what is queued (continuations behind device events included), then join the threads
         std::vector<std::thread> mine;
+        std::thread w;
         {
             std::unique_lock<std::mutex> lk(m);
-            done.wait(lk, [&] { return pending_all == 0; });
+            done.wait(lk, [&] { return pending_all == 0 && wq.empty(); });
             stop = true;
             mine.swap(th);
+            w.swap(waiter);
         }
         work.notify_all();
+        wwork.notify_all();
         for (auto& t : mine) if (t.joinable()) t.join();
+        if (w.joinable()) w.join();
         { std::lock_guard<std::mutex> lk(m); stop = false; }
         done.notify_all();
     }
     ~HostCopier() {
-        { std::lock_guard<std::mutex> lk(m); stop = true; q.clear(); }
+        { std::lock_guard<std::mutex> lk(m); stop = true; q.clear(); wq.clear(); }
         work.notify_all();
+        wwork.notify_all();
         for (auto& t : th) if (t.joinable()) t.join();
+        if (waiter.joinable()) waiter.join();
     }
 };
 HostCopier* g_copier = nullptr;
@@ -336,8 +407,185 @@ HostCopier& host_copier() {
     });
     return *g_copier;
 }
+
+// Page-locked staging blocks, kept per size for the life of the process (lt_shutdown / lt_pinned_trim give them back): the
+// strips of annotated frames land in these and are scattered into the caller's (pageable) frames by the copy threads.  A block is a
+// few dozen MB -- page-locking costs ~0.2 ms per MB, so a window-sized page-locked output array (0.7 GB at 1280x720) was 0.13 s
+// of the first window of every stream, three times over (NOTES D.1).
+struct PinnedBlocks {
+    std::mutex m;
+    std::condition_variable freed;
+    std::map<size_t, std::vector<void*>> free_;
+    size_t allocated = 0;
+    size_t limit() {
+        static const size_t v = [] { const char* e = std::getenv("LT_STAGING_MB"); return (size_t)(e ? std::max(64, std::atoi(e)) : 1536) << 20; }();
+        return v;
+    }
+    void* acquire(size_t bytes) {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            auto& v = free_[bytes];
+            if (!v.empty()) { void* p = v.back(); v.pop_back(); return p; }
+            if (allocated + bytes <= limit() || allocated == 0) break;
+            // over the budget: blocks of other sizes that idle go first, then wait for one of ours
+            bool dropped = false;
+            for (auto& kv : free_)
+                if (kv.first != bytes && !kv.second.empty()) {
+                    void* p = kv.second.back();
+                    kv.second.pop_back();
+                    allocated -= kv.first;
+                    lk.unlock();
+                    (void)hipHostFree(p);
+                    lk.lock();
+                    dropped = true;
+                    break;
+                }
+            if (!dropped) freed.wait(lk);
+        }
+        allocated += bytes;
+        lk.unlock();
+        void* p = nullptr;
+        {
+            lt::TraceScope ts_("hipHostMalloc(staging)", bytes);
+            if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+        }
+        if (!p) { lk.lock(); allocated -= bytes; }
+        return p;
+    }
+    void release(void* p, size_t bytes) {
+        { std::lock_guard<std::mutex> lk(m); free_[bytes].push_back(p); }
+        freed.notify_all();
+    }
+    void trim() {
+        std::vector<void*> out;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            for (auto& kv : free_) { for (void* p : kv.second) { out.push_back(p); allocated -= kv.first; } kv.second.clear(); }
+        }
+        for (void* p : out) (void)hipHostFree(p);
+    }
+};
+PinnedBlocks& pinned_blocks() { static PinnedBlocks* b = new PinnedBlocks; return *b; }
+
+struct EventPool {
+    std::mutex m;
+    std::vector<hipEvent_t> free_;
+};
+EventPool& event_pool() { static EventPool* e = new EventPool; return *e; }
 }  // namespace
 }  // extern "C++"
+
+}  // extern "C"
+namespace lt {
+int host_submit_copy2d(int group, uint8_t* dst, size_t dpitch, const uint8_t* src, size_t spitch, size_t width, size_t height, std::shared_ptr<void> hold) {
+    return host_copier().submit({dst, src, dpitch, spitch, width, height, group, nullptr, std::move(hold)});
+}
+int host_submit_fn(int group, std::function<void()> fn, bool many) { return host_copier().submit_fn(group, std::move(fn), many); }
+int host_reserve(int group) { return host_copier().reserve(group); }
+void host_unreserve(int group) { host_copier().unreserve(group); }
+void host_after_event(hipEvent_t ev, int device, std::function<void()> then) { host_copier().after_event(ev, device, std::move(then)); }
+int host_copy_threads() { return host_copier().threads(); }
+void* pinned_block_acquire(size_t bytes) { return pinned_blocks().acquire(bytes); }
+void pinned_block_release(void* p, size_t bytes) { pinned_blocks().release(p, bytes); }
+hipEvent_t pooled_event() {
+    EventPool& ep = event_pool();
+    {
+        std::lock_guard<std::mutex> lk(ep.m);
+        if (!ep.free_.empty()) { hipEvent_t e = ep.free_.back(); ep.free_.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return e;
+}
+void pooled_event_release(hipEvent_t e) {
+    if (!e) return;
+    EventPool& ep = event_pool();
+    std::lock_guard<std::mutex> lk(ep.m);
+    ep.free_.push_back(e);
+}
+
+// k_overlay_text's arithmetic (csrc/k_overlay.hip) for one frame on the host: every character's cell up to its advance width,
+// white over the frame, out = v + ((255 - v) * alpha + 127) / 255 per channel
+void text_blend_frame(uint8_t* frame, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs,
+                      int gw, int gh, const char* lines, int n_lines, int line_len, int x0, int y0, int step) {
+    for (int l = 0; l < n_lines; ++l) {
+        const char* src = lines + (size_t)l * line_len;
+        int x = x0;
+        bool ended = false;
+        for (int k = 0; k < line_len; ++k) {
+            const unsigned char ch = (unsigned char)src[k];
+            ended = ended || ch == 0;
+            const int xk = std::min(x, 32767);                   // the left edge the device path stores as int16
+            const int g = (int)ch - first_char;
+            if (g < 0 || g >= n_glyphs) continue;
+            const int adv = advance[g];
+            if (!ended) x += adv;
+            const uint8_t* cell = atlas + (size_t)g * gh * gw;
+            for (int gy = 0; gy < gh; ++gy) {
+                const int y = y0 + l * step + gy;
+                if (y < 0 || y >= img_h) continue;
+                uint8_t* row = frame + (size_t)y * img_w * 3;
+                for (int gx = 0; gx < adv && gx < gw; ++gx) {
+                    const int alpha = cell[(size_t)gy * gw + gx];
+                    const int px = xk + gx;
+                    if (alpha == 0 || px < 0 || px >= img_w) continue;
+                    uint8_t* p = row + (size_t)px * 3;
+                    for (int c = 0; c < 3; ++c) {
+                        const int v = p[c];
+                        p[c] = (uint8_t)(v + ((255 - v) * alpha + 127) / 255);
+                    }
+                }
+            }
+        }
+    }
+}
+}  // namespace lt
+extern "C" {
+
+int lt_text_blend_host(uint8_t* frames, size_t frame_stride, int n, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance,
+                       int first_char, int n_glyphs, int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0,
+                       int y0, int step) {
+    if (n < 0 || img_h < 1 || img_w < 1 || n_glyphs < 1 || glyph_w < 1 || glyph_h < 1 || n_lines < 0 || line_len < 0 || first_char < 0)
+        return fail(LT_ERR_INVALID, "lt_text_blend_host: bad geometry");
+    if (n == 0 || n_lines == 0 || line_len == 0) return LT_OK;
+    if (!frames || !atlas || !advance || !lines) return fail(LT_ERR_INVALID, "lt_text_blend_host: null pointer");
+    if (frame_stride < (size_t)img_h * img_w * 3 && n > 1) return fail(LT_ERR_INVALID, "lt_text_blend_host: frame stride below the frame size");
+    for (int i = 0; i < n; ++i)
+        text_blend_frame(frames + (size_t)i * frame_stride, img_h, img_w, atlas, advance, first_char, n_glyphs, glyph_w, glyph_h,
+                         lines + (size_t)i * n_lines * line_len, n_lines, line_len, x0, y0, step);
+    return LT_OK;
+}
+
+int lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_stride, int n, int row0, int row1,
+                             int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
+                             int glyph_h, const char* lines, int n_lines, int line_len, int x0, int y0, int step) {
+    if (n < 0 || img_h < 1 || img_w < 1 || row0 < 0 || row1 < row0 || row1 > img_h || n_lines < 0 || line_len < 0)
+        return fail(LT_ERR_INVALID, "lt_host_text_async_group: bad geometry");
+    if (n == 0) return LT_OK;
+    if (!dst || (row1 > row0 && !src)) return fail(LT_ERR_INVALID, "lt_host_text_async_group: null frames");
+    const bool text = n_lines > 0 && line_len > 0;
+    if (text && (!atlas || !advance || !lines || n_glyphs < 1 || glyph_w < 1 || glyph_h < 1 || first_char < 0))
+        return fail(LT_ERR_INVALID, "lt_host_text_async_group: null or empty font / text");
+    // the caller's text need not outlive the call
+    auto keep = std::make_shared<std::vector<char>>(text ? lines : nullptr, text ? lines + (size_t)n * n_lines * line_len : nullptr);
+    const int parts = std::min(n, host_copy_threads() * 2);
+    const size_t row_bytes = (size_t)img_w * 3;
+    for (int k = 0; k < parts; ++k) {
+        const int f0 = (int)((long long)n * k / parts), f1 = (int)((long long)n * (k + 1) / parts);
+        if (f1 <= f0) continue;
+        auto fn = [=]() {
+            for (int f = f0; f < f1; ++f) {
+                uint8_t* d = dst + (size_t)f * dst_stride;
+                if (row1 > row0) std::memcpy(d + (size_t)row0 * row_bytes, src + (size_t)f * src_stride + (size_t)row0 * row_bytes, (size_t)(row1 - row0) * row_bytes);
+                if (text)
+                    text_blend_frame(d, img_h, img_w, atlas, advance, first_char, n_glyphs, glyph_w, glyph_h,
+                                     keep->data() + (size_t)f * n_lines * line_len, n_lines, line_len, x0, y0, step);
+            }
+        };
+        if (host_submit_fn(group, fn, true)) return fail(LT_ERR_INVALID, "lt_host_text_async_group: unknown group %d", group);
+    }
+    return LT_OK;
+}
 
 int lt_host_copy_group_create(int* group) {
     if (!group) return fail(LT_ERR_INVALID, "lt_host_copy_group_create: null output");
@@ -392,6 +640,7 @@ int lt_host_copy_wait(void) {
 
 int lt_shutdown(void) {
     if (g_copier) g_copier->shutdown();
+    pinned_blocks().trim();
     return LT_OK;
 }
 

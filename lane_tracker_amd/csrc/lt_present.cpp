@@ -154,6 +154,42 @@ static int present_stream(lt_ctx* c) {
     if (!c->present && create_compute_stream(&c->present, c->search_cus) != hipSuccess) return fail(LT_ERR_HIP, "hipStreamCreate failed");
     return LT_OK;
 }
+static int ensure_strips(lt_ctx* c);
+static int ensure_span_staging(lt_ctx* c) {
+    const int bh = c->calib.warp_h;
+    if (c->h_spans_cap >= c->capacity) return LT_OK;
+    int r = sync_all(c);
+    if (r) return r;
+    if (c->h_spans) (void)hipHostFree(c->h_spans);
+    c->h_spans = nullptr;
+    c->h_spans_cap = 0;
+    TraceScope ts_("overlay:hipHostMalloc(spans)", (size_t)c->capacity * bh * 2 * sizeof(int16_t));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
+    c->h_spans_cap = c->capacity;
+    return LT_OK;
+}
+}  // extern "C"
+namespace lt {
+// everything the presentation stage of a window allocates lazily, ahead of the window (lt_warm)
+int warm_presentation(lt_ctx* c, bool strips) {
+    if (!c->have_overlay) return LT_OK;
+    int rc = present_stream(c);
+    if (rc) return rc;
+    const int bh = c->calib.warp_h;
+    if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
+    if ((rc = ensure_span_staging(c))) return rc;
+    if (strips) {
+        if ((rc = ensure_strips(c))) return rc;
+    } else if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
+    if (!c->dl) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
+    }
+    return LT_OK;
+}
+}  // namespace lt
+extern "C" {
 
 int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const double* ploty, const double* ploty2, int n_rows,
                    int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx) {
@@ -185,8 +221,19 @@ int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const do
 
 // lt_overlay_run; rows4: two runs of camera rows {a0, a1, b0, b1} outside which the annotated frames are not needed
 // (lt_present_frame, lt_overlay_run_rows), nullptr = all of them
+// strip mode: the rows the lane can reach (lt_overlay_rows) of every slot, packed, into the context's strip buffer
+static int ensure_strips(lt_ctx* c) {
+    const size_t sb = (size_t)std::max(c->ov_r1 - c->ov_r0, 0) * c->calib.img_w * 3;
+    if (c->d_strip && c->strip_bytes == sb) return LT_OK;
+    int rc = sync_all(c);
+    if (rc) return rc;
+    dev_free(c->d_strip);
+    c->strip_bytes = sb;
+    return dev_alloc(&c->d_strip, (size_t)c->capacity * std::max<size_t>(sb, 4));
+}
+
 static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
-                            const int32_t* right_yx, double alpha, const int* rows4) {
+                            const int32_t* right_yx, double alpha, const int* rows4, bool strip = false) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_run before lt_overlay_configure");
@@ -202,23 +249,17 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
     if ((rc = set_device(c))) return rc;
     const int bh = c->calib.warp_h;
     if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
-    if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
+    if (strip) {
+        if ((rc = ensure_strips(c))) return rc;
+    } else if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
     // One frame (process()): the intervals travel as a kernel argument -- no staging buffer, no copy launch, no events
     static const bool arg_ok = [] { const char* e = std::getenv("LT_SPANS_ARG"); return !(e && e[0] == '0'); }();
-    bool one = arg_ok && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
+    bool one = arg_ok && !strip && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
     int16_t one_spans[2 * LT_SPAN_ARG_ROWS];
     auto claim_staging = [&]() -> int {
         int r = staging_claim(c->spans_busy, first, n);
         if (r) return r;
-        if (c->h_spans_cap < c->capacity) {
-            if ((r = sync_all(c))) return r;
-            if (c->h_spans) (void)hipHostFree(c->h_spans);
-            c->h_spans = nullptr;
-            c->h_spans_cap = 0;
-            TraceScope ts_("overlay:hipHostMalloc(spans)", (size_t)c->capacity * bh * 2 * sizeof(int16_t));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_spans), (size_t)c->capacity * bh * 2 * sizeof(int16_t), hipHostMallocDefault));
-            c->h_spans_cap = c->capacity;
-        }
+        if ((r = ensure_span_staging(c))) return r;
         return (int)LT_OK;
     };
     if (!one && (rc = claim_staging())) return rc;
@@ -285,6 +326,12 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
     }
     launch_copy_from_pinned(ps, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
     const auto t2 = std::chrono::steady_clock::now();
+    if (strip) {
+        if (!launch_overlay_lane_strip(ps, c->d_frames + (size_t)first * c->frame_bytes, c->frame_bytes, c->d_strip + (size_t)first * c->strip_bytes,
+                                       c->strip_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh, c->calib.img_w,
+                                       c->ov_r0, c->ov_r1, bh, c->calib.warp_w, (float)alpha, n))
+            return fail(LT_ERR_STATE, "strip overlay needs a frame width that is a multiple of 4");
+    } else
     launch_overlay_lane(ps, c->d_frames + (size_t)first * c->frame_bytes, c->d_annot + (size_t)first * c->frame_bytes,
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n, rows4);
@@ -319,6 +366,67 @@ int lt_overlay_run_rows(lt_ctx* c, int first, int n, const int32_t* left_n, cons
     const int rc = ordered_rows(c, rows4, r);
     if (rc) return rc;
     return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, r);
+}
+
+int lt_overlay_run_strip(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
+                         const int32_t* right_yx, double alpha) {
+    return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr, true);
+}
+
+// The strips of slots [first, first + n) on their way into the caller's frames: one contiguous copy per block of STRIP_BLOCK slots
+// into page-locked staging (the copy engine at its full rate: 56 GB/s against the 37 GB/s of the kernel that stored row runs into a
+// page-locked frame array, and no CUs taken from the mask chain), then -- on the library's copy threads, once the copy's event has
+// fired -- from staging into rows [ov_r0, ov_r1) of out + i * out_frame_stride.  `out` is ordinary memory.  Complete when
+// lt_host_copy_wait_group(group) returns.
+int lt_strip_download_async(lt_ctx* c, int first, int n, uint8_t* out, size_t out_frame_stride, int group) {
+    int rc = check_slots(c, first, n);
+    if (rc) return rc;
+    if (!out) return fail(LT_ERR_INVALID, "null output frames");
+    if (!c->d_strip || !c->present) return fail(LT_ERR_STATE, "lt_strip_download_async before lt_overlay_run_strip");
+    if (out_frame_stride < c->frame_bytes) return fail(LT_ERR_INVALID, "frame stride below the frame size");
+    if (n == 0 || c->strip_bytes == 0) return LT_OK;
+    if ((rc = set_device(c))) return rc;
+    if (!c->dl) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
+    }
+    hipEvent_t e = next_order_event(c);
+    if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
+    HIP_TRY(hipEventRecord(e, c->present));
+    HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
+    constexpr int STRIP_BLOCK = 32;
+    const size_t sb = c->strip_bytes, block_bytes = (size_t)STRIP_BLOCK * sb;
+    const size_t row_off = (size_t)c->ov_r0 * c->calib.img_w * 3;
+    for (int at = 0; at < n; at += STRIP_BLOCK) {
+        const int m = std::min(STRIP_BLOCK, n - at);
+        if (host_reserve(group)) return fail(LT_ERR_INVALID, "lt_strip_download_async: unknown group %d", group);
+        uint8_t* block = static_cast<uint8_t*>(pinned_block_acquire(block_bytes));
+        hipEvent_t done = block ? pooled_event() : nullptr;
+        if (!block || !done) {
+            if (block) pinned_block_release(block, block_bytes);
+            host_unreserve(group);
+            return fail(LT_ERR_NOMEM, "no page-locked staging block for the strips");
+        }
+        hipError_t he = hipMemcpyAsync(block, c->d_strip + (size_t)(first + at) * sb, (size_t)m * sb, hipMemcpyDeviceToHost, c->dl);
+        if (he == hipSuccess) he = hipEventRecord(done, c->dl);
+        if (he != hipSuccess) {
+            pinned_block_release(block, block_bytes);
+            pooled_event_release(done);
+            host_unreserve(group);
+            return fail(LT_ERR_HIP, "strip download failed: %s", hipGetErrorString(he));
+        }
+        uint8_t* dst = out + (size_t)at * out_frame_stride + row_off;
+        host_after_event(done, c->device, [=]() {
+            std::shared_ptr<void> hold(block, [=](void* p) { pinned_block_release(p, block_bytes); });
+            (void)host_submit_copy2d(group, dst, out_frame_stride, block, sb, sb, (size_t)m, hold);
+            pooled_event_release(done);
+            host_unreserve(group);           // the scatter pieces are queued: the group now waits for those
+        });
+    }
+    if (c->annot_busy.hi <= c->annot_busy.lo) { c->annot_busy.lo = first; c->annot_busy.hi = first + n; }
+    else { c->annot_busy.lo = std::min(c->annot_busy.lo, first); c->annot_busy.hi = std::max(c->annot_busy.hi, first + n); }
+    return staging_mark(c->annot_busy, c->dl);
 }
 
 int lt_overlay_rows(lt_ctx* c, int* row0, int* row1) {

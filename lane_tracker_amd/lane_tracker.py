@@ -475,7 +475,9 @@ class LaneTracker:
 
     def _present_rows(self):
         """The two runs of camera rows an annotated frame can differ from its camera frame in -- the text lines and the rows the
-        lane can reach (lt_overlay_rows) -- as four int32 {a0, a1, b0, b1}, or None when they cover (nearly) the whole frame."""
+        lane can reach (lt_overlay_rows) -- as four int32 {a0, a1, b0, b1}, or None when they cover (nearly) the whole frame.
+        -> (array, its address, [a0, a1, b0, b1], lane rows behind text rows?, host-text: None or (lane-only runs {0, 0, l0, l1}:
+        array, address; (l0, l1); (t0, t1); do rows of the lane run lie outside the rows the mask chain uploads?))."""
         if "_rows4" not in self.__dict__:
             self._configure_overlay()
             H = self.img_size[1]
@@ -492,29 +494,52 @@ class LaneTracker:
                 runs, ahead = [(min(text[0], lane[0]), max(text[1], lane[1])), (H, H)], False
             rows = np.array([runs[0][0], runs[0][1], runs[1][0], runs[1][1]], np.int32)
             covered = (rows[1] - rows[0]) + (rows[3] - rows[2])
-            self._rows4 = (rows, rows.ctypes.data, [int(v) for v in rows], ahead) if covered <= 0.8 * H else None
+            host = None
+            disjoint = text[1] <= lane[0] or lane[1] <= text[0]
+            if self.host_text and disjoint and lane[1] > lane[0] and self.img_size[0] % 4 == 0:
+                # the text lines can be drawn on the host (lt_text_blend_host): of an annotated frame only the lane's run of rows is
+                # the device's business
+                lr = np.array([0, 0, lane[0], lane[1]], np.int32)
+                src = self._ctx.source_rows()
+                host = (lr, lr.ctypes.data, (int(lane[0]), int(lane[1])), (int(text[0]), int(text[1])),
+                        not (src[0] <= lane[0] and lane[1] <= src[1]))
+            self._rows4 = (rows, rows.ctypes.data, [int(v) for v in rows], ahead, host) if covered <= 0.8 * H else None
         return self._rows4
+
+    host_text = os.environ.get("LT_HOST_TEXT", "1") != "0"   # False: the text lines are drawn by the device (lt_overlay_text), as in round 4 (A/B, tests)
 
     _TEXT_ORIGIN, _TEXT_STEP = (20, 8), 35          # Context.present_frame / overlay_text defaults
 
     def _prepare_out(self):
         """While the device is busy with the frame (another 0.1 ms until its record is there): fetch the page-locked array the
         annotated frame will land in and copy the rows no overlay can touch from the camera frame the caller handed in -- they
-        are the same bytes, and what the host copies now does not cross the bus later."""
+        are the same bytes, and what the host copies now does not cross the bus later.  With the text drawn on the host
+        (`_present_rows()[4]`) that is every row but the lane's run: the text is blended over the copied rows once it is known."""
         H, W = self.img_size[1], self.img_size[0]
         out = self._out = _native.pinned_empty((1, H, W, 3))
         self._out_rows = None
+        self._out_host_text = False
         img = self._resident[0] if self._resident is not None else None
         rows = self._rows_for(img)
         if rows is None:
             return
-        a0, a1, b0, b1 = rows[2]
         lib, dst, src, rb, grp = self._ctx.lib, out.ctypes.data, img.ctypes.data, W * 3, self._copy_group()
-        for lo, hi in ((0, a0), (a1, b0), (b1, H)):
+        if rows[4] is not None:
+            l0, l1 = rows[4][2]
+            gaps = ((0, l0), (l1, H))
+        else:
+            a0, a1, b0, b1 = rows[2]
+            gaps = ((0, a0), (a1, b0), (b1, H))
+        for lo, hi in gaps:
             if hi > lo and lib.lt_host_copy_async_group(grp, dst + lo * rb, src + lo * rb, (hi - lo) * rb):
                 raise _native.NativeError("lt_host_copy_async_group failed")
         self._copying = True             # until the group's wait: `out` and `img` must stay as they are
-        self._out_rows, self._out_ahead = rows[1], rows[3]
+        if rows[4] is not None:
+            self._out_rows, self._out_ahead, self._out_host_text = rows[4][1], True, True
+        else:
+            self._out_rows, self._out_ahead = rows[1], rows[3]
+
+    _out_host_text = False      # the text lines of _out are drawn on the host (its row runs are then the lane's run alone)
 
     def _rows_for(self, img):
         """_present_rows() when `img` is a frame whose rows the host can copy as they are, else None."""
@@ -568,8 +593,9 @@ class LaneTracker:
         """Polygon (packed, by address) and text lines onto the frame in `slot` -> the annotated frame.  drawn: _lane_ahead has
         drawn this polygon and sent its rows already; the text lines are what is left."""
         out, rows, self._out, self._out_rows, self._lane_in_flight = self._out, self._out_rows, None, None, None
+        host_text, self._out_host_text = self._out_host_text, False
         if out is None:
-            out, rows = _native.pinned_empty((1, self.img_size[1], self.img_size[0], 3)), None
+            out, rows, host_text = _native.pinned_empty((1, self.img_size[1], self.img_size[0], 3)), None, False
         if len(lines) > 3:
             raise ValueError("at most three text lines")
         if rows is None and self._resident_partial and self._resident is not None:
@@ -578,6 +604,17 @@ class LaneTracker:
             self._resident_partial = False
         text = b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) \
             if self._have_font and lines else None
+        if host_text and rows is not None:
+            # the device's part is the lane's run of rows (drawn and on its way already, or now); the text goes over the rows
+            # the copy thread has brought from the caller's frame, on this thread, while the lane's rows land
+            try:
+                if not drawn:
+                    self._ctx.present_lane_async(slot, left_n, right_n, left_yx, right_yx, out, rows)
+            finally:
+                self._copies_done()
+            if text is not None:
+                _native.text_blend(out, _overlay.font_atlas(), text, len(lines), line_len, self._TEXT_ORIGIN, self._TEXT_STEP)
+            return self._ctx.present_finish(slot, None, 0, line_len, out, rows, origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
         try:
             if drawn and out is not None and rows is not None:
                 return self._ctx.present_finish(slot, text, len(lines), line_len, out, rows, origin=self._TEXT_ORIGIN,
@@ -653,7 +690,11 @@ class LaneTracker:
         if not reuse_frame:
             # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
             rows = self._rows_for(img) if self._want_out else None
-            self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
+            if rows is not None and rows[4] is not None:
+                if rows[4][4]:           # (rows of the lane's run the mask chain does not read: none with the reference calibration)
+                    self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=rows[4][1])
+            else:
+                self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
             self._resident_partial = rows is not None
         if self.last_detection > self.n_reset:                       # :851
             if diagnostics:
@@ -1057,6 +1098,9 @@ class LaneTracker:
                                          # under the copy of the piece before
 
         rest_rows = self._window_rows[1] if self._window_rows is not None else None   # annotated frames travel as row runs
+        rest_needed = annotate
+        if self._window_rows is not None and self._window_rows[4] is not None:         # ... as strips: the lane's run of rows alone,
+            rest_rows, rest_needed = self._window_rows[4][1], annotate and self._window_rows[4][4]   # which the mask chain has uploaded
 
         def feed(upto):                  # keep the device supplied with masks ahead of the searches
             nonlocal masked
@@ -1065,7 +1109,7 @@ class LaneTracker:
                     m = min(span(masked), n - masked)
                     ctx.upload_frame_rows_async(frames[masked:masked + m], first=base + masked)
                     ctx.mask_run(m, fp, first=base + masked)
-                    if annotate:         # the rest of these frames, for the overlay: behind their rows on the copy stream
+                    if rest_needed:      # the rest of these frames, for the overlay: behind their rows on the copy stream
                         ctx.upload_frame_rest(frames[masked:masked + m], first=base + masked, rows=rest_rows)
                 else:
                     q = masked - n
@@ -1076,7 +1120,7 @@ class LaneTracker:
                     m = min(chunk, len(a[0]) - q)
                     ctx.upload_frame_rows_async(a[0][q:q + m], first=a[1] + q)
                     ctx.mask_run(m, fp, first=a[1] + q)
-                    if annotate:
+                    if rest_needed:
                         ctx.upload_frame_rest(a[0][q:q + m], first=a[1] + q, rows=rest_rows)
                     a[2] = q + m
                 masked += m
@@ -1265,6 +1309,34 @@ class LaneTracker:
                                    k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"])
         return k, first_try, fp
 
+    def warm(self, window=256, annotate=True, **kwargs):
+        """Set up, ahead of the first window, what `process_stream` / `process_batch` over windows of up to `window` frames would
+        otherwise set up on the way (`kwargs`: process()'s keywords, as for those calls): the slot regions of a stream
+        (`stream_lookahead` + 1 windows, one more with annotation) sized once, the search and chain buffers for both parameter
+        sets, the presentation stage's buffers, the glyph atlas.  Optional -- a stream that was not warmed does the same work
+        inside its first window (20-35 ms) -- and repeatable (a no-op the second time).  Returns the seconds it took."""
+        import time
+        t0 = time.perf_counter()
+        k, first_try, fp = self._batch_arguments(kwargs)
+        ctx = self._ctx
+        if annotate:
+            self._configure_overlay()
+        look = max(1, int(self.stream_lookahead))
+        regions = look + (2 if annotate else 1)
+        size = (max(int(window), 1) + 1) & ~1
+        if regions * size > ctx.capacity:
+            self._materialise_pending()      # growing the context drops what is still on the device
+            ctx.reserve(regions * size)
+        mode = 0
+        if annotate:
+            rows = self._present_rows() if self.host_copies_rows else None
+            mode = 2 if (rows is not None and rows[4] is not None) else 1
+        for q in (first_try, self._SECOND_TRY):
+            ctx.warm(_native.search_params(window_width=q[9], window_height=q[10], search_range=q[11], mu=q[12], no_success_limit=q[13],
+                                           start_slice=q[14], ignore_sides=q[15], ignore_bottom=q[16], partial=q[18]),
+                     _native.search_params(bandwidth=q[17], ignore_bottom=q[16], partial=q[18]), mode)
+        return time.perf_counter() - t0
+
     @staticmethod
     def _as_window(frames):
         frames = np.ascontiguousarray(frames, np.uint8)
@@ -1276,23 +1348,57 @@ class LaneTracker:
 
     def _window_renderer(self, deferred, base, n, piece=32, frames=None):
         """(flush, out) for a window of n frames in slots base..: `flush(force)` renders the frames committed to `deferred`
-        since the last call -- overlay and text kernels, then the copy into the page-locked `out`, all only enqueued -- once
-        at least `piece` of them have gathered (or `force`); `out` is complete after the next sync (and, with row runs,
-        _copies_done()).  With row runs (`_window_rows`) the rows of `out` that no overlay can touch are copied from `frames`,
-        the window as the caller handed it in, by the library's copy threads, starting now."""
+        since the last call -- overlay kernels, then the copy towards `out`, all only enqueued -- once at least `piece` of them
+        have gathered (or `force`); `out` is complete after `_copies_done(flush.group)` (strips) / the next sync and
+        `_copies_done()` (row runs, whole frames).
+        Strips (`_window_rows[4]`, the default): `out` is ordinary memory.  Of every frame only the lane's run of rows is drawn on the
+        device (lt_overlay_run_strip) and comes back, packed, through the library's page-locked staging blocks
+        (lt_strip_download_async); the rows above and below it are copied from `frames`, the window as the caller handed it in,
+        by the library's copy threads, which also draw the text lines (lt_host_text_async_group).  One completion group per window.
+        Row runs (`_window_rows` without strips: LT_HOST_TEXT=0) and whole frames (LT_HOST_ROWS=0): round 4's ways, `out` page-locked."""
         self._configure_overlay()
         ctx = self._ctx
-        out = _native.pinned_empty((n, ctx.img_h, ctx.img_w, 3))
         empty = np.zeros(0, np.int64)
         done = [0]
-        rows = self._window_rows[1] if (self._window_rows is not None and frames is not None and n) else None
+        wr = self._window_rows if (frames is not None and n) else None
+        H, rb, fb = ctx.img_h, ctx.img_w * 3, ctx.img_h * ctx.img_w * 3
+        if wr is not None and wr[4] is not None:
+            out = np.empty((n, ctx.img_h, ctx.img_w, 3), np.uint8)
+            (l0, l1), (t0, t1) = wr[4][2], wr[4][3]
+            font = _overlay.font_atlas() if self._have_font else None
+            if font is None:
+                t0 = t1 = 0
+            group = _native.host_copy_group()
+            self._window_groups = list(self._window_groups) + [(group, (out, frames))]
+            lib, dst, src = ctx.lib, out.ctypes.data, frames.ctypes.data
+            cuts = sorted([(t0, t1), (l0, l1)])
+            at = 0
+            for lo, hi in cuts + [(H, H)]:                # the rows neither the text nor the lane can touch: from now on
+                if lo > at and lib.lt_host_copy2d_async_group(group, dst + at * rb, fb, src + at * rb, fb, (lo - at) * rb, n):
+                    raise _native.NativeError("lt_host_copy2d_async_group failed")
+                at = max(at, hi)
+
+            def flush(force):
+                lo, hi = done[0], len(deferred)
+                if hi <= lo or (hi - lo < piece and not force):
+                    return
+                part = deferred[lo:hi]
+                ctx.overlay_run_strip_packed(*_pack_deferred(part), first=base + lo)
+                ctx.strip_download_async(out[lo:hi], base + lo, group)
+                text, nl = _native.text_bytes([d[2] for d in part]) if font is not None else (None, 0)
+                if t1 > t0:
+                    _native.host_text_async(group, out[lo:hi], frames[lo:hi], (t0, t1), font, text, nl, 40, self._TEXT_ORIGIN, self._TEXT_STEP)
+                done[0] = hi
+            flush.group = group
+            return flush, out
+        out = _native.pinned_empty((n, ctx.img_h, ctx.img_w, 3))
+        rows = wr[1] if wr is not None else None
         group = None
         if rows is not None:
             # the rows no overlay can touch: from the caller's window into `out` on the library's copy threads, from now on.  In a
             # stream every window has a completion group of its own (the window before is handed out after waiting for ITS
             # copies only); a stand-alone window uses the tracker's.
-            a0, a1, b0, b1 = self._window_rows[2]
-            H, rb, fb = ctx.img_h, ctx.img_w * 3, ctx.img_h * ctx.img_w * 3
+            a0, a1, b0, b1 = wr[2]
             lib, dst, src = ctx.lib, out.ctypes.data, frames.ctypes.data
             if self._in_stream:
                 group = _native.host_copy_group()
@@ -1364,11 +1470,11 @@ class LaneTracker:
                 self._materialise_pending()  # the attributes describe the last frame, as after process() (also waits for `out`)
                 if out is not None:
                     ctx.sync()
-                    self._copies_done()
+                    self._copies_done(flush.group)
                     return list(out)
                 return [None] * n
             finally:
-                self._copies_done()
+                self._all_copies_done()
                 self._window_rows = None
         else:
             ctx.upload_frame_rows(frames)        # the camera rows the path reads; the rest only if frames are annotated
@@ -1415,8 +1521,9 @@ class LaneTracker:
             nonlocal landing
             arrays, region, group = landing
             landing = None
-            ctx.download_overlay_wait()  # these frames have landed; the uploads, masks and searches of the next windows run on
-            self._copies_done(group)     # ... and so have the rows the host copies itself (this window's group only)
+            if not (self._window_rows is not None and self._window_rows[4] is not None):
+                ctx.download_overlay_wait()  # these frames have landed; the uploads, masks and searches of the next windows run on
+            self._copies_done(group)     # ... and so have the rows the host copies itself and -- strips -- the rows from the device (this window's group only)
             free.append(region)
             return list(arrays)
         self._in_stream = True
@@ -1436,6 +1543,7 @@ class LaneTracker:
                         self._materialise_pending()  # growing the context drops what is still on the device
                         size = (n + 1) & ~1
                         ctx.reserve(regions * size)
+                        self.warm(n, annotate, **kwargs)     # (a no-op when the caller has warmed the tracker for this window size)
                     free = [r * size for r in range(regions)]
                     for q in queue:                  # nothing can have been fed ahead of an unplaced window
                         q[1], q[2] = None, 0

@@ -49,6 +49,9 @@ class FakeContext:
     def set_search_cus(self, n):
         pass
 
+    def warm(self, sws=None, band=None, annotate=0):
+        pass
+
     def urgent(self):
         import contextlib
         return contextlib.nullcontext(self)

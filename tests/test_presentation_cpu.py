@@ -155,3 +155,65 @@ def test_triple_split_view_golden():
     # a one-channel third image (no pixels detected -> the bare mask) fills all three channels
     out2 = LaneTracker.triple_split_view(None, [imgs[0], imgs[1], imgs[2][:, :, 0]])
     assert np.array_equal(out2[72:, 64:, 0], out2[72:, 64:, 2])
+
+
+def _atlas_blend(frame, font, lines, origin=(20, 8), step=35):
+    """k_overlay_text / lt_text_blend_host in NumPy: every glyph cell up to its advance, white over the frame."""
+    atlas, adv, first_char = font
+    want = frame.astype(np.int32)
+    for j, line in enumerate(lines):
+        x = origin[0]
+        for ch in line:
+            g = ord(ch) - first_char
+            cell = atlas[g][:, :adv[g]].astype(np.int32)
+            y = origin[1] + step * j
+            reg = want[y:y + cell.shape[0], x:x + cell.shape[1]]
+            reg += ((255 - reg) * cell[:reg.shape[0], :reg.shape[1], None] + 127) // 255
+            x += int(adv[g])
+    return want.astype(np.uint8)
+
+
+def test_text_on_the_host_equals_the_atlas_blend():
+    """lt_text_blend_host (the calling thread) and lt_host_text_async_group (the copy threads: rows copied from the source frames,
+    then the lines) against the NumPy statement the GPU text kernel is tested with -- no GPU needed."""
+    import pytest
+    from lane_tracker_amd import _native, overlay
+    font = overlay.font_atlas()
+    if font is None:
+        pytest.skip("Pillow is not installed: no glyph atlas")
+    rng = np.random.default_rng(11)
+    n, H, W = 5, 144, 420
+    src = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    src[1] = 0
+    texts = [["Curve Radius: %d m" % (1000 + 7 * i), "Eccentricity: %.2f m" % (-0.3 + 0.1 * i), "Frame: %d" % i][:1 + i % 3] for i in range(n)]
+    texts[3] = ["Lane Line Detection Failed", "Frame: 3"]
+    buf, nl = _native.text_bytes(texts)
+    assert nl == 3 and len(buf) == n * 3 * 40
+    # in place, on the calling thread
+    got = src.copy()
+    _native.text_blend(got, font, buf, nl)
+    for i in range(n):
+        assert np.array_equal(got[i], _atlas_blend(src[i], font, texts[i])), i
+    assert (got[1] == 255).any()
+    # on the copy threads: rows [t0, t1) from the source frames, then the text; the other rows of dst are left alone
+    gh = font[0].shape[1]
+    t0, t1 = 8, min(8 + 2 * 35 + gh, H)
+    dst = np.full_like(src, 77)
+    g = _native.host_copy_group()
+    _native.host_text_async(g, dst, src, (t0, t1), font, buf, nl)
+    assert _native.load().lt_host_copy_wait_group(g) == 0
+    for i in range(n):
+        want = _atlas_blend(src[i], font, texts[i])
+        assert np.array_equal(dst[i, t0:t1], want[t0:t1]), i
+        assert (dst[i, :t0] == 77).all() and (dst[i, t1:] == 77).all()
+    # rows only (no font): a plain copy of the run
+    dst2 = np.zeros_like(src)
+    _native.host_text_async(g, dst2, src, (10, 20), None, None, 0)
+    assert _native.load().lt_host_copy_wait_group(g) == 0
+    assert np.array_equal(dst2[:, 10:20], src[:, 10:20]) and not dst2[:, :10].any() and not dst2[:, 20:].any()
+    # text that runs off the right edge and a line origin near the bottom are clipped, not wrapped
+    small = np.zeros((1, 40, 64, 3), np.uint8)
+    b2, n2 = _native.text_bytes([["WWWWWWWWWWWWWWWW"]])
+    _native.text_blend(small, font, b2, n2, origin=(20, 30))
+    assert small.any()
+    _native.host_copy_group_release(g)
