@@ -253,6 +253,61 @@ class _PinnedPool:
 _pinned = _PinnedPool()
 
 
+class _FramePool:
+    """Ordinary (pageable) host blocks behind the NumPy arrays a window of annotated frames is handed out in.  A fresh
+    anonymous mapping costs a page fault -- and a cleared page -- per 4 KB (2 MB with transparent huge pages) at first touch:
+    0.7 GB per window of 256 1280x720 frames, 40-50 ms spread over the copy threads, as much as the rest of the window
+    takes.  So the blocks are kept: an array handed out keeps its block until the array and every view of it are gone, then the
+    block waits here for the next window of that size.  At most `keep` blocks per size and `limit` bytes idle are kept."""
+
+    def __init__(self, limit=6 << 30, keep_per_size=6):
+        self.limit, self.keep = limit, keep_per_size
+        self.free, self.idle_bytes = {}, 0
+
+    def empty(self, shape, dtype=np.uint8):
+        import mmap
+        nbytes = math.prod(shape) * np.dtype(dtype).itemsize
+        if nbytes < (1 << 20):
+            return np.empty(shape, dtype)
+        blocks = self.free.get(nbytes)
+        if blocks:
+            mm = blocks.pop()
+            self.idle_bytes -= nbytes
+        else:
+            try:
+                mm = mmap.mmap(-1, nbytes)
+                if hasattr(mmap, "MADV_HUGEPAGE"):
+                    try:
+                        mm.madvise(mmap.MADV_HUGEPAGE)
+                    except OSError:
+                        pass
+            except (OSError, ValueError):
+                return np.empty(shape, dtype)
+        buf = (C.c_uint8 * nbytes).from_buffer(mm)
+        fin = weakref.finalize(buf, self._release, nbytes, mm)
+        fin.atexit = False
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+    def _release(self, nbytes, mm):
+        blocks = self.free.setdefault(nbytes, [])
+        if len(blocks) < self.keep and self.idle_bytes + nbytes <= self.limit:
+            blocks.append(mm)
+            self.idle_bytes += nbytes
+        # else: the mapping goes with its last reference
+
+    def trim(self):
+        self.free, self.idle_bytes = {}, 0
+
+
+_frames = _FramePool()
+
+
+def frames_empty(shape, dtype=np.uint8):
+    """An uninitialised array in ordinary host memory out of a pool of kept blocks (no first-touch page faults after the first
+    windows of a stream): what process_batch / process_stream return their annotated frames in."""
+    return _frames.empty(shape, dtype)
+
+
 def device_cache_trim(keep_bytes=0):
     """Hand the device memory closed contexts left in the library's cache back to the driver (all of it beyond keep_bytes)."""
     _check(load().lt_device_cache_trim(int(keep_bytes)))

@@ -175,6 +175,7 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_spans);
     dev_free(c->d_annot);
     dev_free(c->d_strip);
+    dev_free(c->d_side_scratch);
     c->maxbands = 0;
     c->capacity = 0;
     c->maxpix = 0;
@@ -267,9 +268,10 @@ bool masks_have_bits(const lt_ctx* c, int first, int n) {
 int ensure_u8_masks(lt_ctx* c, int first, int n) {
     bool any = false;
     for (int i = first; i < first + n; ++i) any = any || !c->mask_u8_ok[(size_t)i];
-    if (!any) return LT_OK;
-    int rc = sync_all(c);
+    int rc = ensure_plane(c, P_MASK);
     if (rc) return rc;
+    if (!any) return LT_OK;
+    if ((rc = sync_all(c))) return rc;
     for (int i = first; i < first + n;) {
         if (c->mask_u8_ok[(size_t)i]) { ++i; continue; }
         int j = i;
@@ -307,6 +309,21 @@ int validate_filter(const lt_filter_params* p) {
     return LT_OK;
 }
 
+// Planes only some paths use are allocated when one of those paths runs first (the whole capacity at once): the u8 mask
+// (d_plane[P_MASK]: lt_upload_masks, lt_download_masks, searches outside the bit-plane kernels' limits), the expanded merged
+// plane (lt_download_plane), the scratch planes of the older threshold kernels (P_T1 .. P_T3).  A 768-slot context is 10.4 GB
+// instead of 14.6 -- and device memory that has been used before costs ~16 ms per GB to allocate (the driver clears it: NOTES D.2).
+int ensure_plane(lt_ctx* c, int idx) {
+    if (c->d_plane[idx]) return LT_OK;
+    int rc = dev_alloc(&c->d_plane[idx], (size_t)c->capacity * c->plane_bytes);
+    if (rc) return rc;
+    if (idx == P_MASK) {             // slots nobody has written a mask to read as zeros
+        HIP_TRY(hipMemsetAsync(c->d_plane[idx], 0, (size_t)c->capacity * c->plane_bytes, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return LT_OK;
+}
+
 // filter_lane_points() on planes P_R / P_B of the given slots (lane_tracker.py:210-238)
 int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter_params* p, int h, int w, int call_frames,
                      bool u8_mask = false) {
@@ -316,11 +333,14 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     uint8_t* thR = c->d_plane[P_THR] + off;
     uint8_t* thB = c->d_plane[P_THB] + off;
     uint8_t* t0 = c->d_plane[P_T0] + off;
-    uint8_t* t1 = c->d_plane[P_T1] + off;
-    uint8_t* t2 = c->d_plane[P_T2] + off;
-    uint8_t* t3 = c->d_plane[P_T3] + off;
-    uint8_t* merged = c->d_plane[P_MERGED] + off;
-    uint8_t* mask = c->d_plane[P_MASK] + off;
+    uint8_t *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;      // allocated by the paths that use them (ensure_plane)
+    auto scratch = [&](int idx, uint8_t*& q) -> int {
+        const int rc = ensure_plane(c, idx);
+        if (!rc) q = c->d_plane[idx] + off;
+        return rc;
+    };
+    uint8_t* mask = nullptr;
+    if (u8_mask) { const int rc = scratch(P_MASK, mask); if (rc) return rc; }
     // the walking threshold kernels read the top-hat planes with a padded row pitch: the dilate launches write them so
     // (the greenery mask, mask_noise, rides along: a third walk with window 65 over the raw Lab-b plane)
     const bool walk = p->filter_type == 0 && !c->brute_tophat && c->d_th_pad[0] && c->d_bits_tmp && c->d_bits_tmp2 &&
@@ -362,10 +382,13 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             // One or two frames cannot fill the chip (a few hundred waves per top-hat kernel), so the two planes'
             // top-hats, which do not depend on each other, run side by side: the R plane on the side stream, the
             // Lab-b plane here; saves the shorter pair's ~40 us of a 160 us chain.  t3 is free until the merge.
+            // (the eroded R plane of these one or two frames: a scratch of its own, two planes per context)
+            if (!c->d_side_scratch) { const int rc = dev_alloc(&c->d_side_scratch, 2 * ps); if (rc) return rc; }
+            uint8_t* ts = c->d_side_scratch;
             HIP_TRY(hipEventRecord(c->ev_fork, s));
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-            launch_morph_runs(c->side, R, t3, nullptr, h, w, 29, false, ps, n);
-            launch_morph_runs(c->side, t3, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes);
+            launch_morph_runs(c->side, R, ts, nullptr, h, w, 29, false, ps, n);
+            launch_morph_runs(c->side, ts, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes);
             // ... and so does the R plane's threshold: its 29x29 top-hat is done while the 55x55 pair still has half its way
             // to go, and the threshold kernel takes its planes one after the other anyway -- here one per launch, the R
             // verdicts as a partial bit plane the open ORs in (12 us less on the one-frame chain)
@@ -414,6 +437,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
                                             p->C_noise, p->noise_thresh, p->mask_noise ? 1 : 0, mbits, h, w, ps,
                                             c->bits_stride, n) == 0;
         if (!merged_done) {              // tile + halo exceeds the LDS: one plane at a time
+            { int rc = scratch(P_T1, t1); if (!rc) rc = scratch(P_T2, t2); if (rc) return rc; }
             launch_bilateral(s, thR, t1, h, w, p->ksize_r, p->C_r, 0, 255, 0, ps, n);
             launch_bilateral(s, thB, t2, h, w, p->ksize_b, p->C_b, 0, 255, 0, ps, n);
         }
@@ -426,12 +450,14 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             partials = true;
             two_partials = true;
         } else {
+            { int rc = scratch(P_T1, t1); if (!rc) rc = scratch(P_T2, t2); if (rc) return rc; }
             launch_adaptive_mean(s, R, t1, h, w, p->ksize_r, p->C_r, ps, n);
             launch_adaptive_mean(s, B, t2, h, w, p->ksize_b, p->C_b, ps, n);
         }
         c->last_adaptive_path = two_partials ? 1 : 0;
     }
     if (!merged_done) {
+        { const int rc = scratch(P_T3, t3); if (rc) return rc; }
         if (p->mask_noise) {
             StageScope t(c, ST_THRESHOLD, s);
             launch_bilateral(s, B, t3, h, w, p->ksize_noise, p->C_noise, 0, 255, 0, ps, n);
@@ -454,7 +480,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
           if (u8_mask) launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n);
           else launch_open5_to_bits(s, mbits, ebits, obits, h, w, c->bits_stride, n);
       } }
-    (void)merged; (void)t0;
+    (void)t0;
     HIP_TRY(hipGetLastError());
     return LT_OK;
 }
@@ -740,7 +766,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     const size_t n = (size_t)capacity;
     if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes + 16))) { free_slots(c); return rc; }   // +16: k_undistort_rows reads 8-byte windows
     if ((rc = dev_alloc(&c->d_und, (size_t)((n + 1) / 2) * 2 * c->und_px))) { free_slots(c); return rc; }
-    for (int i = 0; i < P_COUNT; ++i)
+    for (int i : {(int)P_R, (int)P_B, (int)P_THR, (int)P_THB, (int)P_T0})     // the others when a path that uses them runs (ensure_plane)
         if ((rc = dev_alloc(&c->d_plane[i], n * c->plane_bytes))) { free_slots(c); return rc; }
     c->bits_stride = (size_t)c->calib.warp_h * ((c->calib.warp_w + 63) / 64);
     if ((rc = dev_alloc(&c->d_bits_merged, n * c->bits_stride))) { free_slots(c); return rc; }
@@ -760,7 +786,6 @@ int lt_reserve(lt_ctx* c, int capacity) {
     c->capacity = capacity;
     TraceScope ts_ms("lt_reserve:memset");
     HIP_TRY(hipMemsetAsync(c->d_rec, 0, n * sizeof(lt_lane_record), c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_plane[P_MASK], 0, n * c->plane_bytes, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
 }
@@ -991,6 +1016,7 @@ int lt_upload_masks(lt_ctx* c, const uint8_t* masks, int first, int n) {
     if (!masks) return fail(LT_ERR_INVALID, "null masks");
     if ((rc = set_device(c))) return rc;
     if ((rc = sync_all(c))) return rc;
+    if ((rc = ensure_plane(c, P_MASK))) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_plane[P_MASK] + (size_t)first * c->plane_bytes, masks, (size_t)n * c->plane_bytes,
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1063,6 +1089,7 @@ int lt_download_plane(lt_ctx* c, int plane, int first, int n, uint8_t* out) {
     if (plane == LT_PLANE_MERGED) {   // kept bit-packed on the device; expand on demand
         if ((rc = set_device(c))) return rc;
         if ((rc = sync_all(c))) return rc;
+        if ((rc = ensure_plane(c, P_MERGED))) return rc;
         launch_bits_to_u8(c->stream, c->d_bits_merged + (size_t)first * c->bits_stride,
                           c->d_plane[P_MERGED] + (size_t)first * c->plane_bytes, c->calib.warp_h, c->calib.warp_w,
                           c->plane_bytes, c->bits_stride, n);

@@ -58,7 +58,8 @@ struct lt_ctx {
     uint8_t *d_frames = nullptr, *d_bev = nullptr;
     uint32_t* d_und = nullptr;        // undistorted camera rows [r0, r0+nrows), one RGBX dword per pixel, slots 2p / 2p+1 interleaved (und_slot_base)
     size_t und_px = 0;                // pixels per slot of d_und
-    uint8_t* d_plane[P_COUNT] = {};
+    uint8_t* d_plane[P_COUNT] = {};   // P_R, P_B, P_THR, P_THB, P_T0 with the slots; the others on first use (ensure_plane)
+    uint8_t* d_side_scratch = nullptr;     // two planes: the eroded R plane of a one- or two-frame chain (side stream)
     unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
     unsigned long long* d_bits_open = nullptr;    // the opened mask as the mask chain leaves it (what the searches read)
     unsigned long long* d_bits_tmp = nullptr;     // third and fourth partial plane of the walking threshold kernels
@@ -253,6 +254,7 @@ int set_device(lt_ctx* c);
 hipError_t create_compute_stream(hipStream_t* st, int reserved = 0);
 int download(lt_ctx* c, const void* src, void* dst, size_t bytes);
 int ensure_bev(lt_ctx* c);
+int ensure_plane(lt_ctx* c, int idx);
 int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev);
 bool masks_have_bits(const lt_ctx* c, int first, int n);
 int ensure_u8_masks(lt_ctx* c, int first, int n);

@@ -8,6 +8,8 @@
 #include <chrono>
 #include <ctime>
 #include <pthread.h>
+#include <sched.h>
+#include <atomic>
 #include <functional>
 #include <memory>
 #include <condition_variable>
@@ -265,10 +267,18 @@ struct HostCopier {
     void run() {
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
+            if (q.empty() && !stop && spin_us() > 0 && !spinner.exchange(true)) {
+                lk.unlock();
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us());
+                while (queued.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
+                lk.lock();
+                spinner.store(false);
+            }
             work.wait(lk, [&] { return stop || !q.empty(); });
             if (q.empty()) return;               // stop
             Job j = std::move(q.front());
             q.pop_front();
+            queued.fetch_sub(1, std::memory_order_relaxed);
             lk.unlock();
             if (j.fn) j.fn();
             else if (j.dpitch == j.width && j.spitch == j.width) std::memcpy(j.dst, j.src, j.width * j.height);
@@ -296,9 +306,35 @@ struct HostCopier {
             lk.lock();
         }
     }
-    int threads() {              // LT_COPY_THREADS (1 .. 16), default 4
-        static const int n = [] { const char* e = std::getenv("LT_COPY_THREADS"); const int v = e ? std::atoi(e) : 4; return std::min(std::max(v, 1), 16); }();
+    // LT_COPY_THREADS (1 .. 16); default: half of the CPUs the process may use (affinity mask, cgroup quota), 2 .. 8 -- a window of
+    // annotated frames is 0.7 GB of rows to place (copies from the caller's window, strips from staging, text), and the GPU
+    // boxes show 256 CPUs and grant 16
+    int threads() {
+        static const int n = [] {
+            const char* e = std::getenv("LT_COPY_THREADS");
+            if (e) return std::min(std::max(std::atoi(e), 1), 16);
+            double cpus = (double)std::max(1u, std::thread::hardware_concurrency());
+            cpu_set_t set;
+            if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = std::min(cpus, (double)CPU_COUNT(&set));
+            if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+                char q[64];
+                double per = 0.0;
+                if (std::fscanf(f, "%63s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0.0) cpus = std::min(cpus, std::atof(q) / per);
+                std::fclose(f);
+            }
+            return std::min(std::max((int)(cpus / 2.0), 2), 8);
+        }();
         return n;
+    }
+    // The first worker does not go to sleep at once when the queue runs empty: it polls for LT_COPY_SPIN_US (default 400) first.
+    // LaneTracker.process() sends a copy every 0.2-0.3 ms, and a worker woken from a futex on an idle core starts 50-100 us late
+    // (deep C-states) -- the frame then waits for its own rows (1920x1080: _present 54 -> 240 us between two runs on one box).
+    // One polling thread, only while requests keep coming; LT_COPY_SPIN_US=0 turns it off.
+    std::atomic<size_t> queued{0};
+    std::atomic<bool> spinner{false};
+    static int spin_us() {
+        static const int v = [] { const char* e = std::getenv("LT_COPY_SPIN_US"); return e ? std::max(std::atoi(e), 0) : 400; }();
+        return v;
     }
     bool known(int group) { return group == 0 || groups.count(group) != 0; }      // (under m)
     void start_workers(std::unique_lock<std::mutex>& lk, int want) {               // (under m)
@@ -317,6 +353,7 @@ struct HostCopier {
                 if (r1 > r0) {
                     q.push_back({whole.dst + r0 * whole.dpitch, whole.src + r0 * whole.spitch, whole.dpitch, whole.spitch, whole.width, r1 - r0, whole.group,
                                  nullptr, whole.hold});
+                    queued.fetch_add(1, std::memory_order_release);
                     ++pending[whole.group];
                     ++pending_all;
                 }
@@ -331,6 +368,7 @@ struct HostCopier {
             if (!known(group)) return -1;
             start_workers(lk, many ? threads() : 1);
             q.push_back({nullptr, nullptr, 0, 0, 0, 0, group, std::move(fn), nullptr});
+            queued.fetch_add(1, std::memory_order_release);
             ++pending[group];
             ++pending_all;
         }
@@ -385,7 +423,7 @@ struct HostCopier {
         done.notify_all();
     }
     ~HostCopier() {
-        { std::lock_guard<std::mutex> lk(m); stop = true; q.clear(); wq.clear(); }
+        { std::lock_guard<std::mutex> lk(m); stop = true; q.clear(); wq.clear(); queued.store(0); }
         work.notify_all();
         wwork.notify_all();
         for (auto& t : th) if (t.joinable()) t.join();
