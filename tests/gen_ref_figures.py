@@ -30,3 +30,11 @@ Image.fromarray(a).save(os.path.join(OUT, "search_lane_result01_axes.png"), opti
 a = np.asarray(Image.open(os.path.join(REF, "search_lane_vis01.png")).convert("RGB"))[10:881, 40:895]
 Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=16).save(os.path.join(OUT, "search_lane_vis01_axes.png"), optimize=True)
 print(sorted(os.listdir(OUT)))
+
+# the second pair of the same example (README.md:146-148): the SECOND frame of that video and its band-search visualisation --
+# same axes boxes, same kind of data (round 5: the last unused figure pair)
+a = np.asarray(Image.open(os.path.join(REF, "search_lane_result02.png")).convert("RGB"))[11:514, 33:927]
+Image.fromarray(a).save(os.path.join(OUT, "search_lane_result02_axes.png"), optimize=True)
+a = np.asarray(Image.open(os.path.join(REF, "search_lane_vis02.png")).convert("RGB"))[10:881, 40:895]
+Image.fromarray(a).convert("P", palette=Image.ADAPTIVE, colors=16).save(os.path.join(OUT, "search_lane_vis02_axes.png"), optimize=True)
+print(sorted(os.listdir(OUT)))
