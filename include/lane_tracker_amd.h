@@ -247,7 +247,10 @@ int  lt_fit_poly2(lt_ctx* ctx, const int32_t* ys, const int32_t* xs, int n, int 
 
 /* ---- presentation stage (next row after the hot path) ------------------------ */
 /* Minv: the pickled inverse perspective matrix the reference hands to warpPerspective in draw_lane
- * (lane_tracker.py:648); builds the camera-sized remap table once. */
+ * (lane_tracker.py:648); builds the camera-sized remap table once.  Call it BEFORE uploading frames whose annotated form will be
+ * asked for: when the rows the lane can reach (lt_overlay_rows) stick out of the rows lt_upload_frame_rows brings by a few rows
+ * (458-696 against 457-695 of 720 with the reference calibration), that run is widened to cover them (lt_get_source_rows reports
+ * the new run), so that an annotated frame's lane rows need no upload of their own; a frame uploaded before lacks those rows. */
 int  lt_overlay_configure(lt_ctx* ctx, const double* Minv /* 9 */);
 /* draw_lane() without the text (lane_tracker.py:637-662) for the frames in slots [first, first+n):
  * fillPoly of the polygon left points + reversed right points in (0,255,0), warpPerspective with Minv,
@@ -378,6 +381,10 @@ int  lt_host_copy_wait_group(int group);
  * again with the next request).  For hosts that must not have library threads alive at a point of their choosing -- before a
  * fork(), at interpreter shutdown.  (The child of a fork() gets fresh workers by itself: pthread_atfork.) */
 int  lt_shutdown(void);
+/* Since the process started: seconds the copy threads spent on pieces (summed over the threads), bytes of plain copies, pieces
+ * run, and the number of threads requests are shared among (LT_COPY_THREADS; default half of the CPUs the process may use,
+ * 2 .. 8).  Any pointer may be NULL.  bench.py reports the copy threads' share of an annotated stream from these. */
+int  lt_host_copy_stats(double* busy_seconds, double* copied_bytes, long long* pieces, int* threads);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact
  * size, and reused by later allocations.  Why: memory handed back to the driver is wiped in the background on an SDMA engine,

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "lt_host_copy2d_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t]),
     "lt_host_copy_wait_group": (C.c_int, [C.c_int]),
     "lt_shutdown": (C.c_int, []),
+    "lt_host_copy_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "lt_warm": (C.c_int, [_P, C.POINTER(SearchParams), C.POINTER(SearchParams), C.c_int]),
     "lt_overlay_run_strip": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_double]),
     "lt_strip_download_async": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
@@ -359,6 +360,13 @@ def host_text_async(group, dst, src, rows, font, text, n_lines, line_len=40, ori
                                            None if atlas is None else atlas.ctypes.data, None if advance is None else advance.ctypes.data,
                                            int(first_char), int(g), int(gw), int(gh), text, int(n_lines), int(line_len), int(origin[0]),
                                            int(origin[1]), int(step)))
+
+
+def host_copy_stats():
+    """{'busy_s', 'bytes', 'pieces', 'threads'} of the library's copy threads since the process started (lt_host_copy_stats)."""
+    b, y, p, t = C.c_double(), C.c_double(), C.c_longlong(), C.c_int()
+    _check(load().lt_host_copy_stats(C.byref(b), C.byref(y), C.byref(p), C.byref(t)))
+    return {"busy_s": b.value, "bytes": y.value, "pieces": p.value, "threads": t.value}
 
 
 def device_cache_stats():

@@ -280,10 +280,14 @@ struct HostCopier {
             q.pop_front();
             queued.fetch_sub(1, std::memory_order_relaxed);
             lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
             if (j.fn) j.fn();
             else if (j.dpitch == j.width && j.spitch == j.width) std::memcpy(j.dst, j.src, j.width * j.height);
             else
                 for (size_t r = 0; r < j.height; ++r) std::memcpy(j.dst + r * j.dpitch, j.src + r * j.spitch, j.width);
+            busy_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+            bytes_done.fetch_add((unsigned long long)(j.width * j.height), std::memory_order_relaxed);
+            jobs_done.fetch_add(1, std::memory_order_relaxed);
             j.fn = nullptr;
             j.hold.reset();                      // (outside the lock: the release may take a pool's lock)
             lk.lock();
@@ -330,6 +334,7 @@ struct HostCopier {
     // LaneTracker.process() sends a copy every 0.2-0.3 ms, and a worker woken from a futex on an idle core starts 50-100 us late
     // (deep C-states) -- the frame then waits for its own rows (1920x1080: _present 54 -> 240 us between two runs on one box).
     // One polling thread, only while requests keep coming; LT_COPY_SPIN_US=0 turns it off.
+    std::atomic<unsigned long long> busy_ns{0}, bytes_done{0}, jobs_done{0};   // lt_host_copy_stats (plain copies count their bytes, fn jobs 0)
     std::atomic<size_t> queued{0};
     std::atomic<bool> spinner{false};
     static int spin_us() {
@@ -673,6 +678,15 @@ int lt_host_copy2d_async(void* dst, size_t dst_pitch, const void* src, size_t sr
 
 int lt_host_copy_wait(void) {
     host_copier().wait_all();
+    return LT_OK;
+}
+
+int lt_host_copy_stats(double* busy_seconds, double* copied_bytes, long long* pieces, int* threads) {
+    HostCopier& h = host_copier();
+    if (busy_seconds) *busy_seconds = 1e-9 * (double)h.busy_ns.load();
+    if (copied_bytes) *copied_bytes = (double)h.bytes_done.load();
+    if (pieces) *pieces = (long long)h.jobs_done.load();
+    if (threads) *threads = h.threads();
     return LT_OK;
 }
 

@@ -116,6 +116,10 @@ class LaneTracker:
         self._have_font = False
         self._resident = None       # (frame array, slot) of the camera frame last uploaded to the main context
         self._in_stream = False     # a process_stream() generator is active: its windows own the context's slots
+        # the presentation stage's tables now, not at the first annotated frame: lt_overlay_configure may widen the run of camera
+        # rows the uploads bring by a row or two (so that the lane's rows need no upload of their own), and a frame uploaded before
+        # that would lack them
+        self._configure_overlay()
 
     # ------------------------------------------------------------------------------------------
     def get_success_ratio(self):
