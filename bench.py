@@ -156,7 +156,7 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
     by frame (annotated frame back, as process_video.py uses it), of process_batch() (device-chained searches) and of
     process_stream() over `nwin` DISTINCT windows -- the first pass over them (pages the runtime has never seen) and a second
     pass, separately."""
-    from lane_tracker_amd import calib, settings
+    from lane_tracker_amd import _native, calib, settings
     from lane_tracker_amd.lane_tracker import LaneTracker
     out = {}
     for name, base in streams.items():
@@ -189,26 +189,37 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
 
             def first_passes(ann, trackers=3):
                 """The first pass of a stream -- what a single video pays (process_video.py:41-44) -- from `trackers` FRESH trackers,
-                each over freshly allocated windows the runtime has never seen: frames/s and the time to the first window."""
-                rates, ttfw = [], []
+                each over freshly allocated windows the runtime has never seen: frames/s and the time to the first window, after
+                `LaneTracker.warm(window, annotate)` (its own time beside them: the slot regions, the search / chain / presentation
+                buffers, the output pool) -- and once more from a tracker that was NOT warmed, which does that work inside the pass."""
+                rates, ttfw, warm_ms = [], [], []
                 reuse = bool(os.environ.get("LT_BENCH_OLD_FIRST"))     # diagnosis: round 4's sequence (the tracker of the legs above)
-                for _ in range(1 if reuse else trackers):
+                cold_rate = None
+                for k in range(1 if reuse else trackers + 1):
                     ws = stream_windows(base, window, nwin)
                     fresh = lt if reuse else LaneTracker(**cal)
                     trace = _call_trace(fresh) if os.environ.get("LT_BENCH_TRACE") else None
                     try:
                         first = []
-                        rates.append(stream_rate(ws, ann, fresh, first))
-                        ttfw.append(round(first[0], 2))
+                        if k < trackers and not reuse:
+                            warm_ms.append(round(fresh.warm(window, ann) * 1e3, 1))
+                        r = stream_rate(ws, ann, fresh, first)
+                        if k < trackers:
+                            rates.append(r)
+                            ttfw.append(round(first[0], 2))
+                        else:
+                            cold_rate = {"frames_per_s": r, "time_to_first_window_ms": round(first[0], 2)}
                         if trace is not None:
-                            print("LT_BENCH_TRACE %s annotate=%s %.1f frames/s ttfw %.1f ms: %s" % (name, ann, rates[-1], ttfw[-1], trace()), file=sys.stderr)
+                            print("LT_BENCH_TRACE %s annotate=%s %.1f frames/s ttfw %.1f ms: %s" % (name, ann, r, first[0], trace()), file=sys.stderr)
                     finally:
                         if not reuse:
                             fresh.close()
                     del ws
-                return {"frames_per_s": {"min": min(rates), "median": sorted(rates)[len(rates) // 2], "max": max(rates)},
-                        "time_to_first_window_ms": {"min": min(ttfw), "median": sorted(ttfw)[len(ttfw) // 2], "max": max(ttfw)},
-                        "fresh_trackers": len(rates)}
+                mid = lambda v: sorted(v)[len(v) // 2]
+                return {"frames_per_s": {"min": min(rates), "median": mid(rates), "max": max(rates)},
+                        "time_to_first_window_ms": {"min": min(ttfw), "median": mid(ttfw), "max": max(ttfw)},
+                        "warm_ms": {"min": min(warm_ms), "median": mid(warm_ms), "max": max(warm_ms)} if warm_ms else None,
+                        "fresh_trackers": len(rates), "not_warmed": cold_rate}
             # consecutive windows of one video: process_stream keeps the device busy across window boundaries.
             fp_plain = first_passes(False)
             res["process_stream_first_pass"] = fp_plain
@@ -221,10 +232,16 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
             res["process_stream_annotated_first_pass"] = fp_ann
             res["process_stream_annotated_first_pass_fps"] = fp_ann["frames_per_s"]["median"]
             stream_rate(cold, True)
+            cs0, t_ann = _native.host_copy_stats(), time.perf_counter()
             res["process_stream_annotated_fps"] = max(stream_rate(cold, True) for _ in range(2))
+            cs1, t_ann = _native.host_copy_stats(), time.perf_counter() - t_ann
+            res["copy_threads_busy_share_annotated_stream"] = round((cs1["busy_s"] - cs0["busy_s"]) / max(t_ann * cs1["threads"], 1e-9), 3)
             res["annotated_frames_came_back_by"] = lt._ctx.download_stats()
             rows = lt._present_rows() if lt.host_copies_rows else None
             res["annotated_frames_travel_as"] = ("whole frames" if rows is None else
+                                                 ("strips: rows %s of %d (the rows the lane can reach) drawn on the device, back through page-locked staging "
+                                                  "blocks into ordinary memory; the other rows from the caller's window and the text lines by %d host threads"
+                                                  % (list(rows[4][2]), cal["img_size"][1], _native.host_copy_stats()["threads"])) if rows[4] is not None else
                                                  "row runs %s of %d rows (text lines, rows the lane can reach: copy kernel); the other rows are copied "
                                                  "from the caller's window by host threads" % (rows[2], cal["img_size"][1]))
             res["success_ratio"] = round(lt.get_success_ratio()[0], 4)
@@ -255,7 +272,8 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                    "forwards and backwards into %d separately allocated windows of %d frames: process() = one frame per call, annotated frame "
                    "returned; process_batch() = one window per call, searches chained on the device (lt_band_fit_chain_run), check_validity / "
                    "history on the host; process_stream() = the same over consecutive windows, the next windows' uploads and masks under the "
-                   "current one's searches; *_first_pass = the first time the runtime sees those pages, the figure beside it a later pass "
+                   "current one's searches; *_first_pass = three fresh trackers over pages the runtime has never seen, after LaneTracker.warm() "
+                   "(its time in warm_ms; not_warmed: a fourth fresh tracker without it), the figure beside it a later pass "
                    "(the *_annotated figures return every annotated frame; only the rows an overlay can touch cross the bus, annotated_frames_travel_as; *_outages: four outages of 16 "
                    "frames per window, handled in speculative groups; *_demo1: settings.DEMO_1, mask_noise = True); success_ratio is that of "
                    "the clean streams; 1920x1080 is BASELINE config 5" % (len(next(iter(streams.values()))), nwin, window))

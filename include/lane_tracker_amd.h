@@ -377,13 +377,16 @@ int  lt_host_copy_group_destroy(int group);
 int  lt_host_copy_async_group(int group, void* dst, const void* src, size_t bytes);
 int  lt_host_copy2d_async_group(int group, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t height);
 int  lt_host_copy_wait_group(int group);
+/* Write one byte into every 4 KB page of [p, p + bytes) on the copy threads: first touch of fresh memory ahead of its use (the
+ * output frames of a stream's first windows; ~10 GB/s whatever the thread count).  The contents are undefined afterwards. */
+int  lt_host_touch_async_group(int group, void* p, size_t bytes);
 /* Finish the queued host copies and join the copy threads now (they are also joined when the library is unloaded, and start
  * again with the next request).  For hosts that must not have library threads alive at a point of their choosing -- before a
  * fork(), at interpreter shutdown.  (The child of a fork() gets fresh workers by itself: pthread_atfork.) */
 int  lt_shutdown(void);
 /* Since the process started: seconds the copy threads spent on pieces (summed over the threads), bytes of plain copies, pieces
- * run, and the number of threads requests are shared among (LT_COPY_THREADS; default half of the CPUs the process may use,
- * 2 .. 8).  Any pointer may be NULL.  bench.py reports the copy threads' share of an annotated stream from these. */
+ * run, and the number of threads requests are shared among (LT_COPY_THREADS; default three quarters of the CPUs the process may
+ * use, 2 .. 12).  Any pointer may be NULL.  bench.py reports the copy threads' share of an annotated stream from these. */
 int  lt_host_copy_stats(double* busy_seconds, double* copied_bytes, long long* pieces, int* threads);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <ctime>
 #include <pthread.h>
+#include <immintrin.h>
 #include <sched.h>
 #include <atomic>
 #include <functional>
@@ -242,6 +243,37 @@ int lt_host_free(void* p) {
 // workers of its own instead of queueing for nobody.
 extern "C++" {
 namespace {
+// Large copies with non-temporal stores: the destination (a frame that goes to the caller) is not read again by this core, and a
+// plain store first reads the destination's cache line (read for ownership) -- three bytes of memory traffic per byte copied
+// instead of two.  glibc switches to non-temporal stores only above ~3/4 of the shared cache; the pieces here are 1-30 MB.
+// LT_COPY_NT=0: plain memcpy (A/B).
+__attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t* dst, const uint8_t* src, size_t n) {
+    size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+    if (head > n) head = n;
+    if (head) { std::memcpy(dst, src, head); dst += head; src += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 32));
+        const __m256i c = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 64));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 64), c);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 96), d);
+    }
+    _mm_sfence();
+    if (i < n) std::memcpy(dst + i, src + i, n - i);
+}
+static void copy_bytes(uint8_t* dst, const uint8_t* src, size_t n) {
+    static const bool nt = [] {
+        const char* e = std::getenv("LT_COPY_NT");
+        return !(e && e[0] == '0') && __builtin_cpu_supports("avx2");
+    }();
+    if (nt && n >= (64u << 10)) copy_stream_avx2(dst, src, n);
+    else std::memcpy(dst, src, n);
+}
+
 struct HostCopier {
     // a piece of work for a worker: a 2-D copy, or (fn) anything else that runs on the host alone.  `hold` is released when the
     // last piece that carries it has run (a staging block going back to its pool).
@@ -282,9 +314,9 @@ struct HostCopier {
             lk.unlock();
             const auto t0 = std::chrono::steady_clock::now();
             if (j.fn) j.fn();
-            else if (j.dpitch == j.width && j.spitch == j.width) std::memcpy(j.dst, j.src, j.width * j.height);
+            else if (j.dpitch == j.width && j.spitch == j.width) copy_bytes(j.dst, j.src, j.width * j.height);
             else
-                for (size_t r = 0; r < j.height; ++r) std::memcpy(j.dst + r * j.dpitch, j.src + r * j.spitch, j.width);
+                for (size_t r = 0; r < j.height; ++r) copy_bytes(j.dst + r * j.dpitch, j.src + r * j.spitch, j.width);
             busy_ns.fetch_add((unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
             bytes_done.fetch_add((unsigned long long)(j.width * j.height), std::memory_order_relaxed);
             jobs_done.fetch_add(1, std::memory_order_relaxed);
@@ -310,7 +342,7 @@ struct HostCopier {
             lk.lock();
         }
     }
-    // LT_COPY_THREADS (1 .. 16); default: half of the CPUs the process may use (affinity mask, cgroup quota), 2 .. 8 -- a window of
+    // LT_COPY_THREADS (1 .. 16); default: three quarters of the CPUs the process may use (affinity mask, cgroup quota), 2 .. 12 -- a window of
     // annotated frames is 0.7 GB of rows to place (copies from the caller's window, strips from staging, text), and the GPU
     // boxes show 256 CPUs and grant 16
     int threads() {
@@ -326,7 +358,7 @@ struct HostCopier {
                 if (std::fscanf(f, "%63s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0.0) cpus = std::min(cpus, std::atof(q) / per);
                 std::fclose(f);
             }
-            return std::min(std::max((int)(cpus / 2.0), 2), 8);
+            return std::min(std::max((int)(cpus * 0.75), 2), 12);
         }();
         return n;
     }
@@ -619,6 +651,7 @@ int lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const u
         auto fn = [=]() {
             for (int f = f0; f < f1; ++f) {
                 uint8_t* d = dst + (size_t)f * dst_stride;
+                // (plain memcpy: the text is blended over these rows next, they should be in the cache)
                 if (row1 > row0) std::memcpy(d + (size_t)row0 * row_bytes, src + (size_t)f * src_stride + (size_t)row0 * row_bytes, (size_t)(row1 - row0) * row_bytes);
                 if (text)
                     text_blend_frame(d, img_h, img_w, atlas, advance, first_char, n_glyphs, glyph_w, glyph_h,
@@ -667,6 +700,20 @@ int lt_host_copy2d_async_group(int group, void* dst, size_t dst_pitch, const voi
 
 int lt_host_copy_wait_group(int group) {
     if (host_copier().wait_group(group)) return fail(LT_ERR_INVALID, "lt_host_copy_wait_group: unknown group %d", group);
+    return LT_OK;
+}
+
+int lt_host_touch_async_group(int group, void* p, size_t bytes) {
+    if (bytes == 0) return LT_OK;
+    if (!p) return fail(LT_ERR_INVALID, "lt_host_touch_async_group: null pointer");
+    const int parts = host_copy_threads() * 2;
+    uint8_t* base = static_cast<uint8_t*>(p);
+    for (int k = 0; k < parts; ++k) {
+        const size_t a = (bytes * (size_t)k / parts) & ~(size_t)4095, b = k + 1 == parts ? bytes : (bytes * (size_t)(k + 1) / parts) & ~(size_t)4095;
+        if (b <= a) continue;
+        if (host_submit_fn(group, [=]() { for (size_t o = a; o < b; o += 4096) reinterpret_cast<volatile uint8_t*>(base)[o] = 0; }, true))
+            return fail(LT_ERR_INVALID, "lt_host_touch_async_group: unknown group %d", group);
+    }
     return LT_OK;
 }
 

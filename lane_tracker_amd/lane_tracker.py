@@ -1313,12 +1313,14 @@ class LaneTracker:
                                    k["mask_noise"], k["noise_thresh"], k["ksize_noise"], k["C_noise"])
         return k, first_try, fp
 
-    def warm(self, window=256, annotate=True, **kwargs):
+    def warm(self, window=256, annotate=True, output_pool=True, **kwargs):
         """Set up, ahead of the first window, what `process_stream` / `process_batch` over windows of up to `window` frames would
         otherwise set up on the way (`kwargs`: process()'s keywords, as for those calls): the slot regions of a stream
         (`stream_lookahead` + 1 windows, one more with annotation) sized once, the search and chain buffers for both parameter
-        sets, the presentation stage's buffers, the glyph atlas.  Optional -- a stream that was not warmed does the same work
-        inside its first window (20-35 ms) -- and repeatable (a no-op the second time).  Returns the seconds it took."""
+        sets, the presentation stage's buffers, the glyph atlas and -- `output_pool` -- the memory the annotated frames of the first
+        windows will be returned in, every page touched (first touch of fresh memory runs at ~10 GB/s: 70 ms per window of 256
+        1280x720 frames, which a stream that was not warmed pays inside its first three or four windows).  Optional -- a stream
+        that was not warmed does the same work on the way -- and repeatable (a no-op the second time).  Returns the seconds it took."""
         import time
         t0 = time.perf_counter()
         k, first_try, fp = self._batch_arguments(kwargs)
@@ -1335,6 +1337,8 @@ class LaneTracker:
         if annotate:
             rows = self._present_rows() if self.host_copies_rows else None
             mode = 2 if (rows is not None and rows[4] is not None) else 1
+        if mode == 2 and output_pool:        # the pool of output frames: a window being filled, one landing, one with the caller, one to spare
+            _native.frames_prefault((int(window), ctx.img_h, ctx.img_w, 3), regions)
         for q in (first_try, self._SECOND_TRY):
             ctx.warm(_native.search_params(window_width=q[9], window_height=q[10], search_range=q[11], mu=q[12], no_success_limit=q[13],
                                            start_slice=q[14], ignore_sides=q[15], ignore_bottom=q[16], partial=q[18]),
@@ -1375,11 +1379,10 @@ class LaneTracker:
             group = _native.host_copy_group()
             self._window_groups = list(self._window_groups) + [(group, (out, frames))]
             lib, dst, src = ctx.lib, out.ctypes.data, frames.ctypes.data
-            cuts = sorted([(t0, t1), (l0, l1)])
-            at = 0
-            for lo, hi in cuts + [(H, H)]:                # the rows neither the text nor the lane can touch: from now on
-                if lo > at and lib.lt_host_copy2d_async_group(group, dst + at * rb, fb, src + at * rb, fb, (lo - at) * rb, n):
-                    raise _native.NativeError("lt_host_copy2d_async_group failed")
+            cuts, gaps, at = sorted([(t0, t1), (l0, l1)]), [], 0
+            for lo, hi in cuts + [(H, H)]:                # the rows neither the text nor the lane can touch
+                if lo > at:
+                    gaps.append((at, lo))
                 at = max(at, hi)
 
             def flush(force):
@@ -1389,9 +1392,15 @@ class LaneTracker:
                 part = deferred[lo:hi]
                 ctx.overlay_run_strip_packed(*_pack_deferred(part), first=base + lo)
                 ctx.strip_download_async(out[lo:hi], base + lo, group)
+                # the host's share of these frames, piece by piece as they are committed (all of a window's untouched rows at once, at
+                # its start, sat in the copy threads' queue in front of the last strips of the window before: 9 ms per window
+                # of 1920x1080 frames waiting for them)
                 text, nl = _native.text_bytes([d[2] for d in part]) if font is not None else (None, 0)
                 if t1 > t0:
                     _native.host_text_async(group, out[lo:hi], frames[lo:hi], (t0, t1), font, text, nl, 40, self._TEXT_ORIGIN, self._TEXT_STEP)
+                for a, b in gaps:
+                    if lib.lt_host_copy2d_async_group(group, dst + lo * fb + a * rb, fb, src + lo * fb + a * rb, fb, (b - a) * rb, hi - lo):
+                        raise _native.NativeError("lt_host_copy2d_async_group failed")
                 done[0] = hi
             flush.group = group
             return flush, out
@@ -1547,7 +1556,7 @@ class LaneTracker:
                         self._materialise_pending()  # growing the context drops what is still on the device
                         size = (n + 1) & ~1
                         ctx.reserve(regions * size)
-                        self.warm(n, annotate, **kwargs)     # (a no-op when the caller has warmed the tracker for this window size)
+                        self.warm(n, annotate, output_pool=False, **kwargs)   # (a no-op when the caller has warmed the tracker for this window size)
                     free = [r * size for r in range(regions)]
                     for q in queue:                  # nothing can have been fed ahead of an unplaced window
                         q[1], q[2] = None, 0

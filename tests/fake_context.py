@@ -52,6 +52,12 @@ class FakeContext:
     def warm(self, sws=None, band=None, annotate=0):
         pass
 
+    def overlay_configure(self, Minv):       # (the tracker configures the presentation stage at construction; nothing here draws)
+        pass
+
+    def overlay_set_font(self, atlas, advance, first_char=32):
+        pass
+
     def urgent(self):
         import contextlib
         return contextlib.nullcontext(self)
