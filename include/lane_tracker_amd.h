@@ -385,8 +385,8 @@ int  lt_host_touch_async_group(int group, void* p, size_t bytes);
  * fork(), at interpreter shutdown.  (The child of a fork() gets fresh workers by itself: pthread_atfork.) */
 int  lt_shutdown(void);
 /* Since the process started: seconds the copy threads spent on pieces (summed over the threads), bytes of plain copies, pieces
- * run, and the number of threads requests are shared among (LT_COPY_THREADS; default three quarters of the CPUs the process may
- * use, 2 .. 12).  Any pointer may be NULL.  bench.py reports the copy threads' share of an annotated stream from these. */
+ * run, and the number of threads requests are shared among (LT_COPY_THREADS; default half of the CPUs the process may use,
+ * 2 .. 8).  Any pointer may be NULL.  bench.py reports the copy threads' share of an annotated stream from these. */
 int  lt_host_copy_stats(double* busy_seconds, double* copied_bytes, long long* pieces, int* threads);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact

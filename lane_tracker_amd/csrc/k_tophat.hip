@@ -371,6 +371,9 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
     auto pair = [](unsigned long long v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); };
     // One chain step with three taps: DST[p] = op(SRC[p - D], SRC[p], SRC[p + D]) for p = pa, pb; entry p of
     // plane q lives (q * PLANE + MARGIN + p) * 8 bytes from the wave's chain base.
+#ifdef LT_PROBE_NO_CHAIN       // timing probe (WRONG results): no chain steps through the LDS -- what their round trips cost a step
+#define LT_STEP3(SRC, DST, D) {}
+#else
 #define LT_STEP3(SRC, DST, D)                                                                                        \
     {                                                                                                                \
         unsigned long long a0, a1, a2, b0, b1, b2;                                                                   \
@@ -387,6 +390,7 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         (S0 + (DST) * PLANE)[pb] = op3v<DIL>(pair(b0), pair(b1), pair(b2));                                          \
         wave_lds_fence();                                                                                            \
     }
+#endif
     {
         // First chain step without LDS: the neighbours of entry p = lane (and p = lane + 64) sit in the adjacent
         // lanes' registers, one whole-wave DPP shift away; lane 63's right neighbour is entry 64 (lane 0's second
@@ -439,7 +443,11 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
                     if constexpr (j >= 22 && j <= 31) An[j] = A[j + 2];
                     else
 #endif
+#ifdef LT_PROBE_NO_ACCUM      // timing probe (WRONG results): the vertical pipeline only shifts -- what the window updates cost a step (tools/tophat_probe.sh)
+                    An[j] = A[j + 2] | (Ha[SE::slot(j + 1)] & 1u);
+#else
                     An[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
+#endif
                     asm volatile("" : "+v"(An[j]));   // pins the update into its stage: the optimiser would sink it below every read
                 }
             }, std::make_integer_sequence<int, K - 2>{});

@@ -243,10 +243,10 @@ int lt_host_free(void* p) {
 // workers of its own instead of queueing for nobody.
 extern "C++" {
 namespace {
-// Large copies with non-temporal stores: the destination (a frame that goes to the caller) is not read again by this core, and a
-// plain store first reads the destination's cache line (read for ownership) -- three bytes of memory traffic per byte copied
-// instead of two.  glibc switches to non-temporal stores only above ~3/4 of the shared cache; the pieces here are 1-30 MB.
-// LT_COPY_NT=0: plain memcpy (A/B).
+// Large copies with non-temporal stores (LT_COPY_NT=1; OFF by default): the idea -- the destination is not read again by this core,
+// and a plain store first reads the destination's cache line -- does not pay on the GPU boxes (EPYC 9575F): measured SLOWER, an
+// annotated 1920x1080 stream at 8.7-9.5 k frames/s against 10.7-11.9 k with glibc's memcpy (67-71 against 89-107 GB/s while
+// the threads are busy), a window-sized raw copy on 12 threads at 59 against 135 GB/s.  Kept for other hosts.
 __attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t* dst, const uint8_t* src, size_t n) {
     size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
     if (head > n) head = n;
@@ -268,7 +268,7 @@ __attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t* dst, const
 static void copy_bytes(uint8_t* dst, const uint8_t* src, size_t n) {
     static const bool nt = [] {
         const char* e = std::getenv("LT_COPY_NT");
-        return !(e && e[0] == '0') && __builtin_cpu_supports("avx2");
+        return e && e[0] == '1' && __builtin_cpu_supports("avx2");
     }();
     if (nt && n >= (64u << 10)) copy_stream_avx2(dst, src, n);
     else std::memcpy(dst, src, n);
@@ -342,7 +342,8 @@ struct HostCopier {
             lk.lock();
         }
     }
-    // LT_COPY_THREADS (1 .. 16); default: three quarters of the CPUs the process may use (affinity mask, cgroup quota), 2 .. 12 -- a window of
+    // LT_COPY_THREADS (1 .. 16); default: half of the CPUs the process may use (affinity mask, cgroup quota), 2 .. 8 (with 12 of the 16 CPUs
+    // the GPU boxes grant, the driving thread's Python work ran at half speed: the quota throttles it) -- a window of
     // annotated frames is 0.7 GB of rows to place (copies from the caller's window, strips from staging, text), and the GPU
     // boxes show 256 CPUs and grant 16
     int threads() {
@@ -358,7 +359,7 @@ struct HostCopier {
                 if (std::fscanf(f, "%63s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0.0) cpus = std::min(cpus, std::atof(q) / per);
                 std::fclose(f);
             }
-            return std::min(std::max((int)(cpus * 0.75), 2), 12);
+            return std::min(std::max((int)(cpus / 2.0), 2), 8);
         }();
         return n;
     }
