@@ -343,13 +343,14 @@ int  lt_strip_download_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out, s
  * the HOST, with lt_overlay_text's arithmetic bit for bit (white over the frame: v + ((255 - v) * alpha + 127) / 255): `lines` holds
  * n_lines * line_len bytes per frame (NUL-padded), frame after frame.  No GPU, no context.
  *   lt_text_blend_host        n frames in place, on the calling thread (LaneTracker.process(): ~10 us per frame)
- *   lt_host_text_async_group  on the library's copy threads, in `group`: per frame, first copy rows [row0, row1) of the source
- *                             frame into the destination frame (the rows the text lies in; row0 == row1: nothing), then draw
- *                             the lines.  `lines` is copied; the frames and the atlas must stay valid until the group's wait. */
+ *   lt_host_text_async_group  on the library's copy threads, in `group`: per frame, first copy two runs of rows {a0, a1, b0, b1}
+ *                             (rows4; NULL or empty runs: nothing) of the source frame into the destination frame -- every row
+ *                             the device does not deliver: above and below the lane's run -- then draw the lines over them.
+ *                             `lines` is copied; the frames and the atlas must stay valid until the group's wait. */
 int  lt_text_blend_host(uint8_t* frames, size_t frame_stride, int n, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance,
                         int first_char, int n_glyphs, int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0,
                         int y0, int step);
-int  lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_stride, int n, int row0, int row1,
+int  lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_stride, int n, const int32_t* rows4,
                               int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs,
                               int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0, int y0, int step);
 /* Page-locked host memory for buffers passed to the upload / download entry points (copies from or to pageable

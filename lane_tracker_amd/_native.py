@@ -120,7 +120,7 @@ _SIGNATURES = {
     "lt_strip_download_async": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_size_t, C.c_int]),
     "lt_text_blend_host": (C.c_int, [_P, C.c_size_t, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int,
                                      C.c_int, C.c_int, C.c_int, C.c_int]),
-    "lt_host_text_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
+    "lt_host_text_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_int, _P, C.c_int, C.c_int, _P, _P,
                                            C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
@@ -368,8 +368,9 @@ def text_blend(frames, font, text, n_lines, line_len=40, origin=(20, 8), step=35
 
 
 def host_text_async(group, dst, src, rows, font, text, n_lines, line_len=40, origin=(20, 8), step=35):
-    """On the library's copy threads, in `group`: rows [rows[0], rows[1]) of every frame of `src` into `dst` (both (n, H, W, 3) u8,
-    C-contiguous), then that frame's text lines drawn over them (lt_host_text_async_group).  font None / n_lines 0: only the rows."""
+    """On the library's copy threads, in `group`: the two runs of rows `rows` = (a0, a1, b0, b1) (or one run (a0, a1)) of every frame
+    of `src` into `dst` (both (n, H, W, 3) u8, C-contiguous), then that frame's text lines drawn over them
+    (lt_host_text_async_group).  font None / n_lines 0: only the rows."""
     n, H, W = dst.shape[0], dst.shape[1], dst.shape[2]
     if font is None or not n_lines:
         atlas = advance = None
@@ -378,7 +379,8 @@ def host_text_async(group, dst, src, rows, font, text, n_lines, line_len=40, ori
     else:
         atlas, advance, first_char = font
         g, gh, gw = atlas.shape
-    _check(load().lt_host_text_async_group(int(group), dst.ctypes.data, H * W * 3, src.ctypes.data, H * W * 3, n, int(rows[0]), int(rows[1]), H, W,
+    r4 = np.array((list(rows) + [H, H])[:4] if len(rows) == 2 else list(rows), np.int32)
+    _check(load().lt_host_text_async_group(int(group), dst.ctypes.data, H * W * 3, src.ctypes.data, H * W * 3, n, r4.ctypes.data, H, W,
                                            None if atlas is None else atlas.ctypes.data, None if advance is None else advance.ctypes.data,
                                            int(first_char), int(g), int(gw), int(gh), text, int(n_lines), int(line_len), int(origin[0]),
                                            int(origin[1]), int(step)))

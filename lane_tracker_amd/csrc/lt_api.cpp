@@ -1510,6 +1510,8 @@ int lt_set_search_cus(lt_ctx* c, int n) {
     if (c->urgent) { (void)hipStreamDestroy(c->urgent); c->urgent = nullptr; c->urgent_on = false; }
     if (c->dl) { (void)hipStreamDestroy(c->dl); c->dl = nullptr; }
     c->search_cus = n;
+    c->rec_mirror_slot = -1;             // the stream the mirror of a one-frame search was queued on is gone
+    c->rec_mirror_stream = nullptr;
     return LT_OK;
 }
 

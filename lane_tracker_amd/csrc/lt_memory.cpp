@@ -632,13 +632,16 @@ int lt_text_blend_host(uint8_t* frames, size_t frame_stride, int n, int img_h, i
     return LT_OK;
 }
 
-int lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_stride, int n, int row0, int row1,
+int lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_stride, int n, const int32_t* rows4,
                              int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs, int glyph_w,
                              int glyph_h, const char* lines, int n_lines, int line_len, int x0, int y0, int step) {
-    if (n < 0 || img_h < 1 || img_w < 1 || row0 < 0 || row1 < row0 || row1 > img_h || n_lines < 0 || line_len < 0)
+    int r[4] = {0, 0, 0, 0};
+    if (rows4) for (int k = 0; k < 4; ++k) r[k] = rows4[k];
+    if (n < 0 || img_h < 1 || img_w < 1 || n_lines < 0 || line_len < 0 || !(0 <= r[0] && r[0] <= r[1] && r[1] <= r[2] && r[2] <= r[3] && r[3] <= img_h))
         return fail(LT_ERR_INVALID, "lt_host_text_async_group: bad geometry");
     if (n == 0) return LT_OK;
-    if (!dst || (row1 > row0 && !src)) return fail(LT_ERR_INVALID, "lt_host_text_async_group: null frames");
+    const bool copies = r[1] > r[0] || r[3] > r[2];
+    if (!dst || (copies && !src)) return fail(LT_ERR_INVALID, "lt_host_text_async_group: null frames");
     const bool text = n_lines > 0 && line_len > 0;
     if (text && (!atlas || !advance || !lines || n_glyphs < 1 || glyph_w < 1 || glyph_h < 1 || first_char < 0))
         return fail(LT_ERR_INVALID, "lt_host_text_async_group: null or empty font / text");
@@ -646,14 +649,16 @@ int lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const u
     auto keep = std::make_shared<std::vector<char>>(text ? lines : nullptr, text ? lines + (size_t)n * n_lines * line_len : nullptr);
     const int parts = std::min(n, host_copy_threads() * 2);
     const size_t row_bytes = (size_t)img_w * 3;
+    const int r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
     for (int k = 0; k < parts; ++k) {
         const int f0 = (int)((long long)n * k / parts), f1 = (int)((long long)n * (k + 1) / parts);
         if (f1 <= f0) continue;
         auto fn = [=]() {
-            for (int f = f0; f < f1; ++f) {
+            for (int f = f0; f < f1; ++f) {           // a frame at a time: its rows, then its text over them while they are in the cache
                 uint8_t* d = dst + (size_t)f * dst_stride;
-                // (plain memcpy: the text is blended over these rows next, they should be in the cache)
-                if (row1 > row0) std::memcpy(d + (size_t)row0 * row_bytes, src + (size_t)f * src_stride + (size_t)row0 * row_bytes, (size_t)(row1 - row0) * row_bytes);
+                const uint8_t* q = src + (size_t)f * src_stride;
+                if (r1 > r0) std::memcpy(d + (size_t)r0 * row_bytes, q + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes);
+                if (r3 > r2) std::memcpy(d + (size_t)r2 * row_bytes, q + (size_t)r2 * row_bytes, (size_t)(r3 - r2) * row_bytes);
                 if (text)
                     text_blend_frame(d, img_h, img_w, atlas, advance, first_char, n_glyphs, glyph_w, glyph_h,
                                      keep->data() + (size_t)f * n_lines * line_len, n_lines, line_len, x0, y0, step);

@@ -3,6 +3,7 @@ because memory that goes back to the driver is wiped in the background on an SDM
 run at half speed meanwhile.  Checked here: a closed context's memory stays with the process and serves the
 next context of the same shape; results do not depend on what a reused block held before; the trim returns it to the driver."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -78,3 +79,24 @@ def test_cache_can_be_switched_off():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LT_DEVICE_CACHE_GB="0"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
     assert int(r.stdout.strip().splitlines()[-1]) > 300e6    # closing gave the memory back at once
+
+
+def test_six_annotated_stream_trackers_close_within_a_deadline_and_the_cache_keeps_to_its_limit():
+    """NOTES C.8 (round 4): six trackers one after the other in one process, each streaming annotated windows, the sixth close()
+    did not return.  The scenario runs in a child process under a watchdog (tools/close_hang.py: the child is started before
+    anything here touches the GPU, killed -- never re-exec'd -- on a timeout) with a cache limit that forces blocks back to the
+    driver at every close; every close() must return within the deadline.  Afterwards, in this process: the cache holds no more
+    than its limit, and the default limit is at most 16 GB."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "close_hang.py"), "--cache-gb", "8", "--limit", "45", "--trackers", "6",
+                        "--windows", "4,8,4,6,4,6", "--total-limit", "300"], capture_output=True, text=True, timeout=400)
+    verdict = [l for l in p.stdout.split("\n") if l.startswith("VERDICT ")]
+    assert verdict, p.stdout[-2000:] + p.stderr[-2000:]
+    v = json.loads(verdict[-1][len("VERDICT "):])
+    assert not v["hung"] and v.get("child_rc") == 0, v
+    from lane_tracker_amd import _native
+    st = _native.device_cache_stats()
+    assert st["kept_bytes"] <= max(st["limit_bytes"], 0) and st["limit_bytes"] <= 16 << 30, st

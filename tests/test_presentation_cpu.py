@@ -211,6 +211,13 @@ def test_text_on_the_host_equals_the_atlas_blend():
     _native.host_text_async(g, dst2, src, (10, 20), None, None, 0)
     assert _native.load().lt_host_copy_wait_group(g) == 0
     assert np.array_equal(dst2[:, 10:20], src[:, 10:20]) and not dst2[:, :10].any() and not dst2[:, 20:].any()
+    # two runs (everything but a middle run: what a window's strips leave to the host), text over the first
+    dst3 = np.full_like(src, 9)
+    _native.host_text_async(g, dst3, src, (0, 125, 135, H), font, buf, nl)
+    assert _native.load().lt_host_copy_wait_group(g) == 0
+    for i in range(n):
+        want = _atlas_blend(src[i], font, texts[i])
+        assert np.array_equal(dst3[i, :125], want[:125]) and np.array_equal(dst3[i, 135:], want[135:]) and (dst3[i, 125:135] == 9).all(), i
     # text that runs off the right edge and a line origin near the bottom are clipped, not wrapped
     small = np.zeros((1, 40, 64, 3), np.uint8)
     b2, n2 = _native.text_bytes([["WWWWWWWWWWWWWWWW"]])

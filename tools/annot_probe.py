@@ -28,7 +28,8 @@ for m in ("upload_frame_rows_async", "upload_frame_rest", "mask_run", "sws_fit_r
     timed(_native.Context, m)
 for m in ("host_text_async", "text_bytes", "frames_empty", "pinned_empty", "host_copy_group", "host_copy_group_release", "poly_points"):
     timed(_native, m)
-timed(LTM, "_pack_deferred")
+from lane_tracker_amd import stream as STM
+timed(STM, "_pack_deferred")
 for m in ("_copies_done", "_valid_many", "_record_successes", "_commit_valid_run"):
     timed(LaneTracker, m)
 # raw rate of the copy threads
