@@ -630,12 +630,7 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
 // with the destination's pitch -- the raw Lab-b plane in the layout the threshold walks read (the greenery mask of
 // filter_lane_points, lane_tracker.py:224, is a bilateral threshold of the RAW plane).  One more store per row pair in a
 // kernel whose memory pipe idles.
-// PF (WIDE only): how many row pairs FURTHER ahead the source rows (and the minuend) are requested.  0: the rows of the next
-// pair are requested at the top of a pair and consumed at its end -- one pair's work (0.3 us) to hide a global load, which is
-// enough with four waves per SIMD (a batch) and far from enough with one: probes with the chain steps and the window updates
-// removed (tools/tophat_probe.sh) leave a one-frame 55x55 launch at 22 of 27 us -- 32 dependent row pairs of 0.7 us, the
-// latency of a load.  One or two frames per launch therefore run with PF = 3 (24 more registers, which a lone wave has).
-template <class SE, bool DIL, bool WIDE, bool TH, bool PAIR, bool COPYM = false, int PF = 0>
+template <class SE, bool DIL, bool WIDE, bool TH, bool PAIR, bool COPYM = false>
 __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const uint8_t* __restrict__ minuend,
                                            const RunsGeom& g, uint2* chain, uint8_t* s_out_w, int lane, int strip, int band, int frame) {
     static_assert(WIDE || !PAIR, "pair strips exist for the WIDE kernels only");
@@ -720,26 +715,16 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
         }
         if (LT_MORPH_BIAS) { e0 |= BIAS2; e1 |= BIAS2; }
     };
-    static_assert(PF == 0 || WIDE, "deeper prefetch exists for the WIDE kernels only");
     uint32_t ea0, ea1, eb0, eb1;   // the entries of the next row pair
     combine(load_row(y_first), ea0, ea1);
     combine(load_row(y_first + 1), eb0, eb1);
-    Raw ring_a[PF > 0 ? PF : 1], ring_b[PF > 0 ? PF : 1];   // PF > 0: the raw rows of the pairs behind the next one, oldest first
-#pragma unroll
-    for (int i = 0; i < PF; ++i) {
-        ring_a[i] = load_row(y_first + 2 * (i + 1));
-        ring_b[i] = load_row(y_first + 2 * (i + 1) + 1);
-    }
     uint32_t ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;   // !WIDE: minuend (xa, xb) of output rows y and y+1
     // WIDE: running byte offsets of this lane's dword -- row y + (lane >> 5) of the minuend, row y - 2 + (lane >> 5) of the
     // band (relative to its first row), for the output row y of the current iteration; lanes right of the image stay out of range
     uint32_t m_off = (uint32_t)(__mul24(yb0 - 2 * R + (lane >> 5), g.w) + wcol_c + (lane_b ? b_src : 0));
     uint32_t st_off = wcol < g.w && (!lane_b || has_b) ? (uint32_t)(__mul24(-2 * R - 2 + (lane >> 5), g.dpitch) + wcol + (lane_b ? (int)g.dst_stride : 0))
                                                       : 0x80000000u;
-    uint32_t mq[PF + 1];           // WIDE top-hat: minuend dwords in flight, oldest first; mq[0] is the one the next store uses
-    mq[0] = 0;
-#pragma unroll
-    for (int i = 1; i <= PF; ++i) mq[i] = TH ? __builtin_amdgcn_raw_buffer_load_b32(min_rs, (int)(m_off + (uint32_t)(i - 1) * 2u * (uint32_t)g.w), 0, 0) : 0u;
+    uint32_t mcur = 0;
     const uint32_t s0_rd = (uint32_t)(uintptr_t)(chain + MARGIN + ((R + lane) & 63));
     const uint32_t out_wr = (uint32_t)(uintptr_t)(s_out_w + (WIDE ? 2 * lane : 0));         // LDS offsets
     const uint32_t out_rd = (uint32_t)(uintptr_t)(s_out_w + (WIDE ? 8 * (lane & 31) : 0));
@@ -764,17 +749,13 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
         const uint2 e_pb = make_uint2(ea1, eb1);
         chain[MARGIN + lane] = lane < R ? e_pb : e_pa;   // entry (lane < R ? lane + 64 : lane): what lane (lane - R) mod 64 owns
         wave_lds_fence();
-        const Raw ra = load_row(yy + 2 * (PF + 1)), rb = load_row(yy + 2 * (PF + 1) + 1);
+        const Raw ra = load_row(yy + 2), rb = load_row(yy + 3);
         const int y = yy - R;                       // output rows y and y+1 complete in this iteration
         const uint32_t ca0 = ma0, cb0 = mb0, ca1 = ma1, cb1 = mb1;
-        const uint32_t mprev = mq[0];   // WIDE: minuend of rows y-2, y-1 (stored in this iteration)
-        if (WIDE) {
-#pragma unroll
-            for (int i = 0; i < PF; ++i) mq[i] = mq[i + 1];
-        }
+        const uint32_t mprev = mcur;    // WIDE: minuend of rows y-2, y-1 (stored in this iteration)
         if (TH) {
-            if (WIDE) {   // lane <-> row y + 2 PF + (lane >> 5), columns x0 + 4 (lane & 31) .. + 3: the layout of the dword store
-                mq[PF] = __builtin_amdgcn_raw_buffer_load_b32(min_rs, (int)(m_off + (uint32_t)PF * 2u * (uint32_t)g.w), 0, 0);
+            if (WIDE) {   // lane <-> row y + (lane >> 5), columns x0 + 4 (lane & 31) .. + 3: the layout of the dword store
+                mcur = __builtin_amdgcn_raw_buffer_load_b32(min_rs, (int)m_off, 0, 0);
             } else {
                 const uint8_t* r0 = m + (size_t)min(max(y + 2, 0), g.h - 1) * g.w;
                 const uint8_t* r1 = m + (size_t)min(max(y + 3, 0), g.h - 1) * g.w;
@@ -828,17 +809,8 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
                 if (vb) d[o + xb] = (uint8_t)ob_v;
             }
         }
-        if constexpr (PF == 0) {
-            combine(ra, ea0, ea1);
-            combine(rb, eb0, eb1);
-        } else {
-            combine(ring_a[0], ea0, ea1);
-            combine(ring_b[0], eb0, eb1);
-#pragma unroll
-            for (int i = 0; i + 1 < PF; ++i) { ring_a[i] = ring_a[i + 1]; ring_b[i] = ring_b[i + 1]; }
-            ring_a[PF - 1] = ra;
-            ring_b[PF - 1] = rb;
-        }
+        combine(ra, ea0, ea1);
+        combine(rb, eb0, eb1);
     };
     // 55x55: two row pairs per loop iteration.  The vertical pipeline A moves by two registers per row pair; with one
     // pair per iteration the staged update order (outer rows first) left 11 register copies at the loop's back edge,
@@ -854,7 +826,7 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
         const int y_tail = y_first + 2 * (pairs_run - 1) - R;     // output row y of the last pair the loop ran
         unsigned long long q;
         out_issue(q);
-        out_finish(q, mq[0], y_tail);
+        out_finish(q, mcur, y_tail);
     }
 }
 
@@ -870,7 +842,7 @@ __device__ __forceinline__ void morph_task(const uint8_t* __restrict__ src, uint
 #else
 #define LT_MORPH_WAVES_ATTR
 #endif
-template <class SE, bool DIL, bool WIDE, bool TH, bool COPYM = false, int PF = 0>
+template <class SE, bool DIL, bool WIDE, bool TH, bool COPYM = false>
 __global__ __launch_bounds__(64 * LT_MORPH_WPB) LT_MORPH_WAVES_ATTR void k_morph_runs2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                     const uint8_t* __restrict__ minuend, RunsGeom g) {
     __shared__ uint2 s_chain[LT_MORPH_WPB][4 * PLANE];   // S0, S1, S4, S13
@@ -897,9 +869,9 @@ __global__ __launch_bounds__(64 * LT_MORPH_WPB) LT_MORPH_WAVES_ATTR void k_morph
         const int strip = t % g.nstrips_normal;
         const int band = (t / g.nstrips_normal) % g.nbands;
         const int frame = t / (g.nstrips_normal * g.nbands);
-        morph_task<SE, DIL, WIDE, TH, false, COPYM, PF>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, strip, band, frame);
+        morph_task<SE, DIL, WIDE, TH, false, COPYM>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, strip, band, frame);
     } else if constexpr (WIDE) {
-        morph_task<SE, DIL, WIDE, TH, true, COPYM, PF>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, g.nstrips_normal, task % g.nbands, 2 * (task / g.nbands));
+        morph_task<SE, DIL, WIDE, TH, true, COPYM>(src, dst, minuend, g, s_chain[wv], s_out[wv], lane, g.nstrips_normal, task % g.nbands, 2 * (task / g.nbands));
     }
 }
 
@@ -1006,16 +978,7 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
                 return false;
         }
 #define LT_LAUNCH(DIL_, WIDE_, TH_) hipLaunchKernelGGL((k_morph_runs2<SE, DIL_, WIDE_, TH_>), grid2, block2, extra_lds, s, src, dst, minuend, g)
-#define LT_LAUNCH_PF(DIL_, TH_) hipLaunchKernelGGL((k_morph_runs2<SE, DIL_, true, TH_, false, 3>), grid2, block2, extra_lds, s, src, dst, minuend, g)
-        // a launch that cannot give a SIMD more than a wave or two (one to four frames) is bound by the latency of its loads: rows
-        // requested three pairs further ahead (LT_MORPH_PF=0: as the batch kernels)
-        static const bool pf_ok = [] { const char* e = std::getenv("LT_MORPH_PF"); return !(e && e[0] == '0'); }();
-        const bool deep = pf_ok && (long long)g.ntasks <= 4 * simds;
-        if (wide && deep) {
-            if (th) LT_LAUNCH_PF(true, true);
-            else if (dilate) LT_LAUNCH_PF(true, false);
-            else LT_LAUNCH_PF(false, false);
-        } else if (wide) {
+        if (wide) {
             if (th) LT_LAUNCH(true, true, true);
             else if (dilate) LT_LAUNCH(true, true, false);
             else LT_LAUNCH(false, true, false);
@@ -1025,7 +988,6 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
             else LT_LAUNCH(false, false, false);
         }
 #undef LT_LAUNCH
-#undef LT_LAUNCH_PF
     }
     return copy_dst == nullptr;
 }
