@@ -167,6 +167,8 @@ void free_slots(lt_ctx* c) {
     c->th_padded.clear();
     c->mask_bits_ok.clear();
     c->mask_u8_ok.clear();
+    c->frame_full.clear();
+    c->annot_full.clear();
     dev_free(c->d_rec);
     dev_free(c->d_prev);
     dev_free(c->d_pix);
@@ -215,6 +217,21 @@ int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev) {
         c->maxlev = maxlev;
     }
     return LT_OK;
+}
+
+// Which slots hold their whole camera frame / whole annotated frame (see lt_ctx.h): the row-run entry points leave the other rows
+// of a slot as whatever the block held before -- device memory comes back from the cache dirty -- and a whole-frame call on such
+// a slot would hand out another stream's pixels.
+void mark_frames(lt_ctx* c, int first, int n, int full) {
+    for (int i = first; i < first + n && i < (int)c->frame_full.size(); ++i) c->frame_full[(size_t)i] = (uint8_t)full;
+}
+void mark_annot(lt_ctx* c, int first, int n, int full) {
+    for (int i = first; i < first + n && i < (int)c->annot_full.size(); ++i) c->annot_full[(size_t)i] = (uint8_t)full;
+}
+int first_partial(const std::vector<uint8_t>& v, int first, int n) {
+    for (int i = first; i < first + n && i < (int)v.size(); ++i)
+        if (!v[(size_t)i]) return i;
+    return -1;
 }
 
 int ensure_band_sums(lt_ctx* c, int nbands) {
@@ -783,6 +800,8 @@ int lt_reserve(lt_ctx* c, int capacity) {
     c->th_padded.assign(n, 0);
     c->mask_bits_ok.assign(n, 0);
     c->mask_u8_ok.assign(n, 1);          // zero-filled below
+    c->frame_full.assign(n, 0);
+    c->annot_full.assign(n, 0);
     if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_prev, n * 6))) { free_slots(c); return rc; }
     c->capacity = capacity;
@@ -876,6 +895,7 @@ int lt_upload_frames(lt_ctx* c, const uint8_t* frames, int first, int n) {
     HIP_TRY(hipMemcpyAsync(c->d_frames + (size_t)first * c->frame_bytes, frames, (size_t)n * c->frame_bytes,
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    mark_frames(c, first, n, 1);
     return LT_OK;
 }
 
@@ -893,6 +913,7 @@ int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
     if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
     if ((rc = set_device(c))) return rc;
     if ((rc = sync_all(c))) return rc;
+    mark_frames(c, first, n, 0);         // a new frame's rows: the others are the previous occupant's until lt_upload_frame_rest
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
     const size_t bytes = (size_t)(c->cam_r1 - c->cam_r0) * row_bytes;
     // ONE frame (LaneTracker.process(): the caller's frame is pageable, the host waits for nothing else meanwhile).  LT_UPLOAD1:
@@ -958,6 +979,7 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     if (!frames) return fail(LT_ERR_INVALID, "null frames");
     if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
     if ((rc = set_device(c))) return rc;
+    mark_frames(c, first, n, 0);
     // the copy waits for the kernels that still read these slots' camera rows (the undistortion launches over these slots, the
     // overlay) -- not for the rest of their mask chains, and not for launches over other slots
     bool precise = true;
@@ -1032,6 +1054,7 @@ int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
     uint8_t* dst = c->d_frames + (size_t)first * c->frame_bytes;
     if (c->cam_r1 <= c->cam_r0) {
         HIP_TRY(hipMemcpyAsync(dst, frames, (size_t)n * c->frame_bytes, hipMemcpyHostToDevice, c->copy));
+        mark_frames(c, first, n, 1);
         return rest_mark(c, first, n);
     }
     if (head)
@@ -1039,6 +1062,7 @@ int lt_upload_frame_rest(lt_ctx* c, const uint8_t* frames, int first, int n) {
     if (tail0 < c->frame_bytes)
         HIP_TRY(hipMemcpy2DAsync(dst + tail0, c->frame_bytes, frames + tail0, c->frame_bytes, c->frame_bytes - tail0, (size_t)n,
                                  hipMemcpyHostToDevice, c->copy));
+    mark_frames(c, first, n, 1);
     return rest_mark(c, first, n);
 }
 

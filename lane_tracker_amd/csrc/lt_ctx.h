@@ -86,6 +86,10 @@ struct lt_ctx {
     // per slot: which forms of the mask are current.  The chain writes the bit plane only; the u8 mask
     // (d_plane[P_MASK]) is expanded from it when somebody asks for it; lt_upload_masks provides u8 only.
     std::vector<uint8_t> mask_bits_ok, mask_u8_ok;
+    // per slot: the WHOLE camera frame is on the device (lt_upload_frames, or lt_upload_frame_rows + lt_upload_frame_rest; the row-run
+    // uploads bring parts only) / the WHOLE annotated frame has been drawn (lt_overlay_run; the row-run and strip overlays draw
+    // parts).  Whole-frame overlays and downloads refuse slots that are not (LT_ERR_STATE).
+    std::vector<uint8_t> frame_full, annot_full;
     size_t bits_stride = 0;                                                  // u64 words per slot
     lt_lane_record* d_rec = nullptr;
     double* d_prev = nullptr;
@@ -263,6 +267,9 @@ bool masks_have_bits(const lt_ctx* c, int first, int n);
 int ensure_u8_masks(lt_ctx* c, int first, int n);
 int make_search_geom(lt_ctx* c, const lt_search_params* p, bool band, SearchGeom& g);
 int ensure_band_sums(lt_ctx* c, int nbands);
+void mark_frames(lt_ctx* c, int first, int n, int full);
+void mark_annot(lt_ctx* c, int first, int n, int full);
+int first_partial(const std::vector<uint8_t>& v, int first, int n);
 int ensure_search_stream(lt_ctx* c);                          // lt_chain.cpp
 int ensure_chain_buffers(lt_ctx* c);                          // lt_chain.cpp
 int warm_presentation(lt_ctx* c, bool strips);                // lt_present.cpp

@@ -256,6 +256,12 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
         tr += right_n[i];
     }
     if ((tl && !left_yx) || (tr && !right_yx)) return fail(LT_ERR_INVALID, "null point list");
+    if (!rows4 && !strip) {
+        const int bad = first_partial(c->frame_full, first, n);
+        if (bad >= 0)
+            return fail(LT_ERR_STATE, "slot %d holds only part of its camera frame (lt_upload_frame_rows without lt_upload_frame_rest): a whole-frame "
+                                      "overlay would show rows of the block's previous occupant", bad);
+    }
     if ((rc = set_device(c))) return rc;
     const int bh = c->calib.warp_h;
     if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
@@ -328,6 +334,7 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
                                     c->d_oxy, c->d_ofrac, hs, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, rows4)) {
             HIP_TRY(hipGetLastError());
             if (went_direct) *went_direct = direct_out != nullptr;
+            if (!direct_out) mark_annot(c, first, n, rows4 ? 0 : 1);
             return note_range(c->readers, ps, first, first + n);
         }
         // not launched (the runtime refused the argument block): the staged way after all, with the intervals already built
@@ -348,6 +355,7 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
                         c->frame_bytes, c->d_oxy, c->d_ofrac, c->d_spans + (size_t)first * bh * 2, (size_t)bh,
                         c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, n, rows4);
     HIP_TRY(hipGetLastError());
+    if (!strip) mark_annot(c, first, n, rows4 ? 0 : 1);
     if ((rc = staging_mark(c->spans_busy, ps))) return rc;
     rc = note_range(c->readers, ps, first, first + n);
     if (timing) {
@@ -553,6 +561,10 @@ int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
     if (rc) return rc;
     if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay before lt_overlay_run");
     if (!out) return fail(LT_ERR_INVALID, "null output buffer");
+    {
+        const int bad = first_partial(c->annot_full, first, n);
+        if (bad >= 0) return fail(LT_ERR_STATE, "slot %d holds row runs of its annotated frame only (lt_overlay_run_rows / lt_present_*): no whole frame to download", bad);
+    }
     const uint8_t* src = c->d_annot + (size_t)first * c->frame_bytes;
     const size_t bytes = (size_t)n * c->frame_bytes;
     if (!c->present || n == 0) return download(c, src, out, bytes);
@@ -688,6 +700,10 @@ static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out
     if (rc) return rc;
     if (!out) return fail(LT_ERR_INVALID, "null output buffer");
     if (!c->d_annot) return fail(LT_ERR_STATE, "lt_download_overlay_async before lt_overlay_run");
+    if (!rows4) {
+        const int bad = first_partial(c->annot_full, first, n);
+        if (bad >= 0) return fail(LT_ERR_STATE, "slot %d holds row runs of its annotated frame only (lt_overlay_run_rows / lt_present_*): no whole frame to download", bad);
+    }
     if (n == 0) return LT_OK;
     if ((rc = set_device(c))) return rc;
     // on a stream of its own, behind the overlay work enqueued so far: the copy neither holds up the kernels queued behind

@@ -97,3 +97,16 @@ def test_the_drivers_launch_line_four_ranks_on_one_gpu_fake_rccl():
     assert line["n_gpus"] == 4 and line["scaling"] == "weak" and line["config"]["frames_per_step_all_gpus"] == 256
     assert line["config"]["ranks_share_devices"] is True and line["config"]["gathered_records_checked"] == 256
     assert line["config"]["rank_environment"] == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def test_bench_eight_ranks_on_one_gpu_fake_rccl():
+    """`bench.py --gpus 8 --frames 4096` (BASELINE config 4 in its 8-way form: 512 frames per rank) with all eight rank processes
+    on GPU 0 over the stand-in: the launcher, the rendezvous, the shard arithmetic and the rank-major gather at N = 8 (round 4 had
+    this as a tool only).  Says nothing about xGMI or throughput: the ranks share one device and the line says so."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--frames", "4096", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=fake_rccl.env(), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["frames_per_step_all_gpus"] == 4096
+    assert line["config"]["frames_per_gpu_per_step"] == 512
+    assert line["config"]["ranks_share_devices"] is True and line["config"]["gathered_records_checked"] == 4096

@@ -100,3 +100,30 @@ def test_six_annotated_stream_trackers_close_within_a_deadline_and_the_cache_kee
     from lane_tracker_amd import _native
     st = _native.device_cache_stats()
     assert st["kept_bytes"] <= max(st["limit_bytes"], 0) and st["limit_bytes"] <= 16 << 30, st
+
+
+def test_whole_frame_calls_refuse_slots_that_hold_row_runs_only():
+    """Blocks come back from the device cache dirty: a slot whose frame or annotated frame was filled by the row-run entry points
+    holds another stream's pixels in its other rows.  The C ABI says so instead of handing them out (round 4: only the Python
+    wrapper guarded against it): a whole-frame overlay needs the whole camera frame, a whole-frame download a whole overlay."""
+    from lane_tracker_amd import _native, calib, synth
+    cal = calib.reference_calibration()
+    frames = synth.stream_lanes(2, seed=4)
+    e = np.zeros(0, np.int64)
+    c = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=2)
+    try:
+        c.overlay_configure(cal["warp_matrices"][1])
+        c.upload_frame_rows(frames)                              # the rows the mask chain reads, nothing else
+        c.mask_run(2)
+        with pytest.raises(_native.NativeError, match="only part of its camera frame"):
+            c.overlay_run([(e, e, e, e)] * 2)                    # whole frames wanted
+        rows = np.array([0, 0, *c.overlay_rows()], np.int32)
+        c.overlay_run([(e, e, e, e)] * 2, rows=rows.ctypes.data)  # the lane's run of rows: fine
+        with pytest.raises(_native.NativeError, match="row runs of its annotated frame only"):
+            c.download_overlay(2)
+        c.upload_frame_rest(frames)                              # now the frames are whole
+        c.overlay_run([(e, e, e, e)] * 2)
+        out = c.download_overlay(2)
+        assert np.array_equal(out, frames)                       # an empty polygon: the camera frames themselves
+    finally:
+        c.close()
