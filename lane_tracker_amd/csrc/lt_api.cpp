@@ -745,8 +745,6 @@ void lt_destroy(lt_ctx* c) {
     for (auto& t : c->chains) (void)hipEventDestroy(t.done);
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
     note("hipHostFree(small, rec, rec_stage, cancel)");
-    for (auto q : c->h_up) if (q) (void)hipHostFree(q);
-    if (c->up_group) (void)lt_host_copy_group_destroy(c->up_group);
     if (c->h_small) (void)hipHostFree(c->h_small);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
@@ -916,36 +914,9 @@ int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
     mark_frames(c, first, n, 0);         // a new frame's rows: the others are the previous occupant's until lt_upload_frame_rest
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
     const size_t bytes = (size_t)(c->cam_r1 - c->cam_r0) * row_bytes;
-    // ONE frame (LaneTracker.process(): the caller's frame is pageable, the host waits for nothing else meanwhile).  LT_UPLOAD1:
-    //   0  the pitched copy of the general case, waited for (rounds 1-4: 46 us for 0.9 MB at 1280x720)
-    //   1  a plain copy of the run of rows (it is contiguous), waited for
-    //   2  the rows onto page-locked staging by the library's copy threads, then an asynchronous copy from there: the call returns
-    //      when the staging copy is queued on the context's stream -- the mask chain is launched behind it, under the bus
-    //   3  as 2 with a copy kernel instead of the engine
-    static const int mode1 = [] { const char* e = std::getenv("LT_UPLOAD1"); return e ? std::atoi(e) : 0; }();
-    if (n == 1 && mode1 >= 1) {
-        uint8_t* dst = c->d_frames + (size_t)first * c->frame_bytes + off;
-        if (mode1 == 1) {
-            HIP_TRY(hipMemcpyAsync(dst, frames + off, bytes, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            return LT_OK;
-        }
-        if (c->h_up_bytes < bytes) {
-            for (auto& q : c->h_up) { if (q) (void)hipHostFree(q); q = nullptr; }
-            c->h_up_bytes = 0;
-            for (auto& q : c->h_up) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&q), bytes, hipHostMallocDefault));
-            c->h_up_bytes = bytes;
-        }
-        uint8_t* stage = c->h_up[first & 1];
-        if (c->up_group == 0) HIP_TRY(lt_host_copy_group_create(&c->up_group) == LT_OK ? hipSuccess : hipErrorUnknown);
-        const size_t rows = (size_t)(c->cam_r1 - c->cam_r0);
-        if ((rc = lt_host_copy2d_async_group(c->up_group, stage, row_bytes, frames + off, row_bytes, row_bytes, rows))) return rc;
-        if ((rc = lt_host_copy_wait_group(c->up_group))) return rc;
-        if (mode1 == 3) launch_copy_from_pinned(c->stream, dst, stage, bytes);
-        else HIP_TRY(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipGetLastError());
-        return LT_OK;
-    }
+    // (one frame, measured in round 5 against this pitched copy, 279-286 us per frame of process(): a plain copy of the contiguous
+    // run 315-320; the rows onto page-locked staging by the copy threads and an asynchronous engine copy from there 295-329, a copy
+    // kernel from there 320 -- the runtime's pageable path is the fastest of the four)
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                              bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

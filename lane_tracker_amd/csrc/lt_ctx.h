@@ -181,9 +181,6 @@ struct lt_ctx {
     int* h_cancel = nullptr;                  // page-locked, device-visible: chains launched with an older epoch stop at their next frame
     int* d_cancel = nullptr;                  // its device address
     uint8_t* h_small = nullptr;               // page-locked scratch of the small downloads (download())
-    uint8_t* h_up[2] = {nullptr, nullptr};    // page-locked staging of a one-frame upload (lt_upload_frame_rows, LT_UPLOAD1=2/3), by slot parity
-    size_t h_up_bytes = 0;
-    int up_group = 0;                         // completion group of the copy threads filling it
     int ov_r0 = 0, ov_r1 = 0;                 // camera rows the lane overlay can change (lt_overlay_configure)
     lt_lane_record* h_rec = nullptr;          // page-locked mirror of the record of the last ONE-frame search (mirror_record)
     int rec_mirror_slot = -1;                 // the slot whose record the mirror holds once rec_mirror_stream is idle; -1: none
