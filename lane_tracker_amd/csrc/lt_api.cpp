@@ -702,23 +702,11 @@ void lt_destroy(lt_ctx* c) {
         hipStream_t sts[6] = {c->copy, c->side, c->search, c->present, c->urgent, c->dl};
         for (int i = 0; i < 6; ++i) if (sts[i]) { note(names[i]); (void)hipStreamSynchronize(sts[i]); }
     }
-    note("slots");
-    free_slots(c);
-    note("tables and buffers");
-    dev_free(c->d_uxy);
-    dev_free(c->d_wxy);
-    dev_free(c->d_ufrac);
-    dev_free(c->d_wfrac);
-    dev_free(c->d_gamma);
-    dev_free(c->d_cbrt);
-    dev_free(c->d_coef);
-    dev_free(c->d_oxy);
-    dev_free(c->d_ofrac);
-    dev_free(c->d_atlas);
-    dev_free(c->d_advance);
-    dev_free(c->d_lines);
-    dev_free(c->d_xpos);
-    // (LT_TRACE_DESTROY names every class of call: a close() that did not return in round 4 was somewhere in here, NOTES C.8)
+    // Streams, events and page-locked buffers go FIRST, device memory after them.  Round 4 released the memory first, and when the
+    // cache then handed blocks back to the driver (hipFree of several GB), the hipStreamDestroy of the presentation stream -- a
+    // stream with a CU mask -- that followed did not return: the thread sat in AMDKFD_IOC_WAIT_EVENTS for good (5 of 6 runs of
+    // tools/close_hang.py with round 4's library; never once the stream is destroyed before the hipFree; NOTES D.5).
+    // (LT_TRACE_DESTROY names every class of call.)
     note("events: timing pool, order ring, staging");
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     for (auto e : c->order_events) (void)hipEventDestroy(e);
@@ -762,6 +750,22 @@ void lt_destroy(lt_ctx* c) {
     note("hipStreamDestroy(slot streams)");
     for (auto st : c->streams) if (st) (void)hipStreamDestroy(st);
     if (c->streams.empty() && c->stream) (void)hipStreamDestroy(c->stream);
+    note("slots");
+    free_slots(c);
+    note("tables and buffers");
+    dev_free(c->d_uxy);
+    dev_free(c->d_wxy);
+    dev_free(c->d_ufrac);
+    dev_free(c->d_wfrac);
+    dev_free(c->d_gamma);
+    dev_free(c->d_cbrt);
+    dev_free(c->d_coef);
+    dev_free(c->d_oxy);
+    dev_free(c->d_ofrac);
+    dev_free(c->d_atlas);
+    dev_free(c->d_advance);
+    dev_free(c->d_lines);
+    dev_free(c->d_xpos);
     note("done");
     delete c;
 }

@@ -56,7 +56,8 @@ def test_closed_contexts_leave_their_memory_in_the_cache_and_the_next_one_reuses
     kept = base - _free_bytes()
     assert used1 > 500e6 and kept > 0.9 * used1              # the closed context's blocks are still the process's
     used2, rec2 = run()                                      # same shape: served from the cache (dirty blocks, same results)
-    assert used2 <= used1 * 1.15                             # (what the first run allocated lazily is in the cache as well)
+    assert used2 <= kept * 1.02                              # nothing new from the driver (what the first run allocated on the way -- the planes only
+                                                             # some paths use -- waits in the cache as well)
     assert rec1.tobytes() == rec2.tobytes()
     nat.device_cache_trim(0)
     assert base - _free_bytes() < 0.25 * used1               # ... until they are handed back (the runtime keeps some of its own)
