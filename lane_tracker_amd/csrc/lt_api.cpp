@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -556,7 +557,7 @@ int make_search_geom(lt_ctx* c, const lt_search_params* p, bool band, SearchGeom
 // runtime's default priority and LT_STREAM_PRIORITY has no effect on it: the priority only serves to put the slices of an
 // independent-batch context on separate hardware queues (contexts that never call lt_set_search_cus), while a stream
 // context runs its slices back to back behind the bus anyway.
-hipError_t create_compute_stream(hipStream_t* st, int reserved) {
+static hipError_t make_compute_stream(hipStream_t* st, int reserved) {
     if (reserved > 0) {
         uint32_t mask[8];
         for (auto& w : mask) w = 0xffffffffu;
@@ -569,6 +570,71 @@ hipError_t create_compute_stream(hipStream_t* st, int reserved) {
         return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, greatest);
 }
+
+// Streams are never destroyed: a context takes them from a per-process pool (by device, kind and CU reservation) and gives them
+// back, idle, when it goes.  hipStreamDestroy can hang on this runtime: destroy one stream and, within a few milliseconds,
+// another one that was created with hipExtStreamCreateWithCUMask -- the second call waits in AMDKFD_IOC_WAIT_EVENTS for good
+// (tools/microbench/close_hang.hip: 9 of 9 runs; with 50 ms between the last work and the destroys, or the masked stream
+// destroyed first, 0 of 8).  That was the close() of NOTES C.8 (round 4's library: 8 of 10 runs of tools/close_hang.py).  No
+// ordering inside lt_destroy is safe against a second tracker's streams, so none is destroyed; a stream that has been idle in
+// the pool is as good as a new one, and lt_create saves 20 ms per priority stream it no longer creates.
+namespace {
+struct StreamPool {
+    struct Key { int device, kind, param; bool operator<(const Key& o) const { return std::tie(device, kind, param) < std::tie(o.device, o.kind, o.param); } };
+    std::mutex m;
+    std::map<Key, std::vector<hipStream_t>> idle;
+    std::map<hipStream_t, Key> out;
+};
+StreamPool& stream_pool() { static StreamPool* p = new StreamPool; return *p; }
+}  // namespace
+
+hipError_t stream_get(hipStream_t* st, StreamKind kind, int param) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    StreamPool& sp = stream_pool();
+    const StreamPool::Key key{dev, (int)kind, param};
+    {
+        std::lock_guard<std::mutex> g(sp.m);
+        auto& v = sp.idle[key];
+        if (!v.empty()) {
+            *st = v.back();
+            v.pop_back();
+            sp.out[*st] = key;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipSuccess;
+    if (kind == SK_COMPUTE) e = make_compute_stream(st, param);
+    else if (kind == SK_PLAIN) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    else if (kind == SK_CU_SET) {        // the first `param` CUs and nothing else (the chained search), or -- param < 0 -- CUs 1 .. -param - 1 (the copy kernel)
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (param >= 0) for (int i = 0; i < param && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
+        else for (int b = 1; b < -param && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+        e = hipExtStreamCreateWithCUMask(st, 8, mask);
+    } else {                             // SK_PRIORITY: the highest priority level
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi);
+    }
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> g(sp.m);
+        sp.out[*st] = key;
+    }
+    return e;
+}
+
+void stream_put(hipStream_t st) {
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    StreamPool& sp = stream_pool();
+    std::lock_guard<std::mutex> g(sp.m);
+    auto it = sp.out.find(st);
+    if (it == sp.out.end()) return;      // not ours: left alone
+    sp.idle[it->second].push_back(st);
+    sp.out.erase(it);
+}
+
+hipError_t create_compute_stream(hipStream_t* st, int reserved) { return stream_get(st, SK_COMPUTE, reserved); }
 
 }  // namespace lt
 
@@ -610,8 +676,8 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     c->streams.assign(1, c->stream);
     c->nstreams = 1;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipEventCreate failed"));
-    if (hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+    if (stream_get(&c->copy, SK_PLAIN, 0) != hipSuccess ||
+        stream_get(&c->side, SK_PLAIN, 0) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
         return bail(fail(LT_ERR_HIP, "side stream / event creation failed"));
@@ -713,14 +779,14 @@ void lt_destroy(lt_ctx* c) {
     if (c->spans_busy.done) (void)hipEventDestroy(c->spans_busy.done);
     if (c->text_busy.done) (void)hipEventDestroy(c->text_busy.done);
     if (c->annot_busy.done) (void)hipEventDestroy(c->annot_busy.done);
-    note("hipStreamDestroy(dl)");
-    if (c->dl) (void)hipStreamDestroy(c->dl);
+    note("streams back to the pool: dl");
+    stream_put(c->dl);
     note("events: download timing");
     for (auto& d : c->dl_inflight) { (void)hipEventDestroy(d.a); (void)hipEventDestroy(d.b); }
     for (auto e : c->dl_event_pool) (void)hipEventDestroy(e);
-    note("hipStreamDestroy(present, urgent)");
-    if (c->present) (void)hipStreamDestroy(c->present);
-    if (c->urgent) (void)hipStreamDestroy(c->urgent);
+    note("streams back to the pool: present, urgent");
+    stream_put(c->present);
+    stream_put(c->urgent);
     if (c->rest_done) (void)hipEventDestroy(c->rest_done);
     note("hipHostFree(spans, lines, xpos)");
     if (c->h_spans) (void)hipHostFree(c->h_spans);
@@ -737,19 +803,18 @@ void lt_destroy(lt_ctx* c) {
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
     if (c->h_cancel) (void)hipHostFree(c->h_cancel);
-    note("hipStreamDestroy(search)");
-    if (c->search) (void)hipStreamDestroy(c->search);
-    note("hipStreamDestroy(copy, side)");
-    if (c->copy) { (void)hipStreamSynchronize(c->copy); (void)hipStreamDestroy(c->copy); }
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    note("streams back to the pool: search, copy, side");
+    stream_put(c->search);
+    stream_put(c->copy);
+    stream_put(c->side);
     note("events: fork, join, timer");
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    note("hipStreamDestroy(slot streams)");
-    for (auto st : c->streams) if (st) (void)hipStreamDestroy(st);
-    if (c->streams.empty() && c->stream) (void)hipStreamDestroy(c->stream);
+    note("streams back to the pool: slot streams");
+    for (auto st : c->streams) stream_put(st);
+    if (c->streams.empty()) stream_put(c->stream);
     note("slots");
     free_slots(c);
     note("tables and buffers");
@@ -1528,18 +1593,18 @@ int lt_set_search_cus(lt_ctx* c, int n) {
     for (size_t i = 0; i < c->streams.size(); ++i) {
         hipStream_t st = nullptr;
         if (create_compute_stream(&st, n) != hipSuccess) {
-            for (auto f : fresh) (void)hipStreamDestroy(f);
+            for (auto f : fresh) stream_put(f);
             return fail(LT_ERR_HIP, "stream with a CU mask could not be created");
         }
         fresh.push_back(st);
     }
-    for (auto st : c->streams) if (st) (void)hipStreamDestroy(st);
+    for (auto st : c->streams) stream_put(st);
     c->streams = fresh;
     c->stream = c->streams.empty() ? c->stream : c->streams[0];
-    if (c->search) { (void)hipStreamDestroy(c->search); c->search = nullptr; }
-    if (c->present) { (void)hipStreamDestroy(c->present); c->present = nullptr; }
-    if (c->urgent) { (void)hipStreamDestroy(c->urgent); c->urgent = nullptr; c->urgent_on = false; }
-    if (c->dl) { (void)hipStreamDestroy(c->dl); c->dl = nullptr; }
+    stream_put(c->search); c->search = nullptr;
+    stream_put(c->present); c->present = nullptr;
+    stream_put(c->urgent); c->urgent = nullptr; c->urgent_on = false;
+    stream_put(c->dl); c->dl = nullptr;
     c->search_cus = n;
     c->rec_mirror_slot = -1;             // the stream the mirror of a one-frame search was queued on is gone
     c->rec_mirror_stream = nullptr;

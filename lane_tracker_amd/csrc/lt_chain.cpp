@@ -28,10 +28,8 @@ namespace lt {
 int ensure_search_stream(lt_ctx* c) {
     if (c->search) return LT_OK;
     if (c->search_cus > 0) {                  // the CUs the slots' streams were kept off (lt_set_search_cus)
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const int mine = c->search_cus >= 2 ? 1 : c->search_cus;   // with two or more, the others are the download stream's
-        for (int i = 0; i < mine && i < 256; ++i) mask[i >> 5] |= 1u << (i & 31);
-        HIP_TRY(hipExtStreamCreateWithCUMask(&c->search, 8, mask));
+        HIP_TRY(stream_get(&c->search, SK_CU_SET, mine));
     } else HIP_TRY(create_compute_stream(&c->search));
     return LT_OK;
 }

@@ -256,6 +256,7 @@ int flush_stage_events(lt_ctx* c);
 int check_slots(lt_ctx* c, int first, int n);
 int set_device(lt_ctx* c);
 hipError_t create_compute_stream(hipStream_t* st, int reserved = 0);
+// (stream_get / stream_put -- the per-process stream pool -- are declared in lt_internal.h)
 int download(lt_ctx* c, const void* src, void* dst, size_t bytes);
 int ensure_bev(lt_ctx* c);
 int ensure_plane(lt_ctx* c, int idx);

@@ -197,7 +197,7 @@ int lt_gather_init(lt_ctx* ctx, int rank, int world, const char* id_path, int ti
         lt_gather_destroy(g);
         return set_error(LT_ERR_STATE, "RCCL communicator has %d ranks, expected %d", count, world);
     }
-    if (hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (stream_get(&g->stream, SK_PLAIN, 0) != hipSuccess) {
         lt_gather_destroy(g);
         return set_error(LT_ERR_HIP, "hipStreamCreate failed");
     }
@@ -315,7 +315,7 @@ void lt_gather_destroy(lt_gather* g) {
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(g->comm);
     for (auto e : g->events) (void)hipEventDestroy(e);
-    if (g->stream) (void)hipStreamDestroy(g->stream);
+    stream_put(g->stream);       // (no stream of the library is ever destroyed: lt_api.cpp, StreamPool)
     if (g->d_send) (void)hipFree(g->d_send);
     if (g->d_recv) (void)hipFree(g->d_recv);
     if (g->h_recv) (void)hipHostFree(g->h_recv);

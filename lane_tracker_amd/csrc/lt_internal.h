@@ -203,5 +203,9 @@ int ctx_device(lt_ctx* c);
 int ctx_streams(lt_ctx* c, hipStream_t* out, int cap);        // the streams the slots currently run on; returns the count
 int ctx_sync(lt_ctx* c);
 int ctx_enqueue_records(lt_ctx* c, int first, int n, lt_lane_record* dst_device);
+// every stream of the library comes from a per-process pool and goes back to it idle: none is ever destroyed (lt_api.cpp, StreamPool)
+enum StreamKind { SK_COMPUTE = 0, SK_PLAIN, SK_CU_SET, SK_PRIORITY };
+hipError_t stream_get(hipStream_t* st, StreamKind kind, int param);
+void stream_put(hipStream_t st);
 
 }  // namespace lt

@@ -188,11 +188,7 @@ int warm_presentation(lt_ctx* c, bool strips) {
     if (strips) {
         if ((rc = ensure_strips(c))) return rc;
     } else if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
-    if (!c->dl) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
-    }
+    if (!c->dl) HIP_TRY(stream_get(&c->dl, SK_PRIORITY, 0));
     return LT_OK;
 }
 }  // namespace lt
@@ -406,11 +402,7 @@ int lt_strip_download_async(lt_ctx* c, int first, int n, uint8_t* out, size_t ou
     if (out_frame_stride < c->frame_bytes) return fail(LT_ERR_INVALID, "frame stride below the frame size");
     if (n == 0 || c->strip_bytes == 0) return LT_OK;
     if ((rc = set_device(c))) return rc;
-    if (!c->dl) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
-    }
+    if (!c->dl) HIP_TRY(stream_get(&c->dl, SK_PRIORITY, 0));
     hipEvent_t e = next_order_event(c);
     if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");
     HIP_TRY(hipEventRecord(e, c->present));
@@ -709,15 +701,10 @@ static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out
     // on a stream of its own, behind the overlay work enqueued so far: the copy neither holds up the kernels queued behind
     // it on the context's stream nor shares a queue with the uploads
     if (!c->dl) {
-        if (c->search_cus >= 2) {                  // the reserved CUs but the first are the copy kernel's (lt_set_search_cus)
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = 1; b < c->search_cus && b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
-            HIP_TRY(hipExtStreamCreateWithCUMask(&c->dl, 8, mask));
-        } else {                                   // highest priority: the copy kernel's few workgroups go ahead of the mask kernels'
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            HIP_TRY(hipStreamCreateWithPriority(&c->dl, hipStreamNonBlocking, hi));
-        }
+        // the reserved CUs but the first are the copy kernel's (lt_set_search_cus); otherwise the highest priority: the copy kernel's
+        // few workgroups go ahead of the mask kernels'
+        if (c->search_cus >= 2) HIP_TRY(stream_get(&c->dl, SK_CU_SET, -c->search_cus));
+        else HIP_TRY(stream_get(&c->dl, SK_PRIORITY, 0));
     }
     hipEvent_t e = next_order_event(c);
     if (!e) return fail(LT_ERR_HIP, "hipEventCreate failed");

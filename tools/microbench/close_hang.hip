@@ -10,6 +10,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 #include <vector>
 
 __global__ void touch(uint4* p, size_t n, int rounds) {
@@ -33,6 +34,9 @@ int main(int argc, char** argv) {
     const double gb = argc > 2 ? atof(argv[2]) : 1.4;
     const int blocks = argc > 3 ? atoi(argv[3]) : 16;
     const int order = argc > 4 ? atoi(argv[4]) : 0;
+    // variations (bit flags): 1 = no priority stream at all; 2 = the masked streams are destroyed BEFORE the priority stream;
+    // 4 = hipDeviceSynchronize() in front of the destroys; 8 = the plain stream is destroyed first; 16 = 50 ms pause in front
+    const int mode = argc > 5 ? atoi(argv[5]) : 0;
     const size_t bytes = (size_t)(gb * (1u << 30));
     for (int r = 0; r < rounds; ++r) {
         std::printf("== round %d\n", r);
@@ -45,7 +49,8 @@ int main(int argc, char** argv) {
         STEP("hipExtStreamCreateWithCUMask(CU 0)", hipExtStreamCreateWithCUMask(&one_cu, 8, m_one));
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);
-        STEP("hipStreamCreateWithPriority", hipStreamCreateWithPriority(&prio, hipStreamNonBlocking, hi));
+        if (mode & 1) STEP("hipStreamCreate(instead of the priority stream)", hipStreamCreateWithFlags(&prio, hipStreamNonBlocking));
+        else STEP("hipStreamCreateWithPriority", hipStreamCreateWithPriority(&prio, hipStreamNonBlocking, hi));
         std::vector<void*> p((size_t)blocks, nullptr);
         for (int i = 0; i < blocks; ++i)
             if (hipMalloc(&p[i], bytes) != hipSuccess) { std::printf("hipMalloc %d failed\n", i); return 1; }
@@ -65,10 +70,14 @@ int main(int argc, char** argv) {
             }
         };
         auto destroy_all = [&] {
-            STEP("hipStreamDestroy(prio)", hipStreamDestroy(prio));
+            if (mode & 4) STEP("hipDeviceSynchronize", hipDeviceSynchronize());
+            if (mode & 16) std::this_thread::sleep_for(std::chrono::milliseconds(50));
+            if (mode & 8) STEP("hipStreamDestroy(plain)", hipStreamDestroy(plain));
+            if (!(mode & 2)) STEP("hipStreamDestroy(prio)", hipStreamDestroy(prio));
             STEP("hipStreamDestroy(masked: all but CU 0)", hipStreamDestroy(masked));
             STEP("hipStreamDestroy(masked: CU 0)", hipStreamDestroy(one_cu));
-            STEP("hipStreamDestroy(plain)", hipStreamDestroy(plain));
+            if (mode & 2) STEP("hipStreamDestroy(prio)", hipStreamDestroy(prio));
+            if (!(mode & 8)) STEP("hipStreamDestroy(plain)", hipStreamDestroy(plain));
         };
         if (order == 0) { free_all(); destroy_all(); } else { destroy_all(); free_all(); }
         STEP("hipHostFree", hipHostFree(host));
