@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling, same guide
 MASK_STAGES = ["undistort_rows", "warp_split", "erode_r29", "tophat_r29", "erode_b55", "tophat_b55", "threshold",
                "merge", "open5"]
-PROFILE_TAG = "r04"            # profiles/<tag>_traffic.json, <tag>_kernel_stats_summary.json: the committed counter run of this code
+PROFILE_TAG = "r05"            # profiles/<tag>_traffic.json, <tag>_kernel_stats_summary.json: the committed counter run of this code
 CALIB_TAG = "r02"              # profiles/<tag>_valu_issue.json, <tag>_fetch_calib.json: the issue-rate / counter calibrations (hardware facts)
 
 

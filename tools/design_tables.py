@@ -114,8 +114,8 @@ def main():
     txt = open(design).read()
     new = txt
     for name, body in t.items():
-        pat = re.compile(r"(<!-- bench:%s -->\n).*?(\n<!-- /bench:%s -->)" % (name, name), re.S)
-        new = pat.sub(lambda m: m.group(1) + body + m.group(2), new)
+        pat = re.compile(r"(<!-- bench:%s -->)\n.*?(<!-- /bench:%s -->)" % (name, name), re.S)
+        new = pat.sub(lambda m: m.group(1) + "\n" + body + "\n" + m.group(2), new)
     if "--check" in sys.argv:
         if new != txt:
             print("DESIGN.md is out of date with", os.path.relpath(path, ROOT))
