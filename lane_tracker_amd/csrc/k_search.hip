@@ -1182,9 +1182,10 @@ constexpr int C3_VALUES = 18;     // per side: 8 moments + (rows << 32 | pixels)
 __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, const lt_lane_record* __restrict__ seed_rec, BandPrev seed,
                                                    uint32_t* __restrict__ pix_all, lt_lane_record* __restrict__ recs, int n,
                                                    const int* cancel_epoch, int my_epoch, int prio, int ablate_arg,
-                                                   lt_lane_record* __restrict__ mirror) {
-    // mirror (a chain of one, launch_band_fit_one): page-locked host memory that gets a copy of the record, so that the host
-    // reads it as soon as this kernel has ended
+                                                   lt_lane_record* __restrict__ mirror, unsigned mirror_ticket) {
+    // mirror (a chain of one, launch_band_fit_one): page-locked host memory that gets a copy of the record and, behind it (a
+    // system-scope fence in between), the launch's ticket -- the host polls that word and has the record the moment it is
+    // written, without waiting for the end-of-kernel interrupt (tools/microbench/sync_latency.hip)
     // Timing probes of tools/stream_interference.py, in a build with -DLT_CHAIN_PROBES only (WRONG results): ablate bit 1 no
     // pixel-block stores, 2 no bit-plane loads, 4 no f64 band evaluation, 8 no solve, 16 no reduction; prio = wave priority.
     // The product build compiles them out (ablate is the constant 0, the priority the constant 3).
@@ -1318,7 +1319,11 @@ __global__ __launch_bounds__(CT) void k_band_chain3(MaskBits mb, SearchGeom g, c
             r._pad = 2;               // per-row column masks (k_band_fit2's format)
             r.frame = recs[f].frame;  // keep the caller's tag
             recs[f] = r;
-            if (mirror) mirror[f] = r;
+            if (mirror) {
+                mirror[f] = r;
+                __threadfence_system();
+                *reinterpret_cast<volatile unsigned*>(mirror + 1) = mirror_ticket;
+            }
             for (int k = 0; k < 3; ++k) { carry[k] = r.left_coeffs[k]; carry[3 + k] = r.right_coeffs[k]; }
             carry[6] = detected && flags == 0 ? 1.0 : 0.0;
         }
@@ -1493,12 +1498,12 @@ bool band_chain_supported(const SearchGeom& g, size_t mask_stride) { return band
 // `zero` = any readable device word (the chain's cancel flag; a chain of one never looks at it again); `mirror` = nullptr or
 // device-visible page-locked memory for a copy of the record.  false: not launched.
 bool launch_band_fit_one(hipStream_t s, MaskBits mb, SearchGeom g, const BandPrev& bp, uint32_t* pix, lt_lane_record* rec,
-                         size_t mask_stride, const int* zero, lt_lane_record* mirror) {
+                         size_t mask_stride, const int* zero, lt_lane_record* mirror, unsigned mirror_ticket) {
     static const bool big3 = allow_big_lds(k_band_chain3);
     if (!mb.bits || !bp.by_value || !big3 || g.h > 8192 || !band2_eligible(g, mask_stride)) return false;
     const size_t lds3 = (size_t)C3_VALUES * CT * sizeof(long long);
     hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, (const lt_lane_record*)nullptr, bp, pix, rec, 1, zero, 0x7fffffff,
-                       3, 0, mirror);
+                       3, 0, mirror, mirror_ticket);
     return true;
 }
 
@@ -1519,7 +1524,7 @@ void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, 
         constexpr int prio = 3, ablate = 0;
 #endif
         hipLaunchKernelGGL(k_band_chain3, dim3(1), dim3(CT), lds3, s, mb, g, seed_rec, seed, pix, rec, n, cancel_epoch, my_epoch, prio, ablate,
-                           (lt_lane_record*)nullptr);
+                           (lt_lane_record*)nullptr, 0u);
         return;
     }
     if (mb.bits) hipLaunchKernelGGL(k_band_chain2<true>, dim3(1), dim3(NT), lds2, s, masks, mask_stride, mb, g, seed_rec, seed, pix, rec, nq, n, cancel_epoch, my_epoch);

@@ -875,6 +875,166 @@ __global__ __launch_bounds__(64 * LT_MORPH_WPB) LT_MORPH_WAVES_ATTR void k_morph
     }
 }
 
+// ================================================================================================
+// One or two frames per launch (process(): one frame per call, the host waiting for its record).
+//
+// k_morph_runs2 at one frame is a few hundred waves, each alone on its SIMD, walking band_rows + 2R rows one dependent row
+// pair after the other (0.85 us per pair at one wave per SIMD: profiles/NOTES_r05.md D.4) -- and the walk cannot be shorter
+// than the halo, 2R rows, however short the band.  Here the walk of a (strip, band) task is split over the Q waves of a
+// workgroup BY ROW PAIRS: wave q takes the pairs q, q + Q, q + 2Q, ... of the task's rows.  Each wave runs the horizontal part
+// of its own pairs only (nothing is computed twice) and keeps a vertical pipeline of its own, which now moves by 2Q rows per
+// step instead of two:
+//     A'[j] = op(A[j + 2Q], Ha[slot(j + 1)], Hb[slot(j)]),     j = -1 .. K - 1
+// so that after a step the wave's positions -1 .. 2Q - 2 are final AS FAR AS ITS OWN ROWS GO: partial results of 2Q output
+// rows.  The min / max over the Q waves' partials is the output row.  Partials travel through a ring of rows in LDS (one
+// dword per lane, row and wave); after the step's barrier the rows all Q waves have delivered are combined, two rows per wave,
+// and stored.  A task's dependent chain is (band_rows + 2R) / 2Q steps instead of (band_rows + 2R) / 2.
+//
+// Which rows are complete after step t.  Offsets o count rows from the first output row any wave can complete,
+// yb0 - 2R.  Wave q's pair of step t is rows y_first + 2 (t Q + q) (+1), and it delivers the offsets 2Q t + 2q .. 2Q t + 2q + 2Q - 1.
+// So once every wave has finished step t the offsets 2Q t .. 2Q t + 2Q - 1 are there from all of them (the first 2q of
+// them from wave q's step t - 1).  Offsets below 2R lie above the band and are never stored, which covers t = 0.  The ring
+// holds 3 x 2Q rows: a wave that is already writing step t + 1 (offsets < 2Q (t + 3) - 2) while another one still combines step t
+// touches none of its rows, and nobody gets further ahead than that (one barrier per step).
+//
+// Borders are clamped as in k_morph_runs2; the argument there needs only that an SE row above the image is narrower than the
+// one that lands on row 0, which does not depend on who accumulates which rows.
+template <class SE, bool DIL, bool TH, int Q>
+__global__ __launch_bounds__(64 * Q) void k_morph_one(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      const uint8_t* __restrict__ minuend, RunsGeom g) {
+    constexpr int K = SE::K, R = SE::R, NH = SE::NH, S = 2 * Q, RING = 3 * S;
+    static_assert(S - 1 <= K - 1, "the pipeline must be longer than a step");
+    __shared__ uint2 s_chain[Q][4 * PLANE];   // S0, S1, S4, S13 per wave
+    __shared__ uint32_t s_ring[Q][RING][64];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int task = blockIdx.x;
+    if (!LT_MORPH_BIAS) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);   // f16 denormals kept (see k_morph_runs2)
+    const int strip = task % g.nstrips;
+    const int band = (task / g.nstrips) % g.nbands;
+    const int frame = task / (g.nstrips * g.nbands);
+    const uint8_t* s = src + (size_t)frame * g.plane_stride;
+    uint8_t* d = dst + (size_t)frame * g.dst_stride;
+    const uint8_t* m = TH ? minuend + (size_t)frame * g.plane_stride : nullptr;
+    uint2* chain = s_chain[wv];
+    const int x0 = strip * 128;
+    const int yb0 = band * g.band_rows, yb1 = min(yb0 + g.band_rows, g.h);
+    const int xa = x0 + lane, xb = xa + 64;
+    const bool va = xa < g.w, vb = xb < g.w;
+    const int oa = min(xa, g.w - 1), ob = min(xb, g.w - 1);
+    const int y_first = yb0 - R, y_base = yb0 - 2 * R;
+    const int npairs = (yb1 - yb0 + 2 * R + 1) / 2, nsteps = (npairs + Q - 1) / Q;
+    // the three source columns of a lane (entry 0 = columns (a, b), entry 1 = (b, c)), clamped into the image; rows are 4-byte
+    // aligned (the launcher checks): a pixel arrives as the aligned dword that holds it and one v_perm_b32 per entry picks the two
+    // pixels into the 16-bit halves (as in morph_task)
+    const int c0 = x0 - R + lane;
+    const uint32_t col_a = (uint32_t)min(max(c0, 0), g.w - 1), col_b = (uint32_t)min(max(c0 + 64, 0), g.w - 1), col_c = (uint32_t)min(max(c0 + 128, 0), g.w - 1);
+    constexpr int RSRC_RAW = 0x00027000;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(s), 0, g.h * g.w, RSRC_RAW);
+    auto row_off = [&](int y) { return __mul24(min(max(y, 0), g.h - 1), g.w); };
+    const uint32_t sel_ab = 0x0c000c00u | ((4u + (col_b & 3u)) << 16) | (col_a & 3u);
+    const uint32_t sel_bc = 0x0c000c00u | ((4u + (col_c & 3u)) << 16) | (col_b & 3u);
+    struct Raw { uint32_t a, b, c; };
+    auto load_row = [&](int y) __attribute__((always_inline)) {
+        const int ro = row_off(y);
+        Raw r;
+        r.a = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_a & ~3u), ro, 0);
+        r.b = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_b & ~3u), ro, 0);
+        r.c = __builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(col_c & ~3u), ro, 0);
+        return r;
+    };
+    auto combine = [&](const Raw& r, uint32_t& e0, uint32_t& e1) __attribute__((always_inline)) {
+        asm volatile("v_perm_b32 %0, %3, %2, %5\n\tv_perm_b32 %1, %4, %3, %6" : "=&v"(e0), "=&v"(e1) : "v"(r.a), "v"(r.b), "v"(r.c), "v"(sel_ab), "v"(sel_bc));
+        if (LT_MORPH_BIAS) { e0 |= BIAS2; e1 |= BIAS2; }
+    };
+    constexpr uint32_t NEUTRAL = (DIL ? 0u : 0x00ff00ffu) | BIAS2;
+    uint32_t A[K + 1];                       // position j = -1 .. K - 1 at index j + 1
+#pragma unroll
+    for (int p = 0; p <= K; ++p) A[p] = NEUTRAL;
+    uint32_t ea0, ea1, eb0, eb1;             // the entries of this wave's next row pair
+    {
+        const int yy = y_first + 2 * wv;
+        combine(load_row(yy), ea0, ea1);
+        combine(load_row(yy + 1), eb0, eb1);
+    }
+    const uint32_t s0_rd = (uint32_t)(uintptr_t)(chain + MARGIN + ((R + lane) & 63));
+    for (int t = 0; t < nsteps; ++t) {
+        const int yy = y_first + 2 * (t * Q + wv);            // this wave's pair of the step: rows yy, yy + 1
+        const uint2 e_pa = make_uint2(ea0, eb0);
+        const uint2 e_pb = make_uint2(ea1, eb1);
+        chain[MARGIN + lane] = lane < R ? e_pb : e_pa;        // plane 0 holds the 64 entries the half-width-0 window reads (row_windows2)
+        wave_lds_fence();
+        const Raw ra = load_row(yy + S), rb = load_row(yy + S + 1);
+        // the two output rows this wave combines and stores after the barrier, and their minuend
+        const int o0 = S * t + 2 * wv, yo = y_base + o0;
+        uint32_t m0a = 0, m0b = 0, m1a = 0, m1b = 0;
+        if (TH) {
+            const uint8_t* r0 = m + (size_t)min(max(yo, 0), g.h - 1) * g.w;
+            const uint8_t* r1 = m + (size_t)min(max(yo + 1, 0), g.h - 1) * g.w;
+            m0a = r0[oa]; m0b = r0[ob];
+            m1a = r1[oa]; m1b = r1[ob];
+        }
+        uint32_t Ha[NH], Hb[NH];
+        row_windows2<SE, DIL, false>(chain, lane, e_pa, e_pb, s0_rd, Ha, Hb);
+        wave_lds_fence();                                     // the chain planes are rewritten by the next step
+        uint32_t An[K + 1];
+#pragma unroll
+        for (int p = 0; p <= K; ++p) {
+            const int j = p - 1;
+            const bool prev = j + S <= K - 1, ha = j <= K - 2, hb = j >= 0;
+            // (the slot indices are clamped for the compiler's sake where the operand does not exist)
+            const uint32_t va_ = Ha[SE::slot(j + 1 <= K - 1 ? j + 1 : K - 1)], vb_ = Hb[SE::slot(j >= 0 ? j : 0)];
+            const uint32_t vp = A[prev ? p + S : K];
+            An[p] = prev && ha && hb ? op3<DIL>(vp, va_, vb_) : prev && ha ? op2<DIL>(vp, va_) : ha && hb ? op2<DIL>(va_, vb_) : vb_;
+        }
+        // positions -1 .. S - 2 are this wave's share of the output rows at offsets o0 .. o0 + S - 1
+        {
+            int slot = o0 % RING;
+#pragma unroll
+            for (int q = 0; q < S; ++q) {
+                s_ring[wv][slot][lane] = An[q];
+                slot = slot + 1 == RING ? 0 : slot + 1;
+            }
+        }
+#pragma unroll
+        for (int p = S; p <= K; ++p) A[p] = An[p];
+        __syncthreads();
+        {
+            const int sl0 = o0 % RING, sl1 = sl0 + 1 == RING ? 0 : sl0 + 1;
+            uint32_t v0 = s_ring[0][sl0][lane], v1 = s_ring[0][sl1][lane];
+#pragma unroll
+            for (int q = 1; q < Q; ++q) {
+                v0 = op2<DIL>(v0, s_ring[q][sl0][lane]);
+                v1 = op2<DIL>(v1, s_ring[q][sl1][lane]);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int y = yo + rr;
+                if (y >= yb0 && y < yb1) {                    // wave-uniform
+                    const uint32_t v = rr == 0 ? v0 : v1;
+                    uint32_t pa = v & 0xffu, pb = (v >> 16) & 0xffu;
+                    if (TH) {                                 // src - open(src), never negative
+                        pa = (rr == 0 ? m0a : m1a) - pa;
+                        pb = (rr == 0 ? m0b : m1b) - pb;
+                    }
+                    const size_t o = (size_t)y * g.dpitch;
+                    if (va) d[o + xa] = (uint8_t)pa;
+                    if (vb) d[o + xb] = (uint8_t)pb;
+                }
+            }
+        }
+        combine(ra, ea0, ea1);
+        combine(rb, eb0, eb1);
+    }
+}
+
+template <class SE, int Q>
+void launch_one(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, bool dilate, const RunsGeom& g) {
+    const dim3 grid(g.ntasks), block(64 * Q);
+    if (dilate && minuend) hipLaunchKernelGGL((k_morph_one<SE, true, true, Q>), grid, block, 0, s, src, dst, minuend, g);
+    else if (dilate) hipLaunchKernelGGL((k_morph_one<SE, true, false, Q>), grid, block, 0, s, src, dst, minuend, g);
+    else hipLaunchKernelGGL((k_morph_one<SE, false, false, Q>), grid, block, 0, s, src, dst, minuend, g);
+}
+
 template <class SE>
 bool table_matches(const EllipseSE& se) {
     if (se.k != SE::K) return false;
@@ -899,6 +1059,27 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     static const bool narrow = [] { const char* e = std::getenv("LT_MORPH_WIDE"); return e && e[0] == '0'; }();
     const bool wide = !narrow && (w & 3) == 0 && (plane_stride & 3) == 0 && w >= 4 && (g.dpitch & 3) == 0 && (g.dst_stride & 3) == 0 &&
                       ((uintptr_t)dst & 3) == 0 && ((uintptr_t)minuend & 3) == 0;
+    // One or two frames: the walk of a task split over the waves of a workgroup (k_morph_one).  LT_MORPH_ONE=0: k_morph_runs2 as
+    // for any other frame count (A/B, tests); =8: eight waves per task.  LT_MORPH_ONE_WGS: workgroups per launch to aim for.
+    static const int one_q = [] { const char* e = std::getenv("LT_MORPH_ONE"); return e ? std::atoi(e) : 4; }();
+    if (n <= 2 && (one_q == 4 || one_q == 8) && !one_row && wide && !copy_dst && ((uintptr_t)src & 3) == 0) {
+        static const int want_wgs = [] { const char* e = std::getenv("LT_MORPH_ONE_WGS"); return e ? std::atoi(e) : 0; }();
+        int cus1 = 256, dev1 = 0;
+        (void)hipGetDevice(&dev1);
+        (void)hipDeviceGetAttribute(&cus1, hipDeviceAttributeMultiprocessorCount, dev1);
+        const int target = want_wgs > 0 ? want_wgs : 2 * cus1;
+        int nb = std::max(1, target / std::max(1, n * g.nstrips));
+        int rows = std::max((h + nb - 1) / nb, 8);
+        rows = (rows + 1) & ~1;
+        g.band_rows = rows;
+        g.nbands = (h + rows - 1) / rows;
+        g.nstrips_normal = g.nstrips;
+        g.ntasks = g.n_normal = n * g.nstrips * g.nbands;
+        g.xcd = 0;
+        if (one_q == 8) launch_one<SE, 8>(s, src, dst, minuend, dilate, g);
+        else launch_one<SE, 4>(s, src, dst, minuend, dilate, g);
+        return true;
+    }
     // Band count: every task walks band_rows + 2R rows, and the chip holds `slots` waves at once, so
     // the makespan is ~ ceil(tasks / slots) * (band_rows + 2R).  Pick the band count that minimises
     // it (a grid of 2.25 rounds costs 3 rounds); bands no shorter than 2R keep the halo overhead sane.

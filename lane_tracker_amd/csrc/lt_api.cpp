@@ -2,6 +2,7 @@
 // Owns the context: HIP stream, calibration tables, frame slots; sequences the kernel chain of
 // LaneTracker.find_lane_points() (lane_tracker.py:795-874) for a batch of independent frames.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1276,6 +1277,9 @@ static lt_lane_record* rec_mirror_device(lt_ctx* c) {      // the mirror as kern
     if (!c->h_rec && hipHostMalloc(reinterpret_cast<void**>(&c->h_rec), 256, hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
         c->h_rec = nullptr;
+    } else if (c->h_rec && !c->rec_ticket_counter) {
+        std::memset(c->h_rec, 0, 256);       // (the ticket word behind the record: no stale match)
+        c->rec_ticket_counter = 1;
     }
     void* dev = nullptr;
     if (!c->h_rec || hipHostGetDevicePointer(&dev, c->h_rec, 0) != hipSuccess) {
@@ -1286,6 +1290,7 @@ static lt_lane_record* rec_mirror_device(lt_ctx* c) {      // the mirror as kern
 }
 static void mirror_record(lt_ctx* c, hipStream_t st, int slot) {
     c->rec_mirror_slot = -1;
+    c->rec_ticket = 0;
     if (rec_mirror_device(c) && launch_copy_words_to_pinned(st, c->h_rec, c->d_rec + slot, sizeof(lt_lane_record))) {
         c->rec_mirror_slot = slot;
         c->rec_mirror_stream = st;
@@ -1297,7 +1302,21 @@ int lt_download_records(lt_ctx* c, int first, int n, lt_lane_record* out) {
     if (rc) return rc;
     if (n == 1 && out && c->rec_mirror_slot == first && c->h_rec) {
         if ((rc = set_device(c))) return rc;
-        HIP_TRY(hipStreamSynchronize(c->rec_mirror_stream));
+        // The search kernel stores its ticket behind the record: poll for it (hipStreamSynchronize returns 15-20 us after the
+        // kernel's last store, the word is there within 2: tools/microbench/sync_latency.hip).  LT_RECORD_POLL=0: wait for the
+        // stream (A/B); after 2 ms without the ticket likewise (an error would show there).
+        static const bool poll = [] { const char* e = std::getenv("LT_RECORD_POLL"); return !(e && e[0] == '0'); }();
+        bool seen = false;
+        if (poll && c->rec_ticket) {
+            const volatile unsigned* word = reinterpret_cast<const volatile unsigned*>(c->h_rec + 1);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; !(seen = *word == c->rec_ticket); ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(c->rec_mirror_stream));
         std::memcpy(out, c->h_rec, sizeof(lt_lane_record));
         return LT_OK;
     }
@@ -1550,12 +1569,15 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
         // one frame (process()): the chain kernel with a chain of one, a third of the latency (LT_BAND_ONE=0: k_band_fit2)
         const char* one_env = n == 1 ? std::getenv("LT_BAND_ONE") : nullptr;
         lt_lane_record* mirror = n == 1 ? rec_mirror_device(c) : nullptr;
+        unsigned ticket = ++c->rec_ticket_counter;
+        if (!ticket) ticket = ++c->rec_ticket_counter;      // 0 means "no ticket"
         if (n == 1 && !(one_env && one_env[0] == '0') &&
             launch_band_fit_one(st, mb, g, bp, c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, c->plane_bytes,
-                                reinterpret_cast<const int*>(c->d_prev), mirror)) {
-            if (mirror) {                    // the kernel itself leaves a copy of the record in page-locked memory
+                                reinterpret_cast<const int*>(c->d_prev), mirror, ticket)) {
+            if (mirror) {                    // the kernel itself leaves a copy of the record in page-locked memory, and its ticket
                 c->rec_mirror_slot = f0;
                 c->rec_mirror_stream = st;
+                c->rec_ticket = ticket;
             }
         } else {
             launch_band_fit(st, c->d_plane[P_MASK] + (size_t)f0 * c->plane_bytes, c->plane_bytes, mb, g, c->d_prev + (size_t)f0 * 6, bp,

@@ -185,6 +185,9 @@ struct lt_ctx {
     lt_lane_record* h_rec = nullptr;          // page-locked mirror of the record of the last ONE-frame search (mirror_record)
     int rec_mirror_slot = -1;                 // the slot whose record the mirror holds once rec_mirror_stream is idle; -1: none
     hipStream_t rec_mirror_stream = nullptr;
+    // the kernel that fills the mirror stores this ticket behind the record (k_band_chain3): lt_download_records polls for it
+    // instead of waiting for the stream (0: the mirror is filled by a copy launch, wait for the stream)
+    unsigned rec_ticket = 0, rec_ticket_counter = 0;
     lt_lane_record* h_rec_stage = nullptr;    // capacity records
     int h_rec_stage_cap = 0;
     // timing

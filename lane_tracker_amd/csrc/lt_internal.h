@@ -190,7 +190,7 @@ void launch_band_fit(hipStream_t s, const uint8_t* masks, size_t mask_stride, Ma
 // the first frame around `seed` (by value) or, with seed.by_value == 0, around the fit in *seed_rec (device memory)
 bool band_chain_supported(const SearchGeom& g, size_t mask_stride);
 bool launch_band_fit_one(hipStream_t s, MaskBits mb, SearchGeom g, const BandPrev& bp, uint32_t* pix, lt_lane_record* rec,
-                         size_t mask_stride, const int* zero, lt_lane_record* mirror);
+                         size_t mask_stride, const int* zero, lt_lane_record* mirror, unsigned mirror_ticket);
 void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, MaskBits mb, SearchGeom g, const lt_lane_record* seed_rec,
                        const BandPrev& seed, uint32_t* pix, lt_lane_record* rec, int n, const int* cancel_epoch, int my_epoch);
 

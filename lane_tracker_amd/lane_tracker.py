@@ -252,7 +252,9 @@ class LaneTracker(StreamPipeline):
         self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
                               diagnostics)
 
-    def _search_uploaded(self, ctx, mode, kw, diagnostics, slot=0, lazy=False):
+    def _search_uploaded(self, ctx, mode, kw, diagnostics, slot=0, lazy=False, between=None):
+        """Launch the search over the mask in `slot` and collect its record; `between` (a callable) runs after the launch and
+        before the wait -- host work that hides under the device's."""
         if self._pending is not None and self._pending[0] is ctx and self._pending[1] == slot:
             self._materialise_pixels()       # this search reuses the slot whose lists were not fetched yet
         if mode == 'sws' and self._pending_cent is not None and self._pending_cent[0] is ctx and self._pending_cent[1] == slot:
@@ -263,6 +265,8 @@ class LaneTracker(StreamPipeline):
             prev = np.concatenate([np.asarray(self.last_left_coeffs, np.float64).reshape(3),
                                    np.asarray(self.last_right_coeffs, np.float64).reshape(3)])
             ctx.band_fit_run(1, prev, _native.search_params(**kw), first=slot)
+        if between is not None:
+            between()
         self._collect_search(ctx, want_centroids=(mode == 'sws'), slot=slot, lazy=lazy)
         if diagnostics:
             print("Lane pixels found." if self.detected_pixels else "No lane pixels found.")
@@ -690,17 +694,20 @@ class LaneTracker(StreamPipeline):
         if not have_mask:
             ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
                                                   ksize_noise, C_noise), first=slot)
-        if self._want_out and self._out is None:
-            self._prepare_out()          # the output array; its untouched rows start to fill on the library's copy thread
-        if not reuse_frame:
-            # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
-            rows = self._rows_for(img) if self._want_out else None
-            if rows is not None and rows[4] is not None:
-                if rows[4][4]:           # (rows of the lane's run the mask chain does not read: none with the reference calibration)
-                    self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=rows[4][1])
-            else:
-                self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
-            self._resident_partial = rows is not None
+
+        def while_the_device_searches():
+            # behind the search's launch (the device has the whole chain queued; the host's share of the frame must not delay it)
+            if self._want_out and self._out is None:
+                self._prepare_out()          # the output array; its untouched rows start to fill on the library's copy thread
+            if not reuse_frame:
+                # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
+                rows = self._rows_for(img) if self._want_out else None
+                if rows is not None and rows[4] is not None:
+                    if rows[4][4]:           # (rows of the lane's run the mask chain does not read: none with the reference calibration)
+                        self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=rows[4][1])
+                else:
+                    self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
+                self._resident_partial = rows is not None
         if self.last_detection > self.n_reset:                       # :851
             if diagnostics:
                 print("Using sliding window search.")
@@ -708,12 +715,13 @@ class LaneTracker(StreamPipeline):
                                                    search_range=search_range, mu=mu,
                                                    no_success_limit=no_success_limit, start_slice=start_slice,
                                                    ignore_sides=ignore_sides, ignore_bottom=ignore_bottom,
-                                                   partial=partial), diagnostics, slot=slot, lazy=lazy)
+                                                   partial=partial), diagnostics, slot=slot, lazy=lazy,
+                                  between=while_the_device_searches)
             return 'sws'
         if diagnostics:
             print("Using band search.")
         self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
-                              diagnostics, slot=slot, lazy=lazy)
+                              diagnostics, slot=slot, lazy=lazy, between=while_the_device_searches)
         return 'bs'
 
     # ---- the two outcomes of a frame (reference :1142-1159, :1178-1202) ------------------------------------------

@@ -347,6 +347,20 @@ def test_morph_ellipse_operators(ctx, oracle, k, shape):
     assert_same(ctx.morph_ellipse(img, k, "erode", direct=True), oracle.erode(img, k), f"direct erode {k} {shape}")
 
 
+@pytest.mark.parametrize("k", [29, 55])
+def test_one_frame_morphology_at_full_size_against_direct_taps(ctx, k):
+    """The one-frame kernels (k_morph_one: the walk of a band split over the waves of a workgroup) on a whole bird's-eye plane,
+    and on sizes whose last band / last strip are ragged, against the direct evaluation of the footprint on the same device
+    (itself held against the oracle by test_morph_ellipse_operators)."""
+    for shape in ((1100, 1080), (1650, 1620), (333, 516), (61, 132)):
+        rng = np.random.default_rng(k + shape[0])
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        img[rng.random(shape) < 0.01] = 0
+        img[rng.random(shape) < 0.01] = 255
+        for op in ("erode", "dilate", "tophat"):
+            assert_same(ctx.morph_ellipse(img, k, op), ctx.morph_ellipse(img, k, op, direct=True), f"{op} {k} {shape}")
+
+
 def test_morph_ellipse_footprint_probe(ctx, oracle):
     """Delta images expose every tap of the footprint, including across the 64-column lane seams."""
     for k in (29, 55):
@@ -553,7 +567,8 @@ def test_randomised_differential_run():
                                     "LT_MORPH_PAIR=0", "LT_UNDISTORT_UNALIGNED=1", "LT_WALK_MIN_FRAMES=0,LT_WALK_SPLIT=1",
                                     "LT_WALK_MIN_FRAMES=0,LT_OPEN5_SEPARATE=1", "LT_WALK_MIN_FRAMES=0,LT_MORPH_WIDE=0",
                                     "LT_WALK_MIN_FRAMES=0,LT_MORPH_ONE_ROW=1", "LT_THRESHOLD_SPLIT=0", "LT_OPEN_SHALLOW=0",
-                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN_SHALLOW=0"])
+                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN_SHALLOW=0", "LT_MORPH_ONE=0", "LT_MORPH_ONE=8", "LT_MORPH_ONE_WGS=64",
+                                    "LT_MORPH_ONE=8,LT_MORPH_ONE_WGS=2000"])
 def test_alternative_kernel_paths_keep_parity(switch):
     """Every measurement switch of DESIGN.md selects a path that stays bit-exact: the mask-chain, top-hat operator and
     search parity tests again in a process started with the switch set (the library reads them once)."""
@@ -564,7 +579,7 @@ def test_alternative_kernel_paths_keep_parity(switch):
         name, value = item.split("=")
         env[name] = value
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        "-k", "mask_chain_bit_exact or morph_ellipse_operators or sliding_window_search_vs_reference or "
+                        "-k", "mask_chain_bit_exact or morph_ellipse_operators or one_frame_morphology or sliding_window_search_vs_reference or "
                               "band_search_vs_reference or multi_stream or front_end_bit_exact or odd_slot_ranges"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

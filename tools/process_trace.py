@@ -25,12 +25,22 @@ class Lib:                                   # the library calls themselves, wit
         self._lib = lib
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if name not in ("lt_present_frame", "lt_download_records"):
+        if name not in ("lt_present_frame", "lt_download_records", "lt_host_copy2d_async_group", "lt_host_copy_wait_group", "lt_present_lane_async",
+                        "lt_present_finish", "lt_text_blend_host", "lt_upload_frame_rows", "lt_mask_run", "lt_band_fit_run", "lt_upload_frame_rest_rows"):
             return fn
         def w(*a):
             t0 = time.perf_counter(); r = fn(*a); acc[" " + name] += time.perf_counter() - t0; cnt[" " + name] += 1; return r
         return w
 lt._ctx.lib = Lib(lt._ctx.lib)
+from lane_tracker_amd import _native as _nat
+_pe = _nat.pinned_empty
+def _pe_timed(*a, **k):
+    t0 = time.perf_counter(); r = _pe(*a, **k); acc[" pinned_empty"] += time.perf_counter() - t0; return r
+_nat.pinned_empty = _pe_timed
+_tb = _nat.text_blend
+def _tb_timed(*a, **k):
+    t0 = time.perf_counter(); r = _tb(*a, **k); acc[" text_blend"] += time.perf_counter() - t0; return r
+_nat.text_blend = _tb_timed
 for name in ("_record_success", "check_validity", "_points_packed", "get_curve_radius", "_lane_text", "_present", "_prepare_out", "_copies_done", "_lane_ahead"):
     wrap(lt, name)
 n = len(frames) - 8
