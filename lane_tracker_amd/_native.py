@@ -359,12 +359,18 @@ def text_bytes(lines_per_frame, line_len=40):
 def text_blend(frames, font, text, n_lines, line_len=40, origin=(20, 8), step=35):
     """The text lines of `frames` (n, H, W, 3) u8 drawn in place on the calling thread (lt_text_blend_host: lt_overlay_text's
     arithmetic on the host).  font = (atlas (g, gh, gw) u8, advance (g,) u8, first_char); text = n * n_lines * line_len bytes."""
-    atlas, advance, first_char = font
+    f = _font_args.get(id(font))
+    if f is None or f[0] is not font:                 # (addresses and sizes of a font, once: .ctypes.data costs a microsecond a time)
+        atlas, advance, first_char = font
+        f = _font_args[id(font)] = (font, atlas.ctypes.data, advance.ctypes.data, int(first_char), atlas.shape[0], atlas.shape[2], atlas.shape[1])
     n, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
-    rc = load().lt_text_blend_host(frames.ctypes.data, H * W * 3, n, H, W, atlas.ctypes.data, advance.ctypes.data, int(first_char),
-                                   atlas.shape[0], atlas.shape[2], atlas.shape[1], text, n_lines, line_len, int(origin[0]), int(origin[1]), int(step))
+    rc = (_lib or load()).lt_text_blend_host(frames.ctypes.data, H * W * 3, n, H, W, f[1], f[2], f[3], f[4], f[5], f[6], text, n_lines, line_len,
+                                 int(origin[0]), int(origin[1]), int(step))
     if rc:
         _check(rc)
+
+
+_font_args = {}
 
 
 def host_text_async(group, dst, src, rows, font, text, n_lines, line_len=40, origin=(20, 8), step=35):

@@ -297,6 +297,10 @@ struct Bilateral2Args {
     int h, w, wpr;
     int tiles_x, tiles_y, ntiles;
     size_t plane_stride, bits_stride;
+    // split: two workgroups per tile -- one runs the H phases into `bits`, the other the V phases into `bits_v` (two partial planes
+    // for the merge to OR).  One frame is 81 tiles on 256 CUs; the halves of a tile's work do not depend on each other.
+    int split;
+    unsigned long long* bits_v;
 };
 
 // Per plane: stage the row band -> H phase on all four waves (32 columns each) -> stage the column
@@ -308,7 +312,9 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
     __shared__ unsigned long long s_noise[T2][2];   // bilateral verdict of the raw Lab-b plane (greenery part 2)
     __shared__ unsigned long long s_range[T2][2];   // inRange(lab_b, noise_thresh, 255)             (part 1)
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tile = xcd_contiguous(blockIdx.x, a.ntiles);
+    const int unit = xcd_contiguous(blockIdx.x, a.split ? 2 * a.ntiles : a.ntiles);
+    const int tile = a.split ? unit >> 1 : unit;
+    const int only = a.split ? 1 + (unit & 1) : 3;           // bit 0: the H phases, bit 1: the V phases (workgroup-uniform)
     const int frame = tile / (a.tiles_x * a.tiles_y), tin = tile - frame * (a.tiles_x * a.tiles_y);
     const int tyi = tin / a.tiles_x, txi = tin - tyi * a.tiles_x;
     const size_t fo = (size_t)frame * a.plane_stride;
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
 
         // ---------------- row band: rows y0..y0+127, columns xa..xa+pitch-1 ----------------
         __syncthreads();   // the previous phase is done with the buffer
+        if (only & 1) {
         if (aligned) {
             const int dpr = pitch >> 2;
             uint32_t* hb = reinterpret_cast<uint32_t*>(band);
@@ -416,6 +423,8 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
             atomicOr(&dst[lane][half], (unsigned long long)w0 << sh);
             atomicOr(&dst[lane + 64][half], (unsigned long long)w1 << sh);
         }
+        }
+        if (!(only & 2)) continue;
 
         // ---------------- column band: rows y0-k..y0+127+k+1, columns x0..x0+127 ----------------
         __syncthreads();   // every H wave is done with the row band
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(256) void k_bilateral_tile2(Bilateral2Args a, unsig
             if (a.pl[2].src) m &= ~s_range[r][half] | s_noise[r][half];   // (r|b) & (!part1 | part2)
             const int nvalid = a.w - xw;
             if (nvalid < 64) m &= (1ull << nvalid) - 1ull;
-            bits[(size_t)frame * a.bits_stride + (size_t)gy * a.wpr + (xw >> 6)] = m;
+            (only == 2 ? a.bits_v : bits)[(size_t)frame * a.bits_stride + (size_t)gy * a.wpr + (xw >> 6)] = m;
         }
     }
 }
@@ -653,6 +662,64 @@ __global__ __launch_bounds__(64) void k_merge_open5(unsigned long long* p0, cons
     }
 }
 
+// A few frames (process(): one): OR of the partial planes + the 5x5 open in ONE launch of many small workgroups.  k_merge_open5
+// walks bands of rows, one wave per band -- a few dozen waves for one frame, each a chain of dependent rows; the three shallow
+// kernels (k_or4_bits, k_erode5_bits, k_dilate5_bits) are three launches of 5 us each on a one-frame chain that is made of
+// launch gaps.  Here a workgroup owns RB output rows: the merged words of RB + 8 rows go to LDS, the eroded words of RB + 4 rows
+// are formed from them into LDS, the dilated words from those.  Same arithmetic as k_merge_open5 (borders: erode ignores taps
+// outside the image, dilate too); NP as there; NP >= 2 also writes the merged plane over p0.
+constexpr int OS_RB = 8;
+template <int NP>
+__global__ __launch_bounds__(256) void k_or_open5_small(unsigned long long* p0, const unsigned long long* __restrict__ p1,
+                                                       const unsigned long long* __restrict__ p2, const unsigned long long* __restrict__ p3,
+                                                       const unsigned long long* __restrict__ n0, const unsigned long long* __restrict__ n1,
+                                                       unsigned long long* __restrict__ opened, int h, int w, int wpr, size_t bits_stride) {
+    typedef unsigned long long u64;
+    __shared__ u64 s_m[(OS_RB + 8) * 64], s_e[(OS_RB + 4) * 64];
+    const int yb = blockIdx.x * OS_RB, rows = min(OS_RB, h - yb);
+    const size_t fo = (size_t)blockIdx.y * bits_stride;
+    for (int i = threadIdx.x; i < (OS_RB + 8) * wpr; i += 256) {
+        const int r = i / wpr, j = i - r * wpr, y = yb - 4 + r;
+        u64 m = ~0ull;                                        // rows outside the image count as set (erode ignores them)
+        if (y >= 0 && y < h) {
+            const size_t o = fo + (size_t)y * wpr + j;
+            u64 raw = p0[o];
+            if (NP >= 2) raw |= p1[o];
+            if (NP >= 4) raw |= p2[o] | p3[o];
+            if (NP == 6) raw &= n0[o] | n1[o];
+            if (NP >= 2 && r >= 4 && r < 4 + rows) p0[o] = raw;
+            m = raw | ~valid_bits(j, w);                      // ... and so do pixels right of it
+        }
+        s_m[r * 64 + j] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (OS_RB + 4) * wpr; i += 256) {
+        const int r = i / wpr, j = i - r * wpr, y = yb - 2 + r;   // eroded row y <-> merged rows r .. r + 4 of s_m
+        u64 e = 0ull;
+        if (y >= 0 && y < h) {
+            e = s_m[r * 64 + j] & s_m[(r + 4) * 64 + j];
+#pragma unroll
+            for (int d = 1; d <= 3; ++d) {
+                const u64* q = s_m + (r + d) * 64;
+                e &= hspan5<false>(j > 0 ? q[j - 1] : ~0ull, q[j], j < wpr - 1 ? q[j + 1] : ~0ull);
+            }
+            e &= valid_bits(j, w);
+        }
+        s_e[r * 64 + j] = e;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * wpr; i += 256) {
+        const int r = i / wpr, j = i - r * wpr;                   // output row yb + r <-> eroded rows r .. r + 4 of s_e
+        u64 d = s_e[r * 64 + j] | s_e[(r + 4) * 64 + j];
+#pragma unroll
+        for (int k = 1; k <= 3; ++k) {
+            const u64* q = s_e + (r + k) * 64;
+            d |= hspan5<true>(j > 0 ? q[j - 1] : 0ull, q[j], j < wpr - 1 ? q[j + 1] : 0ull);
+        }
+        opened[fo + (size_t)(yb + r) * wpr + j] = d & valid_bits(j, w);
+    }
+}
+
 // dilate of the eroded bits (out-of-image = clear) and expansion to the u8 {0,255} mask.
 // A block owns DR rows: its threads first build the dilated words of those rows in LDS, then
 // every thread expands 4 pixels at a time into one coalesced dword store.
@@ -732,8 +799,10 @@ __global__ __launch_bounds__(256) void k_bits_to_u8(const unsigned long long* __
 
 int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
                           const uint8_t* labb, int k_n, int C_n, int noise_thresh, int use_noise,
-                          unsigned long long* bits, int h, int w, size_t plane_stride, size_t bits_stride, int n) {
+                          unsigned long long* bits, int h, int w, size_t plane_stride, size_t bits_stride, int n,
+                          unsigned long long* bits_v) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
+    if (bits_v && use_noise) return -1;      // the split form has no greenery mask
     static const bool unpacked = [] { const char* e = std::getenv("LT_BILATERAL_UNPACKED"); return e && e[0] == '1'; }();
     const int kmax = std::max(k_r, std::max(k_b, use_noise ? k_n : 0));
     const int cmax = std::max(std::abs(C_r), std::max(std::abs(C_b), use_noise ? std::abs(C_n) : 0));
@@ -751,6 +820,8 @@ int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
         a.tiles_x = (w + T2 - 1) / T2;
         a.tiles_y = (h + T2 - 1) / T2;
         a.ntiles = a.tiles_x * a.tiles_y * n;
+        a.split = bits_v ? 1 : 0;
+        a.bits_v = bits_v;
         const size_t lds = (size_t)plane2_lds_bytes(kmax);
         if (lds + 3 * T2 * 2 * sizeof(unsigned long long) <= 160 * 1024) {
             if (lds > 48 * 1024 &&
@@ -763,10 +834,11 @@ int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_bilateral_tile2), 256, lds);
                 std::fprintf(stderr, "k_bilateral_tile2: %zu B dynamic LDS, %d workgroups per CU\n", lds, nb);
             }
-            hipLaunchKernelGGL(k_bilateral_tile2, dim3(a.ntiles), dim3(256), lds, s, a, bits);
+            hipLaunchKernelGGL(k_bilateral_tile2, dim3(a.split ? 2 * a.ntiles : a.ntiles), dim3(256), lds, s, a, bits);
             return 0;
         }
     }
+    if (bits_v) return -1;
     BilateralArgs a;
     a.pl[0] = {thr, k_r, C_r};
     a.pl[1] = {thb, k_b, C_b};
@@ -844,6 +916,23 @@ bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned lo
     else if (p1 && !p2) hipLaunchKernelGGL(k_merge_open5<2>, grid, dim3(64), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride, band_rows, G, n);
     else if (p1) hipLaunchKernelGGL(k_merge_open5<4>, grid, dim3(64), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride, band_rows, G, n);
     else hipLaunchKernelGGL(k_merge_open5<1>, grid, dim3(64), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride, band_rows, G, n);
+    return true;
+}
+
+// the same for a few frames (k_or_open5_small); false: not launched (a row wider than 64 words, LT_OPEN_SMALL=0)
+bool launch_or_open5_small(hipStream_t s, unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
+                           const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n,
+                           const unsigned long long* n0, const unsigned long long* n1) {
+    const int wpr = (w + 63) / 64;
+    if ((n0 || n1) && !(n0 && n1 && p1 && p2 && p3)) return false;
+    if ((p2 != nullptr) != (p3 != nullptr) || (p2 && !p1)) return false;
+    static const bool off = [] { const char* e = std::getenv("LT_OPEN_SMALL"); return e && e[0] == '0'; }();   // A/B
+    if (off || n <= 0 || h <= 0 || wpr > 64 || opened == p0) return false;
+    const dim3 grid((h + OS_RB - 1) / OS_RB, n);
+    if (n0) hipLaunchKernelGGL(k_or_open5_small<6>, grid, dim3(256), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride);
+    else if (p1 && !p2) hipLaunchKernelGGL(k_or_open5_small<2>, grid, dim3(256), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride);
+    else if (p1) hipLaunchKernelGGL(k_or_open5_small<4>, grid, dim3(256), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride);
+    else hipLaunchKernelGGL(k_or_open5_small<1>, grid, dim3(256), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride);
     return true;
 }
 

@@ -390,7 +390,13 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
         for (int i = first; i < first + n; ++i) c->th_padded[(size_t)i] = walk ? 1 : 0;
     unsigned long long* mbits = c->d_bits_merged + (size_t)first * c->bits_stride;
     unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
+    unsigned long long* tbits = c->d_bits_tmp ? c->d_bits_tmp + (size_t)first * c->bits_stride : nullptr;
+    unsigned long long* ubits = c->d_bits_tmp2 ? c->d_bits_tmp2 + (size_t)first * c->bits_stride : nullptr;
     bool r_verdicts_done = false;                 // the R plane's threshold ran beside the Lab-b top-hats, into ebits
+    // ... with the H and the V phases of a tile in workgroups of their own (one frame: 81 tiles on 256 CUs), their verdicts in
+    // partial planes of their own: R -> ebits, ubits; Lab-b -> mbits, tbits (LT_THRESHOLD_PHASES=0: one workgroup per tile)
+    static const bool phases_ok = [] { const char* e = std::getenv("LT_THRESHOLD_PHASES"); return !(e && e[0] == '0'); }();
+    bool phase_split = false;
     if (p->filter_type == 0) {
         if (c->brute_tophat) {   // debugging aid (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
@@ -405,19 +411,35 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             if (!c->d_side_scratch) { const int rc = dev_alloc(&c->d_side_scratch, 2 * ps); if (rc) return rc; }
             uint8_t* ts = c->d_side_scratch;
             HIP_TRY(hipEventRecord(c->ev_fork, s));
+            // The Lab-b pair is the longer of the two chains: its first kernel is launched before anything of the side stream
+            // (the host needs 4-5 us per launch, and in launch order "side stream first" the 55x55 erode started 12-16 us after
+            // the warp had ended: tools/process_timeline.sh).  LT_SIDE_FIRST=1: the former order (A/B).
+            static const bool side_first = [] { const char* e = std::getenv("LT_SIDE_FIRST"); return e && e[0] == '1'; }();
+            if (!side_first) launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
             HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
             launch_morph_runs(c->side, R, ts, nullptr, h, w, 29, false, ps, n);
+            if (!side_first) { const int rc = tophat_b(s); if (rc) return rc; }
             launch_morph_runs(c->side, ts, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes);
             // ... and so does the R plane's threshold: its 29x29 top-hat is done while the 55x55 pair still has half its way
             // to go, and the threshold kernel takes its planes one after the other anyway -- here one per launch, the R
             // verdicts as a partial bit plane the open ORs in (12 us less on the one-frame chain)
             static const bool split_ok = [] { const char* e = std::getenv("LT_THRESHOLD_SPLIT"); return !(e && e[0] == '0'); }();
-            if (split_ok && !walk && !p->mask_noise)
+            if (split_ok && !walk && !p->mask_noise) {
+                phase_split = phases_ok && tbits && ubits;
                 r_verdicts_done = launch_bilateral_bits(c->side, thR, p->ksize_r, p->C_r, nullptr, 1, 0, B, p->ksize_noise, p->C_noise,
-                                                        p->noise_thresh, 0, ebits, h, w, ps, c->bits_stride, n) == 0;
+                                                        p->noise_thresh, 0, ebits, h, w, ps, c->bits_stride, n, phase_split ? ubits : nullptr) == 0;
+                if (!r_verdicts_done && phase_split) {       // (packed arithmetic does not fit these parameters: one workgroup per tile)
+                    phase_split = false;
+                    r_verdicts_done = launch_bilateral_bits(c->side, thR, p->ksize_r, p->C_r, nullptr, 1, 0, B, p->ksize_noise, p->C_noise,
+                                                            p->noise_thresh, 0, ebits, h, w, ps, c->bits_stride, n) == 0;
+                }
+            }
             HIP_TRY(hipEventRecord(c->ev_join, c->side));
-            launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
-            { const int rc = tophat_b(s); if (rc) return rc; }
+            if (side_first) {
+                launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
+                const int rc = tophat_b(s);
+                if (rc) return rc;
+            }
             HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
         } else {
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n); }
@@ -428,8 +450,6 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     }
     bool merged_done = false, partials = false;   // partials: mbits, ebits, tmp, tmp2 still wait for their OR
     bool two_partials = false;                    // ... only mbits and ebits (the 'neighborhood' walk)
-    unsigned long long* tbits = c->d_bits_tmp + (size_t)first * c->bits_stride;
-    unsigned long long* ubits = c->d_bits_tmp2 + (size_t)first * c->bits_stride;
     unsigned long long *nbits1 = nullptr, *nbits2 = nullptr;   // the greenery mask of the walking kernels: n1 | n2
     if (p->filter_type == 0) {
         StageScope t(c, ST_THRESHOLD, s);   // both bilateral thresholds, the greenery mask and the OR-merge
@@ -448,8 +468,9 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
         }
         if (!merged_done && r_verdicts_done) {   // the Lab-b plane alone; should that launch be refused, both planes below
             merged_done = launch_bilateral_bits(s, nullptr, 1, 0, thB, p->ksize_b, p->C_b, B, p->ksize_noise, p->C_noise,
-                                                p->noise_thresh, 0, mbits, h, w, ps, c->bits_stride, n) == 0;
-            partials = two_partials = merged_done;
+                                                p->noise_thresh, 0, mbits, h, w, ps, c->bits_stride, n, phase_split ? tbits : nullptr) == 0;
+            partials = merged_done;
+            two_partials = merged_done && !phase_split;
         }
         if (!merged_done)
           merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
@@ -494,6 +515,11 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
       if (!u8_mask && (n >= 16 || (partials && deep_small)))
           opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, two_partials ? nullptr : tbits, two_partials ? nullptr : ubits, obits,
                                       h, w, c->bits_stride, n, nbits1, nbits2);
+      // a few frames: the OR and the open in one launch of small workgroups (the one-frame chain is made of launch gaps: three
+      // kernels of 5 us here; LT_OPEN_SMALL=0 restores them)
+      if (!opened && !u8_mask && n <= 4)
+          opened = launch_or_open5_small(s, mbits, partials ? ebits : nullptr, (!partials || two_partials) ? nullptr : tbits,
+                                         (!partials || two_partials) ? nullptr : ubits, obits, h, w, c->bits_stride, n, nbits1, nbits2);
       if (!opened) {
           if (partials) launch_or4_bits(s, mbits, ebits, two_partials ? ebits : tbits, two_partials ? ebits : ubits, h, w, c->bits_stride, n, nbits1, nbits2);
           if (u8_mask) launch_open5_bits(s, mbits, ebits, mask, h, w, ps, c->bits_stride, n);

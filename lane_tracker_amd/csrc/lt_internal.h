@@ -113,7 +113,8 @@ void launch_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uin
 // bit-plane path (k_threshold.hip): fused bilateral thresholds + merge, u8->bits merge, 5x5 open on bits
 int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, const uint8_t* thb, int k_b, int C_b,
                           const uint8_t* labb, int k_n, int C_n, int noise_thresh, int use_noise,
-                          unsigned long long* bits, int h, int w, size_t plane_stride, size_t bits_stride, int n);
+                          unsigned long long* bits, int h, int w, size_t plane_stride, size_t bits_stride, int n,
+                          unsigned long long* bits_v = nullptr);   // bits_v: the V phases' verdicts as a partial plane of their own (two workgroups per tile)
 void launch_pack_merge(hipStream_t s, const uint8_t* tr, const uint8_t* tb, const uint8_t* labb, const uint8_t* nb,
                        int noise_thresh, int use_noise, unsigned long long* bits, int h, int w, size_t plane_stride,
                        size_t bits_stride, int n);
@@ -136,6 +137,10 @@ int launch_noise_walk(hipStream_t s, const uint8_t* braw, int k_n, int C_n, int 
 // erode + dilate with the 5x5 ellipse, bit plane in, bit plane out
 // p1 alone: two partial planes.  n0 / n1 (both or neither; with p1..p3 only): the merged plane is (p0 | p1 | p2 | p3) & (n0 | n1)
 bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
+                        const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n,
+                        const unsigned long long* n0 = nullptr, const unsigned long long* n1 = nullptr);
+// ... for a few frames: one launch of small workgroups (k_or_open5_small)
+bool launch_or_open5_small(hipStream_t s, unsigned long long* p0, const unsigned long long* p1, const unsigned long long* p2,
                         const unsigned long long* p3, unsigned long long* opened, int h, int w, size_t bits_stride, int n,
                         const unsigned long long* n0 = nullptr, const unsigned long long* n1 = nullptr);
 void launch_open5_to_bits(hipStream_t s, const unsigned long long* merged, unsigned long long* eroded,

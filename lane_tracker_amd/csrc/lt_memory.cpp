@@ -580,6 +580,33 @@ void pooled_event_release(hipEvent_t e) {
     ep.free_.push_back(e);
 }
 
+// One row of a character's cell, `n` pixels wide and wholly inside the frame, 16 pixels (48 bytes) per step:
+//     out = v + ((255 - v) * alpha + 127) / 255,   t / 255 == (t + 1 + (t >> 8)) >> 8 for 0 <= t < 65536
+// (tests/test_presentation_cpu.py holds this against the scalar form for every (v, alpha)).  Lanes right of the cell get alpha 0,
+// which leaves their bytes as they are; the caller guarantees 48 readable / writable bytes from `p` and 16 readable alphas.
+__attribute__((target("avx2"))) static void blend_row_avx2(uint8_t* p, const uint8_t* alpha, int n) {
+    const __m128i idx = _mm_setr_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const __m128i sh0 = _mm_setr_epi8(0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 5);
+    const __m128i sh1 = _mm_setr_epi8(5, 5, 6, 6, 6, 7, 7, 7, 8, 8, 8, 9, 9, 9, 10, 10);
+    const __m128i sh2 = _mm_setr_epi8(10, 11, 11, 11, 12, 12, 12, 13, 13, 13, 14, 14, 14, 15, 15, 15);
+    const __m256i c255 = _mm256_set1_epi16(255), c127 = _mm256_set1_epi16(127), c1 = _mm256_set1_epi16(1);
+    for (int g0 = 0; g0 < n; g0 += 16, p += 48, alpha += 16) {
+        __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(alpha));
+        a = _mm_and_si128(a, _mm_cmpgt_epi8(_mm_set1_epi8((char)std::min(n - g0, 16)), idx));       // alphas beyond the cell: 0
+        if (_mm_testz_si128(a, a)) continue;
+        const __m128i a3[3] = {_mm_shuffle_epi8(a, sh0), _mm_shuffle_epi8(a, sh1), _mm_shuffle_epi8(a, sh2)};
+        for (int k = 0; k < 3; ++k) {
+            __m128i* q = reinterpret_cast<__m128i*>(p + 16 * k);
+            const __m256i v = _mm256_cvtepu8_epi16(_mm_loadu_si128(q)), al = _mm256_cvtepu8_epi16(a3[k]);
+            const __m256i t = _mm256_add_epi16(_mm256_mullo_epi16(_mm256_sub_epi16(c255, v), al), c127);                 // < 65536: unsigned 16 bit
+            const __m256i d = _mm256_srli_epi16(_mm256_add_epi16(_mm256_add_epi16(t, c1), _mm256_srli_epi16(t, 8)), 8);   // t / 255
+            const __m256i o = _mm256_add_epi16(v, d);
+            const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(o, o), 0x08);
+            _mm_storeu_si128(q, _mm256_castsi256_si128(pk));
+        }
+    }
+}
+
 // k_overlay_text's arithmetic (csrc/k_overlay.hip) for one frame on the host: every character's cell up to its advance width,
 // white over the frame, out = v + ((255 - v) * alpha + 127) / 255 per channel
 void text_blend_frame(uint8_t* frame, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs,
@@ -597,10 +624,20 @@ void text_blend_frame(uint8_t* frame, int img_h, int img_w, const uint8_t* atlas
             const int adv = advance[g];
             if (!ended) x += adv;
             const uint8_t* cell = atlas + (size_t)g * gh * gw;
+            const int ncol = std::min(adv, gw);
+            // the vector form where whole steps of 16 pixels stay inside the row and inside the atlas (LT_TEXT_SCALAR=1: never; A/B, tests)
+            static const bool vec_ok = [] { const char* e = std::getenv("LT_TEXT_SCALAR"); return !(e && e[0] == '1') && __builtin_cpu_supports("avx2"); }();
+            const int span = (ncol + 15) & ~15;
+            const bool vec = vec_ok && ncol > 0 && xk >= 0 && xk + span <= img_w &&
+                             (size_t)g * gh * gw + (size_t)(gh - 1) * gw + span <= (size_t)n_glyphs * gh * gw;
             for (int gy = 0; gy < gh; ++gy) {
                 const int y = y0 + l * step + gy;
                 if (y < 0 || y >= img_h) continue;
                 uint8_t* row = frame + (size_t)y * img_w * 3;
+                if (vec) {
+                    blend_row_avx2(row + (size_t)xk * 3, cell + (size_t)gy * gw, ncol);
+                    continue;
+                }
                 for (int gx = 0; gx < adv && gx < gw; ++gx) {
                     const int alpha = cell[(size_t)gy * gw + gx];
                     const int px = xk + gx;

@@ -98,6 +98,26 @@ def test_mask_chain_bit_exact(ctx, nat, oracle, ref_calib, frames, kw):
         assert_same(masks[k], want, f"mask, frame {k}, {kw}")
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(ksize_r=20, C_r=5), dict(mask_noise=True), dict(filter_type="neighborhood", C_r=5),
+                                dict(ksize_r=100, C_r=2, ksize_b=128, C_b=1)],
+                         ids=["default", "demo2", "mask_noise", "neighborhood", "huge_k"])
+def test_one_and_two_frame_chains_bit_exact(ctx, nat, oracle, ref_calib, frames, kw):
+    """The chain as process() issues it -- ONE frame per launch (and two): the one-frame top-hat kernels, the R plane's chain on
+    the side stream, the thresholds' H and V phases in workgroups of their own, the OR + open in one launch -- against the oracle,
+    in both slots process() alternates between."""
+    fp = nat.filter_params(**kw)
+    for n, start, first in ((1, 2, 0), (1, 3, 1), (2, 2, 0), (1, 0, 1), (2, 4, 2)):
+        ctx.upload_frames(frames[start:start + n], first=first)
+        ctx.mask_run(n, fp, first=first)
+        masks = ctx.download_masks(n, first=first)
+        merged = ctx.download_plane(4, n, first=first)
+        for k in range(n):
+            bev = oracle.front_end(ref_calib, frames[start + k])
+            want = oracle.filter_lane_points(bev, oracle.filter_params(**kw))
+            assert_same(masks[k], want, f"mask of frame {start + k} in slot {first + k}, {n} per launch, {kw}")
+            assert_same(oracle.morph_open(merged[k], 5), want, f"open(merged plane) of frame {start + k}, {kw}")
+
+
 def test_bad_filter_type_raises_value_error(ctx, nat, frames):
     ctx.upload_frames(frames[:1])
     with pytest.raises(ValueError):
@@ -568,7 +588,8 @@ def test_randomised_differential_run():
                                     "LT_WALK_MIN_FRAMES=0,LT_OPEN5_SEPARATE=1", "LT_WALK_MIN_FRAMES=0,LT_MORPH_WIDE=0",
                                     "LT_WALK_MIN_FRAMES=0,LT_MORPH_ONE_ROW=1", "LT_THRESHOLD_SPLIT=0", "LT_OPEN_SHALLOW=0",
                                     "LT_WALK_MIN_FRAMES=0,LT_OPEN_SHALLOW=0", "LT_MORPH_ONE=0", "LT_MORPH_ONE=8", "LT_MORPH_ONE_WGS=64",
-                                    "LT_MORPH_ONE=8,LT_MORPH_ONE_WGS=2000"])
+                                    "LT_MORPH_ONE=8,LT_MORPH_ONE_WGS=2000", "LT_OPEN_SMALL=0", "LT_SIDE_FIRST=1", "LT_THRESHOLD_PHASES=0",
+                                    "LT_THRESHOLD_PHASES=0,LT_OPEN_SMALL=0,LT_MORPH_ONE=0"])
 def test_alternative_kernel_paths_keep_parity(switch):
     """Every measurement switch of DESIGN.md selects a path that stays bit-exact: the mask-chain, top-hat operator and
     search parity tests again in a process started with the switch set (the library reads them once)."""
@@ -579,7 +600,7 @@ def test_alternative_kernel_paths_keep_parity(switch):
         name, value = item.split("=")
         env[name] = value
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        "-k", "mask_chain_bit_exact or morph_ellipse_operators or one_frame_morphology or sliding_window_search_vs_reference or "
+                        "-k", "mask_chain_bit_exact or one_and_two_frame or morph_ellipse_operators or one_frame_morphology or sliding_window_search_vs_reference or "
                               "band_search_vs_reference or multi_stream or front_end_bit_exact or odd_slot_ranges"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

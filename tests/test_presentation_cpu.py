@@ -2,6 +2,8 @@
 the NumPy visualisations and the split view, checked against the oracle's generic fillPoly / addWeighted /
 resize restatements and against fixtures produced by the reference's own visualisation methods
 (tests/gen_golden.py; their cv2 calls answered by the oracle, so those three calls stay unpinned)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -224,3 +226,48 @@ def test_text_on_the_host_equals_the_atlas_blend():
     _native.text_blend(small, font, b2, n2, origin=(20, 30))
     assert small.any()
     _native.host_copy_group_release(g)
+
+
+def test_vector_text_blend_is_the_scalar_blend_for_every_value_and_alpha():
+    """The 16-pixels-a-step form of lt_text_blend_host (AVX2; t / 255 as (t + 1 + (t >> 8)) >> 8) against the NumPy statement for
+    every frame value 0..255 under every alpha 0..255, at cell widths that leave ragged last steps, flush against the right edge
+    (the scalar form takes over where a step would leave the row) and against the scalar build switch."""
+    import subprocess, sys, hashlib
+    from lane_tracker_amd import _native
+    rng = np.random.default_rng(3)
+    for gw, adv_w in ((16, 16), (21, 19), (33, 33), (12, 7)):
+        ng, gh = 16, 16
+        atlas = rng.permutation(np.arange(ng * gh * gw) % 256).astype(np.uint8).reshape(ng, gh, gw)
+        atlas[0, 0, :min(gw, 8)] = [0, 1, 2, 127, 128, 254, 255, 255][:min(gw, 8)]
+        adv = np.full(ng, adv_w, np.uint8)
+        font = (atlas, adv, 65)
+        text = "".join(chr(65 + g) for g in range(ng))
+        for W in (adv_w * ng + 20 + 40, adv_w * ng + 20, adv_w * ng + 20 - 5):      # room to spare / flush / clipped
+            frames = np.empty((256, gh + 12, W, 3), np.uint8)
+            frames[:] = np.arange(256, dtype=np.uint8)[:, None, None, None]
+            frames[:, :, :, 1] = 255 - frames[:, :, :, 0]
+            frames[:, :, :, 2] = (frames[:, :, :, 0].astype(np.int32) * 7 + 3).astype(np.uint8)
+            buf, nl = _native.text_bytes([[text]] * 256)
+            got = frames.copy()
+            _native.text_blend(got, font, buf, nl, origin=(20, 8))
+            for v in (0, 1, 2, 100, 127, 128, 200, 254, 255) if W != adv_w * ng + 60 else range(256):
+                want = frames[v].astype(np.int32)
+                x = 20
+                for g in range(ng):
+                    cell = atlas[g][:, :adv_w].astype(np.int32)
+                    reg = want[8:8 + gh, x:x + adv_w]
+                    reg += ((255 - reg) * cell[:, :reg.shape[1], None] + 127) // 255
+                    x += adv_w
+                assert np.array_equal(got[v], want.astype(np.uint8)), (gw, adv_w, W, v)
+    # the same text through the scalar switch, in a process of its own (the library reads the switch once)
+    code = ("import numpy as np, hashlib; from lane_tracker_amd import _native, overlay; f = overlay.font_atlas();\n"
+            "rng = np.random.default_rng(5); a = rng.integers(0, 256, (3, 144, 420, 3), dtype=np.uint8)\n"
+            "b, n = _native.text_bytes([['Curve Radius: 1234 m', 'Eccentricity: -0.25 m', 'Frame: 77']] * 3)\n"
+            "_native.text_blend(a, f, b, n) if f is not None else None; print(hashlib.sha256(a.tobytes()).hexdigest())")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for sw in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, LT_TEXT_SCALAR=sw), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-800:]
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1]
