@@ -236,6 +236,16 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
             res["process_stream_annotated_fps"] = max(stream_rate(cold, True) for _ in range(2))
             cs1, t_ann = _native.host_copy_stats(), time.perf_counter() - t_ann
             res["copy_threads_busy_share_annotated_stream"] = round((cs1["busy_s"] - cs0["busy_s"]) / max(t_ann * cs1["threads"], 1e-9), 3)
+            # ... and drawn into the caller's own windows (annotate="inplace", not in the reference): fresh windows per pass, the
+            # first pass untimed
+            rates = []
+            for k in range(3):
+                ws = stream_windows(base, window, nwin)
+                r = stream_rate(ws, "inplace")
+                if k:
+                    rates.append(r)
+                del ws
+            res["process_stream_annotated_inplace_fps"] = max(rates)
             res["annotated_frames_came_back_by"] = lt._ctx.download_stats()
             rows = lt._present_rows() if lt.host_copies_rows else None
             res["annotated_frames_travel_as"] = ("whole frames" if rows is None else

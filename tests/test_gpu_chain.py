@@ -296,6 +296,43 @@ def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_
         bat.close()
 
 
+def test_inplace_annotation_draws_into_the_callers_windows():
+    """annotate="inplace": the annotated frames ARE the caller's arrays -- same bytes as the frames annotate=True returns for a
+    copy of the same stream, the rows outside the lane's run and the text lines untouched, state equal; a read-only window
+    comes back as new frames; process_batch likewise."""
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    sizes = (24, 40, 1, 31)
+    frames = _stream_with_failures(sum(sizes), 13, seed=41)
+    pristine = frames.copy()
+    wins_a, wins_b, lo = [], [], 0
+    for w in sizes:
+        wins_a.append(frames[lo:lo + w].copy())          # each window an array of its own (a decoder's buffers)
+        wins_b.append(pristine[lo:lo + w])
+        lo += w
+    wins_a[2].flags.writeable = False
+    a, b = LaneTracker(**cal), LaneTracker(**cal)
+    try:
+        for k, (oa, ob) in enumerate(zip(a.process_stream(wins_a, annotate="inplace"), b.process_stream(wins_b, annotate=True))):
+            assert _state(a) == _state(b), k
+            assert all(np.array_equal(x, y) for x, y in zip(oa, ob)), k
+            if k != 2:
+                assert all(np.shares_memory(x, wins_a[k]) for x in oa), k          # the caller's own memory
+                assert not np.array_equal(wins_a[k], wins_b[k])                    # ... drawn over
+            else:
+                assert not any(np.shares_memory(x, wins_a[k]) for x in oa) and np.array_equal(wins_a[k], wins_b[k])
+            assert all(not np.shares_memory(y, wins_b[k]) for y in ob) and np.array_equal(wins_b[k], pristine[sum(sizes[:k]):sum(sizes[:k + 1])])
+        win = pristine[:32].copy()
+        want = b.process_batch(pristine[:32], annotate=True)
+        got = a.process_batch(win, annotate="inplace")
+        assert all(np.array_equal(x, y) for x, y in zip(got, want)) and all(np.shares_memory(x, win) for x in got)
+        assert _state(a) == _state(b)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_annotated_stream_closed_early_leaves_a_usable_tracker():
     """A consumer that stops after the first window: the generator's clean-up cancels the searches in flight and waits for
     the copies still writing into the page-locked frame arrays; the tracker takes frames again and its first window came

@@ -83,6 +83,7 @@ def tables(lines):
     row("… `warm()` itself: median", lambda s: s["process_stream_annotated_first_pass"]["warm_ms"]["median"], ms1)
     row("… `warm()` of the first tracker of the process (touches the output pool)", lambda s: s["process_stream_annotated_first_pass"]["warm_ms"]["max"], ms1)
     row("… a fresh tracker that was NOT warmed", lambda s: s["process_stream_annotated_first_pass"]["not_warmed"]["frames_per_s"])
+    row("`process_stream(annotate=\"inplace\")`: drawn into the caller's windows (not in the reference)", lambda s: s["process_stream_annotated_inplace_fps"])
     row("with outages (four of 16 frames per window)", lambda s: s["process_stream_outages_fps"])
     rows.append("| Demo 1 settings (`mask_noise`) | %s | — |" % span(lines, lambda d: d["stream"]["1280x720"]["process_stream_demo1_fps"]))
     t["stream"] = "\n".join(rows)
