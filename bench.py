@@ -37,28 +37,7 @@ PROFILE_TAG = "r05"            # profiles/<tag>_traffic.json, <tag>_kernel_stats
 CALIB_TAG = "r02"              # profiles/<tag>_valu_issue.json, <tag>_fetch_calib.json: the issue-rate / counter calibrations (hardware facts)
 
 
-def cpu_quota():
-    """CPUs' worth of time the cgroup grants this process (None: unlimited).  The GPU boxes show 256 CPUs and grant 16."""
-    try:
-        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if q == "max" else float(q) / float(per)
-    except Exception:
-        pass
-    try:
-        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        return q / per if q > 0 else None
-    except Exception:
-        return None
-
-
-def usable_cpus():
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    q = cpu_quota()
-    return max(1, min(avail, int(q + 0.999))) if q else avail
+from lane_tracker_amd.hostcpu import cpu_quota, usable_cpus      # (what the cgroup grants; the GPU boxes show 256 CPUs and grant 16)
 
 
 def _render_one(i):
@@ -236,16 +215,18 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
             res["process_stream_annotated_fps"] = max(stream_rate(cold, True) for _ in range(2))
             cs1, t_ann = _native.host_copy_stats(), time.perf_counter() - t_ann
             res["copy_threads_busy_share_annotated_stream"] = round((cs1["busy_s"] - cs0["busy_s"]) / max(t_ann * cs1["threads"], 1e-9), 3)
-            # ... and drawn into the caller's own windows (annotate="inplace", not in the reference): fresh windows per pass, the
-            # first pass untimed
+            # ... and drawn into the caller's own windows (annotate="inplace", not in the reference): windows of their own, restored
+            # from `cold` before every pass (outside the clock); like the line above a later pass -- memory the runtime has seen
+            work = [w.copy() for w in cold]
             rates = []
             for k in range(3):
-                ws = stream_windows(base, window, nwin)
-                r = stream_rate(ws, "inplace")
+                r = stream_rate(work, "inplace")
                 if k:
                     rates.append(r)
-                del ws
+                for w, c0 in zip(work, cold):
+                    np.copyto(w, c0)
             res["process_stream_annotated_inplace_fps"] = max(rates)
+            del work
             res["annotated_frames_came_back_by"] = lt._ctx.download_stats()
             rows = lt._present_rows() if lt.host_copies_rows else None
             res["annotated_frames_travel_as"] = ("whole frames" if rows is None else

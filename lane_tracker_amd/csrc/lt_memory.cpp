@@ -299,12 +299,13 @@ struct HostCopier {
     void run() {
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
-            if (q.empty() && !stop && spin_us() > 0 && !spinner.exchange(true)) {
+            if (q.empty() && !stop && spin_us() > 0 && spinning.load(std::memory_order_relaxed) < max_spinners()) {
+                spinning.fetch_add(1, std::memory_order_relaxed);          // (under m: the bound holds)
                 lk.unlock();
                 const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us());
                 while (queued.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() < until) __builtin_ia32_pause();
                 lk.lock();
-                spinner.store(false);
+                spinning.fetch_sub(1, std::memory_order_relaxed);
             }
             work.wait(lk, [&] { return stop || !q.empty(); });
             if (q.empty()) return;               // stop
@@ -363,13 +364,23 @@ struct HostCopier {
         }();
         return n;
     }
-    // The first worker does not go to sleep at once when the queue runs empty: it polls for LT_COPY_SPIN_US (default 400) first.
-    // LaneTracker.process() sends a copy every 0.2-0.3 ms, and a worker woken from a futex on an idle core starts 50-100 us late
-    // (deep C-states) -- the frame then waits for its own rows (1920x1080: _present 54 -> 240 us between two runs on one box).
-    // One polling thread, only while requests keep coming; LT_COPY_SPIN_US=0 turns it off.
+    // Up to LT_COPY_SPINNERS workers (default 3) do not go to sleep at once when the queue runs empty: they poll for LT_COPY_SPIN_US
+    // (default 400) first.  LaneTracker.process() sends a copy every 0.2-0.3 ms, and a worker woken from a futex on an idle
+    // core starts 50-100 us late (deep C-states) -- the frame then waits for its own rows (1920x1080: _present 54 -> 240 us between
+    // two runs on one box); and every wake-up is a system call of the SUBMITTING thread (10 us per submission on a quiet box,
+    // 0.15-0.5 ms where futex wake-ups are slow: a VM, a host under load), so a submission wakes no more sleepers than it has
+    // pieces the pollers cannot take.  Only while requests keep coming; LT_COPY_SPIN_US=0 turns the polling off.
     std::atomic<unsigned long long> busy_ns{0}, bytes_done{0}, jobs_done{0};   // lt_host_copy_stats (plain copies count their bytes, fn jobs 0)
     std::atomic<size_t> queued{0};
-    std::atomic<bool> spinner{false};
+    std::atomic<int> spinning{0};
+    int max_spinners() {
+        static const int v = [] { const char* e = std::getenv("LT_COPY_SPINNERS"); return e ? std::min(std::max(std::atoi(e), 0), 16) : 3; }();
+        return std::min(v, threads());
+    }
+    void wake(size_t pieces) {      // after a push, outside the lock: sleepers for the pieces the pollers will not take
+        const long need = (long)std::min<size_t>(pieces, (size_t)threads()) - (long)spinning.load(std::memory_order_relaxed);
+        for (long i = 0; i < need; ++i) work.notify_one();
+    }
     static int spin_us() {
         static const int v = [] { const char* e = std::getenv("LT_COPY_SPIN_US"); return e ? std::max(std::atoi(e), 0) : 400; }();
         return v;
@@ -380,8 +391,11 @@ struct HostCopier {
         while ((int)th.size() < want) th.emplace_back([this] { run(); });
     }
     int submit(const Job& whole) {
-        // pieces of whole rows ("rows" of the 2-D copy: frames), a few per worker so that they finish together
-        const size_t parts = whole.height <= 1 ? 1 : std::min<size_t>(whole.height, (size_t)threads() * 2);
+        // pieces of whole rows ("rows" of the 2-D copy: frames), a few per worker so that they finish together -- but none below
+        // 256 KB: a piece costs a queue round trip (and, for a sleeper, a wake-up)
+        const size_t by_size = std::max<size_t>(1, whole.width * whole.height / (256u << 10));
+        const size_t parts = whole.height <= 1 ? 1 : std::min({whole.height, (size_t)threads() * 2, by_size});
+        size_t pushed = 0;
         {
             std::unique_lock<std::mutex> lk(m);
             if (!known(whole.group)) return -1;
@@ -394,10 +408,11 @@ struct HostCopier {
                     queued.fetch_add(1, std::memory_order_release);
                     ++pending[whole.group];
                     ++pending_all;
+                    ++pushed;
                 }
             }
         }
-        work.notify_all();
+        wake(pushed);
         return 0;
     }
     int submit_fn(int group, std::function<void()> fn, bool many) {
@@ -410,7 +425,7 @@ struct HostCopier {
             ++pending[group];
             ++pending_all;
         }
-        work.notify_one();
+        wake(1);
         return 0;
     }
     int reserve(int group) {         // a piece that will be submitted later (behind a device copy): the group is not complete without it

@@ -69,16 +69,17 @@ static void lane_polygon_spans(int16_t* spans, int bh, const int32_t* lyx, int n
     // vertex k of the closed polygon: the left points in order, then the right points reversed (np.flipud)
     const int32_t* last = nr ? ryx : lyx + 2 * (nl - 1);          // vertex np - 1: the first right point, or the last left one
     int px = last[1], py = last[0];
-    for (int k = 0; k < nl; ++k) {
-        span_line(spans, bh, px, py, lyx[2 * k + 1], lyx[2 * k]);
-        px = lyx[2 * k + 1];
-        py = lyx[2 * k];
-    }
-    for (int k = nr - 1; k >= 0; --k) {
-        span_line(spans, bh, px, py, ryx[2 * k + 1], ryx[2 * k]);
-        px = ryx[2 * k + 1];
-        py = ryx[2 * k];
-    }
+    // every vertex is the end point of the edge before it: an edge between neighbouring pixels (nearly all of them: one plot
+    // point per row) adds nothing but its own end point -- its start is on record already (the first edge's start is the
+    // polygon's last vertex, which the last edge ends on)
+    auto edge = [&](int x, int y) {
+        if (std::abs(x - px) <= 1 && std::abs(y - py) <= 1) span_point(spans, bh, x, y);
+        else span_line(spans, bh, px, py, x, y);
+        px = x;
+        py = y;
+    };
+    for (int k = 0; k < nl; ++k) edge(lyx[2 * k + 1], lyx[2 * k]);
+    for (int k = nr - 1; k >= 0; --k) edge(ryx[2 * k + 1], ryx[2 * k]);
 }
 
 }  // namespace

@@ -17,6 +17,7 @@ import os
 
 import numpy as np
 
+from . import hostcpu as _hostcpu
 from . import _native
 from . import overlay as _overlay
 from . import utils as _utils
@@ -63,6 +64,7 @@ class LaneTracker(StreamPipeline):
 
     def __init__(self, img_size, warped_size, cam_matrix, dist_coeffs, warp_matrices, mpp_conversion,
                  n_fail=8, n_reset=4, n_average=2, print_frame_count=False, device=0):
+        _hostcpu.cap_blas_threads()      # no more BLAS threads than CPUs granted: np.polyfit must not freeze the process (hostcpu.py)
         self.img_size = img_size
         self.warped_size = warped_size
         self.cam_matrix = cam_matrix

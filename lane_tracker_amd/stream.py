@@ -557,6 +557,7 @@ class StreamPipeline:
         return frames
 
     _window_rows = None         # _present_rows() while an annotated window / stream sends its frames back as row runs
+    strip_piece = int(os.environ.get("LT_STRIP_PIECE", "32"))   # frames per overlay launch + strip download of a committed run
     _annotate_inplace = False   # annotate="inplace": annotated frames are the caller's own arrays, drawn over (strips only)
 
     def _window_renderer(self, deferred, base, n, piece=32, frames=None):
@@ -593,14 +594,21 @@ class StreamPipeline:
                 lo, hi = done[0], len(deferred)
                 if hi <= lo or (hi - lo < piece and not force):
                     return
-                part = deferred[lo:hi]
-                ctx.overlay_run_strip_packed(*_pack_deferred(part), first=base + lo)
-                ctx.strip_download_async(out[lo:hi], base + lo, group)
-                # the host's share of these frames, piece by piece as they are committed (all of a window's untouched rows at once, at
-                # its start, sat in the copy threads' queue in front of the last strips of the window before: 9 ms per window
-                # of 1920x1080 frames waiting for them), a frame at a time: its rows from the caller's window, then its text
-                text, nl = _native.text_bytes([d[2] for d in part]) if font is not None else (None, 0)
-                _native.host_text_async(group, out[lo:hi], frames[lo:hi], host_rows, font, text, nl, 40, self._TEXT_ORIGIN, self._TEXT_STEP)
+                # A committed run is up to 128 frames; one overlay launch and one download for all of them would let the first strip
+                # leave the device only when the last frame is drawn, and the window would be handed out 2.4 ms (1280x720; 5.6 ms at
+                # 1920x1080) after its last commit -- time the driving thread spends waiting (tools/annot_cprofile.py).  In pieces
+                # of `strip_piece` frames the strips of a piece cross the bus while the next piece is drawn and the copy threads
+                # place the piece before.
+                for a in range(lo, hi, self.strip_piece):
+                    b = min(a + self.strip_piece, hi)
+                    part = deferred[a:b]
+                    ctx.overlay_run_strip_packed(*_pack_deferred(part), first=base + a)
+                    ctx.strip_download_async(out[a:b], base + a, group)
+                    # the host's share of these frames, piece by piece as they are committed (all of a window's untouched rows at
+                    # once, at its start, sat in the copy threads' queue in front of the last strips of the window before: 9 ms per
+                    # window of 1920x1080 frames waiting for them), a frame at a time: its rows from the caller's window, then its text
+                    text, nl = _native.text_bytes([d[2] for d in part]) if font is not None else (None, 0)
+                    _native.host_text_async(group, out[a:b], frames[a:b], host_rows, font, text, nl, 40, self._TEXT_ORIGIN, self._TEXT_STEP)
                 done[0] = hi
             flush.group = group
             return flush, out
