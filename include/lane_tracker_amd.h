@@ -140,6 +140,12 @@ int  lt_upload_frames(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, in
  * those rows: enough for lt_mask_run and the searches, not for lt_overlay_run, which shows the whole frame. */
 int  lt_get_source_rows(lt_ctx* ctx, int* row0, int* row1);
 int  lt_upload_frame_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
+/* The same copy, waited for by nobody: like lt_upload_frame_rows the call first waits for everything the context has in flight,
+ * then enqueues the copy on the slots' own streams -- ahead of whatever is launched over these slots next -- and returns (from
+ * pageable memory: once the runtime has the bytes on their way).  frames_rgb must stay valid and unchanged until a call that
+ * waits for work launched over these slots afterwards has returned (lt_download_records of a search, lt_sync).  What
+ * LaneTracker.process() uses (:876: one frame per call, the caller's array): the engine's copy runs under the mask chain's launches. */
+int  lt_upload_frame_rows_enqueue(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
 /* The same rows without the host wait: the copy is enqueued on the context's copy stream behind the work already
  * enqueued for these slots, and everything enqueued for them afterwards waits for it -- the upload of one slot range
  * runs under the chain of the others (double-buffered host-fed pipeline).  frames_rgb must stay valid (and should be

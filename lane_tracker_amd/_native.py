@@ -77,6 +77,7 @@ _SIGNATURES = {
     "lt_get_source_rows": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lt_upload_frame_rows": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_frame_rows_async": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "lt_upload_frame_rows_enqueue": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_frame_rest": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_upload_frame_rest_rows": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
     "lt_upload_masks": (C.c_int, [_P, _P, C.c_int, C.c_int]),
@@ -544,9 +545,14 @@ class Context:
         _check(self.lib.lt_get_source_rows(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def upload_frame_rows(self, frames, first=0):
-        """Like upload_frames, but only the camera rows the path reads cross the bus (not enough for the overlay)."""
+    def upload_frame_rows(self, frames, first=0, enqueue=False):
+        """Like upload_frames, but only the camera rows the path reads cross the bus (not enough for the overlay).
+        enqueue: no wait for the copy (lt_upload_frame_rows_enqueue) -- the array handed to the library is returned and must stay
+        alive and unchanged until a call that waits for work launched over these slots afterwards (download_record, sync)."""
         f = _u8(frames).reshape(-1, self.img_h, self.img_w, 3)
+        if enqueue:
+            _check(self.lib.lt_upload_frame_rows_enqueue(self._h, f.ctypes.data, first, f.shape[0]))
+            return f
         _check(self.lib.lt_upload_frame_rows(self._h, f.ctypes.data, first, f.shape[0]))
 
     def upload_frame_rows_async(self, frames, first=0):

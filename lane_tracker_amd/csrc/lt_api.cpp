@@ -1000,7 +1000,7 @@ int lt_get_source_rows(lt_ctx* c, int* row0, int* row1) {
     return LT_OK;
 }
 
-int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
+static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, int n, bool enqueue) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if (!frames) return fail(LT_ERR_INVALID, "null frames");
@@ -1013,11 +1013,23 @@ int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) {
     // (one frame, measured in round 5 against this pitched copy, 279-286 us per frame of process(): a plain copy of the contiguous
     // run 315-320; the rows onto page-locked staging by the copy threads and an asynchronous engine copy from there 295-329, a copy
     // kernel from there 320 -- the runtime's pageable path is the fastest of the four)
+    // enqueue (lt_upload_frame_rows_enqueue): the copy on the slots' own streams, ahead of the kernels lt_mask_run puts there, and no
+    // wait.  From the caller's pageable frame the call returns once the runtime has the bytes on their way (22-27 us for one
+    // 1280x720 frame's rows against 49-54 with the wait: the engine's 18 us run under the mask chain's launches).
+    if (enqueue)
+        return for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
+            HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)f0 * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
+                                     bytes, (size_t)m, hipMemcpyHostToDevice, st));
+            return (int)LT_OK;
+        });
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                              bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return LT_OK;
 }
+
+int lt_upload_frame_rows(lt_ctx* c, const uint8_t* frames, int first, int n) { return upload_frame_rows_impl(c, frames, first, n, false); }
+int lt_upload_frame_rows_enqueue(lt_ctx* c, const uint8_t* frames, int first, int n) { return upload_frame_rows_impl(c, frames, first, n, true); }
 
 // Fallback of the stream-ordered uploads when the ring of readers has overflowed: `waiter` waits for the tail of every stream
 // a kernel that reads camera frames can be on -- the slots' compute streams (undistortion), the presentation stream (overlays)

@@ -691,40 +691,51 @@ class LaneTracker(StreamPipeline):
         if not reuse_frame:
             # only the camera rows the path reads are on the critical path; the rest of the frame (the overlay
             # shows it) follows on a copy stream while the mask chain runs
-            ctx.upload_frame_rows(img, first=slot)
-        self._resident = (img, slot)
-        if not have_mask:
-            ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
-                                                  ksize_noise, C_noise), first=slot)
+            # (not waited for: the engine's copy runs under the mask chain's launches; `img` -- or the contiguous copy the binding
+            # made of it -- stays alive until the frame's record is on the host, and process() waits for the device on its way out
+            # of an exception)
+            self._rows_keepalive = ctx.upload_frame_rows(img, first=slot, enqueue=self.enqueues_upload)
+        try:
+            self._resident = (img, slot)
+            if not have_mask:
+                ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
+                                                      ksize_noise, C_noise), first=slot)
 
-        def while_the_device_searches():
-            # behind the search's launch (the device has the whole chain queued; the host's share of the frame must not delay it)
-            if self._want_out and self._out is None:
-                self._prepare_out()          # the output array; its untouched rows start to fill on the library's copy thread
-            if not reuse_frame:
-                # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
-                rows = self._rows_for(img) if self._want_out else None
-                if rows is not None and rows[4] is not None:
-                    if rows[4][4]:           # (rows of the lane's run the mask chain does not read: none with the reference calibration)
-                        self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=rows[4][1])
-                else:
-                    self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
-                self._resident_partial = rows is not None
-        if self.last_detection > self.n_reset:                       # :851
+            def while_the_device_searches():
+                # behind the search's launch (the device has the whole chain queued; the host's share of the frame must not delay it)
+                if self._want_out and self._out is None:
+                    self._prepare_out()          # the output array; its untouched rows start to fill on the library's copy thread
+                if not reuse_frame:
+                    # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
+                    rows = self._rows_for(img) if self._want_out else None
+                    if rows is not None and rows[4] is not None:
+                        if rows[4][4]:           # (rows of the lane's run the mask chain does not read: none with the reference calibration)
+                            self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=rows[4][1])
+                    else:
+                        self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
+                    self._resident_partial = rows is not None
+            if self.last_detection > self.n_reset:                       # :851
+                if diagnostics:
+                    print("Using sliding window search.")
+                self._search_uploaded(ctx, 'sws', dict(window_width=window_width, window_height=window_height,
+                                                       search_range=search_range, mu=mu,
+                                                       no_success_limit=no_success_limit, start_slice=start_slice,
+                                                       ignore_sides=ignore_sides, ignore_bottom=ignore_bottom,
+                                                       partial=partial), diagnostics, slot=slot, lazy=lazy,
+                                      between=while_the_device_searches)
+                return 'sws'
             if diagnostics:
-                print("Using sliding window search.")
-            self._search_uploaded(ctx, 'sws', dict(window_width=window_width, window_height=window_height,
-                                                   search_range=search_range, mu=mu,
-                                                   no_success_limit=no_success_limit, start_slice=start_slice,
-                                                   ignore_sides=ignore_sides, ignore_bottom=ignore_bottom,
-                                                   partial=partial), diagnostics, slot=slot, lazy=lazy,
-                                  between=while_the_device_searches)
-            return 'sws'
-        if diagnostics:
-            print("Using band search.")
-        self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
-                              diagnostics, slot=slot, lazy=lazy, between=while_the_device_searches)
-        return 'bs'
+                print("Using band search.")
+            self._search_uploaded(ctx, 'bs', dict(bandwidth=bandwidth, ignore_bottom=ignore_bottom, partial=partial),
+                                  diagnostics, slot=slot, lazy=lazy, between=while_the_device_searches)
+            return 'bs'
+        except BaseException:
+            if not reuse_frame and self.enqueues_upload:     # the frame's rows may still be on their way: the caller's array must outlive the copy
+                try:
+                    ctx.sync()
+                except Exception:
+                    pass
+            raise
 
     # ---- the two outcomes of a frame (reference :1142-1159, :1178-1202) ------------------------------------------
     def _record_failure(self):
@@ -745,6 +756,8 @@ class LaneTracker(StreamPipeline):
             L, R = L[1:], R[1:]
         return _mean_of_rows([c for c in L if c.size != 0]), _mean_of_rows([c for c in R if c.size != 0])
 
+    enqueues_upload = os.environ.get("LT_UPLOAD_ENQUEUE", "1") != "0"   # False: lt_upload_frame_rows waits for its copy (A/B, tests)
+    _rows_keepalive = None
     speculates_lane = os.environ.get("LT_LANE_AHEAD", "1") != "0"   # False: the lane is drawn once the frame is known to be valid (A/B, tests)
     _lane_in_flight = None      # the packed-point buffers whose polygon lt_present_lane_async is drawing / has drawn for this frame
 

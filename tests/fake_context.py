@@ -65,7 +65,7 @@ class FakeContext:
     def close(self):
         pass
 
-    def upload_frame_rows(self, frames, first=0):
+    def upload_frame_rows(self, frames, first=0, enqueue=False):
         f = np.asarray(frames).reshape(-1, self.img_h, self.img_w, 3)
         for k in range(f.shape[0]):
             assert first + k < self.capacity

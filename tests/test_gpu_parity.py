@@ -118,6 +118,24 @@ def test_one_and_two_frame_chains_bit_exact(ctx, nat, oracle, ref_calib, frames,
             assert_same(oracle.morph_open(merged[k], 5), want, f"open(merged plane) of frame {start + k}, {kw}")
 
 
+def test_enqueued_row_upload_is_the_waited_for_one(ctx, nat, oracle, ref_calib, frames):
+    """lt_upload_frame_rows_enqueue (what process() uses: the copy is not waited for, the mask chain is launched behind it on the
+    slots' own streams) against lt_upload_frame_rows: same masks, for one frame and for several slots' streams at once; the array
+    handed over may be dropped once a record / a sync has been waited for."""
+    for first, n in ((0, 1), (1, 1), (0, 5), (3, 2)):
+        ctx.upload_frame_rows(frames[1:1 + n], first=first)          # what the slots held before: other frames
+        ctx.mask_run(n, first=first)
+        keep = ctx.upload_frame_rows(frames[2:2 + n].copy(), first=first, enqueue=True)
+        ctx.mask_run(n, first=first)
+        ctx.sync()
+        keep[...] = 0
+        del keep
+        masks = ctx.download_masks(n, first=first)
+        for k in range(n):
+            want = oracle.filter_lane_points(oracle.front_end(ref_calib, frames[2 + k]), oracle.filter_params())
+            assert_same(masks[k], want, f"frame {2 + k} in slot {first + k}, enqueued upload of {n}")
+
+
 def test_bad_filter_type_raises_value_error(ctx, nat, frames):
     ctx.upload_frames(frames[:1])
     with pytest.raises(ValueError):
