@@ -122,7 +122,7 @@ def test_enqueued_row_upload_is_the_waited_for_one(ctx, nat, oracle, ref_calib, 
     """lt_upload_frame_rows_enqueue (what process() uses: the copy is not waited for, the mask chain is launched behind it on the
     slots' own streams) against lt_upload_frame_rows: same masks, for one frame and for several slots' streams at once; the array
     handed over may be dropped once a record / a sync has been waited for."""
-    for first, n in ((0, 1), (1, 1), (0, 5), (3, 2)):
+    for first, n in ((0, 1), (1, 1), (0, 4), (3, 2)):
         ctx.upload_frame_rows(frames[1:1 + n], first=first)          # what the slots held before: other frames
         ctx.mask_run(n, first=first)
         keep = ctx.upload_frame_rows(frames[2:2 + n].copy(), first=first, enqueue=True)
