@@ -396,7 +396,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     // ... with the H and the V phases of a tile in workgroups of their own (one frame: 81 tiles on 256 CUs), their verdicts in
     // partial planes of their own: R -> ebits, ubits; Lab-b -> mbits, tbits (LT_THRESHOLD_PHASES=0: one workgroup per tile)
     static const bool phases_ok = [] { const char* e = std::getenv("LT_THRESHOLD_PHASES"); return !(e && e[0] == '0'); }();
-    bool phase_split = false;
+    bool phase_split = false, both_split = false;
     if (p->filter_type == 0) {
         if (c->brute_tophat) {   // debugging aid (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
@@ -424,7 +424,11 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             // to go, and the threshold kernel takes its planes one after the other anyway -- here one per launch, the R
             // verdicts as a partial bit plane the open ORs in (12 us less on the one-frame chain)
             static const bool split_ok = [] { const char* e = std::getenv("LT_THRESHOLD_SPLIT"); return !(e && e[0] == '0'); }();
-            if (split_ok && !walk && !p->mask_noise) {
+            // LT_R_THRESHOLD_MAIN=1 (experiment): the R plane's threshold not on the side stream but with the Lab-b plane's in one
+            // launch behind the join (H phases of both planes into mbits, V phases into ebits)
+            static const bool r_on_main = [] { const char* e = std::getenv("LT_R_THRESHOLD_MAIN"); return e && e[0] == '1'; }();
+            both_split = r_on_main && phases_ok && !walk && !p->mask_noise;
+            if (split_ok && !walk && !p->mask_noise && !both_split) {
                 phase_split = phases_ok && tbits && ubits;
                 r_verdicts_done = launch_bilateral_bits(c->side, thR, p->ksize_r, p->C_r, nullptr, 1, 0, B, p->ksize_noise, p->C_noise,
                                                         p->noise_thresh, 0, ebits, h, w, ps, c->bits_stride, n, phase_split ? ubits : nullptr) == 0;
@@ -471,6 +475,11 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
                                                 p->noise_thresh, 0, mbits, h, w, ps, c->bits_stride, n, phase_split ? tbits : nullptr) == 0;
             partials = merged_done;
             two_partials = merged_done && !phase_split;
+        }
+        if (!merged_done && both_split) {
+            merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise, p->C_noise,
+                                                p->noise_thresh, 0, mbits, h, w, ps, c->bits_stride, n, ebits) == 0;
+            partials = two_partials = merged_done;
         }
         if (!merged_done)
           merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise,
