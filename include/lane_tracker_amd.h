@@ -140,9 +140,9 @@ int  lt_upload_frames(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, in
  * those rows: enough for lt_mask_run and the searches, not for lt_overlay_run, which shows the whole frame. */
 int  lt_get_source_rows(lt_ctx* ctx, int* row0, int* row1);
 int  lt_upload_frame_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
-/* The same copy, waited for by nobody: like lt_upload_frame_rows the call first waits for everything the context has in flight,
- * then enqueues the copy on the slots' own streams -- ahead of whatever is launched over these slots next -- and returns (from
- * pageable memory: once the runtime has the bytes on their way).  frames_rgb must stay valid and unchanged until a call that
+/* The same copy, waited for by nobody: enqueued on the slots' own streams -- behind everything launched over these slots so far
+ * (and behind overlays of other streams that still read them), ahead of whatever is launched over them next -- and the call
+ * returns (from pageable memory: once the runtime has the bytes on their way).  frames_rgb must stay valid and unchanged until a call that
  * waits for work launched over these slots afterwards has returned (lt_download_records of a search, lt_sync).  What
  * LaneTracker.process() uses (:876: one frame per call, the caller's array): the engine's copy runs under the mask chain's launches. */
 int  lt_upload_frame_rows_enqueue(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
@@ -300,6 +300,21 @@ int  lt_present_lane_async(lt_ctx* ctx, int slot, const int32_t* left_n, const i
                            const int32_t* right_yx, double alpha, uint8_t* out, const int32_t* rows4);
 int  lt_present_finish(lt_ctx* ctx, int slot, const char* lines, int n_lines, int line_len, int x0, int y0, int step,
                        uint8_t* out, const int32_t* rows4);
+/* The first half without the host: the averaged lane of the frame in `slot` (draw_lane's polygon, :629-662, of the running average
+ * :1182-1189 that this frame's fit would give) drawn by the device itself, enqueued on the slot's stream right behind its search --
+ * call it after lt_band_fit_run / lt_sws_fit_run over that one slot, before waiting for the record.  prev_sum: the sum, in order,
+ * of the older fits (left a, b, c, right a, b, c) that stay in the average, count: fits in the average with this frame's (1: this
+ * frame's alone, prev_sum ignored); ploty / ploty2: get_poly_points' rows and their squares (:514).  One workgroup forms average,
+ * plot points and the polygon's row intervals from the fit in the slot's record with the host's f64 operations in the host's order;
+ * the overlay stores the rows of rows4's second run (its first run must be empty: text on the host) into the page-locked `out`.
+ * A record without a usable fit (nothing detected, fit_flags != 0) draws nothing; lt_present_finish waits for the rows.  Returns
+ * LT_ERR_STATE where this form does not exist (out not page-locked / 16-byte aligned, too many plot rows): draw with
+ * lt_present_lane_async then.  lt_lane_spans_from_fit: the same workgroup for a fit given by value, its row intervals
+ * (warp_h x (lo, hi) int16) brought back -- for tests. */
+int  lt_present_lane_from_fit_async(lt_ctx* ctx, int slot, const double* prev_sum, int count, const double* ploty,
+                                    const double* ploty2, int n_rows, double alpha, uint8_t* out, const int32_t* rows4);
+int  lt_lane_spans_from_fit(lt_ctx* ctx, const double* fit6, int detected, int fit_flags, const double* prev_sum, int count,
+                            const double* ploty, const double* ploty2, int n_rows, int16_t* spans_out);
 /* Host-only helper (no GPU needed): the (lo, hi) column interval per bird's-eye row that cv2.fillPoly
  * paints for that polygon; empty rows are (32767, -32768).  spans: warp_h * 2 int16. */
 int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const int32_t* right_yx, int n_right,

@@ -97,6 +97,8 @@ _SIGNATURES = {
     "lt_present_frame": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "lt_present_lane_async": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P]),
     "lt_present_finish": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "lt_present_lane_from_fit_async": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_double, _P, _P]),
+    "lt_lane_spans_from_fit": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
     "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "lt_download_overlay": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_overlay_async": (C.c_int, [_P, C.c_int, C.c_int, _P]),
@@ -741,6 +743,27 @@ class Context:
         rc = self.lib.lt_present_lane_async(self._h, slot, left_n, right_n, left_yx, right_yx, alpha, out.ctypes.data, rows)
         if rc:
             _check(rc)
+
+    def present_lane_from_fit_async(self, slot, prev_sum_addr, count, ploty_addr, ploty2_addr, n_rows, out, rows, alpha=0.3):
+        """The lane drawn by the device itself behind the slot's search (lt_present_lane_from_fit_async) -> True, or False where
+        that form does not exist (LT_ERR_STATE: the caller draws once it has the record).  Addresses of f64 buffers the caller keeps."""
+        rc = self.lib.lt_present_lane_from_fit_async(self._h, slot, prev_sum_addr, count, ploty_addr, ploty2_addr, n_rows, alpha,
+                                                     out.ctypes.data, rows)
+        if rc == -5:
+            return False
+        if rc:
+            _check(rc)
+        return True
+
+    def lane_spans_from_fit(self, fit6, prev_sum, count, ploty, ploty2, detected=True, fit_flags=0):
+        """Test hook (lt_lane_spans_from_fit): the row intervals (warp_h, 2) int16 the device forms for a fit given by value."""
+        fit6 = np.ascontiguousarray(fit6, np.float64).reshape(6)
+        ps = np.ascontiguousarray(prev_sum if prev_sum is not None else np.zeros(6), np.float64).reshape(6)
+        ploty, ploty2 = np.ascontiguousarray(ploty, np.float64), np.ascontiguousarray(ploty2, np.float64)
+        out = np.empty((self.warp_h, 2), np.int16)
+        _check(self.lib.lt_lane_spans_from_fit(self._h, fit6.ctypes.data, int(bool(detected)), int(fit_flags), ps.ctypes.data, int(count),
+                                               ploty.ctypes.data, ploty2.ctypes.data, len(ploty), out.ctypes.data))
+        return out
 
     def present_finish(self, slot, text, n_lines, line_len, out, rows, origin=(20, 8), step=35):
         """Second half (lt_present_finish): the text lines, their rows into `out`, and the wait for both halves."""

@@ -124,6 +124,139 @@ __global__ __launch_bounds__(256) void k_overlay_lane4_arg(const uint32_t* __res
     dst[2] = d2;
 }
 
+// ---- the lane polygon of a frame from its fit, on the device (process(): the overlay enqueued right behind the search) --------
+// What the host does between a frame's record and the overlay's launch -- the averaged curves (LaneTracker._averages_with), their
+// plot points (lt_poly_points = get_poly_points, lane_tracker.py:511-528) and the polygon's row intervals (lane_polygon_spans =
+// cv2.fillPoly's hull of the edge lines per row) -- restated for ONE workgroup that runs behind the search kernel and reads
+// the fit from the slot's record: the same f64 operations in the same order (this file is built with -ffp-contract=off), the
+// same integer line walk.  The overlay kernel behind it then finds the intervals in device memory, 40 us before the host could have
+// launched it.  A record without a usable fit (nothing detected, a rank-deficient side: the host refits those) leaves empty
+// intervals -- the frame's rows come back as they are and the host draws whatever it decides on.
+struct LaneFromFit {
+    double prev_sum[6];   // sum, in order, of the older fits that stay in the running average (left a, b, c; right a, b, c)
+    int count;            // fits in the average, this frame's included (>= 1)
+    int n_rows;           // plot rows (ploty, ploty ** 2 of get_poly_points)
+    int bh, bw;           // bird's-eye size
+};
+
+__device__ __forceinline__ void dev_span_point(int* lo, int* hi, int bh, int x, int y) {
+    if (y >= 0 && y < bh) {
+        const int xc = min(max(x, -32768), 32767);
+        atomicMin(&lo[y], xc);
+        atomicMax(&hi[y], xc);
+    }
+}
+// OpenCV's LineIterator as lt_present.cpp::span_line walks it (left end point first, error term dx - 2 dy)
+__device__ void dev_span_line(int* lo, int* hi, int bh, int xa, int ya, int xb, int yb) {
+    if (xb < xa) { const int tx = xa; xa = xb; xb = tx; const int ty = ya; ya = yb; yb = ty; }
+    const int adx = xb - xa, ady = abs(yb - ya), ystep = yb < ya ? -1 : 1;
+    const bool tall = ady > adx;
+    const int len = tall ? ady : adx, across = tall ? adx : ady;
+    int err = len - 2 * across;
+    for (int i = 0, x = xa, y = ya; i <= len; ++i) {
+        dev_span_point(lo, hi, bh, x, y);
+        const bool turn = err < 0;
+        err -= 2 * across;
+        if (turn) err += 2 * len;
+        if (tall) { y += ystep; x += turn ? 1 : 0; }
+        else { x += 1; y += turn ? ystep : 0; }
+    }
+}
+
+constexpr int LFF_T = 256, LFF_LONG = 64;
+__global__ __launch_bounds__(LFF_T) void k_lane_spans_from_fit(const lt_lane_record* __restrict__ rec, LaneFromFit p,
+                                                                const double* __restrict__ ploty, const double* __restrict__ ploty2,
+                                                                short2* __restrict__ spans) {
+    extern __shared__ int s_i[];              // lo[bh], hi[bh], px[2][n_rows]
+    int* lo = s_i;
+    int* hi = lo + p.bh;
+    int* px = hi + p.bh;
+    __shared__ double s_avg[6];
+    __shared__ int s_wave[LFF_T / 64], s_cnt[2], s_long[LFF_LONG], s_nlong;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool usable = rec->detected != 0 && rec->fit_flags == 0;
+    for (int y = tid; y < p.bh; y += LFF_T) { lo[y] = 32767; hi[y] = -32768; }
+    if (tid < 6) {
+        const double fit = tid < 3 ? rec->left_coeffs[tid] : rec->right_coeffs[tid - 3];
+        const double acc = p.count > 1 ? p.prev_sum[tid] + fit : fit;      // _mean_of_rows: the sum in order, this frame's fit last,
+        s_avg[tid] = acc / (double)p.count;                                  // then one division by the count
+    }
+    __syncthreads();
+    if (usable) {
+        const double xmax = (double)(p.bw - 1);
+        for (int side = 0; side < 2; ++side) {
+            const double a = s_avg[3 * side], b = s_avg[3 * side + 1], c = s_avg[3 * side + 2];
+            int base = 0;                                                    // points of this side kept so far (uniform)
+            for (int r0 = 0; r0 < p.n_rows; r0 += LFF_T) {
+                const int r = r0 + tid;
+                bool in = false;
+                int xi = 0;
+                if (r < p.n_rows) {
+                    const double t1 = a * ploty2[r], t2 = b * ploty[r];
+                    const double x = (t1 + t2) + c;
+                    in = x <= xmax && x >= 0.0;
+                    if (in) xi = (int)(long long)x;
+                }
+                const unsigned long long m = __ballot(in);
+                if (lane == 0) s_wave[wv] = __popcll(m);
+                __syncthreads();
+                int before = 0, total = 0;
+                for (int q = 0; q < LFF_T / 64; ++q) { if (q < wv) before += s_wave[q]; total += s_wave[q]; }
+                if (in) px[side * p.n_rows + base + before + __popcll(m & ((1ull << lane) - 1ull))] = xi;
+                base += total;
+                __syncthreads();
+            }
+            if (tid == 0) s_cnt[side] = base;
+        }
+        __syncthreads();
+        // the closed polygon: the left points in order, then the right points reversed; every vertex is the end point of the edge
+        // before it (lane_polygon_spans)
+        const int nl = s_cnt[0], nr = s_cnt[1], np = nl + nr;
+        auto vertex = [&](int i, int& x, int& y) {
+            if (i < nl) { x = px[i]; y = p.bh - nl + i; }
+            else { const int k = nr - 1 - (i - nl); x = px[p.n_rows + k]; y = p.bh - nr + k; }
+        };
+        // Long edges -- the two that close the polygon run across the lane, a few hundred pixels each -- are set aside and walked by
+        // the whole workgroup: pixel i of the iterator in closed form (turns before step i: T_i = max(0, ceil((2 across i - len)
+        // / (2 len))), from err_i = len - 2 across (i + 1) + 2 len T_i; held against the walk for 200 000 random lines)
+        if (tid == 0) s_nlong = 0;
+        __syncthreads();
+        for (int e = tid; e < np; e += LFF_T) {
+            int x0, y0, x1, y1;
+            vertex(e == 0 ? np - 1 : e - 1, x0, y0);
+            vertex(e, x1, y1);
+            const int adx = abs(x1 - x0), ady = abs(y1 - y0);
+            if (adx <= 1 && ady <= 1) dev_span_point(lo, hi, p.bh, x1, y1);
+            else if (max(adx, ady) <= 16) dev_span_line(lo, hi, p.bh, x0, y0, x1, y1);
+            else {
+                const int k = atomicAdd(&s_nlong, 1);
+                if (k < LFF_LONG) s_long[k] = e;
+                else dev_span_line(lo, hi, p.bh, x0, y0, x1, y1);
+            }
+        }
+        __syncthreads();
+        const int nlong = min(s_nlong, LFF_LONG);
+        for (int k = 0; k < nlong; ++k) {
+            const int e = s_long[k];
+            int xa, ya, xb, yb;
+            vertex(e == 0 ? np - 1 : e - 1, xa, ya);
+            vertex(e, xb, yb);
+            if (xb < xa) { const int tx = xa; xa = xb; xb = tx; const int ty = ya; ya = yb; yb = ty; }
+            const int adx = xb - xa, ady = abs(yb - ya), ystep = yb < ya ? -1 : 1;
+            const bool tall = ady > adx;
+            const int len = tall ? ady : adx, across = tall ? adx : ady;
+            for (int i = tid; i <= len; i += LFF_T) {
+                const long long num = 2ll * across * i - len;
+                const int T = num <= 0 ? 0 : (int)((num + 2ll * len - 1) / (2ll * len));
+                if (tall) dev_span_point(lo, hi, p.bh, xa + T, ya + ystep * i);
+                else dev_span_point(lo, hi, p.bh, xa + i, ya + ystep * T);
+            }
+        }
+        __syncthreads();
+    }
+    for (int y = tid; y < p.bh; y += LFF_T) spans[y] = make_short2((short)lo[y], (short)hi[y]);
+}
+
 // Bird's-eye RGB of the undistorted rows (same taps and blend as k_warp_split, colour kept).
 __global__ __launch_bounds__(256) void k_warp_rgb(const uint32_t* __restrict__ und, size_t und_px, int first_slot,
                                                  const int16_t* __restrict__ wxy, const uint16_t* __restrict__ wfrac,
@@ -333,6 +466,28 @@ bool launch_overlay_lane_one(hipStream_t s, const uint8_t* frame, uint8_t* out, 
     hipLaunchKernelGGL(k_overlay_lane4_arg, dim3((na + nb + 255) / 256), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(frame),
                        reinterpret_cast<uint32_t*>(out), oxy, ofrac, qa, na, qb, nb, bh, bw, alpha, arg);
     if (hipGetLastError() != hipSuccess) { refused = true; return false; }
+    return true;
+}
+
+// one word into (page-locked, device-visible) memory behind everything enqueued on `s` so far: a ticket the host polls instead of
+// waiting for the stream (hipStreamSynchronize on a stream with a dozen finished launches costs 15-20 us of bookkeeping)
+namespace { __global__ void k_store_word(volatile unsigned* p, unsigned v) { __threadfence_system(); *p = v; } }
+void launch_store_word(hipStream_t s, unsigned* dev_word, unsigned value) {
+    hipLaunchKernelGGL(k_store_word, dim3(1), dim3(1), 0, s, dev_word, value);
+}
+
+// row intervals of the averaged lane of the frame whose record is *rec (k_lane_spans_from_fit); false: too many rows for the LDS
+bool launch_lane_spans_from_fit(hipStream_t s, const lt_lane_record* rec, const double* prev_sum, int count, const double* ploty,
+                                const double* ploty2, int n_rows, int bh, int bw, int16_t* spans) {
+    const size_t lds = ((size_t)2 * bh + (size_t)2 * std::max(n_rows, 1)) * sizeof(int);
+    if (lds > 60 * 1024 || count < 1 || n_rows < 0) return false;
+    LaneFromFit p;
+    for (int k = 0; k < 6; ++k) p.prev_sum[k] = prev_sum ? prev_sum[k] : 0.0;
+    p.count = count;
+    p.n_rows = n_rows;
+    p.bh = bh;
+    p.bw = bw;
+    hipLaunchKernelGGL(k_lane_spans_from_fit, dim3(1), dim3(LFF_T), lds, s, rec, p, ploty, ploty2, reinterpret_cast<short2*>(spans));
     return true;
 }
 

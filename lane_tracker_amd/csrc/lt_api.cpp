@@ -177,6 +177,8 @@ void free_slots(lt_ctx* c) {
     dev_free(c->d_cent);
     dev_free(c->d_band_sums);
     dev_free(c->d_spans);
+    dev_free(c->d_ploty);
+    c->h_ploty.clear();
     dev_free(c->d_annot);
     dev_free(c->d_strip);
     dev_free(c->d_side_scratch);
@@ -1009,13 +1011,19 @@ int lt_get_source_rows(lt_ctx* c, int* row0, int* row1) {
     return LT_OK;
 }
 
+static int wait_reader_tails(lt_ctx* c, hipStream_t waiter);
 static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, int n, bool enqueue) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if (!frames) return fail(LT_ERR_INVALID, "null frames");
     if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
     if ((rc = set_device(c))) return rc;
-    if ((rc = sync_all(c))) return rc;
+    // The enqueued form waits for nothing on the host: the copy goes onto the slots' own streams (behind everything launched over
+    // these slots there) and, like lt_upload_frame_rows_async's, behind the kernels of OTHER streams that still read the slots'
+    // camera rows -- overlays on the presentation stream (slot-range events).  LT_UPLOAD_SYNC=1: wait for the whole context first, as
+    // lt_upload_frame_rows does (A/B; 5-10 us of a process() frame, on its critical path).
+    static const bool enqueue_syncs = [] { const char* e = std::getenv("LT_UPLOAD_SYNC"); return e && e[0] == '1'; }();
+    if ((!enqueue || enqueue_syncs) && (rc = sync_all(c))) return rc;
     mark_frames(c, first, n, 0);         // a new frame's rows: the others are the previous occupant's until lt_upload_frame_rest
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
     const size_t bytes = (size_t)(c->cam_r1 - c->cam_r0) * row_bytes;
@@ -1027,6 +1035,12 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
     // 1280x720 frame's rows against 49-54 with the wait: the engine's 18 us run under the mask chain's launches).
     if (enqueue)
         return for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
+            if (!enqueue_syncs) {
+                bool precise = true;
+                int wrc = wait_range(c->readers, st, f0, f0 + m, &precise);
+                if (wrc) return wrc;
+                if (!precise && (wrc = wait_reader_tails(c, st))) return wrc;
+            }
             HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)f0 * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                                      bytes, (size_t)m, hipMemcpyHostToDevice, st));
             return (int)LT_OK;

@@ -121,6 +121,11 @@ struct lt_ctx {
     // overlay of a stream of windows ran 30 ms after its frames were ready).  It waits, per slot range, for the kernels that
     // wrote the slots' masks (hence for their camera rows) and for the copies of the remaining rows.
     hipStream_t present = nullptr;
+    // lt_present_lane_from_fit_async: the plot rows (ploty, ploty ** 2) the device evaluates the averaged curves at, as last sent
+    double* d_ploty = nullptr;        // [2][ploty_rows]
+    std::vector<double> h_ploty;      // what d_ploty holds (compared on every call: 2 x 9 KB)
+    hipStream_t lane_spec_stream = nullptr;   // the stream a speculative overlay of process() runs on, until lt_present_finish has waited for it
+    unsigned lane_spec_ticket = 0;            // ... and the ticket a one-thread launch behind it stores at h_rec + 128 bytes (0: none, wait for the stream)
     // lt_set_urgent: while on, the stage calls run on this stream instead of the slots' streams -- behind what was enqueued
     // for THEIR slots only (slot-range events), not behind the masks of later frames queued on the slots' streams, which
     // wait for uploads still on the bus.  The stateful stream handles a frame whose first try failed this way.

@@ -74,6 +74,9 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
 // runs of camera rows {a0, a1, b0, b1} (the others are not written); false: not launched (bh above LT_SPAN_ARG_ROWS, a row
 // length that is no multiple of 4, or the runtime refused the argument block)
 constexpr int LT_SPAN_ARG_ROWS = 1104;
+void launch_store_word(hipStream_t s, unsigned* dev_word, unsigned value);
+bool launch_lane_spans_from_fit(hipStream_t s, const lt_lane_record* rec, const double* prev_sum, int count, const double* ploty,
+                                const double* ploty2, int n_rows, int bh, int bw, int16_t* spans);
 bool launch_overlay_lane_one(hipStream_t s, const uint8_t* frame, uint8_t* out, const int16_t* oxy, const uint16_t* ofrac,
                              const int16_t* spans_host, int img_h, int img_w, int bh, int bw, float alpha, const int* rows4);
 void launch_overlay_text(hipStream_t s, uint8_t* out, size_t frame_stride, int img_h, int img_w, const uint8_t* atlas,

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -659,19 +660,138 @@ int lt_present_lane_async(lt_ctx* c, int slot, const int32_t* left_n, const int3
     return present_copy_rows(c, slot, out, r[2], r[3]);
 }
 
+// The lane of a frame drawn WITHOUT the host: enqueued on the slot's own stream right behind its search (call it after
+// lt_band_fit_run / lt_sws_fit_run over that one slot).  One workgroup forms the running average with the fit of the slot's
+// record, the averaged curves' plot points and the polygon's row intervals (k_lane_spans_from_fit: the host's operations, in the
+// host's order), the overlay kernel behind it stores the rows the lane can reach into the page-locked frame `out` -- 40 us before
+// the host, which has to see the record first, could have launched it.  A record without a usable fit draws nothing (the rows
+// come back as the camera's); a frame the host then finds invalid is drawn again by whatever it presents (lt_present_frame /
+// lt_present_lane_async wait for this overlay).  LT_ERR_STATE: not available for these arguments (rows4's first run not empty,
+// `out` not page-locked, too many plot rows) -- the caller draws the lane itself once it has the record.
+int lt_present_lane_from_fit_async(lt_ctx* c, int slot, const double* prev_sum, int count, const double* ploty, const double* ploty2,
+                                   int n_rows, double alpha, uint8_t* out, const int32_t* rows4) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!out || !ploty || !ploty2 || n_rows < 1 || count < 1 || (count > 1 && !prev_sum)) return fail(LT_ERR_INVALID, "lt_present_lane_from_fit_async: bad arguments");
+    if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_present_lane_from_fit_async before lt_overlay_configure");
+    int r[4];
+    if ((rc = present_rows(c, rows4, false, 0, 0, 0, true, true, r))) return rc;
+    if ((rc = set_device(c))) return rc;
+    void* dev = nullptr;
+    if (r[1] > r[0] || ((uintptr_t)out & 15) || (c->calib.img_w & 3) || hipHostGetDevicePointer(&dev, out, 0) != hipSuccess || !dev) {
+        (void)hipGetLastError();
+        return fail(LT_ERR_STATE, "lt_present_lane_from_fit_async: needs the lane's run alone and a page-locked, 16-byte aligned frame");
+    }
+    const int bh = c->calib.warp_h;
+    if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
+    // the plot rows on the device: sent when they change (they depend on `partial` and the image height only)
+    if ((int)c->h_ploty.size() != 2 * n_rows || std::memcmp(c->h_ploty.data(), ploty, (size_t)n_rows * sizeof(double)) != 0 ||
+        std::memcmp(c->h_ploty.data() + n_rows, ploty2, (size_t)n_rows * sizeof(double)) != 0) {
+        if ((rc = sync_all(c))) return rc;
+        dev_free(c->d_ploty);
+        c->d_ploty = nullptr;
+        c->h_ploty.assign(ploty, ploty + n_rows);
+        c->h_ploty.insert(c->h_ploty.end(), ploty2, ploty2 + n_rows);
+        uint8_t* raw = nullptr;
+        if ((rc = dev_alloc(&raw, (size_t)2 * n_rows * sizeof(double)))) { c->h_ploty.clear(); return rc; }
+        c->d_ploty = reinterpret_cast<double*>(raw);
+        HIP_TRY(hipMemcpyAsync(c->d_ploty, c->h_ploty.data(), (size_t)2 * n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return for_each_slice(c, slot, 1, [&](hipStream_t st, int f0, int) {
+        if (c->rest_pending) {       // rows of the frame the mask chain's upload did not bring (lt_upload_frame_rest): the overlay reads them
+            bool precise = true;
+            int wrc = wait_range(c->rests, st, f0, f0 + 1, &precise);
+            if (wrc) return wrc;
+            if (!precise) HIP_TRY(hipStreamWaitEvent(st, c->rest_done, 0));
+        }
+        int16_t* sp = c->d_spans + (size_t)f0 * bh * 2;
+        if (!launch_lane_spans_from_fit(st, c->d_rec + f0, prev_sum, count, c->d_ploty, c->d_ploty + n_rows, n_rows, bh, c->calib.warp_w, sp))
+            return fail(LT_ERR_STATE, "lt_present_lane_from_fit_async: too many rows for one workgroup's LDS");
+        launch_overlay_lane(st, c->d_frames + (size_t)f0 * c->frame_bytes, static_cast<uint8_t*>(dev), c->frame_bytes, c->d_oxy, c->d_ofrac, sp,
+                            (size_t)bh, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, 1, r);
+        HIP_TRY(hipGetLastError());
+        c->lane_spec_stream = st;
+        c->lane_spec_ticket = 0;
+        if (c->h_rec) {               // (the record mirror's page-locked block, 256 bytes: the record, its ticket at +64, this one at +128)
+            void* hdev = nullptr;
+            if (hipHostGetDevicePointer(&hdev, c->h_rec, 0) == hipSuccess && hdev) {
+                unsigned t = ++c->rec_ticket_counter;
+                if (!t) t = ++c->rec_ticket_counter;
+                launch_store_word(st, reinterpret_cast<unsigned*>(static_cast<char*>(hdev) + 128), t);
+                c->lane_spec_ticket = t;
+            } else (void)hipGetLastError();
+        }
+        int nrc = note_range(c->readers, st, f0, f0 + 1);            // the next upload into this slot waits for the overlay's reads
+        return nrc ? nrc : note_written(c, st, f0, f0 + 1);           // ... and an overlay on the presentation stream for this one's stores
+    });
+}
+
+// test hook: the row intervals k_lane_spans_from_fit forms for a fit given by value (a record of its own in the slot's place)
+int lt_lane_spans_from_fit(lt_ctx* c, const double* fit6, int detected, int fit_flags, const double* prev_sum, int count, const double* ploty,
+                           const double* ploty2, int n_rows, int16_t* spans_out) {
+    if (!c || !fit6 || !ploty || !ploty2 || !spans_out || n_rows < 1 || count < 1) return fail(LT_ERR_INVALID, "lt_lane_spans_from_fit: bad arguments");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = sync_all(c))) return rc;
+    const int bh = c->calib.warp_h;
+    lt_lane_record rec;
+    std::memset(&rec, 0, sizeof rec);
+    for (int k = 0; k < 3; ++k) { rec.left_coeffs[k] = fit6[k]; rec.right_coeffs[k] = fit6[3 + k]; }
+    rec.detected = (uint8_t)(detected != 0);
+    rec.fit_flags = (uint8_t)fit_flags;
+    uint8_t *d_rec = nullptr, *d_pl = nullptr, *d_sp = nullptr;
+    if ((rc = dev_alloc(&d_rec, sizeof rec)) || (rc = dev_alloc(&d_pl, (size_t)2 * n_rows * sizeof(double))) || (rc = dev_alloc(&d_sp, (size_t)bh * 4))) {
+        dev_free(d_rec); dev_free(d_pl); dev_free(d_sp);
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_rec, &rec, sizeof rec, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pl, ploty, (size_t)n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pl + (size_t)n_rows * sizeof(double), ploty2, (size_t)n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_sp, 0x55, (size_t)bh * 4, c->stream);
+    bool launched = false;
+    if (e == hipSuccess) {
+        launched = launch_lane_spans_from_fit(c->stream, reinterpret_cast<const lt_lane_record*>(d_rec), prev_sum, count, reinterpret_cast<const double*>(d_pl),
+                                              reinterpret_cast<const double*>(d_pl) + n_rows, n_rows, bh, c->calib.warp_w, reinterpret_cast<int16_t*>(d_sp));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && launched) e = hipMemcpyAsync(spans_out, d_sp, (size_t)bh * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dev_free(d_rec); dev_free(d_pl); dev_free(d_sp);
+    if (e != hipSuccess) return fail(LT_ERR_HIP, "lt_lane_spans_from_fit failed: %s", hipGetErrorString(e));
+    if (!launched) return fail(LT_ERR_STATE, "lt_lane_spans_from_fit: too many rows for one workgroup's LDS");
+    return LT_OK;
+}
+
 int lt_present_finish(lt_ctx* c, int slot, const char* lines, int n_lines, int line_len, int x0, int y0, int step, uint8_t* out,
                       const int32_t* rows4) {
     int rc = check_slots(c, slot, 1);
     if (rc) return rc;
     if (!out) return fail(LT_ERR_INVALID, "null output buffer");
-    if (!c->d_annot || !c->present) return fail(LT_ERR_STATE, "lt_present_finish before lt_present_lane_async");
     const bool text = lines && n_lines > 0 && line_len > 0 && c->font_glyphs > 0;
+    if ((!c->d_annot || !c->present) && (!c->lane_spec_stream || text || (rows4 && rows4[1] > rows4[0])))
+        return fail(LT_ERR_STATE, "lt_present_finish before lt_present_lane_async");
     int r[4];
     if ((rc = present_rows(c, rows4, text, n_lines, y0, step, false, true, r))) return rc;
     if ((rc = set_device(c))) return rc;
     if (text && (rc = lt_overlay_text(c, slot, 1, lines, n_lines, line_len, x0, y0, step))) return rc;
     if ((rc = present_copy_rows(c, slot, out, r[0], r[1]))) return rc;
-    HIP_TRY(hipStreamSynchronize(c->present));
+    if (c->lane_spec_stream) {       // the lane came from lt_present_lane_from_fit_async, on the slot's own stream
+        bool seen = false;
+        if (c->lane_spec_ticket && c->h_rec) {
+            const volatile unsigned* word = reinterpret_cast<const volatile unsigned*>(reinterpret_cast<const char*>(c->h_rec) + 128);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (unsigned spins = 0; !(seen = *word == c->lane_spec_ticket); ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(c->lane_spec_stream));
+        c->lane_spec_stream = nullptr;
+        c->lane_spec_ticket = 0;
+    }
+    if (c->present) HIP_TRY(hipStreamSynchronize(c->present));
     return LT_OK;
 }
 

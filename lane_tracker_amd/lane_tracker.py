@@ -175,6 +175,7 @@ class LaneTracker(StreamPipeline):
         window centroids are fetched right away, or -- in the stream pipeline, `lazy=True` -- only if
         somebody reads them before the slot is reused (the state machine itself needs the record only)."""
         lf, rf, self.detected_pixels, flags = ctx.download_record(slot)
+        self._fit_flags = flags
         if not self.detected_pixels:
             self._fit = None        # like the reference, a failed search leaves the previous pixel lists in place
             return
@@ -604,6 +605,7 @@ class LaneTracker(StreamPipeline):
         """Polygon (packed, by address) and text lines onto the frame in `slot` -> the annotated frame.  drawn: _lane_ahead has
         drawn this polygon and sent its rows already; the text lines are what is left."""
         out, rows, self._out, self._out_rows, self._lane_in_flight = self._out, self._out_rows, None, None, None
+        self._device_lane = None
         host_text, self._out_host_text = self._out_host_text, False
         if out is None:
             out, rows, host_text = _native.pinned_empty((1, self.img_size[1], self.img_size[0], 3)), None, False
@@ -688,6 +690,7 @@ class LaneTracker(StreamPipeline):
                                  no_success_limit, start_slice, ignore_sides, ignore_bottom, bandwidth, partial,
                                  diagnostics, reuse_frame=False, slot=0, have_mask=False, lazy=False):
         ctx = self._ctx
+        self._device_lane = None
         if not reuse_frame:
             # only the camera rows the path reads are on the critical path; the rest of the frame (the overlay
             # shows it) follows on a copy stream while the mask chain runs
@@ -705,6 +708,9 @@ class LaneTracker(StreamPipeline):
                 # behind the search's launch (the device has the whole chain queued; the host's share of the frame must not delay it)
                 if self._want_out and self._out is None:
                     self._prepare_out()          # the output array; its untouched rows start to fill on the library's copy thread
+                    if not reuse_frame and self.draws_lane_on_device and self.speculates_lane and self._out_host_text and \
+                            self._out_rows is not None and self._out_ahead:
+                        self._device_lane = self._lane_from_fit(partial, slot)
                 if not reuse_frame:
                     # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
                     rows = self._rows_for(img) if self._want_out else None
@@ -758,6 +764,37 @@ class LaneTracker(StreamPipeline):
 
     enqueues_upload = os.environ.get("LT_UPLOAD_ENQUEUE", "1") != "0"   # False: lt_upload_frame_rows waits for its copy (A/B, tests)
     _rows_keepalive = None
+    draws_lane_on_device = os.environ.get("LT_LANE_DEVICE", "1") != "0"   # False: the host launches the overlay once it has the record (A/B, tests)
+    _device_lane = None         # the device draws this frame's lane behind its search (lt_present_lane_from_fit_async was enqueued)
+    _fit_flags = 0
+
+    def _lane_from_fit(self, partial, slot):
+        """Enqueue, behind the search that has just been launched over `slot`, the drawing of the lane this frame will have if it is
+        valid: the device forms the running average with the fit of the slot's record itself (what _averages_with will form on the
+        host: the same sum in the same order, this frame's fit last), its plot points and the polygon, and stores the lane's rows
+        into the output frame -- 40 us before the host, which must see the record first, could launch that overlay.  -> truthy when
+        enqueued."""
+        L, R = self.left_fit_coeffs, self.right_fit_coeffs
+        if len(L) + 1 > self.n_average:
+            L, R = L[1:], R[1:]
+        Lv, Rv = [c for c in L if c.size != 0], [c for c in R if c.size != 0]
+        if len(Lv) != len(Rv):
+            return None
+        buf = self.__dict__.get("_prev_sum")
+        if buf is None:
+            buf = self._prev_sum = np.zeros(6, np.float64)
+        if Lv:
+            accl, accr = Lv[0], Rv[0]
+            for k in range(1, len(Lv)):
+                accl, accr = accl + Lv[k], accr + Rv[k]
+            buf[:3] = accl
+            buf[3:] = accr
+        ploty, ploty2 = self._plot_rows(partial)
+        self._configure_overlay()
+        ok = self._ctx.present_lane_from_fit_async(slot, buf.ctypes.data, len(Lv) + 1, ploty.ctypes.data, ploty2.ctypes.data, len(ploty),
+                                                   self._out, self._out_rows)
+        return (len(Lv) + 1,) if ok else None
+
     speculates_lane = os.environ.get("LT_LANE_AHEAD", "1") != "0"   # False: the lane is drawn once the frame is known to be valid (A/B, tests)
     _lane_in_flight = None      # the packed-point buffers whose polygon lt_present_lane_async is drawing / has drawn for this frame
 
@@ -775,7 +812,9 @@ class LaneTracker(StreamPipeline):
             return None
         self._configure_overlay()
         a = b[4]
-        self._ctx.present_lane_async(slot, a[7], a[8], a[9] if b[1][0] else None, a[10] if b[1][1] else None, self._out, self._out_rows)
+        if self._device_lane is None or self._fit_flags:
+            # (a fit the host refitted -- a rank-deficient side -- is not the record's: the device has drawn nothing for it)
+            self._ctx.present_lane_async(slot, a[7], a[8], a[9] if b[1][0] else None, a[10] if b[1][1] else None, self._out, self._out_rows)
         self._lane_in_flight = b
         return la, ra, b
 
@@ -830,8 +869,8 @@ class LaneTracker(StreamPipeline):
             return self._step(img, first_try, n_tries, diagnostics, slot=self._slot, have_mask=False, lazy=True, annotate=True,
                               visualize_search=visualize_search, split_view=split_view)
         finally:
-            if self._lane_in_flight is not None:     # an exception between the two halves: the copy into _out may still be running
-                self._lane_in_flight = None
+            if self._lane_in_flight is not None or self._device_lane is not None:     # an exception between the two halves: the copy into _out may still be running
+                self._lane_in_flight = self._device_lane = None
                 self._ctx.sync()
             self._copies_done()
             self._want_out, self._out, self._out_rows = False, None, None

@@ -331,3 +331,53 @@ def test_pinned_pool_hands_out_writable_arrays_and_reuses_blocks():
     del b, big
     gc.collect()
     assert _native.load().lt_host_free(None) == 0
+
+
+def test_device_lane_from_fit_equals_the_hosts_average_points_and_polygon(nat, cal):
+    """k_lane_spans_from_fit (lt_present_lane_from_fit_async: the lane of a process() frame drawn by the device behind its
+    search) against what the host forms from the same fit: the running average (_mean_of_rows: the sum in order, the new fit
+    last, one division), get_poly_points (lt_poly_points) and the polygon's row intervals (lt_lane_polygon_spans) -- random
+    lanes, curves that leave the image on either side (the kept points are compacted towards the bottom), steep curves whose
+    edges span several columns per row, one side or both outside the image, every `partial`, histories of 0 to 3 older fits;
+    a record without a usable fit leaves empty intervals."""
+    from lane_tracker_amd.lane_tracker import _mean_of_rows
+    ctx = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=2)
+    try:
+        rng = np.random.default_rng(21)
+        empty = np.tile(np.array([32767, -32768], np.int16), (H, 1))
+        for t in range(160):
+            partial = (1.0, 1.0, 0.5, 0.25, 0.7)[t % 5]
+            ploty = np.linspace(H * (1 - partial), H - 1, int(H * partial))
+            ploty2 = ploty ** 2
+            kind = t % 8
+            lf = np.array([rng.uniform(-1e-4, 1e-4), rng.uniform(-0.2, 0.1), rng.uniform(380, 470)])
+            rf = lf + np.array([rng.uniform(-3e-5, 3e-5), rng.uniform(-0.05, 0.05), rng.uniform(170, 215)])
+            if kind == 1:
+                lf, rf = np.array([4e-4, -0.9, 500.0]), np.array([3e-4, -0.2, 620.0])          # leave the image: chains of different length
+            elif kind == 2:
+                lf = np.array([rng.uniform(1e-3, 3e-3), rng.uniform(-4, -2), rng.uniform(900, 1400)])    # steep: several columns per row
+            elif kind == 3:
+                rf = np.array([0.0, 0.0, 5000.0])                                                # the right curve wholly outside
+            elif kind == 4:
+                lf, rf = np.array([0.0, 0.0, -50.0]), np.array([0.0, 0.0, 5000.0])               # both outside: no polygon
+            elif kind == 5:
+                lf, rf = np.array([0.0, 0.0, 0.0]), np.array([0.0, 0.0, float(W - 1)])           # exactly on the borders (<=, >=)
+            hist = int(rng.integers(0, 4))
+            older_l = [lf + rng.normal(0, [1e-6, 1e-3, 2.0]) for _ in range(hist)]
+            older_r = [rf + rng.normal(0, [1e-6, 1e-3, 2.0]) for _ in range(hist)]
+            prev = None
+            if hist:
+                accl, accr = older_l[0], older_r[0]
+                for k in range(1, hist):
+                    accl, accr = accl + older_l[k], accr + older_r[k]
+                prev = np.concatenate([accl, accr])
+            la, ra = _mean_of_rows(older_l + [lf]), _mean_of_rows(older_r + [rf])
+            ln, rn, lyx, ryx = nat.poly_points((W, H), np.concatenate([la, ra])[None], ploty, ploty2)
+            want = nat.lane_polygon_spans(H, lyx[:, 0], lyx[:, 1], ryx[:, 0], ryx[:, 1])
+            got = ctx.lane_spans_from_fit(np.concatenate([lf, rf]), prev, hist + 1, ploty, ploty2)
+            assert np.array_equal(got, want), (t, kind, partial, hist, np.argwhere(got != want)[:4].tolist())
+            if t < 4:
+                assert np.array_equal(ctx.lane_spans_from_fit(np.concatenate([lf, rf]), prev, hist + 1, ploty, ploty2, detected=False), empty)
+                assert np.array_equal(ctx.lane_spans_from_fit(np.concatenate([lf, rf]), prev, hist + 1, ploty, ploty2, fit_flags=2), empty)
+    finally:
+        ctx.close()

@@ -607,7 +607,7 @@ def test_randomised_differential_run():
                                     "LT_WALK_MIN_FRAMES=0,LT_MORPH_ONE_ROW=1", "LT_THRESHOLD_SPLIT=0", "LT_OPEN_SHALLOW=0",
                                     "LT_WALK_MIN_FRAMES=0,LT_OPEN_SHALLOW=0", "LT_MORPH_ONE=0", "LT_MORPH_ONE=8", "LT_MORPH_ONE_WGS=64",
                                     "LT_MORPH_ONE=8,LT_MORPH_ONE_WGS=2000", "LT_OPEN_SMALL=0", "LT_SIDE_FIRST=1", "LT_THRESHOLD_PHASES=0",
-                                    "LT_THRESHOLD_PHASES=0,LT_OPEN_SMALL=0,LT_MORPH_ONE=0"])
+                                    "LT_THRESHOLD_PHASES=0,LT_OPEN_SMALL=0,LT_MORPH_ONE=0", "LT_R_THRESHOLD_MAIN=1"])
 def test_alternative_kernel_paths_keep_parity(switch):
     """Every measurement switch of DESIGN.md selects a path that stays bit-exact: the mask-chain, top-hat operator and
     search parity tests again in a process started with the switch set (the library reads them once)."""
