@@ -522,7 +522,7 @@ class LaneTracker(StreamPipeline):
 
     _TEXT_ORIGIN, _TEXT_STEP = (20, 8), 35          # Context.present_frame / overlay_text defaults
 
-    def _prepare_out(self):
+    def _prepare_out(self, then=None):
         """While the device is busy with the frame (another 0.1 ms until its record is there): fetch the page-locked array the
         annotated frame will land in and copy the rows no overlay can touch from the camera frame the caller handed in -- they
         are the same bytes, and what the host copies now does not cross the bus later.  With the text drawn on the host
@@ -539,17 +539,17 @@ class LaneTracker(StreamPipeline):
         if rows[4] is not None:
             l0, l1 = rows[4][2]
             gaps = ((0, l0), (l1, H))
+            self._out_rows, self._out_ahead, self._out_host_text = rows[4][1], True, True
         else:
             a0, a1, b0, b1 = rows[2]
             gaps = ((0, a0), (a1, b0), (b1, H))
+            self._out_rows, self._out_ahead = rows[1], rows[3]
+        if then is not None:
+            then()                       # (what needs the output frame but not its rows: the device's work goes first)
         for lo, hi in gaps:          # as rows of a 2-D copy: the copy threads share them (1080 rows of 5.8 KB: 4 MB, 0.3 ms on one thread)
             if hi > lo and lib.lt_host_copy2d_async_group(grp, dst + lo * rb, rb, src + lo * rb, rb, rb, hi - lo):
                 raise _native.NativeError("lt_host_copy2d_async_group failed")
         self._copying = True             # until the group's wait: `out` and `img` must stay as they are
-        if rows[4] is not None:
-            self._out_rows, self._out_ahead, self._out_host_text = rows[4][1], True, True
-        else:
-            self._out_rows, self._out_ahead = rows[1], rows[3]
 
     _out_host_text = False      # the text lines of _out are drawn on the host (its row runs are then the lane's run alone)
 
@@ -706,13 +706,9 @@ class LaneTracker(StreamPipeline):
 
             def while_the_device_searches():
                 # behind the search's launch (the device has the whole chain queued; the host's share of the frame must not delay it)
-                if self._want_out and self._out is None:
-                    self._prepare_out()          # the output array; its untouched rows start to fill on the library's copy thread
-                    if not reuse_frame and self.draws_lane_on_device and self.speculates_lane and self._out_host_text and \
-                            self._out_rows is not None and self._out_ahead:
-                        self._device_lane = self._lane_from_fit(partial, slot)
                 if not reuse_frame:
-                    # ... and of the rest only the rows the overlay will read, when the annotated frame goes back in row runs
+                    # of the rest of the frame only the rows the overlay will read, when the annotated frame goes back in row runs
+                    # (first: the overlay enqueued below waits for the copies known at that moment)
                     rows = self._rows_for(img) if self._want_out else None
                     if rows is not None and rows[4] is not None:
                         if rows[4][4]:           # (rows of the lane's run the mask chain does not read: none with the reference calibration)
@@ -720,6 +716,12 @@ class LaneTracker(StreamPipeline):
                     else:
                         self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
                     self._resident_partial = rows is not None
+                if self._want_out and self._out is None:
+                    def lane_on_the_device():    # enqueued as soon as the output frame exists: ahead of the host's own copies
+                        if not reuse_frame and self.draws_lane_on_device and self.speculates_lane and self._out_host_text and \
+                                self._out_rows is not None and self._out_ahead:
+                            self._device_lane = self._lane_from_fit(partial, slot)
+                    self._prepare_out(lane_on_the_device)   # the output array; its untouched rows start to fill on the library's copy threads
             if self.last_detection > self.n_reset:                       # :851
                 if diagnostics:
                     print("Using sliding window search.")
