@@ -271,3 +271,27 @@ def test_vector_text_blend_is_the_scalar_blend_for_every_value_and_alpha():
         assert r.returncode == 0, r.stderr[-800:]
         outs.append(r.stdout.strip())
     assert outs[0] == outs[1]
+
+
+def test_line_iterator_in_closed_form_is_the_walk():
+    """k_lane_spans_from_fit (csrc/k_overlay.hip) lets a whole workgroup take the pixels of a long polygon edge, pixel i of
+    OpenCV's LineIterator in closed form: with len = max(|dx|, |dy|), across = min(|dx|, |dy|), the minor coordinate has advanced
+    T_i = max(0, ceil((2 across i - len) / (2 len))) times before step i.  Held here against the walk itself -- lt_lane_polygon_spans
+    of a two-vertex polygon is the hull per row of exactly that walk's pixels -- for random segments, no GPU needed."""
+    rng = np.random.default_rng(17)
+    for _ in range(400):
+        xa, ya, xb, yb = (int(v) for v in rng.integers(0, 120, 4))
+        if (xa, ya) == (xb, yb):
+            continue
+        x0, y0, x1, y1 = (xa, ya, xb, yb) if xa <= xb else (xb, yb, xa, ya)      # the iterator starts at the left end point
+        adx, ady, ystep = x1 - x0, abs(y1 - y0), (-1 if y1 < y0 else 1)
+        tall = ady > adx
+        ln, across = (ady, adx) if tall else (adx, ady)
+        lo, hi = np.full(120, 32767), np.full(120, -32768)
+        for i in range(ln + 1):
+            num = 2 * across * i - ln
+            T = 0 if num <= 0 else (num + 2 * ln - 1) // (2 * ln)
+            x, y = (x0 + T, y0 + ystep * i) if tall else (x0 + i, y0 + ystep * T)
+            lo[y], hi[y] = min(lo[y], x), max(hi[y], x)
+        spans = _native.lane_polygon_spans(120, [ya], [xa], [yb], [xb])          # closed polygon of two vertices: the edge, there and back
+        assert np.array_equal(spans[:, 0], lo) and np.array_equal(spans[:, 1], hi), (xa, ya, xb, yb)
