@@ -213,7 +213,12 @@ __device__ __forceinline__ void walk_v_task(const WalkArgs& a, int blk) {
     unsigned long long pva = 0, pvb = 0;              // pass masks of the previous row
     auto store_rows = [&](int row0) {                 // lanes 0..15 hold rows row0 .. row0 + 15
         const int row = row0 + lane;
+#ifdef LT_PROBE_WALK_NO_VSTORE   // timing probe (WRONG results): the vertical tasks' verdict words are formed but never stored -- what the two partial
+        // planes of the vertical pass cost the walks (tools/walk_probe.sh)
+        if (lane < 16 && row >= y0 && row < y1 && a.wpr < 0) {
+#else
         if (lane < 16 && row >= y0 && row < y1) {
+#endif
             unsigned long long* o = out + (size_t)row * a.wpr + wordv;
             o[0] = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
             if (wordv + 1 < a.wpr) o[1] = (unsigned long long)m2 | ((unsigned long long)m3 << 32);
