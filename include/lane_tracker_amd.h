@@ -356,9 +356,16 @@ int  lt_download_stats(lt_ctx* ctx, double* engine_gbs, int* engine_copies, doub
  * other rows and the text the caller adds with lt_host_copy2d_async_group / lt_host_text_async_group in the same group;
  * lt_host_copy_wait_group(group) returns when the frames are complete.  Needs img_w % 4 == 0.
  *   lt_overlay_run_strip     lt_overlay_run for rows [lt_overlay_rows) only, into the context's strip buffer
- *   lt_strip_download_async  the strips of slots [first, first + n) -> rows [row0, row1) of out + i * out_frame_stride (i < n) */
+ *   lt_strip_download_async  the strips of slots [first, first + n) -> rows [row0, row1) of out + i * out_frame_stride (i < n)
+ *   lt_overlay_run_strip_coeffs  lt_overlay_run_strip from the lanes' AVERAGED coefficients (n x 6 doubles: left a, b, c, right
+ *                            a, b, c; :1182-1189) instead of their plot points: get_poly_points (:511-528; ploty / ploty2 as for
+ *                            lt_present_lane_from_fit_async) and the polygons' row intervals are formed on the device, one
+ *                            workgroup per frame.  draw: n bytes, 0 = no lane in that frame (nullptr: all drawn).  LT_ERR_STATE
+ *                            where that form does not exist (an odd bird's-eye height): use the points form */
 int  lt_overlay_run_strip(lt_ctx* ctx, int first_slot, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                           const int32_t* right_yx, double alpha);
+int  lt_overlay_run_strip_coeffs(lt_ctx* ctx, int first_slot, int n, const double* coeffs, const uint8_t* draw, const double* ploty,
+                                 const double* ploty2, int n_rows, double alpha);
 int  lt_strip_download_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out, size_t out_frame_stride, int group);
 /* The text lines of draw_lane() / print_failure() (lane_tracker.py:652-661, 664-673; glyph atlas as for lt_overlay_set_font) drawn on
  * the HOST, with lt_overlay_text's arithmetic bit for bit (white over the frame: v + ((255 - v) * alpha + 127) / 255): `lines` holds

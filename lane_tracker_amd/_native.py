@@ -97,6 +97,7 @@ _SIGNATURES = {
     "lt_present_frame": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "lt_present_lane_async": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_double, _P, _P]),
     "lt_present_finish": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "lt_overlay_run_strip_coeffs": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, C.c_double]),
     "lt_present_lane_from_fit_async": (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_double, _P, _P]),
     "lt_lane_spans_from_fit": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P]),
     "lt_lane_polygon_spans": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, _P]),
@@ -638,6 +639,21 @@ class Context:
             raise ValueError("point lists do not match their counts")
         _check(self.lib.lt_overlay_run_strip(self._h, first, len(ln), ln.ctypes.data, rn.ctypes.data,
                                              lyx.ctypes.data if lyx.size else None, ryx.ctypes.data if ryx.size else None, float(alpha)))
+
+    def overlay_run_strip_coeffs(self, coeffs, draw, ploty, ploty2, first=0, alpha=0.3):
+        """Strips from the lanes' averaged coefficients (lt_overlay_run_strip_coeffs): coeffs (n, 6) f64, draw (n,) u8 (0: no lane in
+        that frame); plot points and polygon intervals are formed on the device.  -> False where that form does not exist."""
+        coeffs = np.ascontiguousarray(coeffs, np.float64).reshape(-1, 6)
+        draw = np.ascontiguousarray(draw, np.uint8)
+        if len(draw) != len(coeffs):
+            raise ValueError("one draw byte per frame")
+        rc = self.lib.lt_overlay_run_strip_coeffs(self._h, first, len(coeffs), coeffs.ctypes.data, draw.ctypes.data, ploty.ctypes.data,
+                                                  ploty2.ctypes.data, len(ploty), float(alpha))
+        if rc == -5:
+            return False
+        if rc:
+            _check(rc)
+        return True
 
     def strip_download_async(self, out, first, group):
         """The strips of slots first .. first+len(out)-1 into rows overlay_rows() of the frames `out` (n, H, W, 3) u8, C-contiguous,

@@ -164,9 +164,13 @@ __device__ void dev_span_line(int* lo, int* hi, int bh, int xa, int ya, int xb, 
 }
 
 constexpr int LFF_T = 256, LFF_LONG = 64;
+// One workgroup per frame.  from_region = 0 (process(): one frame): the fit comes from *rec and is averaged with p.prev_sum / p.count.
+// from_region = 1 (a window's piece, lt_overlay_run_strip_coeffs): frame blockIdx.x finds its six AVERAGED coefficients and a
+// "draw" byte at the start of its own interval region (the host staged them there instead of intervals) and overwrites the region.
 __global__ __launch_bounds__(LFF_T) void k_lane_spans_from_fit(const lt_lane_record* __restrict__ rec, LaneFromFit p,
                                                                 const double* __restrict__ ploty, const double* __restrict__ ploty2,
-                                                                short2* __restrict__ spans) {
+                                                                short2* spans_all, size_t span_stride_rows, int from_region) {
+    short2* spans = spans_all + (size_t)blockIdx.x * span_stride_rows;
     extern __shared__ int s_i[];              // lo[bh], hi[bh], px[2][n_rows]
     int* lo = s_i;
     int* hi = lo + p.bh;
@@ -174,12 +178,15 @@ __global__ __launch_bounds__(LFF_T) void k_lane_spans_from_fit(const lt_lane_rec
     __shared__ double s_avg[6];
     __shared__ int s_wave[LFF_T / 64], s_cnt[2], s_long[LFF_LONG], s_nlong;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const bool usable = rec->detected != 0 && rec->fit_flags == 0;
+    const bool usable = from_region ? reinterpret_cast<const uint8_t*>(spans)[48] != 0 : (rec->detected != 0 && rec->fit_flags == 0);
     for (int y = tid; y < p.bh; y += LFF_T) { lo[y] = 32767; hi[y] = -32768; }
     if (tid < 6) {
-        const double fit = tid < 3 ? rec->left_coeffs[tid] : rec->right_coeffs[tid - 3];
-        const double acc = p.count > 1 ? p.prev_sum[tid] + fit : fit;      // _mean_of_rows: the sum in order, this frame's fit last,
-        s_avg[tid] = acc / (double)p.count;                                  // then one division by the count
+        if (from_region) s_avg[tid] = reinterpret_cast<const double*>(spans)[tid];
+        else {
+            const double fit = tid < 3 ? rec->left_coeffs[tid] : rec->right_coeffs[tid - 3];
+            const double acc = p.count > 1 ? p.prev_sum[tid] + fit : fit;  // _mean_of_rows: the sum in order, this frame's fit last,
+            s_avg[tid] = acc / (double)p.count;                              // then one division by the count
+        }
     }
     __syncthreads();
     if (usable) {
@@ -477,6 +484,22 @@ void launch_store_word(hipStream_t s, unsigned* dev_word, unsigned value) {
 }
 
 // row intervals of the averaged lane of the frame whose record is *rec (k_lane_spans_from_fit); false: too many rows for the LDS
+// the same for n frames whose averaged coefficients (6 doubles) and draw byte (offset 48) stand at the start of their interval regions
+bool launch_lane_spans_from_regions(hipStream_t s, const double* ploty, const double* ploty2, int n_rows, int bh, int bw, int16_t* spans,
+                                    int n) {
+    const size_t lds = ((size_t)2 * bh + (size_t)2 * std::max(n_rows, 1)) * sizeof(int);
+    if (lds > 60 * 1024 || n_rows < 0 || n < 1 || (bh & 1) || bh * 4 < 56) return false;       // (regions of 4 bh bytes: 8-byte aligned, >= 56 bytes)
+    LaneFromFit p;
+    for (int k = 0; k < 6; ++k) p.prev_sum[k] = 0.0;
+    p.count = 1;
+    p.n_rows = n_rows;
+    p.bh = bh;
+    p.bw = bw;
+    hipLaunchKernelGGL(k_lane_spans_from_fit, dim3(n), dim3(LFF_T), lds, s, (const lt_lane_record*)nullptr, p, ploty, ploty2,
+                       reinterpret_cast<short2*>(spans), (size_t)bh, 1);
+    return true;
+}
+
 bool launch_lane_spans_from_fit(hipStream_t s, const lt_lane_record* rec, const double* prev_sum, int count, const double* ploty,
                                 const double* ploty2, int n_rows, int bh, int bw, int16_t* spans) {
     const size_t lds = ((size_t)2 * bh + (size_t)2 * std::max(n_rows, 1)) * sizeof(int);
@@ -487,7 +510,7 @@ bool launch_lane_spans_from_fit(hipStream_t s, const lt_lane_record* rec, const 
     p.n_rows = n_rows;
     p.bh = bh;
     p.bw = bw;
-    hipLaunchKernelGGL(k_lane_spans_from_fit, dim3(1), dim3(LFF_T), lds, s, rec, p, ploty, ploty2, reinterpret_cast<short2*>(spans));
+    hipLaunchKernelGGL(k_lane_spans_from_fit, dim3(1), dim3(LFF_T), lds, s, rec, p, ploty, ploty2, reinterpret_cast<short2*>(spans), (size_t)bh, 0);
     return true;
 }
 

@@ -239,21 +239,46 @@ static int ensure_strips(lt_ctx* c) {
 
 // direct_out (one frame, row runs): the device-visible address of a page-locked frame in HOST memory the kernel stores the drawn
 // rows into itself, instead of the context's annotated-frame buffer and a copy kernel behind it (lt_present_lane_async)
+// the plot rows (ploty, ploty ** 2 of get_poly_points) on the device: sent when they change (they depend on `partial` and the image
+// height only); waits for the whole context when they do
+static int ensure_ploty(lt_ctx* c, const double* ploty, const double* ploty2, int n_rows) {
+    if ((int)c->h_ploty.size() == 2 * n_rows && std::memcmp(c->h_ploty.data(), ploty, (size_t)n_rows * sizeof(double)) == 0 &&
+        std::memcmp(c->h_ploty.data() + n_rows, ploty2, (size_t)n_rows * sizeof(double)) == 0)
+        return LT_OK;
+    int rc = sync_all(c);
+    if (rc) return rc;
+    dev_free(c->d_ploty);
+    c->d_ploty = nullptr;
+    c->h_ploty.assign(ploty, ploty + n_rows);
+    c->h_ploty.insert(c->h_ploty.end(), ploty2, ploty2 + n_rows);
+    uint8_t* raw = nullptr;
+    if ((rc = dev_alloc(&raw, (size_t)2 * n_rows * sizeof(double)))) { c->h_ploty.clear(); return rc; }
+    c->d_ploty = reinterpret_cast<double*>(raw);
+    HIP_TRY(hipMemcpyAsync(c->d_ploty, c->h_ploty.data(), (size_t)2 * n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return LT_OK;
+}
+
+// averaged coefficients instead of points (lt_overlay_run_strip_coeffs): the device forms plot points and row intervals itself
+struct CoeffInput { const double* coeffs; const uint8_t* draw; const double* ploty; const double* ploty2; int n_rows; };
+
 static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                             const int32_t* right_yx, double alpha, const int* rows4, bool strip = false, uint8_t* direct_out = nullptr,
-                            bool* went_direct = nullptr) {
+                            bool* went_direct = nullptr, const CoeffInput* ci = nullptr) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if (!c->have_overlay) return fail(LT_ERR_STATE, "lt_overlay_run before lt_overlay_configure");
     if (n == 0) return LT_OK;
-    if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
-    long long tl = 0, tr = 0;
-    for (int i = 0; i < n; ++i) {
-        if (left_n[i] < 0 || right_n[i] < 0) return fail(LT_ERR_INVALID, "negative point count");
-        tl += left_n[i];
-        tr += right_n[i];
+    if (!ci) {
+        if (!left_n || !right_n) return fail(LT_ERR_INVALID, "null point counts");
+        long long tl = 0, tr = 0;
+        for (int i = 0; i < n; ++i) {
+            if (left_n[i] < 0 || right_n[i] < 0) return fail(LT_ERR_INVALID, "negative point count");
+            tl += left_n[i];
+            tr += right_n[i];
+        }
+        if ((tl && !left_yx) || (tr && !right_yx)) return fail(LT_ERR_INVALID, "null point list");
     }
-    if ((tl && !left_yx) || (tr && !right_yx)) return fail(LT_ERR_INVALID, "null point list");
     if (!rows4 && !strip) {
         const int bad = first_partial(c->frame_full, first, n);
         if (bad >= 0)
@@ -268,7 +293,8 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
     } else if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
     // One frame (process()): the intervals travel as a kernel argument -- no staging buffer, no copy launch, no events
     static const bool arg_ok = [] { const char* e = std::getenv("LT_SPANS_ARG"); return !(e && e[0] == '0'); }();
-    bool one = arg_ok && !strip && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
+    bool one = arg_ok && !strip && !ci && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
+    if (ci && (rc = ensure_ploty(c, ci->ploty, ci->ploty2, ci->n_rows))) return rc;
     int16_t one_spans[2 * LT_SPAN_ARG_ROWS];
     auto claim_staging = [&]() -> int {
         int r = staging_claim(c->spans_busy, first, n);
@@ -293,7 +319,13 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
             orr += (size_t)right_n[i];
         }
     };
-    if (workers == 1) some(0);
+    if (ci) {                                  // six doubles and a draw byte at the start of every slot's interval region
+        for (int i = 0; i < n; ++i) {
+            uint8_t* reg = reinterpret_cast<uint8_t*>(hs + (size_t)i * bh * 2);
+            std::memcpy(reg, ci->coeffs + (size_t)6 * i, 6 * sizeof(double));
+            reg[48] = ci->draw ? ci->draw[i] : 1;
+        }
+    } else if (workers == 1) some(0);
     else {
         std::vector<std::thread> pool;
         for (int w = 1; w < workers; ++w) pool.emplace_back(some, w);
@@ -342,6 +374,8 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
         hs = c->h_spans + (size_t)first * bh * 2;
     }
     launch_copy_from_pinned(ps, c->d_spans + (size_t)first * bh * 2, hs, (size_t)n * bh * 2 * sizeof(int16_t));
+    if (ci && !launch_lane_spans_from_regions(ps, c->d_ploty, c->d_ploty + ci->n_rows, ci->n_rows, bh, c->calib.warp_w, c->d_spans + (size_t)first * bh * 2, n))
+        return fail(LT_ERR_STATE, "lt_overlay_run_strip_coeffs: not available for this bird's-eye height");
     const auto t2 = std::chrono::steady_clock::now();
     if (strip) {
         if (!launch_overlay_lane_strip(ps, c->d_frames + (size_t)first * c->frame_bytes, c->frame_bytes, c->d_strip + (size_t)first * c->strip_bytes,
@@ -389,6 +423,20 @@ int lt_overlay_run_rows(lt_ctx* c, int first, int n, const int32_t* left_n, cons
 int lt_overlay_run_strip(lt_ctx* c, int first, int n, const int32_t* left_n, const int32_t* right_n, const int32_t* left_yx,
                          const int32_t* right_yx, double alpha) {
     return overlay_run_impl(c, first, n, left_n, right_n, left_yx, right_yx, alpha, nullptr, true);
+}
+
+// lt_overlay_run_strip from the lanes' AVERAGED coefficients (n x 6 doubles: left a, b, c, right a, b, c) instead of their plot points:
+// get_poly_points and the polygons' row intervals are formed on the device (k_lane_spans_from_fit, one workgroup per frame: the
+// host's f64 operations in the host's order), which takes 11 us per frame off the thread that drives an annotated stream.
+// draw: n bytes, 0 = no lane in that frame (plain copy); nullptr: all drawn.
+int lt_overlay_run_strip_coeffs(lt_ctx* c, int first, int n, const double* coeffs, const uint8_t* draw, const double* ploty, const double* ploty2,
+                                int n_rows, double alpha) {
+    if (!c || (n > 0 && !coeffs) || !ploty || !ploty2 || n_rows < 1) return fail(LT_ERR_INVALID, "lt_overlay_run_strip_coeffs: bad arguments");
+    const int bh = c->calib.warp_h;
+    if ((bh & 1) || bh * 4 < 56 || ((size_t)2 * bh + (size_t)2 * n_rows) * sizeof(int) > 60 * 1024)
+        return fail(LT_ERR_STATE, "lt_overlay_run_strip_coeffs: not available for this bird's-eye height");
+    const CoeffInput ci{coeffs, draw, ploty, ploty2, n_rows};
+    return overlay_run_impl(c, first, n, nullptr, nullptr, nullptr, nullptr, alpha, nullptr, true, nullptr, nullptr, &ci);
 }
 
 // The strips of slots [first, first + n) on their way into the caller's frames: one contiguous copy per block of STRIP_BLOCK slots
@@ -684,20 +732,7 @@ int lt_present_lane_from_fit_async(lt_ctx* c, int slot, const double* prev_sum, 
     }
     const int bh = c->calib.warp_h;
     if (!c->d_spans && (rc = dev_alloc(&c->d_spans, (size_t)c->capacity * bh * 2))) return rc;
-    // the plot rows on the device: sent when they change (they depend on `partial` and the image height only)
-    if ((int)c->h_ploty.size() != 2 * n_rows || std::memcmp(c->h_ploty.data(), ploty, (size_t)n_rows * sizeof(double)) != 0 ||
-        std::memcmp(c->h_ploty.data() + n_rows, ploty2, (size_t)n_rows * sizeof(double)) != 0) {
-        if ((rc = sync_all(c))) return rc;
-        dev_free(c->d_ploty);
-        c->d_ploty = nullptr;
-        c->h_ploty.assign(ploty, ploty + n_rows);
-        c->h_ploty.insert(c->h_ploty.end(), ploty2, ploty2 + n_rows);
-        uint8_t* raw = nullptr;
-        if ((rc = dev_alloc(&raw, (size_t)2 * n_rows * sizeof(double)))) { c->h_ploty.clear(); return rc; }
-        c->d_ploty = reinterpret_cast<double*>(raw);
-        HIP_TRY(hipMemcpyAsync(c->d_ploty, c->h_ploty.data(), (size_t)2 * n_rows * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    if ((rc = ensure_ploty(c, ploty, ploty2, n_rows))) return rc;
     return for_each_slice(c, slot, 1, [&](hipStream_t st, int f0, int) {
         if (c->rest_pending) {       // rows of the frame the mask chain's upload did not bring (lt_upload_frame_rest): the overlay reads them
             bool precise = true;

@@ -97,23 +97,41 @@ class StreamPipeline:
         avg_radius = np.trunc(total / count).astype(np.int64)
         avg = np.concatenate([suml / k, sumr / k], axis=1)
         ploty, ploty2 = self._plot_rows(partial)
-        ln, rn, lyx, ryx = _native.poly_points(self.warped_size, avg, ploty, ploty2)
-        if not (np.all(ln > 0) and np.all(rn > 0)):
-            return False
-        le, re = np.cumsum(ln), np.cumsum(rn)
         mid = int(self.warped_size[0] / 2)
-        ecc = (((mid - lyx[le - 1, 1].astype(np.int64)) - (ryx[re - 1, 1].astype(np.int64) - mid)) / 2) * self.mpph
+        polys = None
+        if self.stream_lane_on_device and len(ploty):
+            # The pictures are drawn from the averaged coefficients by the device (lt_overlay_run_strip_coeffs forms get_poly_points
+            # and the polygons there); what the host needs of the plot points is the LAST kept point of each curve, for the
+            # eccentricity (:551-559) -- the bottom plot row's, when it lies inside the image, which is the rule: the same two
+            # products and two sums, element-wise.  A frame whose bottom point is outside takes the points' way below.
+            xmax = self.warped_size[0] - 1
+            xl = (avg[:, 0] * ploty2[-1] + avg[:, 1] * ploty[-1]) + avg[:, 2]
+            xr = (avg[:, 3] * ploty2[-1] + avg[:, 4] * ploty[-1]) + avg[:, 5]
+            if np.all((xl <= xmax) & (xl >= 0) & (xr <= xmax) & (xr >= 0)):
+                ecc = (((mid - xl.astype(np.int64)) - (xr.astype(np.int64) - mid)) / 2) * self.mpph
+                plot = (ploty, ploty2)
+                polys = [_CoeffPoly(avg[q], self.warped_size, plot) for q in range(m)]
+        if polys is None:
+            ln, rn, lyx, ryx = _native.poly_points(self.warped_size, avg, ploty, ploty2)
+            if not (np.all(ln > 0) and np.all(rn > 0)):
+                return False
+            le, re = np.cumsum(ln), np.cumsum(rn)
+            ecc = (((mid - lyx[le - 1, 1].astype(np.int64)) - (ryx[re - 1, 1].astype(np.int64) - mid)) / 2) * self.mpph
+            polys = [_PackedPoly(lyx[le[q] - ln[q]:le[q]], ryx[re[q] - rn[q]:re[q]]) for q in range(m)]
         for q in range(m):
             self.counter += 1
             lines = ["Curve Radius: {} m".format(int(avg_radius[q])), "Eccentricity: {:.2f} m".format(float(ecc[q]))]
             if self.print_frame_count:
                 lines.append("Frame: {}".format(self.counter - 1))
-            deferred.append(('lane', _PackedPoly(lyx[le[q] - ln[q]:le[q]], ryx[re[q] - rn[q]:re[q]]), lines))
+            deferred.append(('lane', polys[q], lines))
         self.success += m
         self.left_fit_coeffs = [np.array(c) for c in LF[hi - k:hi]]
         self.right_fit_coeffs = [np.array(c) for c in RF[hi - k:hi]]
         self.average_curve_radii = [int(v) for v in r[hi - k:hi]]
         return True
+
+    _coeff_strips = True         # lt_overlay_run_strip_coeffs exists for this context (cleared on its first refusal)
+    stream_lane_on_device = os.environ.get("LT_STREAM_LANE_DEVICE", "1") != "0"   # False: plot points and polygon intervals of a window's frames on the host (A/B, tests)
 
     # ---- the chained stream pipeline (reference :851-872, :1064-1128, :1178-1199) ------------
     search_cus = 1                   # CUs kept free of the mask chain for the chained search (lt_set_search_cus); 0: shared; >= 2: the
@@ -602,7 +620,34 @@ class StreamPipeline:
                 for a in range(lo, hi, self.strip_piece):
                     b = min(a + self.strip_piece, hi)
                     part = deferred[a:b]
-                    ctx.overlay_run_strip_packed(*_pack_deferred(part), first=base + a)
+                    # Lanes that came as averaged coefficients (`_record_successes`: nearly all of a video) are drawn from them -- plot
+                    # points and polygons on the device --, the others (the frames at the seams of a run, redrawn lanes, second tries)
+                    # from their points: runs of one kind, each one overlay launch; frames without a lane go with either.
+                    g0 = 0
+                    while g0 < len(part):
+                        kind, g1 = None, g0
+                        while g1 < len(part):
+                            d = part[g1]
+                            kd = None if d[0] != 'lane' else ('c' if isinstance(d[1], _CoeffPoly) and self._coeff_strips else 'p')
+                            if kd is not None and kind is not None and kd != kind:
+                                break
+                            kind = kind or kd
+                            g1 += 1
+                        run = part[g0:g1]
+                        if kind == 'c':
+                            first_poly = next(d[1] for d in run if d[0] == 'lane')
+                            co = np.zeros((len(run), 6), np.float64)
+                            dr = np.zeros(len(run), np.uint8)
+                            for i, d in enumerate(run):
+                                if d[0] == 'lane':
+                                    co[i] = d[1].coeffs
+                                    dr[i] = 1
+                            if not ctx.overlay_run_strip_coeffs(co, dr, first_poly.plot[0], first_poly.plot[1], first=base + a + g0):
+                                self._coeff_strips = False           # (this context has no such form: points from now on)
+                                ctx.overlay_run_strip_packed(*_pack_deferred(run), first=base + a + g0)
+                        else:
+                            ctx.overlay_run_strip_packed(*_pack_deferred(run), first=base + a + g0)
+                        g0 = g1
                     ctx.strip_download_async(out[a:b], base + a, group)
                     # the host's share of these frames, piece by piece as they are committed (all of a window's untouched rows at
                     # once, at its start, sat in the copy threads' queue in front of the last strips of the window before: 9 ms per
@@ -826,6 +871,20 @@ class _PackedPoly:
         return a[:, 0], a[:, 1], b[:, 0], b[:, 1]
 
 
+class _CoeffPoly:
+    """A lane polygon as its averaged coefficients (left a, b, c, right a, b, c): `_record_successes` defers these when the device
+    forms plot points and polygon itself (lt_overlay_run_strip_coeffs); `points()` is the host's form, for the pieces that go the
+    points' way (a piece that also holds redrawn or failed-try frames, row runs, whole frames)."""
+    __slots__ = ("coeffs", "size", "plot")
+
+    def __init__(self, coeffs, size, plot):
+        self.coeffs, self.size, self.plot = coeffs, size, plot
+
+    def points(self):
+        _, _, lyx, ryx = _native.poly_points(self.size, self.coeffs[None], self.plot[0], self.plot[1])
+        return lyx, ryx
+
+
 _NO_POINTS = np.zeros((0, 2), np.int32)
 
 
@@ -841,6 +900,10 @@ def _pack_deferred(part):
         elif isinstance(p, _PackedPoly):
             L.append(p.lyx)
             R.append(p.ryx)
+        elif isinstance(p, _CoeffPoly):
+            lyx, ryx = p.points()
+            L.append(lyx)
+            R.append(ryx)
         else:
             L.append(np.stack([p[0], p[1]], 1).astype(np.int32))
             R.append(np.stack([p[2], p[3]], 1).astype(np.int32))
