@@ -884,6 +884,11 @@ class _CoeffPoly:
         _, _, lyx, ryx = _native.poly_points(self.size, self.coeffs[None], self.plot[0], self.plot[1])
         return lyx, ryx
 
+    def as_tuple(self):
+        lyx, ryx = self.points()
+        a, b = lyx.astype(np.int64), ryx.astype(np.int64)
+        return a[:, 0], a[:, 1], b[:, 0], b[:, 1]
+
 
 _NO_POINTS = np.zeros((0, 2), np.int32)
 

@@ -121,16 +121,23 @@ def _scalar_commit(t, lf, rf, partial, deferred):
     deferred.append(('lane', (t.left_avg_y, t.left_avg_x, t.right_avg_y, t.right_avg_x), t._lane_text()))
 
 
+@pytest.mark.parametrize("leaves_the_image", [True, False])
 @pytest.mark.parametrize("n_average,partial,frame_count", [(1, 1.0, False), (2, 1.0, True), (3, 0.5, False), (5, 1.0, True), (8, 0.3, False)])
-def test_run_of_successes_recorded_at_once_equals_frame_by_frame(n_average, partial, frame_count):
+def test_run_of_successes_recorded_at_once_equals_frame_by_frame(n_average, partial, frame_count, leaves_the_image):
     """`_record_successes` (the annotated stream pipeline commits a whole run of valid frames in one go) against
     `_record_success` frame by frame: every picture (polygon points, text lines) and the state left behind, bit for bit --
-    with a history that holds a failure and older fits when the run starts."""
+    with a history that holds a failure and older fits when the run starts.  Without a curve that leaves the image at the bottom
+    the pictures are deferred as averaged coefficients (the device forms their points; here their host form is compared), with
+    one as lt_poly_points' points."""
     rng = np.random.default_rng(10 + n_average)
     g = 70
     LF = np.stack([[rng.uniform(-3e-4, 3e-4), rng.uniform(-0.5, 0.3), rng.uniform(350, 520)] for _ in range(g)])
     RF = LF + np.stack([[rng.uniform(-2e-5, 2e-5), rng.uniform(-0.05, 0.05), rng.uniform(150, 230)] for _ in range(g)])
-    LF[20] = [2e-4, -1.4, 1400.0]                # leaves the image at the bottom: fewer points than rows
+    if leaves_the_image:
+        LF[20] = [2e-4, -1.4, 1400.0]            # leaves the image at the bottom: fewer points than rows
+    else:                                        # tame lanes: every bottom point inside the image
+        LF[:, :2] *= 0.2
+        RF = LF + (RF - LF) * np.array([0.2, 0.2, 1.0])
     a, b = _history_tracker(n_average, frame_count), _history_tracker(n_average, frame_count)
     for t in (a, b):                             # what happened before the run
         d0 = []
@@ -145,6 +152,8 @@ def test_run_of_successes_recorded_at_once_equals_frame_by_frame(n_average, part
     assert b._record_successes(LF, RF, n_average - 1, g - 1, partial, got)
     _scalar_commit(b, np.array(LF[g - 1]), np.array(RF[g - 1]), partial, got)
     assert len(got) == len(want) == g
+    from lane_tracker_amd.stream import _CoeffPoly
+    assert leaves_the_image or any(isinstance(x[1], _CoeffPoly) for x in got)
     for j, (x, y) in enumerate(zip(got, want)):
         assert x[0] == y[0] and x[2] == y[2], (j, x[2], y[2])
         for p, q in zip(_four(x[1]), _four(y[1])):
