@@ -38,8 +38,10 @@ extern "C" {
 /* 4: + lt_host_copy_group_create / _destroy, lt_host_copy_async_group, lt_host_copy2d_async_group, lt_host_copy_wait_group
  *    (completion per group instead of per process), lt_shutdown, lt_device_cache_stats, lt_warm (a stream's set-up ahead of its
  *    first window), lt_overlay_run_strip + lt_strip_download_async (annotated frames as one packed strip of rows per frame through
- *    page-locked staging blocks into ordinary memory), lt_text_blend_host + lt_host_text_async_group (the text lines on the host).
- *    Nothing removed or changed. */
+ *    page-locked staging blocks into ordinary memory), lt_text_blend_host + lt_host_text_async_group (the text lines on the host),
+ *    lt_host_copy_stats, lt_host_touch_async_group; lt_upload_frame_rows_enqueue (an upload nobody waits for),
+ *    lt_present_lane_from_fit_async + lt_lane_spans_from_fit (the lane of a frame drawn by the device behind its search),
+ *    lt_overlay_run_strip_coeffs (strips from averaged coefficients).  Nothing removed or changed. */
 #define LT_ABI_VERSION 4
 
 typedef enum lt_status {
