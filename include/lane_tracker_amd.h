@@ -42,7 +42,9 @@ extern "C" {
  *    lt_host_copy_stats, lt_host_touch_async_group; lt_upload_frame_rows_enqueue (an upload nobody waits for),
  *    lt_present_lane_from_fit_async + lt_lane_spans_from_fit (the lane of a frame drawn by the device behind its search),
  *    lt_overlay_run_strip_coeffs (strips from averaged coefficients).  Nothing removed or changed. */
-#define LT_ABI_VERSION 4
+/* 5: + lt_device_cache_counters (hits / misses / evictions of the device-memory cache since the process started).  Nothing
+ *    removed or changed. */
+#define LT_ABI_VERSION 5
 
 typedef enum lt_status {
     LT_OK = 0,
@@ -431,6 +433,11 @@ int  lt_host_free(void* p);
  * out to live contexts, the current limit, the number of cached blocks (any pointer may be NULL).  No context needed. */
 int  lt_device_cache_trim(size_t keep_bytes);
 int  lt_device_cache_stats(size_t* kept_bytes, size_t* live_bytes, size_t* limit_bytes, int* kept_blocks);
+/* Since the process started: allocations served from the cache, allocations that went to hipMalloc, and what the cache gave
+ * back to the driver (evictions over its limit, lt_device_cache_trim) -- a long-lived process that keeps evicting pays the
+ * driver's wipe with half-rate device-to-host copies each time (tests/test_gpu_soak.py holds these flat).  Any pointer may be NULL. */
+int  lt_device_cache_counters(unsigned long long* hits, unsigned long long* misses, unsigned long long* evicted_blocks,
+                              unsigned long long* evicted_bytes);
 /* the bird's-eye RGB image of the slots' frames (lane_tracker.py:834, :1035): n * warp_h * warp_w * 3;
  * needs lt_mask_run on those slots first (it reuses their undistorted rows) */
 int  lt_download_bev(lt_ctx* ctx, int first_slot, int n, uint8_t* out);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LANE_TRACKER_AMD_LIB: load another build of the same library (tools/toolchain_cases.sh compares variant builds)
 LIB_PATH = os.environ.get("LANE_TRACKER_AMD_LIB") or os.path.join(_HERE, "liblane_tracker_amd.so")
 NUM_STAGES = 12
-ABI_VERSION = 4          # LT_ABI_VERSION of include/lane_tracker_amd.h this table was written against
+ABI_VERSION = 5          # LT_ABI_VERSION of include/lane_tracker_amd.h this table was written against
 
 PLANE_R, PLANE_LAB_B, PLANE_TOPHAT_R, PLANE_TOPHAT_B, PLANE_MERGED, PLANE_MASK = range(6)
 
@@ -168,6 +168,7 @@ _SIGNATURES = {
     "lt_stage_name": (C.c_char_p, [C.c_int]),
     "lt_device_cache_trim": (C.c_int, [C.c_size_t]),
     "lt_device_cache_stats": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
+    "lt_device_cache_counters": (C.c_int, [C.POINTER(C.c_ulonglong)] * 4),
     "lt_set_download_method": (C.c_int, [_P, C.c_int]),
     "lt_download_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "lt_last_threshold_path": (C.c_int, [_P]),
@@ -408,6 +409,13 @@ def device_cache_stats():
     k, l, m, n = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
     _check(load().lt_device_cache_stats(C.byref(k), C.byref(l), C.byref(m), C.byref(n)))
     return {"kept_bytes": k.value, "live_bytes": l.value, "limit_bytes": m.value, "kept_blocks": n.value}
+
+
+def device_cache_counters():
+    """{'hits', 'misses', 'evicted_blocks', 'evicted_bytes'} of the device-memory cache since the process started."""
+    v = [C.c_ulonglong() for _ in range(4)]
+    _check(load().lt_device_cache_counters(*[C.byref(x) for x in v]))
+    return dict(zip(("hits", "misses", "evicted_blocks", "evicted_bytes"), (int(x.value) for x in v)))
 
 
 def pinned_empty(shape, dtype=np.uint8):

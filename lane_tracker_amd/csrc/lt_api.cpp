@@ -854,6 +854,7 @@ void lt_destroy(lt_ctx* c) {
     for (auto st : c->streams) stream_put(st);
     if (c->streams.empty()) stream_put(c->stream);
     note("slots");
+    FreeScope frees(c->device);          // one wait for the device instead of one per block; the blocks enter the cache together
     free_slots(c);
     note("tables and buffers");
     dev_free(c->d_uxy);
@@ -880,9 +881,12 @@ int lt_reserve(lt_ctx* c, int capacity) {
     if (rc) return rc;
     if (capacity <= c->capacity) return LT_OK;
     TraceScope ts_all("lt_reserve", (size_t)capacity);
+    if ((rc = sync_all(c))) return rc;
+    // the old blocks are parked until the new ones are allocated and enter the device cache behind them (FreeScope, lt_memory.cpp):
+    // the cache must not evict, to make room for the small blocks, the large ones this call is about to ask for
+    FreeScope frees(c->device);
     {
-        TraceScope ts_("lt_reserve:sync+free_slots", (size_t)c->capacity);
-        if ((rc = sync_all(c))) return rc;
+        TraceScope ts_("lt_reserve:free_slots", (size_t)c->capacity);
         free_slots(c);
     }
     c->rec_mirror_slot = -1;

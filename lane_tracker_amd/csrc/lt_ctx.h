@@ -239,6 +239,14 @@ void pooled_event_release(hipEvent_t e);
 // ---- device memory (lt_memory.cpp): a cache in front of hipMalloc / hipFree ------------------------------
 void* cached_alloc(size_t bytes);
 void cached_free(void* p);
+// Frees of one thread bracketed by this wait for `device` ONCE and enter the cache together when the scope closes -- behind
+// the allocations made inside it (lt_reserve: the larger blocks first, then the old ones into the cache; lt_destroy).
+struct FreeScope {
+    explicit FreeScope(int device);
+    ~FreeScope();
+    FreeScope(const FreeScope&) = delete;
+    FreeScope& operator=(const FreeScope&) = delete;
+};
 
 template <class T>
 int dev_alloc(T** p, size_t count) {

@@ -66,6 +66,7 @@ struct DevCache {
     std::map<void*, std::pair<int, size_t>> live;              // blocks handed out: their device and size
     size_t kept = 0, live_bytes = 0, high_water = 0;
     unsigned long long seq = 0;
+    unsigned long long hits = 0, misses = 0, evicted_blocks = 0, evicted_bytes = 0;   // lt_device_cache_counters
     long long env_cap = -2;                                    // bytes from LT_DEVICE_CACHE_GB; -1: not set; -2: not read yet
     long long cap() {                                          // (under m)
         if (env_cap == -2) {
@@ -94,6 +95,8 @@ static void release_blocks(const std::vector<std::pair<int, void*>>& out) {
     if (on != cur) (void)hipSetDevice(cur);
 }
 
+static void parked_to_driver();
+
 void* cached_alloc(size_t bytes) {
     DevCache& dc = dev_cache();
     int dev = 0;
@@ -110,6 +113,7 @@ void* cached_alloc(size_t bytes) {
             void* p = it->second.p;
             dc.blocks.erase(it);
             dc.kept -= bytes;
+            ++dc.hits;
             handed_out(p);
             if (trace_on() && bytes >= (1u << 20)) trace_line("device_cache_hit", trace_now(), bytes);
             return p;
@@ -120,12 +124,80 @@ void* cached_alloc(size_t bytes) {
     if (hipMalloc(&p, bytes) != hipSuccess) {                  // make room: everything kept goes back, then once more
         (void)hipGetLastError();
         (void)lt_device_cache_trim(0);
+        parked_to_driver();
         if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     }
     std::lock_guard<std::mutex> g(dc.m);
+    ++dc.misses;
     handed_out(p);
     return p;
 }
+// A scope of frees on one thread (lt_reserve growing a context, lt_destroy): ONE wait for the device when it opens instead of one
+// per block (a context is ~30 blocks; each device-wide wait also waits for every other tracker's work), and the blocks freed
+// inside are PARKED until it closes -- they enter the cache together, behind whatever the scope allocated meanwhile.  That
+// order is the point: a context that grows frees its old blocks and allocates larger ones; with the old blocks entering the
+// cache first, the cache -- over its limit for a moment -- evicted its OLDEST blocks, which were exactly the larger ones a
+// closed tracker had left and this context was about to ask for: 8-14 GB went back to the driver, were allocated again, and for
+// the half second the driver took to wipe them every device-to-host copy of the process ran at half rate (round 5's "later
+// annotated pass of a long-lived tracker": 19.9 k instead of 27 k frames/s, copy threads 49 % busy, in four of four bench runs;
+// tools/annot_state_probe.py, profiles/NOTES_r06.md E.1).
+namespace {
+struct FreeScopeState { int depth = 0; int device = -1; std::vector<std::pair<void*, size_t>> parked; };
+thread_local FreeScopeState t_free_scope;
+
+void cache_insert_and_evict(DevCache& dc, int dev, const std::vector<std::pair<void*, size_t>>& in, std::vector<std::pair<int, void*>>& out) {   // (under dc.m)
+    const long long cap = dc.cap();
+    for (const auto& b : in) {
+        if ((long long)b.second > cap) { out.push_back({dev, b.first}); ++dc.evicted_blocks; dc.evicted_bytes += b.second; continue; }
+        dc.blocks.insert({{dev, b.second}, DevCache::Free{b.first, dc.seq++}});
+        dc.kept += b.second;
+    }
+    while ((long long)dc.kept > cap && !dc.blocks.empty()) {   // over the limit: the block that has waited longest goes
+        auto old = dc.blocks.begin();
+        for (auto j = dc.blocks.begin(); j != dc.blocks.end(); ++j)
+            if (j->second.seq < old->second.seq) old = j;
+        dc.kept -= old->first.second;
+        ++dc.evicted_blocks;
+        dc.evicted_bytes += old->first.second;
+        out.push_back({old->first.first, old->second.p});
+        dc.blocks.erase(old);
+    }
+}
+}  // namespace
+
+FreeScope::FreeScope(int device) {
+    FreeScopeState& fs = t_free_scope;
+    if (fs.depth++ == 0) {
+        fs.device = device;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();          // hipFree's own wait, once for the whole scope (see cached_free)
+        if (cur != device) (void)hipSetDevice(cur);
+    }
+}
+FreeScope::~FreeScope() {
+    FreeScopeState& fs = t_free_scope;
+    if (--fs.depth > 0) return;
+    std::vector<std::pair<int, void*>> out;
+    if (!fs.parked.empty()) {
+        DevCache& dc = dev_cache();
+        std::lock_guard<std::mutex> g(dc.m);
+        cache_insert_and_evict(dc, fs.device, fs.parked, out);
+    }
+    fs.parked.clear();
+    fs.device = -1;
+    release_blocks(out);
+}
+// (cached_alloc's last resort: the parked blocks of this thread go back to the driver)
+static void parked_to_driver() {
+    FreeScopeState& fs = t_free_scope;
+    std::vector<std::pair<int, void*>> out;
+    for (const auto& b : fs.parked) out.push_back({fs.device, b.first});
+    fs.parked.clear();
+    release_blocks(out);
+}
+
 void cached_free(void* p) {
     DevCache& dc = dev_cache();
     std::pair<int, size_t> key;
@@ -136,6 +208,16 @@ void cached_free(void* p) {
         else key = it->second;
     }
     if (key.first < 0) { (void)hipFree(p); return; }          // not ours (never happens: every dev_free pairs a dev_alloc)
+    FreeScopeState& fs = t_free_scope;
+    if (fs.depth > 0 && fs.device == key.first) {             // inside a FreeScope of this device: waited for already, parked
+        {
+            std::lock_guard<std::mutex> g(dc.m);
+            dc.live.erase(p);
+            dc.live_bytes -= key.second;
+        }
+        fs.parked.push_back({p, key.second});
+        return;
+    }
     // hipFree waits for the device before it releases anything, and callers have always relied on that (a block freed while
     // another of the context's streams still works on it); a cached block can be handed out again at once, so the same wait
     // happens here -- for the device the BLOCK lives on, which need not be the calling thread's current one.
@@ -149,20 +231,7 @@ void cached_free(void* p) {
         std::lock_guard<std::mutex> g(dc.m);
         dc.live.erase(p);
         dc.live_bytes -= key.second;
-        const long long cap = dc.cap();
-        if ((long long)key.second > cap) out.push_back({key.first, p});
-        else {
-            dc.blocks.insert({key, DevCache::Free{p, dc.seq++}});
-            dc.kept += key.second;
-            while ((long long)dc.kept > cap && !dc.blocks.empty()) {   // over the limit: the block that has waited longest goes
-                auto old = dc.blocks.begin();
-                for (auto j = dc.blocks.begin(); j != dc.blocks.end(); ++j)
-                    if (j->second.seq < old->second.seq) old = j;
-                dc.kept -= old->first.second;
-                out.push_back({old->first.first, old->second.p});
-                dc.blocks.erase(old);
-            }
-        }
+        cache_insert_and_evict(dc, key.first, {{p, key.second}}, out);
     }
     release_blocks(out);
 }
@@ -175,6 +244,8 @@ void cache_take(size_t keep_bytes, std::vector<std::pair<int, void*>>& out) {
         for (auto j = dc.blocks.begin(); j != dc.blocks.end(); ++j)
             if (j->second.seq < old->second.seq) old = j;
         dc.kept -= old->first.second;
+        ++dc.evicted_blocks;
+        dc.evicted_bytes += old->first.second;
         out.push_back({old->first.first, old->second.p});
         dc.blocks.erase(old);
     }
@@ -214,6 +285,16 @@ int lt_device_cache_stats(size_t* kept_bytes, size_t* live_bytes, size_t* limit_
     if (live_bytes) *live_bytes = dc.live_bytes;
     if (limit_bytes) *limit_bytes = (size_t)std::max<long long>(dc.cap(), 0);
     if (kept_blocks) *kept_blocks = (int)dc.blocks.size();
+    return LT_OK;
+}
+
+int lt_device_cache_counters(unsigned long long* hits, unsigned long long* misses, unsigned long long* evicted_blocks, unsigned long long* evicted_bytes) {
+    DevCache& dc = dev_cache();
+    std::lock_guard<std::mutex> g(dc.m);
+    if (hits) *hits = dc.hits;
+    if (misses) *misses = dc.misses;
+    if (evicted_blocks) *evicted_blocks = dc.evicted_blocks;
+    if (evicted_bytes) *evicted_bytes = dc.evicted_bytes;
     return LT_OK;
 }
 
@@ -378,14 +459,23 @@ struct HostCopier {
         return std::min(v, threads());
     }
     void wake(size_t pieces) {      // after a push, outside the lock: sleepers for the pieces the pollers will not take
-        const long need = (long)std::min<size_t>(pieces, (size_t)threads()) - (long)spinning.load(std::memory_order_relaxed);
+        // counted over EVERYTHING that waits in the queue, not over this submission alone: two submitters that each push one
+        // piece and each see the same single poller must not both leave their piece to it (the second piece would wait, with
+        // every other worker asleep, until the first -- possibly a millisecond of text -- is done)
+        const size_t waiting = std::max(pieces, queued.load(std::memory_order_acquire));
+        const long need = (long)std::min<size_t>(waiting, (size_t)threads()) - (long)spinning.load(std::memory_order_relaxed);
         for (long i = 0; i < need; ++i) work.notify_one();
     }
     static int spin_us() {
         static const int v = [] { const char* e = std::getenv("LT_COPY_SPIN_US"); return e ? std::max(std::atoi(e), 0) : 400; }();
         return v;
     }
-    bool known(int group) { return group == 0 || groups.count(group) != 0; }      // (under m)
+    int adopt_below = 0;             // the child of a fork(): ids below this were handed out by the parent's copier and are taken over on first use
+    bool known(int group) {          // (under m)
+        if (group == 0 || groups.count(group) != 0) return true;
+        if (group > 0 && group < adopt_below) { groups[group] = true; return true; }
+        return false;
+    }
     void start_workers(std::unique_lock<std::mutex>& lk, int want) {               // (under m)
         done.wait(lk, [&] { return !stop; });          // an lt_shutdown() under way: workers start again once it is over
         while ((int)th.size() < want) th.emplace_back([this] { run(); });
@@ -493,8 +583,14 @@ HostCopier& host_copier() {
         g_copier = new HostCopier;
         static CopierOwner owner;
         // the child of a fork gets a copier of its own: the parent's workers do not exist there (the old object, its mutex
-        // possibly held by a thread that is gone, is left alone)
-        pthread_atfork(nullptr, nullptr, [] { g_copier = new HostCopier; });
+        // possibly held by a thread that is gone, is left alone).  Group ids the parent handed out keep their meaning: the child's
+        // copier numbers its own groups behind them and takes an inherited id over, with nothing pending, when it is first used
+        // (a LaneTracker created before the fork keeps working in the child).
+        pthread_atfork(nullptr, nullptr, [] {
+            HostCopier* old = g_copier;
+            g_copier = new HostCopier;
+            if (old) { g_copier->next_group = old->next_group; g_copier->adopt_below = old->next_group; }
+        });
     });
     return *g_copier;
 }

@@ -1,14 +1,19 @@
-"""How many CPUs this process may really use, and NumPy's BLAS pool held to that.
+"""How many CPUs this process may really use, and NumPy's BLAS pool held to that around the library's OWN LAPACK calls.
 
 A container on a large host sees every CPU of the machine (the MI355X boxes: 256) and is granted a few by its cgroup (16).
 OpenBLAS starts one thread per VISIBLE CPU.  `np.polyfit` over a lane's pixels -- `LaneTracker.get_curve_radius` refits them
 as the reference does (`lane_tracker.py:538-546`) when a radius lies next to an integer, a few times per second of video --
 then runs on all of them for a millisecond, the cgroup's CPU quota for the period is gone, and the kernel freezes EVERY thread
 of the process until the next period: 40-80 ms per event, `cpu.stat: nr_throttled`, 7-15 % of `process()`'s time at
-1920x1080 (`tools/process_throttle_probe.py`, profiles/NOTES_r05.md D.9).  `cap_blas_threads()` lowers the pool to the CPUs the
-process may use; it never raises it.  `LT_BLAS_CAP=0` leaves the pool alone."""
+1920x1080 (`tools/process_throttle_probe.py`, profiles/NOTES_r05.md D.9).
+
+`blas_limited()` is a context manager for exactly those calls: inside it the pool runs on no more threads than the CPUs the
+process may use, and on the way out the pool is what the application had set.  (Round 5 lowered the pool once, for good, from
+`LaneTracker.__init__`: a library has no business with its host's global state.)"""
+import contextlib
 import ctypes
 import os
+import threading
 
 
 def cpu_quota():
@@ -35,43 +40,74 @@ def usable_cpus():
     return max(1, min(avail, int(q + 0.999))) if q else avail
 
 
-_capped = None
+_pools = None                    # [(get_num_threads, set_num_threads)] of the BLAS libraries NumPy has loaded, found once
+_lock = threading.Lock()
+_depth = 0                       # blocks of blas_limited() under way (all threads)
+_saved = None                    # the pools' sizes as the first of them found them
 
 
-def cap_blas_threads():
-    """-> the BLAS thread count in force afterwards (None: no BLAS pool found, or LT_BLAS_CAP=0).  Idempotent."""
-    global _capped
-    if _capped is not None or os.environ.get("LT_BLAS_CAP") == "0":
-        return _capped
-    want = usable_cpus()
+def _blas_pools():
+    global _pools
+    if _pools is not None:
+        return _pools
+    found = []
     try:
         import threadpoolctl
-        pools = [p for p in threadpoolctl.threadpool_info() if p.get("user_api") == "blas"]
-        if not pools:
-            return None
-        have = max(p.get("num_threads", 1) for p in pools)
-        if have > want:
-            threadpoolctl.threadpool_limits(limits=want, user_api="blas")      # (not used as a context manager: stays in force)
-            have = want
-        _capped = have
-        return _capped
+        for lc in threadpoolctl.ThreadpoolController().lib_controllers:
+            if getattr(lc, "user_api", None) == "blas":
+                found.append((lc.get_num_threads, lc.set_num_threads))
     except Exception:
-        pass
-    try:        # without threadpoolctl: OpenBLAS by name, in the libraries NumPy has loaded
-        for line in open("/proc/self/maps"):
-            path = line.rsplit(None, 1)[-1]
-            if "openblas" in os.path.basename(path).lower():
-                lib = ctypes.CDLL(path)
-                for suffix in ("", "64_", "_64"):
-                    get = getattr(lib, "openblas_get_num_threads" + suffix, None)
-                    put = getattr(lib, "openblas_set_num_threads" + suffix, None)
-                    if get and put:
-                        have = int(get())
+        found = []
+    if not found:
+        try:        # without threadpoolctl: OpenBLAS by name, in the libraries NumPy has loaded
+            for line in open("/proc/self/maps"):
+                path = line.rsplit(None, 1)[-1]
+                if "openblas" in os.path.basename(path).lower():
+                    lib = ctypes.CDLL(path)
+                    for suffix in ("", "64_", "_64"):
+                        get = getattr(lib, "openblas_get_num_threads" + suffix, None)
+                        put = getattr(lib, "openblas_set_num_threads" + suffix, None)
+                        if get and put:
+                            found.append((lambda g=get: int(g()), lambda n, p=put: p(int(n))))
+                            break
+                    break
+        except Exception:
+            found = []
+    _pools = found
+    return found
+
+
+@contextlib.contextmanager
+def blas_limited():
+    """Inside the block NumPy's BLAS pool runs on at most `usable_cpus()` threads (never more than it had); afterwards it is
+    what it was.  Blocks may nest and run on several threads at once: the first one in lowers the pool, the last one out
+    restores it.  Without a BLAS pool to be found the block runs as it is."""
+    global _depth, _saved
+    pools = _blas_pools()
+    if pools:
+        with _lock:
+            if _depth == 0:
+                want = usable_cpus()
+                _saved = []
+                for get, put in pools:
+                    try:
+                        have = int(get() or 0)
                         if have > want:
-                            put(int(want))
-                            have = want
-                        _capped = have
-                        return _capped
-    except Exception:
-        pass
-    return None
+                            put(want)
+                            _saved.append((put, have))
+                    except Exception:
+                        pass
+            _depth += 1
+    try:
+        yield
+    finally:
+        if pools:
+            with _lock:
+                _depth -= 1
+                if _depth == 0 and _saved:
+                    for put, have in _saved:
+                        try:
+                            put(have)
+                        except Exception:
+                            pass
+                    _saved = None

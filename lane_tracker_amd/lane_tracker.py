@@ -64,7 +64,6 @@ class LaneTracker(StreamPipeline):
 
     def __init__(self, img_size, warped_size, cam_matrix, dist_coeffs, warp_matrices, mpp_conversion,
                  n_fail=8, n_reset=4, n_average=2, print_frame_count=False, device=0):
-        _hostcpu.cap_blas_threads()      # no more BLAS threads than CPUs granted: np.polyfit must not freeze the process (hostcpu.py)
         self.img_size = img_size
         self.warped_size = warped_size
         self.cam_matrix = cam_matrix
@@ -146,6 +145,100 @@ class LaneTracker(StreamPipeline):
     left_window_centroids = _lane_pixel_property("left_window_centroids", True)
     right_window_centroids = _lane_pixel_property("right_window_centroids", True)
     del _lane_pixel_property
+
+    # ---- the cross-frame state as data (reference :139-176; SURVEY.md section 5: "~20 scalars + two lists") ---------------
+    STATE_VERSION = 1
+    _STATE_SCALARS = ("last_detection", "detected_pixels", "valid_lane_lines", "left_curve_radius", "right_curve_radius",
+                      "average_curve_radius", "eccentricity", "counter", "success")
+    _STATE_VECTORS = ("last_left_coeffs", "last_right_coeffs", "left_avg_coeffs", "right_avg_coeffs")          # f64 or None
+    _STATE_INT_ARRAYS = ("left_avg_y", "left_avg_x", "right_avg_y", "right_avg_x")                             # int64 (or the empty f64 array of a new tracker)
+    _STATE_PIXELS = ("left_y", "left_x", "right_y", "right_x")
+
+    def get_state(self):
+        """Everything one frame hands to the next (the attributes of reference :139-176), as a plain dict of Python numbers and
+        lists -- `json.dumps` takes it as it is, f64 values survive the round trip exactly.  A tracker built with the same
+        constructor arguments, in this or another process, continues the stream after `set_state()` with the results this one
+        would have produced (tests/test_gpu_state.py).  Call it between frames / windows, not inside a `process_stream()`."""
+        if self._in_stream:
+            raise RuntimeError("get_state() inside an active process_stream(): exhaust or close the generator first")
+        self._materialise_pending()          # the lane pixels / centroids of the last search leave the device
+
+        def num(v):
+            if v is None:
+                return None
+            if isinstance(v, (bool, np.bool_)):
+                return bool(v)
+            if isinstance(v, (int, np.integer)):
+                return int(v)
+            return float(v)
+
+        def arr(v):
+            return None if v is None else np.asarray(v).tolist()
+        st = {"version": self.STATE_VERSION, "n_fail": num(self.n_fail), "n_reset": num(self.n_reset), "n_average": num(self.n_average),
+              "img_size": [int(v) for v in self.img_size], "warped_size": [int(v) for v in self.warped_size]}
+        for k in self._STATE_SCALARS:
+            st[k] = num(getattr(self, k))
+        for k in self._STATE_VECTORS + self._STATE_INT_ARRAYS:
+            st[k] = arr(getattr(self, k))
+        st["left_fit_coeffs"] = [arr(c) for c in self.left_fit_coeffs]       # history: 3 values, or [] for a failed frame (:1142-1147)
+        st["right_fit_coeffs"] = [arr(c) for c in self.right_fit_coeffs]
+        st["average_curve_radii"] = [int(v) for v in self.average_curve_radii]
+        for k in self._STATE_PIXELS:
+            st[k] = arr(self._lp[k])
+        for k in ("left_window_centroids", "right_window_centroids"):
+            v = self._lp[k]
+            st[k] = None if v is None else [num(c) for c in v]
+        f = self._fit                        # the fit of the last search that found pixels (fit_poly() hands it out)
+        st["last_search_fit"] = None if f is None else [arr(f[2]), arr(f[3])]
+        st["outage_group"] = int(self._outage_group)
+        st["avg_partial"] = None             # the `partial` the plot points of the averages (left_avg_x, ...) were formed with
+        if self._avg_packed is not None:
+            for (partial, _), b in self.__dict__.get("_packed", {}).items():
+                if b is self._avg_packed[0]:
+                    st["avg_partial"] = num(partial)
+        return st
+
+    def set_state(self, state):
+        """Continue the stream `state` (a `get_state()` dict) was taken from.  The tracker must have been built for the same
+        geometry and history lengths; ValueError otherwise."""
+        if self._in_stream:
+            raise RuntimeError("set_state() inside an active process_stream()")
+        if state.get("version") != self.STATE_VERSION:
+            raise ValueError("unknown tracker state version %r" % (state.get("version"),))
+        for k in ("n_fail", "n_reset", "n_average"):
+            if state[k] != getattr(self, k):
+                raise ValueError("state was taken with %s=%r, this tracker has %r" % (k, state[k], getattr(self, k)))
+        if list(state["img_size"]) != [int(v) for v in self.img_size] or list(state["warped_size"]) != [int(v) for v in self.warped_size]:
+            raise ValueError("state was taken from a tracker of another geometry")
+        self._all_copies_done()
+        self._pending = self._pending_cent = None
+        for k in self._STATE_SCALARS:
+            setattr(self, k, state[k])
+        for k in self._STATE_VECTORS:
+            setattr(self, k, None if state[k] is None else np.array(state[k], np.float64))
+        for k in self._STATE_INT_ARRAYS:
+            v = state[k]
+            setattr(self, k, np.array([]) if not v else np.array(v, np.int64))
+        self.left_fit_coeffs = [np.array(c, np.float64) for c in state["left_fit_coeffs"]]
+        self.right_fit_coeffs = [np.array(c, np.float64) for c in state["right_fit_coeffs"]]
+        self.average_curve_radii = [int(v) for v in state["average_curve_radii"]]
+        for k in self._STATE_PIXELS:
+            self._lp[k] = None if state[k] is None else np.array(state[k], np.int64)
+        for k in ("left_window_centroids", "right_window_centroids"):
+            self._lp[k] = None if state[k] is None else list(state[k])
+        f = state["last_search_fit"]
+        self._fit = None if f is None else (self._lp["left_y"], self._lp["right_y"], np.array(f[0], np.float64), np.array(f[1], np.float64))
+        self._outage_group = int(state.get("outage_group", 4))
+        # the packed polygon of the averages, which a failed frame redraws (draw_lane): formed again from the coefficients --
+        # the same lt_poly_points call that left left_avg_x & co. behind
+        self._avg_packed = None
+        if state.get("avg_partial") is not None and self.left_avg_coeffs is not None and self.right_avg_coeffs is not None:
+            b = self._points_packed(self.left_avg_coeffs, self.right_avg_coeffs, state["avg_partial"], 'avg0')
+            nl, nr = int(b[1][0]), int(b[1][1])
+            if np.array_equal(b[2][:nl, 1], self.left_avg_x) and np.array_equal(b[3][:nr, 1], self.right_avg_x):
+                self._avg_packed = (b, self.left_avg_x, self.right_avg_x)
+        self._lane_in_flight = self._device_lane = None
+        self._resident = None
 
     def close(self):
         try:
@@ -411,7 +504,8 @@ class LaneTracker(StreamPipeline):
                 val = radius_of((c[0] * self.mpph / (self.mppv ** 2), c[1] * self.mpph / self.mppv))
             if math.isfinite(val) and abs(val - round(val)) <= 1e-8 * max(1.0, abs(val)):
                 ys, xs = (self.left_y, self.left_x) if side == 0 else (self.right_y, self.right_x)
-                val = radius_of(np.polyfit(np.asarray(ys) * self.mppv, np.asarray(xs) * self.mpph, 2))
+                with _hostcpu.blas_limited():     # (LAPACK on no more threads than the CPUs granted, for this call only: hostcpu.py)
+                    val = radius_of(np.polyfit(np.asarray(ys) * self.mppv, np.asarray(xs) * self.mpph, 2))
             radii.append(int(val))
         self.left_curve_radius, self.right_curve_radius = radii
         average_curve_radius = int(0.5 * (self.left_curve_radius + self.right_curve_radius))
@@ -983,5 +1077,6 @@ def _minimum_norm_parabola(y, x):
     lhs = np.vander(y, 3)
     scale = np.sqrt((lhs * lhs).sum(axis=0))
     scale[scale == 0] = 1.0
-    c = np.linalg.lstsq(lhs / scale, np.asarray(x, np.float64), rcond=len(y) * np.finfo(np.float64).eps)[0]
+    with _hostcpu.blas_limited():
+        c = np.linalg.lstsq(lhs / scale, np.asarray(x, np.float64), rcond=len(y) * np.finfo(np.float64).eps)[0]
     return c / scale

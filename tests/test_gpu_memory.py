@@ -128,3 +128,34 @@ def test_whole_frame_calls_refuse_slots_that_hold_row_runs_only():
         assert np.array_equal(out, frames)                       # an empty polygon: the camera frames themselves
     finally:
         c.close()
+
+
+def test_a_growing_context_takes_the_large_blocks_from_the_cache_instead_of_evicting_them():
+    """Round 5's regression of the long-lived annotated stream: `lt_reserve` gave a growing context's old
+    blocks to the cache BEFORE it asked for the larger ones; the cache, over its limit for a moment, evicted its oldest blocks --
+    the larger ones a closed tracker had just left -- and the driver's wipe of those gigabytes halved the device-to-host copy
+    rate of everything that ran in the next half second.  Now (FreeScope, csrc/lt_memory.cpp) the old blocks enter the cache
+    behind the allocations: nothing is evicted, nothing goes to hipMalloc.  A child process, so that the cache's limit
+    (the high-water mark of live memory) is what this scenario alone makes it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json; sys.path.insert(0, %r)\n"
+            "from lane_tracker_amd import _native, calib\n"
+            "cal = calib.reference_calibration()\n"
+            "mk = lambda n: _native.Context(cal['img_size'], cal['warped_size'], cal['cam_matrix'], cal['dist_coeffs'], cal['warp_matrices'][0], device=0, capacity=n)\n"
+            "a = mk(96); a.close()                      # a closed tracker's large blocks wait in the cache\n"
+            "b = mk(64)                                 # the long-lived one, smaller so far\n"
+            "c0, s0 = _native.device_cache_counters(), _native.device_cache_stats()\n"
+            "b.reserve(96)                              # ... grows to the size the closed one had\n"
+            "c1, s1 = _native.device_cache_counters(), _native.device_cache_stats()\n"
+            "b.close()\n"
+            "print(json.dumps([c0, c1, s0, s1]))\n" % root)
+    env = {k: v for k, v in os.environ.items() if k != "LT_DEVICE_CACHE_GB"}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    import json
+    c0, c1, s0, s1 = json.loads(r.stdout.strip().splitlines()[-1])
+    assert c1["evicted_bytes"] == c0["evicted_bytes"] and c1["evicted_blocks"] == c0["evicted_blocks"], (c0, c1)
+    assert c1["misses"] == c0["misses"] and c1["hits"] - c0["hits"] >= 10, (c0, c1)     # every slot buffer of the larger size was waiting
+    assert 0 < s1["kept_bytes"] <= s1["limit_bytes"], (s0, s1)                           # ... and the old blocks wait in their place

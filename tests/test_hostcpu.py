@@ -20,25 +20,49 @@ def test_usable_cpus_is_within_the_affinity_mask_and_the_quota():
     assert q is None or n <= int(q + 0.999)
 
 
-def test_blas_pool_is_lowered_to_the_usable_cpus_and_never_raised():
-    code = ("import numpy as np, threadpoolctl\n"
+def test_blas_pool_is_limited_inside_the_block_only_and_never_raised():
+    """the library limits BLAS threads around its own np.polyfit / lstsq calls and leaves the process's
+    pool as the application set it."""
+    code = ("import numpy as np, threadpoolctl, threading\n"
             "from lane_tracker_amd import hostcpu\n"
-            "b = [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']\n"
-            "got = hostcpu.cap_blas_threads()\n"
-            "a = [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']\n"
-            "print(b, got, a, hostcpu.usable_cpus())")
+            "n = lambda: [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']\n"
+            "b = n()\n"
+            "with hostcpu.blas_limited():\n"
+            "    i = n()\n"
+            "    with hostcpu.blas_limited():\n"
+            "        ii = n()\n"
+            "    still = n()\n"
+            "    np.polyfit(np.arange(50.0), np.arange(50.0) ** 2, 2)\n"
+            "a = n()\n"
+            "print(b, i, ii, still, a, hostcpu.usable_cpus())")
     try:
         import threadpoolctl  # noqa: F401
     except ImportError:
         import pytest
         pytest.skip("threadpoolctl is not installed")
-    # a pool smaller than the CPUs: left alone
+    # a pool smaller than the CPUs: left alone, inside and outside
     out = _run(code, OPENBLAS_NUM_THREADS="1")
-    assert out.startswith("[1] 1 [1]"), out
-    # a pool larger than the CPUs the process may use (an affinity mask of one CPU): lowered
+    assert out.startswith("[1] [1] [1] [1] [1]"), out
+    # a pool larger than the CPUs the process may use (an affinity mask of one CPU): lowered inside the block (nested blocks
+    # included), and back to the application's value behind it
     cpu = sorted(os.sched_getaffinity(0))[0]
     out = _run("import os; os.sched_setaffinity(0, {%d})\n" % cpu + code, OPENBLAS_NUM_THREADS="4")
-    assert out.endswith("[1] 1") and out.split("]")[0] in ("[4", "[1"), out
-    # the switch
-    out = _run(code, OPENBLAS_NUM_THREADS="4", LT_BLAS_CAP="0")
-    assert " None " in out, out
+    first = out.split("]")[0]
+    assert first in ("[4", "[1"), out
+    assert out == "%s] [1] [1] [1] %s] 1" % (first, first), out
+
+
+def test_constructing_the_module_does_not_touch_the_pool():
+    code = ("import numpy as np, threadpoolctl\n"
+            "n = lambda: [p['num_threads'] for p in threadpoolctl.threadpool_info() if p['user_api'] == 'blas']\n"
+            "b = n()\n"
+            "import lane_tracker_amd.lane_tracker, lane_tracker_amd.hostcpu as h\n"
+            "assert not hasattr(h, 'cap_blas_threads')\n"
+            "print(b == n())")
+    try:
+        import threadpoolctl  # noqa: F401
+    except ImportError:
+        import pytest
+        pytest.skip("threadpoolctl is not installed")
+    cpu = sorted(os.sched_getaffinity(0))[0]
+    assert _run("import os; os.sched_setaffinity(0, {%d})\n" % cpu + code, OPENBLAS_NUM_THREADS="4") == "True"

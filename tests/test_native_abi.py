@@ -24,8 +24,8 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert sorted(_native.exported_symbols()) == declared
-    assert lib.lt_abi_version() == _native.ABI_VERSION == 4
-    assert int(re.search(r"#define LT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "lane_tracker_amd.h")).read()).group(1)) == 4
+    assert lib.lt_abi_version() == _native.ABI_VERSION == 5
+    assert int(re.search(r"#define LT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "lane_tracker_amd.h")).read()).group(1)) == 5
 
 
 def test_library_exports_nothing_but_the_header():

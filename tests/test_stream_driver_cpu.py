@@ -133,3 +133,27 @@ def test_outages_handled_in_groups_equal_frame_by_frame(fake, pool, seed, n_rese
         assert _state(bat) == _state(seq), (lo, w)
         lo += w
     assert 0 < bat.success < bat.counter == 90
+
+
+@pytest.mark.parametrize("cut", [1, 5, 6, 13, 15, 18, 19, 25])
+def test_state_round_trip_through_json_continues_the_stream(fake, pool, cut):
+    """`get_state()` -> JSON -> `set_state()` on ANOTHER tracker at frame `cut` of PLAN (clean runs, behind a one-off failure,
+    inside and right behind the long outage): the second tracker leaves the uncut run's state after every further frame
+    (reference lane_tracker.py:139-176; the GPU form with annotated frames: tests/test_gpu_state.py)."""
+    import json
+    cal = calib.reference_calibration()
+    frames = _stream(pool, PLAN)
+    whole = LaneTracker(**cal)
+    want = []
+    for f in frames:
+        whole.process_batch(f[None], annotate=False)
+        want.append(_state(whole))
+    a = LaneTracker(**cal)
+    a.process_batch(frames[:cut], annotate=False)
+    text = json.dumps(a.get_state())
+    b = LaneTracker(**cal)
+    b.set_state(json.loads(text))
+    assert _state(b) == want[cut - 1]
+    for i in range(cut, len(frames)):
+        b.process_batch(frames[i][None], annotate=False)
+        assert _state(b) == want[i], (cut, i)
