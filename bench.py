@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling, same guide
 MASK_STAGES = ["undistort_rows", "warp_split", "erode_r29", "tophat_r29", "erode_b55", "tophat_b55", "threshold",
                "merge", "open5"]
-PROFILE_TAG = "r05"            # profiles/<tag>_traffic.json, <tag>_kernel_stats_summary.json: the committed counter run of this code
+PROFILE_TAGS = ("r06", "r05")   # profiles/<tag>_traffic.json, <tag>_kernel_stats_summary.json: the committed counter run of this code (the newest that exists)
+PROFILE_TAG = next((t for t in PROFILE_TAGS if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", t + "_traffic.json"))), PROFILE_TAGS[-1])
 CALIB_TAG = "r02"              # profiles/<tag>_valu_issue.json, <tag>_fetch_calib.json: the issue-rate / counter calibrations (hardware facts)
 
 
@@ -130,6 +131,12 @@ def _call_trace(tracker):
     return lambda: {k: [v[0], round(v[1], 2)] for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1])}
 
 
+def spread(values):
+    """min / median / max of a few repetitions (every stream figure of the line is a median of three with its spread)."""
+    v = sorted(values)
+    return {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+
+
 def stream_leg(streams, window=256, seconds=1.0, nwin=8):
     """The stateful stream (BASELINE config 5) through the drop-in API, host-fed: frames/s of process() frame
     by frame (annotated frame back, as process_video.py uses it), of process_batch() (device-chained searches) and of
@@ -156,11 +163,15 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
             res = {"process_fps": sorted(chunks)[1], "process_fps_stretches": chunks}
             for key, ann in (("process_batch_fps", False), ("process_batch_annotated_fps", True)):
                 lt.process_batch(frames, annotate=ann)
-                t0, k = time.perf_counter(), 0
-                while time.perf_counter() - t0 < seconds * 0.2 or k == 0:
-                    lt.process_batch(wins[1 + k % (nwin - 1)], annotate=ann)
-                    k += 1
-                res[key] = round(k * window / (time.perf_counter() - t0), 1)
+                reps, k = [], 0
+                for _ in range(3):
+                    t0, k0 = time.perf_counter(), k
+                    while time.perf_counter() - t0 < seconds * 0.07 or k == k0:
+                        lt.process_batch(wins[1 + k % (nwin - 1)], annotate=ann)
+                        k += 1
+                    reps.append(round((k - k0) * window / (time.perf_counter() - t0), 1))
+                res[key + "_passes"] = spread(reps)
+                res[key] = res[key + "_passes"]["median"]
 
             def stream_rate(ws, ann, tracker=lt, first=None, **kw):
                 t0 = time.perf_counter()
@@ -205,30 +216,41 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
             # consecutive windows of one video: process_stream keeps the device busy across window boundaries.
             fp_plain = first_passes(False)
             res["process_stream_first_pass"] = fp_plain
-            res["process_stream_first_pass_fps"] = fp_plain["frames_per_s"]["median"]
+            res["process_stream_first_pass_fps"] = fp_plain["frames_per_s"]["median"]           # (after LaneTracker.warm(); as in round 5)
+            res["process_stream_first_pass_not_warmed_fps"] = fp_plain["not_warmed"]["frames_per_s"]   # what one short video pays (round 4's meaning of the key above)
             cold = stream_windows(base, window, nwin)
             stream_rate(cold, False)
-            res["process_stream_fps"] = max(stream_rate(cold + cold, False) for _ in range(2))      # 4096 frames per stream
+            res["process_stream_passes"] = spread([stream_rate(cold + cold, False) for _ in range(3)])      # 4096 frames per pass
+            res["process_stream_fps"] = res["process_stream_passes"]["median"]
             # ... and with every annotated frame rendered and copied back (what process_video.py consumes)
             fp_ann = first_passes(True)
             res["process_stream_annotated_first_pass"] = fp_ann
             res["process_stream_annotated_first_pass_fps"] = fp_ann["frames_per_s"]["median"]
+            res["process_stream_annotated_first_pass_not_warmed_fps"] = fp_ann["not_warmed"]["frames_per_s"]
+            # the later passes of the LONG-LIVED tracker (the one that ran process(), process_batch and the plain stream above): what a
+            # deployed process does all day.  Three passes, median with the spread; the device cache's traffic with the driver beside
+            # them (an eviction = a wipe by the driver = half-rate downloads for the next half second: NOTES_r06 E.1)
+            cc0 = _native.device_cache_counters()
             stream_rate(cold, True)
             cs0, t_ann = _native.host_copy_stats(), time.perf_counter()
-            res["process_stream_annotated_fps"] = max(stream_rate(cold, True) for _ in range(2))
+            res["process_stream_annotated_passes"] = spread([stream_rate(cold, True) for _ in range(3)])
+            res["process_stream_annotated_fps"] = res["process_stream_annotated_passes"]["median"]
             cs1, t_ann = _native.host_copy_stats(), time.perf_counter() - t_ann
+            cc1 = _native.device_cache_counters()
             res["copy_threads_busy_share_annotated_stream"] = round((cs1["busy_s"] - cs0["busy_s"]) / max(t_ann * cs1["threads"], 1e-9), 3)
+            res["device_cache_during_annotated_passes"] = {k: cc1[k] - cc0[k] for k in cc1}
             # ... and drawn into the caller's own windows (annotate="inplace", not in the reference): windows of their own, restored
             # from `cold` before every pass (outside the clock); like the line above a later pass -- memory the runtime has seen
             work = [w.copy() for w in cold]
             rates = []
-            for k in range(3):
+            for k in range(4):
                 r = stream_rate(work, "inplace")
                 if k:
                     rates.append(r)
                 for w, c0 in zip(work, cold):
                     np.copyto(w, c0)
-            res["process_stream_annotated_inplace_fps"] = max(rates)
+            res["process_stream_annotated_inplace_passes"] = spread(rates)
+            res["process_stream_annotated_inplace_fps"] = res["process_stream_annotated_inplace_passes"]["median"]
             del work
             res["annotated_frames_came_back_by"] = lt._ctx.download_stats()
             rows = lt._present_rows() if lt.host_copies_rows else None
@@ -246,13 +268,15 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                     broken[i] = (np.random.default_rng(4000 + i).integers(0, 256, broken[i].shape, dtype=np.uint8) if j % 3 == 0
                                  else (128 if j % 3 == 1 else 0))
             list(lt.process_stream([broken] * 2, annotate=False))
-            res["process_stream_outages_fps"] = stream_rate([broken] * 4, False)
+            res["process_stream_outages_passes"] = spread([stream_rate([broken] * 4, False) for _ in range(3)])
+            res["process_stream_outages_fps"] = res["process_stream_outages_passes"]["median"]
             if name == "1280x720":       # the author's Demo 1 settings (tracker_settings.md:1-33: the greenery mask) on the same stream
                 lt1 = LaneTracker(**cal)
                 try:
                     kw = settings.apply(lt1, settings.DEMO_1)
                     stream_rate(cold[:2], False, lt1, **kw)
-                    res["process_stream_demo1_fps"] = stream_rate(cold + cold, False, lt1, **kw)      # 4096 frames, as process_stream_fps
+                    res["process_stream_demo1_passes"] = spread([stream_rate(cold + cold, False, lt1, **kw) for _ in range(3)])   # 4096 frames, as process_stream_fps
+                    res["process_stream_demo1_fps"] = res["process_stream_demo1_passes"]["median"]
                     res["demo1_success_ratio"] = round(lt1.get_success_ratio()[0], 4)
                 finally:
                     lt1.close()
@@ -267,7 +291,7 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                    "returned; process_batch() = one window per call, searches chained on the device (lt_band_fit_chain_run), check_validity / "
                    "history on the host; process_stream() = the same over consecutive windows, the next windows' uploads and masks under the "
                    "current one's searches; *_first_pass = three fresh trackers over pages the runtime has never seen, after LaneTracker.warm() "
-                   "(its time in warm_ms; not_warmed: a fourth fresh tracker without it), the figure beside it a later pass "
+                   "(its time in warm_ms; not_warmed / *_not_warmed_fps: a fourth fresh tracker without it), the figure beside it the later passes of the long-lived tracker: median of three, spread in *_passes "
                    "(the *_annotated figures return every annotated frame; only the rows an overlay can touch cross the bus, annotated_frames_travel_as; *_outages: four outages of 16 "
                    "frames per window, handled in speculative groups; *_demo1: settings.DEMO_1, mask_noise = True); success_ratio is that of "
                    "the clean streams; 1920x1080 is BASELINE config 5" % (len(next(iter(streams.values()))), nwin, window))
@@ -443,6 +467,80 @@ def cpu_baseline(frames, cal, gpu_records, gpu_mask_of, max_seconds=25.0):
     except Exception:
         pass
     return out, parity
+
+
+def config1_leg(calls=200):
+    """BASELINE config 1: ONE 1280x720 photo (the reference's test_images/test4.jpg, kept losslessly as tests/golden/photo_test4.png)
+    through process() with its defaults.  The reference's hard-coded validity limits reject this frame (tests/test_photos.py:
+    pinned by the reference's own run), so every call is the whole two-try path -- undistort + warp + 'bilateral' filter +
+    sliding windows + fit + check_validity, then the same with the 'neighborhood' filter, then the failure frame -- and leaves the
+    tracker in the state it started in (`last_detection > n_reset`: sliding windows again): median of `calls` calls.  Beside it
+    the oracle's two tries of the same frame on ONE CPU thread (masks + searches + fits + validity; no drawing), and the first
+    frame of a video under the author's Demo 1 limits, which accept the frame (first try valid, lane drawn)."""
+    from PIL import Image
+    from lane_tracker_amd import calib, settings
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    from oracle import oracle as O
+    path = os.path.join(ROOT, "tests", "golden", "photo_test4.png")
+    frame = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"), np.uint8))
+    cal = calib.reference_calibration()
+    out = {"frame": "tests/golden/photo_test4.png (= test_images/test4.jpg decoded; SURVEY 8(d))", "calls": calls}
+    lt = LaneTracker(**cal)
+    try:
+        for _ in range(16):
+            lt.process(frame)
+        ts = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            lt.process(frame)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out["process_defaults"] = {"median_ms": round(ts[len(ts) // 2] * 1e3, 4), "p10_ms": round(ts[len(ts) // 10] * 1e3, 4), "p90_ms": round(ts[len(ts) * 9 // 10] * 1e3, 4),
+                                   "frames_per_s": round(1.0 / ts[len(ts) // 2], 1), "valid": bool(lt.valid_lane_lines), "detected": bool(lt.detected_pixels),
+                                   "what": "two tries per call (both rejected by check_validity, as in the reference's own run of this frame), failure frame returned"}
+    finally:
+        lt.close()
+    lt = LaneTracker(**cal)
+    try:
+        kw = settings.apply(lt, settings.DEMO_1)
+        fresh = lt.get_state()
+        ts = []
+        for k in range(16 + min(calls, 100)):
+            lt.set_state(fresh)              # the first frame of a video, every time (outside the clock)
+            t0 = time.perf_counter()
+            lt.process(frame, **kw)
+            if k >= 16:
+                ts.append(time.perf_counter() - t0)
+        ts.sort()
+        out["process_demo1_first_frame"] = {"median_ms": round(ts[len(ts) // 2] * 1e3, 4), "frames_per_s": round(1.0 / ts[len(ts) // 2], 1),
+                                            "valid": bool(lt.valid_lane_lines),
+                                            "what": "settings.DEMO_1 (tracker_settings.md:1-33: greenery mask, wider validity limits): first try valid, lane drawn"}
+    finally:
+        lt.close()
+    oc = O.make_calib(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0])
+    tries = [(O.filter_params(), O.search_params()),
+             (O.filter_params(filter_type="neighborhood", C_r=5), O.search_params(no_success_limit=50, bandwidth=30))]
+
+    def two_tries(fast):
+        ok = []
+        for fp, sp in tries:
+            r = O.frame_sws_fit(oc, frame, fp, sp, fast=fast)
+            ok.append(bool(r["detected"]) and O.check_validity(cal["warped_size"], r["coeffs"][0], r["coeffs"][1]))
+        return ok
+    two_tries(True)
+    reps = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        verdicts = two_tries(True)
+        reps.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    two_tries(False)
+    loops = time.perf_counter() - t0
+    out["cpu_port_one_thread"] = {"median_ms": round(sorted(reps)[2] * 1e3, 2), "frames_per_s": round(1.0 / sorted(reps)[2], 2), "valid": verdicts,
+                                  "parity_checker_form_ms": round(loops * 1e3, 2), "cores": 1, "kind": "port",
+                                  "what": "oracle/lt_oracle.c: both tries of the same frame (mask + sliding windows + fit) + check_validity, thresholds as "
+                                          "running sums; no drawing.  A stated baseline, never a ratio to quote"}
+    return out
 
 
 def host_fed_overlapped(cal, frames, fp, sp, streams, resident_records, batches=12):
@@ -702,6 +800,9 @@ def main():
                     "traffic_bytes_per_launch": traffic, "traffic_over_algorithmic": round(traffic / float(alg), 2),
                     "fetch_write_calibration": tj.get("calibration"),
                     "traffic_over_compulsory": round(traffic / float(tj["mask_stage_compulsory_bytes_per_launch"]), 2) if tj.get("mask_stage_compulsory_bytes_per_launch") else None,
+                    "lds_pipe": ({"busy_frac": round(float(tj["mask_stage_lds_idx_active_cycles_per_launch"]) / (mask_ms * 1e-3 * 2.4e9 * info.cu_count), 4),
+                                  "what": "SQ_LDS_IDX_ACTIVE cycles of the stage's kernels (summed over the CUs) / (CUs x this run's stage time x 2.4 GHz)"}
+                                 if tj.get("mask_stage_lds_idx_active_cycles_per_launch") else None),
                     "valu_issue": {"achieved": round(lane_ops / (mask_ms * 1e-3) / 1e12, 3), "peak": round(peak / 1e12, 3),
                                    "unit": "T lane-ops/s", "frac": round(lane_ops / (mask_ms * 1e-3) / peak, 4),
                                    "peak_from": "profiles/%s_valu_issue.json: %s wave64 instructions per cycle per SIMD measured for "
@@ -726,7 +827,11 @@ def main():
                        "rank_environment": {distributed.IPC_ENV[0]: os.environ.get(distributed.IPC_ENV[0])} if world > 1 else None,
                        "streams_per_gpu": a.streams, "resident_copies_of_the_batch_in_the_timed_region": 1,
                        "detected_fraction": round(float(np.mean(rec_all["detected"])), 4)},
-            "roofline": {"bound": "hbm", "kernel": "warp+threshold stage (%d kernels: %s)" % (len(MASK_STAGES), ",".join(MASK_STAGES)),
+            "roofline": {"bound": "hbm", "binding_unit": "valu+lds",
+                         "binding_unit_fracs": ({"valu_issue_frac": from_profile["valu_issue"]["frac"],
+                                                 "lds_pipe_busy_frac": (from_profile.get("lds_pipe") or {}).get("busy_frac"),
+                                                 "from": "the counters of profile.from_profile over this run's stage time"} if from_profile else None),
+                         "kernel": "warp+threshold stage (%d kernels: %s)" % (len(MASK_STAGES), ",".join(MASK_STAGES)),
                          "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 6),
@@ -735,8 +840,9 @@ def main():
                          "profile": from_profile,
                          "note": "achieved = algorithmic bytes / hipEvent time of the stage's kernels, measured in this run; "
                                  "`traffic` and `profile` are NOT measured in this run: they are the PMC counters of the committed "
-                                 "rocprofv3 run named in profile.from_profile (null when the launch shape differs). The stage is "
-                                 "integer-VALU / LDS bound, not HBM bound; see DESIGN.md"},
+                                 "rocprofv3 run named in profile.from_profile (null when the launch shape differs). `bound` names the roofline "
+                                 "the METRIC asks for (HBM); what binds the stage is binding_unit: the integer-VALU issue port and the CUs' "
+                                 "LDS pipes together (binding_unit_fracs), see DESIGN.md"},
             "kernels_ms_per_step": {k: round(v[0] / KS, 4) for k, v in stages.items() if v[1]},
             "timing_note": "value / ms_per_step: %d steps over the same resident frames on %d HIP streams per GPU (slot slices overlap: the "
                            "latency-bound search of one slice hides under the mask chain of another)%s. kernels_ms_per_step, roofline and "
@@ -774,6 +880,11 @@ def main():
                 out["host_fed"].update(host_fed_overlapped(cal, frames, fp, sp, a.streams, rec_all))
             except Exception as e:   # the resident number stands on its own
                 out["host_fed"]["overlapped_error"] = repr(e)
+        if single and not a.no_cpu_baseline and not a.no_stream:
+            try:
+                out["config1"] = config1_leg()
+            except Exception as e:
+                out["config1"] = {"error": repr(e)}
         if single and streams is not None:
             try:
                 out["stream"] = stream_leg(streams)

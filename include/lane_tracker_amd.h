@@ -42,8 +42,9 @@ extern "C" {
  *    lt_host_copy_stats, lt_host_touch_async_group; lt_upload_frame_rows_enqueue (an upload nobody waits for),
  *    lt_present_lane_from_fit_async + lt_lane_spans_from_fit (the lane of a frame drawn by the device behind its search),
  *    lt_overlay_run_strip_coeffs (strips from averaged coefficients).  Nothing removed or changed. */
-/* 5: + lt_device_cache_counters (hits / misses / evictions of the device-memory cache since the process started).  Nothing
- *    removed or changed. */
+/* 5: + lt_device_cache_counters (hits / misses / evictions of the device-memory cache since the process started),
+ *    lt_set_walk_min_frames (the batch size from which the threshold stage takes its walking kernels; was an environment
+ *    switch).  Nothing removed or changed. */
 #define LT_ABI_VERSION 5
 
 typedef enum lt_status {
@@ -216,6 +217,12 @@ int  lt_band_fit_chain_collect(lt_ctx* ctx, int first_slot, int n, lt_lane_recor
  * and the others belong to the download stream (used when LT_DL_KERNEL=1 copies annotated frames back with a kernel).  Call it
  * on an idle context (it synchronises); a context that only processes independent batches has no use for it. */
 int  lt_set_search_cus(lt_ctx* ctx, int n);
+/* The bilateral threshold (lane_tracker.py:14-83, :214-215) has two kernels: walks down half rows / columns with running sums
+ * (k_bilateral_walk_hv), which win once a call brings enough frames to fill the chip, and 128 x 128 tiles in LDS
+ * (k_bilateral_tile2) for the few frames of a process() call or a short chunk.  A call of at least `frames` frames (of this
+ * context's bird's-eye size) takes the walks; default: 80 frames' worth of 1100 x 1080 pixels, the crossover measured on MI355X
+ * (64 frames: 232 vs 210 us, 96 frames: 255 vs 304 us).  0: always walk; negative: the default again.  Results never depend on it. */
+int  lt_set_walk_min_frames(lt_ctx* ctx, int frames);
 /* Urgent mode, for the frame of a stateful stream whose first try failed (lane_tracker.py:1071-1128: second parameter set,
  * second search) while masks of later frames are already queued: between lt_set_urgent(ctx, 1) and lt_set_urgent(ctx, 0),
  * lt_mask_run / lt_filter_run / lt_sws_fit_run / lt_band_fit_run run on a stream of their own, behind the work enqueued for

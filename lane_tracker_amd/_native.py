@@ -135,6 +135,7 @@ _SIGNATURES = {
     "lt_band_fit_chain_collect": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_band_fit_chain_cancel": (C.c_int, [_P]),
     "lt_set_search_cus": (C.c_int, [_P, C.c_int]),
+    "lt_set_walk_min_frames": (C.c_int, [_P, C.c_int]),
     "lt_set_urgent": (C.c_int, [_P, C.c_int]),
     "lt_poly_points": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
     "lt_download_overlay_wait": (C.c_int, [_P]),
@@ -851,6 +852,10 @@ class Context:
     def set_search_cus(self, n):
         """Reserve n CUs for the chained search (the compute streams are recreated without them); 0 undoes it."""
         _check(self.lib.lt_set_search_cus(self._h, int(n)))
+
+    def set_walk_min_frames(self, frames):
+        """Calls of at least `frames` frames take the walking threshold kernels (0: always; negative: the default, 80)."""
+        _check(self.lib.lt_set_walk_min_frames(self._h, int(frames)))
 
     def urgent(self):
         """Context manager: the stage calls inside run on the context's urgent stream (lt_set_urgent) -- behind the work of their

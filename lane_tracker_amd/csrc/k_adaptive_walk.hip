@@ -204,12 +204,12 @@ __global__ __launch_bounds__(64) void k_adaptive_box_walk(BoxArgs a) {
     }
 }
 
-int g_bands_override = [] { const char* e = std::getenv("LT_BOX_BANDS"); return e ? std::atoi(e) : 0; }();
+int g_bands_override = [] { const char* e = LT_EXP_ENV("LT_BOX_BANDS"); return e ? std::atoi(e) : 0; }();
 
 }  // namespace
 
 bool adaptive_walk_supported(int bs_r, int bs_b, int h, int w, size_t plane_stride) {
-    static const bool off = [] { const char* e = std::getenv("LT_ADAPTIVE_TILES"); return e && e[0] == '1'; }();
+    static const bool off = [] { const char* e = LT_EXP_ENV("LT_ADAPTIVE_TILES"); return e && e[0] == '1'; }();
     if (off) return false;
     auto ok = [](int bs) { return (bs & 1) && bs >= 1 && bs <= 2 * HALO - 1; };
     return ok(bs_r) && ok(bs_b) && (w & 3) == 0 && w >= 4 && h >= 1 && (plane_stride & 3) == 0;
@@ -277,7 +277,7 @@ bool launch_adaptive_walk(hipStream_t s, const uint8_t* R, int bs_r, int C_r, un
     // One launch per plane, each with the ring its own window needs (a 15-pixel window: 5 KB per wave instead of the 10 KB a
     // 35-pixel window beside it imposes): 0.336 against 0.352 ms per 256 frames for one launch over both (LT_BOX_SPLIT=0).  A
     // few dozen frames cannot fill the chip either way and take the single launch (one tail instead of two: 59 against 66 us at 32).
-    static const bool split = [] { const char* e = std::getenv("LT_BOX_SPLIT"); return !(e && e[0] == '0'); }();
+    static const bool split = [] { const char* e = LT_EXP_ENV("LT_BOX_SPLIT"); return !(e && e[0] == '0'); }();
     if (split && n >= 64) return launch_box(s, pl, 1, h, w, plane_stride, bits_stride, n) && launch_box(s, pl + 1, 1, h, w, plane_stride, bits_stride, n);
     return launch_box(s, pl, 2, h, w, plane_stride, bits_stride, n);
 }

@@ -120,13 +120,7 @@ __global__ __launch_bounds__(256) void k_undistort_rows(const uint8_t* __restric
             out |= ((v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11 + 512u) >> 10) << (8 * ch);
         }
         const int slot = first_slot + z;   // wave-uniform: pair and parity go into the scalar offset of the store
-#ifdef LT_PROBE_UND_NO_STORE     // timing probe (WRONG results): table read, taps and blend as shipped, the result kept in a register -- what
-        // staging undistorted pixels into LDS instead of HBM would still cost (tools/front_probe.sh)
-        asm volatile("" :: "v"(out));
-        if (out == 0x12345678u && fx == 77) __builtin_amdgcn_raw_buffer_store_b32(out, urs, (int)o * 8, 0, 0);
-#else
         __builtin_amdgcn_raw_buffer_store_b32(out, urs, (int)o * 8, __builtin_amdgcn_readfirstlane(((slot >> 1) - pair0) * pair_b + (slot & 1) * 4), 0);
-#endif
         q0 = n0;
         q1 = n1;
     }
@@ -301,22 +295,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LT_WARP_WAV
         u32x4 tapA[8], tapB[8];   // [0..3] top row, [4..7] bottom row of the four pixels; A / B alternate between pairs
         auto fetch = [&](u32x4 (&t)[8], int p) __attribute__((always_inline)) {
             const int po = (min(p, pb - 1) - pa) * pair_b;
-#ifdef LT_PROBE_WARP_NO_TAPS    // timing probe (WRONG results): the taps made up in registers -- what the blend, the Lab tables and the stores cost
-            // without a single tap load: the floor of a warp that takes its taps from LDS (tools/front_probe.sh)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                u32x4 v;
-                v.x = (uint32_t)(toff[i & 3] + po) * 2654435761u; v.y = v.x ^ 0x9e3779b9u; v.z = v.x >> 3; v.w = v.y >> 5;
-                asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-                t[i] = v;
-            }
-#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 t[i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i], po, 0);
                 t[4 + i] = __builtin_amdgcn_raw_buffer_load_b128(urs, toff[i] + row_b, po, 0);
             }
-#endif
         };
         auto blend_pair = [&](const u32x4 (&t)[8], int p) __attribute__((always_inline)) {
 #pragma unroll
@@ -482,12 +465,12 @@ __global__ __launch_bounds__(256) void k_undistorted_to_rgb(const uint32_t* __re
 // arithmetic and one memory round trip are paid once per walk) while the launch still has a few groups of
 // frames, so that small batches keep their parallelism.
 static int xcd_remap() {
-    static const int v = [] { const char* e = std::getenv("LT_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
+    static const int v = [] { const char* e = LT_EXP_ENV("LT_XCD_REMAP"); return e ? std::atoi(e) : 1; }();
     return v;
 }
 
 static int frames_per_thread(int n) {
-    static const int cap = [] { const char* e = std::getenv("LT_FRONTEND_FPB"); int v = e ? std::atoi(e) : 16; return v < 1 ? 1 : v; }();
+    static const int cap = [] { const char* e = LT_EXP_ENV("LT_FRONTEND_FPB"); int v = e ? std::atoi(e) : 16; return v < 1 ? 1 : v; }();
     int fpb = n / 8;
     return fpb < 1 ? 1 : (fpb > cap ? cap : fpb);
 }
@@ -497,7 +480,7 @@ void launch_undistort_rows(hipStream_t s, const uint8_t* frames, size_t frame_st
     if (n <= 0 || g.nrows <= 0) return;
     const int fpb = frames_per_thread(n);
     dim3 grid((g.img_w + 255) / 256, g.nrows, (n + fpb - 1) / fpb);
-    static const bool unaligned = [] { const char* e = std::getenv("LT_UNDISTORT_UNALIGNED"); return e && e[0] == '1'; }();   // A/B
+    static const bool unaligned = [] { const char* e = LT_EXP_ENV("LT_UNDISTORT_UNALIGNED"); return e && e[0] == '1'; }();   // A/B
     if (!unaligned && ((uintptr_t)frames & 3) == 0 && (frame_stride & 3) == 0 && (size_t)fpb * frame_stride < (1u << 30))
         hipLaunchKernelGGL(k_undistort_rows<true>, grid, dim3(256), 0, s, frames, frame_stride, uxy, ufrac, g, und, und_px, first_slot, n, fpb, xcd_remap());
     else

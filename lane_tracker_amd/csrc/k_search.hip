@@ -1391,7 +1391,7 @@ void launch_fit_list(hipStream_t s, const uint32_t* pix, int n, int h, int w, do
 }
 
 namespace {
-bool env_flag(const char* name) { const char* e = std::getenv(name); return e && e[0] == '1'; }
+#define env_flag(name) ([] { const char* e = LT_EXP_ENV(name); return e && e[0] == '1'; }())      // (a macro: in the release build the name never reaches the binary)
 
 template <class K>
 bool allow_big_lds(K kernel) {
@@ -1518,8 +1518,8 @@ void launch_band_chain(hipStream_t s, const uint8_t* masks, size_t mask_stride, 
     static const bool big3 = allow_big_lds(k_band_chain3);
     if (mb.bits && !v2 && big3 && g.h <= 8192) {
 #ifdef LT_CHAIN_PROBES
-        static const int prio = [] { const char* e = std::getenv("LT_CHAIN_PRIO"); return e ? std::atoi(e) : 3; }();
-        static const int ablate = [] { const char* e = std::getenv("LT_CHAIN_ABLATE"); return e ? std::atoi(e) : 0; }();
+        static const int prio = [] { const char* e = LT_EXP_ENV("LT_CHAIN_PRIO"); return e ? std::atoi(e) : 3; }();
+        static const int ablate = [] { const char* e = LT_EXP_ENV("LT_CHAIN_ABLATE"); return e ? std::atoi(e) : 0; }();
 #else
         constexpr int prio = 3, ablate = 0;
 #endif

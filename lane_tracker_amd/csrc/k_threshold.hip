@@ -803,7 +803,7 @@ int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
                           unsigned long long* bits_v) {
     if (n <= 0 || h <= 0 || w <= 0) return 0;
     if (bits_v && use_noise) return -1;      // the split form has no greenery mask
-    static const bool unpacked = [] { const char* e = std::getenv("LT_BILATERAL_UNPACKED"); return e && e[0] == '1'; }();
+    static const bool unpacked = [] { const char* e = LT_EXP_ENV("LT_BILATERAL_UNPACKED"); return e && e[0] == '1'; }();
     const int kmax = std::max(k_r, std::max(k_b, use_noise ? k_n : 0));
     const int cmax = std::max(std::abs(C_r), std::max(std::abs(C_b), use_noise ? std::abs(C_n) : 0));
     // packed 16-bit arithmetic is exact while every |S - (k*p - C*k)| < 2^15
@@ -828,7 +828,7 @@ int launch_bilateral_bits(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_bilateral_tile2),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return -1;
-            static const bool report = [] { const char* e = std::getenv("LT_REPORT_OCCUPANCY"); return e && e[0] == '1'; }();
+            static const bool report = [] { const char* e = LT_EXP_ENV("LT_REPORT_OCCUPANCY"); return e && e[0] == '1'; }();
             if (report) {
                 int nb = 0;
                 (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k_bilateral_tile2), 256, lds);
@@ -902,10 +902,10 @@ bool launch_merge_open5(hipStream_t s, unsigned long long* p0, const unsigned lo
     const int wpr = (w + 63) / 64;
     if ((n0 || n1) && !(n0 && n1 && p1 && p2 && p3)) return false;
     if ((p2 != nullptr) != (p3 != nullptr) || (p2 && !p1)) return false;
-    static const bool off = [] { const char* e = std::getenv("LT_OPEN5_SEPARATE"); return e && e[0] == '1'; }();   // A/B
+    static const bool off = [] { const char* e = LT_EXP_ENV("LT_OPEN5_SEPARATE"); return e && e[0] == '1'; }();   // A/B
     if (off || n <= 0 || h <= 0 || wpr > 64 || opened == p0) return false;
     const int G = 64 / wpr;
-    static const int rows_env = [] { const char* e = std::getenv("LT_OPEN5_BAND_ROWS"); return e ? std::atoi(e) : 0; }();
+    static const int rows_env = [] { const char* e = LT_EXP_ENV("LT_OPEN5_BAND_ROWS"); return e ? std::atoi(e) : 0; }();
     // enough bands to give every SIMD a few waves, none shorter than 24 rows (8 halo rows per band are recomputed)
     const int groups = (n + G - 1) / G;
     int nbands = std::max(1, std::min(h / 24, (4096 + groups - 1) / groups));
@@ -926,7 +926,7 @@ bool launch_or_open5_small(hipStream_t s, unsigned long long* p0, const unsigned
     const int wpr = (w + 63) / 64;
     if ((n0 || n1) && !(n0 && n1 && p1 && p2 && p3)) return false;
     if ((p2 != nullptr) != (p3 != nullptr) || (p2 && !p1)) return false;
-    static const bool off = [] { const char* e = std::getenv("LT_OPEN_SMALL"); return e && e[0] == '0'; }();   // A/B
+    static const bool off = [] { const char* e = LT_EXP_ENV("LT_OPEN_SMALL"); return e && e[0] == '0'; }();   // A/B
     if (off || n <= 0 || h <= 0 || wpr > 64 || opened == p0) return false;
     const dim3 grid((h + OS_RB - 1) / OS_RB, n);
     if (n0) hipLaunchKernelGGL(k_or_open5_small<6>, grid, dim3(256), 0, s, p0, p1, p2, p3, n0, n1, opened, h, w, wpr, bits_stride);

@@ -213,12 +213,7 @@ __device__ __forceinline__ void walk_v_task(const WalkArgs& a, int blk) {
     unsigned long long pva = 0, pvb = 0;              // pass masks of the previous row
     auto store_rows = [&](int row0) {                 // lanes 0..15 hold rows row0 .. row0 + 15
         const int row = row0 + lane;
-#ifdef LT_PROBE_WALK_NO_VSTORE   // timing probe (WRONG results): the vertical tasks' verdict words are formed but never stored -- what the two partial
-        // planes of the vertical pass cost the walks (tools/walk_probe.sh)
-        if (lane < 16 && row >= y0 && row < y1 && a.wpr < 0) {
-#else
         if (lane < 16 && row >= y0 && row < y1) {
-#endif
             unsigned long long* o = out + (size_t)row * a.wpr + wordv;
             o[0] = (unsigned long long)m0 | ((unsigned long long)m1 << 32);
             if (wordv + 1 < a.wpr) o[1] = (unsigned long long)m2 | ((unsigned long long)m3 << 32);
@@ -536,12 +531,12 @@ void launch_walk_both(hipStream_t s, const uint8_t* src, int C, unsigned long lo
                       int pitch, size_t plane_stride, size_t bits_stride, int n, int passes) {
     // `passes` (bit 0 horizontal, bit 1 vertical) is a measurement / debugging switch, LT_WALK_PASSES; default both
     const size_t bytes = ((size_t)(n - 1) * bits_stride + (size_t)h * ((w + 63) / 64)) * 8;
-    static const bool split = [] { const char* e = std::getenv("LT_WALK_SPLIT"); return e && e[0] == '1'; }();   // A/B: one launch per pass
+    static const bool split = [] { const char* e = LT_EXP_ENV("LT_WALK_SPLIT"); return e && e[0] == '1'; }();   // A/B: one launch per pass
     if ((passes & 3) == 3 && !split) {
         const WalkArgs ah = walk_args<false>(src, C, out_h, h, w, pitch, plane_stride, bits_stride, n);
         const WalkArgs av = walk_args<true>(src, C, out_v, h, w, pitch, plane_stride, bits_stride, n);
         const int lds = std::max(WalkCfgH<K>::LDS, WalkCfg<K>::V_LDS);
-        static const int xcd = [] { const char* e = std::getenv("LT_WALK_XCD"); return e && e[0] == '0' ? 0 : 1; }();   // A/B
+        static const int xcd = [] { const char* e = LT_EXP_ENV("LT_WALK_XCD"); return e && e[0] == '0' ? 0 : 1; }();   // A/B
         hipLaunchKernelGGL((k_bilateral_walk_hv<K>), dim3(ah.ntasks + av.ntasks), dim3(64), lds, s, ah, av, xcd);
         return;
     }
@@ -560,7 +555,7 @@ void launch_walk_noise(hipStream_t s, const uint8_t* src, int C, int noise_thres
     const WalkArgs av = walk_args<true>(src, C, out_v, h, w, pitch, plane_stride, bits_stride, n);
     ah.rbias = (uint32_t)(0x8000 - std::min(std::max(noise_thresh, 0), 256)) * 0x10001u;
     const int lds = std::max(WalkCfgH<K_NOISE>::LDS, WalkCfg<K_NOISE>::V_LDS);
-    static const int xcd = [] { const char* e = std::getenv("LT_WALK_XCD"); return e && e[0] == '0' ? 0 : 1; }();   // A/B
+    static const int xcd = [] { const char* e = LT_EXP_ENV("LT_WALK_XCD"); return e && e[0] == '0' ? 0 : 1; }();   // A/B
     hipLaunchKernelGGL((k_bilateral_walk_hv<K_NOISE, true>), dim3(ah.ntasks + av.ntasks), dim3(64), lds, s, ah, av, xcd);
 }
 
@@ -578,7 +573,7 @@ void dispatch_walk(int k, hipStream_t s, const uint8_t* src, int C, unsigned lon
 }  // namespace
 
 bool bilateral_walk_supported(int k_r, int C_r, int k_b, int C_b, int h, int w, int pitch) {
-    static const bool off = [] { const char* e = std::getenv("LT_BILATERAL_TILES"); return e && e[0] == '1'; }();
+    static const bool off = [] { const char* e = LT_EXP_ENV("LT_BILATERAL_TILES"); return e && e[0] == '1'; }();
     if (off || !walk_supports(k_r) || !walk_supports(k_b) || C_r < 0 || C_b < 0) return false;
     if ((w & 3) || (pitch & 63) || pitch < w || w < 8 || h < 1) return false;
     return (long long)k_r * (255 + C_r) < 32768 && (long long)k_b * (255 + C_b) < 32768;
@@ -591,7 +586,7 @@ int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
                           unsigned long long* merged, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
                           int h, int w, int pitch, size_t plane_stride, size_t bits_stride, int n, bool merge) {
     if (n <= 0 || !bilateral_walk_supported(k_r, C_r, k_b, C_b, h, w, pitch) || (plane_stride & 63)) return -1;
-    static const int passes = [] { const char* e = std::getenv("LT_WALK_PASSES"); return e ? std::atoi(e) : 15; }();
+    static const int passes = [] { const char* e = LT_EXP_ENV("LT_WALK_PASSES"); return e ? std::atoi(e) : 15; }();
     dispatch_walk(k_r, s, thr, C_r, merged, s1, h, w, pitch, plane_stride, bits_stride, n, passes & 3);
     dispatch_walk(k_b, s, thb, C_b, s2, s3, h, w, pitch, plane_stride, bits_stride, n, (passes >> 2) & 3);
     if (merge) launch_or4_bits(s, merged, s1, s2, s3, h, w, bits_stride, n);
@@ -599,7 +594,7 @@ int launch_bilateral_walk(hipStream_t s, const uint8_t* thr, int k_r, int C_r, c
 }
 
 bool noise_walk_supported(int k_n, int C_n, int h, int w, int pitch) {
-    static const bool off = [] { const char* e = std::getenv("LT_BILATERAL_TILES"); return e && e[0] == '1'; }();
+    static const bool off = [] { const char* e = LT_EXP_ENV("LT_BILATERAL_TILES"); return e && e[0] == '1'; }();
     if (off || k_n != K_NOISE || C_n < 0 || (long long)k_n * (255 + C_n) >= 32768) return false;
     return !((w & 3) || (pitch & 63) || pitch < w || w < 8 || h < 1);
 }

@@ -371,9 +371,6 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
     auto pair = [](unsigned long long v) { return make_uint2((uint32_t)v, (uint32_t)(v >> 32)); };
     // One chain step with three taps: DST[p] = op(SRC[p - D], SRC[p], SRC[p + D]) for p = pa, pb; entry p of
     // plane q lives (q * PLANE + MARGIN + p) * 8 bytes from the wave's chain base.
-#ifdef LT_PROBE_NO_CHAIN       // timing probe (WRONG results): no chain steps through the LDS -- what their round trips cost a step
-#define LT_STEP3(SRC, DST, D) {}
-#else
 #define LT_STEP3(SRC, DST, D)                                                                                        \
     {                                                                                                                \
         unsigned long long a0, a1, a2, b0, b1, b2;                                                                   \
@@ -390,7 +387,6 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
         (S0 + (DST) * PLANE)[pb] = op3v<DIL>(pair(b0), pair(b1), pair(b2));                                          \
         wave_lds_fence();                                                                                            \
     }
-#endif
     {
         // First chain step without LDS: the neighbours of entry p = lane (and p = lane + 64) sit in the adjacent
         // lanes' registers, one whole-wave DPP shift away; lane 63's right neighbour is entry 64 (lane 0's second
@@ -438,16 +434,7 @@ __device__ __forceinline__ void row_windows2(uint2* s, int lane, uint2 e_pa, uin
             for_each_const([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 if constexpr (fused_stage_of_update<SE>(j) == decltype(stage)::value) {
-#ifdef LT_PROBE_SKIP_CENTRE   // timing probe (WRONG results): the ten centre-row updates of 55x55 (half-width 27 on both rows) become moves --
-                    // an upper bound for what pre-reducing those rows with a sliding minimum could save (lead ii)
-                    if constexpr (j >= 22 && j <= 31) An[j] = A[j + 2];
-                    else
-#endif
-#ifdef LT_PROBE_NO_ACCUM      // timing probe (WRONG results): the vertical pipeline only shifts -- what the window updates cost a step (tools/tophat_probe.sh)
-                    An[j] = A[j + 2] | (Ha[SE::slot(j + 1)] & 1u);
-#else
                     An[j] = op3<DIL>(A[j + 2], Ha[SE::slot(j + 1)], Hb[SE::slot(j)]);
-#endif
                     asm volatile("" : "+v"(An[j]));   // pins the update into its stage: the optimiser would sink it below every read
                 }
             }, std::make_integer_sequence<int, K - 2>{});
@@ -900,14 +887,12 @@ __global__ __launch_bounds__(64 * LT_MORPH_WPB) LT_MORPH_WAVES_ATTR void k_morph
 // Borders are clamped as in k_morph_runs2; the argument there needs only that an SE row above the image is narrower than the
 // one that lands on row 0, which does not depend on who accumulates which rows.
 template <class SE, bool DIL, bool TH, int Q>
-__global__ __launch_bounds__(64 * Q) void k_morph_one(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
-                                                      const uint8_t* __restrict__ minuend, RunsGeom g) {
+__device__ __forceinline__ void morph_one_task(const int task, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                               const uint8_t* __restrict__ minuend, const RunsGeom& g, uint2 (*s_chain)[4 * PLANE],
+                                               uint32_t (*s_ring)[3 * 2 * Q][64]) {
     constexpr int K = SE::K, R = SE::R, NH = SE::NH, S = 2 * Q, RING = 3 * S;
     static_assert(S - 1 <= K - 1, "the pipeline must be longer than a step");
-    __shared__ uint2 s_chain[Q][4 * PLANE];   // S0, S1, S4, S13 per wave
-    __shared__ uint32_t s_ring[Q][RING][64];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int task = blockIdx.x;
     if (!LT_MORPH_BIAS) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 3);   // f16 denormals kept (see k_morph_runs2)
     const int strip = task % g.nstrips;
     const int band = (task / g.nstrips) % g.nbands;
@@ -1027,12 +1012,50 @@ __global__ __launch_bounds__(64 * Q) void k_morph_one(const uint8_t* __restrict_
     }
 }
 
+template <class SE, bool DIL, bool TH, int Q>
+__global__ __launch_bounds__(64 * Q) void k_morph_one(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      const uint8_t* __restrict__ minuend, RunsGeom g) {
+    __shared__ uint2 s_chain[Q][4 * PLANE];   // S0, S1, S4, S13 per wave
+    __shared__ uint32_t s_ring[Q][3 * 2 * Q][64];
+    morph_one_task<SE, DIL, TH, Q>((int)blockIdx.x, src, dst, minuend, g, s_chain, s_ring);
+}
+
+// The same step of BOTH top-hats of a frame in ONE launch (process(): the 55x55 erode of the Lab-b plane and the 29x29 erode of the
+// R plane; then the two top-hats): the planes do not depend on each other, one frame's tasks of either fill a fraction of the
+// chip, and as two launches on two streams they cost a fork, a join (11-12 us of signalling on the frame's critical path:
+// profiles/r05_process_timeline.txt) and two more launches.  The 55x55 tasks -- the longer walks -- come first in the grid.
+template <bool DIL, bool TH, int Q>
+__global__ __launch_bounds__(64 * Q) void k_morph_one_pair(const uint8_t* __restrict__ src55, uint8_t* __restrict__ dst55, const uint8_t* __restrict__ min55, RunsGeom g55,
+                                                           const uint8_t* __restrict__ src29, uint8_t* __restrict__ dst29, const uint8_t* __restrict__ min29, RunsGeom g29) {
+    __shared__ uint2 s_chain[Q][4 * PLANE];
+    __shared__ uint32_t s_ring[Q][3 * 2 * Q][64];
+    const int task = (int)blockIdx.x;      // (workgroup-uniform: the branch below costs nothing)
+    if (task < g55.ntasks) morph_one_task<SE55, DIL, TH, Q>(task, src55, dst55, min55, g55, s_chain, s_ring);
+    else morph_one_task<SE29, DIL, TH, Q>(task - g55.ntasks, src29, dst29, min29, g29, s_chain, s_ring);
+}
+
 template <class SE, int Q>
 void launch_one(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, bool dilate, const RunsGeom& g) {
     const dim3 grid(g.ntasks), block(64 * Q);
     if (dilate && minuend) hipLaunchKernelGGL((k_morph_one<SE, true, true, Q>), grid, block, 0, s, src, dst, minuend, g);
     else if (dilate) hipLaunchKernelGGL((k_morph_one<SE, true, false, Q>), grid, block, 0, s, src, dst, minuend, g);
     else hipLaunchKernelGGL((k_morph_one<SE, false, false, Q>), grid, block, 0, s, src, dst, minuend, g);
+}
+
+// Bands of a one- or two-frame launch of k_morph_one: about `want_wgs` workgroups (default: two per CU), none shorter than 8 rows
+static void one_frame_bands(RunsGeom& g, int n, int want_wgs) {
+    int cus1 = 256, dev1 = 0;
+    (void)hipGetDevice(&dev1);
+    (void)hipDeviceGetAttribute(&cus1, hipDeviceAttributeMultiprocessorCount, dev1);
+    const int target = want_wgs > 0 ? want_wgs : 2 * cus1;
+    int nb = std::max(1, target / std::max(1, n * g.nstrips));
+    int rows = std::max((g.h + nb - 1) / nb, 8);
+    rows = (rows + 1) & ~1;
+    g.band_rows = rows;
+    g.nbands = (g.h + rows - 1) / rows;
+    g.nstrips_normal = g.nstrips;
+    g.ntasks = g.n_normal = n * g.nstrips * g.nbands;
+    g.xcd = 0;
 }
 
 template <class SE>
@@ -1055,27 +1078,16 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.dst_stride = dpitch > 0 ? dst_stride : plane_stride;
     g.nstrips = (w + 127) / 128;
     g.nframes = n;
-    static const bool one_row = [] { const char* e = std::getenv("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
-    static const bool narrow = [] { const char* e = std::getenv("LT_MORPH_WIDE"); return e && e[0] == '0'; }();
+    static const bool one_row = [] { const char* e = LT_EXP_ENV("LT_MORPH_ONE_ROW"); return e && e[0] == '1'; }();
+    static const bool narrow = [] { const char* e = LT_EXP_ENV("LT_MORPH_WIDE"); return e && e[0] == '0'; }();
     const bool wide = !narrow && (w & 3) == 0 && (plane_stride & 3) == 0 && w >= 4 && (g.dpitch & 3) == 0 && (g.dst_stride & 3) == 0 &&
                       ((uintptr_t)dst & 3) == 0 && ((uintptr_t)minuend & 3) == 0;
     // One or two frames: the walk of a task split over the waves of a workgroup (k_morph_one).  LT_MORPH_ONE=0: k_morph_runs2 as
     // for any other frame count (A/B, tests); =8: eight waves per task.  LT_MORPH_ONE_WGS: workgroups per launch to aim for.
-    static const int one_q = [] { const char* e = std::getenv("LT_MORPH_ONE"); return e ? std::atoi(e) : 4; }();
+    static const int one_q = [] { const char* e = LT_EXP_ENV("LT_MORPH_ONE"); return e ? std::atoi(e) : 4; }();
     if (n <= 2 && (one_q == 4 || one_q == 8) && !one_row && wide && !copy_dst && ((uintptr_t)src & 3) == 0) {
-        static const int want_wgs = [] { const char* e = std::getenv("LT_MORPH_ONE_WGS"); return e ? std::atoi(e) : 0; }();
-        int cus1 = 256, dev1 = 0;
-        (void)hipGetDevice(&dev1);
-        (void)hipDeviceGetAttribute(&cus1, hipDeviceAttributeMultiprocessorCount, dev1);
-        const int target = want_wgs > 0 ? want_wgs : 2 * cus1;
-        int nb = std::max(1, target / std::max(1, n * g.nstrips));
-        int rows = std::max((h + nb - 1) / nb, 8);
-        rows = (rows + 1) & ~1;
-        g.band_rows = rows;
-        g.nbands = (h + rows - 1) / rows;
-        g.nstrips_normal = g.nstrips;
-        g.ntasks = g.n_normal = n * g.nstrips * g.nbands;
-        g.xcd = 0;
+        static const int want_wgs = [] { const char* e = LT_EXP_ENV("LT_MORPH_ONE_WGS"); return e ? std::atoi(e) : 0; }();
+        one_frame_bands(g, n, want_wgs);
         if (one_q == 8) launch_one<SE, 8>(s, src, dst, minuend, dilate, g);
         else launch_one<SE, 4>(s, src, dst, minuend, dilate, g);
         return true;
@@ -1122,16 +1134,18 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     // there, too, few long walks beat a grid sized to fill the chip on its own (tools/nb_value_sweep.sh: 3 bands
     // 66.8 k frames/s, 4 bands 66.5 k, the model's 5-6 bands 65.5 k).
     else if ((long long)n * g.nstrips * 3 >= slots / 4 && h / 3 >= 2 * SE::R) best_nb = 3;
+#ifdef LT_EXPERIMENTS
     {   // measurement override: LT_MORPH_NB_<k><E|D>=<bands>, e.g. LT_MORPH_NB_55D=5
         char name[32];
         std::snprintf(name, sizeof name, "LT_MORPH_NB_%d%c", SE::K, dilate ? 'D' : 'E');
         const char* e = std::getenv(name);
         if (e && std::atoi(e) > 0) best_nb = std::atoi(e);
     }
+#endif
     g.band_rows = (h + best_nb - 1) / best_nb;
     g.nbands = (h + g.band_rows - 1) / g.band_rows;
     // the last strip as a PAIR strip (two frames per wave) when it is at most 64 columns wide
-    static const bool no_pair = [] { const char* e = std::getenv("LT_MORPH_PAIR"); return e && e[0] == '0'; }();   // A/B
+    static const bool no_pair = [] { const char* e = LT_EXP_ENV("LT_MORPH_PAIR"); return e && e[0] == '0'; }();   // A/B
     const bool pair_strip = wide && !one_row && !no_pair && w - 128 * (g.nstrips - 1) <= 64 &&
                             (long long)plane_stride + (long long)h * w < (1ll << 31) && (long long)g.dst_stride + (long long)h * g.dpitch < (1ll << 31);
     g.nstrips_normal = pair_strip ? g.nstrips - 1 : g.nstrips;
@@ -1139,7 +1153,7 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
     g.ntasks = g.n_normal + (pair_strip ? (n + 1) / 2 * g.nbands : 0);
     // measured (tools/ab_fetch.sh LT_MORPH_XCD): the renumbering makes all four launches 1-5 % SLOWER (0.295 -> 0.311 ms
     // erode 29x29, 0.493 -> 0.508 ms erode 55x55 per 256 frames), so it is off unless asked for
-    static const bool want_xcd = [] { const char* e = std::getenv("LT_MORPH_XCD"); return e && e[0] == '1'; }();
+    static const bool want_xcd = [] { const char* e = LT_EXP_ENV("LT_MORPH_XCD"); return e && e[0] == '1'; }();
     g.xcd = want_xcd ? 1 : 0;
     dim3 grid((g.ntasks + 3) / 4);
     const dim3 grid2((g.ntasks + LT_MORPH_WPB - 1) / LT_MORPH_WPB), block2(64 * LT_MORPH_WPB);
@@ -1148,7 +1162,7 @@ bool launch_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t*
         if (dilate) hipLaunchKernelGGL((k_morph_runs<SE, true>), grid, dim3(256), 0, s, src, dst, minuend, g);
         else hipLaunchKernelGGL((k_morph_runs<SE, false>), grid, dim3(256), 0, s, src, dst, minuend, g);
     } else {
-        static const int extra_lds = [] { const char* e = std::getenv("LT_MORPH_EXTRA_LDS"); return e ? std::atoi(e) : 0; }();   // occupancy experiments
+        static const int extra_lds = [] { const char* e = LT_EXP_ENV("LT_MORPH_EXTRA_LDS"); return e ? std::atoi(e) : 0; }();   // occupancy experiments
         const bool th = dilate && minuend != nullptr;
         if (copy_dst) {   // the minuend copy exists for the 55x55 WIDE top-hat only (the Lab-b plane)
             if constexpr (SE::K == 55) {
@@ -1186,6 +1200,34 @@ bool launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const ui
     if (k == 55)
         return launch_runs<SE55>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride, copy_dst);
     return launch_runs<SE29>(s, src, dst, minuend, h, w, dilate, plane_stride, n, dpitch, dst_stride, copy_dst);
+}
+
+// One or two frames: the same step (erode, or dilate / top-hat) of the 55x55 chain of one plane and of the 29x29 chain of another
+// in ONE launch (k_morph_one_pair).  false: not launched (a geometry k_morph_one does not take) -- the caller launches them one by one.
+bool launch_morph_one_pair(hipStream_t s, const uint8_t* src55, uint8_t* dst55, const uint8_t* min55, const uint8_t* src29, uint8_t* dst29,
+                           const uint8_t* min29, int h, int w, bool dilate, size_t plane_stride, int n, int dpitch, size_t dst_stride) {
+    if (n <= 0 || n > 2 || h <= 0 || w < 4) return false;
+    RunsGeom g;
+    g.copy_dst = nullptr;
+    g.h = h;
+    g.w = w;
+    g.plane_stride = plane_stride;
+    g.dpitch = dpitch > 0 ? dpitch : w;
+    g.dst_stride = dpitch > 0 ? dst_stride : plane_stride;
+    g.nstrips = (w + 127) / 128;
+    g.nframes = n;
+    auto aligned = [](const void* q) { return ((uintptr_t)q & 3) == 0; };
+    if ((w & 3) || (plane_stride & 3) || (g.dpitch & 3) || (g.dst_stride & 3) || !aligned(src55) || !aligned(dst55) || !aligned(min55) ||
+        !aligned(src29) || !aligned(dst29) || !aligned(min29) || (dilate && (min55 == nullptr) != (min29 == nullptr)))
+        return false;
+    RunsGeom g55 = g, g29 = g;
+    one_frame_bands(g55, n, 0);
+    one_frame_bands(g29, n, 0);
+    const dim3 grid(g55.ntasks + g29.ntasks), block(256);
+    if (dilate && min55) hipLaunchKernelGGL((k_morph_one_pair<true, true, 4>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);
+    else if (dilate) hipLaunchKernelGGL((k_morph_one_pair<true, false, 4>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);
+    else hipLaunchKernelGGL((k_morph_one_pair<false, false, 4>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);
+    return true;
 }
 
 // Code objects load on the first launch of one of their kernels (a few ms each, once per process and device): lt_create launches

@@ -394,59 +394,34 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
     unsigned long long* ebits = c->d_bits_eroded + (size_t)first * c->bits_stride;
     unsigned long long* tbits = c->d_bits_tmp ? c->d_bits_tmp + (size_t)first * c->bits_stride : nullptr;
     unsigned long long* ubits = c->d_bits_tmp2 ? c->d_bits_tmp2 + (size_t)first * c->bits_stride : nullptr;
-    bool r_verdicts_done = false;                 // the R plane's threshold ran beside the Lab-b top-hats, into ebits
-    // ... with the H and the V phases of a tile in workgroups of their own (one frame: 81 tiles on 256 CUs), their verdicts in
-    // partial planes of their own: R -> ebits, ubits; Lab-b -> mbits, tbits (LT_THRESHOLD_PHASES=0: one workgroup per tile)
-    static const bool phases_ok = [] { const char* e = std::getenv("LT_THRESHOLD_PHASES"); return !(e && e[0] == '0'); }();
-    bool phase_split = false, both_split = false;
+    // One or two frames (process()): both planes' thresholds in ONE launch with the H and the V phases of a tile in workgroups of
+    // their own (one frame: 81 tiles on 256 CUs) -- H verdicts of both planes into mbits, V verdicts into ebits; the open ORs them
+    bool both_split = false;
     if (p->filter_type == 0) {
-        if (c->brute_tophat) {   // debugging aid (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
+        if (c->brute_tophat) {   // debugging aid of the experiments build (LT_TOPHAT_BRUTE=1): direct footprint evaluation, still on the GPU
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_ellipse(s, R, t0, nullptr, h, w, c->se29, false, ps, n); }
             { StageScope t(c, ST_TOPHAT_R, s); launch_morph_ellipse(s, t0, thR, R, h, w, c->se29, true, ps, n); }
             { StageScope t(c, ST_ERODE_B, s);  launch_morph_ellipse(s, B, t0, nullptr, h, w, c->se55, false, ps, n); }
             { StageScope t(c, ST_TOPHAT_B, s); launch_morph_ellipse(s, t0, thB, B, h, w, c->se55, true, ps, n); }
-        } else if (n <= 2 && !c->stage_timing && c->side && s == c->stream) {
-            // One or two frames cannot fill the chip (a few hundred waves per top-hat kernel), so the two planes'
-            // top-hats, which do not depend on each other, run side by side: the R plane on the side stream, the
-            // Lab-b plane here; saves the shorter pair's ~40 us of a 160 us chain.  t3 is free until the merge.
-            // (the eroded R plane of these one or two frames: a scratch of its own, two planes per context)
+        } else if (n <= 2 && !c->stage_timing && !walk) {
+            // One or two frames cannot fill the chip (a few hundred waves per top-hat kernel), and the two planes' top-hats do not
+            // depend on each other: the 55x55 erode of the Lab-b plane and the 29x29 erode of the R plane are ONE launch, the two
+            // top-hats the next (k_morph_one_pair).  (Round 5 ran the R plane's chain on a side stream: a fork, a join that cost the
+            // frame 11-12 us of signalling, and three more launches.)  The eroded R plane has a scratch of its own, two planes per context.
             if (!c->d_side_scratch) { const int rc = dev_alloc(&c->d_side_scratch, 2 * ps); if (rc) return rc; }
             uint8_t* ts = c->d_side_scratch;
-            HIP_TRY(hipEventRecord(c->ev_fork, s));
-            // The Lab-b pair is the longer of the two chains: its first kernel is launched before anything of the side stream
-            // (the host needs 4-5 us per launch, and in launch order "side stream first" the 55x55 erode started 12-16 us after
-            // the warp had ended: tools/process_timeline.sh).  LT_SIDE_FIRST=1: the former order (A/B).
-            static const bool side_first = [] { const char* e = std::getenv("LT_SIDE_FIRST"); return e && e[0] == '1'; }();
-            if (!side_first) launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
-            HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-            launch_morph_runs(c->side, R, ts, nullptr, h, w, 29, false, ps, n);
-            if (!side_first) { const int rc = tophat_b(s); if (rc) return rc; }
-            launch_morph_runs(c->side, ts, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes);
-            // ... and so does the R plane's threshold: its 29x29 top-hat is done while the 55x55 pair still has half its way
-            // to go, and the threshold kernel takes its planes one after the other anyway -- here one per launch, the R
-            // verdicts as a partial bit plane the open ORs in (12 us less on the one-frame chain)
-            static const bool split_ok = [] { const char* e = std::getenv("LT_THRESHOLD_SPLIT"); return !(e && e[0] == '0'); }();
-            // LT_R_THRESHOLD_MAIN=1 (experiment): the R plane's threshold not on the side stream but with the Lab-b plane's in one
-            // launch behind the join (H phases of both planes into mbits, V phases into ebits)
-            static const bool r_on_main = [] { const char* e = std::getenv("LT_R_THRESHOLD_MAIN"); return e && e[0] == '1'; }();
-            both_split = r_on_main && phases_ok && !walk && !p->mask_noise;
-            if (split_ok && !walk && !p->mask_noise && !both_split) {
-                phase_split = phases_ok && tbits && ubits;
-                r_verdicts_done = launch_bilateral_bits(c->side, thR, p->ksize_r, p->C_r, nullptr, 1, 0, B, p->ksize_noise, p->C_noise,
-                                                        p->noise_thresh, 0, ebits, h, w, ps, c->bits_stride, n, phase_split ? ubits : nullptr) == 0;
-                if (!r_verdicts_done && phase_split) {       // (packed arithmetic does not fit these parameters: one workgroup per tile)
-                    phase_split = false;
-                    r_verdicts_done = launch_bilateral_bits(c->side, thR, p->ksize_r, p->C_r, nullptr, 1, 0, B, p->ksize_noise, p->C_noise,
-                                                            p->noise_thresh, 0, ebits, h, w, ps, c->bits_stride, n) == 0;
+            if (launch_morph_one_pair(s, B, t0, nullptr, R, ts, nullptr, h, w, false, ps, n, 0, 0)) {
+                if (!launch_morph_one_pair(s, t0, thB, B, ts, thR, R, h, w, true, ps, n, 0, 0)) {
+                    launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n);
+                    launch_morph_runs(s, ts, thR, R, h, w, 29, true, ps, n);
                 }
-            }
-            HIP_TRY(hipEventRecord(c->ev_join, c->side));
-            if (side_first) {
+            } else {             // (a geometry the one-frame kernel does not take: an image width that is not a multiple of four)
+                launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n);
+                launch_morph_runs(s, t0, thR, R, h, w, 29, true, ps, n);
                 launch_morph_runs(s, B, t0, nullptr, h, w, 55, false, ps, n);
-                const int rc = tophat_b(s);
-                if (rc) return rc;
+                launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n);
             }
-            HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+            both_split = !p->mask_noise;
         } else {
             { StageScope t(c, ST_ERODE_R, s);  launch_morph_runs(s, R, t0, nullptr, h, w, 29, false, ps, n); }
             { StageScope t(c, ST_TOPHAT_R, s); launch_morph_runs(s, t0, thRd, R, h, w, 29, true, ps, n, dpitch, c->th_pad_bytes); }
@@ -472,13 +447,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
                     return fail(LT_ERR_STATE, "the greenery-mask walk refused parameters its own predicate accepted");
             }
         }
-        if (!merged_done && r_verdicts_done) {   // the Lab-b plane alone; should that launch be refused, both planes below
-            merged_done = launch_bilateral_bits(s, nullptr, 1, 0, thB, p->ksize_b, p->C_b, B, p->ksize_noise, p->C_noise,
-                                                p->noise_thresh, 0, mbits, h, w, ps, c->bits_stride, n, phase_split ? tbits : nullptr) == 0;
-            partials = merged_done;
-            two_partials = merged_done && !phase_split;
-        }
-        if (!merged_done && both_split) {
+        if (!merged_done && both_split) {        // (refused when the packed arithmetic does not fit the parameters: one workgroup per tile below)
             merged_done = launch_bilateral_bits(s, thR, p->ksize_r, p->C_r, thB, p->ksize_b, p->C_b, B, p->ksize_noise, p->C_noise,
                                                 p->noise_thresh, 0, mbits, h, w, ps, c->bits_stride, n, ebits) == 0;
             partials = two_partials = merged_done;
@@ -520,10 +489,7 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
       unsigned long long* obits = c->d_bits_open + (size_t)first * c->bits_stride;
       bool opened = false;
       // one pass over the words; a handful of frames is latency-bound and better off with the wide, shallow kernels
-      // (also with partial planes to OR first: one frame's chain, wall time from the first launch to the record, 134.4 us through
-      // k_merge_open5 against 129.9 through k_or4_bits + the two shallow kernels; LT_OPEN_SHALLOW=0 restores the former)
-      static const bool deep_small = [] { const char* e = std::getenv("LT_OPEN_SHALLOW"); return e && e[0] == '0'; }();
-      if (!u8_mask && (n >= 16 || (partials && deep_small)))
+      if (!u8_mask && n >= 16)
           opened = launch_merge_open5(s, mbits, partials ? ebits : nullptr, two_partials ? nullptr : tbits, two_partials ? nullptr : ubits, obits,
                                       h, w, c->bits_stride, n, nbits1, nbits2);
       // a few frames: the OR and the open in one launch of small workgroups (the one-frame chain is made of launch gaps: three
@@ -602,7 +568,7 @@ static hipError_t make_compute_stream(hipStream_t* st, int reserved) {
         for (int i = 0; i < reserved && i < 256; ++i) mask[i >> 5] &= ~(1u << (i & 31));
         return hipExtStreamCreateWithCUMask(st, 8, mask);
     }
-    const char* e = getenv("LT_STREAM_PRIORITY");
+    const char* e = LT_EXP_ENV("LT_STREAM_PRIORITY");
     int least = 0, greatest = 0;
     if ((e && strcmp(e, "normal") == 0) || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest)
         return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
@@ -707,7 +673,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
         lt_destroy(c);
         return rc;
     };
-    if (const char* e = getenv("LT_WALK_MIN_FRAMES")) c->walk_min_pixels = atoll(e) * calib->warp_w * calib->warp_h;
+    if (const char* e = LT_EXP_ENV("LT_WALK_MIN_FRAMES")) c->walk_min_pixels = atoll(e) * calib->warp_w * calib->warp_h;   // (experiments build; the API: lt_set_walk_min_frames)
     if (hipSetDevice(device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipSetDevice(%d) failed", device));
     if (hipGetDeviceProperties(&c->prop, device) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipGetDeviceProperties failed"));
     if (create_compute_stream(&c->stream) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipStreamCreate failed"));
@@ -754,7 +720,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     if (!tophat_tables_match(c->se29, c->se55))
         return bail(fail(LT_ERR_STATE, "compiled-in ellipse run tables disagree with getStructuringElement's formula"));
     {
-        const char* e = std::getenv("LT_TOPHAT_BRUTE");
+        const char* e = LT_EXP_ENV("LT_TOPHAT_BRUTE");
         c->brute_tophat = e && e[0] == '1';
     }
 
@@ -1026,7 +992,7 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
     // these slots there) and, like lt_upload_frame_rows_async's, behind the kernels of OTHER streams that still read the slots'
     // camera rows -- overlays on the presentation stream (slot-range events).  LT_UPLOAD_SYNC=1: wait for the whole context first, as
     // lt_upload_frame_rows does (A/B; 5-10 us of a process() frame, on its critical path).
-    static const bool enqueue_syncs = [] { const char* e = std::getenv("LT_UPLOAD_SYNC"); return e && e[0] == '1'; }();
+    static const bool enqueue_syncs = [] { const char* e = LT_EXP_ENV("LT_UPLOAD_SYNC"); return e && e[0] == '1'; }();
     if ((!enqueue || enqueue_syncs) && (rc = sync_all(c))) return rc;
     mark_frames(c, first, n, 0);         // a new frame's rows: the others are the previous occupant's until lt_upload_frame_rest
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
@@ -1370,7 +1336,7 @@ int lt_download_records(lt_ctx* c, int first, int n, lt_lane_record* out) {
         // The search kernel stores its ticket behind the record: poll for it (hipStreamSynchronize returns 15-20 us after the
         // kernel's last store, the word is there within 2: tools/microbench/sync_latency.hip).  LT_RECORD_POLL=0: wait for the
         // stream (A/B); after 2 ms without the ticket likewise (an error would show there).
-        static const bool poll = [] { const char* e = std::getenv("LT_RECORD_POLL"); return !(e && e[0] == '0'); }();
+        static const bool poll = [] { const char* e = LT_EXP_ENV("LT_RECORD_POLL"); return !(e && e[0] == '0'); }();
         bool seen = false;
         if (poll && c->rec_ticket) {
             const volatile unsigned* word = reinterpret_cast<const volatile unsigned*>(c->h_rec + 1);
@@ -1632,7 +1598,7 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
         StageScope t(c, ST_BAND_FIT, st);
         const MaskBits mb{use_bits ? c->d_bits_open + (size_t)f0 * c->bits_stride : nullptr, c->bits_stride, wpr};
         // one frame (process()): the chain kernel with a chain of one, a third of the latency (LT_BAND_ONE=0: k_band_fit2)
-        const char* one_env = n == 1 ? std::getenv("LT_BAND_ONE") : nullptr;
+        const char* one_env = n == 1 ? LT_EXP_ENV("LT_BAND_ONE") : nullptr;
         lt_lane_record* mirror = n == 1 ? rec_mirror_device(c) : nullptr;
         unsigned ticket = ++c->rec_ticket_counter;
         if (!ticket) ticket = ++c->rec_ticket_counter;      // 0 means "no ticket"
@@ -1663,6 +1629,12 @@ int lt_set_urgent(lt_ctx* c, int on) {
     if (on && !c->urgent && create_compute_stream(&c->urgent, c->search_cus) != hipSuccess) return fail(LT_ERR_HIP, "hipStreamCreate failed");
     if (!on && c->urgent_on && c->urgent) HIP_TRY(hipStreamSynchronize(c->urgent));   // leaving: nothing of it is left in flight unseen
     c->urgent_on = on != 0;
+    return LT_OK;
+}
+
+int lt_set_walk_min_frames(lt_ctx* c, int frames) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    c->walk_min_pixels = frames < 0 ? 80LL * 1100 * 1080 : (long long)frames * c->calib.warp_w * c->calib.warp_h;
     return LT_OK;
 }
 

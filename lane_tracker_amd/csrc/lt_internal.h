@@ -7,7 +7,20 @@
 
 #include <vector>
 
+#include <cstdlib>
+
 #include "../../include/lane_tracker_amd.h"
+
+// Measurement switches -- alternative kernels and launch shapes for A/B runs, each held bit-exact by the parity suite -- exist in
+// the EXPERIMENTS build only (`make EXPERIMENTS=1` -> liblane_tracker_amd_exp.so, -DLT_EXPERIMENTS; tools/* and
+// tests/test_gpu_parity.py::test_alternative_kernel_paths_keep_parity load that one).  In the release library LT_EXP_ENV(...) is a
+// null pointer constant: the path behind a switch is dead code the compiler drops, and the switch's name does not reach the
+// binary (tests/test_native_abi.py counts the LT_* strings of the release .so against INTEGRATION.md section E).
+#ifdef LT_EXPERIMENTS
+#define LT_EXP_ENV(name) std::getenv(name)
+#else
+#define LT_EXP_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 
 namespace lt {
 
@@ -100,6 +113,9 @@ void launch_morph_ellipse(hipStream_t s, const uint8_t* src, uint8_t* dst, const
 // when that form is not available for the geometry (nothing was launched)
 bool launch_morph_runs(hipStream_t s, const uint8_t* src, uint8_t* dst, const uint8_t* minuend, int h, int w, int k,
                        bool dilate, size_t plane_stride, int n, int dpitch = 0, size_t dst_stride = 0, uint8_t* copy_dst = nullptr);
+// one or two frames: the same step of the 55x55 chain of one plane and of the 29x29 chain of another in one launch; false: not launched
+bool launch_morph_one_pair(hipStream_t s, const uint8_t* src55, uint8_t* dst55, const uint8_t* min55, const uint8_t* src29, uint8_t* dst29,
+                           const uint8_t* min29, int h, int w, bool dilate, size_t plane_stride, int n, int dpitch, size_t dst_stride);
 bool tophat_tables_match(const EllipseSE& se29, const EllipseSE& se55);
 void launch_bilateral(hipStream_t s, const uint8_t* src, uint8_t* dst, int h, int w, int ksize, int C, int mode,
                       int tv, int fv, size_t plane_stride, int n);

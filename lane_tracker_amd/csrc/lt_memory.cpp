@@ -348,7 +348,7 @@ __attribute__((target("avx2"))) static void copy_stream_avx2(uint8_t* dst, const
 }
 static void copy_bytes(uint8_t* dst, const uint8_t* src, size_t n) {
     static const bool nt = [] {
-        const char* e = std::getenv("LT_COPY_NT");
+        const char* e = LT_EXP_ENV("LT_COPY_NT");
         return e && e[0] == '1' && __builtin_cpu_supports("avx2");
     }();
     if (nt && n >= (64u << 10)) copy_stream_avx2(dst, src, n);
@@ -737,7 +737,7 @@ void text_blend_frame(uint8_t* frame, int img_h, int img_w, const uint8_t* atlas
             const uint8_t* cell = atlas + (size_t)g * gh * gw;
             const int ncol = std::min(adv, gw);
             // the vector form where whole steps of 16 pixels stay inside the row and inside the atlas (LT_TEXT_SCALAR=1: never; A/B, tests)
-            static const bool vec_ok = [] { const char* e = std::getenv("LT_TEXT_SCALAR"); return !(e && e[0] == '1') && __builtin_cpu_supports("avx2"); }();
+            static const bool vec_ok = [] { const char* e = LT_EXP_ENV("LT_TEXT_SCALAR"); return !(e && e[0] == '1') && __builtin_cpu_supports("avx2"); }();
             const int span = (ncol + 15) & ~15;
             const bool vec = vec_ok && ncol > 0 && xk >= 0 && xk + span <= img_w &&
                              (size_t)g * gh * gw + (size_t)(gh - 1) * gw + span <= (size_t)n_glyphs * gh * gw;

@@ -292,7 +292,7 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
         if ((rc = ensure_strips(c))) return rc;
     } else if (!c->d_annot && (rc = dev_alloc(&c->d_annot, (size_t)c->capacity * c->frame_bytes))) return rc;
     // One frame (process()): the intervals travel as a kernel argument -- no staging buffer, no copy launch, no events
-    static const bool arg_ok = [] { const char* e = std::getenv("LT_SPANS_ARG"); return !(e && e[0] == '0'); }();
+    static const bool arg_ok = [] { const char* e = LT_EXP_ENV("LT_SPANS_ARG"); return !(e && e[0] == '0'); }();
     bool one = arg_ok && !strip && !ci && n == 1 && bh <= LT_SPAN_ARG_ROWS && (c->calib.img_w & 3) == 0;
     if (ci && (rc = ensure_ploty(c, ci->ploty, ci->ploty2, ci->n_rows))) return rc;
     int16_t one_spans[2 * LT_SPAN_ARG_ROWS];
@@ -304,7 +304,7 @@ static int overlay_run_impl(lt_ctx* c, int first, int n, const int32_t* left_n, 
     };
     if (!one && (rc = claim_staging())) return rc;
     int16_t* hs = one ? one_spans : c->h_spans + (size_t)first * bh * 2;
-    static const bool timing = std::getenv("LT_OVERLAY_TIMING") != nullptr;
+    static const bool timing = LT_EXP_ENV("LT_OVERLAY_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     // ~18 us of edge walking per polygon: a window's piece of 32 .. 128 polygons is shared among a few threads (the caller is
     // the one thread that feeds the device)
@@ -581,7 +581,7 @@ int lt_overlay_text(lt_ctx* c, int first, int n, const char* lines, int n_lines,
     const uint8_t* kl = dl;
     const int16_t* kx = dx;
     void *pl = nullptr, *px = nullptr;
-    static const bool direct_ok = [] { const char* e = std::getenv("LT_TEXT_DIRECT"); return !(e && e[0] == '0'); }();
+    static const bool direct_ok = [] { const char* e = LT_EXP_ENV("LT_TEXT_DIRECT"); return !(e && e[0] == '0'); }();
     if (direct_ok && n <= 2 && hipHostGetDevicePointer(&pl, hl, 0) == hipSuccess && hipHostGetDevicePointer(&px, hx, 0) == hipSuccess &&
         pl && px) {
         kl = static_cast<const uint8_t*>(pl);
@@ -615,7 +615,7 @@ int lt_download_overlay(lt_ctx* c, int first, int n, uint8_t* out) {
     // and once more for a copy it issues only then (10 us of process()'s 0.4 ms per frame).
     if ((rc = set_device(c))) return rc;
     // a frame or two: by a copy kernel (no engine start-up: 11 us less per frame of process()); LT_DL1_KERNEL=0: the engine
-    static const bool by_kernel = [] { const char* e = std::getenv("LT_DL1_KERNEL"); return !(e && e[0] == '0'); }();
+    static const bool by_kernel = [] { const char* e = LT_EXP_ENV("LT_DL1_KERNEL"); return !(e && e[0] == '0'); }();
     if (!(by_kernel && n <= 2 && launch_copy_to_pinned(c->present, out, src, bytes)))
         HIP_TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->present));
     HIP_TRY(hipGetLastError());
@@ -695,7 +695,7 @@ int lt_present_lane_async(lt_ctx* c, int slot, const int32_t* left_n, const int3
     // The lane's rows straight into `out`: when the first run is empty (the text is the host's business, lt_text_blend_host) the
     // overlay kernel stores what it draws into the page-locked frame itself -- one launch instead of two, the rows cross the bus as
     // they are drawn (-13 us per frame of process(); LT_OVERLAY_DIRECT=0: draw into the context's buffer, then the copy kernel).
-    static const bool direct_ok = [] { const char* e = std::getenv("LT_OVERLAY_DIRECT"); return !(e && e[0] == '0'); }();
+    static const bool direct_ok = [] { const char* e = LT_EXP_ENV("LT_OVERLAY_DIRECT"); return !(e && e[0] == '0'); }();
     void* dev = nullptr;
     bool direct = false;
     if (direct_ok && r[1] <= r[0] && ((uintptr_t)out & 15) == 0 && hipHostGetDevicePointer(&dev, out, 0) == hipSuccess && dev) {
@@ -867,7 +867,7 @@ static int download_overlay_async_impl(lt_ctx* c, int first, int n, uint8_t* out
     HIP_TRY(hipEventRecord(e, c->present ? c->present : c->stream));
     HIP_TRY(hipStreamWaitEvent(c->dl, e, 0));
     // engine or kernel: by measurement (choose_download); LT_DL_KERNEL=1 / 0 and lt_set_download_method pin one of them
-    static const int env_method = [] { const char* e = std::getenv("LT_DL_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
+    static const int env_method = [] { const char* e = LT_EXP_ENV("LT_DL_KERNEL"); return !e ? -1 : (e[0] == '0' ? 0 : 1); }();
     if (env_method >= 0 && c->dl_forced < 0) c->dl_forced = env_method;
     harvest_downloads(c);
     int method = choose_download(c);

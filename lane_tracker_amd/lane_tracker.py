@@ -612,7 +612,10 @@ class LaneTracker(StreamPipeline):
             self._rows4 = (rows, rows.ctypes.data, [int(v) for v in rows], ahead, host) if covered <= 0.8 * H else None
         return self._rows4
 
-    host_text = os.environ.get("LT_HOST_TEXT", "1") != "0"   # False: the text lines are drawn by the device (lt_overlay_text), as in round 4 (A/B, tests)
+    # Alternatives kept for A/B runs and tests are plain class attributes (set them on the class or an instance; no environment
+    # switches): host_text, host_copies_rows, enqueues_upload, draws_lane_on_device, speculates_lane; stream_lane_on_device,
+    # strip_piece (stream.py).  None changes results.
+    host_text = True            # False: the text lines are drawn by the device (lt_overlay_text), as in round 4
 
     _TEXT_ORIGIN, _TEXT_STEP = (20, 8), 35          # Context.present_frame / overlay_text defaults
 
@@ -693,7 +696,7 @@ class LaneTracker(StreamPipeline):
 
     _resident_partial = False   # of the resident frame only the rows process() reads and presents are on the device
 
-    host_copies_rows = os.environ.get("LT_HOST_ROWS", "1") != "0"   # False: the whole annotated frame comes back from the device (A/B, tests)
+    host_copies_rows = True     # False: the whole annotated frame comes back from the device
 
     def _present(self, slot, left_n, right_n, left_yx, right_yx, lines, line_len=40, drawn=False):
         """Polygon (packed, by address) and text lines onto the frame in `slot` -> the annotated frame.  drawn: _lane_ahead has
@@ -858,9 +861,9 @@ class LaneTracker(StreamPipeline):
             L, R = L[1:], R[1:]
         return _mean_of_rows([c for c in L if c.size != 0]), _mean_of_rows([c for c in R if c.size != 0])
 
-    enqueues_upload = os.environ.get("LT_UPLOAD_ENQUEUE", "1") != "0"   # False: lt_upload_frame_rows waits for its copy (A/B, tests)
+    enqueues_upload = True      # False: lt_upload_frame_rows waits for its copy
     _rows_keepalive = None
-    draws_lane_on_device = os.environ.get("LT_LANE_DEVICE", "1") != "0"   # False: the host launches the overlay once it has the record (A/B, tests)
+    draws_lane_on_device = True   # False: the host launches the overlay once it has the record
     _device_lane = None         # the device draws this frame's lane behind its search (lt_present_lane_from_fit_async was enqueued)
     _fit_flags = 0
 
@@ -891,7 +894,7 @@ class LaneTracker(StreamPipeline):
                                                    self._out, self._out_rows)
         return (len(Lv) + 1,) if ok else None
 
-    speculates_lane = os.environ.get("LT_LANE_AHEAD", "1") != "0"   # False: the lane is drawn once the frame is known to be valid (A/B, tests)
+    speculates_lane = True      # False: the lane is drawn once the frame is known to be valid
     _lane_in_flight = None      # the packed-point buffers whose polygon lt_present_lane_async is drawing / has drawn for this frame
 
     def _lane_ahead(self, left_fit_coeffs, right_fit_coeffs, partial, slot):

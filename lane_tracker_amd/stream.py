@@ -131,11 +131,11 @@ class StreamPipeline:
         return True
 
     _coeff_strips = True         # lt_overlay_run_strip_coeffs exists for this context (cleared on its first refusal)
-    stream_lane_on_device = os.environ.get("LT_STREAM_LANE_DEVICE", "1") != "0"   # False: plot points and polygon intervals of a window's frames on the host (A/B, tests)
+    stream_lane_on_device = True     # False: plot points and polygon intervals of a window's frames on the host (A/B, tests)
 
     # ---- the chained stream pipeline (reference :851-872, :1064-1128, :1178-1199) ------------
     search_cus = 1                   # CUs kept free of the mask chain for the chained search (lt_set_search_cus); 0: shared; >= 2: the
-                                     # others belong to the kernel that copies annotated frames back when LT_DL_KERNEL=1 asks for it
+                                     # others belong to the kernel that copies annotated frames back when lt_set_download_method asks for it
     chain_searches = True            # False: process_batch searches frame by frame (one record round trip per frame)
     chain_chunk = None               # frames per upload + mask launch, and per chain, inside a window; None: by window size --
                                      # 32 for a stand-alone window (its head and tail count), half a window up to 128 in a
@@ -575,7 +575,7 @@ class StreamPipeline:
         return frames
 
     _window_rows = None         # _present_rows() while an annotated window / stream sends its frames back as row runs
-    strip_piece = int(os.environ.get("LT_STRIP_PIECE", "32"))   # frames per overlay launch + strip download of a committed run
+    strip_piece = 32            # frames per overlay launch + strip download of a committed run
     _annotate_inplace = False   # annotate="inplace": annotated frames are the caller's own arrays, drawn over (strips only)
 
     def _window_renderer(self, deferred, base, n, piece=32, frames=None):
@@ -587,7 +587,7 @@ class StreamPipeline:
         device (lt_overlay_run_strip) and comes back, packed, through the library's page-locked staging blocks
         (lt_strip_download_async); the rows above and below it are copied from `frames`, the window as the caller handed it in,
         by the library's copy threads, which also draw the text lines (lt_host_text_async_group).  One completion group per window.
-        Row runs (`_window_rows` without strips: LT_HOST_TEXT=0) and whole frames (LT_HOST_ROWS=0): round 4's ways, `out` page-locked.
+        Row runs (`_window_rows` without strips: `host_text = False`) and whole frames (`host_copies_rows = False`): round 4's ways, `out` page-locked.
         In place (`annotate="inplace"`, strips only): `out` IS `frames` -- the strips land in the caller's own window and the text is
         drawn over it; no row is copied on the host (0.9 instead of 2.8 MB per 1280x720 frame through the copy threads)."""
         self._configure_overlay()

@@ -18,12 +18,12 @@ def _coeffs(rec):
     return np.concatenate([rec["left_coeffs"], rec["right_coeffs"]])
 
 
-@pytest.mark.parametrize("streams,band_one", [(1, "0"), (3, "0"), (1, "1")])
-def test_chain_records_and_pixels_equal_frame_by_frame_band_search(streams, band_one, monkeypatch):
-    """band_one "0": the frame-by-frame side runs k_band_fit2 (the batch kernel, which a one-frame band search used up to round
-    3); "1" (the default): a one-frame band search is itself a chain of one (launch_band_fit_one)."""
+@pytest.mark.parametrize("streams,batch_kernel", [(1, True), (3, True), (1, False)])
+def test_chain_records_and_pixels_equal_frame_by_frame_band_search(streams, batch_kernel):
+    """batch_kernel: the frame-by-frame side runs k_band_fit2 (the kernel of lt_band_fit_run for two and more frames: frame i is
+    searched together with frame i + 1, whose result under the wrong seed is overwritten by the next step); otherwise one frame
+    per call, which is itself a chain of one (launch_band_fit_one)."""
     from lane_tracker_amd import _native, calib, synth
-    monkeypatch.setenv("LT_BAND_ONE", band_one)
     cal = calib.reference_calibration()
     n = 24
     frames = synth.stream_lanes(n, seed=21)
@@ -38,7 +38,10 @@ def test_chain_records_and_pixels_equal_frame_by_frame_band_search(streams, band
         # frame by frame: each band search seeded by the previous frame's record through the host
         for i in range(1, n):
             prev = _coeffs(a.download_records(1, first=i - 1)[0])
-            a.band_fit_run(1, prev[None, :], sp, first=i)
+            if batch_kernel and i + 1 < n:
+                a.band_fit_run(2, np.stack([prev, prev]), sp, first=i)
+            else:
+                a.band_fit_run(1, prev[None, :], sp, first=i)
         want = a.download_records(n)
         assert want["detected"].all() and (want["mode"][1:] == 1).all()
         # chained: one launch, seeded by the record of slot 0
@@ -254,9 +257,8 @@ def test_chain_fuzz_short():
 
 @pytest.mark.parametrize("annotate,sizes,every,n_average,band_one",
                          [(False, (24, 24, 10, 40, 24, 1, 24), 9, 2, "1"), (True, (24, 24, 10, 40, 24, 1, 24), 9, 2, "1"),
-                          (True, (70, 0, 50, 31), 40, 3, "1"), (True, (64, 64), 1000, 1, "1"),
-                          (False, (24, 24, 10, 40, 24, 1, 24), 9, 2, "0")])     # "0": process() searches with k_band_fit2
-def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_average, band_one, monkeypatch):
+                          (True, (70, 0, 50, 31), 40, 3, "1"), (True, (64, 64), 1000, 1, "1")])
+def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_average, band_one):
     """Windows of one video through process_stream (the next window's uploads and masks run while the current one's searches
     drain; windows resident side by side) -- state after every window and the annotated frames equal process();
     a longer window in the middle forces the context to grow; process() inside an active stream is refused.  The long
@@ -264,7 +266,6 @@ def test_process_stream_equals_process_frame_by_frame(annotate, sizes, every, n_
     window in between; an annotated window is handed out while the next one's first searches are already in flight."""
     from lane_tracker_amd import calib
     from lane_tracker_amd.lane_tracker import LaneTracker
-    monkeypatch.setenv("LT_BAND_ONE", band_one)
     cal = calib.reference_calibration()
     frames = _stream_with_failures(sum(sizes), every, seed=37)
     wins, lo = [], 0

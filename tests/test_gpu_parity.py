@@ -82,10 +82,19 @@ def test_mask_chain_bit_exact(ctx, nat, oracle, ref_calib, frames, kw):
     n = frames.shape[0]
     ctx.upload_frames(frames)
     ctx.mask_run(n, nat.filter_params(**kw))
-    if os.environ.get("LT_WALK_MIN_FRAMES") == "0" and os.environ.get("LT_BILATERAL_TILES") != "1" and \
-            kw.get("filter_type", "bilateral") == "bilateral" and kw.get("ksize_r", 15) in (15, 20, 35):
-        assert ctx.last_threshold_path() == 1      # the greenery mask included (test_alternative_kernel_paths_keep_parity)
     masks = ctx.download_masks(n)
+    # ... and the same call through the kernels a batch of >= 80 frames takes (lt_set_walk_min_frames): the walking thresholds
+    # (windows 15 / 20 / 35, the greenery mask included), the running box sums of 'neighborhood'
+    ctx.set_walk_min_frames(0)
+    try:
+        ctx.mask_run(n, nat.filter_params(**kw))
+        if os.environ.get("LT_BILATERAL_TILES") != "1" and kw.get("filter_type", "bilateral") == "bilateral" and \
+                kw.get("ksize_r", 15) in (15, 20, 35) and kw.get("ksize_b", 35) in (15, 20, 35):
+            assert ctx.last_threshold_path() == 1
+        walked = ctx.download_masks(n)
+    finally:
+        ctx.set_walk_min_frames(-1)
+    assert np.array_equal(walked, masks), "the batch-size kernels and the few-frame kernels disagree"
     thr, thb = ctx.download_plane(2, n), ctx.download_plane(3, n)
     merged = ctx.download_plane(4, n)
     for k in range(n):
@@ -599,27 +608,30 @@ def test_randomised_differential_run():
     assert "0 mismatches" in r.stdout
 
 
+EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lane_tracker_amd", "liblane_tracker_amd_exp.so")
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["LT_MORPH_WIDE=0", "LT_XCD_REMAP=0", "LT_STREAM_PRIORITY=normal", "LT_MORPH_ONE_ROW=1",
-                                    "LT_SEARCH_U8=1", "LT_SWS_V1=1", "LT_BAND_V1=1", "LT_WALK_MIN_FRAMES=0", "LT_BILATERAL_TILES=1",
-                                    "LT_MORPH_PAIR=0", "LT_UNDISTORT_UNALIGNED=1", "LT_WALK_MIN_FRAMES=0,LT_WALK_SPLIT=1",
-                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN5_SEPARATE=1", "LT_WALK_MIN_FRAMES=0,LT_MORPH_WIDE=0",
-                                    "LT_WALK_MIN_FRAMES=0,LT_MORPH_ONE_ROW=1", "LT_THRESHOLD_SPLIT=0", "LT_OPEN_SHALLOW=0",
-                                    "LT_WALK_MIN_FRAMES=0,LT_OPEN_SHALLOW=0", "LT_MORPH_ONE=0", "LT_MORPH_ONE=8", "LT_MORPH_ONE_WGS=64",
-                                    "LT_MORPH_ONE=8,LT_MORPH_ONE_WGS=2000", "LT_OPEN_SMALL=0", "LT_SIDE_FIRST=1", "LT_THRESHOLD_PHASES=0",
-                                    "LT_THRESHOLD_PHASES=0,LT_OPEN_SMALL=0,LT_MORPH_ONE=0", "LT_R_THRESHOLD_MAIN=1"])
-def test_alternative_kernel_paths_keep_parity(switch):
-    """Every measurement switch of DESIGN.md selects a path that stays bit-exact: the mask-chain, top-hat operator and
-    search parity tests again in a process started with the switch set (the library reads them once)."""
+@pytest.mark.parametrize("switch", ["LT_SEARCH_U8=1", "LT_SWS_V1=1,LT_BAND_V1=1", "LT_MORPH_ONE_ROW=1,LT_MORPH_WIDE=0", "LT_BILATERAL_TILES=1",
+                                    "LT_UNDISTORT_UNALIGNED=1", "LT_OPEN5_SEPARATE=1,LT_OPEN_SMALL=0"])
+def test_fallback_kernel_paths_keep_parity_at_the_reference_geometry(switch):
+    """The release library has one path per stage plus FALLBACKS it takes by itself for what the main kernels do not cover: u8
+    masks handed in by the caller, search windows beyond the bit-plane kernels' limits, image widths that are not a multiple of
+    four / strips that are not aligned, a few frames per call, rows wider than 4096 px.  The tests of those geometries reach them
+    in the release build (kernel limits, odd sizes, small calls); here the EXPERIMENTS build (`make EXPERIMENTS=1`,
+    liblane_tracker_amd_exp.so: the same sources with the measurement switches alive) forces each of them at the reference
+    geometry, through the mask-chain, operator and search parity tests of this file, in a process of its own."""
     import subprocess
     import sys
-    env = dict(os.environ)
+    if not os.path.exists(EXP_LIB):
+        subprocess.check_call(["make", "-C", os.path.join(os.path.dirname(EXP_LIB), "csrc"), "-s", "-j8", "EXPERIMENTS=1"])
+    env = dict(os.environ, LANE_TRACKER_AMD_LIB=EXP_LIB)
     for item in switch.split(","):
         name, value = item.split("=")
         env[name] = value
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        "-k", "mask_chain_bit_exact or one_and_two_frame or morph_ellipse_operators or one_frame_morphology or sliding_window_search_vs_reference or "
-                              "band_search_vs_reference or multi_stream or front_end_bit_exact or odd_slot_ranges"],
+                        "-k", "mask_chain_bit_exact or one_and_two_frame or morph_ellipse_operators or sliding_window_search_vs_reference or "
+                              "band_search_vs_reference or front_end_bit_exact or odd_slot_ranges"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 

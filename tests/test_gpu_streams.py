@@ -162,13 +162,18 @@ def test_overlay_pieces_with_targeted_wait_equal_one_blocking_download(nat, cal,
 
 
 def test_kernel_download_path_gives_the_same_frames():
-    """LT_DL_KERNEL=1 (annotated frames copied back by a kernel on the CUs set aside for it, instead of the copy engine): the
-    pieces test above and an annotated stream against process(), in a process of their own (the switch is read once)."""
+    """Annotated frames copied back by a kernel on the CUs set aside for it, instead of the copy engine -- what the measured choice
+    (lt_set_download_method, next test) takes when the engine is the slower way -- forced for every copy of a process: the
+    pieces test above and an annotated stream against process().  Forcing it process-wide is a measurement switch
+    (LT_DL_KERNEL=1), so this runs on the experiments build in a process of its own."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LT_DL_KERNEL="1", LT_TEST_SEARCH_CUS="3")
+    exp = os.path.join(root, "lane_tracker_amd", "liblane_tracker_amd_exp.so")
+    if not os.path.exists(exp):
+        subprocess.check_call(["make", "-C", os.path.join(root, "lane_tracker_amd", "csrc"), "-s", "-j8", "EXPERIMENTS=1"])
+    env = dict(os.environ, LT_DL_KERNEL="1", LT_TEST_SEARCH_CUS="3", LANE_TRACKER_AMD_LIB=exp)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
                         "tests/test_gpu_streams.py::test_overlay_pieces_with_targeted_wait_equal_one_blocking_download",
                         "tests/test_gpu_chain.py::test_process_stream_equals_process_frame_by_frame"],

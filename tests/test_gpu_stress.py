@@ -55,13 +55,13 @@ def test_mask_chain_100_times_in_one_process(monkeypatch):
     """The default mask chain (top-hats, walking thresholds with their inline-assembly lane writes, open) on the same four
     frames 100 times, interleaved with a second parameter set that takes the tile kernel: identical masks every time."""
     import zlib
-    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")          # four frames: force the walking kernels
     from lane_tracker_amd import _native, calib, synth
     cal = calib.reference_calibration()
     r = synth.SceneRenderer(cal)
     frames = np.stack([r.render(300 + i)[0] for i in range(3)] + [synth.frame_uniform(9)], 0)
     ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0],
                           device=0, capacity=4)
+    ctx.set_walk_min_frames(0)                             # four frames: the walking kernels all the same
     try:
         ctx.upload_frames(frames)
         want = {}

@@ -43,12 +43,12 @@ def _bilateral_np(p, k, C):
 
 @pytest.mark.parametrize("size", SIZES)
 def test_walk_kernels_match_the_oracle_on_many_sizes(size, monkeypatch):
-    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")          # read at lt_create: these small calls would take the tile kernel
     from lane_tracker_amd import _native, calib
     from oracle import oracle as O
     w, h = size
     cal = calib.reference_calibration()
     ctx = _native.Context(cal["img_size"], (w, h), cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=3)
+    ctx.set_walk_min_frames(0)                             # these small calls would take the tile kernel by default
     rng = np.random.default_rng(w * 7919 + h)
     try:
         for pi, (kr, cr, kb, cb) in enumerate(PARAMS):
@@ -83,12 +83,12 @@ def test_greenery_mask_through_the_walking_kernels(size, monkeypatch):
     """mask_noise (lane_tracker.py:221-231; the author's Demo 1 / Demo 3 settings): the third walk with window 65 over the raw
     Lab-b plane -- which the 55x55 top-hat launch leaves in the padded layout -- with the inRange term folded in, AND-ed
     into the merged plane on the way into the 5x5 open."""
-    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")
     from lane_tracker_amd import _native, calib
     from oracle import oracle as O
     w, h = size
     cal = calib.reference_calibration()
     ctx = _native.Context(cal["img_size"], (w, h), cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=3)
+    ctx.set_walk_min_frames(0)                             # these small calls would take the tile kernel by default
     rng = np.random.default_rng(w * 31 + h)
     try:
         for pi, nz in enumerate(NOISE):
@@ -124,12 +124,12 @@ def test_greenery_mask_through_the_walking_kernels(size, monkeypatch):
 def test_other_parameters_take_the_tile_kernel_and_agree(monkeypatch):
     """Window sizes outside {15, 20, 35}, a greenery mask with another window than 65 and LT-internal limits fall back to
     k_bilateral_tile2."""
-    monkeypatch.setenv("LT_WALK_MIN_FRAMES", "0")
     from lane_tracker_amd import _native, calib
     from oracle import oracle as O
     cal = calib.reference_calibration()
     w, h = 260, 150
     ctx = _native.Context(cal["img_size"], (w, h), cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=1)
+    ctx.set_walk_min_frames(0)                             # these small calls would take the tile kernel by default
     rng = np.random.default_rng(5)
     try:
         bev = _bev(rng, h, w, 1)[None]
@@ -147,7 +147,6 @@ def test_other_parameters_take_the_tile_kernel_and_agree(monkeypatch):
 
 def test_small_calls_take_the_tile_kernel_by_default(monkeypatch):
     """The policy: a call with few frames cannot fill the chip with long walks and takes the tile kernel."""
-    monkeypatch.delenv("LT_WALK_MIN_FRAMES", raising=False)
     from lane_tracker_amd import _native, calib, synth
     cal = calib.reference_calibration()
     ctx = _native.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=96)
@@ -161,5 +160,11 @@ def test_small_calls_take_the_tile_kernel_by_default(monkeypatch):
         assert ctx.last_threshold_path() == 1
         big = ctx.download_masks(96)
         assert np.array_equal(big[0], small[0]) and np.array_equal(big[95], small[1])
+        ctx.set_walk_min_frames(0)                           # the threshold is the caller's to move (lt_set_walk_min_frames) ...
+        ctx.mask_run(2)
+        assert ctx.last_threshold_path() == 1 and np.array_equal(ctx.download_masks(2), small)
+        ctx.set_walk_min_frames(-1)                          # ... and to put back
+        ctx.mask_run(2)
+        assert ctx.last_threshold_path() == 0
     finally:
         ctx.close()

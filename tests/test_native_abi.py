@@ -282,3 +282,40 @@ def test_host_copy_threads_survive_shutdown_and_fork():
     os.close(r)
     os.waitpid(pid, 0)
     assert got == b"ok"
+
+
+DEPLOYMENT_SWITCHES = {"LT_DEVICE_CACHE_GB", "LT_COPY_THREADS", "LT_COPY_SPINNERS", "LT_COPY_SPIN_US", "LT_STAGING_MB", "LT_TRACE_START",
+                       "LT_TRACE_DESTROY", "LT_RCCL_LIB"}
+PYTHON_SWITCHES = {"LT_GATHER_ID", "LT_DEVICE_MODULO"}                         # lane_tracker_amd/distributed.py (rank rendezvous, shared-GPU test runs)
+
+
+def test_release_library_reads_the_deployment_switches_and_no_others():
+    """measurement switches exist in the experiments build only (LT_EXP_ENV, csrc/lt_internal.h).  The release
+    library's string table holds exactly the documented environment names, the Python package reads two more, and no product
+    source carries a wrong-result probe."""
+    import glob
+    import subprocess
+    from lane_tracker_amd import _native
+    lib = os.path.join(ROOT, "lane_tracker_amd", "liblane_tracker_amd.so")
+    out = subprocess.run(["strings", lib], capture_output=True, text=True, check=True).stdout
+    names = {l.strip() for l in out.splitlines() if re.fullmatch(r"LT_[A-Z0-9_]+", l.strip())}
+    assert names == DEPLOYMENT_SWITCHES, sorted(names ^ DEPLOYMENT_SWITCHES)
+    assert len(names | PYTHON_SWITCHES) <= 12
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for n in DEPLOYMENT_SWITCHES | PYTHON_SWITCHES:
+        assert n in doc, n + " is not documented in INTEGRATION.md"
+    py = set()
+    for f in glob.glob(os.path.join(ROOT, "lane_tracker_amd", "*.py")):
+        py |= set(re.findall(r"environ(?:\.get)?\(?\[?\s*[\"'](LT_[A-Z0-9_]+)[\"']", open(f).read()))
+    assert py == PYTHON_SWITCHES, sorted(py ^ PYTHON_SWITCHES)
+    for f in glob.glob(os.path.join(ROOT, "lane_tracker_amd", "csrc", "*")):
+        if f.endswith((".hip", ".cpp", ".h")):
+            text = open(f).read()
+            assert "LT_PROBE_" not in text, f + " carries a timing probe (they live in tools/probes/*.patch)"
+            direct = set(re.findall(r"getenv\(\"(LT_[A-Z0-9_]+)\"\)", re.sub(r"LT_EXP_ENV\([^)]*\)", "", text)))
+            assert direct <= DEPLOYMENT_SWITCHES, (f, sorted(direct - DEPLOYMENT_SWITCHES))
+    # run_filter_chain reads no switch at all, in either build (its alternatives are gone or are arguments)
+    api = open(os.path.join(ROOT, "lane_tracker_amd", "csrc", "lt_api.cpp")).read()
+    a = api.index("int run_filter_chain(")
+    body = api[a:api.index("\n}\n", a)]
+    assert "getenv" not in body and "LT_EXP_ENV" not in body

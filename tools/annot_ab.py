@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Same-box A/B of the annotated stream's later pass under environment settings: each setting in a child process of its own,
-round robin, `--repeat` times.   python tools/annot_ab.py 1280x720 "" "LT_COPY_SPINNERS=1" "LT_STRIP_PIECE=256" ..."""
+round robin, `--repeat` times.   python tools/annot_ab.py 1280x720 "" "LT_COPY_SPINNERS=1" "ATTR_strip_piece=256" ...
+(LT_* names: the library's switches -- measurement switches need the experiments build, LANE_TRACKER_AMD_LIB=lane_tracker_amd/liblane_tracker_amd_exp.so;
+ATTR_<name>=<int>: a class attribute of LaneTracker, e.g. ATTR_host_text=0, ATTR_stream_lane_on_device=0)"""
 import json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,6 +24,10 @@ def child(size, mode):
     cal = calib.reference_calibration() if size == "1280x720" else calib.scaled_calibration(1.5)
     wins = bench.stream_windows(base, 256, 8)
     work = [w.copy() for w in wins] if ann == "inplace" else wins
+    for k, v in os.environ.items():           # ATTR_<name>=<int>: the tracker's Python-level alternatives are class attributes
+        if k.startswith("ATTR_"):
+            cur = getattr(LaneTracker, k[5:])
+            setattr(LaneTracker, k[5:], type(cur)(int(v)))
     lt = LaneTracker(**cal)
 
     def run():

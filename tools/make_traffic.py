@@ -33,7 +33,7 @@ def compulsory(kernel):
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(p)):
-        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
+        if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE"):
             continue
         m = re.search(r"(k_[a-z0-9_]+)(<[^>]*>)?", r["Kernel_Name"])
         if m:
@@ -45,7 +45,8 @@ for k, v in acc.items():
     mean = lambda x: sum(x) / len(x) if x else 0.0
     per[k] = {"fetch_bytes_raw": mean(v["FETCH_SIZE"]) * 1024, "fetch_factor": fetch_factor(k),
               "fetch_bytes": mean(v["FETCH_SIZE"]) * 1024 * fetch_factor(k), "write_bytes": mean(v["WRITE_SIZE"]) * 1024,
-              "dispatches": len(v["FETCH_SIZE"]), "valu_wave_insts": mean(v["SQ_INSTS_VALU"])}
+              "dispatches": len(v["FETCH_SIZE"]), "valu_wave_insts": mean(v["SQ_INSTS_VALU"]),
+              "lds_idx_active_cycles": mean(v["SQ_LDS_IDX_ACTIVE"])}
     c = compulsory(k)
     if c:
         per[k]["compulsory_read_bytes"], per[k]["compulsory_write_bytes"] = c[0] * frames, c[1] * frames
@@ -54,6 +55,7 @@ for k, v in acc.items():
 fetch = sum(v["fetch_bytes"] for k, v in per.items() if k.startswith(MASK))
 write = sum(v["write_bytes"] for k, v in per.items() if k.startswith(MASK))
 valu = sum(v["valu_wave_insts"] for k, v in per.items() if k.startswith(MASK))
+lds = sum(v["lds_idx_active_cycles"] for k, v in per.items() if k.startswith(MASK))
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/prof_round.sh); bench.py --steps 1 --warmup 1 "
                      "--streams 1 (mean per dispatch), %d frames per launch" % frames,
            "commit": commit,
@@ -65,5 +67,6 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 
            "frames_per_launch": frames, "mask_stage_fetch_bytes_per_launch": fetch, "mask_stage_write_bytes_per_launch": write,
            "mask_stage_traffic_bytes_per_launch": fetch + write,
            "mask_stage_valu_wave_insts_per_launch": valu,   # SQ_INSTS_VALU: wave64 VALU instructions, 64 lane-operations each
+           "mask_stage_lds_idx_active_cycles_per_launch": lds,   # SQ_LDS_IDX_ACTIVE: cycles the CUs' LDS index units were busy, summed over the CUs
            "per_kernel": per}, open(out, "w"), indent=1)
 print("mask stage: fetch %.3f GB  write %.3f GB  per %d frames" % (fetch / 1e9, write / 1e9, frames))
