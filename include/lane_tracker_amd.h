@@ -44,7 +44,7 @@ extern "C" {
  *    lt_overlay_run_strip_coeffs (strips from averaged coefficients).  Nothing removed or changed. */
 /* 5: + lt_device_cache_counters (hits / misses / evictions of the device-memory cache since the process started),
  *    lt_set_walk_min_frames (the batch size from which the threshold stage takes its walking kernels; was an environment
- *    switch).  Nothing removed or changed. */
+ *    switch), lt_host_memory_stats.  Nothing removed or changed. */
 #define LT_ABI_VERSION 5
 
 typedef enum lt_status {
@@ -428,6 +428,11 @@ int  lt_shutdown(void);
  * run, and the number of threads requests are shared among (LT_COPY_THREADS; default half of the CPUs the process may use,
  * 2 .. 8).  Any pointer may be NULL.  bench.py reports the copy threads' share of an annotated stream from these. */
 int  lt_host_copy_stats(double* busy_seconds, double* copied_bytes, long long* pieces, int* threads);
+/* What the library holds on the host right now: page-locked staging blocks it has allocated (bytes; strips of annotated frames
+ * travel through them), pieces waiting in the copy threads' queue, and pieces submitted or reserved but not finished.  A
+ * long-lived process sees the first flat and the other two back at 0 between windows (tests/test_gpu_soak.py).  Any pointer
+ * may be NULL. */
+int  lt_host_memory_stats(size_t* staging_bytes, size_t* queued_pieces, size_t* pending_pieces);
 int  lt_host_free(void* p);
 /* Device memory a context gives up (lt_destroy, lt_reserve growing) is kept in a per-process cache, by device and exact
  * size, and reused by later allocations.  Why: memory handed back to the driver is wiped in the background on an SDMA engine,

@@ -170,6 +170,7 @@ _SIGNATURES = {
     "lt_device_cache_trim": (C.c_int, [C.c_size_t]),
     "lt_device_cache_stats": (C.c_int, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]),
     "lt_device_cache_counters": (C.c_int, [C.POINTER(C.c_ulonglong)] * 4),
+    "lt_host_memory_stats": (C.c_int, [C.POINTER(C.c_size_t)] * 3),
     "lt_set_download_method": (C.c_int, [_P, C.c_int]),
     "lt_download_stats": (C.c_int, [_P, _P, _P, _P, _P, _P]),
     "lt_last_threshold_path": (C.c_int, [_P]),
@@ -410,6 +411,13 @@ def device_cache_stats():
     k, l, m, n = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_int()
     _check(load().lt_device_cache_stats(C.byref(k), C.byref(l), C.byref(m), C.byref(n)))
     return {"kept_bytes": k.value, "live_bytes": l.value, "limit_bytes": m.value, "kept_blocks": n.value}
+
+
+def host_memory_stats():
+    """{'staging_bytes', 'queued_pieces', 'pending_pieces'}: page-locked staging the library holds, and the copy threads' backlog."""
+    v = [C.c_size_t() for _ in range(3)]
+    _check(load().lt_host_memory_stats(*[C.byref(x) for x in v]))
+    return dict(zip(("staging_bytes", "queued_pieces", "pending_pieces"), (int(x.value) for x in v)))
 
 
 def device_cache_counters():

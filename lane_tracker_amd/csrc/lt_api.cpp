@@ -90,10 +90,21 @@ int note_range(lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi) {
     ++r.count;
     return LT_OK;
 }
-// `waiter` waits for the entries that touch slots [lo, hi); *precise = false if the ring has overflowed (the caller then waits
-// for stream tails)
+// One-frame calls of a context of one or two slots (LaneTracker.process(): capacity 2, one slot stream, the frame's kernels one
+// behind the other on it): no event -- stream order is all the ordering the frame needs, and a hipEventRecord between two
+// dependent kernels kept the second one waiting ~6 us (three of them on the way to the record: undistortion -> warp, open ->
+// search, search -> lane spans).  Whoever waits from ANOTHER stream finds `lazy` set and waits for the slot stream's tail.
+int note_range_frame(lt_ctx* c, lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi) {
+    if (c->capacity <= 2 && !c->urgent_on && !c->stage_timing && c->nstreams == 1 && st == c->stream) {
+        r.lazy = true;
+        return LT_OK;
+    }
+    return note_range(r, st, lo, hi);
+}
+// `waiter` waits for the entries that touch slots [lo, hi); *precise = false if the ring has overflowed or work was enqueued
+// without an event (the caller then waits for stream tails)
 int wait_range(const lt_ctx::RangeEvents& r, hipStream_t waiter, int lo, int hi, bool* precise) {
-    *precise = !r.overflow;
+    *precise = !r.overflow && !r.lazy;
     if (r.overflow) return LT_OK;
     for (unsigned i = 0; i < r.count; ++i) {
         const lt_ctx::RangeEvents::Entry& w = r.e[(r.head + i) % (unsigned)r.e.size()];
@@ -102,6 +113,9 @@ int wait_range(const lt_ctx::RangeEvents& r, hipStream_t waiter, int lo, int hi,
     return LT_OK;
 }
 int note_written(lt_ctx* c, hipStream_t st, int lo, int hi) { return note_range(c->writers, st, lo, hi); }
+static int note_written_frame(lt_ctx* c, hipStream_t st, int lo, int hi, int n_call) {
+    return n_call == 1 ? note_range_frame(c, c->writers, st, lo, hi) : note_range(c->writers, st, lo, hi);
+}
 
 // `st` waits for the chains still outstanding (not collected) that read or write slots [lo, hi): ticket by ticket, so that work on
 // a frame in front of a running chain -- the second try of a failed frame while the frames behind it are already chained -- does
@@ -345,6 +359,8 @@ int ensure_plane(lt_ctx* c, int idx) {
     return LT_OK;
 }
 
+constexpr int SIDE_LANES = 10;   // eroded-R scratch of the one- and two-frame chain: one per slice stream (up to 8), one for every other stream
+
 // filter_lane_points() on planes P_R / P_B of the given slots (lane_tracker.py:210-238)
 int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter_params* p, int h, int w, int call_frames,
                      bool u8_mask = false) {
@@ -408,8 +424,13 @@ int run_filter_chain(lt_ctx* c, hipStream_t s, int first, int n, const lt_filter
             // depend on each other: the 55x55 erode of the Lab-b plane and the 29x29 erode of the R plane are ONE launch, the two
             // top-hats the next (k_morph_one_pair).  (Round 5 ran the R plane's chain on a side stream: a fork, a join that cost the
             // frame 11-12 us of signalling, and three more launches.)  The eroded R plane has a scratch of its own, two planes per context.
-            if (!c->d_side_scratch) { const int rc = dev_alloc(&c->d_side_scratch, 2 * ps); if (rc) return rc; }
-            uint8_t* ts = c->d_side_scratch;
+            // (per STREAM, not per slot: a context of a thousand slots runs these one- and two-frame calls on a handful of streams --
+            // the slices' streams and the urgent one -- and calls on one stream are ordered)
+            if (!c->d_side_scratch) { const int rc = dev_alloc(&c->d_side_scratch, (size_t)SIDE_LANES * 2 * ps); if (rc) return rc; }
+            int lane_of_stream = SIDE_LANES - 1;
+            for (int i = 0; i < (int)c->streams.size() && i < SIDE_LANES - 1; ++i)
+                if (c->streams[(size_t)i] == s) { lane_of_stream = i; break; }
+            uint8_t* ts = c->d_side_scratch + (size_t)lane_of_stream * 2 * ps;
             if (launch_morph_one_pair(s, B, t0, nullptr, R, ts, nullptr, h, w, false, ps, n, 0, 0)) {
                 if (!launch_morph_one_pair(s, t0, thB, B, ts, thR, R, h, w, true, ps, n, 0, 0)) {
                     launch_morph_runs(s, t0, thB, B, h, w, 55, true, ps, n);
@@ -1028,6 +1049,7 @@ int lt_upload_frame_rows_enqueue(lt_ctx* c, const uint8_t* frames, int first, in
 // a kernel that reads camera frames can be on -- the slots' compute streams (undistortion), the presentation stream (overlays)
 // and the urgent stream.
 static int wait_reader_tails(lt_ctx* c, hipStream_t waiter) {
+    const bool slices_only = !c->readers.overflow;     // (only `lazy`: the unrecorded readers are on the slots' streams)
     auto tail = [&](hipStream_t st) {
         if (!st || st == waiter) return (int)LT_OK;
         hipEvent_t e = next_order_event(c);
@@ -1037,6 +1059,7 @@ static int wait_reader_tails(lt_ctx* c, hipStream_t waiter) {
         return (int)LT_OK;
     };
     for (int i = 0; i < c->nstreams && i < (int)c->streams.size(); ++i) { const int rc = tail(c->streams[i]); if (rc) return rc; }
+    if (slices_only) return LT_OK;
     int rc = tail(c->present);
     if (!rc) rc = tail(c->urgent);
     return rc;
@@ -1501,13 +1524,13 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
         { StageScope t(c, ST_UNDISTORT, st);
           launch_undistort_rows(st, c->d_frames + (size_t)f0 * c->frame_bytes, c->frame_bytes, c->d_uxy, c->d_ufrac,
                                 c->fe, c->d_und, c->und_px, f0, m); }
-        { int mrc = note_range(c->readers, st, f0, f0 + m); if (mrc) return mrc; }
+        { int mrc = n == 1 ? note_range_frame(c, c->readers, st, f0, f0 + m) : note_range(c->readers, st, f0, f0 + m); if (mrc) return mrc; }
         { StageScope t(c, ST_WARP_SPLIT, st);
           launch_warp_split(st, c->d_und, c->und_px, f0, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
                             c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
                             ps, m); }
         int frc = run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
-        return frc ? frc : note_written(c, st, f0, f0 + m);
+        return frc ? frc : note_written_frame(c, st, f0, f0 + m, n);
     });
     if (rc) return rc;
     c->have_mask = true;
@@ -1560,7 +1583,7 @@ int lt_sws_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p) {
                        c->d_band_sums + (size_t)f0 * g.nbands * c->calib.warp_w, c->d_pix + (size_t)f0 * 2 * c->maxpix,
                        c->d_cent + (size_t)f0 * 2 * (c->maxlev + 2), c->d_rec + f0, m);
         if (n == 1) mirror_record(c, st, f0);
-        return note_written(c, st, f0, f0 + m);
+        return note_written_frame(c, st, f0, f0 + m, n);
     });
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
@@ -1615,7 +1638,7 @@ int lt_band_fit_run(lt_ctx* c, int first, int n, const lt_search_params* p, cons
                             c->d_pix + (size_t)f0 * 2 * c->maxpix, c->d_rec + f0, m);
             if (n == 1) mirror_record(c, st, f0);
         }
-        return note_written(c, st, f0, f0 + m);
+        return note_written_frame(c, st, f0, f0 + m, n);
     });
     if (rc) return rc;
     HIP_TRY(hipGetLastError());

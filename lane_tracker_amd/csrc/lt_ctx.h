@@ -59,7 +59,7 @@ struct lt_ctx {
     uint32_t* d_und = nullptr;        // undistorted camera rows [r0, r0+nrows), one RGBX dword per pixel, slots 2p / 2p+1 interleaved (und_slot_base)
     size_t und_px = 0;                // pixels per slot of d_und
     uint8_t* d_plane[P_COUNT] = {};   // P_R, P_B, P_THR, P_THB, P_T0 with the slots; the others on first use (ensure_plane)
-    uint8_t* d_side_scratch = nullptr;     // two planes: the eroded R plane of a one- or two-frame chain (side stream)
+    uint8_t* d_side_scratch = nullptr;     // the eroded R plane of a one- or two-frame chain: two planes per stream that can run one (run_filter_chain)
     unsigned long long *d_bits_merged = nullptr, *d_bits_eroded = nullptr;   // 1 bit / pixel, wpr words per row
     unsigned long long* d_bits_open = nullptr;    // the opened mask as the mask chain leaves it (what the searches read)
     unsigned long long* d_bits_tmp = nullptr;     // third and fourth partial plane of the walking threshold kernels
@@ -170,7 +170,12 @@ struct lt_ctx {
         std::vector<Entry> e = std::vector<Entry>(32, Entry{0, 0, nullptr});
         unsigned head = 0, count = 0;
         bool overflow = false;
-        void reset() { head = count = 0; overflow = false; }
+        // work on the slots' streams that was NOT given an event of its own (note_range_frame: the one-frame calls of a context of
+        // one or two slots -- LaneTracker.process() -- where every kernel of a frame runs on one stream and an event record between
+        // two of them costs the frame ~6 us of device time each: profiles/r06_process_timeline.txt).  A waiter on another stream
+        // then waits for the tails of the slots' streams, as after an overflow; cleared by the next full synchronisation.
+        bool lazy = false;
+        void reset() { head = count = 0; overflow = false; lazy = false; }
     };
     RangeEvents readers, writers;
     RangeEvents rests;                        // lt_upload_frame_rest copies (copy stream): the overlay of a slot waits for ITS rows only
@@ -264,6 +269,7 @@ void dev_free(T*& p) {
 // ---- streams, slot ranges, ordering (lt_api.cpp) ---------------------------------------------------------
 int sync_all(lt_ctx* c);
 int note_range(lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi);
+int note_range_frame(lt_ctx* c, lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi);   // ... without an event where the context is one frame's (RangeEvents::lazy)
 int wait_range(const lt_ctx::RangeEvents& r, hipStream_t waiter, int lo, int hi, bool* precise);
 int note_written(lt_ctx* c, hipStream_t st, int lo, int hi);
 hipEvent_t next_order_event(lt_ctx* c);

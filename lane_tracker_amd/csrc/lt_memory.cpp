@@ -891,6 +891,21 @@ int lt_host_copy_stats(double* busy_seconds, double* copied_bytes, long long* pi
     return LT_OK;
 }
 
+int lt_host_memory_stats(size_t* staging_bytes, size_t* queued_pieces, size_t* pending_pieces) {
+    if (staging_bytes) {
+        PinnedBlocks& pb = pinned_blocks();
+        std::lock_guard<std::mutex> lk(pb.m);
+        *staging_bytes = pb.allocated;
+    }
+    if (queued_pieces || pending_pieces) {
+        HostCopier& h = host_copier();
+        std::lock_guard<std::mutex> lk(h.m);
+        if (queued_pieces) *queued_pieces = h.q.size();
+        if (pending_pieces) *pending_pieces = h.pending_all;
+    }
+    return LT_OK;
+}
+
 int lt_shutdown(void) {
     if (g_copier) g_copier->shutdown();
     pinned_blocks().trim();

@@ -757,8 +757,8 @@ int lt_present_lane_from_fit_async(lt_ctx* c, int slot, const double* prev_sum, 
                 c->lane_spec_ticket = t;
             } else (void)hipGetLastError();
         }
-        int nrc = note_range(c->readers, st, f0, f0 + 1);            // the next upload into this slot waits for the overlay's reads
-        return nrc ? nrc : note_written(c, st, f0, f0 + 1);           // ... and an overlay on the presentation stream for this one's stores
+        int nrc = note_range_frame(c, c->readers, st, f0, f0 + 1);   // the next upload into this slot waits for the overlay's reads
+        return nrc ? nrc : note_range_frame(c, c->writers, st, f0, f0 + 1);   // ... and an overlay on the presentation stream for this one's stores
     });
 }
 

@@ -7,8 +7,9 @@ then runs on all of them for a millisecond, the cgroup's CPU quota for the perio
 of the process until the next period: 40-80 ms per event, `cpu.stat: nr_throttled`, 7-15 % of `process()`'s time at
 1920x1080 (`tools/process_throttle_probe.py`, profiles/NOTES_r05.md D.9).
 
-`blas_limited()` is a context manager for exactly those calls: inside it the pool runs on no more threads than the CPUs the
-process may use, and on the way out the pool is what the application had set.  (Round 5 lowered the pool once, for good, from
+`blas_limited()` is a context manager for exactly those calls: inside it the pool runs on ONE thread -- a lane's pixels are a
+13 k x 3 least-squares problem, and OpenBLAS helper threads keep polling for ~0.1 s after a job: 16 of them, the whole quota of a
+period, per refit -- and on the way out the pool is what the application had set.  (Round 5 lowered the pool once, for good, from
 `LaneTracker.__init__`: a library has no business with its host's global state.)"""
 import contextlib
 import ctypes
@@ -79,15 +80,14 @@ def _blas_pools():
 
 @contextlib.contextmanager
 def blas_limited():
-    """Inside the block NumPy's BLAS pool runs on at most `usable_cpus()` threads (never more than it had); afterwards it is
-    what it was.  Blocks may nest and run on several threads at once: the first one in lowers the pool, the last one out
+    """Inside the block NumPy's BLAS pool runs on one thread; afterwards it is what it was.  Blocks may nest and run on several threads at once: the first one in lowers the pool, the last one out
     restores it.  Without a BLAS pool to be found the block runs as it is."""
     global _depth, _saved
     pools = _blas_pools()
     if pools:
         with _lock:
             if _depth == 0:
-                want = usable_cpus()
+                want = 1
                 _saved = []
                 for get, put in pools:
                     try:
