@@ -267,9 +267,12 @@ class _FramePool:
     anonymous mapping costs a page fault -- and a cleared page -- per 4 KB (2 MB with transparent huge pages) at first touch:
     0.7 GB per window of 256 1280x720 frames, 40-50 ms spread over the copy threads, as much as the rest of the window
     takes.  So the blocks are kept: an array handed out keeps its block until the array and every view of it are gone, then the
-    block waits here for the next window of that size.  At most `keep` blocks per size and `limit` bytes idle are kept."""
+    block waits here for the next window of that size.  At most `keep` blocks per size and `limit` bytes idle are kept
+    (`frames_pool_limit` changes them; `frames_trim()` gives the idle blocks back -- `LaneTracker.close()` calls it when the last
+    tracker of the process closes).  Returned frames are VIEWS of one window-sized block: keeping one frame keeps its window's
+    block alive (copy the frame to let the window go)."""
 
-    def __init__(self, limit=16 << 30, keep_per_size=6):
+    def __init__(self, limit=8 << 30, keep_per_size=5):
         self.limit, self.keep = limit, keep_per_size
         self.free, self.idle_bytes = {}, 0
 
@@ -325,6 +328,21 @@ class _FramePool:
 
 
 _frames = _FramePool()
+
+
+def frames_trim():
+    """Give the idle blocks of the frame pool back to the system (blocks behind arrays still alive stay with their arrays)."""
+    _frames.trim()
+
+
+def frames_pool_limit(idle_bytes=None, keep_per_size=None):
+    """Limits of the frame pool: at most `idle_bytes` of idle blocks and `keep_per_size` idle blocks per window size (defaults:
+    8 GB, 5 -- a stream keeps four windows in flight).  -> (idle_bytes, keep_per_size) in force."""
+    if idle_bytes is not None:
+        _frames.limit = int(idle_bytes)
+    if keep_per_size is not None:
+        _frames.keep = int(keep_per_size)
+    return _frames.limit, _frames.keep
 
 
 def frames_prefault(shape, count):

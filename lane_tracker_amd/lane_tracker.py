@@ -26,6 +26,7 @@ from .stream import StreamPipeline, _PackedPoly, _pack_deferred      # noqa: F40
 __all__ = ["LaneTracker", "bilateral_adaptive_threshold"]
 
 _default_ctx = None
+_live_trackers = 0          # LaneTracker instances not yet closed: the last one to close trims the process-wide frame pool
 
 
 def _context_for_module_functions():
@@ -106,6 +107,9 @@ class LaneTracker(StreamPipeline):
         # device side
         self.device = device
         self._ctx = _native.Context(img_size, warped_size, cam_matrix, dist_coeffs, self.M, device=device, capacity=2)
+        global _live_trackers
+        _live_trackers += 1
+        self._closed = False
         if self.search_cus:
             self._ctx.set_search_cus(self.search_cus)   # CUs of their own for the stream pipeline's long-running kernels (lt_set_search_cus)
         self._slot = 0              # process() alternates between two slots (see process())
@@ -252,6 +256,12 @@ class LaneTracker(StreamPipeline):
         for c in self._aux_ctx.values():
             c.close()
         self._aux_ctx = {}
+        if not getattr(self, "_closed", True):
+            global _live_trackers
+            self._closed = True
+            _live_trackers -= 1
+            if _live_trackers <= 0:      # nobody left to hand windows to: the pool of output blocks goes back to the system
+                _native.frames_trim()
 
     # ---- device plumbing ----------------------------------------------------------------------
     def _ctx_for_plane(self, h, w):
