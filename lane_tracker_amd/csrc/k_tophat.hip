@@ -1221,12 +1221,26 @@ bool launch_morph_one_pair(hipStream_t s, const uint8_t* src55, uint8_t* dst55, 
         !aligned(src29) || !aligned(dst29) || !aligned(min29) || (dilate && (min55 == nullptr) != (min29 == nullptr)))
         return false;
     RunsGeom g55 = g, g29 = g;
-    one_frame_bands(g55, n, 0);
-    one_frame_bands(g29, n, 0);
-    const dim3 grid(g55.ntasks + g29.ntasks), block(256);
-    if (dilate && min55) hipLaunchKernelGGL((k_morph_one_pair<true, true, 4>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);
-    else if (dilate) hipLaunchKernelGGL((k_morph_one_pair<true, false, 4>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);
-    else hipLaunchKernelGGL((k_morph_one_pair<false, false, 4>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);
+    // workgroups per plane (default: two per CU each) and waves per task: measurement switches of the experiments build
+    static const int wgs55 = [] { const char* e = LT_EXP_ENV("LT_PAIR_WGS55"); return e ? std::atoi(e) : 0; }();
+    static const int wgs29 = [] { const char* e = LT_EXP_ENV("LT_PAIR_WGS29"); return e ? std::atoi(e) : 0; }();
+    static const int pair_q = [] { const char* e = LT_EXP_ENV("LT_PAIR_Q"); return e ? std::atoi(e) : 4; }();
+    one_frame_bands(g55, n, wgs55);
+    one_frame_bands(g29, n, wgs29);
+    const dim3 grid(g55.ntasks + g29.ntasks);
+#define LT_PAIR(Q_)                                                                                                                              \
+    do {                                                                                                                                         \
+        const dim3 block(64 * Q_);                                                                                                               \
+        if (dilate && min55) hipLaunchKernelGGL((k_morph_one_pair<true, true, Q_>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);   \
+        else if (dilate) hipLaunchKernelGGL((k_morph_one_pair<true, false, Q_>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);      \
+        else hipLaunchKernelGGL((k_morph_one_pair<false, false, Q_>), grid, block, 0, s, src55, dst55, min55, g55, src29, dst29, min29, g29);                 \
+    } while (0)
+#ifdef LT_EXPERIMENTS
+    if (pair_q == 8) { LT_PAIR(8); return true; }
+#endif
+    (void)pair_q;
+    LT_PAIR(4);
+#undef LT_PAIR
     return true;
 }
 

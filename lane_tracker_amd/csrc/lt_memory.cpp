@@ -54,7 +54,7 @@ void trace_line(const char* what, double t0, size_t bytes) {
 // and exact size, and handed out again (a tracker closed and another of the same shape opened, a context growing back to a
 // size it had).
 //
-// How much is kept (round 5): at most the high-water mark of what the process's live contexts have held at once, and at most
+// How much is kept (round 5; round 6: a quarter more): at most 1.25 x the high-water mark of what the process's live contexts have held at once + 256 MB, and at most
 // 16 GB -- LT_DEVICE_CACHE_GB=<n> sets another limit, 0 turns the cache off.  (Round 4 kept up to half of the device memory:
 // hostile to anything else in the process or on the GPU.)  Over the limit the blocks that have waited longest go back to the
 // driver first; lt_device_cache_trim(keep) returns everything beyond `keep` at a moment of the caller's choosing, and a failed
@@ -74,7 +74,10 @@ struct DevCache {
             env_cap = e ? (long long)(std::atof(e) * 1e9) : -1;
         }
         if (env_cap >= 0) return env_cap;
-        return (long long)std::min<size_t>(high_water, (size_t)16 << 30);
+        // a quarter above the live high-water mark (+ 256 MB): when the process's largest tracker closes, its blocks must fit BESIDE
+        // the small ones already waiting (a closed two-slot context's, search buffers of other sizes) -- at exactly the high-water
+        // mark every close evicted those, and the next tracker allocated them again (tests/test_gpu_soak.py: 482 MB per reopen)
+        return (long long)std::min<size_t>(high_water + high_water / 4 + ((size_t)256 << 20), (size_t)16 << 30);
     }
 };
 DevCache& dev_cache() { static DevCache* c = new DevCache; return *c; }   // (never destroyed: no order problems at exit)
@@ -378,6 +381,7 @@ struct HostCopier {
         done.notify_all();
     }
     void run() {
+        (void)pthread_setname_np(pthread_self(), "lt-copy");      // (visible in /proc/<pid>/task/*/comm, top -H, gdb)
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             if (q.empty() && !stop && spin_us() > 0 && spinning.load(std::memory_order_relaxed) < max_spinners()) {
@@ -409,6 +413,7 @@ struct HostCopier {
         }
     }
     void run_waiter() {
+        (void)pthread_setname_np(pthread_self(), "lt-wait");
         std::unique_lock<std::mutex> lk(m);
         int on = -1;
         for (;;) {

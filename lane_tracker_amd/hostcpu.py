@@ -78,6 +78,12 @@ def _blas_pools():
     return found
 
 
+def find_blas_pools():
+    """The one-time search for the BLAS libraries NumPy has loaded (threadpoolctl walks every shared object of the process:
+    ~0.1 s with the HIP runtime loaded).  Changes nothing; `LaneTracker.__init__` calls it so that no frame pays for it."""
+    return len(_blas_pools())
+
+
 @contextlib.contextmanager
 def blas_limited():
     """Inside the block NumPy's BLAS pool runs on one thread; afterwards it is what it was.  Blocks may nest and run on several threads at once: the first one in lowers the pool, the last one out

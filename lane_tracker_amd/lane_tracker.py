@@ -110,6 +110,7 @@ class LaneTracker(StreamPipeline):
         global _live_trackers
         _live_trackers += 1
         self._closed = False
+        _hostcpu.find_blas_pools()       # (the one-time search for NumPy's BLAS library -- 0.1 s -- at set-up, not inside a frame's refit)
         if self.search_cus:
             self._ctx.set_search_cus(self.search_cus)   # CUs of their own for the stream pipeline's long-running kernels (lt_set_search_cus)
         self._slot = 0              # process() alternates between two slots (see process())
@@ -731,8 +732,9 @@ class LaneTracker(StreamPipeline):
                 if not drawn:
                     self._ctx.present_lane_async(slot, left_n, right_n, left_yx, right_yx, out, rows)
             finally:
-                self._copies_done()
-            if text is not None:
+                early, self._text_in_flight = self._text_in_flight, None
+                self._copies_done()      # (with the text of _text_early among them)
+            if text is not None and not (early is not None and early[0] is out and early[1] == lines):
                 _native.text_blend(out, _overlay.font_atlas(), text, len(lines), line_len, self._TEXT_ORIGIN, self._TEXT_STEP)
             return self._ctx.present_finish(slot, None, 0, line_len, out, rows, origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
         try:
@@ -743,6 +745,22 @@ class LaneTracker(StreamPipeline):
                                            origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
         finally:
             self._copies_done()          # the rows the host fills itself
+
+    _text_in_flight = None      # (output frame, lines) whose text a copy thread is blending (_text_early), until _present has waited for it
+
+    def _text_early(self):
+        """The text lines of the frame being finished, blended into the output frame by one of the library's copy threads
+        (lt_host_text_async_group: lt_text_blend_host's arithmetic) while this thread goes on with the frame's bookkeeping --
+        10-13 us of the 40-odd between the record and the return.  The rows under the text were copied from the caller's frame by
+        the same threads long ago (`_prepare_out`); they are waited for first all the same."""
+        out, lines = self._out, self._lane_text()
+        if out is None or len(lines) > 3:
+            return
+        self._copies_done()
+        text, nl = _native.text_bytes([lines])
+        _native.host_text_async(self._copy_group(), out, out, (0, 0, 0, 0), _overlay.font_atlas(), text, nl, 40, self._TEXT_ORIGIN, self._TEXT_STEP)
+        self._copying = True
+        self._text_in_flight = (out, lines)
 
     def print_failure(self, img):
         """The failure message on a copy of the frame (upstream writes into the caller's array, :664-673)."""
@@ -927,7 +945,7 @@ class LaneTracker(StreamPipeline):
         self._lane_in_flight = b
         return la, ra, b
 
-    def _record_success(self, left_fit_coeffs, right_fit_coeffs, partial, ahead=None):
+    def _record_success(self, left_fit_coeffs, right_fit_coeffs, partial, ahead=None, on_text=None):
         self.left_fit_coeffs.append(left_fit_coeffs)
         self.right_fit_coeffs.append(right_fit_coeffs)
         self.last_left_coeffs = left_fit_coeffs
@@ -946,11 +964,21 @@ class LaneTracker(StreamPipeline):
             purpose = 'avg1' if keep is not None and keep is self.__dict__.get("_packed", {}).get((partial, 'avg0')) else 'avg0'
             b = self._points_packed(self.left_avg_coeffs, self.right_avg_coeffs, partial, purpose)     # = get_poly_points
         nl, nr, H = int(b[1][0]), int(b[1][1]), self.warped_size[1]
+        early = on_text is not None and nl > 0 and nr > 0
+        if early:
+            # what the frame's text lines need, first: the radius, and the eccentricity from the last plot point of each averaged
+            # curve (get_eccentricity's operands and operations: left_avg_x[-1], right_avg_x[-1] as int64) -- then the text goes to
+            # a copy thread while this one builds the rest of the state
+            self.get_curve_radius()
+            mid = int(self.warped_size[0] / 2)
+            self.eccentricity = (((mid - np.int64(b[2][nl - 1, 1])) - (np.int64(b[3][nr - 1, 1]) - mid)) / 2) * self.mpph
+            on_text()
         self.left_avg_y, self.left_avg_x = np.arange(H - nl, H, dtype=np.int64), b[2][:nl, 1].astype(np.int64)
         self.right_avg_y, self.right_avg_x = np.arange(H - nr, H, dtype=np.int64), b[3][:nr, 1].astype(np.int64)
         self._avg_packed = (b, self.left_avg_x, self.right_avg_x)
-        self.get_curve_radius()
-        self.get_eccentricity()
+        if not early:
+            self.get_curve_radius()
+            self.get_eccentricity()
 
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,
@@ -982,7 +1010,7 @@ class LaneTracker(StreamPipeline):
                 self._lane_in_flight = self._device_lane = None
                 self._ctx.sync()
             self._copies_done()
-            self._want_out, self._out, self._out_rows = False, None, None
+            self._want_out, self._out, self._out_rows, self._text_in_flight = False, None, None, None
 
     def _step(self, img, first_try, n_tries, diagnostics, slot, have_mask, lazy, annotate, visualize_search=False,
               split_view=False, defer=None):
@@ -1062,7 +1090,11 @@ class LaneTracker(StreamPipeline):
             return present(self.draw_lane(img) if redraw else self.print_failure(img))
 
         # success (:1178-1209)
-        self._record_success(left_fit_coeffs, right_fit_coeffs, partial, spec)
+        on_text = None
+        if spec is not None and self._want_out and self._out is not None and self._out_host_text and self._out_rows is not None \
+                and self._have_font and not (visualize_search or split_view):
+            on_text = self._text_early      # the lane is being drawn by the device: the text lines go to a copy thread as soon as they are known
+        self._record_success(left_fit_coeffs, right_fit_coeffs, partial, spec, on_text)
         if not annotate:
             return None
         if defer is not None:

@@ -29,6 +29,8 @@ def test_annotated_stream_soak_is_flat():
         out, err = p.communicate()
         pytest.fail("the soak run did not finish within its deadline:\n" + out[-1500:] + err[-1500:])
     assert p.returncode == 0, out[-1500:] + err[-3000:]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    open(os.path.join(ROOT, "gpurun_out", "soak_last.jsonl"), "w").write(out)             # (kept for the notes: profiles/r06_soak.jsonl)
     lines = [json.loads(l) for l in out.splitlines() if l.startswith("{")]
     verdict = [json.loads(l[len("VERDICT "):]) for l in out.splitlines() if l.startswith("VERDICT ")]
     assert verdict and verdict[0]["reopened"] == 2, out[-1500:]
@@ -37,16 +39,19 @@ def test_annotated_stream_soak_is_flat():
     warm = max(2, len(samples) // 6)
     steady = samples[warm:]
     first = steady[0]
+    held = lambda s: s["cache_kept"] + s["cache_live"]
     for s in steady:
         assert s["queued_pieces"] == 0 and s["pending_pieces"] == 0, s                     # nothing left in the copy threads' queue between passes
-        assert s["staging_bytes"] == first["staging_bytes"], (first, s)                   # page-locked staging: allocated once
+        assert s["staging_bytes"] <= first["staging_bytes"] + (96 << 20), (first, s)       # page-locked staging: a pool of a few blocks, at most three more after a reopen
         assert s["pinned_pool_outstanding"] + s["pinned_pool_idle"] <= first["pinned_pool_outstanding"] + first["pinned_pool_idle"], (first, s)
-        assert s["evicted_bytes"] == first["evicted_bytes"], (first, s)                    # the device cache gives nothing back to the driver ...
-        assert s["cache_misses"] == first["cache_misses"], (first, s)                      # ... and the reopened trackers found every block in it
-        assert s["cache_kept"] + s["cache_live"] == first["cache_kept"] + first["cache_live"], (first, s)
+        assert s["evicted_bytes"] == first["evicted_bytes"], (first, s)                    # the device cache gives NOTHING back to the driver (no wipe, no half-rate downloads)
+        assert held(s) <= held(first) * 1.02 + (64 << 20), (first, s)                      # ... and what the process holds on the device does not grow (a reopened
+        assert s["cache_misses"] - first["cache_misses"] <= 64, (first, s)                 #     tracker finds its slot buffers in the cache; a few small buffers of other sizes may be new)
         assert s["rss"] <= first["rss"] * 1.03 + (64 << 20), (first["rss"], s["rss"])      # resident memory flat (3 % + 64 MB of allocator noise)
-        assert s["threads"] <= first["threads"], (first, s)
+        assert s["threads"] <= first["threads"] + 1, (first, s)
         assert s["success_ratio"] > 0.5
+    last_third = [s for s in steady if s["t"] >= samples[-1]["t"] * 0.72]                  # behind the second reopen: strictly flat
+    assert len({s["staging_bytes"] for s in last_third}) == 1 and len({held(s) for s in last_third}) == 1, last_third
     rates = [s["fps"] for s in steady]
     k = max(1, len(rates) // 4)
     early, late = sorted(rates[:k])[k // 2], sorted(rates[-k:])[k // 2]
