@@ -55,10 +55,6 @@ __global__ __launch_bounds__(256) void k_overlay_lane(const uint8_t* __restrict_
 }
 
 // Four pixels (12 bytes = three dwords) per thread when the row length allows it.
-// TICKET: the launch's LAST workgroup to finish stores `ticket` into `ticket_word` (page-locked, device-visible) behind every
-// workgroup's stores -- the completion word the host polls, without a launch of its own behind the overlay (k_store_word: 4 us
-// of dispatch on the one-frame chain).  `done` is a zeroed device word the last workgroup leaves zeroed again.
-template <bool TICKET>
 __device__ __forceinline__ void overlay_lane4_body(const uint32_t* __restrict__ frames, uint32_t* __restrict__ out,
                                                    size_t frame_stride_dw, size_t out_stride_dw, int out_q0,
                                                    const int16_t* __restrict__ oxy,
@@ -99,26 +95,7 @@ __global__ __launch_bounds__(256) void k_overlay_lane4(const uint32_t* __restric
                                                       const uint16_t* __restrict__ ofrac,
                                                       const short2* __restrict__ spans, size_t span_stride, int qa, int na,
                                                       int qb, int nb, int bh, int bw, float alpha) {
-    overlay_lane4_body<false>(frames, out, frame_stride_dw, out_stride_dw, out_q0, oxy, ofrac, spans, span_stride, qa, na, qb, nb, bh, bw, alpha);
-}
-__global__ __launch_bounds__(256) void k_overlay_lane4_ticket(const uint32_t* __restrict__ frames, uint32_t* __restrict__ out,
-                                                             size_t frame_stride_dw, size_t out_stride_dw, int out_q0,
-                                                             const int16_t* __restrict__ oxy,
-                                                             const uint16_t* __restrict__ ofrac,
-                                                             const short2* __restrict__ spans, size_t span_stride, int qa, int na,
-                                                             int qb, int nb, int bh, int bw, float alpha,
-                                                             unsigned* __restrict__ done, volatile unsigned* __restrict__ ticket_word, unsigned ticket) {
-    overlay_lane4_body<true>(frames, out, frame_stride_dw, out_stride_dw, out_q0, oxy, ofrac, spans, span_stride, qa, na, qb, nb, bh, bw, alpha);
-    __threadfence_system();              // this thread's rows have left for the host's memory ...
-    __syncthreads();                     // ... and so have the whole workgroup's
-    if (threadIdx.x == 0) {
-        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
-        if (atomicAdd(done, 1u) == total - 1u) {     // the last workgroup of the launch
-            *done = 0u;
-            __threadfence_system();
-            *ticket_word = ticket;
-        }
-    }
+    overlay_lane4_body(frames, out, frame_stride_dw, out_stride_dw, out_q0, oxy, ofrac, spans, span_stride, qa, na, qb, nb, bh, bw, alpha);
 }
 
 // k_overlay_lane4 for ONE frame with the row intervals as a kernel ARGUMENT (up to LT_SPAN_ARG_ROWS bird's-eye rows; should the
@@ -467,22 +444,6 @@ bool launch_overlay_lane_strip(hipStream_t s, const uint8_t* frames, size_t fram
     hipLaunchKernelGGL(k_overlay_lane4, dim3((nb + 255) / 256, 1, n), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(frames),
                        reinterpret_cast<uint32_t*>(strips), frame_stride >> 2, strip_stride >> 2, qb, oxy, ofrac,
                        reinterpret_cast<const short2*>(spans), span_stride_rows, 0, 0, qb, nb, bh, bw, alpha);
-    return true;
-}
-
-// the aligned form with a completion ticket stored by the launch's last workgroup (k_overlay_lane4_ticket); false: not launched
-// (a row length or stride that is no multiple of 4, empty runs) -- the caller launches launch_overlay_lane + launch_store_word
-bool launch_overlay_lane_ticket(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
-                                const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w, int bh, int bw,
-                                float alpha, int n, const int* rows4, unsigned* done, unsigned* ticket_word, unsigned ticket) {
-    if (n <= 0 || (img_w & 3) || (frame_stride & 3) || !done || !ticket_word) return false;
-    const int qrow = img_w >> 2;
-    int qa = 0, na = (img_h * img_w) >> 2, qb = 0, nb = 0;
-    if (rows4) { qa = rows4[0] * qrow; na = (rows4[1] - rows4[0]) * qrow; qb = rows4[2] * qrow; nb = (rows4[3] - rows4[2]) * qrow; }
-    if (na + nb <= 0) return false;
-    hipLaunchKernelGGL(k_overlay_lane4_ticket, dim3((na + nb + 255) / 256, 1, n), dim3(256), 0, s,
-                       reinterpret_cast<const uint32_t*>(frames), reinterpret_cast<uint32_t*>(out), frame_stride >> 2, frame_stride >> 2, 0,
-                       oxy, ofrac, reinterpret_cast<const short2*>(spans), span_stride_rows, qa, na, qb, nb, bh, bw, alpha, done, ticket_word, ticket);
     return true;
 }
 

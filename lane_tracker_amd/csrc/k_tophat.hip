@@ -1225,8 +1225,14 @@ bool launch_morph_one_pair(hipStream_t s, const uint8_t* src55, uint8_t* dst55, 
     static const int wgs55 = [] { const char* e = LT_EXP_ENV("LT_PAIR_WGS55"); return e ? std::atoi(e) : 0; }();
     static const int wgs29 = [] { const char* e = LT_EXP_ENV("LT_PAIR_WGS29"); return e ? std::atoi(e) : 0; }();
     static const int pair_q = [] { const char* e = LT_EXP_ENV("LT_PAIR_Q"); return e ? std::atoi(e) : 4; }();
-    one_frame_bands(g55, n, wgs55);
-    one_frame_bands(g29, n, wgs29);
+    // Measured (tools/pair_sweep.sh, wall time of one frame's mask chain + band search + record, three runs each): two
+    // workgroups per CU for each plane -- what a launch of one plane alone takes -- 92.9-94.6 us; one per CU for the 55x55 plane
+    // and one and a half for the 29x29 plane 82.9-83.9 us (256 / 256: 82.9-85.3; 192 / any: 87-93; 384 / any: 88-92).
+    int cus = 256, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    one_frame_bands(g55, n, wgs55 > 0 ? wgs55 : cus);
+    one_frame_bands(g29, n, wgs29 > 0 ? wgs29 : cus + cus / 2);
     const dim3 grid(g55.ntasks + g29.ntasks);
 #define LT_PAIR(Q_)                                                                                                                              \
     do {                                                                                                                                         \

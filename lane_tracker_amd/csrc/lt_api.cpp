@@ -857,7 +857,6 @@ void lt_destroy(lt_ctx* c) {
     dev_free(c->d_advance);
     dev_free(c->d_lines);
     dev_free(c->d_xpos);
-    dev_free(c->d_done_word);
     note("done");
     delete c;
 }

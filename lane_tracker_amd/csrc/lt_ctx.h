@@ -125,7 +125,6 @@ struct lt_ctx {
     double* d_ploty = nullptr;        // [2][ploty_rows]
     std::vector<double> h_ploty;      // what d_ploty holds (compared on every call: 2 x 9 KB)
     hipStream_t lane_spec_stream = nullptr;   // the stream a speculative overlay of process() runs on, until lt_present_finish has waited for it
-    unsigned* d_done_word = nullptr;          // k_overlay_lane4_ticket's count of finished workgroups (zero between launches)
     unsigned lane_spec_ticket = 0;            // ... and the ticket a one-thread launch behind it stores at h_rec + 128 bytes (0: none, wait for the stream)
     // lt_set_urgent: while on, the stage calls run on this stream instead of the slots' streams -- behind what was enqueued
     // for THEIR slots only (slot-range events), not behind the masks of later frames queued on the slots' streams, which

@@ -88,9 +88,6 @@ void launch_overlay_lane(hipStream_t s, const uint8_t* frames, uint8_t* out, siz
 // length that is no multiple of 4, or the runtime refused the argument block)
 constexpr int LT_SPAN_ARG_ROWS = 1104;
 void launch_store_word(hipStream_t s, unsigned* dev_word, unsigned value);
-bool launch_overlay_lane_ticket(hipStream_t s, const uint8_t* frames, uint8_t* out, size_t frame_stride, const int16_t* oxy,
-                                const uint16_t* ofrac, const int16_t* spans, size_t span_stride_rows, int img_h, int img_w, int bh, int bw,
-                                float alpha, int n, const int* rows4, unsigned* done, unsigned* ticket_word, unsigned ticket);
 bool launch_lane_spans_from_regions(hipStream_t s, const double* ploty, const double* ploty2, int n_rows, int bh, int bw, int16_t* spans, int n);
 bool launch_lane_spans_from_fit(hipStream_t s, const lt_lane_record* rec, const double* prev_sum, int count, const double* ploty,
                                 const double* ploty2, int n_rows, int bh, int bw, int16_t* spans);

@@ -743,35 +743,21 @@ int lt_present_lane_from_fit_async(lt_ctx* c, int slot, const double* prev_sum, 
         int16_t* sp = c->d_spans + (size_t)f0 * bh * 2;
         if (!launch_lane_spans_from_fit(st, c->d_rec + f0, prev_sum, count, c->d_ploty, c->d_ploty + n_rows, n_rows, bh, c->calib.warp_w, sp))
             return fail(LT_ERR_STATE, "lt_present_lane_from_fit_async: too many rows for one workgroup's LDS");
+        launch_overlay_lane(st, c->d_frames + (size_t)f0 * c->frame_bytes, static_cast<uint8_t*>(dev), c->frame_bytes, c->d_oxy, c->d_ofrac, sp,
+                            (size_t)bh, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, 1, r);
         c->lane_spec_stream = st;
         c->lane_spec_ticket = 0;
         // the completion word the host polls (the record mirror's page-locked block, 256 bytes: the record, its ticket at +64, this one
-        // at +128): stored by the overlay's own last workgroup; where that form does not launch, by a one-thread launch behind it
-        unsigned* word = nullptr;
+        // at +128): a one-thread launch behind the overlay.  (Round 6 tried to let the overlay's own last workgroup store it -- a
+        // system-scope fence per thread, a count of finished workgroups --: the fences made the overlay 39 us instead of 20 + 4.)
         if (c->h_rec) {
             void* hdev = nullptr;
-            if (hipHostGetDevicePointer(&hdev, c->h_rec, 0) == hipSuccess && hdev) word = reinterpret_cast<unsigned*>(static_cast<char*>(hdev) + 128);
-            else (void)hipGetLastError();
-        }
-        unsigned t = 0;
-        if (word) {
-            t = ++c->rec_ticket_counter;
-            if (!t) t = ++c->rec_ticket_counter;
-            if (!c->d_done_word) {
-                if (dev_alloc(&c->d_done_word, 1) != LT_OK) word = nullptr;
-                else HIP_TRY(hipMemsetAsync(c->d_done_word, 0, sizeof(unsigned), st));
-            }
-        }
-        if (word && launch_overlay_lane_ticket(st, c->d_frames + (size_t)f0 * c->frame_bytes, static_cast<uint8_t*>(dev), c->frame_bytes, c->d_oxy, c->d_ofrac, sp,
-                                               (size_t)bh, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, 1, r, c->d_done_word, word, t)) {
-            c->lane_spec_ticket = t;
-        } else {
-            launch_overlay_lane(st, c->d_frames + (size_t)f0 * c->frame_bytes, static_cast<uint8_t*>(dev), c->frame_bytes, c->d_oxy, c->d_ofrac, sp,
-                                (size_t)bh, c->calib.img_h, c->calib.img_w, bh, c->calib.warp_w, (float)alpha, 1, r);
-            if (word) {
-                launch_store_word(st, word, t);
+            if (hipHostGetDevicePointer(&hdev, c->h_rec, 0) == hipSuccess && hdev) {
+                unsigned t = ++c->rec_ticket_counter;
+                if (!t) t = ++c->rec_ticket_counter;
+                launch_store_word(st, reinterpret_cast<unsigned*>(static_cast<char*>(hdev) + 128), t);
                 c->lane_spec_ticket = t;
-            }
+            } else (void)hipGetLastError();
         }
         HIP_TRY(hipGetLastError());
         int nrc = note_range_frame(c, c->readers, st, f0, f0 + 1);   // the next upload into this slot waits for the overlay's reads

@@ -78,10 +78,27 @@ def _blas_pools():
     return found
 
 
+_warmed = False
+
+
 def find_blas_pools():
-    """The one-time search for the BLAS libraries NumPy has loaded (threadpoolctl walks every shared object of the process:
-    ~0.1 s with the HIP runtime loaded).  Changes nothing; `LaneTracker.__init__` calls it so that no frame pays for it."""
-    return len(_blas_pools())
+    """Set-up work that must not fall into a frame: (1) the one-time search for the BLAS libraries NumPy has loaded
+    (threadpoolctl walks every shared object of the process: ~0.1 s with the HIP runtime loaded); (2) the BLAS pool's own
+    start-up -- OpenBLAS starts its helper threads at the first call that may use them (here: when `blas_limited()` hands the
+    pool back at its full size for the first time), and 63 new threads polling for work cost a process with a quota of 16 CPUs one
+    freeze of 40-80 ms (tools/process_throttle_probe.py names the threads that burned the quota).  `LaneTracker.__init__` calls
+    this, so that the freeze, if the application has not had it yet, happens while a tracker is being built and not in frame 127."""
+    global _warmed
+    n = len(_blas_pools())
+    if n and not _warmed:
+        _warmed = True
+        try:
+            import numpy as np
+            with blas_limited():
+                np.polyfit(np.arange(8.0), np.arange(8.0) ** 2, 2)
+        except Exception:
+            pass
+    return n
 
 
 @contextlib.contextmanager
