@@ -1032,6 +1032,8 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
                 if (wrc) return wrc;
                 if (!precise && (wrc = wait_reader_tails(c, st))) return wrc;
             }
+            // (the rows in two to four pieces, so that the engine's copy of one runs under the runtime's staging of the next: measured
+            // SLOWER, 195-218 against 183-186 us per 1280x720 frame -- every piece pays the call again; NOTES_r06 E.2)
             HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)f0 * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                                      bytes, (size_t)m, hipMemcpyHostToDevice, st));
             return (int)LT_OK;

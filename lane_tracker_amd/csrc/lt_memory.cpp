@@ -392,12 +392,19 @@ struct HostCopier {
                 lk.lock();
                 spinning.fetch_sub(1, std::memory_order_relaxed);
             }
+            ++sleeping;
             work.wait(lk, [&] { return stop || !q.empty(); });
+            --sleeping;
             if (q.empty()) return;               // stop
             Job j = std::move(q.front());
             q.pop_front();
             queued.fetch_sub(1, std::memory_order_relaxed);
+            // more pieces than this worker will take, and colleagues asleep: THIS thread wakes the next one (who wakes the next).  The
+            // submitting thread -- process() between a frame's launches -- used to make those futex calls itself: 5-7 us each,
+            // 37 us per frame in lt_host_copy2d_async_group (tools/process_trace.py, NOTES_r06 E.2)
+            const bool pass_on = !q.empty() && sleeping > 0;
             lk.unlock();
+            if (pass_on) work.notify_one();
             const auto t0 = std::chrono::steady_clock::now();
             if (j.fn) j.fn();
             else if (j.dpitch == j.width && j.spitch == j.width) copy_bytes(j.dst, j.src, j.width * j.height);
@@ -459,17 +466,25 @@ struct HostCopier {
     std::atomic<unsigned long long> busy_ns{0}, bytes_done{0}, jobs_done{0};   // lt_host_copy_stats (plain copies count their bytes, fn jobs 0)
     std::atomic<size_t> queued{0};
     std::atomic<int> spinning{0};
+    int sleeping = 0;                // workers blocked in work.wait (under m)
     int max_spinners() {
         static const int v = [] { const char* e = std::getenv("LT_COPY_SPINNERS"); return e ? std::min(std::max(std::atoi(e), 0), 16) : 3; }();
         return std::min(v, threads());
     }
-    void wake(size_t pieces) {      // after a push, outside the lock: sleepers for the pieces the pollers will not take
-        // counted over EVERYTHING that waits in the queue, not over this submission alone: two submitters that each push one
-        // piece and each see the same single poller must not both leave their piece to it (the second piece would wait, with
-        // every other worker asleep, until the first -- possibly a millisecond of text -- is done)
+    void wake(size_t pieces) {      // after a push, outside the lock
+        // A poller will take the first piece within a microsecond and wake a sleeper for the next one itself (run(): pass_on), and
+        // so on down the queue: the submitting thread makes NO system call then.  With nobody polling, one sleeper is woken here
+        // and passes it on the same way.  (Counted over everything that waits in the queue: a second submitter that finds the
+        // only poller already claimed by another submission's piece wakes a sleeper of its own.)
         const size_t waiting = std::max(pieces, queued.load(std::memory_order_acquire));
-        const long need = (long)std::min<size_t>(waiting, (size_t)threads()) - (long)spinning.load(std::memory_order_relaxed);
-        for (long i = 0; i < need; ++i) work.notify_one();
+        const size_t polling = (size_t)std::max(spinning.load(std::memory_order_relaxed), 0);
+        if (waiting > polling) {
+            // ... except that a large submission (a frame's 1.8-4 MB of rows: more pieces than pollers) gets up to two sleepers
+            // from here as well: woken one after the other by their colleagues they would start 50-100 us apart, and the frame's
+            // rows would not be there when its text is due (12 us of the submitter's time, which waits for the device anyway)
+            const size_t direct = polling == 0 ? 1 : std::min<size_t>(2, waiting - polling);
+            for (size_t i = 0; i < direct; ++i) work.notify_one();
+        }
     }
     static int spin_us() {
         static const int v = [] { const char* e = std::getenv("LT_COPY_SPIN_US"); return e ? std::max(std::atoi(e), 0) : 400; }();

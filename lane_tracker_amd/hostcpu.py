@@ -84,18 +84,25 @@ _warmed = False
 def find_blas_pools():
     """Set-up work that must not fall into a frame: (1) the one-time search for the BLAS libraries NumPy has loaded
     (threadpoolctl walks every shared object of the process: ~0.1 s with the HIP runtime loaded); (2) the BLAS pool's own
-    start-up -- OpenBLAS starts its helper threads at the first call that may use them (here: when `blas_limited()` hands the
-    pool back at its full size for the first time), and 63 new threads polling for work cost a process with a quota of 16 CPUs one
-    freeze of 40-80 ms (tools/process_throttle_probe.py names the threads that burned the quota).  `LaneTracker.__init__` calls
-    this, so that the freeze, if the application has not had it yet, happens while a tracker is being built and not in frame 127."""
+    start-up.  OpenBLAS creates its helper threads at the first call that touches the pool -- `openblas_set_num_threads`
+    included, i.e. the first `blas_limited()` -- and every new thread polls for work for a while before it goes to sleep: 63 of
+    them against a cgroup quota of 16 CPUs are one freeze of 40-80 ms for the whole process (tools/process_throttle_probe.py
+    names the threads that burned the quota: NOTES_r06 E.3).  `LaneTracker.__init__` calls this: the pool is started here, and
+    where it is larger than the CPUs the process may use this call waits the 0.15 s its threads need to fall asleep -- once
+    per process, while a tracker is being built, instead of inside one of the first frames.  The pool's size is the application's
+    before and after."""
     global _warmed
     n = len(_blas_pools())
     if n and not _warmed:
         _warmed = True
         try:
+            import time
             import numpy as np
+            size = max(int(get() or 1) for get, _ in _blas_pools())
             with blas_limited():
                 np.polyfit(np.arange(8.0), np.arange(8.0) ** 2, 2)
+            if size > usable_cpus():
+                time.sleep(0.15)
         except Exception:
             pass
     return n

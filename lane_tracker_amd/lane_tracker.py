@@ -829,6 +829,12 @@ class LaneTracker(StreamPipeline):
                 ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
                                                       ksize_noise, C_noise), first=slot)
 
+            if self._want_out and self._out is None and not reuse_frame:
+                # The output array, and its untouched rows on their way on the library's copy threads, BEFORE the search is launched:
+                # the device needs another 70 us of mask chain before it gets to the search, the host is ahead of it, and the rows
+                # -- 1.8 MB at 1280x720, 4 MB at 1920x1080 -- should be in place when the record arrives and the text is due.
+                self._prepare_out()
+
             def while_the_device_searches():
                 # behind the search's launch (the device has the whole chain queued; the host's share of the frame must not delay it)
                 if not reuse_frame:
@@ -842,11 +848,10 @@ class LaneTracker(StreamPipeline):
                         self._upload_keepalive = ctx.upload_frame_rest(img, first=slot, rows=None if rows is None else rows[1])
                     self._resident_partial = rows is not None
                 if self._want_out and self._out is None:
-                    def lane_on_the_device():    # enqueued as soon as the output frame exists: ahead of the host's own copies
-                        if not reuse_frame and self.draws_lane_on_device and self.speculates_lane and self._out_host_text and \
-                                self._out_rows is not None and self._out_ahead:
-                            self._device_lane = self._lane_from_fit(partial, slot)
-                    self._prepare_out(lane_on_the_device)   # the output array; its untouched rows start to fill on the library's copy threads
+                    self._prepare_out()          # (a frame whose output array could not be prepared ahead of the search)
+                if self._want_out and self._out is not None and self._device_lane is None and not reuse_frame and self.draws_lane_on_device \
+                        and self.speculates_lane and self._out_host_text and self._out_rows is not None and self._out_ahead:
+                    self._device_lane = self._lane_from_fit(partial, slot)   # the lane drawn by the device itself, right behind the search
             if self.last_detection > self.n_reset:                       # :851
                 if diagnostics:
                     print("Using sliding window search.")

@@ -2,7 +2,7 @@
 """Regenerate the measured tables of DESIGN.md from a kept bench line, so that the document and the profile file it cites cannot
 disagree:
 
-    python tools/design_tables.py [profiles/r05_bench.json] [--check]
+    python tools/design_tables.py [profiles/r06_bench.json] [--check]
 
 Everything between `<!-- bench:NAME -->` and `<!-- /bench:NAME -->` in DESIGN.md is replaced by the table NAME built from the
 JSON (one bench.py line, or a list of lines: then every figure is shown as min - max over the lines).  --check: exit 1 if
@@ -67,7 +67,9 @@ def tables(lines):
     row("`process()`, one frame per call, annotated frame back", lambda s: s["process_fps"])
     row("`process_batch`, 256 frames per call", lambda s: s["process_batch_fps"])
     row("`process_batch`, annotated", lambda s: s["process_batch_annotated_fps"])
-    row("`process_stream`, later pass (4096 frames)", lambda s: s["process_stream_fps"])
+    row("`process_stream`, later passes of the long-lived tracker (4096 frames each): median of three", lambda s: s["process_stream_fps"])
+    row("… min / max of the three", lambda s: s["process_stream_passes"]["min"])
+    row("… ", lambda s: s["process_stream_passes"]["max"])
     row("`process_stream`, first pass of a fresh tracker after `warm()`: median of three (min – max)",
         lambda s: s["process_stream_first_pass"]["frames_per_s"]["median"])
     row("… min", lambda s: s["process_stream_first_pass"]["frames_per_s"]["min"])
@@ -75,7 +77,11 @@ def tables(lines):
     row("… time to the first window", lambda s: s["process_stream_first_pass"]["time_to_first_window_ms"]["median"], ms1)
     row("… `warm()` itself (median; the first tracker of a process: max)", lambda s: s["process_stream_first_pass"]["warm_ms"]["median"], ms1)
     row("… a fresh tracker that was NOT warmed", lambda s: s["process_stream_first_pass"]["not_warmed"]["frames_per_s"])
-    row("`process_stream`, annotated, later pass", lambda s: s["process_stream_annotated_fps"])
+    row("`process_stream`, annotated, later passes of the long-lived tracker: median of three", lambda s: s["process_stream_annotated_fps"])
+    row("… min", lambda s: s["process_stream_annotated_passes"]["min"])
+    row("… max", lambda s: s["process_stream_annotated_passes"]["max"])
+    row("… copy threads' busy share; bytes the device cache gave back to the driver meanwhile", lambda s: s["copy_threads_busy_share_annotated_stream"], lambda v: "%.2f" % v)
+    row("… ", lambda s: s["device_cache_during_annotated_passes"]["evicted_bytes"], lambda v: "%d B" % v)
     row("annotated, first pass after `warm()`: median of three", lambda s: s["process_stream_annotated_first_pass"]["frames_per_s"]["median"])
     row("… min", lambda s: s["process_stream_annotated_first_pass"]["frames_per_s"]["min"])
     row("… max", lambda s: s["process_stream_annotated_first_pass"]["frames_per_s"]["max"])
@@ -87,6 +93,18 @@ def tables(lines):
     row("with outages (four of 16 frames per window)", lambda s: s["process_stream_outages_fps"])
     rows.append("| Demo 1 settings (`mask_noise`) | %s | — |" % span(lines, lambda d: d["stream"]["1280x720"]["process_stream_demo1_fps"]))
     t["stream"] = "\n".join(rows)
+    prow = ["| | 1280×720 | 1920×1080 |", "|---|---|---|"]
+    prow.append("| `process()`: median of three stretches of 0.15 s, frames/s | %s | %s |" % (
+        span(lines, lambda d: d["stream"]["1280x720"]["process_fps"]), span(lines, lambda d: d["stream"]["1920x1080"]["process_fps"])))
+    prow.append("| … slowest / fastest stretch | %s / %s | %s / %s |" % (
+        span(lines, lambda d: min(d["stream"]["1280x720"]["process_fps_stretches"])), span(lines, lambda d: max(d["stream"]["1280x720"]["process_fps_stretches"])),
+        span(lines, lambda d: min(d["stream"]["1920x1080"]["process_fps_stretches"])), span(lines, lambda d: max(d["stream"]["1920x1080"]["process_fps_stretches"]))))
+    us = lambda v: "%.0f µs" % (v * 1e3)
+    prow.append("| BASELINE config 1: `tests/golden/photo_test4.png` through `process()` with its defaults (two tries, both rejected, as in the reference's own run): median of 200 calls | %s (%s frames/s) | — |" % (
+        span(lines, lambda d: d["config1"]["process_defaults"]["median_ms"], us), span(lines, lambda d: d["config1"]["process_defaults"]["frames_per_s"])))
+    prow.append("| … the first frame of a video under the Demo 1 limits (first try valid, lane drawn) | %s | — |" % span(lines, lambda d: d["config1"]["process_demo1_first_frame"]["median_ms"], us))
+    prow.append("| … the CPU port's two tries of the same frame on ONE thread (no drawing) | %s | — |" % span(lines, lambda d: d["config1"]["cpu_port_one_thread"]["median_ms"], lambda v: "%.1f ms" % v))
+    t["process"] = "\n".join(prow)
     srows = ["| | frames/s | mask stage ms | threshold + merge ms |", "|---|---|---|---|"]
     for key, label in (("process_defaults", "`process()` defaults"), ("demo1", "Demo 1 (`mask_noise`)"), ("demo2", "Demo 2 (k_r = 20)"),
                        ("demo3", "Demo 3 (`mask_noise`)"), ("second_try", "second try (`'neighborhood'`, no top-hats)")):
@@ -108,7 +126,7 @@ def tables(lines):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
-    path = args[0] if args else os.path.join(ROOT, "profiles", "r05_bench.json")
+    path = args[0] if args else os.path.join(ROOT, "profiles", "r06_bench.json")
     lines = load(path)
     t = tables(lines)
     design = os.path.join(ROOT, "DESIGN.md")

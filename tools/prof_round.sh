@@ -2,7 +2,7 @@
 # Round profile set (GPU box, repo root): tools/prof_round.sh <tag, e.g. r04> <commit>
 #   kernel trace + stats of bench.py on one stream, PMC passes (one counter group per pass), traffic table, bench line.
 set -u
-tag=${1:-r04}
+tag=${1:-r06}
 commit=${2:-unknown}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag; mkdir -p $out
@@ -50,6 +50,13 @@ python3 tools/stream_profile.py > $out/${tag}_stream_profile.json 2>&1
 # process() one frame at a time: host time per call, device time per stage
 { timeout 120 python3 tools/process_trace.py 2>/dev/null | tail -1; timeout 120 python3 tools/process_trace.py x 2>/dev/null | tail -1;
   timeout 120 python3 tools/process_kernels.py 2>/dev/null | tail -1; } > $out/${tag}_process.jsonl
+# process() one frame per call: the device timeline of a frame (kernel + copy trace condensed) and the --stats summary of the same loop
+bash tools/process_timeline.sh $tag > $out/ptl.log 2>&1; cp $root/gpurun_out/ptl_$tag/timeline.txt $out/${tag}_process_timeline.txt
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ptrace -o t -- python3 $root/tools/process_loop.py > $out/ptrace.log 2>&1; echo "process trace rc=$?"
+cd $root
+cp $(find $out/ptrace -name "*kernel_stats.csv" | head -1) $out/${tag}_process_kernel_stats.csv
+rm -rf $out/ptrace
 rm -rf $out/strace $out/settings
 rm -rf $out/trace $out/fetch $out/write $out/sq1 $out/sq2
 ls -la $out
