@@ -161,6 +161,22 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                     k += 1
                 chunks.append(round((k - k0) / (time.perf_counter() - t0), 1))
             res = {"process_fps": sorted(chunks)[1], "process_fps_stretches": chunks}
+            # ... and when the caller's frames already lie in page-locked memory (lt_host_alloc; a decoder that writes into such
+            # buffers): the runtime's staging of the frame's rows -- 24 us of the frame at 1280x720, ~50 at 1920x1080 -- drops out.
+            # Not the reference's call pattern (moviepy hands over ordinary arrays): a separate key, never `process_fps`.
+            try:
+                pin = _native.pinned_empty((64,) + frames.shape[1:])
+                pin[...] = frames[32:96]
+                for f in pin[:8]:
+                    lt.process(f)
+                t0, k0 = time.perf_counter(), 0
+                while time.perf_counter() - t0 < seconds * 0.15:
+                    lt.process(pin[k0 % 64])
+                    k0 += 1
+                res["process_page_locked_input_fps"] = round(k0 / (time.perf_counter() - t0), 1)
+                del pin
+            except Exception as e:
+                res["process_page_locked_input_fps"] = repr(e)
             for key, ann in (("process_batch_fps", False), ("process_batch_annotated_fps", True)):
                 lt.process_batch(frames, annotate=ann)
                 reps, k = [], 0

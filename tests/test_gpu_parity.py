@@ -612,8 +612,8 @@ EXP_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["LT_SEARCH_U8=1", "LT_SWS_V1=1,LT_BAND_V1=1", "LT_MORPH_ONE_ROW=1,LT_MORPH_WIDE=0", "LT_BILATERAL_TILES=1",
-                                    "LT_UNDISTORT_UNALIGNED=1", "LT_OPEN5_SEPARATE=1,LT_OPEN_SMALL=0"])
+@pytest.mark.parametrize("switch", ["LT_SEARCH_U8=1,LT_BILATERAL_TILES=1,LT_UNDISTORT_UNALIGNED=1,LT_OPEN5_SEPARATE=1,LT_OPEN_SMALL=0,LT_MORPH_ONE_ROW=1,LT_MORPH_WIDE=0",
+                                    "LT_SWS_V1=1,LT_BAND_V1=1"])      # (one fallback per stage in the first run: they do not interact)
 def test_fallback_kernel_paths_keep_parity_at_the_reference_geometry(switch):
     """The release library has one path per stage plus FALLBACKS it takes by itself for what the main kernels do not cover: u8
     masks handed in by the caller, search windows beyond the bit-plane kernels' limits, image widths that are not a multiple of

@@ -176,7 +176,7 @@ def test_kernel_download_path_gives_the_same_frames():
     env = dict(os.environ, LT_DL_KERNEL="1", LT_TEST_SEARCH_CUS="3", LANE_TRACKER_AMD_LIB=exp)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
                         "tests/test_gpu_streams.py::test_overlay_pieces_with_targeted_wait_equal_one_blocking_download",
-                        "tests/test_gpu_chain.py::test_process_stream_equals_process_frame_by_frame"],
+                        "tests/test_gpu_chain.py::test_process_stream_equals_process_frame_by_frame[True-sizes1-9-2-1]"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
