@@ -372,6 +372,27 @@ bool launch_copy_words_to_pinned(hipStream_t s, void* dst_pinned, const void* sr
     return true;
 }
 
+// One lane record (64 bytes = 16 words) into its page-locked mirror, and behind it the ticket the host polls (the word after the
+// record): what k_band_chain3 does for a one-frame band search by itself, for the one-frame SLIDING-WINDOW search (the first frame of
+// a video, every frame while the detector is lost: lane_tracker.py:851) -- lt_download_records then polls instead of waiting for
+// the stream, which returns 15-20 us after the data is there.  One wave: the fence in front of the ticket is one wave's.
+namespace {
+__global__ __launch_bounds__(64) void k_mirror_record(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, unsigned ticket) {
+    if (threadIdx.x < 16) dst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned*>(dst + 16) = ticket;
+}
+}  // namespace
+bool launch_mirror_record(hipStream_t s, void* dst_pinned, const void* src_record, unsigned ticket) {
+    void* dst_dev = nullptr;
+    if (hipHostGetDevicePointer(&dst_dev, dst_pinned, 0) != hipSuccess || !dst_dev) {
+        (void)hipGetLastError();
+        return false;
+    }
+    hipLaunchKernelGGL(k_mirror_record, dim3(1), dim3(64), 0, s, static_cast<uint32_t*>(dst_dev), static_cast<const uint32_t*>(src_record), ticket);
+    return true;
+}
+
 // Device -> page-locked host memory by a kernel (16 bytes per lane, grid-stride over a grid that a few CUs hold), the
 // alternative to the copy engine for lt_download_overlay_async (LT_DL_KERNEL=1; trade-off and numbers there and in
 // tools/microbench/d2h_kernel.hip): stores from a kernel cross the bus beside the engine's uploads whatever engine the runtime

@@ -1347,9 +1347,13 @@ static lt_lane_record* rec_mirror_device(lt_ctx* c) {      // the mirror as kern
 static void mirror_record(lt_ctx* c, hipStream_t st, int slot) {
     c->rec_mirror_slot = -1;
     c->rec_ticket = 0;
-    if (rec_mirror_device(c) && launch_copy_words_to_pinned(st, c->h_rec, c->d_rec + slot, sizeof(lt_lane_record))) {
+    static_assert(sizeof(lt_lane_record) == 64, "k_mirror_record copies 16 words and stores the ticket behind them");
+    unsigned ticket = ++c->rec_ticket_counter;
+    if (!ticket) ticket = ++c->rec_ticket_counter;          // 0 means "no ticket"
+    if (rec_mirror_device(c) && launch_mirror_record(st, c->h_rec, c->d_rec + slot, ticket)) {
         c->rec_mirror_slot = slot;
         c->rec_mirror_stream = st;
+        c->rec_ticket = ticket;
     }
 }
 

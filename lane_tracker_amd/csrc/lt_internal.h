@@ -101,6 +101,7 @@ void launch_copy_from_pinned(hipStream_t s, void* dst, const void* src_pinned, s
 bool launch_copy_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes);   // false: not page-locked / aligned
 bool launch_copy_rows_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t pitch, size_t off, size_t bytes, int n);
 bool launch_copy_words_to_pinned(hipStream_t s, void* dst_pinned, const void* src, size_t bytes);          // small, 4-byte granular
+bool launch_mirror_record(hipStream_t s, void* dst_pinned, const void* src_record, unsigned ticket);       // a 64-byte record + the ticket word behind it
 void launch_warp_rgb(hipStream_t s, const uint32_t* und, size_t und_px, int first_slot, const int16_t* wxy, const uint16_t* wfrac,
                      FrontEndGeom g, uint8_t* bev, size_t bev_stride, int n);
 
