@@ -134,7 +134,9 @@ int lt_overlay_configure(lt_ctx* c, const double* Minv) {
     // The rows the mask chain uploads (lt_upload_frame_rows: what the undistortion reads) and the rows the lane can reach are
     // nearly the same run (457-695 and 458-696 of 720 with the reference calibration): a row or two more in the former, and an
     // annotated frame needs no second upload for the lane's run (lt_upload_frame_rest_rows: 12 us per frame of process()).
-    if (c->cam_r1 > c->cam_r0 && c->ov_r1 > c->ov_r0 && c->ov_r0 >= c->cam_r0 - 8 && c->ov_r1 <= c->cam_r1 + 8) {
+    // (a 1920x1080 camera scaled from the reference calibration: 685-1042 against a lane run that ends a dozen rows lower -- the
+    // second upload was 26-29 us of every process() frame there: tools/process_trace.py x; up to 32 rows either side are taken along)
+    if (c->cam_r1 > c->cam_r0 && c->ov_r1 > c->ov_r0 && c->ov_r0 >= c->cam_r0 - 32 && c->ov_r1 <= c->cam_r1 + 32) {
         c->cam_r0 = std::min(c->cam_r0, c->ov_r0);
         c->cam_r1 = std::max(c->cam_r1, c->ov_r1);
     }
