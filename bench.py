@@ -161,9 +161,9 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                     k += 1
                 chunks.append(round((k - k0) / (time.perf_counter() - t0), 1))
             res = {"process_fps": sorted(chunks)[1], "process_fps_stretches": chunks}
-            # ... and when the caller's frames already lie in page-locked memory (lt_host_alloc; a decoder that writes into such
-            # buffers): the runtime's staging of the frame's rows -- 24 us of the frame at 1280x720, ~50 at 1920x1080 -- drops out.
-            # Not the reference's call pattern (moviepy hands over ordinary arrays): a separate key, never `process_fps`.
+            # ... and with the caller's frames in page-locked memory (lt_host_alloc): measures whether the 22-24 us of the upload call
+            # are a staging copy the caller could spare the runtime (they are not: within 2 % of process_fps).  Not the reference's
+            # call pattern (moviepy hands over ordinary arrays): a separate key, never `process_fps`.
             try:
                 pin = _native.pinned_empty((64,) + frames.shape[1:])
                 pin[...] = frames[32:96]

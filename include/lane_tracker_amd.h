@@ -44,7 +44,9 @@ extern "C" {
  *    lt_overlay_run_strip_coeffs (strips from averaged coefficients).  Nothing removed or changed. */
 /* 5: + lt_device_cache_counters (hits / misses / evictions of the device-memory cache since the process started),
  *    lt_set_walk_min_frames (the batch size from which the threshold stage takes its walking kernels; was an environment
- *    switch), lt_host_memory_stats.  Nothing removed or changed. */
+ *    switch), lt_host_memory_stats, lt_mask_rerun (a second parameter set over frames whose front end has run), lt_download_lane_lists (a search's lists in one
+ *    round trip).  Nothing removed or
+ *    changed. */
 #define LT_ABI_VERSION 5
 
 typedef enum lt_status {
@@ -176,6 +178,12 @@ int  lt_download_records(lt_ctx* ctx, int first_slot, int n, lt_lane_record* out
 int  lt_download_pixels(lt_ctx* ctx, int slot, int side, int32_t* ys, int32_t* xs, int cap, int* count);
 /* self.left_window_centroids / right_window_centroids (:439-440) */
 int  lt_download_centroids(lt_ctx* ctx, int slot, int side, int32_t* out, int cap, int* count);
+/* Both sides' lane pixels and, with want_centroids, both window-centroid lists of a slot in ONE round trip to the device (the lists
+ * of lane_tracker.py:434-440 / :492-495 as lt_download_pixels and lt_download_centroids return them).  counts[2] / cent_counts[2]:
+ * the full lengths (left, right); lists longer than cap / cent_cap are cut.  LT_ERR_CAPACITY when the slot's list region does not
+ * fit the staging buffer (very large search windows): use the two calls above. */
+int  lt_download_lane_lists(lt_ctx* ctx, int slot, int32_t* left_y, int32_t* left_x, int32_t* right_y, int32_t* right_x, int cap, int* counts,
+                            int want_centroids, int32_t* cent_left, int32_t* cent_right, int cent_cap, int* cent_counts);
 /* device-to-device copy of n records into caller-owned device memory (e.g. a collective's send buffer) */
 int  lt_copy_records_to_device(lt_ctx* ctx, int first_slot, int n, void* dst_device);
 /* the same copy enqueued behind the slots' searches on the context's streams, without waiting: the records are in
@@ -185,6 +193,11 @@ int  lt_enqueue_records_to_device(lt_ctx* ctx, int first_slot, int n, void* dst_
 /* ---- the hot path, device resident ----------------------------------------------------------- */
 /* find_lane_points() part 1 (:832-846): undistort -> warpPerspective -> filter_lane_points. */
 int  lt_mask_run(lt_ctx* ctx, int first_slot, int n, const lt_filter_params* p);
+/* The same over slots whose frames have been through lt_mask_run already, with OTHER filter parameters -- the second try of a frame
+ * (lane_tracker.py:1081-1101: the 'neighborhood' set over the same bird's-eye image): the undistortion and the warp are skipped
+ * where a slot's R / Lab-b planes are still those of the frame it holds (any upload of camera rows into the slot, or lt_filter_run,
+ * ends that), and run as in lt_mask_run where they are not.  Results are those of lt_mask_run. */
+int  lt_mask_rerun(lt_ctx* ctx, int first_slot, int n, const lt_filter_params* p);
 /* filter_lane_points() only, on bird's-eye RGB images already uploaded with lt_upload_bev (:183-240) */
 int  lt_upload_bev(lt_ctx* ctx, const uint8_t* bev_rgb, int first_slot, int n);
 int  lt_filter_run(lt_ctx* ctx, int first_slot, int n, const lt_filter_params* p);

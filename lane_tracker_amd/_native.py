@@ -87,6 +87,8 @@ _SIGNATURES = {
     "lt_download_records": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_download_pixels": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_int, C.POINTER(C.c_int)]),
     "lt_download_centroids": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, C.POINTER(C.c_int)]),
+    "lt_download_lane_lists": (C.c_int, [_P, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "lt_copy_records_to_device": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_enqueue_records_to_device": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "lt_overlay_configure": (C.c_int, [_P, _P]),
@@ -127,6 +129,7 @@ _SIGNATURES = {
     "lt_host_text_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_int, _P, C.c_int, C.c_int, _P, _P,
                                            C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
+    "lt_mask_rerun": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "lt_filter_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_sws_fit_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(SearchParams)]),
@@ -839,6 +842,28 @@ class Context:
         _check(self.lib.lt_download_centroids(self._h, slot, side, out.ctypes.data, cap, C.byref(cnt)))
         return [int(v) for v in out[:cnt.value]]
 
+    def download_lane_lists(self, slot, want_centroids=True):
+        """(left_y, left_x, right_y, right_x, left centroids or None, right centroids or None) of the slot's last search in ONE round
+        trip to the device (lt_download_lane_lists); the lists are what download_pixels / download_centroids return."""
+        cap = 1 << 16
+        for _ in range(2):
+            arrs = self.__dict__.get("_list_buf")
+            if arrs is None or arrs[0].size < cap:
+                arrs = self._list_buf = [np.empty(cap, np.int32) for _ in range(4)]       # (kept: 1 MB, filled by every call)
+            cnt, ccnt = (C.c_int * 2)(), (C.c_int * 2)()
+            ccap = self.info().max_levels + 2 if want_centroids else 0
+            cl, cr = np.zeros(max(ccap, 1), np.int32), np.zeros(max(ccap, 1), np.int32)
+            _check(self.lib.lt_download_lane_lists(self._h, int(slot), arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data,
+                                                   arrs[0].size, cnt, int(bool(want_centroids)), cl.ctypes.data, cr.ctypes.data, ccap, ccnt))
+            if max(cnt[0], cnt[1]) <= arrs[0].size:
+                break
+            cap = max(cnt[0], cnt[1])
+        nl, nr = cnt[0], cnt[1]
+        out = (arrs[0][:nl].astype(np.int64), arrs[1][:nl].astype(np.int64), arrs[2][:nr].astype(np.int64), arrs[3][:nr].astype(np.int64))
+        if not want_centroids:
+            return out + (None, None)
+        return out + ([int(v) for v in cl[:ccnt[0]]], [int(v) for v in cr[:ccnt[1]]])
+
     def copy_records_to_device(self, n, dst_ptr, first=0):
         _check(self.lib.lt_copy_records_to_device(self._h, first, n, C.c_void_p(int(dst_ptr))))
 
@@ -850,9 +875,12 @@ class Context:
         _check(self.lib.lt_set_frame_base(self._h, first, n, int(first_frame)))
 
     # -- compute (asynchronous on the context's stream)
-    def mask_run(self, n, fp=None, first=0):
+    def mask_run(self, n, fp=None, first=0, reuse_front=False):
+        """undistort + warp + filter_lane_points over slots first .. first+n-1.  reuse_front: the slots' frames have been through
+        mask_run already and only the filter parameters differ (the second try of a frame): lt_mask_rerun skips the front end where
+        the slots' planes are still current."""
         fp = fp or filter_params()
-        _check(self.lib.lt_mask_run(self._h, first, n, C.byref(fp)))
+        _check((self.lib.lt_mask_rerun if reuse_front else self.lib.lt_mask_run)(self._h, first, n, C.byref(fp)))
 
     def filter_run(self, n, fp=None, first=0):
         fp = fp or filter_params()

@@ -185,6 +185,7 @@ void free_slots(lt_ctx* c) {
     c->mask_u8_ok.clear();
     c->frame_full.clear();
     c->annot_full.clear();
+    c->front_ok.clear();
     dev_free(c->d_rec);
     dev_free(c->d_prev);
     dev_free(c->d_pix);
@@ -242,6 +243,9 @@ int ensure_search_buffers(lt_ctx* c, int maxpix, int maxlev) {
 // a slot would hand out another stream's pixels.
 void mark_frames(lt_ctx* c, int first, int n, int full) {
     for (int i = first; i < first + n && i < (int)c->frame_full.size(); ++i) c->frame_full[(size_t)i] = (uint8_t)full;
+}
+static void front_stale(lt_ctx* c, int first, int n) {      // new camera rows in these slots: their planes are the old frames'
+    for (int i = first; i < first + n && i < (int)c->front_ok.size(); ++i) c->front_ok[(size_t)i] = 0;
 }
 void mark_annot(lt_ctx* c, int first, int n, int full) {
     for (int i = first; i < first + n && i < (int)c->annot_full.size(); ++i) c->annot_full[(size_t)i] = (uint8_t)full;
@@ -825,6 +829,7 @@ void lt_destroy(lt_ctx* c) {
     for (auto e : c->chain_event_pool) (void)hipEventDestroy(e);
     note("hipHostFree(small, rec, rec_stage, cancel)");
     if (c->h_small) (void)hipHostFree(c->h_small);
+    if (c->h_lists) (void)hipHostFree(c->h_lists);
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
     if (c->h_cancel) (void)hipHostFree(c->h_cancel);
@@ -898,6 +903,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     c->mask_u8_ok.assign(n, 1);          // zero-filled below
     c->frame_full.assign(n, 0);
     c->annot_full.assign(n, 0);
+    c->front_ok.assign(n, 0);
     if ((rc = dev_alloc(&c->d_rec, n))) { free_slots(c); return rc; }
     if ((rc = dev_alloc(&c->d_prev, n * 6))) { free_slots(c); return rc; }
     c->capacity = capacity;
@@ -992,6 +998,7 @@ int lt_upload_frames(lt_ctx* c, const uint8_t* frames, int first, int n) {
                            hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     mark_frames(c, first, n, 1);
+    front_stale(c, first, n);
     return LT_OK;
 }
 
@@ -1016,6 +1023,7 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
     static const bool enqueue_syncs = [] { const char* e = LT_EXP_ENV("LT_UPLOAD_SYNC"); return e && e[0] == '1'; }();
     if ((!enqueue || enqueue_syncs) && (rc = sync_all(c))) return rc;
     mark_frames(c, first, n, 0);         // a new frame's rows: the others are the previous occupant's until lt_upload_frame_rest
+    front_stale(c, first, n);
     const size_t row_bytes = (size_t)c->calib.img_w * 3, off = (size_t)c->cam_r0 * row_bytes;
     const size_t bytes = (size_t)(c->cam_r1 - c->cam_r0) * row_bytes;
     // (one frame, measured in round 5 against this pitched copy, 279-286 us per frame of process(): a plain copy of the contiguous
@@ -1077,6 +1085,7 @@ int lt_upload_frame_rows_async(lt_ctx* c, const uint8_t* frames, int first, int 
     if (n == 0 || c->cam_r1 <= c->cam_r0) return LT_OK;
     if ((rc = set_device(c))) return rc;
     mark_frames(c, first, n, 0);
+    front_stale(c, first, n);
     // the copy waits for the kernels that still read these slots' camera rows (the undistortion launches over these slots, the
     // overlay) -- not for the rest of their mask chains, and not for launches over other slots
     bool precise = true;
@@ -1383,26 +1392,18 @@ int lt_download_records(lt_ctx* c, int first, int n, lt_lane_record* out) {
     return download(c, c->d_rec + first, out, (size_t)n * sizeof(lt_lane_record));
 }
 
-int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, int cap, int* count) {
-    int rc = check_slots(c, slot, 1);
-    if (rc) return rc;
-    if (side < 0 || side > 1 || !count || cap < 0) return fail(LT_ERR_INVALID, "bad side/count/cap");
-    if (!c->d_pix) return fail(LT_ERR_STATE, "no search has run yet");
-    lt_lane_record r;
-    if ((rc = download(c, c->d_rec + slot, &r, sizeof r))) return rc;
+// The lane pixels of one side of a slot, expanded from the form the search kernels leave on the device (`region`: a host copy of the
+// slot's list region, at least the words the record's format uses) into the reference's (y, x) lists, in the reference's order.
+static int expand_pixels(const lt_ctx* c, const lt_lane_record& r, const uint32_t* region, size_t region_words, int side, int32_t* ys,
+                         int32_t* xs, int cap, int* count) {
     if (r._pad == 1) {
         // k_sws_fit2 leaves one column mask per window row (lt_internal.h: sws2_mask_offset); the lists
         // self.left_y / left_x (level-major, row-major inside a window, ascending x) are expanded here
-        const uint32_t* block = c->d_pix + (size_t)slot * 2 * c->maxpix;
-        uint32_t hdr[4];
-        if ((rc = download(c, block, hdr, sizeof hdr))) return rc;
-        const int nlev = (int)hdr[0], wh = (int)hdr[1], H1 = (int)hdr[2];
+        const int nlev = (int)region[0], wh = (int)region[1], H1 = (int)region[2];
         const long long words = sws2_block_words(nlev, wh);
-        if (nlev < 1 || wh < 1 || words > 2LL * c->maxpix) return fail(LT_ERR_STATE, "corrupt lane-pixel block");
-        std::vector<uint32_t> blk((size_t)words);
-        if ((rc = download(c, block, blk.data(), (size_t)words * 4))) return rc;
-        const int32_t* roi = reinterpret_cast<const int32_t*>(blk.data() + 4);
-        const uint32_t* masks = blk.data() + sws2_mask_offset(nlev);
+        if (nlev < 1 || wh < 1 || words > (long long)region_words) return fail(LT_ERR_STATE, "corrupt lane-pixel block");
+        const int32_t* roi = reinterpret_cast<const int32_t*>(region + 4);
+        const uint32_t* masks = region + sws2_mask_offset(nlev);
         int n = 0;
         for (int level = 0; level < nlev; ++level) {
             const int sl = side * nlev + level, a = roi[sl * 2], b = roi[sl * 2 + 1];
@@ -1425,16 +1426,11 @@ int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, 
     }
     if (r._pad == 2) {
         // k_band_fit2: one column mask and one first column per (side, row); row-major, ascending x
-        const uint32_t* block = c->d_pix + (size_t)slot * 2 * c->maxpix;
-        uint32_t hdr[4];
-        if ((rc = download(c, block, hdr, sizeof hdr))) return rc;
-        const int nrows = (int)hdr[0], top = (int)hdr[1];
+        const int nrows = (int)region[0], top = (int)region[1];
         const long long words = band2_block_words(nrows);
-        if (nrows < 0 || words > 2LL * c->maxpix) return fail(LT_ERR_STATE, "corrupt lane-pixel block");
-        std::vector<uint32_t> blk((size_t)words);
-        if ((rc = download(c, block, blk.data(), (size_t)words * 4))) return rc;
-        const int32_t* row_a = reinterpret_cast<const int32_t*>(blk.data() + 4) + (size_t)side * nrows;
-        const uint32_t* masks = blk.data() + band2_mask_offset(nrows) + (size_t)side * nrows * 2;
+        if (nrows < 0 || words > (long long)region_words) return fail(LT_ERR_STATE, "corrupt lane-pixel block");
+        const int32_t* row_a = reinterpret_cast<const int32_t*>(region + 4) + (size_t)side * nrows;
+        const uint32_t* masks = region + band2_mask_offset(nrows) + (size_t)side * nrows * 2;
         int n = 0;
         for (int ry = 0; ry < nrows; ++ry) {
             unsigned long long m = (unsigned long long)masks[2 * ry] | ((unsigned long long)masks[2 * ry + 1] << 32);
@@ -1449,17 +1445,101 @@ int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, 
         if (n > 0 && cap > 0 && (!ys || !xs)) return fail(LT_ERR_INVALID, "null pixel buffers");
         return LT_OK;
     }
+    // first-version kernels: packed (y << 16 | x) lists, side by side
     int n = side == 0 ? r.n_left : r.n_right;
     if (n > c->maxpix) n = c->maxpix;
     *count = n;
     if (n > cap) n = cap;
     if (n <= 0) return LT_OK;
     if (!ys || !xs) return fail(LT_ERR_INVALID, "null pixel buffers");
-    std::vector<uint32_t> tmp((size_t)n);
-    if ((rc = download(c, c->d_pix + ((size_t)slot * 2 + side) * c->maxpix, tmp.data(), (size_t)n * 4))) return rc;
+    const uint32_t* tmp = region + (size_t)side * c->maxpix;
     for (int i = 0; i < n; ++i) {
         ys[i] = (int32_t)(tmp[i] >> 16);
         xs[i] = (int32_t)(tmp[i] & 0xffffu);
+    }
+    return LT_OK;
+}
+
+int lt_download_pixels(lt_ctx* c, int slot, int side, int32_t* ys, int32_t* xs, int cap, int* count) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (side < 0 || side > 1 || !count || cap < 0) return fail(LT_ERR_INVALID, "bad side/count/cap");
+    if (!c->d_pix) return fail(LT_ERR_STATE, "no search has run yet");
+    lt_lane_record r;
+    if ((rc = download(c, c->d_rec + slot, &r, sizeof r))) return rc;
+    const uint32_t* block = c->d_pix + (size_t)slot * 2 * c->maxpix;
+    size_t words = 0;
+    if (r._pad == 1 || r._pad == 2) {
+        uint32_t hdr[4];
+        if ((rc = download(c, block, hdr, sizeof hdr))) return rc;
+        const long long w = r._pad == 1 ? sws2_block_words((int)hdr[0], (int)hdr[1]) : band2_block_words((int)hdr[0]);
+        if (w < 4 || w > 2LL * c->maxpix) return fail(LT_ERR_STATE, "corrupt lane-pixel block");
+        words = (size_t)w;
+    } else {
+        words = (size_t)c->maxpix + (size_t)std::min(std::max((int)r.n_right, 0), c->maxpix);     // both sides' lists, the right one as far as it goes
+        if (side == 0) words = (size_t)std::min(std::max((int)r.n_left, 0), c->maxpix);
+    }
+    std::vector<uint32_t> blk(std::max<size_t>(words, 4));
+    if (words && (rc = download(c, block, blk.data(), words * 4))) return rc;
+    return expand_pixels(c, r, blk.data(), blk.size(), side, ys, xs, cap, count);
+}
+
+// Both sides' lane pixels and (want_centroids) both window-centroid lists of a slot in ONE round trip to the device: the record, the
+// slot's list region and its centroid lists are copied into page-locked memory by three launches behind each other, the host waits
+// once and expands.  LaneTracker fetches the lists of a search lazily -- when somebody reads lt.left_x, or when the NEXT search over
+// the same slot is about to overwrite them (the second try of a frame, lane_tracker.py:1101: the first try's lists stay the
+// tracker's if the second finds nothing) -- and did so through lt_download_pixels / lt_download_centroids: fourteen round trips,
+// 300 us of a two-try frame (profiles/r06_config1_timeline.txt).  counts[2] / cent_counts[2] return the full lengths; lists longer
+// than cap / cent_cap are cut (call again with larger buffers).  LT_ERR_CAPACITY: the slot's region does not fit the staging
+// buffer (huge search windows) -- use lt_download_pixels / lt_download_centroids.
+int lt_download_lane_lists(lt_ctx* c, int slot, int32_t* ly, int32_t* lx, int32_t* ry, int32_t* rx, int cap, int* counts, int want_centroids,
+                           int32_t* cent_l, int32_t* cent_r, int cent_cap, int* cent_counts) {
+    int rc = check_slots(c, slot, 1);
+    if (rc) return rc;
+    if (!counts || cap < 0 || (want_centroids && (!cent_counts || cent_cap < 0))) return fail(LT_ERR_INVALID, "lt_download_lane_lists: bad arguments");
+    if (!c->d_pix) return fail(LT_ERR_STATE, "no search has run yet");
+    if (want_centroids && !c->d_cent) return fail(LT_ERR_STATE, "no sliding-window search has run yet");
+    if ((rc = set_device(c))) return rc;
+    const size_t region_words = 2 * (size_t)c->maxpix, cent_words = want_centroids ? 2 * ((size_t)c->maxlev + 2) : 0;
+    const size_t bytes = sizeof(lt_lane_record) + (region_words + cent_words) * 4;
+    if (bytes > ((size_t)2 << 20)) return fail(LT_ERR_CAPACITY, "lt_download_lane_lists: the slot's list region (%zu bytes) exceeds the staging buffer", bytes);
+    if (c->h_lists_bytes < bytes) {
+        if (c->h_lists) (void)hipHostFree(c->h_lists);
+        c->h_lists = nullptr;
+        c->h_lists_bytes = 0;
+        if (hipHostMalloc(reinterpret_cast<void**>(&c->h_lists), bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->h_lists = nullptr;
+            return fail(LT_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+        }
+        c->h_lists_bytes = bytes;
+    }
+    hipStream_t st = c->stream;
+    if (c->urgent_on && c->urgent) st = c->urgent;      // as in download(): what is asked for was produced on the urgent stream (or is complete)
+    else if ((rc = sync_all(c))) return rc;
+    uint8_t* h = c->h_lists;
+    bool ok = launch_copy_words_to_pinned(st, h, c->d_rec + slot, sizeof(lt_lane_record)) &&
+              launch_copy_words_to_pinned(st, h + sizeof(lt_lane_record), c->d_pix + (size_t)slot * region_words, region_words * 4);
+    if (ok && cent_words) ok = launch_copy_words_to_pinned(st, h + sizeof(lt_lane_record) + region_words * 4, c->d_cent + (size_t)slot * cent_words, cent_words * 4);
+    if (!ok) return fail(LT_ERR_HIP, "lt_download_lane_lists: the copy launches were refused");
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    lt_lane_record r;
+    std::memcpy(&r, h, sizeof r);
+    const uint32_t* region = reinterpret_cast<const uint32_t*>(h + sizeof(lt_lane_record));
+    if ((rc = expand_pixels(c, r, region, region_words, 0, ly, lx, cap, &counts[0]))) return rc;
+    if ((rc = expand_pixels(c, r, region, region_words, 1, ry, rx, cap, &counts[1]))) return rc;
+    if (want_centroids) {
+        const int32_t* cw = reinterpret_cast<const int32_t*>(region + region_words);
+        for (int side = 0; side < 2; ++side) {
+            const int32_t* t = cw + (size_t)side * (c->maxlev + 2);
+            int n = t[0];
+            if (n < 0) n = 0;
+            if (n > c->maxlev + 1) n = c->maxlev + 1;
+            cent_counts[side] = n;
+            int32_t* out = side == 0 ? cent_l : cent_r;
+            for (int i = 0; i < n && i < cent_cap && out; ++i) out[i] = t[1 + i];
+        }
     }
     return LT_OK;
 }
@@ -1519,7 +1599,7 @@ int lt_set_frame_base(lt_ctx* c, int first, int n, int first_frame) {
 }
 
 // ---- compute ------------------------------------------------------------------------------------------
-int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
+static int mask_run_impl(lt_ctx* c, int first, int n, const lt_filter_params* p, bool reuse_front) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
     if ((rc = validate_filter(p))) return rc;
@@ -1527,14 +1607,21 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     if (n == 0) return LT_OK;
     const size_t ps = c->plane_bytes;
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
-        { StageScope t(c, ST_UNDISTORT, st);
-          launch_undistort_rows(st, c->d_frames + (size_t)f0 * c->frame_bytes, c->frame_bytes, c->d_uxy, c->d_ufrac,
-                                c->fe, c->d_und, c->und_px, f0, m); }
-        { int mrc = n == 1 ? note_range_frame(c, c->readers, st, f0, f0 + m) : note_range(c->readers, st, f0, f0 + m); if (mrc) return mrc; }
-        { StageScope t(c, ST_WARP_SPLIT, st);
-          launch_warp_split(st, c->d_und, c->und_px, f0, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
-                            c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
-                            ps, m); }
+        // the front end -- unless the caller asked for a RE-run (lt_mask_rerun: the second try of a frame, other filter parameters
+        // over the same bird's-eye planes) and these slots' planes are those of the frames they hold
+        bool have_front = reuse_front && !c->stage_timing && f0 + m <= (int)c->front_ok.size();
+        for (int i = f0; have_front && i < f0 + m; ++i) have_front = c->front_ok[(size_t)i] != 0;
+        if (!have_front) {
+            { StageScope t(c, ST_UNDISTORT, st);
+              launch_undistort_rows(st, c->d_frames + (size_t)f0 * c->frame_bytes, c->frame_bytes, c->d_uxy, c->d_ufrac,
+                                    c->fe, c->d_und, c->und_px, f0, m); }
+            { int mrc = n == 1 ? note_range_frame(c, c->readers, st, f0, f0 + m) : note_range(c->readers, st, f0, f0 + m); if (mrc) return mrc; }
+            { StageScope t(c, ST_WARP_SPLIT, st);
+              launch_warp_split(st, c->d_und, c->und_px, f0, c->d_wxy, c->d_wfrac, c->fe, c->d_gamma,
+                                c->d_cbrt, c->d_coef, c->d_plane[P_R] + (size_t)f0 * ps, c->d_plane[P_B] + (size_t)f0 * ps,
+                                ps, m); }
+            for (int i = f0; i < f0 + m && i < (int)c->front_ok.size(); ++i) c->front_ok[(size_t)i] = 1;
+        }
         int frc = run_filter_chain(c, st, f0, m, p, c->calib.warp_h, c->calib.warp_w, n);
         return frc ? frc : note_written_frame(c, st, f0, f0 + m, n);
     });
@@ -1544,6 +1631,9 @@ int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     return LT_OK;
 }
 
+int lt_mask_run(lt_ctx* c, int first, int n, const lt_filter_params* p) { return mask_run_impl(c, first, n, p, false); }
+int lt_mask_rerun(lt_ctx* c, int first, int n, const lt_filter_params* p) { return mask_run_impl(c, first, n, p, true); }
+
 int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -1552,6 +1642,7 @@ int lt_filter_run(lt_ctx* c, int first, int n, const lt_filter_params* p) {
     if (!c->d_bev) return fail(LT_ERR_STATE, "lt_upload_bev has not been called");
     if (n == 0) return LT_OK;
     const size_t ps = c->plane_bytes;
+    front_stale(c, first, n);            // the planes become the uploaded bird's-eye image's
     rc = for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
         { StageScope t(c, ST_SPLIT_BEV, st);
           launch_split_bev(st, c->d_bev + (size_t)f0 * c->bev_bytes, c->bev_bytes, (int)ps, c->d_gamma, c->d_cbrt,

@@ -90,6 +90,10 @@ struct lt_ctx {
     // uploads bring parts only) / the WHOLE annotated frame has been drawn (lt_overlay_run; the row-run and strip overlays draw
     // parts).  Whole-frame overlays and downloads refuse slots that are not (LT_ERR_STATE).
     std::vector<uint8_t> frame_full, annot_full;
+    // per slot: the R / Lab-b planes (and the undistorted rows) are those of the camera rows the slot holds now -- set by lt_mask_run's
+    // front end, cleared by every upload of camera rows and by lt_filter_run.  A second lt_mask_run over such slots with other
+    // filter parameters (the second try of a frame, lane_tracker.py:1081-1101) skips the undistortion and the warp: same planes.
+    std::vector<uint8_t> front_ok;
     size_t bits_stride = 0;                                                  // u64 words per slot
     lt_lane_record* d_rec = nullptr;
     double* d_prev = nullptr;
@@ -191,6 +195,8 @@ struct lt_ctx {
     int* h_cancel = nullptr;                  // page-locked, device-visible: chains launched with an older epoch stop at their next frame
     int* d_cancel = nullptr;                  // its device address
     uint8_t* h_small = nullptr;               // page-locked scratch of the small downloads (download())
+    uint8_t* h_lists = nullptr;               // page-locked landing area of lt_download_lane_lists (record + list region + centroids)
+    size_t h_lists_bytes = 0;
     int ov_r0 = 0, ov_r1 = 0;                 // camera rows the lane overlay can change (lt_overlay_configure)
     lt_lane_record* h_rec = nullptr;          // page-locked mirror of the record of the last ONE-frame search (mirror_record)
     int rec_mirror_slot = -1;                 // the slot whose record the mirror holds once rec_mirror_stream is idle; -1: none

@@ -307,8 +307,13 @@ class LaneTracker(StreamPipeline):
             # lists when a radius lies within 1e-8 of an integer, which near-straight lanes do for frames on end).
             scope = ctx.urgent() if hasattr(ctx, "urgent") else contextlib.nullcontext()
             with scope:
-                self._lp['left_y'], self._lp['left_x'] = ctx.download_pixels(slot, 0)
-                self._lp['right_y'], self._lp['right_x'] = ctx.download_pixels(slot, 1)
+                try:
+                    if not hasattr(ctx, "download_lane_lists"):
+                        raise _native.NativeError("no combined download")
+                    self._lp['left_y'], self._lp['left_x'], self._lp['right_y'], self._lp['right_x'] = ctx.download_lane_lists(slot, False)[:4]
+                except _native.NativeError:
+                    self._lp['left_y'], self._lp['left_x'] = ctx.download_pixels(slot, 0)
+                    self._lp['right_y'], self._lp['right_x'] = ctx.download_pixels(slot, 1)
             if self._fit is not None and isinstance(self._fit[0], str):
                 self._fit = (self._lp['left_y'], self._lp['right_y'], self._fit[2], self._fit[3])
 
@@ -321,6 +326,24 @@ class LaneTracker(StreamPipeline):
             self._lp['right_window_centroids'] = ctx.download_centroids(slot, 1)
 
     def _materialise_pending(self):
+        # the usual case -- the lists of ONE sliding-window search, pixels and centroids of the same slot -- is one round trip to
+        # the device instead of fourteen (lt_download_lane_lists)
+        p, q = self._pending, self._pending_cent
+        if p is not None and q is not None and p[0] is q[0] and p[1] == q[1] and hasattr(p[0], "download_lane_lists"):
+            ctx, slot = p
+            self._pending = self._pending_cent = None
+            scope = ctx.urgent() if hasattr(ctx, "urgent") else contextlib.nullcontext()
+            try:
+                with scope:
+                    ly, lx, ry, rx, cl, cr = ctx.download_lane_lists(slot, True)
+            except _native.NativeError:          # (a list region beyond the staging buffer: the two calls)
+                self._pending, self._pending_cent = p, q
+            else:
+                self._lp['left_y'], self._lp['left_x'], self._lp['right_y'], self._lp['right_x'] = ly, lx, ry, rx
+                self._lp['left_window_centroids'], self._lp['right_window_centroids'] = cl, cr
+                if self._fit is not None and isinstance(self._fit[0], str):
+                    self._fit = (self._lp['left_y'], self._lp['right_y'], self._fit[2], self._fit[3])
+                return
         self._materialise_pixels()
         self._materialise_centroids()
 
@@ -362,9 +385,13 @@ class LaneTracker(StreamPipeline):
     def _search_uploaded(self, ctx, mode, kw, diagnostics, slot=0, lazy=False, between=None):
         """Launch the search over the mask in `slot` and collect its record; `between` (a callable) runs after the launch and
         before the wait -- host work that hides under the device's."""
-        if self._pending is not None and self._pending[0] is ctx and self._pending[1] == slot:
-            self._materialise_pixels()       # this search reuses the slot whose lists were not fetched yet
-        if mode == 'sws' and self._pending_cent is not None and self._pending_cent[0] is ctx and self._pending_cent[1] == slot:
+        pix_here = self._pending is not None and self._pending[0] is ctx and self._pending[1] == slot
+        cent_here = mode == 'sws' and self._pending_cent is not None and self._pending_cent[0] is ctx and self._pending_cent[1] == slot
+        if pix_here and cent_here:
+            self._materialise_pending()      # this search reuses the slot whose lists were not fetched yet: both in one round trip
+        elif pix_here:
+            self._materialise_pixels()
+        elif cent_here:
             self._materialise_centroids()    # ... and a sliding-window search rewrites the slot's centroid lists
         if mode == 'sws':
             ctx.sws_fit_run(1, _native.search_params(**kw), first=slot)
@@ -826,8 +853,9 @@ class LaneTracker(StreamPipeline):
         try:
             self._resident = (img, slot)
             if not have_mask:
+                # (reuse_frame: the second try of this frame -- the bird's-eye planes are there, only the filter differs)
                 ctx.mask_run(1, _native.filter_params(filter_type, ksize_r, C_r, ksize_b, C_b, mask_noise, noise_thresh,
-                                                      ksize_noise, C_noise), first=slot)
+                                                      ksize_noise, C_noise), first=slot, reuse_front=reuse_frame)
 
             if self._want_out and self._out is None and not reuse_frame:
                 # The output array, and its untouched rows on their way on the library's copy threads, BEFORE the search is launched:

@@ -242,12 +242,12 @@ class StreamPipeline:
             e2 = end
             if speculate is not None and end < k and v1[end] == 1:
                 spec = speculate(i + end + 1)                      # seeded on the device by the record the first try of frame `end` left
-            ctx.mask_run(e2, _native.filter_params(*[self._SECOND_TRY[x] for x in (4, 0, 1, 2, 3, 5, 6, 7, 8)]), first=base + i)
+            ctx.mask_run(e2, _native.filter_params(*[self._SECOND_TRY[x] for x in (4, 0, 1, 2, 3, 5, 6, 7, 8)]), first=base + i, reuse_front=True)
             rec2 = search(1, 0, e2)
             if rec2 is None:
                 if spec is not None:
                     ctx.band_fit_chain_cancel()
-                ctx.mask_run(e2, fp, first=base + i)
+                ctx.mask_run(e2, fp, first=base + i, reuse_front=True)
                 self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
                 return 1, bool(self.valid_lane_lines), None
             v2 = verdicts(rec2)
@@ -291,7 +291,7 @@ class StreamPipeline:
             if t == 0 and rec2 is not None and j < e2:
                 # the second try of that frame ran on its slot afterwards and found nothing: the lists this search left are
                 # the tracker's, so it is run again (same mask, same search: same lists)
-                ctx.mask_run(1, fp, first=base + i + j)
+                ctx.mask_run(1, fp, first=base + i + j, reuse_front=True)
                 search(0, j, j + 1)
             self._pending = (ctx, base + i + j)
             if j >= n_bs:
@@ -310,7 +310,7 @@ class StreamPipeline:
             if annotate:
                 deferred.append(('lane', (self.left_avg_y, self.left_avg_x, self.right_avg_y, self.right_avg_x), self._lane_text()))
         if e2 > committed:               # frames behind the last committed one still carry second-try masks
-            ctx.mask_run(e2 - committed, fp, first=base + i + committed)
+            ctx.mask_run(e2 - committed, fp, first=base + i + committed, reuse_front=True)
         if not committed:                # frame i itself needs the frame-by-frame route (a rank-deficient fit)
             self._step(frames[i], first_try, n_tries, False, slot=base + i, have_mask=True, lazy=True, annotate=annotate, defer=deferred)
             return 1, bool(self.valid_lane_lines), None

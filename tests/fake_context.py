@@ -101,7 +101,7 @@ class FakeContext:
         return list(self._slot(slot)["cent"][side])
 
     # -- compute
-    def mask_run(self, n, fp=None, first=0):
+    def mask_run(self, n, fp=None, first=0, reuse_front=False):
         fp = fp or _native.filter_params()
         key_fp = tuple(getattr(fp, f[0]) for f in fp._fields_)
         for k in range(n):

@@ -704,3 +704,56 @@ def test_config5_1080p_batch_masks_bit_exact(nat, oracle):
             assert bool(rec[k]["detected"]) == bool(o["detected"]) and int(rec[k]["n_left"]) == len(o["left_y"]), k
     finally:
         c.close()
+
+
+def test_mask_rerun_skips_the_front_end_only_while_the_planes_are_the_frames(nat, cal, oracle, ref_calib, frames):
+    """lt_mask_rerun (the second try of a frame, lane_tracker.py:1081-1101): another filter over the bird's-eye planes the first
+    lt_mask_run left -- the oracle's mask for the second parameter set; after an upload of new camera rows into a slot the planes
+    are stale and the re-run computes them again (the oracle's mask of the NEW frame, not of the old planes)."""
+    n = min(3, frames.shape[0])
+    c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=n)
+    try2 = dict(filter_type="neighborhood", C_r=5)
+    try:
+        c.upload_frames(frames[:n])
+        c.mask_run(n)
+        first = c.download_masks(n)
+        c.mask_run(n, nat.filter_params(**try2), reuse_front=True)
+        for k in range(n):
+            assert_same(c.download_masks(1, first=k)[0], oracle.mask_from_frame(ref_calib, frames[k], oracle.filter_params(**try2)), f"second try, slot {k}")
+        c.mask_run(n, reuse_front=True)                        # ... and back: the first try's masks again
+        assert np.array_equal(c.download_masks(n), first)
+        c.upload_frame_rows(frames[n - 1:n], first=0)          # slot 0 gets another frame's rows: its planes are stale
+        c.mask_run(1, nat.filter_params(**try2), first=0, reuse_front=True)
+        assert_same(c.download_masks(1, first=0)[0], oracle.mask_from_frame(ref_calib, frames[n - 1], oracle.filter_params(**try2)), "stale planes recomputed")
+        c.mask_run(1, first=1, reuse_front=True)               # slot 1 was not touched: still served from its planes
+        assert np.array_equal(c.download_masks(1, first=1)[0], first[1])
+    finally:
+        c.close()
+
+
+def test_lane_lists_in_one_round_trip_equal_the_piecewise_downloads(nat, cal, frames):
+    """lt_download_lane_lists against lt_download_pixels + lt_download_centroids: after a sliding-window search (column masks per
+    window row, centroids) and after a band search (column masks per band row) over the same slot."""
+    c = nat.Context(cal["img_size"], cal["warped_size"], cal["cam_matrix"], cal["dist_coeffs"], cal["warp_matrices"][0], device=0, capacity=2)
+    try:
+        c.upload_frames(frames[:2])
+        c.mask_run(2)
+        c.sws_fit_run(2)
+        rec = c.download_records(2)
+        for slot in (0, 1):
+            ly, lx, ry, rx, cl, cr = c.download_lane_lists(slot, True)
+            py0, px0 = c.download_pixels(slot, 0)
+            py1, px1 = c.download_pixels(slot, 1)
+            assert np.array_equal(ly, py0) and np.array_equal(lx, px0) and np.array_equal(ry, py1) and np.array_equal(rx, px1)
+            assert cl == c.download_centroids(slot, 0) and cr == c.download_centroids(slot, 1)
+            assert (len(ly), len(ry)) == (int(rec[slot]["n_left"]), int(rec[slot]["n_right"]))
+        if rec[0]["detected"]:
+            prev = np.concatenate([rec[0]["left_coeffs"], rec[0]["right_coeffs"]])
+            c.band_fit_run(1, prev[None], first=0)
+            ly, lx, ry, rx, cl, cr = c.download_lane_lists(0, False)
+            py0, px0 = c.download_pixels(0, 0)
+            py1, px1 = c.download_pixels(0, 1)
+            assert np.array_equal(ly, py0) and np.array_equal(lx, px0) and np.array_equal(ry, py1) and np.array_equal(rx, px1)
+            assert cl is None and cr is None and len(ly) > 0
+    finally:
+        c.close()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Device timeline of one process() frame from a rocprofv3 --kernel-trace --memory-copy-trace run of tools/process_loop.py:
 frames are cut at the dispatches of k_undistort_rows; per kernel / copy (in dispatch order) the median start and end in us from
-the start of the frame's undistortion, over the last frames of the run.  usage: process_timeline.py <dir>"""
+the start of the frame's undistortion, over the last frames of the run.  usage: process_timeline.py <dir> [undistortions per frame]
+(2 for a frame that takes both tries: tools/config1_loop.py)"""
 import collections, csv, glob, statistics, sys
 d = sys.argv[1]
 ev = []
@@ -12,7 +13,7 @@ for f in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", "?"), "-"))
 ev.sort()
-starts = [i for i, e in enumerate(ev) if "k_undistort_rows" in e[2]]
+starts = [i for i, e in enumerate(ev) if "k_undistort_rows" in e[2]][::int(sys.argv[2]) if len(sys.argv) > 2 else 1]
 frames = []
 for a, b in zip(starts[:-1], starts[1:]):
     # the upload of a frame precedes its undistortion: attach the copies between the previous frame's last kernel and this start
