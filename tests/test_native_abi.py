@@ -319,3 +319,48 @@ def test_release_library_reads_the_deployment_switches_and_no_others():
     a = api.index("int run_filter_chain(")
     body = api[a:api.index("\n}\n", a)]
     assert "getenv" not in body and "LT_EXP_ENV" not in body
+
+
+def test_copy_groups_survive_a_fork_and_two_submitters_do_not_starve_each_other():
+    """(1) the child of a fork() gets a fresh copier -- a completion group created before the fork must keep working
+    there (its id is taken over on first use) and the child's own groups must not collide with it; (2) pieces submitted by two
+    threads at once are all carried out promptly (the wake-up accounting counts what waits in the queue, not one submission)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys, threading, time
+sys.path.insert(0, %r)
+import numpy as np
+from lane_tracker_amd import _native
+lib = _native.load()
+g = _native.host_copy_group()
+src, dst = np.arange(1 << 20, dtype=np.uint8), np.zeros(1 << 20, np.uint8)
+assert lib.lt_host_copy_async_group(g, dst.ctypes.data, src.ctypes.data, src.size) == 0 and lib.lt_host_copy_wait_group(g) == 0
+pid = os.fork()
+if pid == 0:
+    d2 = np.zeros(1 << 20, np.uint8)
+    ok = lib.lt_host_copy_async_group(g, d2.ctypes.data, src.ctypes.data, src.size) == 0 and lib.lt_host_copy_wait_group(g) == 0 and np.array_equal(d2, src)
+    g2 = _native.host_copy_group()
+    os._exit(0 if ok and g2 != g else 3)
+_, status = os.waitpid(pid, 0)
+assert os.WEXITSTATUS(status) == 0, status
+# two submitters, one piece each, many times: every wait returns quickly
+def worker(k, out):
+    gg = _native.host_copy_group()
+    d = np.zeros(1 << 16, np.uint8)
+    worst = 0.0
+    for _ in range(300):
+        t0 = time.perf_counter()
+        assert lib.lt_host_copy_async_group(gg, d.ctypes.data, src.ctypes.data, d.size) == 0 and lib.lt_host_copy_wait_group(gg) == 0
+        worst = max(worst, time.perf_counter() - t0)
+    out[k] = worst
+    _native.host_copy_group_release(gg)
+res = {}
+ts = [threading.Thread(target=worker, args=(k, res)) for k in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+assert max(res.values()) < 0.25, res
+lib.lt_shutdown()
+print("ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-800:] + r.stderr[-1500:]
