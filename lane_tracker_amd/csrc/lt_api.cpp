@@ -705,11 +705,7 @@ int lt_create(const lt_calib* calib, int device, lt_ctx** out) {
     c->streams.assign(1, c->stream);
     c->nstreams = 1;
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) return bail(fail(LT_ERR_HIP, "hipEventCreate failed"));
-    if (stream_get(&c->copy, SK_PLAIN, 0) != hipSuccess ||
-        stream_get(&c->side, SK_PLAIN, 0) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
-        return bail(fail(LT_ERR_HIP, "side stream / event creation failed"));
+    if (stream_get(&c->copy, SK_PLAIN, 0) != hipSuccess) return bail(fail(LT_ERR_HIP, "copy stream creation failed"));
 
     // host tables
     const double t_tables = trace_on() ? trace_now() : 0.0;
@@ -793,9 +789,9 @@ void lt_destroy(lt_ctx* c) {
     note("streams of the slots");
     for (auto st : c->streams) if (st) (void)hipStreamSynchronize(st);
     {
-        const char* names[6] = {"copy", "side", "search", "present", "urgent", "dl"};
-        hipStream_t sts[6] = {c->copy, c->side, c->search, c->present, c->urgent, c->dl};
-        for (int i = 0; i < 6; ++i) if (sts[i]) { note(names[i]); (void)hipStreamSynchronize(sts[i]); }
+        const char* names[5] = {"copy", "search", "present", "urgent", "dl"};
+        hipStream_t sts[5] = {c->copy, c->search, c->present, c->urgent, c->dl};
+        for (int i = 0; i < 5; ++i) if (sts[i]) { note(names[i]); (void)hipStreamSynchronize(sts[i]); }
     }
     // Streams, events and page-locked buffers go FIRST, device memory after them.  Round 4 released the memory first, and when the
     // cache then handed blocks back to the driver (hipFree of several GB), the hipStreamDestroy of the presentation stream -- a
@@ -833,13 +829,10 @@ void lt_destroy(lt_ctx* c) {
     if (c->h_rec) (void)hipHostFree(c->h_rec);
     if (c->h_rec_stage) (void)hipHostFree(c->h_rec_stage);
     if (c->h_cancel) (void)hipHostFree(c->h_cancel);
-    note("streams back to the pool: search, copy, side");
+    note("streams back to the pool: search, copy");
     stream_put(c->search);
     stream_put(c->copy);
-    stream_put(c->side);
-    note("events: fork, join, timer");
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    note("events: timer");
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     note("streams back to the pool: slot streams");

@@ -41,8 +41,6 @@ struct lt_ctx {
     hipStream_t stream = nullptr;             // = streams[0]
     std::vector<hipStream_t> streams;         // slot s runs on streams[s * nstreams / capacity]
     hipStream_t copy = nullptr;               // lt_upload_frame_rest: the rows the path does not read, off the critical path
-    hipStream_t side = nullptr;               // second branch of a one- or two-frame chain (R and b top-hats side by side)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int nstreams = 1;
     hipDeviceProp_t prop{};
     lt::FrontEndGeom fe{};
