@@ -45,8 +45,9 @@ extern "C" {
 /* 5: + lt_device_cache_counters (hits / misses / evictions of the device-memory cache since the process started),
  *    lt_set_walk_min_frames (the batch size from which the threshold stage takes its walking kernels; was an environment
  *    switch), lt_host_memory_stats, lt_mask_rerun (a second parameter set over frames whose front end has run), lt_download_lane_lists (a search's lists in one
- *    round trip).  Nothing removed or
- *    changed. */
+ *    round trip), lt_set_direct_upload + lt_direct_upload_count (one frame's rows stored through the PCIe aperture),
+ *    lt_host_text_now_group (a frame's text lines drawn at once, behind the group's copies), lt_frame_tail (validity, average,
+ *    plot points, radius and eccentricity of a valid first try in one host call).  Nothing removed or changed. */
 #define LT_ABI_VERSION 5
 
 typedef enum lt_status {
@@ -153,6 +154,15 @@ int  lt_upload_frame_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot
  * waits for work launched over these slots afterwards has returned (lt_download_records of a search, lt_sync).  What
  * LaneTracker.process() uses (:876: one frame per call, the caller's array): the engine's copy runs under the mask chain's launches. */
 int  lt_upload_frame_rows_enqueue(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
+/* A small lt_upload_frame_rows_enqueue (at most 8 MB of rows: the one frame of a process() call) does not go to the copy engine
+ * where the device's memory is mapped into the process (large BAR): the calling thread stores the rows into the slot itself,
+ * through the PCIe aperture -- 20 us of bus time for a 1280x720 frame's 914 KB instead of 22-24 us of call + 23 us of engine
+ * copy + 6 us until the first kernel behind it.  The call then returns with the copy DONE (frames_rgb is the caller's again) after
+ * waiting, on the host, for kernels that still read those slots' camera rows.  Same bytes, same results.
+ * lt_set_direct_upload(ctx, on): 1 / 0 allows (the default) / forbids it, negative leaves the setting; returns 1 when such calls take
+ * the aperture on this context, 0 when not (no large BAR, memory not mapped, forbidden).  lt_direct_upload_count: calls that did. */
+int  lt_set_direct_upload(lt_ctx* ctx, int on);
+unsigned long long lt_direct_upload_count(lt_ctx* ctx);
 /* The same rows without the host wait: the copy is enqueued on the context's copy stream behind the work already
  * enqueued for these slots, and everything enqueued for them afterwards waits for it -- the upload of one slot range
  * runs under the chain of the others (double-buffered host-fed pipeline).  frames_rgb must stay valid (and should be
@@ -350,6 +360,17 @@ int  lt_lane_polygon_spans(int warp_h, const int32_t* left_yx, int n_left, const
  * n counts; left_yx / right_yx: room for n * n_rows (y, x) pairs each, written back to back. */
 int  lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const double* ploty, const double* ploty2, int n_rows,
                     int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx);
+/* Host-only (no GPU needed): what LaneTracker.process() computes between a frame's record and its text lines when the frame's first
+ * try is valid -- check_validity (:561-627), the running average of the fits (:1186-1187), get_poly_points of the averaged curves
+ * (:511-528), get_curve_radius through the pixel fit (:530-549) and get_eccentricity (:551-559) -- in the host's operations and
+ * order, in one call.  in: 22 doubles {left fit a b c, right fit a b c, sum of the window's other valid fits (6), divisor, the seven
+ * validity limits, metres per pixel vertical, horizontal}; ploty_v / ploty2_v: plot rows of partial = 1, ploty / ploty2: of the
+ * frame's partial; avg6, left_n .. right_yx: the averaged coefficients and their points as lt_poly_points leaves them; out: 5
+ * doubles {valid, not-reproduced flag, left radius, right radius, eccentricity}.  With the flag set the caller computes the frame the
+ * long way (a radius within 1e-8 of an integer, where upstream's refit decides int(); no plot point inside the image; ...). */
+int  lt_frame_tail(int warp_w, int warp_h, const double* in, const double* ploty_v, const double* ploty2_v, int n_rows_v, const double* ploty,
+                   const double* ploty2, int n_rows, double* avg6, int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx,
+                   double* out);
 /* annotated frames, RGB interleaved, n * img_h * img_w * 3 bytes */
 int  lt_download_overlay(lt_ctx* ctx, int first_slot, int n, uint8_t* out);
 /* The same copy enqueued behind the slots' overlay work without waiting: `out` (page-locked memory from lt_host_alloc, or
@@ -398,13 +419,18 @@ int  lt_strip_download_async(lt_ctx* ctx, int first_slot, int n, uint8_t* out, s
  *   lt_host_text_async_group  on the library's copy threads, in `group`: per frame, first copy two runs of rows {a0, a1, b0, b1}
  *                             (rows4; NULL or empty runs: nothing) of the source frame into the destination frame -- every row
  *                             the device does not deliver: above and below the lane's run -- then draw the lines over them.
- *                             `lines` is copied; the frames and the atlas must stay valid until the group's wait. */
+ *                             `lines` is copied; the frames and the atlas must stay valid until the group's wait.
+ *   lt_host_text_now_group    ONE frame, now: waits for `group` (whose copies bring the rows under the text), then draws the lines --
+ *                             the first on the calling thread, the others on copy threads that are polling at that moment (or here);
+ *                             returns with the text drawn.  LaneTracker.process(): no job, no second wait. */
 int  lt_text_blend_host(uint8_t* frames, size_t frame_stride, int n, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance,
                         int first_char, int n_glyphs, int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0,
                         int y0, int step);
 int  lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const uint8_t* src, size_t src_stride, int n, const int32_t* rows4,
                               int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char, int n_glyphs,
                               int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0, int y0, int step);
+int  lt_host_text_now_group(int group, uint8_t* frame, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char,
+                            int n_glyphs, int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0, int y0, int step);
 /* Page-locked host memory for buffers passed to the upload / download entry points (copies from or to pageable
  * memory run at a fraction of the PCIe rate).  Needs a GPU; lt_host_free(NULL) is a no-op.  The reference has no
  * counterpart: its frames are NumPy arrays on the host (lane_tracker.py:876, :662). */

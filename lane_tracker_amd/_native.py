@@ -128,6 +128,8 @@ _SIGNATURES = {
                                      C.c_int, C.c_int, C.c_int, C.c_int]),
     "lt_host_text_async_group": (C.c_int, [C.c_int, _P, C.c_size_t, _P, C.c_size_t, C.c_int, _P, C.c_int, C.c_int, _P, _P,
                                            C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "lt_host_text_now_group": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_int]),
     "lt_mask_run": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_mask_rerun": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(FilterParams)]),
     "lt_upload_bev": (C.c_int, [_P, _P, C.c_int, C.c_int]),
@@ -139,8 +141,11 @@ _SIGNATURES = {
     "lt_band_fit_chain_cancel": (C.c_int, [_P]),
     "lt_set_search_cus": (C.c_int, [_P, C.c_int]),
     "lt_set_walk_min_frames": (C.c_int, [_P, C.c_int]),
+    "lt_set_direct_upload": (C.c_int, [_P, C.c_int]),
+    "lt_direct_upload_count": (C.c_ulonglong, [_P]),
     "lt_set_urgent": (C.c_int, [_P, C.c_int]),
     "lt_poly_points": (C.c_int, [C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "lt_frame_tail": (C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "lt_download_overlay_wait": (C.c_int, [_P]),
     "lt_set_frame_base": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "lt_mask_batch": (C.c_int, [_P, _P, C.c_int, C.POINTER(FilterParams), _P]),
@@ -418,6 +423,19 @@ def host_text_async(group, dst, src, rows, font, text, n_lines, line_len=40, ori
                                            None if atlas is None else atlas.ctypes.data, None if advance is None else advance.ctypes.data,
                                            int(first_char), int(g), int(gw), int(gh), text, int(n_lines), int(line_len), int(origin[0]),
                                            int(origin[1]), int(step)))
+
+
+def host_text_now(group, frame, font, text, n_lines, line_len=40, origin=(20, 8), step=35):
+    """The text lines of ONE frame `frame` (1, H, W, 3) u8, drawn before the call returns and behind the copies of `group`
+    (lt_host_text_now_group): the wait for the rows under the text and the drawing in one call."""
+    f = _font_args.get(id(font))
+    if f is None or f[0] is not font:
+        atlas, advance, first_char = font
+        f = _font_args[id(font)] = (font, atlas.ctypes.data, advance.ctypes.data, int(first_char), atlas.shape[0], atlas.shape[2], atlas.shape[1])
+    rc = (_lib or load()).lt_host_text_now_group(group, frame.ctypes.data, frame.shape[1], frame.shape[2], f[1], f[2], f[3], f[4], f[5], f[6], text,
+                                                 n_lines, line_len, origin[0], origin[1], step)
+    if rc:
+        _check(rc)
 
 
 def host_copy_stats():
@@ -910,6 +928,17 @@ class Context:
     def set_walk_min_frames(self, frames):
         """Calls of at least `frames` frames take the walking threshold kernels (0: always; negative: the default, 80)."""
         _check(self.lib.lt_set_walk_min_frames(self._h, int(frames)))
+
+    def set_direct_upload(self, on=-1):
+        """One frame's rows (upload_frame_rows(enqueue=True) of a frame or two) stored by the calling thread through the PCIe
+        aperture instead of copied by the engine: True / False allows / forbids, -1 asks.  -> does this context take the aperture?"""
+        r = self.lib.lt_set_direct_upload(self._h, -1 if on == -1 else int(bool(on)))
+        if r < 0:
+            _check(r)
+        return bool(r)
+
+    def direct_upload_count(self):
+        return int(self.lib.lt_direct_upload_count(self._h))
 
     def urgent(self):
         """Context manager: the stage calls inside run on the context's urgent stream (lt_set_urgent) -- behind the work of their

@@ -12,11 +12,15 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <tuple>
 #include <vector>
+#include <immintrin.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <hip/hip_ext.h>
 
@@ -97,6 +101,7 @@ int note_range(lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi) {
 int note_range_frame(lt_ctx* c, lt_ctx::RangeEvents& r, hipStream_t st, int lo, int hi) {
     if (c->capacity <= 2 && !c->urgent_on && !c->stage_timing && c->nstreams == 1 && st == c->stream) {
         r.lazy = true;
+        ++r.lazy_seq;
         return LT_OK;
     }
     return note_range(r, st, lo, hi);
@@ -878,6 +883,7 @@ int lt_reserve(lt_ctx* c, int capacity) {
     c->capacity = capacity;
     const size_t n = (size_t)capacity;
     if ((rc = dev_alloc(&c->d_frames, n * c->frame_bytes + 16))) { free_slots(c); return rc; }   // +16: k_undistort_rows reads 8-byte windows
+    c->direct_upload = -1;               // a new frame buffer: whether the host can write it is found out by the first small upload
     if ((rc = dev_alloc(&c->d_und, (size_t)((n + 1) / 2) * 2 * c->und_px))) { free_slots(c); return rc; }
     for (int i : {(int)P_R, (int)P_B, (int)P_THR, (int)P_THB, (int)P_T0})     // the others when a path that uses them runs (ensure_plane)
         if ((rc = dev_alloc(&c->d_plane[i], n * c->plane_bytes))) { free_slots(c); return rc; }
@@ -1003,6 +1009,102 @@ int lt_get_source_rows(lt_ctx* c, int* row0, int* row1) {
 }
 
 static int wait_reader_tails(lt_ctx* c, hipStream_t waiter);
+
+// ---- one frame's rows through the PCIe aperture ----------------------------------------------------------------------------------
+// With a large BAR the whole device memory is mapped into the process, write-combining, at the addresses hipMalloc hands out: the
+// calling thread can store a frame's rows into the slot itself.  For the ONE frame of a LaneTracker.process() call that beats the
+// copy engine: hipMemcpy2DAsync costs the call 20-24 us before the engine even starts (23 us of copy + 6 us until the first
+// kernel behind it), the stores take the bus's 20 us for the 914 KB of a 1280x720 frame's rows and the undistortion can be
+// launched the moment they are out (tools/microbench/upload_latency.hip: rows + a dependent kernel 52 -> 43 us with nothing else
+// going on; NOTES_r06 E.6 for the frame).  The bytes are the same bytes; only their way differs.
+// Ordering: the stores end with an sfence and are posted writes of this thread, like the doorbell of the launch that follows
+// them; the kernels behind them start with an acquire that drops what the XCDs' L2s still hold of the slot's previous frame (as
+// between any two kernels), and the memory-side cache sees the bus's writes.  In front: the host waits for the kernels that still
+// read the slot's camera rows (an idle context: two or three stream queries).
+static bool host_has_mapped(const void* p, size_t n) {
+    const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
+    unsigned char v = 0;
+    auto mapped = [&](uintptr_t a) { return mincore((void*)(a & ~(pg - 1)), 1, &v) == 0; };
+    return n > 0 && mapped((uintptr_t)p) && mapped((uintptr_t)p + n - 1);
+}
+static bool direct_upload_possible(lt_ctx* c) {
+    if (c->direct_upload < 0)
+        c->direct_upload = c->prop.isLargeBar && c->d_frames && host_has_mapped(c->d_frames, (size_t)c->capacity * c->frame_bytes) ? 1 : 0;
+    return c->direct_upload == 1 && c->direct_upload_wanted;
+}
+__attribute__((target("avx2"))) static void store_stream_avx2(uint8_t* dst, const uint8_t* src, size_t n) {
+    size_t head = (32 - ((uintptr_t)dst & 31)) & 31;
+    if (head > n) head = n;
+    if (head) { std::memcpy(dst, src, head); dst += head; src += head; n -= head; }
+    size_t i = 0;
+    for (; i + 128 <= n; i += 128) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 32));
+        const __m256i d = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 64));
+        const __m256i e = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(src + i + 96));
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i), a);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 32), b);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 64), d);
+        _mm256_stream_si256(reinterpret_cast<__m256i*>(dst + i + 96), e);
+    }
+    if (i < n) std::memcpy(dst + i, src + i, n - i);
+}
+static void store_piece(uint8_t* dst, const uint8_t* src, size_t n) {
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) store_stream_avx2(dst, src, n);
+    else std::memcpy(dst, src, n);
+    _mm_sfence();
+}
+// One thread moves a frame's rows at what it can READ from memory the caller's frame lies cold in (30 us for 914 KB); two or three
+// reach the bus's 20 us (tools/microbench/upload_latency.hip, COLD=1).  The copy threads that are polling for work at this moment
+// (LaneTracker.process() keeps two or three of them warm with the rows of its output frames) are offered a piece each; pieces
+// nobody has claimed when the calling thread is through with its own are the calling thread's again -- no piece waits for a
+// sleeper, and none for a queue another tracker has filled.
+static void store_through_aperture(uint8_t* dst, const uint8_t* src, size_t n) {
+    const int helpers = n >= ((size_t)256 << 10) ? std::min(host_copy_pollers(), 2) : 0;
+    if (helpers <= 0) { store_piece(dst, src, n); return; }
+    struct Split {
+        std::atomic<int> claimed[3];
+        std::atomic<int> done{0};
+        uint8_t* dst; const uint8_t* src; size_t lo[4];
+        void run(int k) { store_piece(dst + lo[k], src + lo[k], lo[k + 1] - lo[k]); done.fetch_add(1, std::memory_order_release); }
+    };
+    auto sp = std::make_shared<Split>();
+    const int pieces = helpers + 1;
+    sp->dst = dst; sp->src = src;
+    for (int k = 0; k <= pieces; ++k) sp->lo[k] = k == pieces ? n : (n * (size_t)k / (size_t)pieces) & ~(size_t)127;
+    for (int k = 0; k < 3; ++k) sp->claimed[k].store(0, std::memory_order_relaxed);
+    sp->claimed[0].store(1, std::memory_order_relaxed);
+    for (int k = 1; k < pieces; ++k)
+        if (host_submit_fn(0, [sp, k] { if (!sp->claimed[k].exchange(1, std::memory_order_acq_rel)) sp->run(k); }, false) != 0) break;   // (not submitted: claimed below)
+    sp->run(0);
+    for (int k = 1; k < pieces; ++k)
+        if (!sp->claimed[k].exchange(1, std::memory_order_acq_rel)) sp->run(k);
+    while (sp->done.load(std::memory_order_acquire) < pieces) __builtin_ia32_pause();
+}
+// Does the host KNOW that no kernel reads the camera rows of slots [first, first + n) any more?  Asked without a call that could
+// cost the frame anything: hipStreamQuery on a stream whose last kernel carries no signal makes the runtime enqueue a marker and
+// wait for it (measured: process() 172 -> 198 us per frame with two such queries in front of the stores) -- so the answer comes
+// from what the library has seen itself: the recorded readers' events (a query of an existing signal), and for the unrecorded
+// ones of a one-frame context the completion word the host polled at the end of the previous frame (RangeEvents::lazy_seen).
+// "Not known" is not "busy": the caller then takes the engine's stream-ordered copy, which needs no answer.
+static bool camera_rows_known_idle(lt_ctx* c, int first, int n) {
+    const lt_ctx::RangeEvents& r = c->readers;
+    if (r.overflow || r.lazy_seen != r.lazy_seq) return false;
+    for (unsigned i = 0; i < r.count; ++i) {
+        const lt_ctx::RangeEvents::Entry& w = r.e[(r.head + i) % (unsigned)r.e.size()];
+        if (w.lo < first + n && w.hi > first && hipEventQuery(w.ev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    return true;
+}
+
+int lt_set_direct_upload(lt_ctx* c, int on) {
+    if (!c) return fail(LT_ERR_INVALID, "null context");
+    if (on >= 0) c->direct_upload_wanted = on != 0;
+    return direct_upload_possible(c) ? 1 : 0;
+}
+unsigned long long lt_direct_upload_count(lt_ctx* c) { return c ? c->direct_uploads : 0; }
+
 static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, int n, bool enqueue) {
     int rc = check_slots(c, first, n);
     if (rc) return rc;
@@ -1025,6 +1127,14 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
     // enqueue (lt_upload_frame_rows_enqueue): the copy on the slots' own streams, ahead of the kernels lt_mask_run puts there, and no
     // wait.  From the caller's pageable frame the call returns once the runtime has the bytes on their way (22-27 us for one
     // 1280x720 frame's rows against 49-54 with the wait: the engine's 18 us run under the mask chain's launches).
+    if (enqueue && !enqueue_syncs && (size_t)n * bytes <= ((size_t)8 << 20) && direct_upload_possible(c) && camera_rows_known_idle(c, first, n)) {
+        // a frame or two, and nothing left on the device that reads these slots' rows: by this thread's own stores (above); the
+        // caller's array is free again when the call returns
+        for (int k = 0; k < n; ++k)
+            store_through_aperture(c->d_frames + (size_t)(first + k) * c->frame_bytes + off, frames + (size_t)k * c->frame_bytes + off, bytes);
+        ++c->direct_uploads;
+        return LT_OK;
+    }
     if (enqueue)
         return for_each_slice(c, first, n, [&](hipStream_t st, int f0, int m) {
             if (!enqueue_syncs) {
@@ -1037,6 +1147,9 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
             // SLOWER, 195-218 against 183-186 us per 1280x720 frame -- every piece pays the call again; NOTES_r06 E.2)
             HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)f0 * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
                                      bytes, (size_t)m, hipMemcpyHostToDevice, st));
+            // (where a later small call could take the aperture, this copy counts as work on the slots' rows that the host has not
+            // seen finished: stores from the host must not be overtaken by it)
+            if (c->direct_upload == 1 && (size_t)m * bytes <= ((size_t)8 << 20)) return note_range_frame(c, c->readers, st, f0, f0 + m);
             return (int)LT_OK;
         });
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,

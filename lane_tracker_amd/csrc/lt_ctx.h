@@ -41,6 +41,13 @@ struct lt_ctx {
     hipStream_t stream = nullptr;             // = streams[0]
     std::vector<hipStream_t> streams;         // slot s runs on streams[s * nstreams / capacity]
     hipStream_t copy = nullptr;               // lt_upload_frame_rest: the rows the path does not read, off the critical path
+    // One frame's rows written by the calling thread straight into the slot through the PCIe aperture (lt_upload_frame_rows_enqueue of
+    // a small call; lt_set_direct_upload): -1 = not yet decided for the current frame buffer, 0 = no (no large BAR, the buffer is
+    // not mapped into this process, or switched off), 1 = yes.
+    int direct_upload = -1;
+    bool direct_upload_wanted = true;
+    unsigned long long lane_spec_reader_seq = 0;   // readers.lazy_seq when the completion word of lt_present_lane_from_fit_async was launched
+    unsigned long long direct_uploads = 0;    // calls that took the aperture (lt_set_direct_upload(ctx, -1) reports the state, tests read this through it)
     int nstreams = 1;
     hipDeviceProp_t prop{};
     lt::FrontEndGeom fe{};
@@ -177,7 +184,12 @@ struct lt_ctx {
         // two of them costs the frame ~6 us of device time each: profiles/r06_process_timeline.txt).  A waiter on another stream
         // then waits for the tails of the slots' streams, as after an overflow; cleared by the next full synchronisation.
         bool lazy = false;
-        void reset() { head = count = 0; overflow = false; lazy = false; }
+        // ... and how much of it the HOST has seen finished: every lazy note counts (`lazy_seq`); a completion word the host polls
+        // (lt_present_finish: the word stored behind the frame's overlay) carries the count at its launch, and seeing it moves
+        // `lazy_seen` there -- everything noted up to then ran in front of it on the same stream.  lazy_seq == lazy_seen: nothing
+        // unrecorded is in flight (the direct upload's question, lt_upload_frame_rows_enqueue).
+        unsigned long long lazy_seq = 0, lazy_seen = 0;
+        void reset() { head = count = 0; overflow = false; lazy = false; lazy_seen = lazy_seq; }
     };
     RangeEvents readers, writers;
     RangeEvents rests;                        // lt_upload_frame_rest copies (copy stream): the overlay of a slot waits for ITS rows only
@@ -240,6 +252,7 @@ int host_reserve(int group);                                 // a piece that wil
 void host_unreserve(int group);
 void host_after_event(hipEvent_t ev, int device, std::function<void()> then);   // `then` runs on the library's waiter thread once `ev` has fired
 int host_copy_threads();
+int host_copy_pollers();                                     // copy threads polling for work right now (they take a piece within a microsecond)
 void* pinned_block_acquire(size_t bytes);                    // page-locked staging, pooled per size (nullptr: allocation failed)
 void pinned_block_release(void* p, size_t bytes);
 hipEvent_t pooled_event();                                   // process-wide events (they outlive the context that recorded them)

@@ -692,6 +692,7 @@ int host_reserve(int group) { return host_copier().reserve(group); }
 void host_unreserve(int group) { host_copier().unreserve(group); }
 void host_after_event(hipEvent_t ev, int device, std::function<void()> then) { host_copier().after_event(ev, device, std::move(then)); }
 int host_copy_threads() { return host_copier().threads(); }
+int host_copy_pollers() { return std::max(host_copier().spinning.load(std::memory_order_relaxed), 0); }
 void* pinned_block_acquire(size_t bytes) { return pinned_blocks().acquire(bytes); }
 void pinned_block_release(void* p, size_t bytes) { pinned_blocks().release(p, bytes); }
 hipEvent_t pooled_event() {
@@ -834,6 +835,49 @@ int lt_host_text_async_group(int group, uint8_t* dst, size_t dst_stride, const u
         };
         if (host_submit_fn(group, fn, true)) return fail(LT_ERR_INVALID, "lt_host_text_async_group: unknown group %d", group);
     }
+    return LT_OK;
+}
+
+// One frame's text lines NOW: wait for the group (the rows under the text are among its copies), then draw -- line 0 on the calling
+// thread, the others offered to copy threads that are polling at this moment and drawn here if nobody has claimed them by then.  What
+// LaneTracker.process() calls once radius and eccentricity are known: one call and ~5 us of blending on its critical path where a
+// job for a copy thread (lt_host_text_async_group) cost the submission, the thread's start and a second wait (22 -> 12 us of the
+// frame, tools/process_points.py).
+int lt_host_text_now_group(int group, uint8_t* frame, int img_h, int img_w, const uint8_t* atlas, const uint8_t* advance, int first_char,
+                           int n_glyphs, int glyph_w, int glyph_h, const char* lines, int n_lines, int line_len, int x0, int y0, int step) {
+    if (img_h < 1 || img_w < 1 || n_lines < 0 || n_lines > 8 || line_len < 0) return fail(LT_ERR_INVALID, "lt_host_text_now_group: bad geometry");
+    if (host_copier().wait_group(group)) return fail(LT_ERR_INVALID, "lt_host_text_now_group: unknown group %d", group);
+    if (n_lines == 0 || line_len == 0) return LT_OK;
+    if (!frame || !atlas || !advance || !lines || n_glyphs < 1 || glyph_w < 1 || glyph_h < 1 || first_char < 0)
+        return fail(LT_ERR_INVALID, "lt_host_text_now_group: null or empty font / text / frame");
+    struct Lines {
+        std::atomic<int> claimed[8];
+        std::atomic<int> done{0};
+        std::vector<char> text;
+        std::function<void(int)> draw;
+        void run(int l) { draw(l); done.fetch_add(1, std::memory_order_release); }
+    };
+    auto one = [=](const char* text, int l) {
+        text_blend_frame(frame, img_h, img_w, atlas, advance, first_char, n_glyphs, glyph_w, glyph_h, text + (size_t)l * line_len, 1, line_len, x0,
+                         y0 + l * step, step);
+    };
+    const int helpers = std::min(host_copy_pollers(), n_lines - 1);
+    if (helpers <= 0) {
+        for (int l = 0; l < n_lines; ++l) one(lines, l);
+        return LT_OK;
+    }
+    auto sp = std::make_shared<Lines>();
+    sp->text.assign(lines, lines + (size_t)n_lines * line_len);
+    for (int l = 0; l < 8; ++l) sp->claimed[l].store(0, std::memory_order_relaxed);
+    Lines* raw = sp.get();
+    sp->draw = [one, raw](int l) { one(raw->text.data(), l); };
+    sp->claimed[0].store(1, std::memory_order_relaxed);
+    for (int l = 1; l <= helpers; ++l)
+        if (host_submit_fn(0, [sp, l] { if (!sp->claimed[l].exchange(1, std::memory_order_acq_rel)) sp->run(l); }, false) != 0) break;
+    sp->run(0);
+    for (int l = 1; l < n_lines; ++l)
+        if (!sp->claimed[l].exchange(1, std::memory_order_acq_rel)) sp->run(l);
+    while (sp->done.load(std::memory_order_acquire) < n_lines) __builtin_ia32_pause();
     return LT_OK;
 }
 

@@ -226,6 +226,91 @@ int lt_poly_points(int warp_w, int warp_h, const double* coeffs, int n, const do
     return LT_OK;
 }
 
+// The host's arithmetic between a frame's record and its text, for the frame LaneTracker.process() sees nearly always: a first try
+// whose fit is valid.  One call instead of five Python functions (fit_poly, _lane_ahead, check_validity, get_curve_radius,
+// get_eccentricity: 29 us of a 1280x720 frame's 56 us between the record and the return, tools/process_points.py) -- the same IEEE
+// operations in the same order, on the same libm (`pow` is the function CPython's float ** calls), and a flag instead of an answer
+// wherever the Python path does anything this function does not reproduce (the caller then takes that path; nothing was changed):
+//   in[0..2], in[3..5]   this frame's left / right fit (a, b, c)
+//   in[6..11], in[12]    the sum of the valid fits still in the averaging window (left, right; lt_present_lane_from_fit_async's
+//                        prev_sum) and the number of fits the average divides by, this frame's included
+//   in[13..19]           check_validity's limits: min / max distance at y1, y2, y3, tangent threshold (lane_tracker.py:588-593, :617)
+//   in[20], in[21]       metres per pixel, vertical and horizontal
+//   ploty_v / ploty2_v   the plot rows of partial = 1 (check_validity counts the points inside the image, :565-569);
+//   ploty / ploty2       those of the frame's `partial`: the averaged curves' points go to left_yx / right_yx (get_poly_points)
+//   avg6                 the averaged coefficients (np.average over the window, :1186-1187)
+//   out[0]               1 valid, 0 invalid (check_validity); out[1] = 1: not reproduced here (no plot point inside the image, a
+//                        radius that is not finite / is within 1e-8 of an integer -- upstream's refit of the pixels decides its
+//                        int() -- / is beyond 2e15), out[2], out[3] the left / right radius (int() of it, as a double),
+//                        out[4] the eccentricity in metres (:551-559)
+int lt_frame_tail(int warp_w, int warp_h, const double* in, const double* ploty_v, const double* ploty2_v, int n_rows_v, const double* ploty,
+                  const double* ploty2, int n_rows, double* avg6, int32_t* left_n, int32_t* right_n, int32_t* left_yx, int32_t* right_yx,
+                  double* out) {
+    if (warp_w < 1 || warp_h < 1 || !in || !avg6 || !left_n || !right_n || !left_yx || !right_yx || !out || n_rows < 0 || n_rows_v < 0 ||
+        (n_rows && (!ploty || !ploty2)) || (n_rows_v && (!ploty_v || !ploty2_v)))
+        return fail(LT_ERR_INVALID, "lt_frame_tail: bad arguments");
+    const double* lf = in;
+    const double* rf = in + 3;
+    out[0] = out[1] = out[2] = out[3] = out[4] = 0.0;
+    // ---- check_validity (:561-627) ----
+    const double xmax = (double)(warp_w - 1);
+    int cnt_v[2];
+    for (int side = 0; side < 2; ++side) {
+        const double a = in[3 * side], b = in[3 * side + 1], cc = in[3 * side + 2];
+        int cnt = 0;
+        for (int r = 0; r < n_rows_v; ++r) {
+            const double x = (a * ploty2_v[r] + b * ploty_v[r]) + cc;
+            cnt += (x <= xmax && x >= 0.0) ? 1 : 0;
+        }
+        cnt_v[side] = cnt;
+    }
+    const int nv = std::min(cnt_v[0], cnt_v[1]);
+    const long long y1 = warp_w - 1, y2 = warp_w - (long long)((double)nv * 0.35), y3 = warp_w - (long long)((double)nv * 0.75);   // (the WIDTH, as upstream)
+    auto at = [](const double* c, long long y) { return (c[0] * (double)(y * y) + c[1] * (double)y) + c[2]; };
+    auto slope = [](const double* c, long long y) { return (2.0 * c[0]) * (double)y + c[1]; };
+    const double x1d = std::fabs(at(lf, y1) - at(rf, y1)), x2d = std::fabs(at(lf, y2) - at(rf, y2)), x3d = std::fabs(at(lf, y3) - at(rf, y3));
+    const double* lim = in + 13;
+    bool valid = !((x1d < lim[0]) || (x1d > lim[1]) || (x2d < lim[2]) || (x2d > lim[3]) || (x3d < lim[4]) || (x3d > lim[5]));
+    if (x1d != x1d || x2d != x2d || x3d != x3d) { out[1] = 1.0; return LT_OK; }     // (NaN: the Python path's comparisons decide)
+    if (valid) {
+        const double n1 = std::fabs(slope(lf, y1) - slope(rf, y1)), n2 = std::fabs(slope(lf, y3) - slope(rf, y3));
+        if (n1 != n1 || n2 != n2) { out[1] = 1.0; return LT_OK; }
+        valid = !((n1 >= lim[6]) || (n2 >= lim[6]));
+    }
+    out[0] = valid ? 1.0 : 0.0;
+    if (!valid) return LT_OK;
+    // ---- the running average with this fit last (:1186-1187: np.average over the window = sequential sum, one division) ----
+    const double count = in[12];
+    if (!(count >= 1.0)) { out[1] = 1.0; return LT_OK; }
+    for (int k = 0; k < 6; ++k) avg6[k] = (count > 1.0 ? in[6 + k] + in[k] : in[k]) / count;
+    // ---- get_poly_points of the averaged curves (:511-528) ----
+    int rc = lt_poly_points(warp_w, warp_h, avg6, 1, ploty, ploty2, n_rows, left_n, right_n, left_yx, right_yx);
+    if (rc) return rc;
+    if (left_n[0] < 1 || right_n[0] < 1) { out[1] = 1.0; return LT_OK; }
+    // ---- get_curve_radius (:530-549), through the pixel fit's coefficients in metric units ----
+    // (libm's pow through a pointer the compiler cannot see through: `x ** 2` in Python is pow(x, 2.0) at run time, and a compiler
+    // that rewrites the call as x * x -- always allowed, always done -- may differ from it in the last bit)
+    static double (*volatile const libm_pow)(double, double) = ::pow;
+    const double mppv = in[20], mpph = in[21], y_eval = (double)warp_h;
+    for (int side = 0; side < 2; ++side) {
+        const double* c = in + 3 * side;
+        const double a = c[0] * mpph / libm_pow(mppv, 2.0), b = c[1] * mpph / mppv;
+        if (a == 0.0) { out[1] = 1.0; return LT_OK; }
+        const double t = ((2.0 * a) * y_eval) * mppv + b;
+        const double val = libm_pow(1.0 + libm_pow(t, 2.0), 1.5) / std::fabs(2.0 * a);
+        if (!std::isfinite(val) || std::fabs(val) >= 2e15 || std::fabs(val - std::nearbyint(val)) <= 1e-8 * std::max(1.0, std::fabs(val))) {
+            out[1] = 1.0;
+            return LT_OK;
+        }
+        out[2 + side] = std::trunc(val);
+    }
+    // ---- get_eccentricity (:551-559): the last plot point of each averaged curve ----
+    const long long mid = (long long)((double)warp_w / 2.0);
+    const long long xl = left_yx[2 * (left_n[0] - 1) + 1], xr = right_yx[2 * (right_n[0] - 1) + 1];
+    out[4] = ((double)((mid - xl) - (xr - mid)) / 2.0) * mpph;
+    return LT_OK;
+}
+
 // lt_overlay_run; rows4: two runs of camera rows {a0, a1, b0, b1} outside which the annotated frames are not needed
 // (lt_present_frame, lt_overlay_run_rows), nullptr = all of them
 // strip mode: the rows the lane can reach (lt_overlay_rows) of every slot, packed, into the context's strip buffer
@@ -763,6 +848,7 @@ int lt_present_lane_from_fit_async(lt_ctx* c, int slot, const double* prev_sum, 
         }
         HIP_TRY(hipGetLastError());
         int nrc = note_range_frame(c, c->readers, st, f0, f0 + 1);   // the next upload into this slot waits for the overlay's reads
+        c->lane_spec_reader_seq = c->readers.lazy_seq;               // (what the completion word, once seen, proves finished)
         return nrc ? nrc : note_range_frame(c, c->writers, st, f0, f0 + 1);   // ... and an overlay on the presentation stream for this one's stores
     });
 }
@@ -828,6 +914,8 @@ int lt_present_finish(lt_ctx* c, int slot, const char* lines, int n_lines, int l
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (!seen) HIP_TRY(hipStreamSynchronize(c->lane_spec_stream));
+        // the word sits behind the frame's overlay on the slot's stream: every unrecorded reader noted up to its launch is done
+        if (c->readers.lazy && c->lane_spec_stream == c->stream && c->lane_spec_reader_seq > c->readers.lazy_seen) c->readers.lazy_seen = c->lane_spec_reader_seq;
         c->lane_spec_stream = nullptr;
         c->lane_spec_ticket = 0;
     }

@@ -443,6 +443,17 @@ class LaneTracker(StreamPipeline):
         """get_poly_points through lt_poly_points (host C, the same f64 operations in the same order; pinned to the reference's
         fixtures by tests/test_host_geometry.py) into buffers this tracker keeps per (partial, purpose) -> the buffers:
         [0] the six coefficients, [1] int32 counts (left, right), [2] / [3] the left / right (y, x) pairs, [4] addresses."""
+        b = self._packed_buffers(partial, purpose)
+        co = b[0]
+        co[:3] = left_fit_coeffs
+        co[3:] = right_fit_coeffs
+        rc = b[5](*b[4])
+        if rc:
+            _native._check(rc)
+        return b
+
+    def _packed_buffers(self, partial, purpose):
+        """The buffers of _points_packed for (partial, purpose), created on first use (nothing is computed)."""
         packed = self.__dict__.setdefault("_packed", {})
         b = packed.get((partial, purpose))
         if b is None:
@@ -453,12 +464,6 @@ class LaneTracker(StreamPipeline):
             args = (int(self.warped_size[0]), int(self.warped_size[1]), co.ctypes.data, 1, ploty.ctypes.data, ploty2.ctypes.data,
                     rows, cnt.ctypes.data, cnt.ctypes.data + 4, lyx.ctypes.data, ryx.ctypes.data)
             b = packed[(partial, purpose)] = (co, cnt, lyx, ryx, args, _native.load().lt_poly_points, (ploty, ploty2))
-        co = b[0]
-        co[:3] = left_fit_coeffs
-        co[3:] = right_fit_coeffs
-        rc = b[5](*b[4])
-        if rc:
-            _native._check(rc)
         return b
 
     def get_poly_points(self, left_fit_coeffs, right_fit_coeffs, partial=1):
@@ -545,6 +550,10 @@ class LaneTracker(StreamPipeline):
                 with _hostcpu.blas_limited():     # (LAPACK on no more threads than the CPUs granted, for this call only: hostcpu.py)
                     val = radius_of(np.polyfit(np.asarray(ys) * self.mppv, np.asarray(xs) * self.mpph, 2))
             radii.append(int(val))
+        self._note_radii(radii)
+
+    def _note_radii(self, radii):
+        """left / right radius of this frame -> the running average over the window (reference :544-549)."""
         self.left_curve_radius, self.right_curve_radius = radii
         average_curve_radius = int(0.5 * (self.left_curve_radius + self.right_curve_radius))
         self.average_curve_radii.append(average_curve_radius)
@@ -773,6 +782,7 @@ class LaneTracker(StreamPipeline):
         finally:
             self._copies_done()          # the rows the host fills itself
 
+    text_now = True             # False: the text lines as a job for a copy thread (lt_host_text_async_group), waited for in _present
     _text_in_flight = None      # (output frame, lines) whose text a copy thread is blending (_text_early), until _present has waited for it
 
     def _text_early(self):
@@ -782,6 +792,14 @@ class LaneTracker(StreamPipeline):
         the same threads long ago (`_prepare_out`); they are waited for first all the same."""
         out, lines = self._out, self._lane_text()
         if out is None or len(lines) > 3:
+            return
+        if self.text_now:
+            # ... or, since the overlap is only a few microseconds wide by now, drawn right here: ONE call waits for the rows and
+            # draws (the lines spread over the copy threads that happen to be polling) -- no job, no second wait in _present
+            text, nl = _native.text_bytes([lines])
+            _native.host_text_now(self._copy_group(), out, _overlay.font_atlas(), text, nl, 40, self._TEXT_ORIGIN, self._TEXT_STEP)
+            self._copying, self._copy_keepalive = False, None        # (the call has waited for the group)
+            self._text_in_flight = (out, lines)
             return
         self._copies_done()
         text, nl = _native.text_bytes([lines])
@@ -1013,6 +1031,75 @@ class LaneTracker(StreamPipeline):
             self.get_curve_radius()
             self.get_eccentricity()
 
+    fast_tail = True            # False: a valid first try's bookkeeping by the Python functions one after the other (A/B, tests)
+
+    def _tail_fast(self, partial):
+        """The frame process() sees nearly always -- a first try the device has searched, fitted and drawn, about to turn out valid
+        -- between its record and its text lines in ONE host call (lt_frame_tail: check_validity, the running average, its plot
+        points, radius, eccentricity: the operations of fit_poly / _lane_ahead / check_validity / _record_success / get_curve_radius
+        in their order) instead of 29 us of Python.  -> True: valid, the state is what _record_success leaves (text lines on their
+        way); False: check_validity says no (nothing else changed); None: not this frame -- the caller goes the long way, from an
+        unchanged state (a radius whose int() upstream's refit decides, a fit the host refitted, no device-drawn lane, ...)."""
+        fit = self._fit
+        if not (fit is not None and isinstance(fit[0], str) and not self._fit_flags and self._device_lane is not None
+                and self._out is not None and self._out_rows is not None and self._out_ahead and self._out_host_text
+                and self._have_font and self.speculates_lane and type(self.mppv) is float and type(self.mpph) is float):
+            return None
+        keep = self._avg_packed[0] if self._avg_packed is not None else None
+        purpose = 'avg1' if keep is not None and keep is self.__dict__.get("_packed", {}).get((partial, 'avg0')) else 'avg0'
+        b = self._packed_buffers(partial, purpose)
+        if b is keep:
+            return None
+        t = self.__dict__.get("_tail")
+        if t is None:
+            t = self._tail = (np.zeros(24, np.float64), np.zeros(8, np.float64), {}, _native.load().lt_frame_tail)
+        inp, out, argsets, fn = t
+        args = argsets.get((partial, purpose))
+        if args is None:
+            pv, pv2 = self._plot_rows(1)
+            pp, pp2 = b[6]
+            args = argsets[(partial, purpose)] = (int(self.warped_size[0]), int(self.warped_size[1]), inp.ctypes.data, pv.ctypes.data,
+                                                  pv2.ctypes.data, len(pv), pp.ctypes.data, pp2.ctypes.data, len(pp), b[0].ctypes.data,
+                                                  b[1].ctypes.data, b[1].ctypes.data + 4, b[2].ctypes.data, b[3].ctypes.data, out.ctypes.data)
+        lim = self.validity_limits
+        try:
+            inp[0:3] = fit[2]
+            inp[3:6] = fit[3]
+            inp[6:12] = self._prev_sum
+            inp[12] = self._device_lane[0]
+            inp[13:22] = (lim['min_dist_y1'], lim['max_dist_y1'], lim['min_dist_y2'], lim['max_dist_y2'], lim['min_dist_y3'],
+                          lim['max_dist_y3'], lim['thresh'], self.mppv, self.mpph)
+        except (TypeError, ValueError, KeyError):
+            return None
+        if fn(*args) or out[1]:
+            return None
+        if not out[0]:
+            self.valid_lane_lines = False
+            return False
+        # valid: what _lane_ahead, check_validity and _record_success (with the lane ahead and the text early) leave
+        lf, rf = fit[2].copy(), fit[3].copy()
+        self.valid_lane_lines = True
+        self._lane_in_flight = b
+        self.left_fit_coeffs.append(lf)
+        self.right_fit_coeffs.append(rf)
+        self.last_left_coeffs = lf
+        self.last_right_coeffs = rf
+        if len(self.left_fit_coeffs) > self.n_average:
+            self.left_fit_coeffs.pop(0)
+            self.right_fit_coeffs.pop(0)
+        self.last_detection = 0
+        self.success += 1
+        co = b[0]
+        self.left_avg_coeffs, self.right_avg_coeffs = co[:3].copy(), co[3:].copy()
+        nl, nr, H = int(b[1][0]), int(b[1][1]), self.warped_size[1]
+        self._note_radii([int(out[2]), int(out[3])])
+        self.eccentricity = out[4] * 1.0          # (an np.float64 of its own, as the NumPy scalars of get_eccentricity give)
+        self._text_early()
+        self.left_avg_y, self.left_avg_x = np.arange(H - nl, H, dtype=np.int64), b[2][:nl, 1].astype(np.int64)
+        self.right_avg_y, self.right_avg_x = np.arange(H - nr, H, dtype=np.int64), b[3][:nr, 1].astype(np.int64)
+        self._avg_packed = (b, self.left_avg_x, self.right_avg_x)
+        return True
+
     # ---- process (reference :876-1209) -----------------------------------------------------------------------
     def process(self, img, ksize_r=15, C_r=8, ksize_b=35, C_b=5, filter_type='bilateral', mask_noise=False,
                 noise_thresh=140, ksize_noise=65, C_noise=10, window_width=30, window_height=40, search_range=20,
@@ -1061,13 +1148,17 @@ class LaneTracker(StreamPipeline):
         search_mode = self._find_lane_points_device(img, *first_try, diagnostics, reuse_frame=have_mask, slot=slot,
                                                     have_mask=have_mask, lazy=lazy)
         spec = None
+        fast = None
         if self.detected_pixels:
-            left_fit_coeffs, right_fit_coeffs = self.fit_poly()
-            if self._out_rows is not None and self._out_ahead and self.speculates_lane:
-                spec = self._lane_ahead(left_fit_coeffs, right_fit_coeffs, partial, slot)
-            self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
-            if diagnostics and self.valid_lane_lines:
-                print("Success at first attempt!")
+            if self.fast_tail and self._want_out and not (diagnostics or visualize_search or split_view):
+                fast = self._tail_fast(partial)
+            if fast is None:
+                left_fit_coeffs, right_fit_coeffs = self.fit_poly()
+                if self._out_rows is not None and self._out_ahead and self.speculates_lane:
+                    spec = self._lane_ahead(left_fit_coeffs, right_fit_coeffs, partial, slot)
+                self.check_validity(left_fit_coeffs, right_fit_coeffs, diagnostics)
+                if diagnostics and self.valid_lane_lines:
+                    print("Success at first attempt!")
             if not self.valid_lane_lines:
                 spec = self._lane_in_flight = None      # drawn for nothing: whatever is presented later draws everything again
 
@@ -1123,6 +1214,8 @@ class LaneTracker(StreamPipeline):
             return present(self.draw_lane(img) if redraw else self.print_failure(img))
 
         # success (:1178-1209)
+        if fast:                            # (recorded by _tail_fast already, text lines included)
+            return present(self.draw_lane(img))
         on_text = None
         if spec is not None and self._want_out and self._out is not None and self._out_host_text and self._out_rows is not None \
                 and self._have_font and not (visualize_search or split_view):

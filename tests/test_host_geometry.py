@@ -363,3 +363,100 @@ def test_record_success_keeps_the_points_of_get_poly_points():
         assert (int(b[1][0]), int(b[1][1])) == (len(want[0]), len(want[2]))
         assert np.array_equal(b[2][:len(want[0])], np.stack([want[0], want[1]], 1))
         assert np.array_equal(b[3][:len(want[2])], np.stack([want[2], want[3]], 1))
+
+
+def test_frame_tail_is_the_python_functions():
+    """lt_frame_tail (one host call between a valid first try's record and its text lines) against the functions it stands for:
+    check_validity, the running average (_averages_with), get_poly_points of the average (_points_packed), get_curve_radius on
+    the pixel fit, get_eccentricity -- bit for bit, on and around the validity limits, with custom limits, for lanes that are nearly
+    straight, leave the image or fail; and the not-reproduced flag exactly where the Python path does something else (a radius
+    next to an integer, no plot point inside the image)."""
+    import math
+    from lane_tracker_amd import _native
+    from lane_tracker_amd.lane_tracker import _mean_of_rows
+    fn = _native.load().lt_frame_tail
+    rng = np.random.default_rng(2024)
+    seen = {"valid": 0, "invalid": 0, "flag": 0, "integer": 0}
+    for i in range(6000):
+        size = [(1080, 1100), (1280, 720), (640, 480)][i % 3]
+        t = _bare_tracker(size)
+        W, H = size
+        if i % 5 == 0:
+            t.validity_limits = dict(min_dist_y1=rng.uniform(50, 160), max_dist_y1=rng.uniform(200, 600), min_dist_y2=rng.uniform(40, 120),
+                                     max_dist_y2=rng.uniform(200, 600), min_dist_y3=rng.uniform(30, 90), max_dist_y3=rng.uniform(180, 600),
+                                     thresh=rng.uniform(0.1, 0.6))
+        partial = (1.0, 1, 0.5, 0.3)[(i // 3) % 4]
+        scale = 10.0 ** rng.uniform(-7.5, -3.3)
+        lf = np.array([rng.choice([-1, 1]) * scale, rng.uniform(-0.3, 0.3), rng.uniform(0.2, 0.45) * W])
+        sep = rng.choice([80.0, 110.0, 150.0, 200.0, 230.0, rng.uniform(60, 260), 190.0, 175.0])
+        d_slope = rng.choice([0.25, -0.25, 0.2499999999999, rng.uniform(-0.3, 0.3)]) if i % 4 == 0 else rng.uniform(-0.04, 0.04)
+        rf = lf + np.array([rng.uniform(-1, 1) * scale * 0.1, d_slope, sep])
+        if i % 37 == 0:
+            lf[2] -= 3 * W                                               # both curves outside the image: no plot point
+            rf[2] -= 3 * W
+        if i % 41 == 0:                                                  # a radius that IS an integer: upstream's refit decides
+            a_m = lambda c: c[0] * t.mpph / (t.mppv ** 2)
+            lf[1] = 0.0 - 2 * lf[0] * H                                  # tangent 0 at y_eval: radius = 1 / |2 a_m|
+            lf[0] = np.sign(lf[0]) * t.mppv ** 2 / (2.0 * t.mpph * float(rng.integers(50, 5000)))
+            lf[1] = -2 * lf[0] * H
+        hist = [np.array([rng.uniform(-1e-4, 1e-4), rng.uniform(-0.2, 0.2), rng.uniform(300, 500)]) for _ in range(int(rng.integers(0, 3)))]
+        hist_r = [h + np.array([0.0, 0.0, 180.0]) for h in hist]
+        # ---- the Python functions ----
+        t.valid_lane_lines = None
+        t.check_validity(lf, rf)
+        want_valid = t.valid_lane_lines
+        la, ra = _mean_of_rows(hist + [lf]), _mean_of_rows(hist_r + [rf])
+        wb = t._points_packed(la, ra, partial, 'want')
+        want_flag, want_r = False, None
+        if want_valid:
+            if int(wb[1][0]) < 1 or int(wb[1][1]) < 1:
+                want_flag = True
+            else:
+                t._fit = ("pending", None, lf, rf)
+                t.average_curve_radii = []
+                try:
+                    t.get_curve_radius()
+                    want_r = (t.left_curve_radius, t.right_curve_radius)
+                except (AttributeError, OverflowError, ValueError):      # next to an integer: the pixel lists are asked for (none here)
+                    want_flag = True
+                    seen["integer"] += 1
+                if not want_flag:
+                    mid = int(W / 2)
+                    want_ecc = (((mid - np.int64(wb[2][int(wb[1][0]) - 1, 1])) - (np.int64(wb[3][int(wb[1][1]) - 1, 1]) - mid)) / 2) * t.mpph
+        # ---- the one call ----
+        inp, out = np.zeros(24), np.full(8, -7.0)
+        inp[0:3], inp[3:6] = lf, rf
+        if hist:
+            sl, sr = hist[0], hist_r[0]
+            for h, g in zip(hist[1:], hist_r[1:]):
+                sl, sr = sl + h, sr + g
+            inp[6:9], inp[9:12] = sl, sr
+        inp[12] = len(hist) + 1
+        lim = t.validity_limits
+        inp[13:22] = (lim['min_dist_y1'], lim['max_dist_y1'], lim['min_dist_y2'], lim['max_dist_y2'], lim['min_dist_y3'], lim['max_dist_y3'],
+                      lim['thresh'], t.mppv, t.mpph)
+        pv, pv2 = t._plot_rows(1)
+        gb = t._packed_buffers(partial, 'got')
+        pp, pp2 = gb[6]
+        gb[1][:] = -1
+        rc = fn(W, H, inp.ctypes.data, pv.ctypes.data, pv2.ctypes.data, len(pv), pp.ctypes.data, pp2.ctypes.data, len(pp), gb[0].ctypes.data,
+                gb[1].ctypes.data, gb[1].ctypes.data + 4, gb[2].ctypes.data, gb[3].ctypes.data, out.ctypes.data)
+        assert rc == 0
+        if out[1]:
+            assert want_valid and want_flag, (i, lf, rf)
+            seen["flag"] += 1
+            continue
+        assert bool(out[0]) == bool(want_valid), (i, lf, rf)
+        if not want_valid:
+            seen["invalid"] += 1
+            continue
+        assert not want_flag, (i, lf, rf)
+        seen["valid"] += 1
+        assert gb[0][:3].tobytes() == la.tobytes() and gb[0][3:].tobytes() == ra.tobytes(), i
+        nl, nr = int(wb[1][0]), int(wb[1][1])
+        assert (int(gb[1][0]), int(gb[1][1])) == (nl, nr), i
+        assert np.array_equal(gb[2][:nl], wb[2][:nl]) and np.array_equal(gb[3][:nr], wb[3][:nr]), i
+        assert (int(out[2]), int(out[3])) == want_r, (i, lf, rf)
+        assert np.float64(out[4]).tobytes() == np.float64(want_ecc).tobytes(), i
+        assert math.isfinite(out[4])
+    assert seen["valid"] > 1200 and seen["invalid"] > 500 and seen["flag"] > 20 and seen["integer"] > 5, seen

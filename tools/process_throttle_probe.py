@@ -2,7 +2,8 @@
 """Is process() slowed down by the cgroup's CPU quota?  bench.py's process() leg (a window of 256 rendered frames, one frame
 per call) at one size, with /sys/fs/cgroup/cpu.stat (nr_throttled, throttled_usec) read before and after, the per-call wall
 times of tools/process_trace.py and the spread of the frame times.
-  python tools/process_throttle_probe.py 1920x1080 [seconds]     (environment: LT_COPY_THREADS, LT_COPY_SPIN_US, ...)"""
+  python tools/process_throttle_probe.py 1920x1080 [seconds] [engine]     (environment: LT_COPY_THREADS, LT_COPY_SPIN_US, ...;
+  engine: the frame's rows by the copy engine instead of through the PCIe aperture, lt_set_direct_upload(ctx, 0))"""
 import collections, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,6 +32,8 @@ cal = calib.reference_calibration() if size == "1280x720" else calib.scaled_cali
 frames = bench.stream_windows(base, 256, 1)[0]
 time.sleep(1.0)
 lt = LaneTracker(**cal)
+if len(sys.argv) > 3 and sys.argv[3] == "engine":
+    lt._ctx.set_direct_upload(False)
 for f in frames[:4]:
     lt.process(f)
 def thread_cpu():
@@ -77,7 +80,7 @@ while time.perf_counter() < t_end:
         snap, snap_k = thread_cpu(), k
 s1 = cpu_stat()
 t = np.array(times) * 1e6
-print(json.dumps({"size": size, "frames": k, "fps": round(k / t.sum() * 1e6, 1), "us_median": round(float(np.median(t)), 1),
+print(json.dumps({"size": size, "rows_through_the_aperture": lt._ctx.direct_upload_count() > 0, "frames": k, "fps": round(k / t.sum() * 1e6, 1), "us_median": round(float(np.median(t)), 1),
                   "us_p10": round(float(np.percentile(t, 10)), 1), "us_p90": round(float(np.percentile(t, 90)), 1),
                   "us_p99": round(float(np.percentile(t, 99)), 1), "us_max": round(float(t.max()), 1),
                   "share_of_time_in_frames_over_2x_median": round(float(t[t > 2 * np.median(t)].sum() / t.sum()), 3),

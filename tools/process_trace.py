@@ -13,6 +13,8 @@ else:
     frames = synth.stream_lanes(24, seed=5, cal=cal)
     frames = np.concatenate([frames, frames[::-1]] * 4, 0)
 lt = LaneTracker(**cal)
+if "engine" in sys.argv[3:]:                               # the frame's rows by the copy engine, not through the PCIe aperture
+    lt._ctx.set_direct_upload(False)
 for f in frames[:8]:
     lt.process(f)
 acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
