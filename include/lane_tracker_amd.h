@@ -154,7 +154,7 @@ int  lt_upload_frame_rows(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot
  * waits for work launched over these slots afterwards has returned (lt_download_records of a search, lt_sync).  What
  * LaneTracker.process() uses (:876: one frame per call, the caller's array): the engine's copy runs under the mask chain's launches. */
 int  lt_upload_frame_rows_enqueue(lt_ctx* ctx, const uint8_t* frames_rgb, int first_slot, int n);
-/* A small lt_upload_frame_rows_enqueue (at most 8 MB of rows: the one frame of a process() call) does not go to the copy engine
+/* A small lt_upload_frame_rows_enqueue (at most 1.5 MB of rows: the one 1280x720 frame of a process() call) does not go to the copy engine
  * where the device's memory is mapped into the process (large BAR): the calling thread stores the rows into the slot itself,
  * through the PCIe aperture -- 20 us of bus time for a 1280x720 frame's 914 KB instead of 22-24 us of call + 23 us of engine
  * copy + 6 us until the first kernel behind it.  The call then returns with the copy DONE (frames_rgb is the caller's again) after

@@ -1021,6 +1021,10 @@ static int wait_reader_tails(lt_ctx* c, hipStream_t waiter);
 // them; the kernels behind them start with an acquire that drops what the XCDs' L2s still hold of the slot's previous frame (as
 // between any two kernels), and the memory-side cache sees the bus's writes.  In front: the host waits for the kernels that still
 // read the slot's camera rows (an idle context: two or three stream queries).
+// Up to 1.5 MB per call: the 914 KB of a 1280x720 frame's rows take the calling thread (and two polling copy threads) 25 us against
+// the engine's 8 + 29 us; the 2.0 MB of a 1920x1080 frame's take them 52-60 us against the engine's 9 + 51 us, most of which the
+// engine spends beside the mask chain's launches -- no gain there, and a busy host (tools/process_points.py, NOTES_r06 E.6).
+constexpr size_t APERTURE_MAX_BYTES = (size_t)3 << 19;
 static bool host_has_mapped(const void* p, size_t n) {
     const uintptr_t pg = (uintptr_t)sysconf(_SC_PAGESIZE);
     unsigned char v = 0;
@@ -1127,7 +1131,7 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
     // enqueue (lt_upload_frame_rows_enqueue): the copy on the slots' own streams, ahead of the kernels lt_mask_run puts there, and no
     // wait.  From the caller's pageable frame the call returns once the runtime has the bytes on their way (22-27 us for one
     // 1280x720 frame's rows against 49-54 with the wait: the engine's 18 us run under the mask chain's launches).
-    if (enqueue && !enqueue_syncs && (size_t)n * bytes <= ((size_t)8 << 20) && direct_upload_possible(c) && camera_rows_known_idle(c, first, n)) {
+    if (enqueue && !enqueue_syncs && (size_t)n * bytes <= APERTURE_MAX_BYTES && direct_upload_possible(c) && camera_rows_known_idle(c, first, n)) {
         // a frame or two, and nothing left on the device that reads these slots' rows: by this thread's own stores (above); the
         // caller's array is free again when the call returns
         for (int k = 0; k < n; ++k)
@@ -1149,7 +1153,7 @@ static int upload_frame_rows_impl(lt_ctx* c, const uint8_t* frames, int first, i
                                      bytes, (size_t)m, hipMemcpyHostToDevice, st));
             // (where a later small call could take the aperture, this copy counts as work on the slots' rows that the host has not
             // seen finished: stores from the host must not be overtaken by it)
-            if (c->direct_upload == 1 && (size_t)m * bytes <= ((size_t)8 << 20)) return note_range_frame(c, c->readers, st, f0, f0 + m);
+            if (c->direct_upload == 1 && (size_t)m * bytes <= APERTURE_MAX_BYTES) return note_range_frame(c, c->readers, st, f0, f0 + m);
             return (int)LT_OK;
         });
     HIP_TRY(hipMemcpy2DAsync(c->d_frames + (size_t)first * c->frame_bytes + off, c->frame_bytes, frames + off, c->frame_bytes,
