@@ -160,9 +160,12 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
                     lt.process(frames[32 + k % (window - 32)])
                     k += 1
                 chunks.append(round((k - k0) / (time.perf_counter() - t0), 1))
-            res = {"process_fps": sorted(chunks)[1], "process_fps_stretches": chunks}
-            # ... and with the caller's frames in page-locked memory (lt_host_alloc): measures whether the 22-24 us of the upload call
-            # are a staging copy the caller could spare the runtime (they are not: within 2 % of process_fps).  Not the reference's
+            res = {"process_fps": sorted(chunks)[1], "process_fps_stretches": chunks,
+                   # how the frame's rows reached the device: stored through the PCIe aperture by the calling thread (a large-BAR box,
+                   # at most 1.5 MB per frame: lt_set_direct_upload) or copied by the engine
+                   "process_rows_through_the_aperture": bool(lt._ctx.direct_upload_count() > 0)}
+            # ... and with the caller's frames in page-locked memory (lt_host_alloc): measures whether the upload's cost is a staging
+            # copy the caller could spare the runtime (it is not: within a few % of process_fps).  Not the reference's
             # call pattern (moviepy hands over ordinary arrays): a separate key, never `process_fps`.
             try:
                 pin = _native.pinned_empty((64,) + frames.shape[1:])
