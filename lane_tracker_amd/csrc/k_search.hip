@@ -551,6 +551,10 @@ typedef LT_LDS unsigned lds_u32;
 typedef LT_LDS const unsigned lds_cu32;
 typedef LT_LDS const uint16_t lds_cu16;
 typedef LT_LDS int lds_i32;
+// ... and a GLOBAL pointer its own: the centroid list lives in global memory, and through a generic pointer every store to it was a
+// flat_store -- which counts in lgkmcnt as well as vmcnt, so that each of the recurrence's waits for an LDS read also waited for the
+// last centroid's round trip to L2 (39 of the one-frame kernel's 57 us were phase B; LT_SWS2_PROBE, NOTES_r06 E.8)
+typedef __attribute__((address_space(1))) int32_t glb_i32;
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // first/last argmax of conv[a:b), conv = np.convolve(ones(ww), src[0:ncnt)) ('full').  Only the entries a
@@ -616,60 +620,114 @@ __device__ __forceinline__ bool box_argmax_window(SRC src, int ncnt, int ww, int
 #else
 #define LT_SWS2_RECURRENCE_LINKAGE __noinline__
 #endif
+// Two waves since round 6: a level's two window searches (left, right: box_argmax_window, 0.75 us each -- a chain of LDS round trips
+// and DPP scans on one wave, 39 of the one-frame kernel's 57 us: LT_SWS2_PROBE) do not depend on each other -- only the
+// bookkeeping behind them does (the right side's no-hit branch reads what the left side has just become, :423-425).  Wave 0
+// searches the left side and wave 1 the right side AT THE SAME TIME, each on a prefix scratch of its own; each hands its result
+// {found, first, last} to the other through LDS behind a level tag, and BOTH then run the bookkeeping of both sides, left first,
+// from the same two results: every state variable is identical in the two waves at every level, which is also why a wave always
+// knows whether the other one will search (and publish) at all.  Wave 0 alone stores centroids and windows.
+struct Sws2Result { int found, first, last; };
+__device__ __forceinline__ void sws2_publish(lds_i32* box, int tag, Sws2Result r) {
+    if (lane_id() == 0) {
+        box[0] = r.found; box[1] = r.first; box[2] = r.last;
+        __hip_atomic_store(box + 3, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (workgroup scope: LDS only -- a wider scope would write back and invalidate the vector caches at every level)
+    }
+}
+__device__ __forceinline__ Sws2Result sws2_collect(lds_i32* box, int tag) {
+    // (bounded: half a second of polling -- a result that never came would be a bug in the conditions above, and a wrong record
+    // that the parity tests catch is better than a kernel nobody can stop)
+    for (unsigned spins = 0; uniform(__hip_atomic_load(box + 3, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != tag && spins < (1u << 23); ++spins) __builtin_amdgcn_s_sleep(1);
+    Sws2Result r;
+    r.found = uniform(box[0]); r.first = uniform(box[1]); r.last = uniform(box[2]);
+    return r;
+}
 __device__ LT_SWS2_RECURRENCE_LINKAGE void sws2_recurrence(SearchGeom g, int nlev, lds_cu32* sum0, lds_u32* prefix, lds_cu16* lev,
-                                             lds_i32* roi_ab, lds_i32* state, int32_t* cent) {
+                                             lds_i32* roi_ab, lds_i32* state, glb_i32* cent, int wv, lds_i32* boxes) {
     const int lane = lane_id();
     const int W = g.w, ww = g.ww, wh = g.wh, hw = g.hw, H1 = g.img_height;
+    const bool writer = wv == 0;
     struct Side { int c, ns, lo, hi, ndiff, last_diff, ncent, nroi; };
     Side sd[2] = {{0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0}};
     auto set_roi = [&](int s, Side& me, int level) {
         const int ra = me.c - hw, rb = min(me.c + hw, W);
-        if (lane == 0) {
+        if (writer && lane == 0) {
             roi_ab[(s * nlev + level) * 2] = ra < 0 ? rb : ra;       // negative start: NumPy slice is empty
             roi_ab[(s * nlev + level) * 2 + 1] = rb;
         }
         me.nroi++;
     };
     auto put_centroid = [&](int s, Side& me, int value) {
-        if (lane == 0 && me.ncent < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + me.ncent] = value;
+        if (writer && lane == 0 && me.ncent < g.maxlev + 1) cent[s * (g.maxlev + 2) + 1 + me.ncent] = value;
         me.ncent++;
     };
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {                                    // level 0 (:290-332)
-        Side& me = sd[s];
+    // a side's result of a level: searched by its own wave, fetched by the other.  One box per (side, level), tag 0 = not there yet:
+    // a wave whose partner has stopped searching runs ahead of it by any number of levels, and must not overwrite what the partner
+    // has yet to read
+    auto box_of = [&](int side, int level) { return boxes + (side * nlev + level) * 4; };
+    {                                                                // level 0 (:290-332)
+        const int s = wv;
         const int c0 = s == 0 ? g.ignore_sides : g.img_center;
         const int c1 = s == 0 ? g.img_center : W - g.ignore_sides;
-        bool found = false;
-        int first = 0, last = 0;
-        if (c1 > c0 && H1 > g.y_start)
-            found = box_argmax_window(sum0 + c0, c1 - c0, ww, 0, (c1 - c0) + ww - 1, prefix, first, last);
-        if (found) {
-            me.c = uniform(((first + last) >> 1) - hw + c0);         // :296-297 / :316-317
-            if (H1 - wh >= 0) set_roi(s, me, 0);
-            else me.nroi++;
-        } else {
-            me.c = s == 0 ? g.def_left : g.def_right;                // :308 / :328
+        Sws2Result mine = {0, 0, 0};
+        if (c1 > c0 && H1 > g.y_start) {
+            int first = 0, last = 0;
+            mine.found = box_argmax_window(sum0 + c0, c1 - c0, ww, 0, (c1 - c0) + ww - 1, prefix, first, last) ? 1 : 0;
+            mine.first = first; mine.last = last;
         }
-        put_centroid(s, me, me.c);
-        me.lo = -g.search_range;
-        me.hi = g.search_range;
+        sws2_publish(box_of(wv, 0), 1, mine);
+        const Sws2Result theirs = sws2_collect(box_of(1 - wv, 0), 1);
+        const Sws2Result res0 = wv == 0 ? mine : theirs, res1 = wv == 0 ? theirs : mine;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            Side& me = sd[t];
+            const Sws2Result r = t == 0 ? res0 : res1;
+            const int d0 = t == 0 ? g.ignore_sides : g.img_center;
+            if (r.found) {
+                me.c = uniform(((r.first + r.last) >> 1) - hw + d0);    // :296-297 / :316-317
+                if (H1 - wh >= 0) set_roi(t, me, 0);
+                else me.nroi++;
+            } else {
+                me.c = t == 0 ? g.def_left : g.def_right;             // :308 / :328
+            }
+            put_centroid(t, me, me.c);
+            me.lo = -g.search_range;
+            me.hi = g.search_range;
+        }
     }
     const int conv_len = W + ww - 1;                                 // :351
     for (int level = 1; level < g.nlevels; ++level) {                // :346-430
         lds_cu16* sums = lev + (size_t)(level - 1) * W;
+        const int tag = level + 1;
+        // this wave's own side first: its window search needs nothing of the other side's at this level
+        // (no array is indexed by the wave number: a private array with a run-time index lives in scratch memory, a global round
+        // trip per access -- the first version of this function was SLOWER than one wave for that, 52 against 39 us)
+        Sws2Result mine = {0, 0, 0};
+        const bool searched0 = sd[0].ns < g.limit, searched1 = sd[1].ns < g.limit;
+        const int lo_i0 = max(sd[0].c + sd[0].lo + hw, 0), lo_i1 = max(sd[1].c + sd[1].lo + hw, 0);      // :356
+        const bool my_search = wv == 0 ? searched0 : searched1, their_search = wv == 0 ? searched1 : searched0;
+        if (my_search) {
+            const int my_c = wv == 0 ? sd[0].c : sd[1].c, my_hi = wv == 0 ? sd[0].hi : sd[1].hi;
+            const int lo_i = wv == 0 ? lo_i0 : lo_i1;
+            const int hi_i = min(my_c + my_hi + hw, W);              // :357
+            const int a = min(lo_i, conv_len);                       // conv[lo_i:hi_i], Python slice rules
+            const int b = hi_i < 0 ? max(conv_len + hi_i, 0) : min(hi_i, conv_len);
+            int first = 0, last = 0;
+            mine.found = (b > a && box_argmax_window(sums, W, ww, a, b, prefix, first, last)) ? 1 : 0;   // :360
+            mine.first = first; mine.last = last;
+            sws2_publish(box_of(wv, level), tag, mine);
+        }
+        Sws2Result theirs = {0, 0, 0};
+        if (their_search) theirs = sws2_collect(box_of(1 - wv, level), tag);
+        const Sws2Result res0 = wv == 0 ? mine : theirs, res1 = wv == 0 ? theirs : mine;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {                                // left first, then right (:354, :395)
             Side& me = sd[s];
             const Side& other = sd[1 - s];
-            if (me.ns >= g.limit) continue;
-            const int lo_i = max(me.c + me.lo + hw, 0);              // :356
-            const int hi_i = min(me.c + me.hi + hw, W);              // :357
-            const int a = min(lo_i, conv_len);                       // conv[lo_i:hi_i], Python slice rules
-            const int b = hi_i < 0 ? max(conv_len + hi_i, 0) : min(hi_i, conv_len);
-            int first = 0, last = 0;
-            const bool found = b > a && box_argmax_window(sums, W, ww, a, b, prefix, first, last);   // :360
-            if (found) {
-                const int newc = uniform(((first + last + 1) >> 1) + lo_i - hw);   // ceil, :363-364
+            if (!(s == 0 ? searched0 : searched1)) continue;
+            const Sws2Result r = s == 0 ? res0 : res1;
+            if (r.found) {
+                const int newc = uniform(((r.first + r.last + 1) >> 1) + (s == 0 ? lo_i0 : lo_i1) - hw);   // ceil, :363-364
                 put_centroid(s, me, newc);
                 me.last_diff = newc - me.c;                          // :366
                 me.ndiff++;
@@ -687,7 +745,7 @@ __device__ LT_SWS2_RECURRENCE_LINKAGE void sws2_recurrence(SearchGeom g, int nle
             }
         }
     }
-    if (lane == 0) {
+    if (writer && lane == 0) {
         cent[0] = sd[0].ncent;
         cent[g.maxlev + 2] = sd[1].ncent;
         state[0] = sd[0].nroi;
@@ -696,7 +754,7 @@ __device__ LT_SWS2_RECURRENCE_LINKAGE void sws2_recurrence(SearchGeom g, int nle
 }
 
 struct Sws2Layout {       // byte offsets into dynamic LDS
-    int sum0, prefix, lev, roi, rowbits, state, mom, total;
+    int sum0, prefix, boxes, lev, roi, rowbits, state, mom, total;
     int nlev;
 };
 __host__ __device__ inline Sws2Layout sws2_layout(const SearchGeom& g) {
@@ -705,7 +763,8 @@ __host__ __device__ inline Sws2Layout sws2_layout(const SearchGeom& g) {
     int o = 0;
     auto take = [&o](int bytes) { const int at = o; o = (o + bytes + 15) & ~15; return at; };   // 16-byte aligned sections
     L.sum0 = take(g.w * 4);
-    L.prefix = take((g.w + g.ww + 64) * 4);           // window sums of one level: up to w + ww - 1 entries
+    L.prefix = take(2 * (g.w + g.ww + 64) * 4);       // window sums of one level: up to w + ww - 1 entries, one scratch per searching wave
+    L.boxes = take(2 * L.nlev * 4 * 4);              // the two waves' results of every level: {found, first, last, tag} (sws2_recurrence)
     L.lev = take((L.nlev - 1) * g.w * 2);
     L.roi = take(L.nlev * 2 * 2 * 4);                // (a, b) per (side, level)
     L.rowbits = take(2 * L.nlev * g.wh * 8);         // one 64-bit column mask per window row
@@ -769,14 +828,16 @@ __global__ __launch_bounds__(NT) void k_sws_fit2(const uint8_t* __restrict__ mas
         for (int i = threadIdx.x; i < nlev * 4; i += NT) roi_ab[i] = 0;  // a = b = 0: no window
         for (int i = threadIdx.x; i < 2 * nlev * wh; i += NT) reinterpret_cast<unsigned long long*>(smem + L.rowbits)[i] = 0ull;
         if (threadIdx.x < 8) state[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < 2 * nlev * 4; i += NT) reinterpret_cast<int*>(smem + L.boxes)[i] = 0;   // (tag 0: nothing published)
         if (threadIdx.x < 16) s_mom[threadIdx.x] = 0;
     }
     __syncthreads();
 
     SWS2_T(1)
-    // ---- B: the recurrence over the levels, wave 0, LDS only (lane_tracker.py:290-430) -----------
-    if (wv == 0)
-        sws2_recurrence(g, nlev, (lds_cu32*)sum0, (lds_u32*)prefix, (lds_cu16*)lev, (lds_i32*)roi_ab, (lds_i32*)state, cent);
+    // ---- B: the recurrence over the levels, waves 0 (left side) and 1 (right side), LDS only (lane_tracker.py:290-430) -----------
+    if (wv < 2)
+        sws2_recurrence(g, nlev, (lds_cu32*)sum0, (lds_u32*)(prefix + (size_t)wv * (g.w + g.ww + 64)), (lds_cu16*)lev, (lds_i32*)roi_ab,
+                        (lds_i32*)state, (glb_i32*)cent, wv, (lds_i32*)(smem + L.boxes));
     __syncthreads();
 
     SWS2_T(2)

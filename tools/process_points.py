@@ -58,7 +58,13 @@ while now() < t_end:
     lt.process(frames[8 + k % 248])
     total.append((now() - t0) * 1e6)
     k += 1
-out = {"size": size, "flags": flags, "frames": k, "rows_through_the_aperture": lt._ctx.direct_upload_count() > 0,
+parity = {}
+if "parity" in flags:                          # the same timeline for even and odd frames apart (the two slots / the two output blocks)
+    for par in (0, 1):
+        parity[str(par)] = {"us_median": round(float(np.median(total[par::2])), 1),
+                            "timeline_us": {kk: round(float(np.median(v[par::2])), 1) for kk, v in sorted(marks.items(), key=lambda kv: np.median(kv[1]))
+                                            if len(v) == len(total)}}
+out = {"size": size, "flags": flags, "frames": k, "by_frame_parity": parity or None, "rows_through_the_aperture": lt._ctx.direct_upload_count() > 0,
        "us_median": round(float(np.median(total)), 1), "us_p10": round(float(np.percentile(total, 10)), 1),
        "timeline_us": {kk: round(float(np.median(v)), 1) for kk, v in sorted(marks.items(), key=lambda kv: np.median(kv[1]))}}
 print(json.dumps(out))

@@ -22,10 +22,29 @@ gcs = []
 gc.callbacks.append(lambda phase, info: gcs.append((phase, info["generation"], time.perf_counter())))
 t = np.empty(n)
 now = time.perf_counter
+cur = {}
+def wrap(obj, name):
+    fn = getattr(obj, name)
+    def w(*a, **k):
+        t0 = now(); r = fn(*a, **k); cur[name] = cur.get(name, 0.0) + (now() - t0); return r
+    setattr(obj, name, w)
+for name in ("upload_frame_rows", "mask_run", "band_fit_run", "sws_fit_run", "download_record", "present_finish", "present_lane_from_fit_async"):
+    wrap(lt._ctx, name)
+for name in ("_prepare_out", "_text_early", "_tail_fast", "_present"):
+    wrap(lt, name)
+from lane_tracker_amd import _native as _nat
+_pe = _nat.pinned_empty
+def _pe_t(*a, **k):
+    t0 = now(); r = _pe(*a, **k); cur["pinned_empty"] = cur.get("pinned_empty", 0.0) + (now() - t0); return r
+_nat.pinned_empty = _pe_t
+stalls = []
 for k in range(n):
+    cur.clear()
     t0 = now()
     lt.process(frames[32 + k % 224])
     t[k] = now() - t0
+    if t[k] > 1e-3 and len(stalls) < 12:
+        stalls.append({"frame": k, "ms": round(t[k] * 1e3, 2), "ms_by_call": {kk: round(v * 1e3, 2) for kk, v in cur.items() if v > 2e-4}})
 t *= 1e6
 med = float(np.median(t))
 slow = np.where(t > 1.25 * med)[0]
@@ -35,6 +54,7 @@ out = {"size": size, "frames": n, "flags": sys.argv[3:], "us_mean": round(float(
        "percentiles_us": {str(p): round(float(np.percentile(t, p)), 1) for p in (1, 10, 25, 50, 75, 90, 95, 99, 99.9)},
        "frames_over_1.25x_median": int(len(slow)), "their_share_of_time": round(float(t[slow].sum() / t.sum()), 4),
        "excess_us_per_frame_from_them": round(float((t[slow] - med).sum() / n), 2),
+       "frames_over_1ms": stalls, "frames_over_1ms_count": int((t > 1000).sum()), "their_indices": [int(i) for i in np.where(t > 1000)[0][:40]],
        "gc_runs_by_generation": {g: sum(1 for x in starts if x[1] == g) for g in (0, 1, 2)},
        "mean_us_by_frame_mod_2": [round(float(t[i::2].mean()), 1) for i in range(2)],
        "mean_us_by_frame_mod_224_first_8": [round(float(t[np.arange(n) % 224 == i].mean()), 1) for i in range(8)],
