@@ -568,6 +568,15 @@ __device__ __forceinline__ bool box_argmax_window(SRC src, int ncnt, int ww, int
     if (ph <= pl) return false;                      // every window sum is empty -> np.any false
     const int lane = lane_id(), n = ph - pl;
     unsigned run = 0;
+    if (n <= 128) {                                  // the levels above the start slice (n = reach + window width ~ 70): ONE pass, two
+        const int i0 = 2 * lane, i1 = i0 + 1;        // entries per lane -- a second pass of LDS read -> scan -> LDS write is 0.15 us of latency
+        const unsigned v0 = i0 < n ? (unsigned)src[pl + i0] : 0u, v1 = i1 < n ? (unsigned)src[pl + i1] : 0u;
+        const unsigned t = v0 + v1;
+        const unsigned incl = wave_inclusive_sum_dpp(t);
+        if (i0 < n) q[i0] = incl - t;
+        if (i1 < n) q[i1] = incl - v1;
+        run = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    } else
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
         const unsigned v = i < n ? (unsigned)src[pl + i] : 0u;

@@ -4,7 +4,7 @@
   cd lane_tracker_amd/csrc && make && hipcc <the Makefile's flags> -DLT_SWS2_PROBE --offload-arch=gfx950 -c k_search.hip -o /tmp/k_search.o \
     && hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=exports.map -o ../liblane_tracker_amd_sws2probe.so <the other .o files> /tmp/k_search.o
   LANE_TRACKER_AMD_LIB=lane_tracker_amd/liblane_tracker_amd_sws2probe.so python tools/sws2_probe.py
-Round 6: A 4.8 us, B 39 -> 31 us (two waves, one per side), C 7.5 us, fit 4.5 us."""
+Round 6: A 4.8 us, B 39 -> 28 us (two waves, one per side; one-pass scan), C 7.5 us, fit 4.5 us."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lane_tracker_amd import _native, calib, synth
