@@ -759,8 +759,9 @@ class LaneTracker(StreamPipeline):
             # the whole frame is wanted after all (draw_lane() by hand on the frame process() has just seen): bring the rest
             self._upload_keepalive = self._ctx.upload_frame_rest(self._resident[0], first=slot)
             self._resident_partial = False
-        text = b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) \
-            if self._have_font and lines else None
+        def packed():        # the lines as the library takes them (only where somebody still has to draw them)
+            return b"".join(t.encode("ascii", "replace")[:line_len].ljust(line_len, b"\0") for t in lines) \
+                if self._have_font and lines else None
         if host_text and rows is not None:
             # the device's part is the lane's run of rows (drawn and on its way already, or now); the text goes over the rows
             # the copy thread has brought from the caller's frame, on this thread, while the lane's rows land
@@ -770,9 +771,12 @@ class LaneTracker(StreamPipeline):
             finally:
                 early, self._text_in_flight = self._text_in_flight, None
                 self._copies_done()      # (with the text of _text_early among them)
-            if text is not None and not (early is not None and early[0] is out and early[1] == lines):
-                _native.text_blend(out, _overlay.font_atlas(), text, len(lines), line_len, self._TEXT_ORIGIN, self._TEXT_STEP)
+            if not (early is not None and early[0] is out and early[1] == lines):
+                text = packed()
+                if text is not None:
+                    _native.text_blend(out, _overlay.font_atlas(), text, len(lines), line_len, self._TEXT_ORIGIN, self._TEXT_STEP)
             return self._ctx.present_finish(slot, None, 0, line_len, out, rows, origin=self._TEXT_ORIGIN, step=self._TEXT_STEP)[0]
+        text = packed()
         try:
             if drawn and out is not None and rows is not None:
                 return self._ctx.present_finish(slot, text, len(lines), line_len, out, rows, origin=self._TEXT_ORIGIN,
