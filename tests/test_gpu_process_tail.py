@@ -50,3 +50,38 @@ def test_one_call_tail_leaves_what_the_python_functions_leave(scale, demo, n_ave
     finally:
         fast.close()
         slow.close()
+
+
+def test_two_trackers_on_two_threads_share_the_copy_threads_without_mixing_anything():
+    """Two trackers, one per thread, process() at the same time: the aperture stores and the text lines of both offer pieces to the
+    same polling copy threads (work stealing, group 0), each context keeps its own account of its slots' readers.  Frames and final
+    states equal those of each tracker run alone."""
+    import threading
+    from lane_tracker_amd import calib
+    from lane_tracker_amd.lane_tracker import LaneTracker
+    cal = calib.reference_calibration()
+    streams = [_stream_with_failures(120, 11, seed=5), _stream_with_failures(120, 13, seed=6)]
+
+    def run(frames, out):
+        lt = LaneTracker(**cal)
+        try:
+            out.append([lt.process(f).copy() for f in frames])
+            out.append(_full(lt))
+        finally:
+            lt.close()
+    alone = []
+    for s in streams:
+        o = []
+        run(s, o)
+        alone.append(o)
+    together = [[], []]
+    threads = [threading.Thread(target=run, args=(streams[i], together[i])) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        assert len(together[i]) == 2, "a thread died"
+        assert together[i][1] == alone[i][1], i
+        for k, (a, b) in enumerate(zip(together[i][0], alone[i][0])):
+            assert np.array_equal(a, b), (i, k)
