@@ -1084,7 +1084,10 @@ static void store_through_aperture(uint8_t* dst, const uint8_t* src, size_t n) {
     sp->run(0);
     for (int k = 1; k < pieces; ++k)
         if (!sp->claimed[k].exchange(1, std::memory_order_acq_rel)) sp->run(k);
-    while (sp->done.load(std::memory_order_acquire) < pieces) __builtin_ia32_pause();
+    // (a helper that has claimed a piece finishes it in microseconds -- unless the scheduler has taken its core: then give ours up too)
+    for (unsigned spins = 0; sp->done.load(std::memory_order_acquire) < pieces; ++spins) {
+        if ((spins & 0xffffu) == 0xffffu) std::this_thread::yield(); else __builtin_ia32_pause();
+    }
 }
 // Does the host KNOW that no kernel reads the camera rows of slots [first, first + n) any more?  Asked without a call that could
 // cost the frame anything: hipStreamQuery on a stream whose last kernel carries no signal makes the runtime enqueue a marker and

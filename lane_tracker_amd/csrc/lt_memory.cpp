@@ -877,7 +877,9 @@ int lt_host_text_now_group(int group, uint8_t* frame, int img_h, int img_w, cons
     sp->run(0);
     for (int l = 1; l < n_lines; ++l)
         if (!sp->claimed[l].exchange(1, std::memory_order_acq_rel)) sp->run(l);
-    while (sp->done.load(std::memory_order_acquire) < n_lines) __builtin_ia32_pause();
+    for (unsigned spins = 0; sp->done.load(std::memory_order_acquire) < n_lines; ++spins) {     // (a claimed line is microseconds of work)
+        if ((spins & 0xffffu) == 0xffffu) std::this_thread::yield(); else __builtin_ia32_pause();
+    }
     return LT_OK;
 }
 
