@@ -153,14 +153,22 @@ def stream_leg(streams, window=256, seconds=1.0, nwin=8):
         try:
             for f in frames[:32]:        # (page-locked output blocks, copy threads, the plot rows on the device: first uses)
                 lt.process(f)
-            chunks, k = [], 0
+            chunks, k, per_frame = [], 0, []
             for _ in range(3):           # three stretches, the median: a stretch of 0.15 s is 600 frames, and one stall of the host shows
                 t0, k0 = time.perf_counter(), k
-                while time.perf_counter() - t0 < seconds * 0.15:
+                t_prev = t0
+                while t_prev - t0 < seconds * 0.15:
                     lt.process(frames[32 + k % (window - 32)])
                     k += 1
-                chunks.append(round((k - k0) / (time.perf_counter() - t0), 1))
+                    t_now = time.perf_counter()
+                    per_frame.append(t_now - t_prev)
+                    t_prev = t_now
+                chunks.append(round((k - k0) / (t_prev - t0), 1))
+            per_frame.sort()
+            pct = lambda q: round(per_frame[min(int(q * len(per_frame)), len(per_frame) - 1)] * 1e6, 1)
             res = {"process_fps": sorted(chunks)[1], "process_fps_stretches": chunks,
+                   # (process_fps is frames per wall time, i.e. the MEAN frame; the frame itself:)
+                   "process_frame_us": {"median": pct(0.5), "p10": pct(0.1), "p90": pct(0.9), "p99": pct(0.99), "frames": len(per_frame)},
                    # how the frame's rows reached the device: stored through the PCIe aperture by the calling thread (a large-BAR box,
                    # at most 1.5 MB per frame: lt_set_direct_upload) or copied by the engine
                    "process_rows_through_the_aperture": bool(lt._ctx.direct_upload_count() > 0)}

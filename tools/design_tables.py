@@ -99,6 +99,9 @@ def tables(lines):
     prow.append("| … slowest / fastest stretch | %s / %s | %s / %s |" % (
         span(lines, lambda d: min(d["stream"]["1280x720"]["process_fps_stretches"])), span(lines, lambda d: max(d["stream"]["1280x720"]["process_fps_stretches"])),
         span(lines, lambda d: min(d["stream"]["1920x1080"]["process_fps_stretches"])), span(lines, lambda d: max(d["stream"]["1920x1080"]["process_fps_stretches"]))))
+    usf = lambda v: "%.0f µs" % v
+    prow.append("| … the frame itself (process_fps is frames per wall time, the MEAN frame): median / p90 / p99 | %s / %s / %s | %s / %s / %s |" % tuple(
+        span(lines, lambda d, z=z, q=q: d["stream"][z]["process_frame_us"][q], usf) for z in ("1280x720", "1920x1080") for q in ("median", "p90", "p99")))
     us = lambda v: "%.0f µs" % (v * 1e3)
     prow.append("| BASELINE config 1: `tests/golden/photo_test4.png` through `process()` with its defaults (two tries, both rejected, as in the reference's own run): median of 200 calls | %s (%s frames/s) | — |" % (
         span(lines, lambda d: d["config1"]["process_defaults"]["median_ms"], us), span(lines, lambda d: d["config1"]["process_defaults"]["frames_per_s"])))
