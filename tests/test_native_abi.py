@@ -151,6 +151,24 @@ int main(void) {
     if (lt_lane_polygon_spans(4, left, 2, right, 2, spans) != 0) return 5;
     if (spans[0] != 3 || spans[1] != 6 || spans[2] != 3 || spans[3] != 7) return 6;
     if (spans[4] <= spans[5]) return 7;                            /* untouched rows are empty intervals */
+    {   /* lt_frame_tail (host only): a straight, centred lane 180 px wide is valid; its average with nothing is itself */
+        double in[24], out[8], avg6[6], ploty[8], ploty2[8];
+        int32_t ln = 0, rn = 0, lyx[16], ryx[16];
+        int i;
+        memset(in, 0, sizeof in);
+        in[2] = 450.0; in[5] = 630.0;                              /* left x = 450, right x = 630 */
+        in[12] = 1.0;                                              /* the average divides by one fit: this one */
+        in[13] = 150; in[14] = 230; in[15] = 110; in[16] = 230; in[17] = 80; in[18] = 200; in[19] = 0.25;
+        in[20] = 30.0 / 720.0; in[21] = 3.7 / 700.0;
+        for (i = 0; i < 8; ++i) { ploty[i] = 1092.0 + i; ploty2[i] = ploty[i] * ploty[i]; }
+        if (lt_frame_tail(1080, 1100, in, ploty, ploty2, 8, ploty, ploty2, 8, avg6, &ln, &rn, lyx, ryx, out) != 0) return 8;
+        if (out[0] != 1.0 || ln != 8 || rn != 8 || avg6[2] != 450.0 || avg6[5] != 630.0 || lyx[1] != 450 || ryx[15] != 630) return 9;
+        if (out[1] != 1.0) return 10;                              /* a dead-straight lane has no radius: "not reproduced here" */
+        in[0] = 1e-4; in[3] = 1e-4;                                /* a curve: radii and eccentricity come back */
+        in[2] = 450.0 - 1e-4 * 1099.0 * 1099.0; in[5] = 630.0 - 1e-4 * 1099.0 * 1099.0;
+        if (lt_frame_tail(1080, 1100, in, ploty, ploty2, 8, ploty, ploty2, 8, avg6, &ln, &rn, lyx, ryx, out) != 0) return 11;
+        if (out[0] != 1.0 || out[1] != 0.0 || !(out[2] > 0.0) || out[2] != out[3]) return 12;
+    }
     printf("abi ok\\n");
     return 0;
 }
