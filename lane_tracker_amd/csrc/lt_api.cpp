@@ -1013,14 +1013,14 @@ static int wait_reader_tails(lt_ctx* c, hipStream_t waiter);
 // ---- one frame's rows through the PCIe aperture ----------------------------------------------------------------------------------
 // With a large BAR the whole device memory is mapped into the process, write-combining, at the addresses hipMalloc hands out: the
 // calling thread can store a frame's rows into the slot itself.  For the ONE frame of a LaneTracker.process() call that beats the
-// copy engine: hipMemcpy2DAsync costs the call 20-24 us before the engine even starts (23 us of copy + 6 us until the first
-// kernel behind it), the stores take the bus's 20 us for the 914 KB of a 1280x720 frame's rows and the undistortion can be
-// launched the moment they are out (tools/microbench/upload_latency.hip: rows + a dependent kernel 52 -> 43 us with nothing else
-// going on; NOTES_r06 E.6 for the frame).  The bytes are the same bytes; only their way differs.
-// Ordering: the stores end with an sfence and are posted writes of this thread, like the doorbell of the launch that follows
-// them; the kernels behind them start with an acquire that drops what the XCDs' L2s still hold of the slot's previous frame (as
-// between any two kernels), and the memory-side cache sees the bus's writes.  In front: the host waits for the kernels that still
-// read the slot's camera rows (an idle context: two or three stream queries).
+// copy engine: hipMemcpy2DAsync costs the call 8-24 us (by box) before the engine even starts (23 us of copy + 6 us until the
+// first kernel behind it), the stores take the bus's 20 us for the 914 KB of a 1280x720 frame's rows and the undistortion can be
+// launched the moment they are out (tools/microbench/upload_latency.hip: rows out of cold memory + a dependent kernel 66 -> 43 us;
+// NOTES_r06 E.6 for the frame).  The bytes are the same bytes; only their way differs.
+// Ordering: the stores end with an sfence and are posted writes of the thread that then rings the launch's doorbell (or of
+// threads it has waited for); the kernels behind them start with an acquire that drops what the XCDs' L2s still hold of the
+// slot's previous frame (as between any two kernels), and the memory-side cache sees the bus's writes.  In front: nothing is
+// waited for -- the aperture is taken only when the library already KNOWS the slot's readers are done (camera_rows_known_idle).
 // Up to 1.5 MB per call: the 914 KB of a 1280x720 frame's rows take the calling thread (and two polling copy threads) 25 us against
 // the engine's 8 + 29 us; the 2.0 MB of a 1920x1080 frame's take them 52-60 us against the engine's 9 + 51 us, most of which the
 // engine spends beside the mask chain's launches -- no gain there, and a busy host (tools/process_points.py, NOTES_r06 E.6).
