@@ -111,8 +111,6 @@ class LaneTracker(StreamPipeline):
         _live_trackers += 1
         self._closed = False
         _hostcpu.find_blas_pools()       # (the one-time search for NumPy's BLAS library -- 0.1 s -- at set-up, not inside a frame's refit)
-        if self.search_cus:
-            self._ctx.set_search_cus(self.search_cus)   # CUs of their own for the stream pipeline's long-running kernels (lt_set_search_cus)
         self._slot = 0              # process() alternates between two slots (see process())
         self._aux_ctx = {}          # contexts for images that are not the calibration's BEV size
         self._fit = None            # (left_y array, right_y array, left coeffs, right coeffs) of the last search

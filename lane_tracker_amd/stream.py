@@ -516,8 +516,22 @@ class StreamPipeline:
             yield
 
 
+    _search_cus_set = False
+
+    def _reserve_search_cus(self):
+        """CUs of their own for the stream pipeline's long-running kernels (lt_set_search_cus), at the first call that uses that
+        pipeline -- not in the constructor: a tracker that only ever serves process() has no chained search to protect, runs its
+        kernels on every CU, and creates no CU-masked streams (which, never destroyed, make a process die in the runtime's exit
+        handlers under rocprofv3: NOTES_r06 E.7).  The call synchronises the (idle) context and replaces its streams."""
+        if not self._search_cus_set:
+            self._search_cus_set = True
+            if self.search_cus:
+                self._ctx.set_search_cus(self.search_cus)
+
     def _batch_arguments(self, kwargs):
-        """process()'s keywords with its defaults -> (keyword dict, first-try parameter tuple, filter parameters)."""
+        """process()'s keywords with its defaults -> (keyword dict, first-try parameter tuple, filter parameters).  (Every entry of
+        the stream pipeline -- warm, process_batch, process_stream -- comes through here first.)"""
+        self._reserve_search_cus()
         import inspect
         sig = inspect.signature(type(self).process)
         k = {name: v.default for name, v in sig.parameters.items() if name not in ("self", "img")}
